@@ -1,0 +1,61 @@
+// C-ABI core: error reporting, library info, kernel-level GEMM entry point.
+#include "common.h"
+#include "gemm.h"
+#include "../../include/prx.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void prx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* prx_last_error(void) { return g_err; }
+
+int prx_abi_version(void) { return PRX_ABI_VERSION; }
+
+int prx_device_info(int* cu_count, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    PRX_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    PRX_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PRX_REQUIRE(g != nullptr, "prx_k_gemm: null args");
+    GemmDesc d;
+    d.A = g->A; d.a_is_f32 = g->a_is_f32; d.a_mode = g->a_mode; d.lda = g->lda;
+    d.B = (const bf16_t*)g->B; d.ldb = g->ldb;
+    d.M = g->M; d.N = g->N; d.K = g->K;
+    d.H = g->H; d.W = g->W; d.Cin = g->Cin; d.up = g->up;
+    d.alpha = g->alpha;
+    d.bias_n = g->bias_n; d.bias_m = g->bias_m;
+    d.aux = (const bf16_t*)g->aux; d.ldaux = g->ldaux;
+    d.resid = g->resid; d.ldr = g->ldr;
+    d.act = g->act;
+    d.out_f32 = g->out_f32; d.ldc_f32 = g->ldc_f32;
+    d.out_bf16 = (bf16_t*)g->out_bf16; d.out_bf16_pre = (bf16_t*)g->out_bf16_pre;
+    d.ldc_bf16 = g->ldc_bf16;
+    return prx_gemm_launch(d, (float*)ws, ws_bytes, stream);
+}
+
+void prx_profile_gemm_enable(int on) { prx_gemm_profile_enable(on); }
+int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches) {
+    return prx_gemm_profile_collect(total_ms, total_flop, launches);
+}
+
+}  // extern "C"

@@ -1,0 +1,5 @@
+#pragma once
+#include "common.h"
+// qkv: bf16 [N*T, 3C] (q | k | v, head h at columns h*64..), out/dout: bf16 [N*T, C]
+int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s);
+int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int T, int C, int heads, hipStream_t s);

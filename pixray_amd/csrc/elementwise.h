@@ -1,0 +1,17 @@
+#pragma once
+#include "common.h"
+int prx_transpose_bf16(const bf16_t* in, int ldin, bf16_t* out, int ldout, int R, int C, hipStream_t s);
+int prx_softmax_rows(const float* S, int lds_, float scale, bf16_t* P, int ldp, bf16_t* PT, int ldpt, int rows,
+                     int cols, hipStream_t s);
+int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, float scale, bf16_t* dS, int ldds,
+                         bf16_t* dST, int lddst, int rows, int cols, hipStream_t s);
+int prx_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, hipStream_t s);
+int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s);
+int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);
+int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s);
+int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
+                       int HW, hipStream_t s);
+int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
+                   size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t s);
+int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);

@@ -1,0 +1,275 @@
+// Small HBM-bound helpers of the decoder / optimiser path: layout changes,
+// row softmax (decoder AttnBlock), nearest-2x upsample backward, the
+// (x+1)/2 + ClampWithGrad image head (vqgan.py:66-79,195), Adam + clip_z
+// (pixray.py:539,1484-1487; vqgan.py:202-204).
+#include "elementwise.h"
+#include <algorithm>
+
+namespace {
+
+inline int ew_grid(size_t total, int per = 256) { return (int)std::min<size_t>((total + per - 1) / per, 8192); }
+
+// out[c][r] = in[r][c]   (bf16), tiled through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int ldin,
+                                                             bf16_t* __restrict__ out, int ldout, int R, int C) {
+    __shared__ bf16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : (bf16_t)0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ldout + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// P = softmax(scale * S) per row; one wave per row; writes bf16 P (and optionally P^T)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds_, float scale,
+                                                           bf16_t* __restrict__ P, int ldp, bf16_t* __restrict__ PT,
+                                                           int ldpt, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + (size_t)row * lds_;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, s[c] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(s[c] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int c = lane; c < cols; c += 64) {
+        bf16_t p = (bf16_t)(__expf(s[c] * scale - mx) * inv);
+        P[(size_t)row * ldp + c] = p;
+        if (PT) PT[(size_t)c * ldpt + row] = p;
+    }
+}
+
+// dS = scale * P o (dP - rowsum(dP o P));  writes bf16 dS and dS^T
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ P, int ldp,
+                                                               const float* __restrict__ dP, int lddp, float scale,
+                                                               bf16_t* __restrict__ dS, int ldds,
+                                                               bf16_t* __restrict__ dST, int lddst, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64)
+        dot += bf16_to_f32(P[(size_t)row * ldp + c]) * dP[(size_t)row * lddp + c];
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) {
+        float p = bf16_to_f32(P[(size_t)row * ldp + c]);
+        bf16_t v = (bf16_t)(scale * p * (dP[(size_t)row * lddp + c] - dot));
+        dS[(size_t)row * ldds + c] = v;
+        if (dST) dST[(size_t)c * lddst + row] = v;
+    }
+}
+
+// low[b][y][x][c] = sum over the 2x2 children of hi (NHWC fp32) -- backward of nearest-2x upsample
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ hi, float* __restrict__ low,
+                                                             int NB, int Hl, int Wl, int C) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)NB * Hl * Wl * C4;
+    const int Wh = Wl * 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        int cq = (int)(idx % C4);
+        size_t pix = idx / C4;
+        int x = (int)(pix % Wl);
+        size_t t = pix / Wl;
+        int y = (int)(t % Hl);
+        int b = (int)(t / Hl);
+        const float4* h4 = reinterpret_cast<const float4*>(hi);
+        size_t p00 = (((size_t)b * Hl * 2 + 2 * y) * Wh + 2 * x) * C4 + cq;
+        float4 a = h4[p00], bb = h4[p00 + C4], c = h4[p00 + (size_t)Wh * C4], d = h4[p00 + (size_t)Wh * C4 + C4];
+        reinterpret_cast<float4*>(low)[idx] =
+            make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z),
+                        (a.w + bb.w) + (c.w + d.w));
+    }
+}
+
+// NCHW fp32 -> NHWC (fp32 and/or bf16), channels padded with zeros up to Cpad
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
+                                                           bf16_t* __restrict__ out_bf16, int NB, int C, int HW,
+                                                           int Cpad) {
+    const size_t total = (size_t)NB * HW * Cpad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % Cpad);
+        size_t t = idx / Cpad;
+        int p = (int)(t % HW);
+        int b = (int)(t / HW);
+        float v = c < C ? in[((size_t)b * C + c) * HW + p] : 0.f;
+        if (out_f32) out_f32[idx] = v;
+        if (out_bf16) out_bf16[idx] = (bf16_t)v;
+    }
+}
+
+// NHWC fp32 (channel stride ldc) -> NCHW fp32
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int ldc,
+                                                           float* __restrict__ out, int NB, int C, int HW) {
+    const size_t total = (size_t)NB * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        size_t t = idx / HW;
+        int c = (int)(t % C);
+        int b = (int)(t / C);
+        out[idx] = in[((size_t)b * HW + p) * ldc + c];
+    }
+}
+
+// image head: img = clamp((x+1)/2, 0, 1)  (x is NHWC with channel stride ldc, img is NCHW)
+__global__ __launch_bounds__(256) void image_head_fwd_kernel(const float* __restrict__ x, int ldc,
+                                                             float* __restrict__ img, int NB, int C, int HW) {
+    const size_t total = (size_t)NB * C * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        size_t t = idx / HW;
+        int c = (int)(t % C);
+        int b = (int)(t / C);
+        float v = (x[((size_t)b * HW + p) * ldc + c] + 1.f) * 0.5f;
+        img[idx] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
+// ClampWithGrad backward (vqgan.py:76-79): g passes where g*(u - clamp(u)) >= 0, u=(x+1)/2, then *0.5.
+// Output dx in NHWC (fp32, channel stride ldo, zero-padded) and bf16 copy for the dgrad conv.
+__global__ __launch_bounds__(256) void image_head_bwd_kernel(const float* __restrict__ x, int ldc,
+                                                             const float* __restrict__ gimg, float* __restrict__ dx,
+                                                             bf16_t* __restrict__ dx_bf16, int ldo, int NB, int C,
+                                                             int HW) {
+    const size_t total = (size_t)NB * HW * ldo;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % ldo);
+        size_t t = idx / ldo;
+        int p = (int)(t % HW);
+        int b = (int)(t / HW);
+        float o = 0.f;
+        if (c < C) {
+            float u = (x[((size_t)b * HW + p) * ldc + c] + 1.f) * 0.5f;
+            float g = gimg[((size_t)b * C + c) * HW + p];
+            float uc = fminf(fmaxf(u, 0.f), 1.f);
+            o = (g * (u - uc) >= 0.f) ? 0.5f * g : 0.f;
+        }
+        if (dx) dx[idx] = o;
+        if (dx_bf16) dx_bf16[idx] = (bf16_t)o;
+    }
+}
+
+// Adam (torch.optim.Adam semantics, amsgrad off, weight_decay 0) fused with clip_z.
+// z is NCHW [1, C, HW]; zmin/zmax per channel (may be null -> no clamp).
+__global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ z, float* __restrict__ m,
+                                                         float* __restrict__ v, const float* __restrict__ g,
+                                                         const float* __restrict__ zmin, const float* __restrict__ zmax,
+                                                         int hw, size_t n, float lr, float b1, float b2, float eps,
+                                                         float bc1, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        float mi = b1 * m[i] + (1.f - b1) * gi;          // exp_avg.lerp_(grad, 1-beta1)
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        float zi = z[i] - (lr / bc1) * (mi / denom);
+        if (zmin) {
+            int c = (int)(i / hw);
+            zi = fminf(fmaxf(zi, zmin[c]), zmax[c]);
+        }
+        z[i] = zi;
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                          size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (bf16_t)in[i];
+}
+
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+}  // namespace
+
+int prx_transpose_bf16(const bf16_t* in, int ldin, bf16_t* out, int ldout, int R, int C, hipStream_t s) {
+    dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, in, ldin, out, ldout, R, C);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_softmax_rows(const float* S, int lds_, float scale, bf16_t* P, int ldp, bf16_t* PT, int ldpt, int rows,
+                     int cols, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, P, ldp, PT, ldpt,
+                       rows, cols);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, float scale, bf16_t* dS, int ldds,
+                         bf16_t* dST, int lddst, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, P, ldp, dP, lddp, scale, dS,
+                       ldds, dST, lddst, rows, cols);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, hipStream_t s) {
+    PRX_REQUIRE(C % 4 == 0, "upsample2x_bwd: C %% 4 != 0");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, NB,
+                       Hl, Wl, C);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((size_t)NB * HW * Cpad)), dim3(256), 0, s, in, out_f32,
+                       out_bf16, NB, C, HW, Cpad);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((size_t)NB * HW * C)), dim3(256), 0, s, in, ldc, out, NB, C,
+                       HW);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(image_head_fwd_kernel, dim3(ew_grid((size_t)NB * HW * C)), dim3(256), 0, s, x, ldc, img, NB, C,
+                       HW);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
+                       int HW, hipStream_t s) {
+    hipLaunchKernelGGL(image_head_bwd_kernel, dim3(ew_grid((size_t)NB * HW * ldo)), dim3(256), 0, s, x, ldc, gimg, dx,
+                       dx_bf16, ldo, NB, C, HW);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
+                   size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t s) {
+    PRX_REQUIRE(step >= 1, "adam: step must be >= 1");
+    const double bc1 = 1.0 - pow((double)b1, step);
+    const double bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, s, z, m, v, g, zmin, zmax, hw, n, lr, b1, b2,
+                       eps, (float)bc1, (float)sqrt(bc2));
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, n);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(add_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, s, a, b, out, n);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,45 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution engine (gfx950).
+//   C[M,N] = epilogue( A[M,K] * Bt[N,K]^T )
+// A is either a row-major matrix (bf16, or f32 converted on load) or the
+// implicit im2col view of an NHWC activation for a 3x3/pad-1 convolution
+// (optionally reading through a fused nearest-2x upsample).  Bt is always the
+// bf16 weight pack, K contiguous.  Accumulation is fp32 on
+// v_mfma_f32_32x32x16_bf16.
+#pragma once
+#include "common.h"
+
+enum { PRX_ACT_NONE = 0, PRX_ACT_QUICKGELU = 1, PRX_ACT_MUL_DQUICKGELU = 2 };
+enum { PRX_A_ROWMAJOR = 0, PRX_A_CONV3X3 = 1 };
+
+struct GemmDesc {
+    // operands
+    const void* A = nullptr;   // bf16 or f32 (a_is_f32)
+    int a_is_f32 = 0;
+    int a_mode = PRX_A_ROWMAJOR;
+    int lda = 0;               // row stride (row-major) or pixel stride (conv), elements
+    const bf16_t* B = nullptr; // [N, K], ldb
+    int ldb = 0;
+    int M = 0, N = 0, K = 0;
+    // conv geometry: M = NB*H*W output pixels, K = 9*Cin; `up` reads an (H/2)x(W/2) input
+    int H = 0, W = 0, Cin = 0, up = 0;
+    // epilogue:  v = alpha*acc + bias_n[n] + bias_m[m];  v *= dquickgelu(aux) ; v += resid
+    float alpha = 1.f;
+    const float* bias_n = nullptr;
+    const float* bias_m = nullptr;
+    const bf16_t* aux = nullptr; int ldaux = 0;
+    const float* resid = nullptr; int ldr = 0;
+    int act = PRX_ACT_NONE;
+    float* out_f32 = nullptr; int ldc_f32 = 0;
+    bf16_t* out_bf16 = nullptr;      // post-activation
+    bf16_t* out_bf16_pre = nullptr;  // pre-activation (QUICKGELU only)
+    int ldc_bf16 = 0;
+};
+
+// Launch on `stream`.  `ws` is a scratch buffer for split-K partials (may be
+// null -> split-K disabled).  Returns 0 or a negative error code.
+int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);
+
+// Per-launch timing hook used by bench.py's roofline leg (HIP events on the
+// launch stream).  When enabled every prx_gemm_launch is bracketed by events.
+void prx_gemm_profile_enable(int on);
+int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches);

@@ -1,0 +1,351 @@
+// bf16 MFMA GEMM / implicit-GEMM conv engine for gfx950 (see gemm.h).
+//
+// Structure (round 1): 256-thread workgroup = 4 waves in a 2x2 grid, block tile
+// BMxBN in {128x128, 128x64, 64x64}, BK = 64.  Operands are staged
+// global -> VGPR -> LDS (the A loader applies the im2col / upsample / f32->bf16
+// transforms, which is why this is not an LDS-DMA path), LDS rows are padded to
+// 144 B so the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
+// 16-B slots, and every wave issues v_mfma_f32_32x32x16_bf16 on (BM/64)x(BN/64)
+// accumulator tiles.  The next K tile's global loads are issued before the
+// MFMAs of the current one.
+#include "gemm.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDS_LD = BK + 8;  // elements; 144-byte rows
+
+struct GemmArgs {
+    GemmDesc d;
+    int tiles_m, tiles_n, splits, kt_per_split, kt_total;
+    float* ws;
+};
+
+__device__ __forceinline__ float quickgelu_f(float t) { return t * sigmoidf_(1.702f * t); }
+__device__ __forceinline__ float dquickgelu_f(float t) {
+    float s = sigmoidf_(1.702f * t);
+    return s * (1.f + 1.702f * t * (1.f - s));
+}
+
+__device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int col, float v) {
+    v *= d.alpha;
+    if (d.bias_n) v += d.bias_n[col];
+    if (d.bias_m) v += d.bias_m[row];
+    if (d.act == PRX_ACT_MUL_DQUICKGELU) {
+        float t = bf16_to_f32(d.aux[(size_t)row * d.ldaux + col]);
+        v *= dquickgelu_f(t);
+    }
+    if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
+    if (d.act == PRX_ACT_QUICKGELU) {
+        bf16_t pre = f32_to_bf16(v);
+        if (d.out_bf16_pre) d.out_bf16_pre[(size_t)row * d.ldc_bf16 + col] = pre;
+        v = quickgelu_f(bf16_to_f32(pre));
+    }
+    if (d.out_f32) d.out_f32[(size_t)row * d.ldc_f32 + col] = v;
+    if (d.out_bf16) d.out_bf16[(size_t)row * d.ldc_bf16 + col] = f32_to_bf16(v);
+}
+
+template <typename TA>
+__device__ __forceinline__ bf16x8 load8(const TA* p);
+template <>
+__device__ __forceinline__ bf16x8 load8<bf16_t>(const bf16_t* p) {
+    return *reinterpret_cast<const bf16x8*>(p);
+}
+template <>
+__device__ __forceinline__ bf16x8 load8<float>(const float* p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+
+template <int BM, int BN, typename TA, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int A_CH = BM * 8 / 256;  // 16-byte chunks per thread per K tile
+    constexpr int B_CH = BN * 8 / 256;
+    constexpr int MT = BM / 64;         // 32x32 MFMA tiles per wave along M
+    constexpr int NT = BN / 64;
+
+    __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDS_LD];
+
+    const GemmDesc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int bid = blockIdx.x;
+    const int tm = bid / p.tiles_n;
+    const int tn = bid - tm * p.tiles_n;
+    const int split = blockIdx.y;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(p.kt_total, kt0 + p.kt_per_split);
+
+    const TA* __restrict__ Ap = reinterpret_cast<const TA*>(d.A);
+    const bf16_t* __restrict__ Bp = d.B;
+
+    // ---- per-thread loader coordinates (fixed across the K loop) ------------
+    int a_row[A_CH];          // row within the tile
+    long long a_base[A_CH];   // row-major: element offset of the row; conv: unused
+    int a_y[A_CH], a_x[A_CH], a_b[A_CH];
+    bool a_ok[A_CH];
+    const int kc = tid & 7;   // which 8-element chunk of the 64-wide K tile
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int row = (tid >> 3) + 32 * i;
+        a_row[i] = row;
+        int gm = tm * BM + row;
+        a_ok[i] = gm < d.M;
+        if (AMODE == PRX_A_ROWMAJOR) {
+            a_base[i] = (long long)gm * d.lda;
+            a_y[i] = a_x[i] = a_b[i] = 0;
+        } else {
+            int hw = d.H * d.W;
+            int b = gm / hw;
+            int rem = gm - b * hw;
+            int y = rem / d.W;
+            a_b[i] = b; a_y[i] = y; a_x[i] = rem - y * d.W;
+            a_base[i] = 0;
+        }
+    }
+    int b_row[B_CH];
+    long long b_base[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int row = (tid >> 3) + 32 * i;
+        b_row[i] = row;
+        int gn = tn * BN + row;
+        b_ok[i] = gn < d.N;
+        b_base[i] = (long long)gn * d.ldb;
+    }
+
+    bf16x8 a_reg[A_CH], b_reg[B_CH];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + kc * 8;
+        const bool k_ok = k < d.K;
+        if (AMODE == PRX_A_ROWMAJOR) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i)
+                a_reg[i] = (a_ok[i] && k_ok) ? load8<TA>(Ap + a_base[i] + k) : zero8;
+        } else {
+            int tap = k / d.Cin;
+            int c = k - tap * d.Cin;
+            int ky = tap / 3;
+            int kx = tap - 3 * ky;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
+                bool ok = a_ok[i] && k_ok && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+                long long pix;
+                if (d.up) pix = ((long long)a_b[i] * (d.H >> 1) + (yy >> 1)) * (d.W >> 1) + (xx >> 1);
+                else      pix = ((long long)a_b[i] * d.H + yy) * d.W + xx;
+                a_reg[i] = ok ? load8<TA>(Ap + pix * d.lda + c) : zero8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const bf16x8*>(Bp + b_base[i] + k) : zero8;
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            *reinterpret_cast<bf16x8*>(&As[a_row[i] * LDS_LD + kc * 8]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            *reinterpret_cast<bf16x8*>(&Bs[b_row[i] * LDS_LD + kc * 8]) = b_reg[i];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tiles(kt0);
+        store_tiles();
+    }
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = 8 * (lane >> 5);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) load_tiles(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(
+                    &As[(wm * (BM / 2) + i * 32 + frag_row) * LDS_LD + ks * 16 + frag_k]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(
+                    &Bs[(wn * (BN / 2) + j * 32 + frag_row) * LDS_LD + ks * 16 + frag_k]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------
+    const int row0 = tm * BM + wm * (BM / 2) + 4 * (lane >> 5);
+    const int col0 = tn * BN + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + j * 32;
+            if (col >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= d.M) continue;
+                if (p.splits > 1)
+                    p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
+                else
+                    epilogue_store(d, row, col, acc[i][j][r]);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const GemmDesc& d = p.d;
+    const size_t total = (size_t)d.M * d.N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.splits; ++s) v += p.ws[(size_t)s * total + idx];
+        int row = (int)(idx / d.N);
+        int col = (int)(idx - (size_t)row * d.N);
+        epilogue_store(d, row, col, v);
+    }
+}
+
+template <int BM, int BN>
+void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    const GemmDesc& d = a.d;
+    if (d.a_mode == PRX_A_ROWMAJOR) {
+        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a);
+    } else {
+        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
+    }
+}
+
+// ---- optional per-launch profiling (bench.py roofline leg) -------------------
+struct ProfRec { hipEvent_t a, b; double flop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+}  // namespace
+
+void prx_gemm_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, fl = 0;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+        ms += t; fl += r.flop;
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flop) *total_flop = fl;
+    if (launches) *launches = (long long)g_prof.size();
+    g_prof.clear();
+    return 0;
+}
+
+int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
+    PRX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    PRX_REQUIRE(d.K % 8 == 0 && d.ldb % 8 == 0, "gemm: K (%d) and ldb (%d) must be multiples of 8", d.K, d.ldb);
+    PRX_REQUIRE(d.lda % 8 == 0, "gemm: lda (%d) must be a multiple of 8", d.lda);
+    PRX_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
+    if (d.a_mode == PRX_A_CONV3X3) {
+        PRX_REQUIRE(d.Cin % 8 == 0 && d.K == 9 * d.Cin, "gemm/conv: need Cin %% 8 == 0 and K == 9*Cin (Cin=%d K=%d)", d.Cin, d.K);
+        PRX_REQUIRE(d.H > 0 && d.W > 0 && d.M % (d.H * d.W) == 0, "gemm/conv: M (%d) must be NB*H*W (%dx%d)", d.M, d.H, d.W);
+        PRX_REQUIRE(!d.up || (d.H % 2 == 0 && d.W % 2 == 0), "gemm/conv: upsample needs even H, W");
+    }
+    PRX_REQUIRE(d.act != PRX_ACT_MUL_DQUICKGELU || d.aux, "gemm: MUL_DQUICKGELU needs aux");
+
+    // ---- tile / split-K selection -------------------------------------------
+    const int target_blocks = 256;  // one per CU
+    int BM = 128, BN = 128;
+    auto ntiles = [&](int bm, int bn) { return ceil_div(d.M, bm) * ceil_div(d.N, bn); };
+    if (ntiles(128, 128) < 2 * target_blocks) { BM = 128; BN = 64; }
+    if (BN == 64 && ntiles(128, 64) < 2 * target_blocks) { BM = 64; BN = 64; }
+    if (d.N <= 64) { BN = 64; if (BM == 128 && ntiles(128, 64) < target_blocks) BM = 64; }
+    GemmArgs a;
+    a.d = d;
+    a.tiles_m = ceil_div(d.M, BM);
+    a.tiles_n = ceil_div(d.N, BN);
+    a.kt_total = ceil_div(d.K, BK);
+    int tiles = a.tiles_m * a.tiles_n;
+    int splits = 1;
+    if (ws && tiles < target_blocks && a.kt_total >= 8) {
+        splits = std::min(std::min(ceil_div(2 * target_blocks, tiles), a.kt_total / 4), 32);
+        while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    a.kt_per_split = ceil_div(a.kt_total, splits);
+    splits = ceil_div(a.kt_total, a.kt_per_split);
+    a.splits = splits;
+    a.ws = ws;
+
+    ProfRec rec{};
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        prof = g_prof_on;
+    }
+    if (prof) {
+        PRX_CHECK_HIP(hipEventCreate(&rec.a));
+        PRX_CHECK_HIP(hipEventCreate(&rec.b));
+        rec.flop = 2.0 * d.M * d.N * d.K;
+        PRX_CHECK_HIP(hipEventRecord(rec.a, stream));
+    }
+
+    dim3 grid(tiles, splits);
+    if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);
+    else if (BM == 128 && BN == 64) launch_cfg<128, 64>(a, grid, stream);
+    else launch_cfg<64, 64>(a, grid, stream);
+    PRX_LAUNCH_CHECK();
+    if (splits > 1) {
+        size_t total = (size_t)d.M * d.N;
+        int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        PRX_LAUNCH_CHECK();
+    }
+    if (prof) {
+        PRX_CHECK_HIP(hipEventRecord(rec.b, stream));
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+    return 0;
+}

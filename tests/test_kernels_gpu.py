@@ -1,0 +1,265 @@
+"""Kernel-level parity tests (GPU): every HIP kernel alone, through the C ABI, against a plain
+PyTorch fp32 reference of the same op evaluated on the same (bf16-rounded where the kernel
+consumes bf16) inputs.  Tolerances are written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pixray_amd import _lib
+from pixray_amd._lib import GemmArgs, call
+
+DEV = "cuda"
+
+
+def stream():
+    return _lib.current_stream()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+def run_gemm(A, Bt, M, N, K, *, a_mode=0, lda=None, H=0, W=0, Cin=0, up=0, alpha=1.0, bias_n=None, bias_m=None,
+             aux=None, resid=None, act=0, want_f32=True, want_bf16=False, want_pre=False, ws=None):
+    g = GemmArgs()
+    g.A = A.data_ptr(); g.a_is_f32 = int(A.dtype == torch.float32); g.a_mode = a_mode
+    g.lda = lda if lda is not None else A.shape[-1]
+    g.B = Bt.data_ptr(); g.ldb = Bt.shape[-1]
+    g.M, g.N, g.K = M, N, K
+    g.H, g.W, g.Cin, g.up = H, W, Cin, up
+    g.alpha = alpha
+    g.bias_n = bias_n.data_ptr() if bias_n is not None else None
+    g.bias_m = bias_m.data_ptr() if bias_m is not None else None
+    g.aux = aux.data_ptr() if aux is not None else None
+    g.ldaux = N
+    g.resid = resid.data_ptr() if resid is not None else None
+    g.ldr = N
+    g.act = act
+    out_f32 = torch.full((M, N), float("nan"), device=DEV) if want_f32 else None
+    out_bf16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16) if want_bf16 else None
+    out_pre = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16) if want_pre else None
+    g.out_f32 = out_f32.data_ptr() if want_f32 else None
+    g.ldc_f32 = N
+    g.out_bf16 = out_bf16.data_ptr() if want_bf16 else None
+    g.out_bf16_pre = out_pre.data_ptr() if want_pre else None
+    g.ldc_bf16 = N
+    if ws is None:
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    call("prx_k_gemm", g, ws, ws.numel(), stream())
+    torch.cuda.synchronize()
+    return out_f32, out_bf16, out_pre
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (128, 128, 64), (64, 64, 64), (256, 512, 4608),   # exercises split-K
+    (3200, 768, 768), (3200, 2304, 768), (3136, 768, 3072), (3200, 3072, 768), (64, 512, 768),
+    (65536, 128, 1152), (100, 72, 136),               # ragged M/N, K not a multiple of 64
+])
+def test_gemm_rowmajor_bf16(M, N, K):
+    torch.manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device=DEV))
+    # asymmetric B (rule: transpose-detecting)
+    Bt = bf(torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None])
+    out, _, _ = run_gemm(A, Bt, M, N, K)
+    ref = A.float() @ Bt.float().T
+    # fp32 accumulate of exact bf16 products; only summation order differs -> 1e-5 relative
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    assert torch.isfinite(out).all()
+
+
+def test_gemm_f32_A_and_epilogues():
+    torch.manual_seed(0)
+    M, N, K = 3200, 768, 3072
+    A32 = torch.randn(M, K, device=DEV)
+    Bt = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    bias = torch.randn(N, device=DEV)
+    resid = torch.randn(M, N, device=DEV)
+    out, ob, _ = run_gemm(A32, Bt, M, N, K, bias_n=bias, resid=resid, want_bf16=True)
+    ref = bf(A32).float() @ Bt.float().T + bias + resid
+    assert rel_l2(out, ref) < 2e-5
+    assert rel_l2(ob, ref) < 4e-3  # bf16 output rounding (2^-9 relative per element)
+    # QuickGELU forward epilogue (+ pre-activation copy) and its backward multiplier
+    out, ob, pre = run_gemm(bf(A32), Bt, M, N, K, bias_n=bias, act=1, want_bf16=True, want_pre=True)
+    t = bf(A32).float() @ Bt.float().T + bias
+    assert rel_l2(pre, t) < 4e-3
+    tq = pre.float()
+    assert rel_l2(out, tq * torch.sigmoid(1.702 * tq)) < 1e-5
+    aux = pre
+    out2, _, _ = run_gemm(bf(A32), Bt, M, N, K, act=2, aux=aux)
+    s = torch.sigmoid(1.702 * tq)
+    ref2 = (bf(A32).float() @ Bt.float().T) * (s * (1 + 1.702 * tq * (1 - s)))
+    assert rel_l2(out2, ref2) < 2e-5
+    # bias_m + alpha
+    bm = torch.randn(M, device=DEV)
+    out3, _, _ = run_gemm(bf(A32), Bt, M, N, K, bias_m=bm, alpha=0.5)
+    assert rel_l2(out3, 0.5 * (bf(A32).float() @ Bt.float().T) + bm[:, None]) < 2e-5
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [
+    (16, 16, 256, 512, 0, 1), (32, 32, 512, 256, 1, 1), (64, 64, 128, 128, 0, 1), (8, 12, 32, 40, 1, 2),
+    (256, 256, 128, 128, 0, 1), (64, 64, 8, 128, 0, 1),
+])
+def test_gemm_conv3x3(H, W, Cin, Cout, up, NB):
+    """implicit-GEMM 3x3/pad-1 conv on NHWC (optionally through a fused nearest-2x upsample)"""
+    torch.manual_seed(H * W + Cin)
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(NB, Cin, hin, win, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, device=DEV)
+    x_nhwc = bf(x.permute(0, 2, 3, 1).contiguous())
+    w_pack = bf(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous())
+    out, _, _ = run_gemm(x_nhwc, w_pack, NB * H * W, Cout, 9 * Cin, a_mode=1, lda=Cin, H=H, W=W, Cin=Cin, up=up,
+                         bias_n=bias)
+    xr = bf(x).float()
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    # f32 activation input converted on load
+    x32 = x.permute(0, 2, 3, 1).contiguous()
+    out2, _, _ = run_gemm(x32, w_pack, NB * H * W, Cout, 9 * Cin, a_mode=1, lda=Cin, H=H, W=W, Cin=Cin, up=up,
+                          bias_n=bias)
+    assert rel_l2(out2, ref) < 2e-5
+
+
+@pytest.mark.parametrize("P,C,swish", [(256, 512, 1), (1024, 256, 1), (4096, 128, 0), (65536, 128, 1)])
+def test_groupnorm_fwd_bwd(P, C, swish):
+    torch.manual_seed(P + C)
+    NB = 1
+    x = (torch.randn(NB, P, C, device=DEV) * 1.5 + 0.3).requires_grad_(True)
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1.0
+    beta = torch.randn(C, device=DEV) * 0.1
+    stats = torch.zeros(NB * 64, dtype=torch.float64, device=DEV)
+    out_bf16 = torch.empty(NB, P, C, dtype=torch.bfloat16, device=DEV)
+    out_f32 = torch.empty(NB, P, C, device=DEV)
+    call("prx_k_groupnorm_fwd", x, gamma, beta, stats, out_bf16, out_f32, NB, P, C, swish, 1e-6, stream())
+    y = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-6).permute(0, 2, 1)
+    ref = y * torch.sigmoid(y) if swish else y
+    torch.cuda.synchronize()
+    assert rel_l2(out_f32, ref) < 1e-5
+    assert rel_l2(out_bf16, ref) < 4e-3
+    g = torch.randn(NB, P, C, device=DEV)
+    add = torch.randn(NB, P, C, device=DEV)
+    (gx,) = torch.autograd.grad(ref, x, g)
+    bstats = torch.zeros(NB * 64, dtype=torch.float64, device=DEV)
+    dx = torch.empty(NB, P, C, device=DEV)
+    call("prx_k_groupnorm_bwd", g, x.detach(), gamma, beta, stats, bstats, add, dx, NB, P, C, swish, 1e-6, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dx, gx + add) < 2e-5, rel_l2(dx, gx + add)
+
+
+@pytest.mark.parametrize("rows,C", [(3200, 768), (64, 768), (257, 1024)])
+def test_layernorm_fwd_bwd(rows, C):
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, C, device=DEV) * 2 + 0.5).requires_grad_(True)
+    gamma = torch.randn(C, device=DEV) * 0.2 + 1.0
+    beta = torch.randn(C, device=DEV) * 0.1
+    ob = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    of = torch.empty(rows, C, device=DEV)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    call("prx_k_layernorm_fwd", x, C, gamma, beta, ob, of, mean, rstd, rows, C, 1e-5, stream())
+    ref = F.layer_norm(x, (C,), gamma, beta, eps=1e-5)
+    torch.cuda.synchronize()
+    assert rel_l2(of, ref) < 1e-5
+    assert rel_l2(ob, ref) < 4e-3
+    g = torch.randn(rows, C, device=DEV)
+    add = torch.randn(rows, C, device=DEV)
+    (gx,) = torch.autograd.grad(ref, x, g)
+    dx = torch.empty(rows, C, device=DEV)
+    call("prx_k_layernorm_bwd", g, C, x.detach(), C, gamma, mean, rstd, add, C, dx, C, rows, C, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dx, gx + add) < 1e-5
+
+
+def test_transpose_softmax_upsample_layout():
+    torch.manual_seed(1)
+    a = bf(torch.randn(256, 1536, device=DEV))
+    out = torch.empty(512, 256, dtype=torch.bfloat16, device=DEV)
+    call("prx_k_transpose_bf16", a[:, 512:], 1536, out, 256, 256, 512, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, a[:, 512:1024].T.contiguous())  # bit-exact data movement
+    S = torch.randn(256, 256, device=DEV) * 20
+    P = torch.empty(256, 256, dtype=torch.bfloat16, device=DEV)
+    PT = torch.empty(256, 256, dtype=torch.bfloat16, device=DEV)
+    scale = 512 ** -0.5
+    call("prx_k_softmax_rows", S, 256, scale, P, 256, PT, 256, 256, 256, stream())
+    ref = torch.softmax(S * scale, dim=-1)
+    torch.cuda.synchronize()
+    assert rel_l2(P, ref) < 4e-3 and torch.equal(P.T.contiguous(), PT)
+    dP = torch.randn(256, 256, device=DEV)
+    dS = torch.empty_like(P)
+    dST = torch.empty_like(P)
+    call("prx_k_softmax_rows_bwd", P, 256, dP, 256, scale, dS, 256, dST, 256, 256, 256, stream())
+    pf = P.float()
+    refd = scale * pf * (dP - (pf * dP).sum(-1, keepdim=True))
+    torch.cuda.synchronize()
+    assert rel_l2(dS, refd) < 4e-3 and torch.equal(dS.T.contiguous(), dST)
+    hi = torch.randn(2, 16, 24, 128, device=DEV)
+    low = torch.empty(2, 8, 12, 128, device=DEV)
+    call("prx_k_upsample2x_bwd", hi, low, 2, 8, 12, 128, stream())
+    ref = hi.view(2, 8, 2, 12, 2, 128).sum(dim=(2, 4))
+    torch.cuda.synchronize()
+    assert rel_l2(low, ref) < 1e-6
+    x = torch.randn(2, 3, 50, device=DEV)
+    o32 = torch.empty(2, 50, 8, device=DEV)
+    ob = torch.empty(2, 50, 8, dtype=torch.bfloat16, device=DEV)
+    call("prx_k_nchw_to_nhwc", x, o32, ob, 2, 3, 50, 8, stream())
+    back = torch.empty(2, 3, 50, device=DEV)
+    call("prx_k_nhwc_to_nchw", o32, 8, back, 2, 3, 50, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(back, x) and torch.equal(o32[..., 3:], torch.zeros_like(o32[..., 3:]))
+    assert torch.equal(ob, bf(o32))
+
+
+def test_image_head():
+    torch.manual_seed(2)
+    HW, C, ld = 4096, 3, 4
+    x = torch.randn(1, HW, ld, device=DEV) * 1.5
+    img = torch.empty(1, C, HW, device=DEV)
+    call("prx_k_image_head_fwd", x, ld, img, 1, C, HW, stream())
+    u = (x[..., :C].permute(0, 2, 1) + 1) / 2
+    torch.cuda.synchronize()
+    assert torch.equal(img, u.clamp(0, 1))
+    g = torch.randn(1, C, HW, device=DEV)
+    dx = torch.empty(1, HW, 8, device=DEV)
+    dxb = torch.empty(1, HW, 8, dtype=torch.bfloat16, device=DEV)
+    call("prx_k_image_head_bwd", x, ld, g, dx, dxb, 8, 1, C, HW, stream())
+    # ClampWithGrad.backward (vqgan.py:76-79) then d/dx of (x+1)/2
+    ref = (g * (g * (u - u.clamp(0, 1)) >= 0)) * 0.5
+    torch.cuda.synchronize()
+    assert torch.equal(dx[..., :C], ref.permute(0, 2, 1)) and (dx[..., C:] == 0).all()
+    assert torch.equal(dxb, bf(dx))
+
+
+@pytest.mark.parametrize("N,T", [(64, 50), (3, 64), (2, 17)])
+def test_mha_fwd_bwd(N, T):
+    torch.manual_seed(N * T)
+    C, heads = 768, 12
+    qkv = bf(torch.randn(N * T, 3 * C, device=DEV))
+    out = torch.full((N * T, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call("prx_k_mha_fwd", qkv, out, N, T, C, heads, stream())
+    q, k, v = [t.reshape(N, T, heads, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+               for t in qkv.float().split(C, dim=1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(N * T, C)
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before PV and the output is bf16: 2^-8-class errors
+    assert rel_l2(out, ref) < 8e-3, rel_l2(out, ref)
+    do = bf(torch.randn(N * T, C, device=DEV))
+    dqkv = torch.full((N * T, 3 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call("prx_k_mha_bwd", qkv, do, dqkv, N, T, C, heads, stream())
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), do.float())
+    refd = torch.cat([t.permute(0, 2, 1, 3).reshape(N * T, C) for t in (gq, gk, gv)], dim=1)
+    torch.cuda.synchronize()
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(dqkv[:, i * C:(i + 1) * C], refd[:, i * C:(i + 1) * C])
+        assert e < 1.2e-2, (nm, e)
