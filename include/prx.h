@@ -110,6 +110,109 @@ int prx_k_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, 
 int prx_k_mha_fwd(const void* qkv, void* out, int N, int T, int C, int heads, prx_stream_t s);
 int prx_k_mha_bwd(const void* qkv, const void* dout, void* dqkv, int N, int T, int C, int heads, prx_stream_t s);
 
+/* ------------------------------------------------------------------------ */
+/* Path-level operators: the drop-in boundary of the hot path                */
+/* ------------------------------------------------------------------------ */
+
+/* --- VqganDrawer (vqgan.py:83-214): synth = vector_quantize (60-64, straight-through 48-58) ->
+ *     taming VQModel.decode [UPSTREAM] -> add(1).div(2) -> clamp_with_grad(0,1) (66-79,195).
+ * weights[]: fp32 device tensors in taming state-dict order:
+ *   quantize.embedding.weight [n_embed, embed_dim];
+ *   post_quant_conv.{weight[zc,ed,1,1], bias}; decoder.conv_in.{weight, bias};
+ *   mid.block_1 (ResnetBlock), mid.attn_1 (AttnBlock), mid.block_2;
+ *   for level = n_mult-1 .. 0: (num_res_blocks+1) x [ResnetBlock (+ AttnBlock at attn_resolution)], then
+ *     upsample.conv.{weight,bias} when level != 0;
+ *   norm_out.{weight,bias}; conv_out.{weight,bias}.
+ *   ResnetBlock = norm1.{w,b}, conv1.{w,b}, norm2.{w,b}, conv2.{w,b} [, nin_shortcut.{w,b} if Cin != Cout]
+ *   AttnBlock   = norm.{w,b}, q.{w,b}, k.{w,b}, v.{w,b}, proj_out.{w,b}
+ * The caller may free the weight tensors after the stream has drained. */
+typedef struct prx_vqgan prx_vqgan;
+typedef struct prx_vqgan_config {
+    int ch;                /* 128 */
+    int ch_mult[8];        /* {1,1,2,2,4} */
+    int n_mult;            /* 5 -> f = 16 (DrawingInterface.get_num_resolutions, vqgan.py:187-188) */
+    int num_res_blocks;    /* 2 */
+    int attn_resolution;   /* 16 */
+    int resolution;        /* nominal training resolution of the config, 256 */
+    int z_channels;        /* 256 */
+    int embed_dim;         /* 256 */
+    int n_embed;           /* 16384 */
+    int out_ch;            /* 3 */
+    int latent_h, latent_w;/* z is [1, z_channels, latent_h, latent_w] */
+} prx_vqgan_config;
+int prx_vqgan_create(prx_vqgan** out, const prx_vqgan_config* cfg, const float* const* weights, int n_weights,
+                     prx_stream_t s);
+void prx_vqgan_destroy(prx_vqgan* h);
+/* per-channel codebook min/max used by VqganDrawer.clip_z (vqgan.py:155-158, 202-204) */
+int prx_vqgan_z_bounds(prx_vqgan* h, float* zmin, float* zmax, prx_stream_t s);
+/* z [1,zc,h,w] -> img [1,out_ch,16h,16w] in [0,1]; indices (optional, int32 [h*w]) = chosen codes;
+ * quantize=0 skips the VQ step (decode of an already-quantised latent). */
+int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int quantize, prx_stream_t s);
+/* d loss / d img -> d loss / d z of the forward in flight on this handle */
+int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s);
+
+/* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
+ * desc: fp32 [n_cut][32] per-cutout descriptor (layout in pixray_amd/cutouts.py and csrc/cutouts.hip):
+ *   [0..8] stage-A 3x3 (dst pixel -> source sampling position), [9..17] stage-B 3x3,
+ *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill),
+ *   [20] fill gray, [21] jitter on/off, [22] saturation factor, [23] hue shift (rad), [24] saturation-first,
+ *   [25] noise factor.
+ * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/stage_a are caller-owned save-for-backward
+ * buffers ([3,S,S] f32, [3,S,S] i32, [n_cut,3,S,S] f32). */
+int prx_cutouts_forward(const float* img, int H, int W, const float* desc, const float* noise, int n_cut, int S,
+                        float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s);
+int prx_cutouts_backward(const float* g_out, const float* desc, int n_cut, int S, int H, int W, const float* stage_a,
+                         const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s);
+
+/* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].
+ * weights[]: fp32 device tensors in OpenAI state-dict order under `visual.`:
+ *   conv1.weight, class_embedding, positional_embedding, ln_pre.{weight,bias},
+ *   per layer: ln_1.{weight,bias}, attn.in_proj_{weight,bias}, attn.out_proj.{weight,bias},
+ *              ln_2.{weight,bias}, mlp.c_fc.{weight,bias}, mlp.c_proj.{weight,bias},
+ *   ln_post.{weight,bias}, proj.
+ * The batch-global min/max renorm (slip.py:21-36) couples all cutouts, so the call sequence is split to
+ * let a sharded caller all-reduce the two small buffers in between:
+ *   minmax(cutouts) -> mm[2] {min,max}      [all-reduce MIN/MAX over ranks]
+ *   encode(cutouts, mm) -> embeds [n, output_dim] (unit vectors)
+ *   backward_reduce(d_embeds) -> acc[4] doubles {sum g, sum g*y, #min, #max}   [all-reduce SUM]
+ *   backward_finish(acc) -> g_cutouts [n,3,R,R] */
+typedef struct prx_clip_vit prx_clip_vit;
+typedef struct prx_clip_vit_config {
+    int input_resolution;  /* 224 */
+    int patch_size;        /* 32 */
+    int width;             /* 768 */
+    int layers;            /* 12 */
+    int heads;             /* 12 */
+    int output_dim;        /* 512 */
+    int max_batch;         /* capacity in cutouts */
+} prx_clip_vit_config;
+int prx_clip_vit_create(prx_clip_vit** out, const prx_clip_vit_config* cfg, const float* const* weights, int n_weights,
+                        prx_stream_t s);
+void prx_clip_vit_destroy(prx_clip_vit* h);
+int prx_clip_vit_minmax(prx_clip_vit* h, const float* cutouts, int n, float* mm, prx_stream_t s);
+int prx_clip_vit_encode(prx_clip_vit* h, const float* cutouts, int n, const float* mm, float* embeds, prx_stream_t s);
+int prx_clip_vit_backward_reduce(prx_clip_vit* h, const float* cutouts, const float* mm, const float* d_embeds,
+                                 double* acc, prx_stream_t s);
+int prx_clip_vit_backward_finish(prx_clip_vit* h, const float* cutouts, const float* mm, const double* acc,
+                                 float* g_cutouts, prx_stream_t s);
+
+/* --- Prompt.forward (pixray.py:275-280) fused with its backward.
+ * rowloss[i] = sum_j sign(w) * 2*asin(|x^_i - e^_j|/2)^2 (forward value: |w| * sum(rowloss)/denom);
+ * grad = d/d input of |w| * mean(max(sign(w) d, stop)) with the mean over `denom` (= global n*m) pairs. */
+int prx_prompt_loss_fwd_bwd(const float* input, const float* embed, int n, int m, int D, float weight, float stop,
+                            float denom, float* rowloss, float* grad, prx_stream_t s);
+
+/* --- optim.Adam([z], lr) step (pixray.py:539,1484-1485) fused with VqganDrawer.clip_z (vqgan.py:202-204).
+ * z/exp_avg/exp_avg_sq/grad: [1,C,hw] fp32; zmin/zmax per channel or NULL; step is 1-based. */
+int prx_adam_clamp_step(float* z, float* exp_avg, float* exp_avg_sq, const float* grad, const float* zmin,
+                        const float* zmax, int hw, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                        prx_stream_t s);
+
+int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook,
+                     const float* cnorm, int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq,
+                     prx_stream_t s);
+int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t s);
+
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
 void prx_profile_gemm_enable(int on);
 int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches);

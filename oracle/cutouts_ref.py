@@ -1,0 +1,236 @@
+"""ORACLE (test infrastructure only -- never imported by the product package).
+
+CPU fp32 restatement of `MakeCutouts.forward` (/root/reference/pixray.py:445-511, ctor 401-443,
+kornia overrides 326-366) with every random draw made an explicit input (`params`), because
+the reference's RNG streams (kornia parameter generators, device randn) cannot be reproduced.
+
+The geometric and colour operators are kornia==0.6.2 (/root/reference/requirements.txt:18),
+which is NOT vendored; their published algorithms are restated here the way kornia builds
+them -- normalised homographies + `F.grid_sample` / `F.affine_grid` -- following
+SURVEY.md Appendix A.3.  The product computes the same maps in pixel space inside one HIP
+kernel, so agreement between the two is a real check of both.  Parity status: **unpinned**
+(the reference's tests hold no fixture for this path; no second implementation of kornia's
+augmentations is available offline).
+
+Pipeline (pixray.py):
+  pooled = (AdaptiveAvgPool2d(S)(img) + AdaptiveMaxPool2d(S)(img)) / 2            461-463 (same for every cutout)
+  zoom set, first int(0.6*cutn) cutouts                                            414-417, 493
+     MyRandomPerspective(0.4, p=.7)  [padding_mode = reflection / border by iteration parity, 1250-1253]
+     RandomResizedCrop(S, scale=(.25,.95), ratio=(.85,1.2), cropping_mode='resample')
+     ColorJitter(hue=.1, saturation=.1, p=.8)
+  wide set, the rest                                                               419-437, 494
+     MyRandomAffine(translate=±2.5%, scale=.95, padding 'fill' gray)
+     CenterCrop(S) on an S x S image (identity resample, align_corners=True)
+     MyRandomPerspectivePadded(0.2, p=.7, padding 'fill' gray)
+     ColorJitter(hue=.1, saturation=.1, p=.8)
+  batch + U(0, 0.1) * N(0,1)                                                       508-510
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+TWO_PI = 2.0 * math.pi
+
+
+# ---------------------------------------------------------------- kornia geometry [UPSTREAM]
+def get_perspective_transform(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """kornia.geometry.transform.get_perspective_transform: 3x3 M with M @ src_i ~ dst_i (DLT, 8x8 solve)."""
+    B = src.shape[0]
+    rows = []
+    for i in range(4):
+        x, y = src[:, i, 0], src[:, i, 1]
+        u, v = dst[:, i, 0], dst[:, i, 1]
+        o, z = torch.ones_like(x), torch.zeros_like(x)
+        rows.append(torch.stack([x, y, o, z, z, z, -x * u, -y * u], dim=1))
+        rows.append(torch.stack([z, z, z, x, y, o, -x * v, -y * v], dim=1))
+    A = torch.stack(rows, dim=1)
+    b = dst.reshape(B, 8, 1)
+    X = torch.linalg.solve(A, b)
+    M = torch.cat([X[:, :, 0], torch.ones(B, 1, dtype=src.dtype)], dim=1).reshape(B, 3, 3)
+    return M
+
+
+def _normal_transform_pixel(h: int, w: int, dtype) -> torch.Tensor:
+    """kornia normal_transform_pixel: pixel [0, W-1] -> [-1, 1]."""
+    t = torch.tensor([[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]], dtype=dtype)
+    wd = 1e-14 if w == 1 else w - 1.0
+    hd = 1e-14 if h == 1 else h - 1.0
+    t[0, 0] = t[0, 0] * 2.0 / wd
+    t[1, 1] = t[1, 1] * 2.0 / hd
+    return t
+
+
+def normalize_homography(M, src_hw, dst_hw):
+    """kornia normalize_homography: dst_norm <- src_norm."""
+    sn = _normal_transform_pixel(src_hw[0], src_hw[1], M.dtype)
+    dn = _normal_transform_pixel(dst_hw[0], dst_hw[1], M.dtype)
+    return dn @ (M @ torch.linalg.inv(sn))
+
+
+def _meshgrid_norm(h, w, dtype):
+    """kornia create_meshgrid(normalized_coordinates=True): linspace(-1, 1) (the [0, W-1] convention)."""
+    xs = (torch.linspace(0, w - 1, w, dtype=dtype) / (w - 1) - 0.5) * 2
+    ys = (torch.linspace(0, h - 1, h, dtype=dtype) / (h - 1) - 0.5) * 2
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    return torch.stack([gx, gy], dim=-1)  # [h, w, 2]
+
+
+def _fill_and_warp(src, grid, mode, align_corners, fill_value):
+    """kornia 0.6.2 _fill_and_warp (padding_mode='fill')."""
+    ones = torch.ones_like(src)
+    fv = fill_value.to(src)[None, :, None, None]
+    inv_ones = 1 - F.grid_sample(ones, grid, align_corners=align_corners, mode=mode, padding_mode="zeros")
+    return F.grid_sample(src, grid, align_corners=align_corners, mode=mode, padding_mode="zeros") + inv_ones * fv
+
+
+def warp_perspective(src, M, dsize, padding_mode, align_corners, fill_value=None):
+    """kornia warp_perspective (bilinear). M maps src pixels -> dst pixels. Geometry in float64, sampling fp32."""
+    B, _, H, W = src.shape
+    Md = M.double()
+    dn_sn = normalize_homography(Md, (H, W), dsize)
+    sn_dn = torch.linalg.inv(dn_sn)
+    grid = _meshgrid_norm(dsize[0], dsize[1], torch.float64)[None].expand(B, -1, -1, -1)
+    hom = torch.cat([grid, torch.ones_like(grid[..., :1])], dim=-1)           # [B,h,w,3]
+    pts = torch.einsum("bij,bhwj->bhwi", sn_dn, hom)
+    z = pts[..., 2:3]
+    scale = torch.where(z.abs() > 1e-8, 1.0 / z, torch.ones_like(z))
+    g = (pts[..., :2] * scale).to(src.dtype)
+    if padding_mode == "fill":
+        return _fill_and_warp(src, g, "bilinear", align_corners, fill_value)
+    return F.grid_sample(src, g, align_corners=align_corners, mode="bilinear", padding_mode=padding_mode)
+
+
+def warp_affine(src, M2x3, dsize, padding_mode, align_corners, fill_value=None):
+    """kornia warp_affine (bilinear): affine_grid + grid_sample."""
+    B, C, H, W = src.shape
+    M = torch.cat([M2x3.double(), torch.tensor([[[0.0, 0.0, 1.0]]], dtype=torch.float64).expand(B, 1, 3)], dim=1)
+    dn_sn = normalize_homography(M, (H, W), dsize)
+    sn_dn = torch.linalg.inv(dn_sn)
+    g = F.affine_grid(sn_dn[:, :2, :].to(src.dtype), [B, C, dsize[0], dsize[1]], align_corners=align_corners)
+    if padding_mode == "fill":
+        return _fill_and_warp(src, g, "bilinear", align_corners, fill_value)
+    return F.grid_sample(src, g, align_corners=align_corners, mode="bilinear", padding_mode=padding_mode)
+
+
+# ---------------------------------------------------------------- kornia colour [UPSTREAM]
+def rgb_to_hsv(image, eps=1e-8):
+    max_rgb, argmax_rgb = image.max(-3)
+    min_rgb, _ = image.min(-3)
+    deltac = max_rgb - min_rgb
+    v = max_rgb
+    s = deltac / (max_rgb + eps)
+    deltac = torch.where(deltac == 0, torch.ones_like(deltac), deltac)
+    rc, gc, bc = torch.unbind(max_rgb.unsqueeze(-3) - image, dim=-3)
+    h1 = bc - gc
+    h2 = (rc - bc) + 2.0 * deltac
+    h3 = (gc - rc) + 4.0 * deltac
+    h = torch.stack((h1, h2, h3), dim=-3) / deltac.unsqueeze(-3)
+    h = torch.gather(h, dim=-3, index=argmax_rgb.unsqueeze(-3)).squeeze(-3)
+    h = (h / 6.0) % 1.0
+    h = TWO_PI * h
+    return torch.stack((h, s, v), dim=-3)
+
+
+def hsv_to_rgb(image):
+    h = image[..., 0, :, :] / TWO_PI
+    s = image[..., 1, :, :]
+    v = image[..., 2, :, :]
+    hi = torch.floor(h * 6) % 6
+    f = ((h * 6) % 6) - hi
+    one = torch.tensor(1.0, dtype=image.dtype)
+    p = v * (one - s)
+    q = v * (one - f * s)
+    t = v * (one - (one - f) * s)
+    hi = hi.long()
+    indices = torch.stack([hi, hi + 6, hi + 12], dim=-3)
+    out = torch.stack((v, q, p, p, t, v, t, v, v, q, p, p, p, p, t, v, v, q), dim=-3)
+    return torch.gather(out, -3, indices)
+
+
+def adjust_saturation(img, factor):
+    hsv = rgb_to_hsv(img)
+    h, s, v = hsv[:, 0:1], hsv[:, 1:2], hsv[:, 2:3]
+    s = torch.clamp(s * factor.view(-1, 1, 1, 1), 0.0, 1.0)
+    return hsv_to_rgb(torch.cat([h, s, v], dim=1))
+
+
+def adjust_hue(img, factor_rad):
+    hsv = rgb_to_hsv(img)
+    h, s, v = hsv[:, 0:1], hsv[:, 1:2], hsv[:, 2:3]
+    h = torch.fmod(h + factor_rad.view(-1, 1, 1, 1), TWO_PI)
+    return hsv_to_rgb(torch.cat([h, s, v], dim=1))
+
+
+def color_jitter(img, apply, sat, hue, sat_first: bool):
+    """kornia ColorJitter(hue=.1, saturation=.1): brightness/contrast factors are neutral (their code path
+    is a clamp to [0,1], an identity here); saturation and hue applied in the batch's random order."""
+    x = img
+    if sat_first:
+        x = adjust_hue(adjust_saturation(x, sat), hue * TWO_PI)
+    else:
+        x = adjust_saturation(adjust_hue(x, hue * TWO_PI), sat)
+    return torch.where(apply.view(-1, 1, 1, 1), x, img)
+
+
+# ---------------------------------------------------------------- MakeCutouts
+def pooled_image(img, S):
+    return (F.adaptive_avg_pool2d(img, (S, S)) + F.adaptive_max_pool2d(img, (S, S))) / 2
+
+
+def _persp_matrix(rand, dscale, S):
+    B = rand.shape[0]
+    start = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
+    start = start[None].expand(B, 4, 2)
+    fx = dscale * S / 2
+    pts_norm = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
+    end = start + fx * rand.double() * pts_norm[None]
+    return get_perspective_transform(start, end)
+
+
+def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+    """MakeCutouts.forward(img[1,3,H,W]) -> [cutn,3,S,S] with explicit randomness `prm`
+    (see pixray_amd.cutouts.sample_cutout_params for the fields)."""
+    cutn = int(prm["cutn"])
+    nz = int(0.6 * cutn)                                   # pixray.py:407
+    nw = cutn - nz
+    base = pooled_image(img, S)                            # pixray.py:463
+    pad_mode = "reflection" if int(prm["reflect"]) else "border"   # pixray.py:1250-1253
+    fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)   # pixray.py:1255-1258
+    outs = []
+    if nz > 0:
+        x = base.expand(nz, -1, -1, -1)
+        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, S)
+        warped = warp_perspective(x, Mp, (S, S), pad_mode, align_corners=False)
+        x = torch.where(prm["z_persp_apply"].view(-1, 1, 1, 1), warped, x)
+        xs, ys, w, h = [prm["z_crop"][:, i].double() for i in range(4)]
+        src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
+                           torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
+        dst = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
+        Mc = get_perspective_transform(src, dst[None].expand(nz, 4, 2))
+        x = warp_affine(x, Mc[:, :2, :], (S, S), "zeros", align_corners=False)
+        x = color_jitter(x, prm["z_jit_apply"], prm["z_sat"], prm["z_hue"], bool(prm["z_sat_first"]))
+        outs.append(x)
+    if nw > 0:
+        x = base.expand(nw, -1, -1, -1)
+        s = 0.95
+        c = S / 2.0 - 0.5
+        Ma = torch.zeros(nw, 2, 3, dtype=torch.float64)
+        Ma[:, 0, 0] = s
+        Ma[:, 1, 1] = s
+        Ma[:, 0, 2] = (1 - s) * c + prm["w_trans"][:, 0].double()
+        Ma[:, 1, 2] = (1 - s) * c + prm["w_trans"][:, 1].double()
+        x = warp_affine(x, Ma, (S, S), "fill", align_corners=False, fill_value=fill)
+        # CenterCrop(S) of an SxS image with align_corners=True is the identity resampling.
+        Mp = _persp_matrix(prm["w_persp_rand"], 0.2, S)
+        warped = warp_perspective(x, Mp, (S, S), "fill", align_corners=False, fill_value=fill)
+        x = torch.where(prm["w_persp_apply"].view(-1, 1, 1, 1), warped, x)
+        x = color_jitter(x, prm["w_jit_apply"], prm["w_sat"], prm["w_hue"], bool(prm["w_sat_first"]))
+        outs.append(x)
+    batch = torch.cat(outs, dim=0)
+    if "noise" in prm and prm["noise"] is not None:
+        batch = batch + prm["noise_fac"].view(-1, 1, 1, 1) * prm["noise"]   # pixray.py:508-510
+    return batch

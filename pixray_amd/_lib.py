@@ -112,6 +112,8 @@ def _ptr(x):
         return None
     if isinstance(x, int):
         return x
+    if isinstance(x, ctypes.c_void_p):
+        return x.value
     if hasattr(x, "data_ptr"):
         return x.data_ptr()
     if isinstance(x, (ctypes.Structure,)):

@@ -1,0 +1,105 @@
+// C-ABI path-level operators: what the Python plugin surface (pixray_amd/*.py) binds.
+#include "common.h"
+#include "vit.h"
+#include "vqgan.h"
+#include "cutouts.h"
+#include "prompt_vq.h"
+#include "elementwise.h"
+#include "../../include/prx.h"
+
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" {
+
+// ---- VQGAN drawer ---------------------------------------------------------------------------
+int prx_vqgan_create(prx_vqgan** out, const prx_vqgan_config* c, const float* const* weights, int n_weights,
+                     prx_stream_t s) {
+    PRX_REQUIRE(out && c && weights, "prx_vqgan_create: null argument");
+    PRX_REQUIRE(c->n_mult >= 1 && c->n_mult <= 8, "prx_vqgan_create: bad n_mult %d", c->n_mult);
+    return prx_vqgan_create_impl((PrxVqgan**)out, c->ch, c->ch_mult, c->n_mult, c->num_res_blocks, c->attn_resolution,
+                                 c->resolution, c->z_channels, c->embed_dim, c->n_embed, c->out_ch, c->latent_h,
+                                 c->latent_w, weights, n_weights, S_(s));
+}
+void prx_vqgan_destroy(prx_vqgan* h) { prx_vqgan_destroy_impl((PrxVqgan*)h); }
+int prx_vqgan_z_bounds(prx_vqgan* h, float* zmin, float* zmax, prx_stream_t s) {
+    PRX_REQUIRE(h, "null handle");
+    return prx_vqgan_bounds_impl((PrxVqgan*)h, zmin, zmax, S_(s));
+}
+int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int quantize, prx_stream_t s) {
+    PRX_REQUIRE(h && z && img, "prx_vqgan_synth: null argument");
+    return prx_vqgan_synth_impl((PrxVqgan*)h, z, img, indices, quantize, S_(s));
+}
+int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s) {
+    PRX_REQUIRE(h && g_img && dz, "prx_vqgan_synth_backward: null argument");
+    return prx_vqgan_backward_impl((PrxVqgan*)h, g_img, dz, S_(s));
+}
+
+// ---- MakeCutouts ------------------------------------------------------------------------------
+int prx_cutouts_forward(const float* img, int H, int W, const float* desc, const float* noise, int n_cut, int S,
+                        float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s) {
+    PRX_REQUIRE(img && desc && pooled && argmax && stage_a && out, "prx_cutouts_forward: null argument");
+    int r;
+    if ((r = prx_pool_fwd(img, pooled, argmax, 3, H, W, S, S_(s)))) return r;
+    if ((r = prx_warp_a_fwd(pooled, S, S, desc, stage_a, n_cut, S, S_(s)))) return r;
+    return prx_warp_b_fwd(stage_a, desc, noise, out, n_cut, S, S_(s));
+}
+int prx_cutouts_backward(const float* g_out, const float* desc, int n_cut, int S, int H, int W, const float* stage_a,
+                         const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s) {
+    PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_pooled && g_img, "prx_cutouts_backward: null argument");
+    int r;
+    if ((r = prx_warp_b_bwd(stage_a, desc, g_out, g_stage_a, n_cut, S, S_(s)))) return r;
+    if ((r = prx_warp_a_bwd(g_stage_a, S, S, desc, g_pooled, n_cut, S, 1, S_(s)))) return r;
+    return prx_pool_bwd(g_pooled, argmax, g_img, 3, H, W, S, S_(s));
+}
+
+// ---- CLIP visual tower ------------------------------------------------------------------------
+int prx_clip_vit_create(prx_clip_vit** out, const prx_clip_vit_config* c, const float* const* weights, int n_weights,
+                        prx_stream_t s) {
+    PRX_REQUIRE(out && c && weights, "prx_clip_vit_create: null argument");
+    return prx_vit_create_impl((PrxVit**)out, c->input_resolution, c->patch_size, c->width, c->layers, c->heads,
+                               c->output_dim, c->max_batch, weights, n_weights, S_(s));
+}
+void prx_clip_vit_destroy(prx_clip_vit* h) { prx_vit_destroy_impl((PrxVit*)h); }
+int prx_clip_vit_minmax(prx_clip_vit* h, const float* cutouts, int n, float* mm, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm, "prx_clip_vit_minmax: null argument");
+    return prx_vit_minmax_impl((PrxVit*)h, cutouts, n, mm, S_(s));
+}
+int prx_clip_vit_encode(prx_clip_vit* h, const float* cutouts, int n, const float* mm, float* embeds, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && embeds, "prx_clip_vit_encode: null argument");
+    return prx_vit_forward_impl((PrxVit*)h, cutouts, n, mm, embeds, S_(s));
+}
+int prx_clip_vit_backward_reduce(prx_clip_vit* h, const float* cutouts, const float* mm, const float* d_embeds,
+                                 double* acc, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && d_embeds && acc, "prx_clip_vit_backward_reduce: null argument");
+    return prx_vit_backward_a_impl((PrxVit*)h, cutouts, mm, d_embeds, acc, S_(s));
+}
+int prx_clip_vit_backward_finish(prx_clip_vit* h, const float* cutouts, const float* mm, const double* acc,
+                                 float* g_cutouts, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && acc && g_cutouts, "prx_clip_vit_backward_finish: null argument");
+    return prx_vit_backward_b_impl((PrxVit*)h, cutouts, mm, acc, g_cutouts, S_(s));
+}
+
+// ---- Prompt loss, optimiser -------------------------------------------------------------------
+int prx_prompt_loss_fwd_bwd(const float* input, const float* embed, int n, int m, int D, float weight, float stop,
+                            float denom, float* rowloss, float* grad, prx_stream_t s) {
+    PRX_REQUIRE(input && embed && rowloss && grad, "prx_prompt_loss_fwd_bwd: null argument");
+    return prx_prompt_loss(input, embed, n, m, D, weight, stop, denom, rowloss, grad, S_(s));
+}
+int prx_adam_clamp_step(float* z, float* exp_avg, float* exp_avg_sq, const float* grad, const float* zmin,
+                        const float* zmax, int hw, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                        prx_stream_t s) {
+    PRX_REQUIRE(z && exp_avg && exp_avg_sq && grad, "prx_adam_clamp_step: null argument");
+    return prx_adam_clamp(z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, n, lr, beta1, beta2, eps, step, S_(s));
+}
+
+// kernel-level entries for the pieces above (tests)
+int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook,
+                     const float* cnorm, int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq,
+                     prx_stream_t s) {
+    return prx_vq_nearest(z, tok_stride, ch_stride, codebook, cnorm, P, NC, D, pmin, pidx, idx_out, zq, S_(s));
+}
+int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t s) {
+    return prx_sqnorm_rows(w, out, rows, D, S_(s));
+}
+
+}  // extern "C"

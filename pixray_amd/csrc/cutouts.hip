@@ -1,0 +1,569 @@
+// MakeCutouts (pixray.py:400-511) as coalesced HBM gather kernels, forward and backward,
+// plus the batch-global min/max renorm + CLIP mean/std + patchify that
+// CLIP_Base.preprocess (slip.py:21-42,52-60) feeds to the visual tower.
+//
+//   pool      : (AdaptiveAvgPool2d + AdaptiveMaxPool2d)/2 of the synthesised image, computed ONCE
+//               (the reference recomputes it per cutout, pixray.py:461-463)
+//   stage A   : per-cutout bilinear warp of the pooled image (zoom: perspective with
+//               reflection/border padding; wide: affine with gray fill)
+//   stage B   : per-cutout bilinear warp of stage A (zoom: resized crop, zeros padding; wide:
+//               perspective with gray fill) fused with ColorJitter (HSV saturation/hue) and the
+//               additive noise.
+// Each geometric stage is described by a 3x3 matrix taking a destination pixel (x, y, 1) to the
+// source sampling position in F.grid_sample's unnormalised pixel coordinates; the host
+// (pixray_amd/cutouts.py) folds kornia's normalisation conventions into it.
+// Backward scatters with fp32 atomics (as the reference's grid_sampler_2d_backward does,
+// pixray.py:29); the ColorJitter Jacobian is obtained with forward-mode duals.
+#include "cutouts.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int DESC_WORDS = 32;
+// descriptor word offsets (all stored as fp32)
+enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
+       D_SATFIRST = 24, D_NOISE = 25 };
+enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4 };
+
+inline int ew_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 16384); }
+
+// ------------------------------------------------------------------ pooling
+__device__ __forceinline__ int win_start(int i, int in, int out) { return (int)(((long long)i * in) / out); }
+__device__ __forceinline__ int win_end(int i, int in, int out) { return (int)((((long long)(i + 1)) * in + out - 1) / out); }
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ img, float* __restrict__ pooled,
+                                                       int* __restrict__ argmax, int C, int H, int W, int S) {
+    const int total = C * S * S;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int x = idx % S, y = (idx / S) % S, c = idx / (S * S);
+        const int y0 = win_start(y, H, S), y1 = win_end(y, H, S);
+        const int x0 = win_start(x, W, S), x1 = win_end(x, W, S);
+        float sum = 0.f, mx = -INFINITY;
+        int am = y0 * W + x0;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+                float v = img[((size_t)c * H + yy) * W + xx];
+                sum += v;
+                if (v > mx || v != v) { mx = v; am = yy * W + xx; }   // first max wins (torch CPU scan order)
+            }
+        pooled[idx] = 0.5f * (sum / (float)((y1 - y0) * (x1 - x0)) + mx);
+        argmax[idx] = am;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const int* __restrict__ argmax,
+                                                       float* __restrict__ gimg, int C, int H, int W, int S) {
+    const int total = C * S * S;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int x = idx % S, y = (idx / S) % S, c = idx / (S * S);
+        const int y0 = win_start(y, H, S), y1 = win_end(y, H, S);
+        const int x0 = win_start(x, W, S), x1 = win_end(x, W, S);
+        const float gv = 0.5f * g[idx];
+        const float ga = gv / (float)((y1 - y0) * (x1 - x0));
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) atomicAdd(&gimg[((size_t)c * H + yy) * W + xx], ga);
+        atomicAdd(&gimg[(size_t)c * H * W + argmax[idx]], gv);
+    }
+}
+
+// ------------------------------------------------------------------ bilinear sampling
+struct Taps {
+    int x0, y0;          // north-west tap
+    float wx, wy;        // weight of the east / south taps
+    bool vx0, vx1, vy0, vy1;
+};
+
+__device__ __forceinline__ float reflect_coord(float in, float size) {
+    // F.grid_sample reflection, align_corners=False: reflect about [-0.5, size-0.5]
+    const float mn = -0.5f, span = size;
+    in = fabsf(in - mn);
+    float extra = fmodf(in, span);
+    int flips = (int)floorf(in / span);
+    return (flips & 1) ? (span - extra + mn) : (extra + mn);
+}
+
+__device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, int mode) {
+    if (mode == MODE_BORDER) {
+        u = fminf(fmaxf(u, 0.f), (float)(W - 1));
+        v = fminf(fmaxf(v, 0.f), (float)(H - 1));
+    } else if (mode == MODE_REFLECT) {
+        u = fminf(fmaxf(reflect_coord(u, (float)W), 0.f), (float)(W - 1));
+        v = fminf(fmaxf(reflect_coord(v, (float)H), 0.f), (float)(H - 1));
+    }
+    Taps t;
+    float fx = floorf(u), fy = floorf(v);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    t.wx = u - fx; t.wy = v - fy;
+    t.vx0 = t.x0 >= 0 && t.x0 < W;
+    t.vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    t.vy0 = t.y0 >= 0 && t.y0 < H;
+    t.vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    return t;
+}
+
+__device__ __forceinline__ bool project(const float* m, int x, int y, float& u, float& v) {
+    float X = m[0] * x + m[1] * y + m[2];
+    float Y = m[3] * x + m[4] * y + m[5];
+    float Z = m[6] * x + m[7] * y + m[8];
+    float iz = (fabsf(Z) > 1e-8f) ? 1.f / Z : 1.f;
+    u = X * iz; v = Y * iz;
+    return true;
+}
+
+// sample one channel plane; returns value and the coverage (sum of in-bounds weights)
+__device__ __forceinline__ float sample_plane(const float* __restrict__ p, int W, const Taps& t) {
+    float v00 = (t.vx0 && t.vy0) ? p[t.y0 * W + t.x0] : 0.f;
+    float v01 = (t.vx1 && t.vy0) ? p[t.y0 * W + t.x0 + 1] : 0.f;
+    float v10 = (t.vx0 && t.vy1) ? p[(t.y0 + 1) * W + t.x0] : 0.f;
+    float v11 = (t.vx1 && t.vy1) ? p[(t.y0 + 1) * W + t.x0 + 1] : 0.f;
+    return v00 * (1.f - t.wx) * (1.f - t.wy) + v01 * t.wx * (1.f - t.wy) + v10 * (1.f - t.wx) * t.wy + v11 * t.wx * t.wy;
+}
+__device__ __forceinline__ float coverage(const Taps& t) {
+    float c = 0.f;
+    if (t.vx0 && t.vy0) c += (1.f - t.wx) * (1.f - t.wy);
+    if (t.vx1 && t.vy0) c += t.wx * (1.f - t.wy);
+    if (t.vx0 && t.vy1) c += (1.f - t.wx) * t.wy;
+    if (t.vx1 && t.vy1) c += t.wx * t.wy;
+    return c;
+}
+__device__ __forceinline__ void scatter_plane(float* __restrict__ p, int W, const Taps& t, float g) {
+    if (t.vx0 && t.vy0) atomicAdd(&p[t.y0 * W + t.x0], g * (1.f - t.wx) * (1.f - t.wy));
+    if (t.vx1 && t.vy0) atomicAdd(&p[t.y0 * W + t.x0 + 1], g * t.wx * (1.f - t.wy));
+    if (t.vx0 && t.vy1) atomicAdd(&p[(t.y0 + 1) * W + t.x0], g * (1.f - t.wx) * t.wy);
+    if (t.vx1 && t.vy1) atomicAdd(&p[(t.y0 + 1) * W + t.x0 + 1], g * t.wx * t.wy);
+}
+
+// ------------------------------------------------------------------ ColorJitter (HSV) with duals
+template <int ND>
+struct Dual {
+    float v;
+    float d[ND > 0 ? ND : 1];
+};
+template <int ND> __device__ __forceinline__ Dual<ND> cst(float c) {
+    Dual<ND> r; r.v = c;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = 0.f;
+    return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND>& a, const Dual<ND>& b) {
+    Dual<ND> r; float ib = 1.f / b.v; r.v = a.v * ib;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+template <int ND> __device__ __forceinline__ Dual<ND> addc(const Dual<ND>& a, float c) { Dual<ND> r = a; r.v += c; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> mulc(const Dual<ND>& a, float c) {
+    Dual<ND> r; r.v = a.v * c;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * c;
+    return r;
+}
+
+constexpr float TWO_PI_F = 6.283185307179586f;
+
+template <int ND>
+__device__ __forceinline__ void rgb_to_hsv_d(const Dual<ND> (&rgb)[3], Dual<ND>& H, Dual<ND>& S, Dual<ND>& V) {
+    // kornia.color.rgb_to_hsv (eps 1e-8); first max / first min on ties (torch CPU reduction order)
+    int imax = 0; Dual<ND> mx = rgb[0];
+    if (rgb[1].v > mx.v) { mx = rgb[1]; imax = 1; }
+    if (rgb[2].v > mx.v) { mx = rgb[2]; imax = 2; }
+    Dual<ND> mn = rgb[0];
+    if (rgb[1].v < mn.v) mn = rgb[1];
+    if (rgb[2].v < mn.v) mn = rgb[2];
+    Dual<ND> delta = mx - mn;
+    V = mx;
+    S = delta / addc(mx, 1e-8f);
+    Dual<ND> dc = (delta.v == 0.f) ? cst<ND>(1.f) : delta;
+    Dual<ND> rc = mx - rgb[0], gc = mx - rgb[1], bc = mx - rgb[2];
+    Dual<ND> h;
+    if (imax == 0) h = (bc - gc) / dc;
+    else if (imax == 1) h = ((rc - bc) + mulc(dc, 2.f)) / dc;
+    else h = ((gc - rc) + mulc(dc, 4.f)) / dc;
+    h = mulc(h, 1.f / 6.f);
+    h = addc(h, -floorf(h.v));          // python-style % 1.0
+    H = mulc(h, TWO_PI_F);
+}
+
+template <int ND>
+__device__ __forceinline__ void hsv_to_rgb_d(const Dual<ND>& H, const Dual<ND>& S, const Dual<ND>& V, Dual<ND> (&rgb)[3]) {
+    Dual<ND> h6 = mulc(mulc(H, 1.f / TWO_PI_F), 6.f);
+    float fl = floorf(h6.v);
+    int hi = (int)fl % 6; if (hi < 0) hi += 6;
+    // f = ((h*6) % 6) - hi  with python-style %
+    float m6 = h6.v - 6.f * floorf(h6.v / 6.f);
+    Dual<ND> f = h6; f.v = m6 - (float)hi;
+    Dual<ND> one = cst<ND>(1.f);
+    Dual<ND> p = V * (one - S);
+    Dual<ND> q = V * (one - f * S);
+    Dual<ND> t = V * (one - (one - f) * S);
+    switch (hi) {
+        case 0: rgb[0] = V; rgb[1] = t; rgb[2] = p; break;
+        case 1: rgb[0] = q; rgb[1] = V; rgb[2] = p; break;
+        case 2: rgb[0] = p; rgb[1] = V; rgb[2] = t; break;
+        case 3: rgb[0] = p; rgb[1] = q; rgb[2] = V; break;
+        case 4: rgb[0] = t; rgb[1] = p; rgb[2] = V; break;
+        default: rgb[0] = V; rgb[1] = p; rgb[2] = q; break;
+    }
+}
+
+template <int ND>
+__device__ __forceinline__ void adjust_sat_d(Dual<ND> (&rgb)[3], float factor) {
+    Dual<ND> H, S, V;
+    rgb_to_hsv_d<ND>(rgb, H, S, V);
+    S = mulc(S, factor);
+    if (S.v < 0.f) S = cst<ND>(0.f); else if (S.v > 1.f) S = cst<ND>(1.f);
+    hsv_to_rgb_d<ND>(H, S, V, rgb);
+}
+template <int ND>
+__device__ __forceinline__ void adjust_hue_d(Dual<ND> (&rgb)[3], float shift_rad) {
+    Dual<ND> H, S, V;
+    rgb_to_hsv_d<ND>(rgb, H, S, V);
+    float hv = H.v + shift_rad;
+    H.v = fmodf(hv, TWO_PI_F);           // torch.fmod (C semantics)
+    hsv_to_rgb_d<ND>(H, S, V, rgb);
+}
+template <int ND>
+__device__ __forceinline__ void jitter_d(Dual<ND> (&rgb)[3], float sat, float hue_rad, bool sat_first) {
+    if (sat_first) { adjust_sat_d<ND>(rgb, sat); adjust_hue_d<ND>(rgb, hue_rad); }
+    else { adjust_hue_d<ND>(rgb, hue_rad); adjust_sat_d<ND>(rgb, sat); }
+}
+
+// ------------------------------------------------------------------ warp stages
+// Stage A: out[n][c][y][x] from the shared source src[c][Hs][Ws]
+__global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict__ src, int Hs, int Ws,
+                                                         const float* __restrict__ desc, float* __restrict__ out,
+                                                         int n_cut, int S) {
+    const size_t total = (size_t)n_cut * S * S;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
+        const float* d = desc + (size_t)n * DESC_WORDS;
+        const int mode = (int)d[D_MODE1];
+        float* o = out + ((size_t)n * 3) * S * S + (size_t)y * S + x;
+        if (mode == MODE_IDENT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[(size_t)c * S * S] = src[(size_t)c * Hs * Ws + (size_t)y * Ws + x];
+            continue;
+        }
+        float u, v;
+        project(d + D_M1, x, y, u, v);
+        Taps t = make_taps(u, v, Ws, Hs, mode);
+        const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[(size_t)c * S * S] = sample_plane(src + (size_t)c * Hs * Ws, Ws, t) + fillc;
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
+                                                         const float* __restrict__ desc, float* __restrict__ gsrc,
+                                                         int n_cut, int S) {
+    const size_t total = (size_t)n_cut * S * S;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
+        const float* d = desc + (size_t)n * DESC_WORDS;
+        const int mode = (int)d[D_MODE1];
+        const float* gi = g + ((size_t)n * 3) * S * S + (size_t)y * S + x;
+        if (mode == MODE_IDENT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&gsrc[(size_t)c * Hs * Ws + (size_t)y * Ws + x], gi[(size_t)c * S * S]);
+            continue;
+        }
+        float u, v;
+        project(d + D_M1, x, y, u, v);
+        Taps t = make_taps(u, v, Ws, Hs, mode);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) scatter_plane(gsrc + (size_t)c * Hs * Ws, Ws, t, gi[(size_t)c * S * S]);
+    }
+}
+
+// Stage B (+ ColorJitter + noise): out[n] from a[n] (per-cutout source, same S x S geometry)
+__global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, const float* __restrict__ desc,
+                                                         const float* __restrict__ noise, float* __restrict__ out,
+                                                         int n_cut, int S) {
+    const size_t total = (size_t)n_cut * S * S;
+    const size_t plane = (size_t)S * S;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
+        const float* d = desc + (size_t)n * DESC_WORDS;
+        const int mode = (int)d[D_MODE2];
+        const float* an = a + (size_t)n * 3 * plane;
+        const size_t pix = (size_t)y * S + x;
+        Dual<0> rgb[3];
+        if (mode == MODE_IDENT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c].v = an[c * plane + pix];
+        } else {
+            float u, v;
+            project(d + D_M2, x, y, u, v);
+            Taps t = make_taps(u, v, S, S, mode);
+            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c].v = sample_plane(an + c * plane, S, t) + fillc;
+        }
+        if (d[D_JIT] != 0.f) jitter_d<0>(rgb, d[D_SAT], d[D_HUE], d[D_SATFIRST] != 0.f);
+        const float nf = d[D_NOISE];
+        float* o = out + (size_t)n * 3 * plane + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = rgb[c].v;
+            if (noise) v += nf * noise[(size_t)n * 3 * plane + c * plane + pix];
+            o[c * plane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, const float* __restrict__ desc,
+                                                         const float* __restrict__ g, float* __restrict__ ga, int n_cut,
+                                                         int S) {
+    const size_t total = (size_t)n_cut * S * S;
+    const size_t plane = (size_t)S * S;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
+        const float* d = desc + (size_t)n * DESC_WORDS;
+        const int mode = (int)d[D_MODE2];
+        const float* an = a + (size_t)n * 3 * plane;
+        float* gan = ga + (size_t)n * 3 * plane;
+        const size_t pix = (size_t)y * S + x;
+        float gin[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gin[c] = g[(size_t)n * 3 * plane + c * plane + pix];
+        Taps t{};
+        float grgb[3] = {gin[0], gin[1], gin[2]};
+        const bool jit = d[D_JIT] != 0.f;
+        if (mode != MODE_IDENT) {
+            float u, v;
+            project(d + D_M2, x, y, u, v);
+            t = make_taps(u, v, S, S, mode);
+        }
+        if (jit) {
+            Dual<3> rgb[3];
+            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rgb[c] = cst<3>(mode == MODE_IDENT ? an[c * plane + pix] : sample_plane(an + c * plane, S, t) + fillc);
+                rgb[c].d[c] = 1.f;
+            }
+            jitter_d<3>(rgb, d[D_SAT], d[D_HUE], d[D_SATFIRST] != 0.f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) grgb[i] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
+        }
+        if (mode == MODE_IDENT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&gan[c * plane + pix], grgb[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) scatter_plane(gan + c * plane, S, t, grgb[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ batch min/max + CLIP normalise + patchify
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, size_t n,
+                                                             float* __restrict__ part) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = x[i];
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ float s[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s[w] = mn; s[4 + w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+        part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+    }
+}
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ part, int nparts,
+                                                           float* __restrict__ mm) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        mn = fminf(mn, part[2 * i]); mx = fmaxf(mx, part[2 * i + 1]);
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    __shared__ float s[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s[w] = mn; s[4 + w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[0] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+        mm[1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+    }
+}
+
+__constant__ float c_clip_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+__constant__ float c_clip_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+
+// A[(n*T + 1 + gy*G + gx)][c*P*P + py*P + px] = ((x - mn)/(mx - mn) - mean_c)/std_c ; row n*T is zero (class token)
+__global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
+                                                           bf16_t* __restrict__ A, int N, int S, int P, int T) {
+    const int G = S / P;
+    const int K = 3 * P * P;
+    const int K8 = K / 8;
+    const size_t total = (size_t)N * T * K8;
+    const float mn = mm[0];
+    const float range = mm[1] - mm[0];
+    const float inv = range != 0.f ? 1.f / range : 1.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k8 = (int)(idx % K8);
+        const size_t row = idx / K8;
+        const int tok = (int)(row % T), n = (int)(row / T);
+        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tok > 0) {
+            const int k = k8 * 8;
+            const int c = k / (P * P), py = (k / P) % P, px = k % P;
+            const int gy = (tok - 1) / G, gx = (tok - 1) % G;
+            const float* src = cut + (((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px;
+            const float im = c_clip_mean[c], is = 1.f / c_clip_std[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((((src[e] - mn) * inv) - im) * is);
+        }
+        reinterpret_cast<bf16x8*>(A)[idx] = r;
+    }
+}
+
+// Reduction for the min/max renorm backward: acc = {sum g_y, sum g_y*y, count(x==min), count(x==max)} (double)
+__global__ __launch_bounds__(256) void patchify_bwd_reduce_kernel(const float* __restrict__ cut,
+                                                                  const float* __restrict__ mm,
+                                                                  const float* __restrict__ dA, double* __restrict__ acc,
+                                                                  int N, int S, int P, int T) {
+    const int G = S / P;
+    const int K = 3 * P * P;
+    const size_t total = (size_t)N * 3 * S * S;
+    const float mn = mm[0], mx = mm[1];
+    const float range = mx - mn;
+    const float inv = range != 0.f ? 1.f / range : 1.f;
+    double s1 = 0, s2 = 0, cmin = 0, cmax = 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), c = (int)((idx / ((size_t)S * S)) % 3);
+        const int n = (int)(idx / ((size_t)3 * S * S));
+        const int tok = 1 + (y / P) * G + (x / P);
+        const int k = c * P * P + (y % P) * P + (x % P);
+        const float gy = dA[((size_t)n * T + tok) * K + k] / c_clip_std[c];
+        const float xv = cut[idx];
+        s1 += gy; s2 += gy * ((xv - mn) * inv);
+        cmin += (xv == mn); cmax += (xv == mx);
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cmin = wave_sum_d(cmin); cmax = wave_sum_d(cmax);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], s1); atomicAdd(&acc[1], s2); atomicAdd(&acc[2], cmin); atomicAdd(&acc[3], cmax);
+    }
+}
+
+// g_cut = g_y/range + [x==min]*gmin/cnt_min + [x==max]*gmax/cnt_max   (slip.py:21-36 backward)
+__global__ __launch_bounds__(256) void patchify_bwd_apply_kernel(const float* __restrict__ cut,
+                                                                 const float* __restrict__ mm,
+                                                                 const float* __restrict__ dA,
+                                                                 const double* __restrict__ acc, float* __restrict__ gcut,
+                                                                 int N, int S, int P, int T) {
+    const int G = S / P;
+    const int K = 3 * P * P;
+    const size_t total = (size_t)N * 3 * S * S;
+    const float mn = mm[0], mx = mm[1];
+    const float range = mx - mn;
+    const bool live = range != 0.f;
+    const float inv = live ? 1.f / range : 1.f;
+    const float gmin = live ? (float)((acc[1] - acc[0]) * inv / fmax(acc[2], 1.0)) : 0.f;
+    const float gmax = live ? (float)(-acc[1] * inv / fmax(acc[3], 1.0)) : 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S), y = (int)((idx / S) % S), c = (int)((idx / ((size_t)S * S)) % 3);
+        const int n = (int)(idx / ((size_t)3 * S * S));
+        const int tok = 1 + (y / P) * G + (x / P);
+        const int k = c * P * P + (y % P) * P + (x % P);
+        const float gy = dA[((size_t)n * T + tok) * K + k] / c_clip_std[c];
+        const float xv = cut[idx];
+        float g = gy * inv;
+        if (xv == mn) g += gmin;
+        if (xv == mx) g += gmax;
+        gcut[idx] = g;
+    }
+}
+
+}  // namespace
+
+int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s) {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, img, pooled, argmax, C, H, W, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * C * H * W, s));
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, g, argmax, gimg, C, H, W, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_warp_a_fwd(const float* src, int Hs, int Ws, const float* desc, float* out, int n_cut, int S, hipStream_t s) {
+    hipLaunchKernelGGL(warp_a_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, src, Hs, Ws, desc, out,
+                       n_cut, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const float* desc, float* gsrc, int n_cut, int S, int zero_first,
+                   hipStream_t s) {
+    if (zero_first) PRX_CHECK_HIP(hipMemsetAsync(gsrc, 0, sizeof(float) * 3 * Hs * Ws, s));
+    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, g, Hs, Ws, desc, gsrc,
+                       n_cut, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_warp_b_fwd(const float* a, const float* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s) {
+    hipLaunchKernelGGL(warp_b_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, noise, out,
+                       n_cut, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_warp_b_bwd(const float* a, const float* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * S * S, s));
+    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, g, ga, n_cut, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, s, x, n, part);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, s, part, nparts, mm);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S, int P, int T, hipStream_t s) {
+    PRX_REQUIRE(S % P == 0 && P % 8 == 0 && T == (S / P) * (S / P) + 1, "patchify: bad geometry S=%d P=%d T=%d", S, P, T);
+    hipLaunchKernelGGL(patchify_fwd_kernel, dim3(ew_grid((size_t)N * T * 3 * P * P / 8)), dim3(256), 0, s, cut, mm, A, N,
+                       S, P, T);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,
+                            hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
+    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 2048)), dim3(256), 0, s,
+                       cut, mm, dA, acc, N, S, P, T);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, const double* acc, float* gcut, int N,
+                           int S, int P, int T, hipStream_t s) {
+    hipLaunchKernelGGL(patchify_bwd_apply_kernel, dim3(ew_grid((size_t)N * 3 * S * S)), dim3(256), 0, s, cut, mm, dA, acc,
+                       gcut, N, S, P, T);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,235 @@
+// Prompt spherical-distance loss (pixray.py:268-280, ReplaceGrad 249-259) fused forward +
+// analytic backward, and the VQGAN nearest-codebook quantiser (vector_quantize, vqgan.py:60-64)
+// in exact fp32.
+#include "prompt_vq.h"
+#include <algorithm>
+
+namespace {
+
+// One wave per input row i.  rowloss[i] = sum_j sign(w) * 2*asin(|xn_i - en_j|/2)^2   (forward value, no stop)
+// grad[i][:] = d/dx_i of  |w| * mean_ij max(sign(w)*d_ij, stop)   with mean over `denom` pairs.
+__global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
+                                                          int n, int m, int D, float weight, float stop, float denom,
+                                                          float* __restrict__ rowloss, float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    constexpr int MAXE = 16;  // D <= 1024
+    const int ne = D / 64;
+    float xv[MAXE], gacc[MAXE];
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+        if (e < ne) { xv[e] = x[(size_t)i * D + e * 64 + lane]; ss += xv[e] * xv[e]; gacc[e] = 0.f; }
+    const float xnorm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);      // F.normalize eps
+    const float ixn = 1.f / xnorm;
+    const float sgn = (weight > 0.f) ? 1.f : ((weight < 0.f) ? -1.f : 0.f);
+    float loss = 0.f;
+    for (int j = 0; j < m; ++j) {
+        float ev[MAXE];
+        float es = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (e < ne) { ev[e] = embed[(size_t)j * D + e * 64 + lane]; es += ev[e] * ev[e]; }
+        const float ien = 1.f / fmaxf(sqrtf(wave_sum(es)), 1e-12f);
+        float r2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (e < ne) { float u = xv[e] * ixn - ev[e] * ien; r2 += u * u; }
+        const float r = sqrtf(wave_sum(r2));
+        const float a = asinf(fminf(r * 0.5f, 1.f));
+        const float d = 2.f * a * a * sgn;
+        loss += d;
+        // gradient of max(d, stop): 1 above, 1/2 on a tie, 0 below (torch.maximum)
+        float mask = (d > stop) ? 1.f : ((d == stop) ? 0.5f : 0.f);
+        // dd/dr = 2a / sqrt(1 - r^2/4);  dr/dxn = u / r
+        float coef = 0.f;
+        if (r > 1e-20f) coef = sgn * mask * (2.f * a / sqrtf(fmaxf(1.f - 0.25f * r * r, 1e-20f))) / r;
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e)
+            if (e < ne) gacc[e] += coef * (xv[e] * ixn - ev[e] * ien);
+    }
+    // through F.normalize: g_x = (g - xn (xn.g)) / |x|
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+        if (e < ne) dot += gacc[e] * xv[e] * ixn;
+    dot = wave_sum(dot);
+    const float sc = fabsf(weight) / denom;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+        if (e < ne) grad[(size_t)i * D + e * 64 + lane] = sc * (gacc[e] - xv[e] * ixn * dot) * ixn;
+    if (lane == 0) rowloss[i] = loss;
+}
+
+// e_hat = e/|e|  (slip.py:66) and its backward  de = (g - e_hat (e_hat.g))/|e|
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ e, float* __restrict__ out, int n, int D) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = e[(size_t)i * D + c]; ss += v * v; }
+    const float inv = 1.f / sqrtf(wave_sum(ss));
+    for (int c = lane; c < D; c += 64) out[(size_t)i * D + c] = e[(size_t)i * D + c] * inv;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ e, const float* __restrict__ g,
+                                                         float* __restrict__ de, int n, int D) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        float v = e[(size_t)i * D + c];
+        ss += v * v; dot += v * g[(size_t)i * D + c];
+    }
+    ss = wave_sum(ss); dot = wave_sum(dot);
+    const float inv = 1.f / sqrtf(ss);
+    for (int c = lane; c < D; c += 64) {
+        float v = e[(size_t)i * D + c];
+        de[(size_t)i * D + c] = (g[(size_t)i * D + c] - v * dot / ss) * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// VQ: d[p][c] = (|x_p|^2 + |c|^2) - 2 x_p.c ; argmin over c (first index on ties) ; z_q = codebook[idx]
+// Tokens are read from the NCHW z: x[p][k] = z[k*P + p].  fp32 FMA tiles: 64 tokens x 64 codes per block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = w[(size_t)i * D + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    if (lane == 0) out[i] = ss;
+}
+
+__global__ __launch_bounds__(256) void vq_dist_kernel(const float* __restrict__ z, long long tok_stride,
+                                                      long long ch_stride, const float* __restrict__ codebook,
+                                                      const float* __restrict__ cnorm, int P, int NC, int D,
+                                                      float* __restrict__ pmin, int* __restrict__ pidx) {
+    __shared__ float Xs[16][64 + 1];
+    __shared__ float Cs[16][64 + 1];
+    __shared__ float red_v[64][16];
+    __shared__ int red_i[64][16];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;   // tx: code quad, ty: token quad
+    const int p0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    float acc[4][4];
+    float xn[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 16) {
+        // load 64 tokens x 16 k and 64 codes x 16 k
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int e = tid + 256 * r;           // 0..1023
+            int kk = e >> 6, t = e & 63;     // tokens contiguous in NCHW (stride 1 along p)
+            int p = p0 + t;
+            Xs[kk][t] = (p < P) ? z[(long long)(k0 + kk) * ch_stride + (long long)p * tok_stride] : 0.f;
+            int cc = e >> 4, kc = e & 15;    // codebook row-major: k contiguous
+            int c = c0 + cc;
+            Cs[kc][cc] = (c < NC) ? codebook[(size_t)c * D + k0 + kc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float xa[4], cb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; cb[i] = Cs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xn[i] = fmaf(xa[i], xa[i], xn[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xa[i], cb[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = c0 + tx * 4 + j;
+            if (c < NC) {
+                float d = (xn[i] + cnorm[c]) - 2.f * acc[i][j];
+                if (d < best) { best = d; bi = c; }
+            }
+        }
+        red_v[ty * 4 + i][tx] = best;
+        red_i[ty * 4 + i][tx] = bi;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float best = red_v[tid][0]; int bi = red_i[tid][0];
+        for (int j = 1; j < 16; ++j)
+            if (red_v[tid][j] < best) { best = red_v[tid][j]; bi = red_i[tid][j]; }
+        int p = p0 + tid;
+        if (p < P) { pmin[(size_t)p * gridDim.x + blockIdx.x] = best; pidx[(size_t)p * gridDim.x + blockIdx.x] = bi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict__ pmin, const int* __restrict__ pidx,
+                                                        int ntiles, const float* __restrict__ codebook, int D,
+                                                        int* __restrict__ idx_out, float* __restrict__ zq, int P) {
+    const int p = blockIdx.x;
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        float v = pmin[(size_t)p * ntiles + t]; int id = pidx[(size_t)p * ntiles + t];
+        if (v < best || (v == best && id < bi)) { best = v; bi = id; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            float v = sv[threadIdx.x + o]; int id = si[threadIdx.x + o];
+            if (v < sv[threadIdx.x] || (v == sv[threadIdx.x] && id < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = id; }
+        }
+        __syncthreads();
+    }
+    const int sel = si[0];
+    if (threadIdx.x == 0 && idx_out) idx_out[p] = sel;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) zq[(size_t)p * D + c] = codebook[(size_t)sel * D + c];
+}
+
+}  // namespace
+
+int prx_prompt_loss(const float* x, const float* embed, int n, int m, int D, float weight, float stop, float denom,
+                    float* rowloss, float* grad, hipStream_t s) {
+    PRX_REQUIRE(D % 64 == 0 && D <= 1024, "prompt_loss: D must be a multiple of 64 and <= 1024 (D=%d)", D);
+    hipLaunchKernelGGL(prompt_loss_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, x, embed, n, m, D, weight, stop, denom,
+                       rowloss, grad);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_l2norm_fwd(const float* e, float* out, int n, int D, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, e, out, n, D);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_l2norm_bwd(const float* e, const float* g, float* de, int n, int D, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, e, g, de, n, D);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_sqnorm_rows(const float* w, float* out, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(sqnorm_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, out, rows, D);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook, const float* cnorm,
+                   int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq, hipStream_t s) {
+    PRX_REQUIRE(D % 16 == 0, "vq: D %% 16 != 0");
+    const int ntiles = ceil_div(NC, 64);
+    hipLaunchKernelGGL(vq_dist_kernel, dim3(ntiles, ceil_div(P, 64)), dim3(256), 0, s, z, tok_stride, ch_stride, codebook,
+                       cnorm, P, NC, D, pmin, pidx);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vq_select_kernel, dim3(P), dim3(256), 0, s, pmin, pidx, ntiles, codebook, D, idx_out, zq, P);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,265 @@
+// CLIP visual tower runner (clip.model.VisionTransformer [UPSTREAM openai/CLIP], as called by
+// CLIP_Base.encode_image, slip.py:62-66): forward and activation-gradient backward on the
+// bf16 MFMA engine.  Residual stream and LayerNorm statistics stay fp32; every GEMM operand
+// (LN outputs, qkv, attention output, MLP hidden) is bf16; weights are packed once to bf16 in
+// both orientations (forward Bt = W[out,in], dgrad Bt = W^T[in,out]) because they are frozen
+// (slip.py:176).
+#include "vit.h"
+#include "gemm.h"
+#include "norms.h"
+#include "attention.h"
+#include "cutouts.h"
+#include "prompt_vq.h"
+#include "elementwise.h"
+#include <vector>
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int R, int C) {
+    // out[c][r] = bf16(in[r][c])
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * R + r] = (bf16_t)tile[tx][ty + 8 * i];
+    }
+}
+
+__global__ __launch_bounds__(256) void add_cls_pos_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                          const float* __restrict__ pos, int N, int T, int W) {
+    const size_t total = (size_t)N * T * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const int t = (int)((i / W) % T);
+        float v = x[i] + pos[(size_t)t * W + c];
+        if (t == 0) v += cls[c];
+        x[i] = v;
+    }
+}
+
+}  // namespace
+
+int prx_pack_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { return prx_f32_to_bf16(in, out, n, s); }
+int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStream_t s) {
+    hipLaunchKernelGGL(pack_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, s, in, out, R, C);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+
+struct VitLayer {
+    float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *b1, *b2;
+    bf16_t *Wqkv, *WqkvT, *Wo, *WoT, *W1, *W1T, *W2, *W2T;
+    // saved activations
+    float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
+    bf16_t *qkv, *t;
+};
+
+struct PrxVit {
+    int res, patch, width, layers, heads, out_dim, T, max_n, KP;
+    std::vector<void*> allocs;
+    bf16_t *Wp, *WpT, *projT, *proj;
+    float *cls, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
+    std::vector<VitLayer> L;
+    // workspace
+    bf16_t *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv;
+    float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
+    float* ws; size_t ws_bytes;
+    int cur_n;
+};
+
+namespace {
+template <typename Tp>
+int dev_alloc(PrxVit* v, Tp** p, size_t count) {
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, count * sizeof(Tp)));
+    v->allocs.push_back(q);
+    *p = (Tp*)q;
+    return 0;
+}
+#define ALLOC(ptr, count) do { int _r = dev_alloc(v, &(ptr), (count)); if (_r) return _r; } while (0)
+
+int copy_f32(PrxVit* v, float** dst, const float* src, size_t n, hipStream_t s) {
+    ALLOC(*dst, n);
+    PRX_CHECK_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int pack_both(PrxVit* v, bf16_t** W, bf16_t** WT, const float* src, int out, int in, hipStream_t s) {
+    ALLOC(*W, (size_t)out * in);
+    ALLOC(*WT, (size_t)out * in);
+    int r = prx_pack_bf16(src, *W, (size_t)out * in, s);
+    if (r) return r;
+    return prx_pack_transpose_bf16(src, *WT, out, in, s);
+}
+}  // namespace
+
+int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers, int heads, int out_dim, int max_n,
+                        const float* const* w, int n_w, hipStream_t s) {
+    PRX_REQUIRE(n_w == 5 + 12 * layers + 3, "vit_create: expected %d weight tensors, got %d", 5 + 12 * layers + 3, n_w);
+    PRX_REQUIRE(res % patch == 0 && width == heads * 64 && width % 256 == 0, "vit_create: unsupported geometry");
+    const int G = res / patch;
+    const int T = G * G + 1;
+    PRX_REQUIRE(T <= 64, "vit_create: this build supports sequences of <= 64 tokens (T=%d)", T);
+    PrxVit* v = new PrxVit();
+    v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
+    v->T = T; v->max_n = max_n; v->KP = 3 * patch * patch; v->cur_n = 0;
+    const int W = width, KP = v->KP;
+    int r;
+    if ((r = pack_both(v, &v->Wp, &v->WpT, w[0], W, KP, s))) return r;
+    if ((r = copy_f32(v, &v->cls, w[1], W, s))) return r;
+    if ((r = copy_f32(v, &v->pos, w[2], (size_t)T * W, s))) return r;
+    if ((r = copy_f32(v, &v->lnpre_g, w[3], W, s))) return r;
+    if ((r = copy_f32(v, &v->lnpre_b, w[4], W, s))) return r;
+    v->L.resize(layers);
+    const size_t R = (size_t)max_n * T;
+    for (int l = 0; l < layers; ++l) {
+        const float* const* q = w + 5 + 12 * l;
+        VitLayer& y = v->L[l];
+        if ((r = copy_f32(v, &y.ln1_g, q[0], W, s))) return r;
+        if ((r = copy_f32(v, &y.ln1_b, q[1], W, s))) return r;
+        if ((r = pack_both(v, &y.Wqkv, &y.WqkvT, q[2], 3 * W, W, s))) return r;
+        if ((r = copy_f32(v, &y.bqkv, q[3], 3 * W, s))) return r;
+        if ((r = pack_both(v, &y.Wo, &y.WoT, q[4], W, W, s))) return r;
+        if ((r = copy_f32(v, &y.bo, q[5], W, s))) return r;
+        if ((r = copy_f32(v, &y.ln2_g, q[6], W, s))) return r;
+        if ((r = copy_f32(v, &y.ln2_b, q[7], W, s))) return r;
+        if ((r = pack_both(v, &y.W1, &y.W1T, q[8], 4 * W, W, s))) return r;
+        if ((r = copy_f32(v, &y.b1, q[9], 4 * W, s))) return r;
+        if ((r = pack_both(v, &y.W2, &y.W2T, q[10], W, 4 * W, s))) return r;
+        if ((r = copy_f32(v, &y.b2, q[11], W, s))) return r;
+        ALLOC(y.x_in, R * W); ALLOC(y.x_mid, R * W);
+        ALLOC(y.mean1, R); ALLOC(y.rstd1, R); ALLOC(y.mean2, R); ALLOC(y.rstd2, R);
+        ALLOC(y.qkv, R * 3 * W); ALLOC(y.t, R * 4 * W);
+    }
+    const float* const* q = w + 5 + 12 * layers;
+    if ((r = copy_f32(v, &v->lnpost_g, q[0], W, s))) return r;
+    if ((r = copy_f32(v, &v->lnpost_b, q[1], W, s))) return r;
+    // proj is [width, out]: forward Bt = proj^T [out, width]; dgrad Bt = proj [width, out]
+    if ((r = pack_both(v, &v->proj, &v->projT, q[2], W, out_dim, s))) return r;
+    ALLOC(v->A0, R * KP); ALLOC(v->h, R * W); ALLOC(v->att_o, R * W); ALLOC(v->u, R * 4 * W);
+    ALLOC(v->hpost, (size_t)max_n * W); ALLOC(v->dt, R * 4 * W); ALLOC(v->do_, R * W); ALLOC(v->dqkv, R * 3 * W);
+    ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R); ALLOC(v->x_final, R * W);
+    ALLOC(v->mean_post, max_n); ALLOC(v->rstd_post, max_n); ALLOC(v->e, (size_t)max_n * out_dim);
+    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
+    ALLOC(v->dhpost, (size_t)max_n * W); ALLOC(v->mm_part, 2 * 1024);
+    v->ws_bytes = (size_t)64 << 20;
+    ALLOC(v->ws, v->ws_bytes / sizeof(float));
+    *out = v;
+    return 0;
+}
+
+void prx_vit_destroy_impl(PrxVit* v) {
+    if (!v) return;
+    for (void* p : v->allocs) (void)hipFree(p);
+    delete v;
+}
+
+static int vit_gemm(PrxVit* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
+
+int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
+    PRX_REQUIRE(n >= 1 && n <= v->max_n, "vit: batch %d exceeds handle capacity %d", n, v->max_n);
+    return prx_minmax(cutouts, (size_t)n * 3 * v->res * v->res, v->mm_part, 1024, mm, s);
+}
+
+int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm, float* embeds, hipStream_t s) {
+    PRX_REQUIRE(n >= 1 && n <= v->max_n, "vit: batch %d exceeds handle capacity %d", n, v->max_n);
+    const int W = v->width, T = v->T, R = n * T, KP = v->KP;
+    int r;
+    v->cur_n = n;
+    if ((r = prx_patchify_fwd(cutouts, mm, v->A0, n, v->res, v->patch, T, s))) return r;
+    {   // conv1 (patch embed) as GEMM
+        GemmDesc d; d.A = v->A0; d.lda = KP; d.B = v->Wp; d.ldb = KP; d.M = R; d.N = W; d.K = KP;
+        d.out_f32 = v->xpre; d.ldc_f32 = W;
+        if ((r = vit_gemm(v, d, s))) return r;
+    }
+    hipLaunchKernelGGL(add_cls_pos_kernel, dim3(2048), dim3(256), 0, s, v->xpre, v->cls, v->pos, n, T, W);
+    PRX_LAUNCH_CHECK();
+    float* x0 = v->layers > 0 ? v->L[0].x_in : v->x_final;
+    if ((r = prx_layernorm_fwd(v->xpre, W, v->lnpre_g, v->lnpre_b, nullptr, x0, v->mean_pre, v->rstd_pre, R, W, 1e-5f, s))) return r;
+    for (int l = 0; l < v->layers; ++l) {
+        VitLayer& y = v->L[l];
+        float* x_next = (l + 1 < v->layers) ? v->L[l + 1].x_in : v->x_final;
+        if ((r = prx_layernorm_fwd(y.x_in, W, y.ln1_g, y.ln1_b, v->h, nullptr, y.mean1, y.rstd1, R, W, 1e-5f, s))) return r;
+        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.Wqkv; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W;
+            d.bias_n = y.bqkv; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        if ((r = prx_mha_fwd(y.qkv, v->att_o, n, T, W, v->heads, s))) return r;
+        {   GemmDesc d; d.A = v->att_o; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
+            d.bias_n = y.bo; d.resid = y.x_in; d.ldr = W; d.out_f32 = y.x_mid; d.ldc_f32 = W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        if ((r = prx_layernorm_fwd(y.x_mid, W, y.ln2_g, y.ln2_b, v->h, nullptr, y.mean2, y.rstd2, R, W, 1e-5f, s))) return r;
+        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
+            d.bias_n = y.b1; d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
+            d.bias_n = y.b2; d.resid = y.x_mid; d.ldr = W; d.out_f32 = x_next; d.ldc_f32 = W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+    }
+    // ln_post on the class token, projection, L2 normalisation (slip.py:66)
+    if ((r = prx_layernorm_fwd(v->x_final, (long long)T * W, v->lnpost_g, v->lnpost_b, v->hpost, nullptr, v->mean_post,
+                               v->rstd_post, n, W, 1e-5f, s))) return r;
+    {   GemmDesc d; d.A = v->hpost; d.lda = W; d.B = v->projT; d.ldb = W; d.M = n; d.N = v->out_dim; d.K = W;
+        d.out_f32 = v->e; d.ldc_f32 = v->out_dim;
+        if ((r = vit_gemm(v, d, s))) return r; }
+    return prx_l2norm_fwd(v->e, embeds, n, v->out_dim, s);
+}
+
+// Backward part A: from d(embeds) down to the patch-embed input gradient and the reduction the
+// batch-global min/max renorm needs (acc[4] doubles, to be summed over ranks when the cutout
+// batch is sharded).
+int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, const float* d_embeds, double* acc,
+                            hipStream_t s) {
+    const int n = v->cur_n;
+    PRX_REQUIRE(n >= 1, "vit backward: no forward in flight on this handle");
+    const int W = v->width, T = v->T, R = n * T, KP = v->KP;
+    int r;
+    if ((r = prx_l2norm_bwd(v->e, d_embeds, v->de, n, v->out_dim, s))) return r;
+    {   GemmDesc d; d.A = v->de; d.a_is_f32 = 1; d.lda = v->out_dim; d.B = v->proj; d.ldb = v->out_dim;
+        d.M = n; d.N = W; d.K = v->out_dim; d.out_f32 = v->dhpost; d.ldc_f32 = W;
+        if ((r = vit_gemm(v, d, s))) return r; }
+    PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
+    if ((r = prx_layernorm_bwd(v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
+                               nullptr, 0, v->dx, (long long)T * W, n, W, s))) return r;
+    for (int l = v->layers - 1; l >= 0; --l) {
+        VitLayer& y = v->L[l];
+        // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
+        {   GemmDesc d; d.A = v->dx; d.a_is_f32 = 1; d.lda = W; d.B = y.W2T; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
+            d.act = PRX_ACT_MUL_DQUICKGELU; d.aux = y.t; d.ldaux = 4 * W; d.out_bf16 = v->dt; d.ldc_bf16 = 4 * W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
+            d.out_f32 = v->dh; d.ldc_f32 = W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        if ((r = prx_layernorm_bwd(v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, R, W, s))) return r;
+        // attention: x_mid = x_in + out_proj(mha(ln_1(x_in)))
+        {   GemmDesc d; d.A = v->dx; d.a_is_f32 = 1; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
+            d.out_bf16 = v->do_; d.ldc_bf16 = W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        if ((r = prx_mha_bwd(y.qkv, v->do_, v->dqkv, n, T, W, v->heads, s))) return r;
+        {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
+            d.out_f32 = v->dh; d.ldc_f32 = W;
+            if ((r = vit_gemm(v, d, s))) return r; }
+        if ((r = prx_layernorm_bwd(v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, R, W, s))) return r;
+    }
+    // ln_pre backward (in place on dx), then patch-embed dgrad
+    if ((r = prx_layernorm_bwd(v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, R, W, s))) return r;
+    {   GemmDesc d; d.A = v->dh; d.a_is_f32 = 1; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
+        d.out_f32 = v->dA0; d.ldc_f32 = KP;
+        if ((r = vit_gemm(v, d, s))) return r; }
+    return prx_patchify_bwd_reduce(cutouts, mm, v->dA0, acc, n, v->res, v->patch, T, s);
+}
+
+int prx_vit_backward_b_impl(PrxVit* v, const float* cutouts, const float* mm, const double* acc, float* g_cutouts,
+                            hipStream_t s) {
+    const int n = v->cur_n;
+    PRX_REQUIRE(n >= 1, "vit backward: no forward in flight on this handle");
+    int r = prx_patchify_bwd_apply(cutouts, mm, v->dA0, acc, g_cutouts, n, v->res, v->patch, v->T, s);
+    return r;
+}

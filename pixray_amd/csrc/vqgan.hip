@@ -1,0 +1,431 @@
+// VqganDrawer.synth runner (vqgan.py:190-195): vector_quantize (straight-through) ->
+// taming VQModel.decode = post_quant_conv + Decoder [UPSTREAM taming-transformers,
+// taming/modules/diffusionmodules/model.py] -> (x+1)/2 -> ClampWithGrad, forward and
+// activation-gradient backward (weights frozen, vqgan.py:125).
+//
+// Data layout: every feature map is NHWC ([H*W, C] row-major = a GEMM A matrix), batch 1.  The
+// residual stream / conv outputs are fp32 (they are also the saved activations the GroupNorm
+// backward needs); GroupNorm+swish writes the bf16 GEMM operand; 3x3 convs (and the nearest-2x
+// upsample in front of them) run as implicit GEMMs on the MFMA engine, dgrad uses the
+// flipped/transposed weight pack.
+#include "vqgan.h"
+#include "gemm.h"
+#include "norms.h"
+#include "elementwise.h"
+#include "prompt_vq.h"
+#include "vit.h"  // prx_pack_* helpers
+#include <vector>
+#include <memory>
+
+namespace {
+
+// Wf[co][tap*Cin + ci] = w[co][ci][ky][kx]           (forward pack)
+// Wd[ci][tap*CoP + co] = w[co][ci][2-ky][2-kx]       (dgrad pack; co padded with zeros to CoP)
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ Wf,
+                                                           bf16_t* __restrict__ Wd, int Cout, int Cin, int CoP) {
+    const size_t total_f = (size_t)Cout * 9 * Cin;
+    const size_t total_d = (size_t)Cin * 9 * CoP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d;
+         i += (size_t)gridDim.x * blockDim.x) {
+        if (i < total_f) {
+            int ci = (int)(i % Cin);
+            int tap = (int)((i / Cin) % 9);
+            int co = (int)(i / ((size_t)9 * Cin));
+            Wf[i] = (bf16_t)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+        } else {
+            size_t j = i - total_f;
+            int co = (int)(j % CoP);
+            int tap = (int)((j / CoP) % 9);
+            int ci = (int)(j / ((size_t)9 * CoP));
+            int ky = 2 - tap / 3, kx = 2 - tap % 3;
+            Wd[j] = (co < Cout) ? (bf16_t)w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : (bf16_t)0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colminmax_kernel(const float* __restrict__ w, float* __restrict__ mn,
+                                                        float* __restrict__ mx, int rows, int D) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = INFINITY, b = -INFINITY;
+    for (int r = 0; r < rows; ++r) { float v = w[(size_t)r * D + c]; a = fminf(a, v); b = fmaxf(b, v); }
+    mn[c] = a; mx[c] = b;
+}
+
+}  // namespace
+
+struct Conv3 { int Cin, Cout, CoP; bf16_t *Wf, *Wd; float* b; };
+struct Conv1 { int Cin, Cout; bf16_t *W, *WT; float* b; };
+struct GN { int C; float *g, *b; double* stats; };
+
+struct ResBlock {
+    int Cin, Cout, res;
+    GN n1, n2; Conv3 c1, c2; Conv1 sc; bool has_sc;
+    float *x_in, *h1, *scbuf, *out;
+};
+struct AttnBlock {
+    int C, res;
+    GN n; Conv1 qkv, proj;   // qkv = [3C, C] concatenated q|k|v
+    float* x_in; bf16_t *qkvb, *Pm, *PT; float* out;
+};
+struct UpBlock { int C, res_out; Conv3 c; float *x_in, *out; };
+
+struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
+
+struct PrxVqgan {
+    int zc, D, NC, ch, out_ch, h0, w0, H, W, nstage;
+    std::vector<void*> allocs;
+    float *codebook, *cnorm, *zmin, *zmax;
+    Conv1 pq; Conv3 conv_in, conv_out; GN norm_out;
+    std::vector<ResBlock> res; std::vector<AttnBlock> attn; std::vector<UpBlock> ups; std::vector<Stage> stages;
+    // activations
+    float *zq, *pqo, *h_in, *y; int* idx;
+    float *pmin; int* pidx;
+    bf16_t* a;             // GN(+swish) operand, max size
+    bf16_t *tA, *tB, *tC, *tD, *dqkv, *dy8;  // attention temporaries [P*C max], dgrad head input
+    float *S, *g0, *g1, *g2; // score matrix; gradient ping-pong buffers (max P*C)
+    double* bstats;
+    float* ws; size_t ws_bytes;
+    float* x_last;  // input of norm_out
+};
+
+namespace {
+template <typename Tp>
+int dalloc(PrxVqgan* v, Tp** p, size_t count) {
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(Tp)));
+    v->allocs.push_back(q);
+    *p = (Tp*)q;
+    return 0;
+}
+#define VALLOC(ptr, count) do { int _r = dalloc(v, &(ptr), (count)); if (_r) return _r; } while (0)
+
+struct WCursor { const float* const* w; int n, pos; };
+#define NEXTW(cur, dst) do { PRX_REQUIRE((cur).pos < (cur).n, "vqgan_create: weight list too short"); (dst) = (cur).w[(cur).pos++]; } while (0)
+
+int copyf(PrxVqgan* v, float** dst, const float* src, size_t n, hipStream_t s) {
+    VALLOC(*dst, n);
+    PRX_CHECK_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int make_gn(PrxVqgan* v, GN& g, int C, WCursor& cur, hipStream_t s) {
+    const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
+    g.C = C;
+    int r;
+    if ((r = copyf(v, &g.g, w, C, s))) return r;
+    if ((r = copyf(v, &g.b, b, C, s))) return r;
+    VALLOC(g.stats, 64);
+    return 0;
+}
+int make_conv3(PrxVqgan* v, Conv3& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
+    const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
+    c.Cin = Cin; c.Cout = Cout; c.CoP = (Cout + 7) / 8 * 8;
+    VALLOC(c.Wf, (size_t)Cout * 9 * Cin);
+    VALLOC(c.Wd, (size_t)Cin * 9 * c.CoP);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(1024), dim3(256), 0, s, w, c.Wf, c.Wd, Cout, Cin, c.CoP);
+    PRX_LAUNCH_CHECK();
+    return copyf(v, &c.b, b, Cout, s);
+}
+int make_conv1(PrxVqgan* v, Conv1& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
+    const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
+    c.Cin = Cin; c.Cout = Cout;
+    VALLOC(c.W, (size_t)Cout * Cin); VALLOC(c.WT, (size_t)Cout * Cin);
+    int r;
+    if ((r = prx_pack_bf16(w, c.W, (size_t)Cout * Cin, s))) return r;
+    if ((r = prx_pack_transpose_bf16(w, c.WT, Cout, Cin, s))) return r;
+    return copyf(v, &c.b, b, Cout, s);
+}
+int make_res(PrxVqgan* v, int Cin, int Cout, int res, WCursor& cur, hipStream_t s) {
+    ResBlock rb{};
+    rb.Cin = Cin; rb.Cout = Cout; rb.res = res; rb.has_sc = Cin != Cout;
+    int r;
+    if ((r = make_gn(v, rb.n1, Cin, cur, s))) return r;
+    if ((r = make_conv3(v, rb.c1, Cin, Cout, cur, s))) return r;
+    if ((r = make_gn(v, rb.n2, Cout, cur, s))) return r;
+    if ((r = make_conv3(v, rb.c2, Cout, Cout, cur, s))) return r;
+    const size_t P = (size_t)res * res;
+    if (rb.has_sc) {
+        if ((r = make_conv1(v, rb.sc, Cin, Cout, cur, s))) return r;
+        VALLOC(rb.scbuf, P * Cout);
+    }
+    VALLOC(rb.h1, P * Cout); VALLOC(rb.out, P * Cout);
+    v->stages.push_back({0, (int)v->res.size()});
+    v->res.push_back(rb);
+    return 0;
+}
+int make_attn(PrxVqgan* v, int C, int res, WCursor& cur, hipStream_t s) {
+    AttnBlock ab{};
+    ab.C = C; ab.res = res;
+    int r;
+    if ((r = make_gn(v, ab.n, C, cur, s))) return r;
+    // q, k, v 1x1 convs are concatenated into one [3C, C] GEMM
+    const float *wq, *bq, *wk, *bk, *wv, *bv;
+    NEXTW(cur, wq); NEXTW(cur, bq); NEXTW(cur, wk); NEXTW(cur, bk); NEXTW(cur, wv); NEXTW(cur, bv);
+    float *wcat, *bcat;
+    VALLOC(wcat, (size_t)3 * C * C); VALLOC(bcat, 3 * C);
+    const float* ws_[3] = {wq, wk, wv}; const float* bs_[3] = {bq, bk, bv};
+    for (int i = 0; i < 3; ++i) {
+        PRX_CHECK_HIP(hipMemcpyAsync(wcat + (size_t)i * C * C, ws_[i], sizeof(float) * C * C, hipMemcpyDeviceToDevice, s));
+        PRX_CHECK_HIP(hipMemcpyAsync(bcat + i * C, bs_[i], sizeof(float) * C, hipMemcpyDeviceToDevice, s));
+    }
+    ab.qkv.Cin = C; ab.qkv.Cout = 3 * C; ab.qkv.b = bcat;
+    VALLOC(ab.qkv.W, (size_t)3 * C * C); VALLOC(ab.qkv.WT, (size_t)3 * C * C);
+    if ((r = prx_pack_bf16(wcat, ab.qkv.W, (size_t)3 * C * C, s))) return r;
+    if ((r = prx_pack_transpose_bf16(wcat, ab.qkv.WT, 3 * C, C, s))) return r;
+    if ((r = make_conv1(v, ab.proj, C, C, cur, s))) return r;
+    const size_t P = (size_t)res * res;
+    VALLOC(ab.qkvb, P * 3 * C); VALLOC(ab.Pm, P * P); VALLOC(ab.PT, P * P); VALLOC(ab.out, P * C);
+    v->stages.push_back({1, (int)v->attn.size()});
+    v->attn.push_back(ab);
+    return 0;
+}
+int make_up(PrxVqgan* v, int C, int res_out, WCursor& cur, hipStream_t s) {
+    UpBlock ub{};
+    ub.C = C; ub.res_out = res_out;
+    int r;
+    if ((r = make_conv3(v, ub.c, C, C, cur, s))) return r;
+    VALLOC(ub.out, (size_t)res_out * res_out * C);
+    v->stages.push_back({2, (int)v->ups.size()});
+    v->ups.push_back(ub);
+    return 0;
+}
+}  // namespace
+
+int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult, int num_res_blocks, int attn_res,
+                          int resolution, int z_channels, int embed_dim, int n_embed, int out_ch, int h0, int w0,
+                          const float* const* w, int n_w, hipStream_t s) {
+    PRX_REQUIRE(h0 == w0, "vqgan_create: only square latents are supported in this build (h0=%d w0=%d)", h0, w0);
+    PRX_REQUIRE(embed_dim == z_channels, "vqgan_create: embed_dim must equal z_channels");
+    PrxVqgan* v = new PrxVqgan();
+    std::unique_ptr<PrxVqgan> guard(v);
+    v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
+    WCursor cur{w, n_w, 0};
+    int r;
+    const float* cb; NEXTW(cur, cb);
+    if ((r = copyf(v, &v->codebook, cb, (size_t)n_embed * embed_dim, s))) return r;
+    VALLOC(v->cnorm, n_embed); VALLOC(v->zmin, embed_dim); VALLOC(v->zmax, embed_dim);
+    if ((r = prx_sqnorm_rows(v->codebook, v->cnorm, n_embed, embed_dim, s))) return r;
+    hipLaunchKernelGGL(colminmax_kernel, dim3(ceil_div(embed_dim, 256)), dim3(256), 0, s, v->codebook, v->zmin, v->zmax,
+                       n_embed, embed_dim);
+    PRX_LAUNCH_CHECK();
+    if ((r = make_conv1(v, v->pq, embed_dim, z_channels, cur, s))) return r;
+    int block_in = ch * ch_mult[n_mult - 1];
+    int res = h0;
+    if ((r = make_conv3(v, v->conv_in, z_channels, block_in, cur, s))) return r;
+    if ((r = make_res(v, block_in, block_in, res, cur, s))) return r;
+    if ((r = make_attn(v, block_in, res, cur, s))) return r;
+    if ((r = make_res(v, block_in, block_in, res, cur, s))) return r;
+    // taming decides AttnBlock placement from the config's NOMINAL resolution, not the actual latent size
+    int nominal = resolution >> (n_mult - 1);
+    for (int lvl = n_mult - 1; lvl >= 0; --lvl) {
+        int block_out = ch * ch_mult[lvl];
+        for (int b = 0; b < num_res_blocks + 1; ++b) {
+            if ((r = make_res(v, block_in, block_out, res, cur, s))) return r;
+            block_in = block_out;
+            if (nominal == attn_res) { if ((r = make_attn(v, block_in, res, cur, s))) return r; }
+        }
+        if (lvl != 0) {
+            res *= 2; nominal *= 2;
+            if ((r = make_up(v, block_in, res, cur, s))) return r;
+        }
+    }
+    v->H = res; v->W = res;
+    if ((r = make_gn(v, v->norm_out, block_in, cur, s))) return r;
+    if ((r = make_conv3(v, v->conv_out, block_in, out_ch, cur, s))) return r;
+    PRX_REQUIRE(cur.pos == n_w, "vqgan_create: %d weight tensors given, %d consumed", n_w, cur.pos);
+    // activations / scratch
+    const size_t P0 = (size_t)h0 * w0, PH = (size_t)res * res;
+    size_t maxPC = 0, maxAttnPC = 1;
+    for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.res * rb.res * std::max(rb.Cin, rb.Cout));
+    for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.res_out * ub.res_out * ub.C);
+    for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)ab.res * ab.res * (size_t)std::max(ab.C, ab.res * ab.res));
+    VALLOC(v->zq, P0 * embed_dim); VALLOC(v->pqo, P0 * z_channels);
+    VALLOC(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
+    VALLOC(v->y, PH * 4); VALLOC(v->idx, P0);
+    const int ntiles = ceil_div(n_embed, 64);
+    VALLOC(v->pmin, P0 * ntiles); VALLOC(v->pidx, P0 * ntiles);
+    VALLOC(v->a, maxPC);
+    VALLOC(v->tA, maxAttnPC); VALLOC(v->tB, maxAttnPC); VALLOC(v->tC, maxAttnPC); VALLOC(v->tD, maxAttnPC);
+    VALLOC(v->dqkv, maxAttnPC * 3); VALLOC(v->dy8, PH * 8);
+    VALLOC(v->S, maxAttnPC);
+    VALLOC(v->g0, maxPC); VALLOC(v->g1, maxPC); VALLOC(v->g2, maxPC);
+    VALLOC(v->bstats, 64);
+    v->ws_bytes = (size_t)64 << 20;
+    VALLOC(v->ws, v->ws_bytes / sizeof(float));
+    *out = guard.release();
+    return 0;
+}
+
+void prx_vqgan_destroy_impl(PrxVqgan* v) {
+    if (!v) return;
+    for (void* p : v->allocs) (void)hipFree(p);
+    delete v;
+}
+
+static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
+
+static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int res, bool up, const float* resid,
+                     float* out, int ldc, hipStream_t s) {
+    GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
+    d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = res * res; d.N = c.Cout; d.K = 9 * c.Cin;
+    d.H = res; d.W = res; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
+    d.out_f32 = out; d.ldc_f32 = ldc;
+    return vg(v, d, s);
+}
+// dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
+static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int res, float* dx, hipStream_t s) {
+    GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
+    d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = res * res; d.N = c.Cin; d.K = 9 * c.CoP;
+    d.H = res; d.W = res; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
+    return vg(v, d, s);
+}
+static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s) {
+    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s);
+}
+static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx, int P,
+                  int swish, hipStream_t s) {
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, v->bstats, add, dx, 1, P, g.C, swish, 1e-6f, s);
+}
+
+int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemcpyAsync(zmin, v->zmin, sizeof(float) * v->D, hipMemcpyDeviceToDevice, s));
+    PRX_CHECK_HIP(hipMemcpyAsync(zmax, v->zmax, sizeof(float) * v->D, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// z: NCHW [1, zc, h0, w0] fp32 -> img NCHW [1, out_ch, H, W] in [0,1]; indices (optional) int32 [h0*w0]
+int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, int quantize, hipStream_t s) {
+    const int P0 = v->h0 * v->w0;
+    int r;
+    if (quantize) {
+        if ((r = prx_vq_nearest(z, 1, P0, v->codebook, v->cnorm, P0, v->NC, v->D, v->pmin, v->pidx, v->idx, v->zq, s))) return r;
+        if (indices) PRX_CHECK_HIP(hipMemcpyAsync(indices, v->idx, sizeof(int) * P0, hipMemcpyDeviceToDevice, s));
+    } else {
+        if ((r = prx_nchw_to_nhwc(z, v->zq, nullptr, 1, v->zc, P0, v->zc, s))) return r;
+    }
+    {   GemmDesc d; d.A = v->zq; d.a_is_f32 = 1; d.lda = v->D; d.B = v->pq.W; d.ldb = v->D; d.M = P0; d.N = v->zc; d.K = v->D;
+        d.bias_n = v->pq.b; d.out_f32 = v->pqo; d.ldc_f32 = v->zc;
+        if ((r = vg(v, d, s))) return r; }
+    if ((r = conv3_fwd(v, v->conv_in, v->pqo, true, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s))) return r;
+    float* x = v->h_in;
+    for (auto& st : v->stages) {
+        if (st.kind == 0) {
+            ResBlock& b = v->res[st.idx];
+            const int P = b.res * b.res;
+            b.x_in = x;
+            if ((r = gn_fwd(v, b.n1, x, P, 1, s))) return r;
+            if ((r = conv3_fwd(v, b.c1, v->a, false, b.res, false, nullptr, b.h1, b.Cout, s))) return r;
+            const float* resid = x;
+            if (b.has_sc) {
+                GemmDesc d; d.A = x; d.a_is_f32 = 1; d.lda = b.Cin; d.B = b.sc.W; d.ldb = b.Cin; d.M = P; d.N = b.Cout; d.K = b.Cin;
+                d.bias_n = b.sc.b; d.out_f32 = b.scbuf; d.ldc_f32 = b.Cout;
+                if ((r = vg(v, d, s))) return r;
+                resid = b.scbuf;
+            }
+            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s))) return r;
+            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s))) return r;
+            x = b.out;
+        } else if (st.kind == 1) {
+            AttnBlock& b = v->attn[st.idx];
+            const int P = b.res * b.res, C = b.C;
+            b.x_in = x;
+            if ((r = gn_fwd(v, b.n, x, P, 0, s))) return r;
+            {   GemmDesc d; d.A = v->a; d.lda = C; d.B = b.qkv.W; d.ldb = C; d.M = P; d.N = 3 * C; d.K = C;
+                d.bias_n = b.qkv.b; d.out_bf16 = b.qkvb; d.ldc_bf16 = 3 * C;
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = prx_transpose_bf16(b.qkvb + 2 * C, 3 * C, v->tA, P, P, C, s))) return r;   // tA = v^T [C, P]
+            {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = b.qkvb + C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
+                d.out_f32 = v->S; d.ldc_f32 = P;
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P, b.PT, P, P, P, s))) return r;
+            {   GemmDesc d; d.A = b.Pm; d.lda = P; d.B = v->tA; d.ldb = P; d.M = P; d.N = C; d.K = P;
+                d.out_bf16 = v->tB; d.ldc_bf16 = C;
+                if ((r = vg(v, d, s))) return r; }
+            {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
+                d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
+                if ((r = vg(v, d, s))) return r; }
+            x = b.out;
+        } else {
+            UpBlock& b = v->ups[st.idx];
+            b.x_in = x;
+            if ((r = conv3_fwd(v, b.c, x, true, b.res_out, true, nullptr, b.out, b.C, s))) return r;
+            x = b.out;
+        }
+    }
+    v->x_last = x;
+    const int PH = v->H * v->W;
+    if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s))) return r;
+    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, false, nullptr, v->y, 4, s))) return r;
+    return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
+}
+
+// g_img: NCHW [1, out_ch, H, W] -> dz: NCHW [1, zc, h0, w0] (straight-through over the quantiser)
+int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStream_t s) {
+    const int PH = v->H * v->W;
+    int r;
+    PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
+    if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
+    float *g = v->g0, *t1 = v->g1, *t2 = v->g2;
+    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, t1, s))) return r;
+    if ((r = gn_bwd(v, v->norm_out, t1, v->x_last, nullptr, g, PH, 1, s))) return r;
+    for (int si = (int)v->stages.size() - 1; si >= 0; --si) {
+        const Stage& st = v->stages[si];
+        if (st.kind == 0) {
+            ResBlock& b = v->res[st.idx];
+            const int P = b.res * b.res;
+            if ((r = conv3_bwd(v, b.c2, g, true, b.res, t1, s))) return r;               // d a2
+            if ((r = gn_bwd(v, b.n2, t1, b.h1, nullptr, t2, P, 1, s))) return r;          // d h1
+            if ((r = conv3_bwd(v, b.c1, t2, true, b.res, t1, s))) return r;              // d a1
+            const float* add = g;
+            if (b.has_sc) {
+                GemmDesc d; d.A = g; d.a_is_f32 = 1; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
+                d.out_f32 = t2; d.ldc_f32 = b.Cin;
+                if ((r = vg(v, d, s))) return r;
+                add = t2;
+            }
+            // dx = GN1_bwd(d a1) + shortcut grad ; write into a buffer that is not `add` or `t1`
+            float* dst = (add == g) ? t2 : g;
+            if ((r = gn_bwd(v, b.n1, t1, b.x_in, add, dst, P, 1, s))) return r;
+            if (dst != g) std::swap(g, t2);
+        } else if (st.kind == 1) {
+            AttnBlock& b = v->attn[st.idx];
+            const int P = b.res * b.res, C = b.C;
+            {   GemmDesc d; d.A = g; d.a_is_f32 = 1; d.lda = C; d.B = b.proj.WT; d.ldb = C; d.M = P; d.N = C; d.K = C;
+                d.out_bf16 = v->tA; d.ldc_bf16 = C;                                      // tA = d o [P, C]
+                if ((r = vg(v, d, s))) return r; }
+            {   GemmDesc d; d.A = v->tA; d.lda = C; d.B = b.qkvb + 2 * C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
+                d.out_f32 = v->S; d.ldc_f32 = P;                                         // dP = do v^T
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = prx_softmax_rows_bwd(b.Pm, P, v->S, P, 1.f / sqrtf((float)C), v->tB, P, v->tC, P, P, P, s))) return r;  // tB = dS, tC = dS^T
+            if ((r = prx_transpose_bf16(b.qkvb + C, 3 * C, v->tD, P, P, C, s))) return r;        // tD = k^T [C, P]
+            {   GemmDesc d; d.A = v->tB; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+                d.out_bf16 = v->dqkv; d.ldc_bf16 = 3 * C;                               // dq = dS k
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = prx_transpose_bf16(b.qkvb, 3 * C, v->tD, P, P, C, s))) return r;            // tD = q^T
+            {   GemmDesc d; d.A = v->tC; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+                d.out_bf16 = v->dqkv + C; d.ldc_bf16 = 3 * C;                           // dk = dS^T q
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = prx_transpose_bf16(v->tA, C, v->tD, P, P, C, s))) return r;                 // tD = do^T
+            {   GemmDesc d; d.A = b.PT; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+                d.out_bf16 = v->dqkv + 2 * C; d.ldc_bf16 = 3 * C;                       // dv = P^T do
+                if ((r = vg(v, d, s))) return r; }
+            {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
+                d.out_f32 = t1; d.ldc_f32 = C;                                           // d GN(x)
+                if ((r = vg(v, d, s))) return r; }
+            if ((r = gn_bwd(v, b.n, t1, b.x_in, g, t2, P, 0, s))) return r;
+            std::swap(g, t2);
+        } else {
+            UpBlock& b = v->ups[st.idx];
+            if ((r = conv3_bwd(v, b.c, g, true, b.res_out, t1, s))) return r;            // d up(x) at high res
+            if ((r = prx_upsample2x_bwd(t1, t2, 1, b.res_out / 2, b.res_out / 2, b.C, s))) return r;
+            std::swap(g, t2);
+        }
+    }
+    // conv_in, post_quant_conv, straight-through VQ (ReplaceGrad, vqgan.py:48-58)
+    if ((r = conv3_bwd(v, v->conv_in, g, true, v->h0, t1, s))) return r;
+    const int P0 = v->h0 * v->w0;
+    {   GemmDesc d; d.A = t1; d.a_is_f32 = 1; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
+        d.out_f32 = t2; d.ldc_f32 = v->D;
+        if ((r = vg(v, d, s))) return r; }
+    return prx_nhwc_to_nchw(t2, v->D, dz, 1, v->D, P0, s);
+}

@@ -1,0 +1,203 @@
+"""MakeCutouts (reference: /root/reference/pixray.py:400-511) on the HIP cutout kernels.
+
+The reference draws its augmentation parameters inside kornia's parameter generators
+(kornia==0.6.2, un-vendored) from torch's global RNG.  Here the draws are made on the host
+from an explicit `torch.Generator` (`sample_cutout_params`), turned into per-cutout
+descriptors (`build_descriptors`: two 3x3 pixel-space sampling matrices + modes + colour
+jitter factors), uploaded, and consumed by one HIP kernel pipeline.  The same `params` dict
+is what the CPU oracle consumes, which is how parity is defined (SURVEY.md §7 "Parity
+definition").
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+DESC_WORDS = 32
+MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL = 0, 1, 2, 3, 4
+
+
+def _uniform(gen, shape, lo=0.0, hi=1.0):
+    return torch.rand(shape, generator=gen, dtype=torch.float64) * (hi - lo) + lo
+
+
+def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int = 0, noise_fac: float = 0.1,
+                         fill: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """Host-side mirror of the reference's per-iteration draws.
+
+    zoom set (first int(0.6*cutn), pixray.py:407): RandomPerspective(0.4, p=.7) corner offsets,
+    RandomResizedCrop(scale .25-.95, ratio .85-1.2) box (10 tries then whole image), ColorJitter(p=.8)
+    saturation U(.9,1.1) / hue U(-.1,.1) and the order of the two; wide set: RandomAffine
+    translate U(+-2.5%), RandomPerspective(0.2, p=.7), ColorJitter; per-cutout noise factor
+    U(0, noise_fac) (pixray.py:508-510); padding mode by iteration parity (1250-1253); gray fill
+    U(0,1) (1255-1258)."""
+    nz = int(0.6 * cutn)
+    nw = cutn - nz
+    p: Dict[str, torch.Tensor] = {"cutn": torch.tensor(cutn)}
+    p["reflect"] = torch.tensor(1 if iteration % 2 == 0 else 0)
+    p["fill"] = torch.tensor(float(_uniform(gen, ()).item()) if fill is None else float(fill), dtype=torch.float64)
+    # ---- zoom
+    p["z_persp_apply"] = _uniform(gen, (nz,)) < 0.7
+    p["z_persp_rand"] = _uniform(gen, (nz, 4, 2))
+    area = _uniform(gen, (nz, 10), 0.25, 0.95) * S * S
+    log_ratio = _uniform(gen, (nz, 10), math.log(0.85), math.log(1.2))
+    aspect = torch.exp(log_ratio)
+    w = torch.sqrt(area * aspect).round().floor()
+    h = torch.sqrt(area / aspect).round().floor()
+    ok = (w > 0) & (w < S) & (h > 0) & (h < S)
+    first = torch.where(ok.any(1), ok.float().argmax(1), torch.zeros(nz, dtype=torch.long))
+    ar = torch.arange(nz)
+    cw = torch.where(ok.any(1), w[ar, first], torch.full((nz,), float(S), dtype=torch.float64))
+    chh = torch.where(ok.any(1), h[ar, first], torch.full((nz,), float(S), dtype=torch.float64))
+    xs = (_uniform(gen, (nz,)) * (S - cw + 1)).floor()
+    ys = (_uniform(gen, (nz,)) * (S - chh + 1)).floor()
+    p["z_crop"] = torch.stack([xs, ys, cw, chh], dim=1)
+    p["z_jit_apply"] = _uniform(gen, (nz,)) < 0.8
+    p["z_sat"] = _uniform(gen, (nz,), 0.9, 1.1).float()
+    p["z_hue"] = _uniform(gen, (nz,), -0.1, 0.1).float()
+    p["z_sat_first"] = torch.tensor(bool(_uniform(gen, ()).item() < 0.5))
+    # ---- wide
+    p["w_trans"] = _uniform(gen, (nw, 2), -0.025 * S, 0.025 * S)
+    p["w_persp_apply"] = _uniform(gen, (nw,)) < 0.7
+    p["w_persp_rand"] = _uniform(gen, (nw, 4, 2))
+    p["w_jit_apply"] = _uniform(gen, (nw,)) < 0.8
+    p["w_sat"] = _uniform(gen, (nw,), 0.9, 1.1).float()
+    p["w_hue"] = _uniform(gen, (nw,), -0.1, 0.1).float()
+    p["w_sat_first"] = torch.tensor(bool(_uniform(gen, ()).item() < 0.5))
+    p["noise_fac"] = _uniform(gen, (cutn,), 0.0, noise_fac).float()
+    p["noise"] = None
+    return p
+
+
+def _dlt(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """4-point homography (float64) with M @ src ~ dst."""
+    B = src.shape[0]
+    A = torch.zeros(B, 8, 8, dtype=torch.float64)
+    b = torch.zeros(B, 8, dtype=torch.float64)
+    for i in range(4):
+        x, y, u, v = src[:, i, 0], src[:, i, 1], dst[:, i, 0], dst[:, i, 1]
+        A[:, 2 * i, 0], A[:, 2 * i, 1], A[:, 2 * i, 2] = x, y, 1.0
+        A[:, 2 * i, 6], A[:, 2 * i, 7] = -x * u, -y * u
+        A[:, 2 * i + 1, 3], A[:, 2 * i + 1, 4], A[:, 2 * i + 1, 5] = x, y, 1.0
+        A[:, 2 * i + 1, 6], A[:, 2 * i + 1, 7] = -x * v, -y * v
+        b[:, 2 * i], b[:, 2 * i + 1] = u, v
+    X = torch.linalg.solve(A, b.unsqueeze(-1)).squeeze(-1)
+    return torch.cat([X, torch.ones(B, 1, dtype=torch.float64)], dim=1).reshape(B, 3, 3)
+
+
+def _corners(S: int, B: int) -> torch.Tensor:
+    c = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
+    return c[None].repeat(B, 1, 1)
+
+
+def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+    """[cutn, 32] fp32 descriptor table for prx_cutouts_forward (layout: include/prx.h).
+
+    Each stage's matrix maps a destination pixel (x, y, 1) to the source sampling position in
+    F.grid_sample's align_corners=False pixel coordinates.  kornia 0.6.2 normalises homographies
+    with the [0, W-1] -> [-1, 1] convention while sampling with align_corners=False, so
+      warp_perspective: T = A . M^-1            A = [[W/(W-1), 0, -1/2], [0, H/(H-1), -1/2], [0, 0, 1]]
+      warp_affine     : T = A . M^-1 . B        B = [[(W-1)/W, 0, (W-1)/(2W)], [0, (H-1)/H, (H-1)/(2H)], [0, 0, 1]]
+    (M maps source pixels to destination pixels)."""
+    cutn = int(p["cutn"])
+    nz = int(0.6 * cutn)
+    nw = cutn - nz
+    f = S / (S - 1.0)
+    A = torch.tensor([[f, 0.0, -0.5], [0.0, f, -0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    Bm = torch.tensor([[1 / f, 0.0, 0.5 / f], [0.0, 1 / f, 0.5 / f], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    pts_norm = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
+    desc = torch.zeros(cutn, DESC_WORDS, dtype=torch.float64)
+    desc[:, 20] = float(p["fill"])
+    eye = torch.eye(3, dtype=torch.float64).reshape(9)
+    desc[:, 0:9] = eye
+    desc[:, 9:18] = eye
+    if nz > 0:
+        start = _corners(S, nz)
+        end = start + (0.4 * S / 2) * p["z_persp_rand"].double() * pts_norm[None]
+        T1 = A @ torch.linalg.inv(_dlt(start, end))
+        app = p["z_persp_apply"]
+        desc[:nz, 0:9] = torch.where(app[:, None], T1.reshape(nz, 9), eye[None])
+        pad = MODE_REFLECT if int(p["reflect"]) else MODE_BORDER
+        desc[:nz, 18] = torch.where(app, torch.tensor(float(pad), dtype=torch.float64),
+                                    torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        xs, ys, w, h = [p["z_crop"][:, i].double() for i in range(4)]
+        src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
+                           torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
+        Mc = _dlt(src, _corners(S, nz))
+        Mc[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)   # warp_affine drops the last row
+        desc[:nz, 9:18] = (A @ torch.linalg.inv(Mc) @ Bm).reshape(nz, 9)
+        desc[:nz, 19] = MODE_ZEROS
+        desc[:nz, 21] = p["z_jit_apply"].double()
+        desc[:nz, 22] = p["z_sat"].double()
+        desc[:nz, 23] = p["z_hue"].double() * (2.0 * math.pi)
+        desc[:nz, 24] = float(bool(p["z_sat_first"]))
+    if nw > 0:
+        s = 0.95
+        c = S / 2.0 - 0.5
+        Ma = torch.zeros(nw, 3, 3, dtype=torch.float64)
+        Ma[:, 0, 0] = s; Ma[:, 1, 1] = s; Ma[:, 2, 2] = 1.0
+        Ma[:, 0, 2] = (1 - s) * c + p["w_trans"][:, 0].double()
+        Ma[:, 1, 2] = (1 - s) * c + p["w_trans"][:, 1].double()
+        desc[nz:, 0:9] = (A @ torch.linalg.inv(Ma) @ Bm).reshape(nw, 9)
+        desc[nz:, 18] = MODE_FILL
+        start = _corners(S, nw)
+        end = start + (0.2 * S / 2) * p["w_persp_rand"].double() * pts_norm[None]
+        T2 = A @ torch.linalg.inv(_dlt(start, end))
+        app = p["w_persp_apply"]
+        desc[nz:, 9:18] = torch.where(app[:, None], T2.reshape(nw, 9), eye[None])
+        desc[nz:, 19] = torch.where(app, torch.tensor(float(MODE_FILL), dtype=torch.float64),
+                                    torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        desc[nz:, 21] = p["w_jit_apply"].double()
+        desc[nz:, 22] = p["w_sat"].double()
+        desc[nz:, 23] = p["w_hue"].double() * (2.0 * math.pi)
+        desc[nz:, 24] = float(bool(p["w_sat_first"]))
+    desc[:, 25] = p["noise_fac"].double()
+    return desc.float()
+
+
+class MakeCutouts(nn.Module):
+    """Drop-in for the reference's `MakeCutouts(cut_size, cutn, cut_pow=1.)` (pixray.py:400-511):
+    `forward(input[1,3,H,W]) -> [cutn,3,S,S]`, autograd-connected to `input`.
+
+    Extra (optional) knobs the reference keeps in module globals: `iteration` (padding-mode parity,
+    pixray.py:1250-1253), the RNG `generator`, and `shard=(lo, hi)` to produce only a slice of the
+    cutout batch (multi-GPU sharding).  `last_params` / `transforms` hold the draws of
+    the latest call (the reference's `.transforms` cache, pixray.py:480-498, is cleared the same way)."""
+
+    def __init__(self, cut_size, cutn, cut_pow=1., generator: Optional[torch.Generator] = None, noise_fac: float = 0.1):
+        super().__init__()
+        self.cut_size = cut_size
+        self.cutn = cutn
+        self.cutn_zoom = int(0.6 * cutn)
+        self.cut_pow = cut_pow
+        self.noise_fac = noise_fac
+        self.transforms = None
+        self.generator = generator if generator is not None else torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        self.iteration = 0
+        self.shard = None
+        self.last_params = None
+        self.fixed_params = None   # tests / parity: use these draws instead of sampling
+
+    def forward(self, input, spot=None):
+        if spot is not None:
+            raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
+        S = self.cut_size
+        prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
+            self.cutn, S, self.generator, self.iteration, self.noise_fac)
+        self.last_params = prm
+        desc = build_descriptors(prm, S)
+        lo, hi = (0, self.cutn) if self.shard is None else self.shard
+        desc_dev = desc[lo:hi].contiguous().to(input.device, non_blocking=True)
+        self.transforms = desc[:, 0:18]
+        noise = prm.get("noise")
+        if noise is None and self.noise_fac:
+            # device-side N(0,1) draws, as the reference's randn_like (pixray.py:510)
+            noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32)
+        elif noise is not None:
+            noise = noise[lo:hi].to(input.device, dtype=torch.float32).contiguous()
+        return ops.make_cutouts(input, desc_dev, noise, S)

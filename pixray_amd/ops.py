@@ -1,0 +1,269 @@
+"""torch.autograd.Function wrappers over the C ABI (include/prx.h).
+
+Every op here enqueues HIP kernels on torch's current stream and returns real torch tensors with
+a `grad_fn`, so unmodified reference plugins (`LossInterface.get_loss`, `FilterInterface.forward`,
+custom drawers) compose with them through ordinary autograd.  There is no CPU
+path: tensors must live on a ROCm device and the shared library must be built.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import PrxError, call
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise PrxError("pixray_amd ops run on an MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+def _weight_array(tensors: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise PrxError("weights must be contiguous fp32 device tensors")
+        arr[i] = t.data_ptr()
+    return arr
+
+
+# --------------------------------------------------------------------------------------- cutouts
+class _MakeCutoutsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, desc, noise, S):
+        _need_cuda(img, desc, noise)
+        assert img.dim() == 4 and img.shape[0] == 1 and img.shape[1] == 3, "MakeCutouts expects [1,3,H,W]"
+        img = img.contiguous().float()
+        n = desc.shape[0]
+        H, W = img.shape[2], img.shape[3]
+        dev = img.device
+        pooled = torch.empty(3, S, S, device=dev)
+        argmax = torch.empty(3, S, S, device=dev, dtype=torch.int32)
+        stage_a = torch.empty(n, 3, S, S, device=dev)
+        out = torch.empty(n, 3, S, S, device=dev)
+        call("prx_cutouts_forward", img, H, W, desc, noise, n, S, pooled, argmax, stage_a, out, _stream())
+        ctx.save_for_backward(desc, argmax, stage_a)
+        ctx.geom = (n, S, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        desc, argmax, stage_a = ctx.saved_tensors
+        n, S, H, W = ctx.geom
+        g = g.contiguous().float()
+        dev = g.device
+        g_a = torch.empty(n, 3, S, S, device=dev)
+        g_pooled = torch.empty(3, S, S, device=dev)
+        g_img = torch.empty(1, 3, H, W, device=dev)
+        call("prx_cutouts_backward", g, desc, n, S, H, W, stage_a, argmax, g_a, g_pooled, g_img, _stream())
+        return g_img, None, None, None
+
+
+def make_cutouts(img, desc, noise, S):
+    return _MakeCutoutsFn.apply(img, desc, noise, S)
+
+
+# --------------------------------------------------------------------------------------- CLIP ViT
+class ClipVitHandle:
+    """Owns a `prx_clip_vit` (packed bf16 weights + activation workspace for `max_batch` cutouts)."""
+
+    def __init__(self, cfg, params, max_batch: int, device):
+        from .weights import clip_vit_param_shapes
+        names = list(clip_vit_param_shapes(cfg).keys())
+        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        c = _ClipCfg(cfg.input_resolution, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch)
+        h = ctypes.c_void_p()
+        call("prx_clip_vit_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
+        torch.cuda.synchronize(device)   # weight tensors may now be released
+        self.h = h
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_clip_vit_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+def _keep(obj, arr):
+    obj._arr = arr   # keep the ctypes array alive for the duration of the call
+    return ctypes.addressof(arr)
+
+
+class _ClipCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("input_resolution", "patch_size", "width", "layers", "heads",
+                                            "output_dim", "max_batch")]
+
+
+class _VqganCfg(ctypes.Structure):
+    _fields_ = [("ch", ctypes.c_int), ("ch_mult", ctypes.c_int * 8), ("n_mult", ctypes.c_int),
+                ("num_res_blocks", ctypes.c_int), ("attn_resolution", ctypes.c_int), ("resolution", ctypes.c_int),
+                ("z_channels", ctypes.c_int), ("embed_dim", ctypes.c_int), ("n_embed", ctypes.c_int),
+                ("out_ch", ctypes.c_int), ("latent_h", ctypes.c_int), ("latent_w", ctypes.c_int)]
+
+
+class _ClipEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cutouts, handle, group):
+        _need_cuda(cutouts)
+        cutouts = cutouts.contiguous().float()
+        n = cutouts.shape[0]
+        R = handle.cfg.input_resolution
+        assert cutouts.shape[1:] == (3, R, R), f"perceptor expects [n,3,{R},{R}] cutouts"
+        dev = cutouts.device
+        mm = torch.empty(2, device=dev)
+        call("prx_clip_vit_minmax", handle.h, cutouts, n, mm, _stream())
+        if group is not None:
+            # batch-global renorm couples every cutout (slip.py:21-36): min/max over all ranks
+            import torch.distributed as dist
+            mm[0].neg_()
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+            mm[0].neg_()
+        emb = torch.empty(n, handle.cfg.output_dim, device=dev)
+        call("prx_clip_vit_encode", handle.h, cutouts, n, mm, emb, _stream())
+        ctx.save_for_backward(cutouts, mm)
+        ctx.handle = handle
+        ctx.group = group
+        return emb
+
+    @staticmethod
+    def backward(ctx, g):
+        cutouts, mm = ctx.saved_tensors
+        handle = ctx.handle
+        g = g.contiguous().float()
+        dev = g.device
+        acc = torch.empty(4, device=dev, dtype=torch.float64)
+        call("prx_clip_vit_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
+        if ctx.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=ctx.group)
+        gc = torch.empty_like(cutouts)
+        call("prx_clip_vit_backward_finish", handle.h, cutouts, mm, acc, gc, _stream())
+        return gc, None, None
+
+
+def clip_encode_image(cutouts, handle: ClipVitHandle, group=None):
+    return _ClipEncodeFn.apply(cutouts, handle, group)
+
+
+# --------------------------------------------------------------------------------------- VQGAN
+class VqganHandle:
+    def __init__(self, cfg, params, latent_hw, device):
+        from .weights import vqgan_param_shapes
+        names = list(vqgan_param_shapes(cfg).keys())
+        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        c = _VqganCfg()
+        c.ch = cfg.ch
+        for i, m in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = m
+        c.n_mult = len(cfg.ch_mult)
+        c.num_res_blocks = cfg.num_res_blocks
+        c.attn_resolution = cfg.attn_resolutions[0] if len(cfg.attn_resolutions) else -1
+        c.resolution = cfg.resolution
+        c.z_channels = cfg.z_channels
+        c.embed_dim = cfg.embed_dim
+        c.n_embed = cfg.n_embed
+        c.out_ch = cfg.out_ch
+        c.latent_h, c.latent_w = latent_hw
+        h = ctypes.c_void_p()
+        call("prx_vqgan_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
+        torch.cuda.synchronize(device)
+        self.h = h
+        self.cfg = cfg
+        self.latent_hw = tuple(latent_hw)
+        self.f = 2 ** (len(cfg.ch_mult) - 1)
+        self.device = device
+        self.last_indices = None
+
+    def z_bounds(self):
+        zmin = torch.empty(self.cfg.embed_dim, device=self.device)
+        zmax = torch.empty(self.cfg.embed_dim, device=self.device)
+        call("prx_vqgan_z_bounds", self.h, zmin, zmax, _stream())
+        return zmin, zmax
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_vqgan_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class _VqganSynthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, handle, quantize):
+        _need_cuda(z)
+        z = z.contiguous().float()
+        hh, ww = handle.latent_hw
+        assert z.shape == (1, handle.cfg.z_channels, hh, ww), f"z must be [1,{handle.cfg.z_channels},{hh},{ww}]"
+        dev = z.device
+        img = torch.empty(1, handle.cfg.out_ch, hh * handle.f, ww * handle.f, device=dev)
+        idx = torch.empty(hh * ww, device=dev, dtype=torch.int32)
+        call("prx_vqgan_synth", handle.h, z, img, idx, int(quantize), _stream())
+        handle.last_indices = idx
+        ctx.handle = handle
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        handle = ctx.handle
+        g = g.contiguous().float()
+        hh, ww = handle.latent_hw
+        dz = torch.empty(1, handle.cfg.z_channels, hh, ww, device=g.device)
+        call("prx_vqgan_synth_backward", handle.h, g, dz, _stream())
+        return dz, None, None
+
+
+def vqgan_synth(z, handle: VqganHandle, quantize: bool = True):
+    return _VqganSynthFn.apply(z, handle, quantize)
+
+
+# --------------------------------------------------------------------------------------- Prompt loss
+class _PromptLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, embed, weight, stop, denom):
+        _need_cuda(input, embed)
+        x = input.contiguous().float()
+        e = embed.contiguous().float()
+        n, D = x.shape
+        m = e.shape[0]
+        rowloss = torch.empty(n, device=x.device)
+        grad = torch.empty_like(x)
+        den = float(denom) if denom is not None else float(n * m)
+        call("prx_prompt_loss_fwd_bwd", x, e, n, m, D, float(weight), float(stop), den, rowloss, grad, _stream())
+        ctx.save_for_backward(grad)
+        return rowloss.sum() * (abs(float(weight)) / den)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def prompt_loss(input, embed, weight=1.0, stop=float("-inf"), denom=None):
+    return _PromptLossFn.apply(input, embed, weight, stop, denom)
+
+
+# --------------------------------------------------------------------------------------- optimiser
+def adam_clamp_step(z, exp_avg, exp_avg_sq, grad, zmin, zmax, lr, step, betas=(0.9, 0.999), eps=1e-8):
+    """In-place Adam step on z fused with the per-channel clip_z clamp."""
+    _need_cuda(z, grad)
+    assert z.is_contiguous() and grad.is_contiguous() and z.dtype == torch.float32
+    hw = z.shape[-1] * z.shape[-2]
+    call("prx_adam_clamp_step", z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, z.numel(), float(lr), float(betas[0]),
+         float(betas[1]), float(eps), int(step), _stream())

@@ -1,0 +1,190 @@
+"""Model configurations and parameter containers for the two frozen networks on the hot path.
+
+No checkpoints exist offline (SURVEY.md §7 "No weights, no network"), so `synthetic_*` build
+seeded random parameters with the REAL architectures' shapes (FLOPs and bytes identical to the
+reference's `imagenet_f16_16384` VQGAN, vqgan.py:86, and OpenAI CLIP ViT-B/32).  Parameter names
+and orders are the upstream state-dict ones, so a real checkpoint's state dict drops in
+(`decoder.*` / `post_quant_conv.*` / `quantize.embedding.weight`; `visual.*`).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import torch
+
+
+# --------------------------------------------------------------------------- VQGAN (taming) config
+@dataclass
+class VqganConfig:
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
+    num_res_blocks: int = 2
+    attn_resolutions: Tuple[int, ...] = (16,)
+    resolution: int = 256
+    z_channels: int = 256
+    embed_dim: int = 256
+    n_embed: int = 16384
+    out_ch: int = 3
+
+    @property
+    def num_resolutions(self) -> int:  # DrawingInterface.get_num_resolutions (vqgan.py:187-188)
+        return len(self.ch_mult)
+
+    def oracle_cfg(self) -> dict:
+        return dict(ch=self.ch, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks,
+                    attn_resolutions=self.attn_resolutions, resolution=self.resolution,
+                    z_channels=self.z_channels, out_ch=self.out_ch)
+
+
+VQGAN_CONFIGS = {
+    "imagenet_f16_16384": VqganConfig(),
+    # reduced graph with the same operator mix, for fast parity tests
+    "tiny_f4": VqganConfig(ch=128, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=64,
+                           z_channels=128, embed_dim=128, n_embed=512),
+}
+
+
+def vqgan_param_shapes(cfg: VqganConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered (name -> shape) list in the order the C ABI expects (include/prx.h, prx_vqgan_create)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        sh[name + ".weight"] = (cout, cin, k, k)
+        sh[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        sh[name + ".weight"] = (c,)
+        sh[name + ".bias"] = (c,)
+
+    def res(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cout, cin, 3)
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cout, cin, 1)
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for t in ("q", "k", "v", "proj_out"):
+            conv(name + "." + t, c, c, 1)
+
+    sh["quantize.embedding.weight"] = (cfg.n_embed, cfg.embed_dim)
+    conv("post_quant_conv", cfg.z_channels, cfg.embed_dim, 1)
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    curr_res = cfg.resolution // 2 ** (nres - 1)
+    conv("decoder.conv_in", block_in, cfg.z_channels, 3)
+    res("decoder.mid.block_1", block_in, block_in)
+    attn("decoder.mid.attn_1", block_in)
+    res("decoder.mid.block_2", block_in, block_in)
+    for lvl in reversed(range(nres)):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks + 1):
+            res(f"decoder.up.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+            if curr_res in cfg.attn_resolutions:
+                attn(f"decoder.up.{lvl}.attn.{b}", block_in)
+        if lvl != 0:
+            conv(f"decoder.up.{lvl}.upsample.conv", block_in, block_in, 3)
+            curr_res *= 2
+    norm("decoder.norm_out", block_in)
+    conv("decoder.conv_out", cfg.out_ch, block_in, 3)
+    return sh
+
+
+def synthetic_vqgan_params(cfg: VqganConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    g = torch.Generator().manual_seed(seed)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in vqgan_param_shapes(cfg).items():
+        if name == "quantize.embedding.weight":
+            t = torch.randn(shape, generator=g)
+        elif name.endswith(".weight") and len(shape) == 1:      # GroupNorm gamma
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias") and (".norm" in name or "norm_out" in name):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 1.0
+            if name.endswith("conv2.weight") or name.endswith("proj_out.weight"):
+                gain = 0.5       # residual branches: keep the stream O(1) through 20 blocks
+            if name.endswith("conv_out.weight"):
+                gain = 0.7
+            t = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+        out[name] = t
+    return out
+
+
+# --------------------------------------------------------------------------- CLIP ViT config
+@dataclass
+class ClipVitConfig:
+    name: str = "ViT-B/32"
+    input_resolution: int = 224
+    patch_size: int = 32
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    output_dim: int = 512
+
+    @property
+    def tokens(self) -> int:
+        return (self.input_resolution // self.patch_size) ** 2 + 1
+
+
+CLIP_CONFIGS = {
+    "ViT-B/32": ClipVitConfig(),
+    "ViT-B/16": ClipVitConfig("ViT-B/16", 224, 16, 768, 12, 12, 512),
+    "ViT-L/14": ClipVitConfig("ViT-L/14", 224, 14, 1024, 24, 16, 768),
+    # reduced tower (same operators, 2 layers) for fast parity tests
+    "tiny-B/32": ClipVitConfig("tiny-B/32", 224, 32, 256, 2, 4, 128),
+}
+
+
+def clip_vit_param_shapes(cfg: ClipVitConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    w = cfg.width
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    sh["conv1.weight"] = (w, 3, cfg.patch_size, cfg.patch_size)
+    sh["class_embedding"] = (w,)
+    sh["positional_embedding"] = (cfg.tokens, w)
+    sh["ln_pre.weight"] = (w,); sh["ln_pre.bias"] = (w,)
+    for i in range(cfg.layers):
+        p = f"transformer.resblocks.{i}."
+        sh[p + "ln_1.weight"] = (w,); sh[p + "ln_1.bias"] = (w,)
+        sh[p + "attn.in_proj_weight"] = (3 * w, w); sh[p + "attn.in_proj_bias"] = (3 * w,)
+        sh[p + "attn.out_proj.weight"] = (w, w); sh[p + "attn.out_proj.bias"] = (w,)
+        sh[p + "ln_2.weight"] = (w,); sh[p + "ln_2.bias"] = (w,)
+        sh[p + "mlp.c_fc.weight"] = (4 * w, w); sh[p + "mlp.c_fc.bias"] = (4 * w,)
+        sh[p + "mlp.c_proj.weight"] = (w, 4 * w); sh[p + "mlp.c_proj.bias"] = (w,)
+    sh["ln_post.weight"] = (w,); sh["ln_post.bias"] = (w,)
+    sh["proj"] = (w, cfg.output_dim)
+    return sh
+
+
+def synthetic_clip_vit_params(cfg: ClipVitConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """OpenAI's initialisation scheme (clip/model.py CLIP.initialize_parameters) with seeded draws."""
+    g = torch.Generator().manual_seed(seed)
+    w = cfg.width
+    proj_std = (w ** -0.5) * ((2 * cfg.layers) ** -0.5)
+    attn_std = w ** -0.5
+    fc_std = (2 * w) ** -0.5
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in clip_vit_param_shapes(cfg).items():
+        if name == "conv1.weight":
+            t = torch.randn(shape, generator=g) / math.sqrt(3 * cfg.patch_size ** 2)
+        elif name in ("class_embedding", "positional_embedding", "proj"):
+            t = torch.randn(shape, generator=g) * (w ** -0.5)
+        elif name.endswith("in_proj_weight"):
+            t = torch.randn(shape, generator=g) * attn_std
+        elif name.endswith("out_proj.weight") or name.endswith("c_proj.weight"):
+            t = torch.randn(shape, generator=g) * proj_std
+        elif name.endswith("c_fc.weight"):
+            t = torch.randn(shape, generator=g) * fc_std
+        elif name.endswith(".weight"):       # LayerNorm gamma
+            t = 1.0 + 0.05 * torch.randn(shape, generator=g)
+        else:                                # biases / LayerNorm beta
+            t = 0.02 * torch.randn(shape, generator=g)
+        out[name] = t
+    return out
