@@ -152,16 +152,18 @@ int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int 
 int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s);
 
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
- * desc: fp32 [n_cut][32] per-cutout descriptor (layout in pixray_amd/cutouts.py and csrc/cutouts.hip):
- *   [0..8] stage-A 3x3 (dst pixel -> source sampling position), [9..17] stage-B 3x3,
+ * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
+ *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination
+ *          coords -> normalised source coords, [0,W-1]->[-1,1] convention),
  *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill),
  *   [20] fill gray, [21] jitter on/off, [22] saturation factor, [23] hue shift (rad), [24] saturation-first,
- *   [25] noise factor.
+ *   [25] noise factor, [26]/[27] stage-A/B grid flavour (0 = create_meshgrid + transform_points as in
+ *   kornia warp_perspective, 1 = F.affine_grid as in kornia warp_affine).
  * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/stage_a are caller-owned save-for-backward
  * buffers ([3,S,S] f32, [3,S,S] i32, [n_cut,3,S,S] f32). */
-int prx_cutouts_forward(const float* img, int H, int W, const float* desc, const float* noise, int n_cut, int S,
+int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S,
                         float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s);
-int prx_cutouts_backward(const float* g_out, const float* desc, int n_cut, int S, int H, int W, const float* stage_a,
+int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int H, int W, const float* stage_a,
                          const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s);
 
 /* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].

@@ -35,7 +35,7 @@ int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_st
 }
 
 // ---- MakeCutouts ------------------------------------------------------------------------------
-int prx_cutouts_forward(const float* img, int H, int W, const float* desc, const float* noise, int n_cut, int S,
+int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S,
                         float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s) {
     PRX_REQUIRE(img && desc && pooled && argmax && stage_a && out, "prx_cutouts_forward: null argument");
     int r;
@@ -43,7 +43,7 @@ int prx_cutouts_forward(const float* img, int H, int W, const float* desc, const
     if ((r = prx_warp_a_fwd(pooled, S, S, desc, stage_a, n_cut, S, S_(s)))) return r;
     return prx_warp_b_fwd(stage_a, desc, noise, out, n_cut, S, S_(s));
 }
-int prx_cutouts_backward(const float* g_out, const float* desc, int n_cut, int S, int H, int W, const float* stage_a,
+int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int H, int W, const float* stage_a,
                          const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s) {
     PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_pooled && g_img, "prx_cutouts_backward: null argument");
     int r;

@@ -3,11 +3,11 @@
 #define PRX_CUT_DESC_WORDS 32
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s);
 int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s);
-int prx_warp_a_fwd(const float* src, int Hs, int Ws, const float* desc, float* out, int n_cut, int S, hipStream_t s);
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const float* desc, float* gsrc, int n_cut, int S, int zero_first,
+int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int S, hipStream_t s);
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc, int n_cut, int S, int zero_first,
                    hipStream_t s);
-int prx_warp_b_fwd(const float* a, const float* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s);
-int prx_warp_b_bwd(const float* a, const float* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s);
+int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s);
+int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s);
 int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hipStream_t s);
 int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S, int P, int T, hipStream_t s);
 int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,

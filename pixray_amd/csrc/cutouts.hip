@@ -20,9 +20,11 @@
 namespace {
 
 constexpr int DESC_WORDS = 32;
-// descriptor word offsets (all stored as fp32)
+// descriptor word offsets (all stored as fp64; the two 3x3 matrices map NORMALISED destination coordinates to
+// NORMALISED source coordinates exactly as kornia builds them, so sampling positions round like the oracle's)
 enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
-       D_SATFIRST = 24, D_NOISE = 25 };
+       D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27 };
+enum { GRID_MESH = 0, GRID_AFFINE = 1 };
 enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4 };
 
 inline int ew_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 16384); }
@@ -101,13 +103,35 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, int mo
     return t;
 }
 
-__device__ __forceinline__ bool project(const float* m, int x, int y, float& u, float& v) {
-    float X = m[0] * x + m[1] * y + m[2];
-    float Y = m[3] * x + m[4] * y + m[5];
-    float Z = m[6] * x + m[7] * y + m[8];
-    float iz = (fabsf(Z) > 1e-8f) ? 1.f / Z : 1.f;
-    u = X * iz; v = Y * iz;
-    return true;
+// torch.linspace(-1, 1, n) in fp32 (ATen's symmetric two-sided formula)
+__device__ __forceinline__ float linspace_pm1(int i, int n) {
+    const float step = 2.f / (float)(n - 1);
+    return (i < n / 2) ? (-1.f + step * (float)i) : (1.f - step * (float)(n - 1 - i));
+}
+
+// Source sampling position (F.grid_sample pixel coordinates, align_corners=False) of destination pixel
+// (x, y).  GRID_MESH: kornia create_meshgrid + transform_points (fp64) -> fp32 grid (warp_perspective);
+// GRID_AFFINE: F.affine_grid's fp32 base grid times the fp32 theta (warp_affine).  The fp32 grid value is
+// then unnormalised the way ATen does: (g + 1) * (size / 2) - 0.5.
+__device__ __forceinline__ void project(const double* m, int gtype, int x, int y, int Wd, int Hd, int Ws, int Hs,
+                                        float& u, float& v) {
+    float gx, gy;
+    if (gtype == GRID_MESH) {
+        const double xn = ((double)x / (double)(Wd - 1) - 0.5) * 2.0;
+        const double yn = ((double)y / (double)(Hd - 1) - 0.5) * 2.0;
+        const double X = m[0] * xn + m[1] * yn + m[2];
+        const double Y = m[3] * xn + m[4] * yn + m[5];
+        const double Z = m[6] * xn + m[7] * yn + m[8];
+        const double sc = (fabs(Z) > 1e-8) ? 1.0 / Z : 1.0;
+        gx = (float)(X * sc); gy = (float)(Y * sc);
+    } else {
+        const float xb = (linspace_pm1(x, Wd) * (float)(Wd - 1)) / (float)Wd;
+        const float yb = (linspace_pm1(y, Hd) * (float)(Hd - 1)) / (float)Hd;
+        gx = (float)((double)xb * m[0] + (double)yb * m[1] + m[2]);
+        gy = (float)((double)xb * m[3] + (double)yb * m[4] + m[5]);
+    }
+    u = (gx + 1.f) * ((float)Ws * 0.5f) - 0.5f;
+    v = (gy + 1.f) * ((float)Hs * 0.5f) - 0.5f;
 }
 
 // sample one channel plane; returns value and the coverage (sum of in-bounds weights)
@@ -164,12 +188,18 @@ template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& 
     return r;
 }
 template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND>& a, const Dual<ND>& b) {
-    Dual<ND> r; float ib = 1.f / b.v; r.v = a.v * ib;
+    Dual<ND> r; r.v = a.v / b.v;   // true (correctly rounded) division: mirrors torch's op sequence
 #pragma unroll
-    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
     return r;
 }
 template <int ND> __device__ __forceinline__ Dual<ND> addc(const Dual<ND>& a, float c) { Dual<ND> r = a; r.v += c; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> divc(const Dual<ND>& a, float c) {
+    Dual<ND> r; r.v = a.v / c;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] / c;
+    return r;
+}
 template <int ND> __device__ __forceinline__ Dual<ND> mulc(const Dual<ND>& a, float c) {
     Dual<ND> r; r.v = a.v * c;
 #pragma unroll
@@ -197,14 +227,14 @@ __device__ __forceinline__ void rgb_to_hsv_d(const Dual<ND> (&rgb)[3], Dual<ND>&
     if (imax == 0) h = (bc - gc) / dc;
     else if (imax == 1) h = ((rc - bc) + mulc(dc, 2.f)) / dc;
     else h = ((gc - rc) + mulc(dc, 4.f)) / dc;
-    h = mulc(h, 1.f / 6.f);
+    h = divc(h, 6.f);
     h = addc(h, -floorf(h.v));          // python-style % 1.0
     H = mulc(h, TWO_PI_F);
 }
 
 template <int ND>
 __device__ __forceinline__ void hsv_to_rgb_d(const Dual<ND>& H, const Dual<ND>& S, const Dual<ND>& V, Dual<ND> (&rgb)[3]) {
-    Dual<ND> h6 = mulc(mulc(H, 1.f / TWO_PI_F), 6.f);
+    Dual<ND> h6 = mulc(divc(H, TWO_PI_F), 6.f);
     float fl = floorf(h6.v);
     int hi = (int)fl % 6; if (hi < 0) hi += 6;
     // f = ((h*6) % 6) - hi  with python-style %
@@ -249,13 +279,13 @@ __device__ __forceinline__ void jitter_d(Dual<ND> (&rgb)[3], float sat, float hu
 // ------------------------------------------------------------------ warp stages
 // Stage A: out[n][c][y][x] from the shared source src[c][Hs][Ws]
 __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict__ src, int Hs, int Ws,
-                                                         const float* __restrict__ desc, float* __restrict__ out,
+                                                         const double* __restrict__ desc, float* __restrict__ out,
                                                          int n_cut, int S) {
     const size_t total = (size_t)n_cut * S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
-        const float* d = desc + (size_t)n * DESC_WORDS;
+        const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE1];
         float* o = out + ((size_t)n * 3) * S * S + (size_t)y * S + x;
         if (mode == MODE_IDENT) {
@@ -264,22 +294,22 @@ __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict
             continue;
         }
         float u, v;
-        project(d + D_M1, x, y, u, v);
+        project(d + D_M1, (int)d[D_GRID1], x, y, S, S, Ws, Hs, u, v);
         Taps t = make_taps(u, v, Ws, Hs, mode);
-        const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+        const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[(size_t)c * S * S] = sample_plane(src + (size_t)c * Hs * Ws, Ws, t) + fillc;
     }
 }
 
 __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
-                                                         const float* __restrict__ desc, float* __restrict__ gsrc,
+                                                         const double* __restrict__ desc, float* __restrict__ gsrc,
                                                          int n_cut, int S) {
     const size_t total = (size_t)n_cut * S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
-        const float* d = desc + (size_t)n * DESC_WORDS;
+        const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE1];
         const float* gi = g + ((size_t)n * 3) * S * S + (size_t)y * S + x;
         if (mode == MODE_IDENT) {
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
             continue;
         }
         float u, v;
-        project(d + D_M1, x, y, u, v);
+        project(d + D_M1, (int)d[D_GRID1], x, y, S, S, Ws, Hs, u, v);
         Taps t = make_taps(u, v, Ws, Hs, mode);
 #pragma unroll
         for (int c = 0; c < 3; ++c) scatter_plane(gsrc + (size_t)c * Hs * Ws, Ws, t, gi[(size_t)c * S * S]);
@@ -296,14 +326,14 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
 }
 
 // Stage B (+ ColorJitter + noise): out[n] from a[n] (per-cutout source, same S x S geometry)
-__global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, const float* __restrict__ desc,
+__global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, const double* __restrict__ desc,
                                                          const float* __restrict__ noise, float* __restrict__ out,
                                                          int n_cut, int S) {
     const size_t total = (size_t)n_cut * S * S;
     const size_t plane = (size_t)S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
-        const float* d = desc + (size_t)n * DESC_WORDS;
+        const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE2];
         const float* an = a + (size_t)n * 3 * plane;
         const size_t pix = (size_t)y * S + x;
@@ -313,14 +343,14 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
             for (int c = 0; c < 3; ++c) rgb[c].v = an[c * plane + pix];
         } else {
             float u, v;
-            project(d + D_M2, x, y, u, v);
+            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, S, S, u, v);
             Taps t = make_taps(u, v, S, S, mode);
-            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgb[c].v = sample_plane(an + c * plane, S, t) + fillc;
         }
-        if (d[D_JIT] != 0.f) jitter_d<0>(rgb, d[D_SAT], d[D_HUE], d[D_SATFIRST] != 0.f);
-        const float nf = d[D_NOISE];
+        if (d[D_JIT] != 0.0) jitter_d<0>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
+        const float nf = (float)d[D_NOISE];
         float* o = out + (size_t)n * 3 * plane + pix;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -331,14 +361,14 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, const float* __restrict__ desc,
+__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, const double* __restrict__ desc,
                                                          const float* __restrict__ g, float* __restrict__ ga, int n_cut,
                                                          int S) {
     const size_t total = (size_t)n_cut * S * S;
     const size_t plane = (size_t)S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
-        const float* d = desc + (size_t)n * DESC_WORDS;
+        const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE2];
         const float* an = a + (size_t)n * 3 * plane;
         float* gan = ga + (size_t)n * 3 * plane;
@@ -348,21 +378,21 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict
         for (int c = 0; c < 3; ++c) gin[c] = g[(size_t)n * 3 * plane + c * plane + pix];
         Taps t{};
         float grgb[3] = {gin[0], gin[1], gin[2]};
-        const bool jit = d[D_JIT] != 0.f;
+        const bool jit = d[D_JIT] != 0.0;
         if (mode != MODE_IDENT) {
             float u, v;
-            project(d + D_M2, x, y, u, v);
+            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, S, S, u, v);
             t = make_taps(u, v, S, S, mode);
         }
         if (jit) {
             Dual<3> rgb[3];
-            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * d[D_FILL] : 0.f;
+            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 rgb[c] = cst<3>(mode == MODE_IDENT ? an[c * plane + pix] : sample_plane(an + c * plane, S, t) + fillc);
                 rgb[c].d[c] = 1.f;
             }
-            jitter_d<3>(rgb, d[D_SAT], d[D_HUE], d[D_SATFIRST] != 0.f);
+            jitter_d<3>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
 #pragma unroll
             for (int i = 0; i < 3; ++i) grgb[i] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
         }
@@ -512,13 +542,13 @@ int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, i
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_fwd(const float* src, int Hs, int Ws, const float* desc, float* out, int n_cut, int S, hipStream_t s) {
+int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int S, hipStream_t s) {
     hipLaunchKernelGGL(warp_a_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, src, Hs, Ws, desc, out,
                        n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const float* desc, float* gsrc, int n_cut, int S, int zero_first,
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc, int n_cut, int S, int zero_first,
                    hipStream_t s) {
     if (zero_first) PRX_CHECK_HIP(hipMemsetAsync(gsrc, 0, sizeof(float) * 3 * Hs * Ws, s));
     hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, g, Hs, Ws, desc, gsrc,
@@ -526,13 +556,13 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const float* desc, float* gsr
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_fwd(const float* a, const float* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s) {
+int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s) {
     hipLaunchKernelGGL(warp_b_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, noise, out,
                        n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_bwd(const float* a, const float* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
+int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * S * S, s));
     hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, g, ga, n_cut, S);
     PRX_LAUNCH_CHECK();

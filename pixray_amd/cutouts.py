@@ -20,6 +20,7 @@ from . import ops
 
 DESC_WORDS = 32
 MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL = 0, 1, 2, 3, 4
+GRID_MESH, GRID_AFFINE = 0, 1
 
 
 def _uniform(gen, shape, lo=0.0, hi=1.0):
@@ -95,46 +96,62 @@ def _corners(S: int, B: int) -> torch.Tensor:
     return c[None].repeat(B, 1, 1)
 
 
-def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
-    """[cutn, 32] fp32 descriptor table for prx_cutouts_forward (layout: include/prx.h).
+def _nk(S: int) -> torch.Tensor:
+    """kornia normal_transform_pixel: pixel [0, S-1] -> [-1, 1]"""
+    return torch.tensor([[2.0 / (S - 1), 0.0, -1.0], [0.0, 2.0 / (S - 1), -1.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
 
-    Each stage's matrix maps a destination pixel (x, y, 1) to the source sampling position in
-    F.grid_sample's align_corners=False pixel coordinates.  kornia 0.6.2 normalises homographies
-    with the [0, W-1] -> [-1, 1] convention while sampling with align_corners=False, so
-      warp_perspective: T = A . M^-1            A = [[W/(W-1), 0, -1/2], [0, H/(H-1), -1/2], [0, 0, 1]]
-      warp_affine     : T = A . M^-1 . B        B = [[(W-1)/W, 0, (W-1)/(2W)], [0, (H-1)/H, (H-1)/(2H)], [0, 0, 1]]
-    (M maps source pixels to destination pixels)."""
+
+def _src_norm_from_dst_norm(M: torch.Tensor, S: int) -> torch.Tensor:
+    """inverse of kornia normalize_homography(M): maps normalised destination coords to normalised source coords"""
+    nk = _nk(S)
+    return torch.linalg.inv(nk @ (M @ torch.linalg.inv(nk)))
+
+
+def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+    """[cutn, 32] fp64 descriptor table for prx_cutouts_forward (layout: include/prx.h).
+
+    Each stage carries kornia's `src_norm_trans_dst_norm` 3x3 (the inverse of normalize_homography(M) with
+    the [0, W-1] -> [-1, 1] convention) plus the grid flavour that produced the sampling grid in kornia 0.6.2:
+      GRID_MESH   (warp_perspective): create_meshgrid(normalized) + transform_points, then F.grid_sample
+      GRID_AFFINE (warp_affine)     : F.affine_grid(theta = first two rows, rounded to fp32), then F.grid_sample
+    both sampled with align_corners=False (the augmentation flag the reference passes, pixray.py:333-334,349,363).
+    The kernel evaluates the grid with the same precision steps, so tap positions round like the oracle's."""
     cutn = int(p["cutn"])
     nz = int(0.6 * cutn)
     nw = cutn - nz
-    f = S / (S - 1.0)
-    A = torch.tensor([[f, 0.0, -0.5], [0.0, f, -0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    Bm = torch.tensor([[1 / f, 0.0, 0.5 / f], [0.0, 1 / f, 0.5 / f], [0.0, 0.0, 1.0]], dtype=torch.float64)
     pts_norm = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
     desc = torch.zeros(cutn, DESC_WORDS, dtype=torch.float64)
     desc[:, 20] = float(p["fill"])
     eye = torch.eye(3, dtype=torch.float64).reshape(9)
     desc[:, 0:9] = eye
     desc[:, 9:18] = eye
+
+    def affine_theta(M):
+        t = _src_norm_from_dst_norm(M, S)
+        t[:, :2, :] = t[:, :2, :].float().double()       # F.affine_grid receives theta in fp32
+        t[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+        return t.reshape(-1, 9)
+
     if nz > 0:
         start = _corners(S, nz)
         end = start + (0.4 * S / 2) * p["z_persp_rand"].double() * pts_norm[None]
-        T1 = A @ torch.linalg.inv(_dlt(start, end))
         app = p["z_persp_apply"]
-        desc[:nz, 0:9] = torch.where(app[:, None], T1.reshape(nz, 9), eye[None])
+        desc[:nz, 0:9] = torch.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nz, 9), eye[None])
         pad = MODE_REFLECT if int(p["reflect"]) else MODE_BORDER
         desc[:nz, 18] = torch.where(app, torch.tensor(float(pad), dtype=torch.float64),
                                     torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        desc[:nz, 26] = GRID_MESH
         xs, ys, w, h = [p["z_crop"][:, i].double() for i in range(4)]
         src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
                            torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
         Mc = _dlt(src, _corners(S, nz))
         Mc[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)   # warp_affine drops the last row
-        desc[:nz, 9:18] = (A @ torch.linalg.inv(Mc) @ Bm).reshape(nz, 9)
+        desc[:nz, 9:18] = affine_theta(Mc)
         desc[:nz, 19] = MODE_ZEROS
+        desc[:nz, 27] = GRID_AFFINE
         desc[:nz, 21] = p["z_jit_apply"].double()
         desc[:nz, 22] = p["z_sat"].double()
-        desc[:nz, 23] = p["z_hue"].double() * (2.0 * math.pi)
+        desc[:nz, 23] = (p["z_hue"].float() * (2.0 * math.pi)).double()      # kornia: hue_factor * 2*pi in fp32
         desc[:nz, 24] = float(bool(p["z_sat_first"]))
     if nw > 0:
         s = 0.95
@@ -143,21 +160,22 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         Ma[:, 0, 0] = s; Ma[:, 1, 1] = s; Ma[:, 2, 2] = 1.0
         Ma[:, 0, 2] = (1 - s) * c + p["w_trans"][:, 0].double()
         Ma[:, 1, 2] = (1 - s) * c + p["w_trans"][:, 1].double()
-        desc[nz:, 0:9] = (A @ torch.linalg.inv(Ma) @ Bm).reshape(nw, 9)
+        desc[nz:, 0:9] = affine_theta(Ma)
         desc[nz:, 18] = MODE_FILL
+        desc[nz:, 26] = GRID_AFFINE
         start = _corners(S, nw)
         end = start + (0.2 * S / 2) * p["w_persp_rand"].double() * pts_norm[None]
-        T2 = A @ torch.linalg.inv(_dlt(start, end))
         app = p["w_persp_apply"]
-        desc[nz:, 9:18] = torch.where(app[:, None], T2.reshape(nw, 9), eye[None])
+        desc[nz:, 9:18] = torch.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nw, 9), eye[None])
         desc[nz:, 19] = torch.where(app, torch.tensor(float(MODE_FILL), dtype=torch.float64),
                                     torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        desc[nz:, 27] = GRID_MESH
         desc[nz:, 21] = p["w_jit_apply"].double()
         desc[nz:, 22] = p["w_sat"].double()
-        desc[nz:, 23] = p["w_hue"].double() * (2.0 * math.pi)
+        desc[nz:, 23] = (p["w_hue"].float() * (2.0 * math.pi)).double()
         desc[nz:, 24] = float(bool(p["w_sat_first"]))
     desc[:, 25] = p["noise_fac"].double()
-    return desc.float()
+    return desc
 
 
 class MakeCutouts(nn.Module):
