@@ -1,0 +1,184 @@
+"""ORACLE (test infrastructure only -- never imported by the product package).
+
+One full iteration of the reference loop on the CPU in fp32, assembled from the restated pieces:
+  train()       /root/reference/pixray.py:1436-1512   zero_grad -> ascend_txt -> backward -> Adam -> clip_z
+  ascend_txt()  /root/reference/pixray.py:1243-1406   synth -> MakeCutouts -> encode_image -> Prompt
+plus harnesses that run the HIP path and this oracle on identical seeds / explicit augmentation draws and
+report the parity metrics (used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg).
+Parity status of the assembled path: **unpinned** by the reference's own tests (see the piece modules).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import clip_vit_ref, cutouts_ref, prompt_ref, vqgan_ref
+
+
+class OraclePerceptor:
+    """CLIP_Base-shaped wrapper over the oracle tower (CPU)."""
+
+    def __init__(self, cfg, params):
+        self.cfg, self.params = cfg, params
+        self.input_resolution, self.output_dim = cfg.input_resolution, cfg.output_dim
+
+    def encode_image(self, imgs, input_range=None, apply_preprocess=True):
+        c = self.cfg
+        return clip_vit_ref.encode_image(self.params, imgs, patch=c.patch_size, heads=c.heads, layers=c.layers,
+                                         apply_preprocess=apply_preprocess)
+
+
+class OracleMakeCutouts(torch.nn.Module):
+    """MakeCutouts-shaped wrapper over the oracle cutouts (CPU); draws come from `sampler(iteration)`."""
+
+    def __init__(self, cut_size, cutn, sampler):
+        super().__init__()
+        self.cut_size, self.cutn, self.sampler = cut_size, cutn, sampler
+        self.iteration, self.fill, self.shard, self.transforms = 0, None, None, None
+        self.last_params = None
+
+    def forward(self, input, spot=None):
+        prm = self.sampler(self.iteration, self.fill)
+        self.last_params = prm
+        out = cutouts_ref.make_cutouts(input, prm, self.cut_size)
+        if self.shard is not None:
+            out = out[self.shard[0]:self.shard[1]]
+        return out
+
+
+def oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, prompts, S):
+    img = vqgan_ref.synth(vq_params, z, vq_cfg.oracle_cfg())
+    cut = cutouts_ref.make_cutouts(img, prm, S)
+    emb = clip_vit_ref.encode_image(clip_params, cut, patch=clip_cfg.patch_size, heads=clip_cfg.heads,
+                                    layers=clip_cfg.layers)
+    losses = [prompt_ref.Prompt(e, w, s)(emb) for (e, w, s) in prompts]
+    return losses, img, cut, emb
+
+
+def oracle_iteration(vq_params, vq_cfg, clip_params, clip_cfg, z0, prm, prompts, S):
+    z = z0.detach().clone().requires_grad_(True)
+    losses, img, cut, emb = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, prompts, S)
+    loss = sum(losses)
+    loss.backward()
+    return dict(loss=loss.detach(), dz=z.grad.detach(), img=img.detach(), emb=emb.detach())
+
+
+def _metrics(a: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
+    a, b = a.detach().float().cpu().flatten(), b.detach().float().cpu().flatten()
+    rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+    cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+    return rel, cos
+
+
+def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2):
+    from pixray_amd import api
+    return api.build_vqgan_clip_session(size=size, vqgan_model=vqgan_model, clip_model=clip_model, num_cuts=cutn,
+                                        seed=seed, device=device, learning_rate=lr)
+
+
+def _oracle_inputs(vqgan_model, clip_model, seed):
+    from pixray_amd import weights
+    vq_cfg = weights.VQGAN_CONFIGS[vqgan_model]
+    clip_cfg = weights.CLIP_CONFIGS[clip_model]
+    vq_params = weights.synthetic_vqgan_params(vq_cfg, seed)           # same seeds as api.build_vqgan_clip_session
+    clip_params = weights.synthetic_clip_vit_params(clip_cfg, seed + 1)
+    return vq_cfg, clip_cfg, vq_params, clip_params
+
+
+def _draws(cutn, S, seed, iteration, with_noise=True):
+    from pixray_amd import cutouts as pc
+    g = torch.Generator().manual_seed(5000 + 17 * seed + iteration)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=iteration)
+    if with_noise:
+        prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    return prm
+
+
+def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
+                          device="cuda:0") -> Dict[str, float]:
+    """dL/dz (and the intermediate image / embeddings / loss) of the HIP path vs the oracle after ONE iteration."""
+    from pixray_amd import api
+    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device)
+    vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
+    S = clip_cfg.input_resolution
+    prm = _draws(cutn, S, seed, 0)
+    mk = sess.cutoutsTable[S]
+    mk.fixed_params = prm
+    z0 = sess.drawer.get_z().detach().cpu().clone()
+    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    losses = sess.ascend_txt()
+    loss = sum(losses)
+    loss.backward()
+    dz = sess.drawer.get_z().grad.detach().cpu()
+    img_hip = sess.drawer.synth(0).detach().cpu()
+    ref = oracle_iteration(vq_params, vq_cfg, clip_params, clip_cfg, z0, prm, [(emb_p, 1.0, float("-inf"))], S)
+    idx_ref, _ = vqgan_ref.vq_indices(z0.movedim(1, 3).reshape(-1, z0.shape[1]), vq_params["quantize.embedding.weight"])
+    rel, cos = _metrics(dz, ref["dz"])
+    erel, _ = _metrics(sess.last_embeds, ref["emb"])
+    irel, _ = _metrics(img_hip, ref["img"])
+    return dict(loss_hip=float(loss), loss_ref=float(ref["loss"]), loss_abs_err=abs(float(loss) - float(ref["loss"])),
+                dz_rel_l2=rel, dz_cosine=cos, embeds_rel_l2=erel, image_rel_l2=irel,
+                indices_equal=bool(torch.equal(sess.drawer.handle.last_indices.cpu().long(), idx_ref)))
+
+
+def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
+                    device="cuda:0", lr=0.2) -> Dict[str, float]:
+    """z after k optimiser steps (train(): synth .. Adam .. clip_z) of the HIP path vs the oracle."""
+    from pixray_amd import api
+    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr)
+    vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
+    S = clip_cfg.input_resolution
+    mk = sess.cutoutsTable[S]
+    z_ref = sess.drawer.get_z().detach().cpu().clone().requires_grad_(True)
+    z_start = z_ref.detach().clone()
+    opt = torch.optim.Adam([z_ref], lr=lr)
+    zmin, zmax = vqgan_ref.z_bounds(vq_params)
+    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    for it in range(k):
+        prm = _draws(cutn, S, seed, it)
+        mk.fixed_params = prm
+        sess.train(it)
+        opt.zero_grad()
+        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z_ref, prm, [(emb_p, 1.0, float("-inf"))], S)
+        sum(losses).backward()
+        opt.step()
+        with torch.no_grad():
+            z_ref.copy_(vqgan_ref.clip_z(z_ref, zmin, zmax))
+    z_hip = sess.drawer.get_z().detach().cpu()
+    rel, cos = _metrics(z_hip, z_ref)
+    drel, dcos = _metrics(z_hip - z_start, z_ref.detach() - z_start)
+    return dict(z_rel_l2=rel, z_cosine=cos, dz_total_rel_l2=drel, dz_total_cosine=dcos, steps=k)
+
+
+def time_oracle_iterations(n_iters=3, warmup=1, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
+                           size=(256, 256), cutn=64, seed=0, lr=0.2, threads: Optional[int] = None) -> Dict[str, float]:
+    """CPU baseline leg of bench.py: the full oracle iteration (incl. Adam + clip_z) timed on the host cores."""
+    import os
+    from pixray_amd import api, weights
+    if threads:
+        torch.set_num_threads(threads)
+    vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
+    S = clip_cfg.input_resolution
+    f = 2 ** (vq_cfg.num_resolutions - 1)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(1, vq_cfg.z_channels, size[1] // f, size[0] // f, generator=g).requires_grad_(True)
+    opt = torch.optim.Adam([z], lr=lr)
+    zmin, zmax = vqgan_ref.z_bounds(vq_params)
+    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    times = []
+    for it in range(warmup + n_iters):
+        t0 = time.perf_counter()
+        prm = _draws(cutn, S, seed, it)
+        opt.zero_grad()
+        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, [(emb_p, 1.0, float("-inf"))], S)
+        sum(losses).backward()
+        opt.step()
+        with torch.no_grad():
+            z.copy_(vqgan_ref.clip_z(z, zmin, zmax))
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    mean = sum(times) / len(times)
+    return dict(seconds_per_iter=mean, iters_per_sec=1.0 / mean, threads=torch.get_num_threads(), cores=os.cpu_count(),
+                iters=n_iters)

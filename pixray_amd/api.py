@@ -1,0 +1,52 @@
+"""Product factory: assembles a `Session` from HIP-backed parts only (no oracle, no CPU fallback)."""
+from __future__ import annotations
+
+import json
+import os
+import types
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from .cutouts import MakeCutouts
+from .engine import Session
+from .perceptor import get_clip_perceptor
+from .prompt import Prompt
+from .vqgan_drawer import VqganDrawer
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def seeded_unit_vectors(n: int, dim: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    e = torch.randn(n, dim, generator=g)
+    return e / e.norm(dim=-1, keepdim=True)
+
+
+def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
+                             num_cuts=64, learning_rate=0.2, iterations=250, prompt_embeds: Optional[torch.Tensor] = None,
+                             prompt_weight=1.0, extra_prompts: Sequence = (), seed=0, device="cuda", group=None, rank=0,
+                             world_size=1, custom_losses=(), filters=(), learning_rate_drops=()) -> Session:
+    """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
+    a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z."""
+    _lib.load()   # fail loudly if the HIP extension is missing
+    if not torch.cuda.is_available():
+        raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
+    dev = torch.device(device)
+    settings = types.SimpleNamespace(vqgan_model=vqgan_model, size=tuple(size), weight_seed=seed,
+                                     vqgan_config=None, vqgan_checkpoint=None)
+    drawer = VqganDrawer(settings)
+    drawer.load_model(settings, dev)
+    drawer.init_from_tensor(None)
+    per_rank = num_cuts // world_size
+    perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group)
+    mk = MakeCutouts(perceptor.input_resolution, num_cuts, generator=torch.Generator().manual_seed(1000 + seed))
+    if prompt_embeds is None:
+        prompt_embeds = seeded_unit_vectors(1, perceptor.output_dim, seed + 2)
+    pms = [Prompt(prompt_embeds.to(dev), prompt_weight, float("-inf")).to(dev)]
+    for (emb, w, stop) in extra_prompts:
+        pms.append(Prompt(emb.to(dev), w, stop).to(dev))
+    return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, {clip_model: pms},
+                   learning_rate=learning_rate, iterations=iterations, custom_losses=custom_losses, filters=filters,
+                   seed=seed, group=group, rank=rank, world_size=world_size, learning_rate_drops=learning_rate_drops)

@@ -198,6 +198,7 @@ class MakeCutouts(nn.Module):
         self.generator = generator if generator is not None else torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
         self.iteration = 0
         self.shard = None
+        self.fill = None           # gray fill for this call (pixray.py:1255-1258); drawn if None
         self.last_params = None
         self.fixed_params = None   # tests / parity: use these draws instead of sampling
 
@@ -206,7 +207,7 @@ class MakeCutouts(nn.Module):
             raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
         S = self.cut_size
         prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
-            self.cutn, S, self.generator, self.iteration, self.noise_fac)
+            self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill)
         self.last_params = prm
         desc = build_descriptors(prm, S)
         lo, hi = (0, self.cutn) if self.shard is None else self.shard

@@ -1,0 +1,231 @@
+"""The per-iteration loop of the reference (`train`, pixray.py:1436-1512; `ascend_txt`, 1243-1406;
+`do_synth_and_filter`, 1203-1241; `rebuild_optimisers`, 520-555; `checkdrop`, 1091-1109) as an object
+instead of module globals (pixray.py:1022-1063).
+
+A `Session` is generic over its parts: it only relies on the duck-typed plugin surface of SURVEY.md §8b
+(drawer.synth / get_z / clip_z / get_opts, perceptor.encode_image, MakeCutouts(out), Prompt(embeds),
+LossInterface.get_loss, FilterInterface.forward).  The product factory (`pixray_amd.api`) fills it with the
+HIP-backed parts only; tests may assemble one from other parts (e.g. the CPU oracle) to exercise the host
+logic without a GPU.
+
+Multi-GPU: the cutout batch is sharded over the ranks of `group`; every rank holds the same
+z and replicates the drawer; the gradient of the loss w.r.t. the synthesised image is all-reduced (SUM)
+before it enters the drawer's backward, so every rank then computes the identical, exact dL/dz and takes
+the identical optimiser step.  (The reduction is done on dL/d(image) rather than on dL/dz because
+ClampWithGrad's backward, vqgan.py:76-79, is not linear in the incoming gradient.)
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+
+def spherical_dist_loss(x, y):
+    """pixray.py:262-265 (used by the z regularisers, 1344-1356)"""
+    x = F.normalize(x, dim=-1)
+    y = F.normalize(y, dim=-1)
+    return (x - y).norm(dim=-1).div(2).arcsin().pow(2).mul(2)
+
+
+class HipAdam(torch.optim.Optimizer):
+    """`optim.Adam([z], lr)` (pixray.py:539) on the fused HIP Adam(+clip_z) kernel. One fp32 tensor."""
+
+    def __init__(self, params, lr=0.2, betas=(0.9, 0.999), eps=1e-8, bounds=None):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps))
+        self.bounds = bounds   # (zmin[C], zmax[C]) or None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import ops
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                zmin, zmax = self.bounds if self.bounds is not None else (None, None)
+                ops.adam_clamp_step(p, st["exp_avg"], st["exp_avg_sq"], p.grad.contiguous(), zmin, zmax, group["lr"],
+                                    st["step"], group["betas"], group["eps"])
+
+
+class Session:
+    def __init__(self, drawer, perceptors: Dict[str, object], cutouts: Dict[int, object],
+                 prompts: Dict[str, Sequence[object]], *, learning_rate: float = 0.2, iterations: int = 250,
+                 batches: int = 1, learning_rate_drops: Sequence[int] = (), custom_losses: Sequence[dict] = (),
+                 filters: Sequence[dict] = (), args=None, init_weight: float = 0.0, init_weight_dist: float = 0.0,
+                 z_orig=None, optimiser_factory=None, seed: int = 0, group=None, rank: int = 0, world_size: int = 1,
+                 auto_stop: bool = False):
+        self.drawer = drawer
+        self.perceptors = perceptors
+        self.cutoutsTable = cutouts
+        self.cutoutSizeTable = {name: p.input_resolution for name, p in perceptors.items()}
+        self.pmsTable = prompts
+        self.learning_rate = learning_rate
+        self.iterations = iterations
+        self.batches = batches
+        self.learning_rate_drops = list(learning_rate_drops)
+        self.custom_losses = list(custom_losses)     # [{"loss": LossInterface, "weight": float}] (pixray.py:961-995)
+        self.filters = list(filters)                 # [{"filter": FilterInterface, "weight": float}] (650-669)
+        self.args = args if args is not None else types.SimpleNamespace()
+        self.init_weight = init_weight
+        self.init_weight_dist = init_weight_dist
+        self.z_orig = z_orig
+        self.optimiser_factory = optimiser_factory
+        self.group, self.rank, self.world_size = group, rank, world_size
+        self.auto_stop = auto_stop
+        self.cur_iteration = 0
+        self.num_loss_drop = 0
+        self.max_loss_drops = 2
+        self.iter_drop_delay = 20
+        self.best_loss = None
+        self.best_iter = 0
+        self.lossGlobals = {}
+        self.rng = torch.Generator().manual_seed(seed)       # fill colour stream (python random in the reference)
+        self.last_losses: Optional[List[torch.Tensor]] = None
+        self.last_embeds = None
+        self._shard_cutouts()
+        self.opts = self.rebuild_optimisers()
+
+    # ------------------------------------------------------------------ setup
+    def _shard_cutouts(self):
+        for mk in self.cutoutsTable.values():
+            cutn = mk.cutn
+            if self.world_size > 1:
+                if cutn % self.world_size:
+                    raise ValueError(f"num_cuts {cutn} must be divisible by the number of GPUs {self.world_size}")
+                per = cutn // self.world_size
+                mk.shard = (self.rank * per, (self.rank + 1) * per)
+        for name, pms in self.pmsTable.items():
+            cutn = self.cutoutsTable[self.cutoutSizeTable[name]].cutn
+            for pm in pms:
+                if self.world_size > 1 and hasattr(pm, "denom"):
+                    pm.denom = float(cutn * pm.embed.shape[0])    # global mean denominator (pixray.py:280)
+
+    def rebuild_optimisers(self):
+        """pixray.py:520-555"""
+        drop_divisor = 10 ** self.num_loss_drop
+        new_opts = self.drawer.get_opts(drop_divisor)
+        if new_opts is None:
+            lr = self.learning_rate / drop_divisor
+            z = self.drawer.get_z()
+            if self.optimiser_factory is not None:
+                new_opts = [self.optimiser_factory([z], lr)]
+            elif z.is_cuda:
+                bounds = None
+                if hasattr(self.drawer, "_zmin_flat"):
+                    bounds = (self.drawer._zmin_flat, self.drawer._zmax_flat)
+                    self.drawer._fused_clamp = True
+                new_opts = [HipAdam([z], lr=lr, bounds=bounds)]
+            else:
+                new_opts = [torch.optim.Adam([z], lr=lr)]
+        return new_opts
+
+    # ------------------------------------------------------------------ forward of one iteration
+    def do_synth_and_filter(self, loss_list):
+        """pixray.py:1203-1241 (RGBA flattening is a diffvg-drawer feature and is not provided)"""
+        out = self.drawer.synth(self.cur_iteration)
+        for f in self.filters:
+            out, new_losses = f["filter"](out)
+            if not isinstance(new_losses, (list, tuple)):
+                loss_list.append(f["weight"] * new_losses)
+            else:
+                loss_list += [f["weight"] * l for l in new_losses]
+        if out.shape[1] == 4:
+            out = out[:, 0:3, :, :]
+        return out
+
+    def ascend_txt(self):
+        """pixray.py:1243-1406"""
+        it = self.cur_iteration
+        fill = float(torch.rand((), generator=self.rng, dtype=torch.float64))       # pixray.py:1255-1258
+        result: List[torch.Tensor] = []
+        out = self.do_synth_and_filter(result)
+        if self.world_size > 1 and out.requires_grad:
+            import torch.distributed as dist
+
+            def _allreduce(g):
+                g = g.contiguous()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                return g
+            out.register_hook(_allreduce)
+        cur_cutouts = {}
+        for size, mk in self.cutoutsTable.items():
+            if hasattr(mk, "iteration"):
+                mk.iteration = it              # padding mode parity, pixray.py:1250-1253
+                mk.fill = fill
+            cur_cutouts[size] = mk(out)
+        iii = None
+        for name, perceptor in self.perceptors.items():
+            iii = perceptor.encode_image(cur_cutouts[self.cutoutSizeTable[name]]).float()     # pixray.py:1295
+            for prompt in self.pmsTable[name]:
+                result.append(prompt(iii))                                                     # pixray.py:1297-1299
+        for mk in self.cutoutsTable.values():
+            mk.transforms = None                                                               # pixray.py:1339-1342
+        # regularisers on z are replicated on every rank (they do not pass through `out`)
+        if self.init_weight and self.z_orig is not None:
+            f = self.drawer.get_z().reshape(1, -1)
+            result.append((spherical_dist_loss(f, self.z_orig.reshape(1, -1)) * self.init_weight)[0])
+        if self.init_weight_dist and self.z_orig is not None:
+            result.append(F.mse_loss(self.drawer.get_z(), self.z_orig) * self.init_weight_dist / 2)
+        needed_globals = {"cur_iteration": it, "embeds": iii}                                  # pixray.py:1377-1381
+        for t in self.custom_losses:
+            w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]
+            new_losses = t["loss"].get_loss(cur_cutouts, out, self.args, globals=needed_globals,
+                                            lossGlobals=self.lossGlobals)
+            if not isinstance(new_losses, (list, tuple)):
+                result.append(w * new_losses)
+            else:
+                result += [w * l for l in new_losses]
+        self.last_embeds = iii
+        return result
+
+    # ------------------------------------------------------------------ one optimiser step
+    def train(self, cur_it: Optional[int] = None) -> bool:
+        """pixray.py:1436-1512 (image saving / overlays / animation are outside the hot path)"""
+        if cur_it is None:
+            cur_it = self.cur_iteration
+        self.cur_iteration = cur_it
+        rebuild = False
+        if cur_it < self.iterations:
+            for opt in self.opts:
+                opt.zero_grad()
+            for i in range(self.batches):
+                lossAll = self.ascend_txt()
+                if i == 0:
+                    if cur_it in self.learning_rate_drops:
+                        rebuild = True
+                    elif self.auto_stop:
+                        rebuild = self.checkdrop(cur_it, lossAll)
+                loss = sum(lossAll)
+                loss.backward()
+                self.last_losses = lossAll
+            for opt in self.opts:
+                opt.step()
+            self.drawer.clip_z()
+        if cur_it == self.iterations:
+            return False
+        if rebuild:
+            self.num_loss_drop += 1
+            if self.num_loss_drop > self.max_loss_drops:
+                return False
+            self.best_iter = cur_it
+            self.best_loss = None
+            self.opts = self.rebuild_optimisers()
+        self.cur_iteration = cur_it + 1
+        return True
+
+    def checkdrop(self, it, losses) -> bool:
+        """pixray.py:1091-1109 -- the comparison forces a device->host sync, exactly as in the reference; it only
+        runs when auto_stop is enabled."""
+        loss_sum = float(sum(losses))
+        if self.best_loss is None or loss_sum < self.best_loss:
+            self.best_loss, self.best_iter = loss_sum, it
+            return False
+        return (it - self.best_iter) >= self.iter_drop_delay

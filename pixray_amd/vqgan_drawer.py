@@ -1,0 +1,101 @@
+"""`VqganDrawer` with the reference's drawer surface (/root/reference/vqgan.py:83-214) on the HIP VQGAN runner.
+
+Call sites the loop relies on: add_settings (pixray.py:2070), __init__(settings) (612),
+load_model(settings, device) (613), get_num_resolutions (614), init_from_tensor (718-727),
+reapply_from_tensor (1420), get_z_from_tensor (843), get_opts (525), synth(cur_iteration) (1206),
+to_image (1413), clip_z (1487), get_z / set_z / get_z_copy (537, 1104, 1346).
+
+Not on the hot path and not provided here: the VQGAN *encoder* (init / overlay images)
+and checkpoint download; `init_from_tensor(None)`-style random initialisation of z is provided instead.
+"""
+import torch
+
+from . import ops
+from .interfaces import DrawingInterface
+from .weights import VQGAN_CONFIGS, synthetic_vqgan_params
+
+
+class VqganDrawer(DrawingInterface):
+    @staticmethod
+    def add_settings(parser):
+        parser.add_argument("--vqgan_model", type=str, help="VQGAN model", default='imagenet_f16_16384', dest='vqgan_model')
+        parser.add_argument("--vqgan_config", type=str, help="VQGAN config", default=None, dest='vqgan_config')
+        parser.add_argument("--vqgan_checkpoint", type=str, help="VQGAN checkpoint", default=None, dest='vqgan_checkpoint')
+        return parser
+
+    def __init__(self, settings):
+        super(DrawingInterface, self).__init__()
+        self.vqgan_model = getattr(settings, "vqgan_model", "imagenet_f16_16384")
+        self.size = tuple(getattr(settings, "size", (256, 256)))          # (width, height) as in the reference
+        self.state_dict = getattr(settings, "vqgan_state_dict", None)     # taming state dict, if the caller has one
+        self.weight_seed = getattr(settings, "weight_seed", 0)
+        self.z = None
+        self._fused_clamp = False
+
+    def load_model(self, settings, device):
+        if self.vqgan_model not in VQGAN_CONFIGS:
+            raise ValueError(f"unknown model type: {self.vqgan_model}")
+        self.cfg = VQGAN_CONFIGS[self.vqgan_model]
+        self.device = torch.device(device)
+        params = self.state_dict if self.state_dict is not None else synthetic_vqgan_params(self.cfg, self.weight_seed)
+        f = 2 ** (self.cfg.num_resolutions - 1)
+        w, h = self.size
+        if w % f or h % f:
+            raise ValueError(f"size {self.size} must be a multiple of {f} (pixray.py:621-626 rounds it for you)")
+        self.latent_hw = (h // f, w // f)
+        self.handle = ops.VqganHandle(self.cfg, params, self.latent_hw, self.device)
+        self.e_dim = self.cfg.embed_dim
+        self.n_toks = self.cfg.n_embed
+        zmin, zmax = self.handle.z_bounds()                                # vqgan.py:155-158
+        self.z_min = zmin[None, :, None, None]
+        self.z_max = zmax[None, :, None, None]
+        self._zmin_flat, self._zmax_flat = zmin, zmax
+
+    def get_opts(self, decay_divisor):
+        return None
+
+    def rand_init(self, seed=1):
+        g = torch.Generator().manual_seed(seed)
+        z = torch.randn(1, self.cfg.z_channels, *self.latent_hw, generator=g).to(self.device)
+        self.z = z.maximum(self.z_min).minimum(self.z_max).requires_grad_(True)
+
+    def init_from_tensor(self, init_tensor):
+        if init_tensor is not None:
+            raise NotImplementedError("encoding an init image needs the VQGAN encoder (vqgan.py:174-176), "
+                                      "which is outside the hot path (SURVEY.md §8f-1)")
+        self.rand_init()
+
+    def reapply_from_tensor(self, new_tensor):
+        raise NotImplementedError("VQGAN encoder is outside the hot path (SURVEY.md §8f-1)")
+
+    def get_z_from_tensor(self, ref_tensor):
+        raise NotImplementedError("VQGAN encoder is outside the hot path (SURVEY.md §8f-1)")
+
+    def get_num_resolutions(self):
+        return self.cfg.num_resolutions
+
+    def synth(self, cur_iteration):
+        return ops.vqgan_synth(self.z, self.handle, True)
+
+    @torch.no_grad()
+    def to_image(self):
+        from PIL import Image
+        out = self.synth(None)
+        arr = out[0].mul(255).clamp(0, 255).byte().permute(1, 2, 0).cpu().numpy()
+        return Image.fromarray(arr)
+
+    def clip_z(self):
+        if self._fused_clamp:
+            return          # the fused Adam+clamp kernel already applied the bounds this step
+        with torch.no_grad():
+            self.z.copy_(self.z.maximum(self.z_min).minimum(self.z_max))
+
+    def get_z(self):
+        return self.z
+
+    def set_z(self, new_z):
+        with torch.no_grad():
+            return self.z.copy_(new_z)
+
+    def get_z_copy(self):
+        return self.z.clone()
