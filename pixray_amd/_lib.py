@@ -87,6 +87,10 @@ def load() -> ctypes.CDLL:
         raise PrxError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C pixray_amd/csrc`). There is no CPU fallback for the hot path.")
+    # PyTorch bundles its own HIP/HSA runtime (SONAME libamdhip64.so.7, same as /opt/rocm's).  Import torch FIRST so
+    # that the dynamic loader binds this library to the runtime torch already loaded: one process, one runtime,
+    # and the hipStream_t handed over from torch belongs to the runtime that launches our kernels.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (restype, argtypes) in _protos.items():

@@ -13,6 +13,7 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -75,36 +76,38 @@ def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int
     return p
 
 
-def _dlt(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    """4-point homography (float64) with M @ src ~ dst."""
+def _dlt(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """4-point homographies (float64, batched) with M @ src ~ dst."""
     B = src.shape[0]
-    A = torch.zeros(B, 8, 8, dtype=torch.float64)
-    b = torch.zeros(B, 8, dtype=torch.float64)
-    for i in range(4):
-        x, y, u, v = src[:, i, 0], src[:, i, 1], dst[:, i, 0], dst[:, i, 1]
-        A[:, 2 * i, 0], A[:, 2 * i, 1], A[:, 2 * i, 2] = x, y, 1.0
-        A[:, 2 * i, 6], A[:, 2 * i, 7] = -x * u, -y * u
-        A[:, 2 * i + 1, 3], A[:, 2 * i + 1, 4], A[:, 2 * i + 1, 5] = x, y, 1.0
-        A[:, 2 * i + 1, 6], A[:, 2 * i + 1, 7] = -x * v, -y * v
-        b[:, 2 * i], b[:, 2 * i + 1] = u, v
-    X = torch.linalg.solve(A, b.unsqueeze(-1)).squeeze(-1)
-    return torch.cat([X, torch.ones(B, 1, dtype=torch.float64)], dim=1).reshape(B, 3, 3)
+    A = np.zeros((B, 8, 8))
+    x, y, u, v = src[:, :, 0], src[:, :, 1], dst[:, :, 0], dst[:, :, 1]
+    A[:, 0::2, 0], A[:, 0::2, 1], A[:, 0::2, 2] = x, y, 1.0
+    A[:, 0::2, 6], A[:, 0::2, 7] = -x * u, -y * u
+    A[:, 1::2, 3], A[:, 1::2, 4], A[:, 1::2, 5] = x, y, 1.0
+    A[:, 1::2, 6], A[:, 1::2, 7] = -x * v, -y * v
+    b = np.empty((B, 8, 1))
+    b[:, 0::2, 0], b[:, 1::2, 0] = u, v
+    X = np.linalg.solve(A, b)[:, :, 0]
+    return np.concatenate([X, np.ones((B, 1))], axis=1).reshape(B, 3, 3)
 
 
-def _corners(S: int, B: int) -> torch.Tensor:
-    c = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
-    return c[None].repeat(B, 1, 1)
+def _corners(S: int, B: int) -> np.ndarray:
+    c = np.array([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]])
+    return np.repeat(c[None], B, axis=0)
 
 
-def _nk(S: int) -> torch.Tensor:
-    """kornia normal_transform_pixel: pixel [0, S-1] -> [-1, 1]"""
-    return torch.tensor([[2.0 / (S - 1), 0.0, -1.0], [0.0, 2.0 / (S - 1), -1.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+def _src_norm_from_dst_norm(M: np.ndarray, S: int) -> np.ndarray:
+    """inverse of kornia normalize_homography(M): maps normalised destination coords to normalised source coords
+    (kornia normal_transform_pixel: pixel [0, S-1] -> [-1, 1])"""
+    nk = np.array([[2.0 / (S - 1), 0.0, -1.0], [0.0, 2.0 / (S - 1), -1.0], [0.0, 0.0, 1.0]])
+    return np.linalg.inv(nk @ (M @ np.linalg.inv(nk)))
 
 
-def _src_norm_from_dst_norm(M: torch.Tensor, S: int) -> torch.Tensor:
-    """inverse of kornia normalize_homography(M): maps normalised destination coords to normalised source coords"""
-    nk = _nk(S)
-    return torch.linalg.inv(nk @ (M @ torch.linalg.inv(nk)))
+_PTS_NORM = np.array([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]])
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64) if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
 
 
 def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
@@ -115,67 +118,67 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
       GRID_MESH   (warp_perspective): create_meshgrid(normalized) + transform_points, then F.grid_sample
       GRID_AFFINE (warp_affine)     : F.affine_grid(theta = first two rows, rounded to fp32), then F.grid_sample
     both sampled with align_corners=False (the augmentation flag the reference passes, pixray.py:333-334,349,363).
-    The kernel evaluates the grid with the same precision steps, so tap positions round like the oracle's."""
+    The kernel evaluates the grid with the same precision steps, so tap positions round like the oracle's.
+    (numpy float64 on the host: ~0.3 ms for 64 cutouts.)"""
     cutn = int(p["cutn"])
     nz = int(0.6 * cutn)
     nw = cutn - nz
-    pts_norm = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
-    desc = torch.zeros(cutn, DESC_WORDS, dtype=torch.float64)
+    desc = np.zeros((cutn, DESC_WORDS))
     desc[:, 20] = float(p["fill"])
-    eye = torch.eye(3, dtype=torch.float64).reshape(9)
+    eye = np.eye(3).reshape(9)
     desc[:, 0:9] = eye
     desc[:, 9:18] = eye
 
     def affine_theta(M):
         t = _src_norm_from_dst_norm(M, S)
-        t[:, :2, :] = t[:, :2, :].float().double()       # F.affine_grid receives theta in fp32
-        t[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+        t[:, :2, :] = t[:, :2, :].astype(np.float32).astype(np.float64)   # F.affine_grid receives theta in fp32
+        t[:, 2, :] = (0.0, 0.0, 1.0)
         return t.reshape(-1, 9)
 
     if nz > 0:
         start = _corners(S, nz)
-        end = start + (0.4 * S / 2) * p["z_persp_rand"].double() * pts_norm[None]
-        app = p["z_persp_apply"]
-        desc[:nz, 0:9] = torch.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nz, 9), eye[None])
+        end = start + (0.4 * S / 2) * _np(p["z_persp_rand"]) * _PTS_NORM[None]
+        app = _np(p["z_persp_apply"]) != 0
+        desc[:nz, 0:9] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nz, 9), eye[None])
         pad = MODE_REFLECT if int(p["reflect"]) else MODE_BORDER
-        desc[:nz, 18] = torch.where(app, torch.tensor(float(pad), dtype=torch.float64),
-                                    torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        desc[:nz, 18] = np.where(app, float(pad), float(MODE_IDENT))
         desc[:nz, 26] = GRID_MESH
-        xs, ys, w, h = [p["z_crop"][:, i].double() for i in range(4)]
-        src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
-                           torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
+        crop = _np(p["z_crop"])
+        xs, ys, w, h = crop[:, 0], crop[:, 1], crop[:, 2], crop[:, 3]
+        src = np.stack([np.stack([xs, ys], 1), np.stack([xs + w - 1, ys], 1),
+                        np.stack([xs + w - 1, ys + h - 1], 1), np.stack([xs, ys + h - 1], 1)], axis=1)
         Mc = _dlt(src, _corners(S, nz))
-        Mc[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)   # warp_affine drops the last row
+        Mc[:, 2, :] = (0.0, 0.0, 1.0)                                      # warp_affine drops the last row
         desc[:nz, 9:18] = affine_theta(Mc)
         desc[:nz, 19] = MODE_ZEROS
         desc[:nz, 27] = GRID_AFFINE
-        desc[:nz, 21] = p["z_jit_apply"].double()
-        desc[:nz, 22] = p["z_sat"].double()
-        desc[:nz, 23] = (p["z_hue"].float() * (2.0 * math.pi)).double()      # kornia: hue_factor * 2*pi in fp32
+        desc[:nz, 21] = _np(p["z_jit_apply"])
+        desc[:nz, 22] = _np(p["z_sat"])
+        desc[:nz, 23] = (p["z_hue"].float() * (2.0 * math.pi)).double().numpy()   # kornia: hue_factor * 2*pi in fp32
         desc[:nz, 24] = float(bool(p["z_sat_first"]))
     if nw > 0:
         s = 0.95
         c = S / 2.0 - 0.5
-        Ma = torch.zeros(nw, 3, 3, dtype=torch.float64)
+        tr = _np(p["w_trans"])
+        Ma = np.zeros((nw, 3, 3))
         Ma[:, 0, 0] = s; Ma[:, 1, 1] = s; Ma[:, 2, 2] = 1.0
-        Ma[:, 0, 2] = (1 - s) * c + p["w_trans"][:, 0].double()
-        Ma[:, 1, 2] = (1 - s) * c + p["w_trans"][:, 1].double()
+        Ma[:, 0, 2] = (1 - s) * c + tr[:, 0]
+        Ma[:, 1, 2] = (1 - s) * c + tr[:, 1]
         desc[nz:, 0:9] = affine_theta(Ma)
         desc[nz:, 18] = MODE_FILL
         desc[nz:, 26] = GRID_AFFINE
         start = _corners(S, nw)
-        end = start + (0.2 * S / 2) * p["w_persp_rand"].double() * pts_norm[None]
-        app = p["w_persp_apply"]
-        desc[nz:, 9:18] = torch.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nw, 9), eye[None])
-        desc[nz:, 19] = torch.where(app, torch.tensor(float(MODE_FILL), dtype=torch.float64),
-                                    torch.tensor(float(MODE_IDENT), dtype=torch.float64))
+        end = start + (0.2 * S / 2) * _np(p["w_persp_rand"]) * _PTS_NORM[None]
+        app = _np(p["w_persp_apply"]) != 0
+        desc[nz:, 9:18] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nw, 9), eye[None])
+        desc[nz:, 19] = np.where(app, float(MODE_FILL), float(MODE_IDENT))
         desc[nz:, 27] = GRID_MESH
-        desc[nz:, 21] = p["w_jit_apply"].double()
-        desc[nz:, 22] = p["w_sat"].double()
-        desc[nz:, 23] = (p["w_hue"].float() * (2.0 * math.pi)).double()
+        desc[nz:, 21] = _np(p["w_jit_apply"])
+        desc[nz:, 22] = _np(p["w_sat"])
+        desc[nz:, 23] = (p["w_hue"].float() * (2.0 * math.pi)).double().numpy()
         desc[nz:, 24] = float(bool(p["w_sat_first"]))
-    desc[:, 25] = p["noise_fac"].double()
-    return desc
+    desc[:, 25] = _np(p["noise_fac"])
+    return torch.from_numpy(desc)
 
 
 class MakeCutouts(nn.Module):
