@@ -215,6 +215,9 @@ int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, 
                      prx_stream_t s);
 int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t s);
 
+/* A/B switch between the two GEMM kernels (1 = direct-to-LDS v2, default; 0 = register-staged v1) */
+void prx_gemm_variant(int use_glds);
+
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
 void prx_profile_gemm_enable(int on);
 int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches);

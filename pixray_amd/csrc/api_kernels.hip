@@ -18,7 +18,7 @@ int prx_k_groupnorm_fwd(const float* x, const float* gamma, const float* beta, d
 int prx_k_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                         double* bstats, const float* add, float* dx, int NB, int P, int C, int swish, float eps,
                         prx_stream_t s) {
-    return prx_groupnorm_bwd(g, x, gamma, beta, fstats, bstats, add, dx, NB, P, C, swish, eps, S_(s));
+    return prx_groupnorm_bwd(g, x, gamma, beta, fstats, bstats, add, dx, nullptr, NB, P, C, swish, eps, S_(s));
 }
 int prx_k_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, void* out_bf16,
                         float* out_f32, float* mean, float* rstd, int rows, int C, float eps, prx_stream_t s) {
@@ -27,7 +27,7 @@ int prx_k_layernorm_fwd(const float* x, long long ldx, const float* gamma, const
 int prx_k_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                         const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
                         long long lddx, int rows, int C, prx_stream_t s) {
-    return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, rows, C, S_(s));
+    return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, nullptr, 0, rows, C, S_(s));
 }
 int prx_k_transpose_bf16(const void* in, int ldin, void* out, int ldout, int R, int C, prx_stream_t s) {
     return prx_transpose_bf16(CB_(in), ldin, B_(out), ldout, R, C, S_(s));
@@ -41,7 +41,7 @@ int prx_k_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, fl
     return prx_softmax_rows_bwd(CB_(P), ldp, dP, lddp, scale, B_(dS), ldds, B_(dST), lddst, rows, cols, S_(s));
 }
 int prx_k_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, prx_stream_t s) {
-    return prx_upsample2x_bwd(hi, low, NB, Hl, Wl, C, S_(s));
+    return prx_upsample2x_bwd(hi, low, nullptr, NB, Hl, Wl, C, S_(s));
 }
 int prx_k_nchw_to_nhwc(const float* in, float* out_f32, void* out_bf16, int NB, int C, int HW, int Cpad,
                        prx_stream_t s) {

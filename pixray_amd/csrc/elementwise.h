@@ -5,7 +5,7 @@ int prx_softmax_rows(const float* S, int lds_, float scale, bf16_t* P, int ldp, 
                      int cols, hipStream_t s);
 int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, float scale, bf16_t* dS, int ldds,
                          bf16_t* dST, int lddst, int rows, int cols, hipStream_t s);
-int prx_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, hipStream_t s);
+int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s);
 int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s);
 int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);
 int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s);

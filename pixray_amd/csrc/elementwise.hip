@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __r
 
 // low[b][y][x][c] = sum over the 2x2 children of hi (NHWC fp32) -- backward of nearest-2x upsample
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ hi, float* __restrict__ low,
-                                                             int NB, int Hl, int Wl, int C) {
+                                                             bf16_t* __restrict__ low_bf16, int NB, int Hl, int Wl,
+                                                             int C) {
     const int C4 = C >> 2;
     const size_t total = (size_t)NB * Hl * Wl * C4;
     const int Wh = Wl * 2;
@@ -87,9 +88,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         const float4* h4 = reinterpret_cast<const float4*>(hi);
         size_t p00 = (((size_t)b * Hl * 2 + 2 * y) * Wh + 2 * x) * C4 + cq;
         float4 a = h4[p00], bb = h4[p00 + C4], c = h4[p00 + (size_t)Wh * C4], d = h4[p00 + (size_t)Wh * C4 + C4];
-        reinterpret_cast<float4*>(low)[idx] =
-            make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z),
-                        (a.w + bb.w) + (c.w + d.w));
+        float4 o = make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z),
+                               (a.w + bb.w) + (c.w + d.w));
+        reinterpret_cast<float4*>(low)[idx] = o;
+        if (low_bf16) {
+            bf16x4 r;
+            r[0] = (bf16_t)o.x; r[1] = (bf16_t)o.y; r[2] = (bf16_t)o.z; r[3] = (bf16_t)o.w;
+            reinterpret_cast<bf16x4*>(low_bf16)[idx] = r;
+        }
     }
 }
 
@@ -220,10 +226,10 @@ int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, fl
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, hipStream_t s) {
+int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s) {
     PRX_REQUIRE(C % 4 == 0, "upsample2x_bwd: C %% 4 != 0");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, NB,
-                       Hl, Wl, C);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, low_bf16,
+                       NB, Hl, Wl, C);
     PRX_LAUNCH_CHECK();
     return 0;
 }

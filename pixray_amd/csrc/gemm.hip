@@ -227,6 +227,178 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2: operands go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write), LDS is
+// double-buffered with ONE barrier per K tile, and the unpadded [rows][64] bf16 tile is XOR-swizzled on the
+// *source* side (the DMA destination is lane-linear): LDS chunk position c of row r holds global chunk
+// c ^ ((r >> 1) & 7), which makes every 16-lane ds_read_b128 group hit 16 distinct 16-byte slots.
+// Out-of-range rows / K tails / conv zero padding read from a zero page.  bf16 A only.
+// ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
+    constexpr int A_IN = BM / 32;   // DMA instructions (8 rows x 128 B each) per wave per K tile
+    constexpr int B_IN = BN / 32;
+    constexpr int MT = BM / 64;
+    constexpr int NT = BN / 64;
+    constexpr int TILE = (BM + BN) * BK;   // bf16 elements per stage
+
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * TILE];
+
+    const GemmDesc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int bid = blockIdx.x;
+    const int tm = bid / p.tiles_n;
+    const int tn = bid - tm * p.tiles_n;
+    const int split = blockIdx.y;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(p.kt_total, kt0 + p.kt_per_split);
+
+    const bf16_t* __restrict__ Ap = reinterpret_cast<const bf16_t*>(d.A);
+    const bf16_t* __restrict__ Bp = d.B;
+
+    // ---- per-lane DMA coordinates (fixed across the K loop) -------------------
+    const int lrow = lane >> 3, cpos = lane & 7;
+    long long a_base[A_IN];
+    int a_sw[A_IN], a_y[A_IN], a_x[A_IN], a_b[A_IN];
+    bool a_ok[A_IN];
+#pragma unroll
+    for (int i = 0; i < A_IN; ++i) {
+        const int row = (wave * A_IN + i) * 8 + lrow;
+        a_sw[i] = cpos ^ ((row >> 1) & 7);
+        const int gm = tm * BM + row;
+        a_ok[i] = gm < d.M;
+        if (AMODE == PRX_A_ROWMAJOR) {
+            a_base[i] = (long long)gm * d.lda;
+            a_y[i] = a_x[i] = a_b[i] = 0;
+        } else {
+            const int hw = d.H * d.W;
+            const int b = gm / hw;
+            const int rem = gm - b * hw;
+            const int y = rem / d.W;
+            a_b[i] = b; a_y[i] = y; a_x[i] = rem - y * d.W;
+            a_base[i] = 0;
+        }
+    }
+    long long b_base[B_IN];
+    int b_sw[B_IN];
+    bool b_ok[B_IN];
+#pragma unroll
+    for (int i = 0; i < B_IN; ++i) {
+        const int row = (wave * B_IN + i) * 8 + lrow;
+        b_sw[i] = cpos ^ ((row >> 1) & 7);
+        const int gn = tn * BN + row;
+        b_ok[i] = gn < d.N;
+        b_base[i] = (long long)gn * d.ldb;
+    }
+
+    auto issue = [&](int kt, int buf) {
+        bf16_t* As = lds + buf * TILE;
+        bf16_t* Bs = As + BM * BK;
+#pragma unroll
+        for (int i = 0; i < A_IN; ++i) {
+            const int k = kt * BK + a_sw[i] * 8;
+            const bf16_t* src = zero_page;
+            if (AMODE == PRX_A_ROWMAJOR) {
+                if (a_ok[i] && k < d.K) src = Ap + a_base[i] + k;
+            } else {
+                const int tap = k / d.Cin;
+                const int c = k - tap * d.Cin;
+                const int ky = tap / 3;
+                const int kx = tap - 3 * ky;
+                const int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
+                if (a_ok[i] && k < d.K && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) {
+                    long long pix;
+                    if (d.up) pix = ((long long)a_b[i] * (d.H >> 1) + (yy >> 1)) * (d.W >> 1) + (xx >> 1);
+                    else      pix = ((long long)a_b[i] * d.H + yy) * d.W + xx;
+                    src = Ap + pix * d.lda + c;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * A_IN + i) * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IN; ++i) {
+            const int k = kt * BK + b_sw[i] * 8;
+            const bf16_t* src = (b_ok[i] && k < d.K) ? (Bp + b_base[i] + k) : zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (wave * B_IN + i) * 8 * BK), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) issue(kt0, 0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int khalf = lane >> 5;
+    int a_off[MT], a_key[MT], b_off[NT], b_key[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + frag_row;
+        a_off[i] = r * BK; a_key[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int r = wn * (BN / 2) + j * 32 + frag_row;
+        b_off[j] = r * BK; b_key[j] = (r >> 1) & 7;
+    }
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
+        const bf16_t* As = lds + cur * TILE;
+        const bf16_t* Bs = As + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int kc = ks * 2 + khalf;
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(As + a_off[i] + ((kc ^ a_key[i]) << 3));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[j] + ((kc ^ b_key[j]) << 3));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int row0 = tm * BM + wm * (BM / 2) + 4 * (lane >> 5);
+    const int col0 = tn * BN + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + j * 32;
+            if (col >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= d.M) continue;
+                if (p.splits > 1)
+                    p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
+                else
+                    epilogue_store(d, row, col, acc[i][j][r]);
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const GemmDesc& d = p.d;
     const size_t total = (size_t)d.M * d.N;
@@ -252,13 +424,41 @@ void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
 }
 
+template <int BM, int BN>
+void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR)
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a, zero_page);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a, zero_page);
+}
+
+std::mutex g_zero_mu;
+bf16_t* g_zero_page[16] = {nullptr};
+
+// a 256-byte page of zeros per device (source of the DMA for out-of-range / padded operand chunks)
+const bf16_t* zero_page_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_zero_mu);
+    if (!g_zero_page[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        g_zero_page[dev] = (bf16_t*)p;
+    }
+    return g_zero_page[dev];
+}
+
 // ---- optional per-launch profiling (bench.py roofline leg) -------------------
 struct ProfRec { hipEvent_t a, b; double flop; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+bool g_use_glds = true;   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
 
 }  // namespace
+
+void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
 
 void prx_gemm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -332,7 +532,13 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     }
 
     dim3 grid(tiles, splits);
-    if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);
+    if (!d.a_is_f32 && g_use_glds) {
+        const bf16_t* zp = zero_page_for_current_device();
+        PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
+        if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp);
+        else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp);
+        else launch_glds<64, 64>(a, grid, stream, zp);
+    } else if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);
     else if (BM == 128 && BN == 64) launch_cfg<128, 64>(a, grid, stream);
     else launch_cfg<64, 64>(a, grid, stream);
     PRX_LAUNCH_CHECK();

@@ -5,11 +5,11 @@
 int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, double* stats, bf16_t* out_bf16,
                       float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s);
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
-                      double* bstats, const float* add, float* dx, int NB, int P, int C, int swish, float eps,
-                      hipStream_t s);
+                      double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
+                      float eps, hipStream_t s);
 // LayerNorm on rows of width C.
 int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, bf16_t* out_bf16,
                       float* out_f32, float* mean, float* rstd, int rows, int C, float eps, hipStream_t s);
 int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
-                      long long lddx, int rows, int C, hipStream_t s);
+                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s);

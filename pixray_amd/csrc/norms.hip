@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_
 
 // dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat)) (+ add)
 __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const double* bstats, const float* add,
-                                                           float* dx, int NB) {
+                                                           float* dx, bf16_t* dx_bf16, int NB) {
     const int C4 = a.C >> 2;
     const int gs = a.C / 32;
     const size_t total = (size_t)NB * a.P * C4;
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const
             o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
         }
         reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+        if (dx_bf16) {
+            bf16x4 r;
+            r[0] = (bf16_t)o[0]; r[1] = (bf16_t)o[1]; r[2] = (bf16_t)o[2]; r[3] = (bf16_t)o[3];
+            reinterpret_cast<bf16x4*>(dx_bf16)[idx] = r;
+        }
     }
 }
 
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ x, long long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ add,
-                                                     long long ldadd, float* __restrict__ dx, long long lddx, int rows,
-                                                     int C) {
+                                                     long long ldadd, float* __restrict__ dx, long long lddx,
+                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -264,6 +269,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                 o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
             }
             reinterpret_cast<float4*>(dx + (size_t)row * lddx)[c4] = o;
+            if (dx_bf16) {
+                bf16x4 r;
+                r[0] = (bf16_t)o.x; r[1] = (bf16_t)o.y; r[2] = (bf16_t)o.z; r[3] = (bf16_t)o.w;
+                reinterpret_cast<bf16x4*>(dx_bf16 + (size_t)row * lddxb)[c4] = r;
+            }
         }
 }
 
@@ -290,8 +300,8 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
 }
 
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
-                      double* bstats, const float* add, float* dx, int NB, int P, int C, int swish, float eps,
-                      hipStream_t s) {
+                      double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
+                      float eps, hipStream_t s) {
     PRX_REQUIRE(256 % (C / 4) == 0 && (C / 32) % 4 == 0, "groupnorm bwd: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.g = g; a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.stats = bstats;
@@ -302,7 +312,7 @@ int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const 
     hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(blocks, NB), dim3(256), 0, s, a);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,
-                       NB);
+                       dx_bf16, NB);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -323,15 +333,15 @@ int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const f
 
 int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
-                      long long lddx, int rows, int C, hipStream_t s) {
+                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s) {
     PRX_REQUIRE(C % 256 == 0 && C <= 2048, "layernorm bwd: C must be a multiple of 256 and <= 2048 (C=%d)", C);
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, rows, C);
+                           lddx, dx_bf16, lddxb, rows, C);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, rows, C);
+                           lddx, dx_bf16, lddxb, rows, C);
     PRX_LAUNCH_CHECK();
     return 0;
 }

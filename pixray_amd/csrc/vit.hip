@@ -70,7 +70,7 @@ struct PrxVit {
     float *cls, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
     std::vector<VitLayer> L;
     // workspace
-    bf16_t *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv;
+    bf16_t *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf;
     float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
     float* ws; size_t ws_bytes;
     int cur_n;
@@ -148,7 +148,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     ALLOC(v->hpost, (size_t)max_n * W); ALLOC(v->dt, R * 4 * W); ALLOC(v->do_, R * W); ALLOC(v->dqkv, R * 3 * W);
     ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R); ALLOC(v->x_final, R * W);
     ALLOC(v->mean_post, max_n); ALLOC(v->rstd_post, max_n); ALLOC(v->e, (size_t)max_n * out_dim);
-    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
+    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dx_bf, R * W); ALLOC(v->dh_bf, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
     ALLOC(v->dhpost, (size_t)max_n * W); ALLOC(v->mm_part, 2 * 1024);
     v->ws_bytes = (size_t)64 << 20;
     ALLOC(v->ws, v->ws_bytes / sizeof(float));
@@ -225,32 +225,34 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     {   GemmDesc d; d.A = v->de; d.a_is_f32 = 1; d.lda = v->out_dim; d.B = v->proj; d.ldb = v->out_dim;
         d.M = n; d.N = W; d.K = v->out_dim; d.out_f32 = v->dhpost; d.ldc_f32 = W;
         if ((r = vit_gemm(v, d, s))) return r; }
+    // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
     PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
+    PRX_CHECK_HIP(hipMemsetAsync(v->dx_bf, 0, sizeof(bf16_t) * (size_t)R * W, s));
     if ((r = prx_layernorm_bwd(v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
-                               nullptr, 0, v->dx, (long long)T * W, n, W, s))) return r;
+                               nullptr, 0, v->dx, (long long)T * W, v->dx_bf, (long long)T * W, n, W, s))) return r;
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
         // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
-        {   GemmDesc d; d.A = v->dx; d.a_is_f32 = 1; d.lda = W; d.B = y.W2T; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
+        {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.W2T; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
             d.act = PRX_ACT_MUL_DQUICKGELU; d.aux = y.t; d.ldaux = 4 * W; d.out_bf16 = v->dt; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
         {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_layernorm_bwd(v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, R, W, s))) return r;
+        if ((r = prx_layernorm_bwd(v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, v->dx_bf, W, R, W, s))) return r;
         // attention: x_mid = x_in + out_proj(mha(ln_1(x_in)))
-        {   GemmDesc d; d.A = v->dx; d.a_is_f32 = 1; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
+        {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.out_bf16 = v->do_; d.ldc_bf16 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
         if ((r = prx_mha_bwd(y.qkv, v->do_, v->dqkv, n, T, W, v->heads, s))) return r;
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_layernorm_bwd(v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, R, W, s))) return r;
+        if ((r = prx_layernorm_bwd(v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, W, R, W, s))) return r;
     }
     // ln_pre backward (in place on dx), then patch-embed dgrad
-    if ((r = prx_layernorm_bwd(v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, R, W, s))) return r;
-    {   GemmDesc d; d.A = v->dh; d.a_is_f32 = 1; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
+    if ((r = prx_layernorm_bwd(v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, W, R, W, s))) return r;
+    {   GemmDesc d; d.A = v->dh_bf; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
         d.out_f32 = v->dA0; d.ldc_f32 = KP;
         if ((r = vit_gemm(v, d, s))) return r; }
     return prx_patchify_bwd_reduce(cutouts, mm, v->dA0, acc, n, v->res, v->patch, T, s);

@@ -62,13 +62,14 @@ struct ResBlock {
     int Cin, Cout, res;
     GN n1, n2; Conv3 c1, c2; Conv1 sc; bool has_sc;
     float *x_in, *h1, *scbuf, *out;
+    bf16_t *x_in_bf, *out_bf;   // bf16 twins (only where a GEMM consumes the tensor)
 };
 struct AttnBlock {
     int C, res;
     GN n; Conv1 qkv, proj;   // qkv = [3C, C] concatenated q|k|v
-    float* x_in; bf16_t *qkvb, *Pm, *PT; float* out;
+    float* x_in; bf16_t *qkvb, *Pm, *PT; float* out; bf16_t* out_bf;
 };
-struct UpBlock { int C, res_out; Conv3 c; float *x_in, *out; };
+struct UpBlock { int C, res_out; Conv3 c; float *x_in, *out; bf16_t *x_in_bf, *out_bf; };
 
 struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
 
@@ -79,11 +80,12 @@ struct PrxVqgan {
     Conv1 pq; Conv3 conv_in, conv_out; GN norm_out;
     std::vector<ResBlock> res; std::vector<AttnBlock> attn; std::vector<UpBlock> ups; std::vector<Stage> stages;
     // activations
-    float *zq, *pqo, *h_in, *y; int* idx;
+    float *zq, *h_in, *y; int* idx; bf16_t *pqo_bf, *h_in_bf, *dpq_bf;
     float *pmin; int* pidx;
     bf16_t* a;             // GN(+swish) operand, max size
     bf16_t *tA, *tB, *tC, *tD, *dqkv, *dy8;  // attention temporaries [P*C max], dgrad head input
     float *S, *g0, *g1, *g2; // score matrix; gradient ping-pong buffers (max P*C)
+    bf16_t *g0b, *g1b, *g2b; // their bf16 twins (dgrad GEMM operands)
     double* bstats;
     float* ws; size_t ws_bytes;
     float* x_last;  // input of norm_out
@@ -239,7 +241,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.res * rb.res * std::max(rb.Cin, rb.Cout));
     for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.res_out * ub.res_out * ub.C);
     for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)ab.res * ab.res * (size_t)std::max(ab.C, ab.res * ab.res));
-    VALLOC(v->zq, P0 * embed_dim); VALLOC(v->pqo, P0 * z_channels);
+    VALLOC(v->zq, P0 * embed_dim); VALLOC(v->pqo_bf, P0 * z_channels); VALLOC(v->dpq_bf, P0 * z_channels);
     VALLOC(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
     VALLOC(v->y, PH * 4); VALLOC(v->idx, P0);
     const int ntiles = ceil_div(n_embed, 64);
@@ -249,6 +251,23 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     VALLOC(v->dqkv, maxAttnPC * 3); VALLOC(v->dy8, PH * 8);
     VALLOC(v->S, maxAttnPC);
     VALLOC(v->g0, maxPC); VALLOC(v->g1, maxPC); VALLOC(v->g2, maxPC);
+    VALLOC(v->g0b, maxPC); VALLOC(v->g1b, maxPC); VALLOC(v->g2b, maxPC);
+    // bf16 twins of stage outputs that feed a GEMM directly (1x1 shortcut or upsample conv of the next stage)
+    v->h_in_bf = nullptr;
+    for (size_t i = 0; i < v->stages.size(); ++i) {
+        const Stage& st = v->stages[i];
+        const bool need = (st.kind == 0 && v->res[st.idx].has_sc) || st.kind == 2;
+        if (!need) continue;
+        bf16_t** slot; size_t cnt;
+        if (i == 0) { slot = &v->h_in_bf; cnt = P0 * (size_t)(ch * ch_mult[n_mult - 1]); }
+        else {
+            const Stage& pr = v->stages[i - 1];
+            if (pr.kind == 0) { ResBlock& b = v->res[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res * b.res * b.Cout; }
+            else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res * b.res * b.C; }
+            else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res_out * b.res_out * b.C; }
+        }
+        VALLOC(*slot, cnt);
+    }
     VALLOC(v->bstats, 64);
     v->ws_bytes = (size_t)64 << 20;
     VALLOC(v->ws, v->ws_bytes / sizeof(float));
@@ -265,26 +284,28 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
 static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
 
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int res, bool up, const float* resid,
-                     float* out, int ldc, hipStream_t s) {
+                     float* out, int ldc, hipStream_t s, bf16_t* out_bf = nullptr) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
     d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = res * res; d.N = c.Cout; d.K = 9 * c.Cin;
     d.H = res; d.W = res; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
-    d.out_f32 = out; d.ldc_f32 = ldc;
+    d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
-static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int res, float* dx, hipStream_t s) {
+static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int res, float* dx, hipStream_t s,
+                     bf16_t* dx_bf = nullptr) {
     GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
     d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = res * res; d.N = c.Cin; d.K = 9 * c.CoP;
     d.H = res; d.W = res; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
+    d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
     return vg(v, d, s);
 }
 static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s) {
     return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s);
 }
-static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx, int P,
-                  int swish, hipStream_t s) {
-    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, v->bstats, add, dx, 1, P, g.C, swish, 1e-6f, s);
+static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
+                  bf16_t* dx_bf, int P, int swish, hipStream_t s) {
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, v->bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -304,27 +325,29 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
         if ((r = prx_nchw_to_nhwc(z, v->zq, nullptr, 1, v->zc, P0, v->zc, s))) return r;
     }
     {   GemmDesc d; d.A = v->zq; d.a_is_f32 = 1; d.lda = v->D; d.B = v->pq.W; d.ldb = v->D; d.M = P0; d.N = v->zc; d.K = v->D;
-        d.bias_n = v->pq.b; d.out_f32 = v->pqo; d.ldc_f32 = v->zc;
+        d.bias_n = v->pq.b; d.out_bf16 = v->pqo_bf; d.ldc_bf16 = v->zc;
         if ((r = vg(v, d, s))) return r; }
-    if ((r = conv3_fwd(v, v->conv_in, v->pqo, true, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s))) return r;
+    if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf))) return r;
     float* x = v->h_in;
+    bf16_t* x_bf = v->h_in_bf;   // bf16 twin of x (null when no GEMM reads x directly)
     for (auto& st : v->stages) {
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
             const int P = b.res * b.res;
-            b.x_in = x;
+            b.x_in = x; b.x_in_bf = x_bf;
             if ((r = gn_fwd(v, b.n1, x, P, 1, s))) return r;
             if ((r = conv3_fwd(v, b.c1, v->a, false, b.res, false, nullptr, b.h1, b.Cout, s))) return r;
             const float* resid = x;
             if (b.has_sc) {
-                GemmDesc d; d.A = x; d.a_is_f32 = 1; d.lda = b.Cin; d.B = b.sc.W; d.ldb = b.Cin; d.M = P; d.N = b.Cout; d.K = b.Cin;
+                PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the shortcut input");
+                GemmDesc d; d.A = x_bf; d.lda = b.Cin; d.B = b.sc.W; d.ldb = b.Cin; d.M = P; d.N = b.Cout; d.K = b.Cin;
                 d.bias_n = b.sc.b; d.out_f32 = b.scbuf; d.ldc_f32 = b.Cout;
                 if ((r = vg(v, d, s))) return r;
                 resid = b.scbuf;
             }
             if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s))) return r;
-            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s))) return r;
-            x = b.out;
+            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s, b.out_bf))) return r;
+            x = b.out; x_bf = b.out_bf;
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
             const int P = b.res * b.res, C = b.C;
@@ -343,13 +366,15 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
+                d.out_bf16 = b.out_bf; d.ldc_bf16 = C;
                 if ((r = vg(v, d, s))) return r; }
-            x = b.out;
+            x = b.out; x_bf = b.out_bf;
         } else {
             UpBlock& b = v->ups[st.idx];
-            b.x_in = x;
-            if ((r = conv3_fwd(v, b.c, x, true, b.res_out, true, nullptr, b.out, b.C, s))) return r;
-            x = b.out;
+            b.x_in = x; b.x_in_bf = x_bf;
+            PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the upsample input");
+            if ((r = conv3_fwd(v, b.c, x_bf, false, b.res_out, true, nullptr, b.out, b.C, s, b.out_bf))) return r;
+            x = b.out; x_bf = b.out_bf;
         }
     }
     v->x_last = x;
@@ -365,32 +390,33 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     int r;
     PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
     if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
-    float *g = v->g0, *t1 = v->g1, *t2 = v->g2;
-    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, t1, s))) return r;
-    if ((r = gn_bwd(v, v->norm_out, t1, v->x_last, nullptr, g, PH, 1, s))) return r;
+    struct GB { float* f; bf16_t* b; };
+    GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
+    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, t1.f, s))) return r;
+    if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s))) return r;
     for (int si = (int)v->stages.size() - 1; si >= 0; --si) {
         const Stage& st = v->stages[si];
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
             const int P = b.res * b.res;
-            if ((r = conv3_bwd(v, b.c2, g, true, b.res, t1, s))) return r;               // d a2
-            if ((r = gn_bwd(v, b.n2, t1, b.h1, nullptr, t2, P, 1, s))) return r;          // d h1
-            if ((r = conv3_bwd(v, b.c1, t2, true, b.res, t1, s))) return r;              // d a1
-            const float* add = g;
+            if ((r = conv3_bwd(v, b.c2, g.b, false, b.res, t1.f, s))) return r;                // d a2
+            if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, t2.f, t2.b, P, 1, s))) return r;     // d h1
+            if ((r = conv3_bwd(v, b.c1, t2.b, false, b.res, t1.f, s))) return r;               // d a1
+            const float* add = g.f;
             if (b.has_sc) {
-                GemmDesc d; d.A = g; d.a_is_f32 = 1; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
-                d.out_f32 = t2; d.ldc_f32 = b.Cin;
+                GemmDesc d; d.A = g.b; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
+                d.out_f32 = t2.f; d.ldc_f32 = b.Cin;
                 if ((r = vg(v, d, s))) return r;
-                add = t2;
+                add = t2.f;
             }
-            // dx = GN1_bwd(d a1) + shortcut grad ; write into a buffer that is not `add` or `t1`
-            float* dst = (add == g) ? t2 : g;
-            if ((r = gn_bwd(v, b.n1, t1, b.x_in, add, dst, P, 1, s))) return r;
-            if (dst != g) std::swap(g, t2);
+            // dx = GN1_bwd(d a1) + shortcut grad ; written into a buffer that is neither `add` nor `t1`
+            GB& dst = (add == g.f) ? t2 : g;
+            if ((r = gn_bwd(v, b.n1, t1.f, b.x_in, add, dst.f, dst.b, P, 1, s))) return r;
+            if (&dst != &g) std::swap(g, t2);
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
             const int P = b.res * b.res, C = b.C;
-            {   GemmDesc d; d.A = g; d.a_is_f32 = 1; d.lda = C; d.B = b.proj.WT; d.ldb = C; d.M = P; d.N = C; d.K = C;
+            {   GemmDesc d; d.A = g.b; d.lda = C; d.B = b.proj.WT; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.out_bf16 = v->tA; d.ldc_bf16 = C;                                      // tA = d o [P, C]
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tA; d.lda = C; d.B = b.qkvb + 2 * C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
@@ -410,22 +436,22 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
                 d.out_bf16 = v->dqkv + 2 * C; d.ldc_bf16 = 3 * C;                       // dv = P^T do
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
-                d.out_f32 = t1; d.ldc_f32 = C;                                           // d GN(x)
+                d.out_f32 = t1.f; d.ldc_f32 = C;                                         // d GN(x)
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = gn_bwd(v, b.n, t1, b.x_in, g, t2, P, 0, s))) return r;
+            if ((r = gn_bwd(v, b.n, t1.f, b.x_in, g.f, t2.f, t2.b, P, 0, s))) return r;
             std::swap(g, t2);
         } else {
             UpBlock& b = v->ups[st.idx];
-            if ((r = conv3_bwd(v, b.c, g, true, b.res_out, t1, s))) return r;            // d up(x) at high res
-            if ((r = prx_upsample2x_bwd(t1, t2, 1, b.res_out / 2, b.res_out / 2, b.C, s))) return r;
+            if ((r = conv3_bwd(v, b.c, g.b, false, b.res_out, t1.f, s))) return r;       // d up(x) at high res
+            if ((r = prx_upsample2x_bwd(t1.f, t2.f, t2.b, 1, b.res_out / 2, b.res_out / 2, b.C, s))) return r;
             std::swap(g, t2);
         }
     }
     // conv_in, post_quant_conv, straight-through VQ (ReplaceGrad, vqgan.py:48-58)
-    if ((r = conv3_bwd(v, v->conv_in, g, true, v->h0, t1, s))) return r;
+    if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, t1.f, s, v->dpq_bf))) return r;
     const int P0 = v->h0 * v->w0;
-    {   GemmDesc d; d.A = t1; d.a_is_f32 = 1; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
-        d.out_f32 = t2; d.ldc_f32 = v->D;
+    {   GemmDesc d; d.A = v->dpq_bf; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
+        d.out_f32 = t2.f; d.ldc_f32 = v->D;
         if ((r = vg(v, d, s))) return r; }
-    return prx_nhwc_to_nchw(t2, v->D, dz, 1, v->D, P0, s);
+    return prx_nhwc_to_nchw(t2.f, v->D, dz, 1, v->D, P0, s);
 }

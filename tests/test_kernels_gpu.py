@@ -19,6 +19,14 @@ def stream():
     return _lib.current_stream()
 
 
+@pytest.fixture(params=[1, 0], ids=["glds_v2", "regstage_v1"])
+def gemm_variant(request):
+    """both GEMM kernels: direct-to-LDS (default) and register-staged"""
+    _lib.load().prx_gemm_variant(request.param)
+    yield request.param
+    _lib.load().prx_gemm_variant(1)
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 
@@ -63,7 +71,7 @@ def run_gemm(A, Bt, M, N, K, *, a_mode=0, lda=None, H=0, W=0, Cin=0, up=0, alpha
     (3200, 768, 768), (3200, 2304, 768), (3136, 768, 3072), (3200, 3072, 768), (64, 512, 768),
     (65536, 128, 1152), (100, 72, 136),               # ragged M/N, K not a multiple of 64
 ])
-def test_gemm_rowmajor_bf16(M, N, K):
+def test_gemm_rowmajor_bf16(M, N, K, gemm_variant):
     torch.manual_seed(M + N + K)
     A = bf(torch.randn(M, K, device=DEV))
     # asymmetric B (rule: transpose-detecting)
@@ -75,7 +83,7 @@ def test_gemm_rowmajor_bf16(M, N, K):
     assert torch.isfinite(out).all()
 
 
-def test_gemm_f32_A_and_epilogues():
+def test_gemm_f32_A_and_epilogues(gemm_variant):
     torch.manual_seed(0)
     M, N, K = 3200, 768, 3072
     A32 = torch.randn(M, K, device=DEV)
@@ -107,7 +115,7 @@ def test_gemm_f32_A_and_epilogues():
     (16, 16, 256, 512, 0, 1), (32, 32, 512, 256, 1, 1), (64, 64, 128, 128, 0, 1), (8, 12, 32, 40, 1, 2),
     (256, 256, 128, 128, 0, 1), (64, 64, 8, 128, 0, 1),
 ])
-def test_gemm_conv3x3(H, W, Cin, Cout, up, NB):
+def test_gemm_conv3x3(H, W, Cin, Cout, up, NB, gemm_variant):
     """implicit-GEMM 3x3/pad-1 conv on NHWC (optionally through a fused nearest-2x upsample)"""
     torch.manual_seed(H * W + Cin)
     hin, win = (H // 2, W // 2) if up else (H, W)

@@ -34,9 +34,12 @@ def bench(M, N, K, conv=None, iters=20):
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
-    for (M, N, K) in [(3200, 2304, 768), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (3136, 768, 3072),
-                      (4096, 4096, 4096), (8192, 8192, 8192)]:
-        bench(M, N, K)
-    for (H, C, Co, up) in [(16, 512, 512, 0), (32, 512, 512, 1), (64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0),
-                           (256, 128, 128, 0), (256, 128, 128, 1)]:
-        bench(H * H, Co, 9 * C, conv=(H, H, C, up))
+  for variant in (0, 1):
+      _lib.load().prx_gemm_variant(variant)
+      print("== variant", "glds_v2" if variant else "regstage_v1")
+      for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (3136, 768, 3072),
+                        (4096, 4096, 4096), (8192, 8192, 8192)]:
+          bench(M, N, K)
+      for (H, C, Co, up) in [(16, 512, 512, 0), (32, 512, 512, 1), (64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0),
+                             (256, 128, 128, 0), (256, 128, 128, 1)]:
+          bench(H * H, Co, 9 * C, conv=(H, H, C, up))
