@@ -163,8 +163,10 @@ int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_st
  * buffers ([3,S,S] f32, [3,S,S] i32, [n_cut,3,S,S] f32). */
 int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S,
                         float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s);
+/* scratch: g_stage_a and g_pooled_priv are [n_cut,3,S,S] fp32 each, g_pooled is [3,S,S] */
 int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int H, int W, const float* stage_a,
-                         const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s);
+                         const int* argmax, float* g_stage_a, float* g_pooled_priv, float* g_pooled, float* g_img,
+                         prx_stream_t s);
 
 /* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].
  * weights[]: fp32 device tensors in OpenAI state-dict order under `visual.`:

@@ -44,11 +44,13 @@ int prx_cutouts_forward(const float* img, int H, int W, const double* desc, cons
     return prx_warp_b_fwd(stage_a, desc, noise, out, n_cut, S, S_(s));
 }
 int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int H, int W, const float* stage_a,
-                         const int* argmax, float* g_stage_a, float* g_pooled, float* g_img, prx_stream_t s) {
-    PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_pooled && g_img, "prx_cutouts_backward: null argument");
+                         const int* argmax, float* g_stage_a, float* g_pooled_priv, float* g_pooled, float* g_img,
+                         prx_stream_t s) {
+    PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_pooled_priv && g_pooled && g_img,
+                "prx_cutouts_backward: null argument");
     int r;
     if ((r = prx_warp_b_bwd(stage_a, desc, g_out, g_stage_a, n_cut, S, S_(s)))) return r;
-    if ((r = prx_warp_a_bwd(g_stage_a, S, S, desc, g_pooled, n_cut, S, 1, S_(s)))) return r;
+    if ((r = prx_warp_a_bwd(g_stage_a, S, S, desc, g_pooled_priv, g_pooled, n_cut, S, S_(s)))) return r;
     return prx_pool_bwd(g_pooled, argmax, g_img, 3, H, W, S, S_(s));
 }
 

@@ -4,7 +4,7 @@
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s);
 int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s);
 int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int S, hipStream_t s);
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc, int n_cut, int S, int zero_first,
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int S,
                    hipStream_t s);
 int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s);
 int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s);

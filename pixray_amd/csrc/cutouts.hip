@@ -302,26 +302,98 @@ __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict
     }
 }
 
+// ---- backward scatter with LDS tile staging -----------------------------------------------------------------
+// A block owns a 16x16 tile of destination pixels of ONE cutout.  Its bilinear taps land in a compact window of
+// the source plane, so they are accumulated with ds_add_f32 into an LDS window (WIN x WIN x 3) anchored at the
+// block's minimum tap, and the window is flushed once to HBM (one atomic per touched source pixel instead of
+// four per destination pixel).  Taps that fall outside the window (reflection wrap-around, extreme
+// perspective) go straight to HBM atomics, so the result never depends on the window size.
+constexpr int TILE_W = 16;
+constexpr int WIN = 48;
+
+struct ScatterWin {
+    float acc[3][WIN][WIN];
+    int org[2];
+};
+
+__device__ __forceinline__ void win_begin(ScatterWin& w, bool has_taps, const Taps& t) {
+    if (threadIdx.x == 0) { w.org[0] = 0x7fffffff; w.org[1] = 0x7fffffff; }
+    for (int i = threadIdx.x; i < 3 * WIN * WIN; i += 256) (&w.acc[0][0][0])[i] = 0.f;
+    __syncthreads();
+    if (has_taps) {
+        atomicMin(&w.org[0], max(t.x0, 0));
+        atomicMin(&w.org[1], max(t.y0, 0));
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void win_add(ScatterWin& w, float* __restrict__ plane, int W, int c, int x, int y, float v) {
+    const int lx = x - w.org[0], ly = y - w.org[1];
+    if (lx >= 0 && lx < WIN && ly >= 0 && ly < WIN) atomicAdd(&w.acc[c][ly][lx], v);
+    else atomicAdd(&plane[y * W + x], v);
+}
+__device__ __forceinline__ void win_scatter(ScatterWin& w, float* __restrict__ plane, int W, int c, const Taps& t, float g) {
+    if (t.vx0 && t.vy0) win_add(w, plane, W, c, t.x0, t.y0, g * (1.f - t.wx) * (1.f - t.wy));
+    if (t.vx1 && t.vy0) win_add(w, plane, W, c, t.x0 + 1, t.y0, g * t.wx * (1.f - t.wy));
+    if (t.vx0 && t.vy1) win_add(w, plane, W, c, t.x0, t.y0 + 1, g * (1.f - t.wx) * t.wy);
+    if (t.vx1 && t.vy1) win_add(w, plane, W, c, t.x0 + 1, t.y0 + 1, g * t.wx * t.wy);
+}
+// flush the window into the 3 planes at `base` (plane stride Hs*Ws)
+__device__ __forceinline__ void win_flush(ScatterWin& w, float* __restrict__ base, int Hs, int Ws) {
+    __syncthreads();
+    const int ox = w.org[0], oy = w.org[1];
+    if (ox == 0x7fffffff) return;
+    for (int i = threadIdx.x; i < 3 * WIN * WIN; i += 256) {
+        const float v = (&w.acc[0][0][0])[i];
+        if (v == 0.f) continue;
+        const int c = i / (WIN * WIN), r = (i / WIN) % WIN, q = i % WIN;
+        const int x = ox + q, y = oy + r;
+        if (x < Ws && y < Hs) atomicAdd(&base[(size_t)c * Hs * Ws + (size_t)y * Ws + x], v);
+    }
+}
+
+// Stage A backward: g[n][3][S][S] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws]
+// (summed over n afterwards by reduce_planes_kernel: no cross-cutout atomic contention on the shared image)
 __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
                                                          const double* __restrict__ desc, float* __restrict__ gsrc,
                                                          int n_cut, int S) {
-    const size_t total = (size_t)n_cut * S * S;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
-        const double* d = desc + (size_t)n * DESC_WORDS;
-        const int mode = (int)d[D_MODE1];
-        const float* gi = g + ((size_t)n * 3) * S * S + (size_t)y * S + x;
-        if (mode == MODE_IDENT) {
+    __shared__ ScatterWin w;
+    const int tiles = (S + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
+    const int y = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const bool valid = x < S && y < S;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE1];
+    float* gs = gsrc + (size_t)n * 3 * Hs * Ws;
+    const float* gi = g + ((size_t)n * 3) * S * S + (size_t)y * S + x;
+    if (mode == MODE_IDENT) {      // 1:1 copy: each source pixel has exactly one writer
+        if (valid) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&gsrc[(size_t)c * Hs * Ws + (size_t)y * Ws + x], gi[(size_t)c * S * S]);
-            continue;
+            for (int c = 0; c < 3; ++c) gs[(size_t)c * Hs * Ws + (size_t)y * Ws + x] = gi[(size_t)c * S * S];
         }
+        return;
+    }
+    Taps t{};
+    if (valid) {
         float u, v;
         project(d + D_M1, (int)d[D_GRID1], x, y, S, S, Ws, Hs, u, v);
-        Taps t = make_taps(u, v, Ws, Hs, mode);
+        t = make_taps(u, v, Ws, Hs, mode);
+    }
+    win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
+    if (valid) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) scatter_plane(gsrc + (size_t)c * Hs * Ws, Ws, t, gi[(size_t)c * S * S]);
+        for (int c = 0; c < 3; ++c) win_scatter(w, gs + (size_t)c * Hs * Ws, Ws, c, t, gi[(size_t)c * S * S]);
+    }
+    win_flush(w, gs, Hs, Ws);
+}
+
+// out[i] = sum_n planes[n][i]
+__global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restrict__ planes, float* __restrict__ out,
+                                                            int n, size_t plane_elems) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += planes[(size_t)k * plane_elems + i];
+        out[i] = acc;
     }
 }
 
@@ -364,27 +436,31 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, const double* __restrict__ desc,
                                                          const float* __restrict__ g, float* __restrict__ ga, int n_cut,
                                                          int S) {
-    const size_t total = (size_t)n_cut * S * S;
+    __shared__ ScatterWin w;
     const size_t plane = (size_t)S * S;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
-        const double* d = desc + (size_t)n * DESC_WORDS;
-        const int mode = (int)d[D_MODE2];
-        const float* an = a + (size_t)n * 3 * plane;
-        float* gan = ga + (size_t)n * 3 * plane;
-        const size_t pix = (size_t)y * S + x;
+    const int tiles = (S + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
+    const int y = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const bool valid = x < S && y < S;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE2];
+    const float* an = a + (size_t)n * 3 * plane;
+    float* gan = ga + (size_t)n * 3 * plane;
+    const size_t pix = (size_t)y * S + x;
+    Taps t{};
+    float grgb[3] = {0.f, 0.f, 0.f};
+    if (valid) {
         float gin[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gin[c] = g[(size_t)n * 3 * plane + c * plane + pix];
-        Taps t{};
-        float grgb[3] = {gin[0], gin[1], gin[2]};
-        const bool jit = d[D_JIT] != 0.0;
+        grgb[0] = gin[0]; grgb[1] = gin[1]; grgb[2] = gin[2];
         if (mode != MODE_IDENT) {
             float u, v;
             project(d + D_M2, (int)d[D_GRID2], x, y, S, S, S, S, u, v);
             t = make_taps(u, v, S, S, mode);
         }
-        if (jit) {
+        if (d[D_JIT] != 0.0) {
             Dual<3> rgb[3];
             const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
 #pragma unroll
@@ -396,14 +472,20 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 3; ++i) grgb[i] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
         }
-        if (mode == MODE_IDENT) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&gan[c * plane + pix], grgb[c]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) scatter_plane(gan + c * plane, S, t, grgb[c]);
-        }
     }
+    if (mode == MODE_IDENT) {      // 1:1: one writer per source pixel
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gan[c * plane + pix] = grgb[c];
+        }
+        return;
+    }
+    win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) win_scatter(w, gan + c * plane, S, c, t, grgb[c]);
+    }
+    win_flush(w, gan, S, S);
 }
 
 // ------------------------------------------------------------------ batch min/max + CLIP normalise + patchify
@@ -495,9 +577,12 @@ __global__ __launch_bounds__(256) void patchify_bwd_reduce_kernel(const float* _
         cmin += (xv == mn); cmax += (xv == mx);
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); cmin = wave_sum_d(cmin); cmax = wave_sum_d(cmax);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&acc[0], s1); atomicAdd(&acc[1], s2); atomicAdd(&acc[2], cmin); atomicAdd(&acc[3], cmax);
-    }
+    __shared__ double red[4][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = s1; red[wv][1] = s2; red[wv][2] = cmin; red[wv][3] = cmax; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        atomicAdd(&acc[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // g_cut = g_y/range + [x==min]*gmin/cnt_min + [x==max]*gmax/cnt_max   (slip.py:21-36 backward)
@@ -548,11 +633,15 @@ int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* 
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc, int n_cut, int S, int zero_first,
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int S,
                    hipStream_t s) {
-    if (zero_first) PRX_CHECK_HIP(hipMemsetAsync(gsrc, 0, sizeof(float) * 3 * Hs * Ws, s));
-    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, g, Hs, Ws, desc, gsrc,
-                       n_cut, S);
+    // gsrc_priv: [n_cut][3][Hs][Ws] per-cutout private planes (scratch); gsrc: [3][Hs][Ws] their sum
+    PRX_CHECK_HIP(hipMemsetAsync(gsrc_priv, 0, sizeof(float) * (size_t)n_cut * 3 * Hs * Ws, s));
+    const int tiles = (S + TILE_W - 1) / TILE_W;
+    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, gsrc_priv, n_cut, S);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
+                       (size_t)3 * Hs * Ws);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -564,7 +653,8 @@ int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float
 }
 int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * S * S, s));
-    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, g, ga, n_cut, S);
+    const int tiles = (S + TILE_W - 1) / TILE_W;
+    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, a, desc, g, ga, n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -585,7 +675,7 @@ int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S,
 int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,
                             hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
-    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 2048)), dim3(256), 0, s,
+    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 512)), dim3(256), 0, s,
                        cut, mm, dA, acc, N, S, P, T);
     PRX_LAUNCH_CHECK();
     return 0;

@@ -20,6 +20,7 @@ constexpr int LDS_LD = BK + 8;  // elements; 144-byte rows
 struct GemmArgs {
     GemmDesc d;
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
+    int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     float* ws;
 };
 
@@ -45,6 +46,38 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     }
     if (d.out_f32) d.out_f32[(size_t)row * d.ldc_f32 + col] = v;
     if (d.out_bf16) d.out_bf16[(size_t)row * d.ldc_bf16 + col] = f32_to_bf16(v);
+}
+
+// 4 consecutive columns at once (all pointers / leading dimensions checked 16-byte friendly by the host)
+__device__ __forceinline__ void epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
+    v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
+    if (d.bias_n) {
+        const float4 b = *reinterpret_cast<const float4*>(d.bias_n + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (d.bias_m) { const float b = d.bias_m[row]; v.x += b; v.y += b; v.z += b; v.w += b; }
+    if (d.act == PRX_ACT_MUL_DQUICKGELU) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(d.aux + (size_t)row * d.ldaux + col);
+        v.x *= dquickgelu_f((float)t[0]); v.y *= dquickgelu_f((float)t[1]);
+        v.z *= dquickgelu_f((float)t[2]); v.w *= dquickgelu_f((float)t[3]);
+    }
+    if (d.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (d.act == PRX_ACT_QUICKGELU) {
+        bf16x4 pre;
+        pre[0] = (bf16_t)v.x; pre[1] = (bf16_t)v.y; pre[2] = (bf16_t)v.z; pre[3] = (bf16_t)v.w;
+        if (d.out_bf16_pre) *reinterpret_cast<bf16x4*>(d.out_bf16_pre + (size_t)row * d.ldc_bf16 + col) = pre;
+        v.x = quickgelu_f((float)pre[0]); v.y = quickgelu_f((float)pre[1]);
+        v.z = quickgelu_f((float)pre[2]); v.w = quickgelu_f((float)pre[3]);
+    }
+    if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + (size_t)row * d.ldc_f32 + col) = v;
+    if (d.out_bf16) {
+        bf16x4 o;
+        o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+        *reinterpret_cast<bf16x4*>(d.out_bf16 + (size_t)row * d.ldc_bf16 + col) = o;
+    }
 }
 
 template <typename TA>
@@ -379,6 +412,42 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
         __syncthreads();
     }
 
+    if (p.vec_epi) {
+        // Epilogue through LDS: the MFMA C layout holds one column per lane (2- or 4-byte scattered stores);
+        // staging each wave's 32 x (BN/2) slab row-major lets every lane handle 4 consecutive columns, so bias /
+        // residual / aux loads and all stores are 8-16-byte coalesced accesses.
+        constexpr int CW = BN / 2;            // columns of the wave tile
+        constexpr int LDW = CW + 4;           // padded row (floats), keeps rows 16-byte aligned
+        constexpr int LPR = CW / 4;           // lanes per row
+        constexpr int RPP = 64 / LPR;         // rows per pass
+        float* stage = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
+        const int rbase = tm * BM + wm * (BM / 2);
+        const int cbase = tn * BN + wn * (BN / 2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDW + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += RPP) {
+                const int lr = rr + lane / LPR;
+                const int lc = (lane % LPR) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
+                const int row = rbase + i * 32 + lr, col = cbase + lc;
+                if (row < d.M && col < d.N) {
+                    if (p.splits > 1)
+                        *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
+                    else
+                        epilogue_store4(d, row, col, v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int row0 = tm * BM + wm * (BM / 2) + 4 * (lane >> 5);
     const int col0 = tn * BN + wn * (BN / 2) + (lane & 31);
 #pragma unroll
@@ -402,6 +471,20 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const GemmDesc& d = p.d;
     const size_t total = (size_t)d.M * d.N;
+    if (p.vec_epi) {
+        const size_t total4 = total >> 2;
+        for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < p.splits; ++s) {
+                const float4 w = reinterpret_cast<const float4*>(p.ws + (size_t)s * total)[i4];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            const size_t idx = i4 << 2;
+            const int row = (int)(idx / d.N);
+            epilogue_store4(d, row, (int)(idx - (size_t)row * d.N), v);
+        }
+        return;
+    }
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         float v = 0.f;
@@ -513,6 +596,11 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
         if (splits < 1) splits = 1;
     }
+    auto al = [](const void* p, size_t a_) { return p == nullptr || ((uintptr_t)p % a_) == 0; };
+    a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && (d.resid == nullptr || d.ldr % 4 == 0) &&
+                al(d.aux, 8) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
+                (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, 8) && al(d.out_bf16_pre, 8) &&
+                ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;

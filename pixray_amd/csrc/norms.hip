@@ -60,27 +60,39 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs a) {
         be = reinterpret_cast<const float4*>(a.beta)[cq];
     }
     float s0 = 0.f, s1 = 0.f;
-    if (pl < ppb) {
-        for (int p = blockIdx.x * ppb + pl; p < a.P; p += gridDim.x * ppb) {
-            float4 v = x4[(size_t)p * C4 + cq];
-            if (MODE == 0) {
-                s0 += (v.x + v.y) + (v.z + v.w);
-                s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            } else {
-                float4 gg = g4[(size_t)p * C4 + cq];
-                float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
-                float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+    auto accum = [&](const float4& v, const float4& gg) {
+        if (MODE == 0) {
+            s0 += (v.x + v.y) + (v.z + v.w);
+            s1 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+            float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+            float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float xh = (xv[i] - mean) * rstd;
-                    float gy = gv[i];
-                    if (a.swish) gy *= swish_grad(xh * gav[i] + bev[i]);
-                    float dxh = gy * gav[i];
-                    s0 += dxh;
-                    s1 += dxh * xh;
-                }
+            for (int i = 0; i < 4; ++i) {
+                float xh = (xv[i] - mean) * rstd;
+                float gy = gv[i];
+                if (a.swish) gy *= swish_grad(xh * gav[i] + bev[i]);
+                float dxh = gy * gav[i];
+                s0 += dxh;
+                s1 += dxh * xh;
             }
         }
+    };
+    {
+        const int stride = gridDim.x * ppb;
+        int p = blockIdx.x * ppb + pl;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; p + 3 * stride < a.P; p += 4 * stride) {      // 4 independent loads in flight per thread
+            float4 v0 = x4[(size_t)p * C4 + cq], v1 = x4[(size_t)(p + stride) * C4 + cq];
+            float4 v2 = x4[(size_t)(p + 2 * stride) * C4 + cq], v3 = x4[(size_t)(p + 3 * stride) * C4 + cq];
+            float4 g0 = z4, g1 = z4, g2 = z4, g3 = z4;
+            if (MODE) {
+                g0 = g4[(size_t)p * C4 + cq]; g1 = g4[(size_t)(p + stride) * C4 + cq];
+                g2 = g4[(size_t)(p + 2 * stride) * C4 + cq]; g3 = g4[(size_t)(p + 3 * stride) * C4 + cq];
+            }
+            accum(v0, g0); accum(v1, g1); accum(v2, g2); accum(v3, g3);
+        }
+        for (; p < a.P; p += stride) accum(x4[(size_t)p * C4 + cq], MODE ? g4[(size_t)p * C4 + cq] : z4);
     }
     __shared__ float red[256][2];
     red[threadIdx.x][0] = s0;
@@ -282,13 +294,13 @@ int gn_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 40
 }  // namespace
 
 int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, double* stats, bf16_t* out_bf16,
-                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s) {
+                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats) {
     PRX_REQUIRE(C % 32 == 0 && (C / 32) % 4 == 0 && 256 % (C / 4) == 0, "groupnorm: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.gamma = gamma; a.beta = beta; a.stats = stats; a.P = P; a.C = C; a.swish = swish; a.eps = eps;
-    PRX_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * NB * 64, s));
+    if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * NB * 64, s));
     const int ppb = 256 / (C / 4);
-    int blocks = std::min(ceil_div(P, ppb * 8), 1024);
+    int blocks = std::min(ceil_div(P, ppb * 4), 256);   // <= one block per CU: few (contended) double atomics
     hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(blocks, NB), dim3(256), 0, s, a);
     PRX_LAUNCH_CHECK();
     if (out_bf16 || out_f32) {
@@ -301,14 +313,14 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
 
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
-                      float eps, hipStream_t s) {
+                      float eps, hipStream_t s, int zero_stats) {
     PRX_REQUIRE(256 % (C / 4) == 0 && (C / 32) % 4 == 0, "groupnorm bwd: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.g = g; a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.stats = bstats;
     a.P = P; a.C = C; a.swish = swish; a.eps = eps;
-    PRX_CHECK_HIP(hipMemsetAsync(bstats, 0, sizeof(double) * NB * 64, s));
+    if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(bstats, 0, sizeof(double) * NB * 64, s));
     const int ppb = 256 / (C / 4);
-    int blocks = std::min(ceil_div(P, ppb * 8), 1024);
+    int blocks = std::min(ceil_div(P, ppb * 4), 256);
     hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(blocks, NB), dim3(256), 0, s, a);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,

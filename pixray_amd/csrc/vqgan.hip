@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void colminmax_kernel(const float* __restrict_
 
 struct Conv3 { int Cin, Cout, CoP; bf16_t *Wf, *Wd; float* b; };
 struct Conv1 { int Cin, Cout; bf16_t *W, *WT; float* b; };
-struct GN { int C; float *g, *b; double* stats; };
+struct GN { int C; float *g, *b; double *stats, *bstats; int id; };
 
 struct ResBlock {
     int Cin, Cout, res;
@@ -86,7 +86,7 @@ struct PrxVqgan {
     bf16_t *tA, *tB, *tC, *tD, *dqkv, *dy8;  // attention temporaries [P*C max], dgrad head input
     float *S, *g0, *g1, *g2; // score matrix; gradient ping-pong buffers (max P*C)
     bf16_t *g0b, *g1b, *g2b; // their bf16 twins (dgrad GEMM operands)
-    double* bstats;
+    double* all_stats; int n_gn;   // [n_gn][64] forward stats followed by [n_gn][64] backward stats
     float* ws; size_t ws_bytes;
     float* x_last;  // input of norm_out
 };
@@ -116,7 +116,8 @@ int make_gn(PrxVqgan* v, GN& g, int C, WCursor& cur, hipStream_t s) {
     int r;
     if ((r = copyf(v, &g.g, w, C, s))) return r;
     if ((r = copyf(v, &g.b, b, C, s))) return r;
-    VALLOC(g.stats, 64);
+    g.id = v->n_gn++;
+    g.stats = g.bstats = nullptr;   // assigned once every GroupNorm is known
     return 0;
 }
 int make_conv3(PrxVqgan* v, Conv3& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
@@ -200,7 +201,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     PRX_REQUIRE(embed_dim == z_channels, "vqgan_create: embed_dim must equal z_channels");
     PrxVqgan* v = new PrxVqgan();
     std::unique_ptr<PrxVqgan> guard(v);
-    v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
+    v->n_gn = 0; v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
     WCursor cur{w, n_w, 0};
     int r;
     const float* cb; NEXTW(cur, cb);
@@ -268,7 +269,13 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
         }
         VALLOC(*slot, cnt);
     }
-    VALLOC(v->bstats, 64);
+    {   // one contiguous stats slab: forward stats of every GroupNorm, then the backward stats
+        VALLOC(v->all_stats, (size_t)2 * v->n_gn * 64);
+        auto fix = [&](GN& g) { g.stats = v->all_stats + (size_t)g.id * 64; g.bstats = v->all_stats + (size_t)(v->n_gn + g.id) * 64; };
+        for (auto& b : v->res) { fix(b.n1); fix(b.n2); }
+        for (auto& b : v->attn) fix(b.n);
+        fix(v->norm_out);
+    }
     v->ws_bytes = (size_t)64 << 20;
     VALLOC(v->ws, v->ws_bytes / sizeof(float));
     *out = guard.release();
@@ -301,11 +308,11 @@ static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, i
     return vg(v, d, s);
 }
 static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s) {
-    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s);
+    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0);
 }
 static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
                   bf16_t* dx_bf, int P, int swish, hipStream_t s) {
-    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, v->bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s);
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -318,6 +325,7 @@ int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) 
 int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, int quantize, hipStream_t s) {
     const int P0 = v->h0 * v->w0;
     int r;
+    PRX_CHECK_HIP(hipMemsetAsync(v->all_stats, 0, sizeof(double) * (size_t)v->n_gn * 64, s));   // all forward GN stats
     if (quantize) {
         if ((r = prx_vq_nearest(z, 1, P0, v->codebook, v->cnorm, P0, v->NC, v->D, v->pmin, v->pidx, v->idx, v->zq, s))) return r;
         if (indices) PRX_CHECK_HIP(hipMemcpyAsync(indices, v->idx, sizeof(int) * P0, hipMemcpyDeviceToDevice, s));
@@ -389,6 +397,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     const int PH = v->H * v->W;
     int r;
     PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
+    PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
     if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
     struct GB { float* f; bf16_t* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};

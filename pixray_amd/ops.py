@@ -61,9 +61,10 @@ class _MakeCutoutsFn(torch.autograd.Function):
         g = g.contiguous().float()
         dev = g.device
         g_a = torch.empty(n, 3, S, S, device=dev)
+        g_priv = torch.empty(n, 3, S, S, device=dev)
         g_pooled = torch.empty(3, S, S, device=dev)
         g_img = torch.empty(1, 3, H, W, device=dev)
-        call("prx_cutouts_backward", g, desc, n, S, H, W, stage_a, argmax, g_a, g_pooled, g_img, _stream())
+        call("prx_cutouts_backward", g, desc, n, S, H, W, stage_a, argmax, g_a, g_priv, g_pooled, g_img, _stream())
         return g_img, None, None, None
 
 
