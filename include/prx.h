@@ -219,6 +219,8 @@ int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t 
 
 /* A/B switch between the two GEMM kernels (1 = direct-to-LDS v2, default; 0 = register-staged v1) */
 void prx_gemm_variant(int use_glds);
+/* tuning override of the tile / split-K heuristic: bm,bn in {(128,128),(128,64),(64,64)}; (0,0,0) = heuristic */
+void prx_gemm_tile_override(int bm, int bn, int splits);
 
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
 void prx_profile_gemm_enable(int on);

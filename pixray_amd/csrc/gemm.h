@@ -42,5 +42,6 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
 // Per-launch timing hook used by bench.py's roofline leg (HIP events on the
 // launch stream).  When enabled every prx_gemm_launch is bracketed by events.
 void prx_gemm_set_variant(int use_glds);   // 1 (default): direct-to-LDS v2 kernel for bf16 A; 0: register-staged v1
+void prx_gemm_force_tile(int bm, int bn, int splits);   // tuning override; (0,0,0) restores the heuristic
 void prx_gemm_profile_enable(int on);
 int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches);

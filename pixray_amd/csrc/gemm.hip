@@ -536,12 +536,14 @@ const bf16_t* zero_page_for_current_device() {
 struct ProfRec { hipEvent_t a, b; double flop; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
-bool g_use_glds = true;   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
+bool g_use_glds = true;
+int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
 
 }  // namespace
 
 void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
+void prx_gemm_force_tile(int bm, int bn, int splits) { g_force_bm = bm; g_force_bn = bn; g_force_splits = splits; }
 
 void prx_gemm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -577,13 +579,26 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     }
     PRX_REQUIRE(d.act != PRX_ACT_MUL_DQUICKGELU || d.aux, "gemm: MUL_DQUICKGELU needs aux");
 
-    // ---- tile / split-K selection -------------------------------------------
-    const int target_blocks = 256;  // one per CU
+    // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
+    // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the
+    // per-tile efficiency (bigger wave tiles do more MFMA per LDS byte).
+    const int n_cu = 256;
     int BM = 128, BN = 128;
     auto ntiles = [&](int bm, int bn) { return ceil_div(d.M, bm) * ceil_div(d.N, bn); };
-    if (ntiles(128, 128) < 2 * target_blocks) { BM = 128; BN = 64; }
-    if (BN == 64 && ntiles(128, 64) < 2 * target_blocks) { BM = 64; BN = 64; }
-    if (d.N <= 64) { BN = 64; if (BM == 128 && ntiles(128, 64) < target_blocks) BM = 64; }
+    {
+        struct Cand { int bm, bn, per_cu; double eff; };
+        const Cand cands[3] = {{128, 128, 2, 1.0}, {128, 64, 3, 0.85}, {64, 64, 5, 0.75}};
+        double best = -1.0;
+        for (const Cand& c : cands) {
+            if (d.N <= 64 && c.bn > 64) continue;
+            const int t = ntiles(c.bm, c.bn);
+            const int slots = n_cu * c.per_cu;
+            const double fill = (double)t / ((double)ceil_div(t, slots) * slots);
+            const double score = fill * c.eff;
+            if (score > best) { best = score; BM = c.bm; BN = c.bn; }
+        }
+    }
+    if (g_force_bm) { BM = g_force_bm; BN = g_force_bn; }
     GemmArgs a;
     a.d = d;
     a.tiles_m = ceil_div(d.M, BM);
@@ -591,16 +606,20 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     a.kt_total = ceil_div(d.K, BK);
     int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (ws && tiles < target_blocks && a.kt_total >= 8) {
-        splits = std::min(std::min(ceil_div(2 * target_blocks, tiles), a.kt_total / 4), 32);
+    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16) {
+        // few tiles, long K (the 16x16 / 32x32 decoder convs): aim at ~320 blocks, >= 4 K tiles per split
+        splits = std::max(1, std::min(std::min((320 + tiles / 2) / tiles, a.kt_total / 4), 32));
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
-        if (splits < 1) splits = 1;
     }
     auto al = [](const void* p, size_t a_) { return p == nullptr || ((uintptr_t)p % a_) == 0; };
     a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && (d.resid == nullptr || d.ldr % 4 == 0) &&
                 al(d.aux, 8) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
                 (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, 8) && al(d.out_bf16_pre, 8) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
+    if (g_force_splits > 0 && ws) {
+        splits = std::min(g_force_splits, a.kt_total);
+        while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
+    }
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;
