@@ -17,17 +17,56 @@ import torch
 from . import clip_vit_ref, cutouts_ref, prompt_ref, vqgan_ref
 
 
-class OraclePerceptor:
-    """CLIP_Base-shaped wrapper over the oracle tower (CPU)."""
+class _ShardedMinMaxNorm(torch.autograd.Function):
+    """(x - min)/(max - min) with min/max taken over the cutouts of ALL ranks (slip.py:21-36 on a sharded batch).
+    Same protocol as the HIP path (ops._ClipEncodeFn): all-reduce MIN/MAX forward; backward all-reduces
+    {sum g, sum g*y, #argmin, #argmax} so the gradient through min/max lands on the owning rank's pixels."""
 
-    def __init__(self, cfg, params):
-        self.cfg, self.params = cfg, params
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        mm = torch.stack([-x.min(), x.max()])
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+        mn, mx = -mm[0], mm[1]
+        rng = mx - mn
+        y = (x - mn) / rng if rng != 0 else x - mn
+        ctx.save_for_backward(x, y, mn, mx)
+        ctx.group = group
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        x, y, mn, mx = ctx.saved_tensors
+        rng = mx - mn
+        if rng == 0:
+            return g, None
+        acc = torch.stack([g.double().sum(), (g.double() * y.double()).sum(), (x == mn).double().sum(),
+                           (x == mx).double().sum()])
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=ctx.group)
+        gmin = ((acc[1] - acc[0]) / rng / acc[2].clamp(min=1)).to(g.dtype)
+        gmax = (-acc[1] / rng / acc[3].clamp(min=1)).to(g.dtype)
+        return g / rng + (x == mn) * gmin + (x == mx) * gmax, None
+
+
+class OraclePerceptor:
+    """CLIP_Base-shaped wrapper over the oracle tower (CPU). With `group`, the batch-global min/max renorm spans
+    the cutouts of every rank."""
+
+    def __init__(self, cfg, params, group=None):
+        self.cfg, self.params, self.group = cfg, params, group
         self.input_resolution, self.output_dim = cfg.input_resolution, cfg.output_dim
 
     def encode_image(self, imgs, input_range=None, apply_preprocess=True):
         c = self.cfg
-        return clip_vit_ref.encode_image(self.params, imgs, patch=c.patch_size, heads=c.heads, layers=c.layers,
-                                         apply_preprocess=apply_preprocess)
+        if self.group is None:
+            return clip_vit_ref.encode_image(self.params, imgs, patch=c.patch_size, heads=c.heads, layers=c.layers,
+                                             apply_preprocess=apply_preprocess)
+        x = _ShardedMinMaxNorm.apply(imgs, self.group)
+        mean = torch.tensor(clip_vit_ref.CLIP_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+        std = torch.tensor(clip_vit_ref.CLIP_STD, dtype=x.dtype).view(1, 3, 1, 1)
+        e = clip_vit_ref.vit_forward(self.params, (x - mean) / std, patch=c.patch_size, heads=c.heads, layers=c.layers)
+        return e / e.norm(dim=-1, keepdim=True)
 
 
 class OracleMakeCutouts(torch.nn.Module):

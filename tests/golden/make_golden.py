@@ -1,0 +1,148 @@
+"""Generate the golden fixtures under tests/golden/ (run in the build container, where /root/reference and
+HF transformers are available):
+
+    python tests/golden/make_golden.py
+
+  prompt_golden.npz     outputs of pixray's OWN Prompt / spherical_dist_loss (pixray.py:249-280), extracted from
+                        /root/reference by AST and executed
+  vq_clamp_golden.npz   outputs of pixray's OWN vector_quantize / ClampWithGrad (vqgan.py:48-79), same way
+  clip_vit_golden.npz   an independent implementation of OpenAI's VisionTransformer (HF CLIPVisionModelWithProjection,
+                        hidden_act=quick_gelu) on the seeded weights of pixray_amd.weights
+  decoder_golden.npz    an independent implementation of taming's Decoder (HF JanusVQVAEDecoder, derived from taming)
+                        on the seeded weights of pixray_amd.weights
+Weights are NOT stored: they are re-derived from the seeds by pixray_amd.weights.synthetic_*.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import _refextract as rx  # noqa: E402
+from pixray_amd import weights  # noqa: E402
+
+GOLDEN_CLIP = weights.ClipVitConfig("golden-tiny", 64, 16, 256, 2, 4, 64)
+GOLDEN_VQ = weights.VqganConfig(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=16,
+                                z_channels=128, embed_dim=128, n_embed=256)
+
+
+def hf_clip_from_params(cfg, p):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    hc = CLIPVisionConfig(hidden_size=cfg.width, intermediate_size=4 * cfg.width, num_hidden_layers=cfg.layers,
+                          num_attention_heads=cfg.heads, image_size=cfg.input_resolution, patch_size=cfg.patch_size,
+                          projection_dim=cfg.output_dim, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                          attention_dropout=0.0)
+    m = CLIPVisionModelWithProjection(hc).eval()
+    sd = {}
+    w = cfg.width
+    sd["vision_model.embeddings.class_embedding"] = p["class_embedding"]
+    sd["vision_model.embeddings.patch_embedding.weight"] = p["conv1.weight"]
+    sd["vision_model.embeddings.position_embedding.weight"] = p["positional_embedding"]
+    sd["vision_model.pre_layrnorm.weight"] = p["ln_pre.weight"]
+    sd["vision_model.pre_layrnorm.bias"] = p["ln_pre.bias"]
+    for i in range(cfg.layers):
+        a, b = f"transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+        wq, wk, wv = p[a + "attn.in_proj_weight"].split(w, 0)
+        bq, bk, bv = p[a + "attn.in_proj_bias"].split(w, 0)
+        for n, (ww, bb) in zip("qkv", ((wq, bq), (wk, bk), (wv, bv))):
+            sd[b + f"self_attn.{n}_proj.weight"] = ww
+            sd[b + f"self_attn.{n}_proj.bias"] = bb
+        sd[b + "self_attn.out_proj.weight"] = p[a + "attn.out_proj.weight"]
+        sd[b + "self_attn.out_proj.bias"] = p[a + "attn.out_proj.bias"]
+        sd[b + "layer_norm1.weight"] = p[a + "ln_1.weight"]; sd[b + "layer_norm1.bias"] = p[a + "ln_1.bias"]
+        sd[b + "layer_norm2.weight"] = p[a + "ln_2.weight"]; sd[b + "layer_norm2.bias"] = p[a + "ln_2.bias"]
+        sd[b + "mlp.fc1.weight"] = p[a + "mlp.c_fc.weight"]; sd[b + "mlp.fc1.bias"] = p[a + "mlp.c_fc.bias"]
+        sd[b + "mlp.fc2.weight"] = p[a + "mlp.c_proj.weight"]; sd[b + "mlp.fc2.bias"] = p[a + "mlp.c_proj.bias"]
+    sd["vision_model.post_layernorm.weight"] = p["ln_post.weight"]
+    sd["vision_model.post_layernorm.bias"] = p["ln_post.bias"]
+    sd["visual_projection.weight"] = p["proj"].T.contiguous()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def hf_decoder_from_params(cfg, p):
+    from transformers.models.janus.configuration_janus import JanusVQVAEConfig
+    from transformers.models.janus.modeling_janus import JanusVQVAEDecoder
+    jc = JanusVQVAEConfig(base_channels=cfg.ch, channel_multiplier=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks,
+                          latent_channels=cfg.z_channels, out_channels=cfg.out_ch, dropout=0.0)
+    d = JanusVQVAEDecoder(jc).eval()
+    nres = len(cfg.ch_mult)
+    sd = {}
+    for k, v in p.items():
+        if not k.startswith("decoder."):
+            continue
+        k2 = k[len("decoder."):]
+        if k2.startswith("up."):
+            parts = k2.split(".")
+            parts[1] = str(nres - 1 - int(parts[1]))      # Janus appends levels in forward order
+            k2 = ".".join(parts)
+        sd[k2] = v
+    d.load_state_dict(sd, strict=True)
+    return d
+
+
+def main():
+    out = HERE
+    # ---- pixray's own fragments ----------------------------------------------------------------------------------
+    ns = rx.pixray_prompt_ns()
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 64, generator=g)
+    e = torch.randn(3, 64, generator=g)
+    rec = {"x": x.numpy(), "embed": e.numpy()}
+    for tag, (w, stop) in {"a": (1.0, float("-inf")), "b": (-0.7, float("-inf")), "c": (2.0, 1.2)}.items():
+        xr = x.clone().requires_grad_(True)
+        loss = ns["Prompt"](e, w, stop)(xr)
+        (gr,) = torch.autograd.grad(loss, xr)
+        rec[f"w_{tag}"] = np.float32(w); rec[f"stop_{tag}"] = np.float32(stop)
+        rec[f"loss_{tag}"] = loss.detach().numpy(); rec[f"grad_{tag}"] = gr.numpy()
+    rec["sdl"] = ns["spherical_dist_loss"](x, e[:1].expand(8, -1)).numpy()
+    np.savez(os.path.join(out, "prompt_golden.npz"), **rec)
+
+    vs = rx.vqgan_ns()
+    xq = torch.randn(1, 4, 4, 16, generator=g)
+    cb = torch.randn(64, 16, generator=g)
+    xr = xq.clone().requires_grad_(True)
+    q = vs["vector_quantize"](xr, cb)
+    gq = torch.randn(1, 4, 4, 16, generator=g)
+    (gx,) = torch.autograd.grad(q, xr, gq)
+    u = torch.randn(2, 3, 8, 8, generator=g) * 0.8 + 0.5
+    ur = u.clone().requires_grad_(True)
+    c = vs["clamp_with_grad"](ur, 0, 1)
+    gc = torch.randn(2, 3, 8, 8, generator=g)
+    (gu,) = torch.autograd.grad(c, ur, gc)
+    np.savez(os.path.join(out, "vq_clamp_golden.npz"), x=xq.numpy(), codebook=cb.numpy(), q=q.detach().numpy(),
+             gq=gq.numpy(), gx=gx.numpy(), u=u.numpy(), c=c.detach().numpy(), gc=gc.numpy(), gu=gu.numpy())
+
+    # ---- independent implementations of the un-vendored towers ---------------------------------------------------
+    p = weights.synthetic_clip_vit_params(GOLDEN_CLIP, 21)
+    m = hf_clip_from_params(GOLDEN_CLIP, p)
+    xin = torch.randn(3, 3, 64, 64, generator=g)
+    xr = xin.clone().requires_grad_(True)
+    emb = m(pixel_values=xr).image_embeds
+    ge = torch.randn(3, 64, generator=g)
+    (gxi,) = torch.autograd.grad(emb, xr, ge)
+    np.savez(os.path.join(out, "clip_vit_golden.npz"), x=xin.numpy(), emb=emb.detach().numpy(), ge=ge.numpy(),
+             gx=gxi.numpy(), seed=np.int64(21))
+
+    pv = weights.synthetic_vqgan_params(GOLDEN_VQ, 22)
+    d = hf_decoder_from_params(GOLDEN_VQ, pv)
+    zq = torch.randn(1, 128, 8, 8, generator=g)
+    zr = zq.clone().requires_grad_(True)
+    img = d(zr)
+    gi = torch.randn(1, 3, 16, 16, generator=g)
+    (gz,) = torch.autograd.grad(img, zr, gi)
+    np.savez(os.path.join(out, "decoder_golden.npz"), z=zq.numpy(), img=img.detach().numpy(), gi=gi.numpy(),
+             gz=gz.numpy(), seed=np.int64(22))
+    for f in sorted(os.listdir(out)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(out, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

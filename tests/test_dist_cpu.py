@@ -1,0 +1,114 @@
+"""CPU tests (no GPU): the N>1 path on the `gloo` backend, world_size 2.
+
+The Session shards the cutout batch over the ranks, all-reduces dL/d(image) before the drawer's backward and takes
+the same optimiser step everywhere.  Here the per-rank arithmetic is supplied by the CPU oracle parts (test
+infrastructure); what is under test is the product's host logic: shard assignment, global-mean loss scaling, the
+image-gradient all-reduce hook, and the batch-global min/max protocol.  The sharded result must equal the
+single-process result on the full batch."""
+import os
+import socket
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(cutn, world, rank, group):
+    from oracle import prompt_ref, step_ref
+    from pixray_amd import cutouts as pc, weights
+    from pixray_amd.engine import Session
+    from pixray_amd.pixel_grid_drawer import PixelGridDrawer
+    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    params = weights.synthetic_clip_vit_params(cfg, 1)
+    st = types.SimpleNamespace(size=(96, 96), pixel_size=(12, 12), pixel_scale=None)
+    drawer = PixelGridDrawer(st)
+    drawer.load_model(st, "cpu")
+    g = torch.Generator().manual_seed(7)
+    drawer.init_from_tensor(torch.rand(1, 3, 96, 96, generator=g) * 2.6 - 1.3)     # some pixels start out of range
+    perceptor = step_ref.OraclePerceptor(cfg, params, group=group)
+
+    def sampler(iteration, fill):
+        gg = torch.Generator().manual_seed(1000 + iteration)
+        prm = pc.sample_cutout_params(cutn, 224, gg, iteration=iteration, fill=fill)
+        prm["noise"] = torch.randn(cutn, 3, 224, 224, generator=gg)
+        return prm
+    mk = step_ref.OracleMakeCutouts(224, cutn, sampler)
+    e = torch.randn(2, cfg.output_dim, generator=g)
+    pm = prompt_ref.Prompt(e, 1.0, float("-inf"))
+    pm.denom = None
+
+    class _P(torch.nn.Module):      # Prompt with the global-mean denominator the Session sets on sharded runs
+        def __init__(self):
+            super().__init__()
+            self.embed, self.denom = e, None
+
+        def forward(self, x):
+            full = prompt_ref.Prompt(e, 1.0, float("-inf"))(x)        # mean over the local pairs
+            if self.denom is None:
+                return full
+            return full * (x.shape[0] * e.shape[0]) / self.denom      # rescale to the global mean
+    return Session(drawer, {"tiny-B/32": perceptor}, {224: mk}, {"tiny-B/32": [_P()]}, learning_rate=0.05, iterations=10,
+                   seed=3, world_size=world, rank=rank, group=group)
+
+
+def _worker(rank, world, port, cutn, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    sess = _build(cutn, world, rank, dist.group.WORLD)
+    for it in range(2):
+        sess.train(it)
+    q.put((rank, sess.drawer.get_z().detach().numpy().copy(), sess.drawer.get_z().grad.detach().numpy().copy(),
+           float(sum(l.detach() for l in sess.last_losses))))      # numpy: pickled by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_matches_single_process():
+    cutn, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cutn, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, full batch
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None)
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    (_, z0, g0, l0), (_, z1, g1, l1) = res
+    z0, g0, z1, g1 = [torch.from_numpy(t) for t in (z0, g0, z1, g1)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    # identical math, different summation order across the shard boundary: fp32 round-off only
+    assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (z0 - z_ref).abs().max().item() < 1e-5
+    # each rank's loss is its share of the global mean; the shares add up to the full-batch loss
+    assert abs((l0 + l1) - float(sum(l.detach() for l in ref.last_losses))) < 1e-5
+
+
+def test_cutn_must_divide_world_size():
+    from pixray_amd.engine import Session
+    with pytest.raises(ValueError):
+        mk = types.SimpleNamespace(cutn=5, shard=None)
+        Session(types.SimpleNamespace(get_opts=lambda d: [], get_z=lambda: None), {}, {224: mk}, {}, world_size=2, rank=0)

@@ -1,0 +1,185 @@
+"""End-to-end parity tests (GPU): the whole iteration of the HIP path, driven through the plugin surface, against the
+CPU oracle on identical seeds and explicit augmentation draws (SURVEY.md §8d "Parity gate"), plus the committed golden
+fixtures and the drop-in behaviour of plugin losses / filters on native tensors.
+
+Stated tolerances for the bf16-operand / fp32-accumulate path: dL/dz rel-L2 <= 2e-2 and cosine >=
+0.999 at the headline config; z after 10 Adam steps: Adam normalises the step, so 1-2% gradient noise can flip the
+direction of near-zero components -- the accumulated *update* must keep cosine >= 0.97 and z itself rel-L2 <= 5e-2.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from oracle import step_ref
+from pixray_amd import api, ops, weights
+from pixray_amd.interfaces import FilterInterface, LossInterface
+
+G = os.path.join(HERE, "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_headline_config_one_iteration_vs_oracle():
+    r = step_ref.compare_one_iteration()            # vqgan 256^2 + ViT-B/32 + 64 cutouts
+    print(r)
+    assert r["indices_equal"]                        # integer work: exact
+    assert r["loss_abs_err"] < 1e-3
+    assert r["image_rel_l2"] < 1e-2 and r["embeds_rel_l2"] < 1e-2
+    assert r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r     # measured 1.3e-2 / 0.99994
+
+
+def test_headline_config_ten_steps_vs_oracle():
+    r = step_ref.compare_k_steps(10)
+    print(r)
+    assert r["z_rel_l2"] < 5e-2, r
+    assert r["dz_total_cosine"] > 0.97, r
+
+
+def test_reduced_config_one_iteration_vs_oracle():
+    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0)
+    assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
+    # a 2-layer random tower on 8 cutouts of a 64x64 image has a much noisier loss surface than the headline config
+    assert r["dz_rel_l2"] < 8e-2 and r["dz_cosine"] > 0.997, r
+
+
+# ------------------------------------------------------------------------------------------- golden fixtures
+def test_prompt_kernel_vs_reference_golden():
+    d = np.load(os.path.join(G, "prompt_golden.npz"))
+    for tag in "abc":
+        x = torch.from_numpy(d["x"]).to(DEV).requires_grad_(True)
+        out = ops.prompt_loss(x, torch.from_numpy(d["embed"]).to(DEV), float(d[f"w_{tag}"]), float(d[f"stop_{tag}"]))
+        (g,) = torch.autograd.grad(out, x)
+        assert abs(out.item() - float(d[f"loss_{tag}"])) < 1e-5
+        assert rel(g, torch.from_numpy(d[f"grad_{tag}"])) < 1e-4
+
+
+def test_clip_tower_vs_independent_golden():
+    import make_golden as mg
+    d = np.load(os.path.join(G, "clip_vit_golden.npz"))
+    cfg = mg.GOLDEN_CLIP
+    p = weights.synthetic_clip_vit_params(cfg, int(d["seed"]))
+    h = ops.ClipVitHandle(cfg, p, max_batch=3, device=DEV)
+    # the golden holds the raw tower output on an already-normalised input; drive the fused path with an input whose
+    # batch min/max are exactly 0/1 after undoing CLIP's mean/std, so preprocessing is the identity up to rounding
+    x = torch.from_numpy(d["x"])
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    u = x * std + mean
+    lo, hi = u.min(), u.max()
+    u01 = ((u - lo) / (hi - lo)).to(DEV)
+    emb = ops.clip_encode_image(u01, h).cpu()
+    # reference: same affine map applied to the golden's input
+    ref_in = ((u - lo) / (hi - lo) - mean) / std
+    from oracle import clip_vit_ref
+    ref = clip_vit_ref.vit_forward(p, ref_in, patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers)
+    ref = ref / ref.norm(dim=-1, keepdim=True)
+    assert rel(emb, ref) < 1e-2
+    # and the oracle itself reproduces the independent implementation on the golden's own input (CPU test pins this too)
+    g_emb = clip_vit_ref.vit_forward(p, x, patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers)
+    assert rel(g_emb, torch.from_numpy(d["emb"])) < 1e-5
+
+
+def test_decoder_vs_independent_golden():
+    import make_golden as mg
+    d = np.load(os.path.join(G, "decoder_golden.npz"))
+    cfg = mg.GOLDEN_VQ
+    p = dict(weights.synthetic_vqgan_params(cfg, int(d["seed"])))
+    p["post_quant_conv.weight"] = torch.eye(cfg.z_channels).reshape(cfg.z_channels, cfg.z_channels, 1, 1)
+    p["post_quant_conv.bias"] = torch.zeros(cfg.z_channels)
+    h = ops.VqganHandle(cfg, p, (8, 8), DEV)
+    z = torch.from_numpy(d["z"]).to(DEV).requires_grad_(True)
+    img = ops.vqgan_synth(z, h, quantize=False)              # decode only: golden has no VQ
+    ref = ((torch.from_numpy(d["img"]) + 1) / 2).clamp(0, 1)
+    assert (img.detach().cpu() - ref).abs().mean().item() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------- plugin surface on the GPU
+class _ColourfulLoss(LossInterface):
+    """a third-party loss written against LossInterface: uses the cutouts, the image and the embeddings"""
+
+    def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+        cut = next(iter(cur_cutouts.values()))
+        assert cut.grad_fn is not None and out.grad_fn is not None and globals["embeds"].grad_fn is not None
+        return [-cut.std() * args.w, out.mean() * 0.1, globals["embeds"].pow(2).mean()]
+
+
+class _Dim(FilterInterface):
+    def forward(self, img):
+        return img * 0.9, (img ** 2).mean() * 0.01
+
+
+def test_custom_loss_and_filter_compose_with_native_ops():
+    args = types.SimpleNamespace(w=0.5)
+    sess = api.build_vqgan_clip_session(size=(64, 64), vqgan_model="tiny_f4", clip_model="tiny-B/32", num_cuts=8,
+                                        custom_losses=[{"loss": _ColourfulLoss(device=DEV), "weight": 1.0}],
+                                        filters=[{"filter": _Dim(None, DEV), "weight": 1.0}])
+    sess.args = args
+    z0 = sess.drawer.get_z_copy()
+    for it in range(3):
+        assert sess.train(it)
+    assert len(sess.last_losses) == 5 and all(torch.isfinite(l) for l in sess.last_losses)
+    assert not torch.equal(sess.drawer.get_z(), z0)
+    zmin, zmax = sess.drawer.z_min, sess.drawer.z_max
+    assert (sess.drawer.get_z() >= zmin).all() and (sess.drawer.get_z() <= zmax).all()      # fused clip_z
+
+
+def test_cutout_shards_reproduce_the_unsharded_gradient():
+    """run N shards sequentially on one GPU; the summed image gradient equals the full batch's.
+    (The batch-global min/max statistics are taken from the full batch, as the all-reduce provides on N GPUs.)"""
+    from pixray_amd import cutouts as pc
+    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    p = weights.synthetic_clip_vit_params(cfg, 2)
+    cutn, S = 8, 224
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 96, 96, generator=g).to(DEV)
+    prm = pc.sample_cutout_params(cutn, S, g)
+    prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    e = torch.randn(1, cfg.output_dim, generator=g).to(DEV)
+    hfull = ops.ClipVitHandle(cfg, p, max_batch=cutn, device=DEV)
+    mk = pc.MakeCutouts(S, cutn)
+    mk.fixed_params = prm
+    x = img.clone().requires_grad_(True)
+    emb = ops.clip_encode_image(mk(x), hfull)
+    ops.prompt_loss(emb, e).backward()
+    g_full = x.grad.clone()
+    # the same batch in two slices with the global-mean denominator; min/max agree because both slices see the same
+    # extreme pixels only if they are in the slice -- so feed the full-batch statistics by encoding the full batch's
+    # cutouts slice-by-slice through a handle that was given the full-batch min/max
+    cuts = mk(img).detach()
+    mm = torch.stack([cuts.min(), cuts.max()])
+    acc_total = torch.zeros(4, dtype=torch.float64, device=DEV)
+    gs = []
+    hs = [ops.ClipVitHandle(cfg, p, max_batch=cutn // 2, device=DEV) for _ in range(2)]
+    from pixray_amd._lib import call
+    embs, gembs, locals_ = [], [], []
+    for r in range(2):
+        c = cuts[r * 4:(r + 1) * 4].contiguous()
+        emb_r = torch.empty(4, cfg.output_dim, device=DEV)
+        call("prx_clip_vit_encode", hs[r].h, c, 4, mm, emb_r, ops._stream())
+        er = emb_r.clone().requires_grad_(True)
+        ops.prompt_loss(er, e, denom=float(cutn)).backward()
+        acc = torch.empty(4, dtype=torch.float64, device=DEV)
+        call("prx_clip_vit_backward_reduce", hs[r].h, c, mm, er.grad.contiguous(), acc, ops._stream())
+        acc_total += acc
+        locals_.append(c)
+    gcuts = []
+    for r in range(2):
+        gc = torch.empty_like(locals_[r])
+        call("prx_clip_vit_backward_finish", hs[r].h, locals_[r], mm, acc_total, gc, ops._stream())
+        gcuts.append(gc)
+    x2 = img.clone().requires_grad_(True)
+    mk(x2).backward(torch.cat(gcuts))
+    assert rel(x2.grad, g_full) < 2e-3, rel(x2.grad, g_full)

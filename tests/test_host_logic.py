@@ -1,0 +1,287 @@
+"""CPU tests (no GPU): host-side logic of the package.
+
+* the 33 assertions of the reference's own test-suite (tests/test_util.py, tests/test_pixray.py) ported to
+  pixray_amd.settings;
+* the C-ABI library loads and exports every symbol include/prx.h declares (no compute calls);
+* cutout parameter sampling / descriptor construction;
+* BASELINE.json configs[0]: the plugin surface end to end on the CPU (pixel-grid drawer, ViT-B/32, cutn=2, 10
+  iterations) with the *oracle* supplying the perceptor / cutout / prompt arithmetic -- the Session loop is the product
+  code under test, the oracle parts are test infrastructure;
+* unmodified reference plugins (Losses/SaturationLoss.py, Losses/SymmetryLoss.py, filters/colorlookup.py loaded from
+  /root/reference when present) drop into the loop.
+"""
+import argparse
+import ctypes
+import importlib.util
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refextract as rx
+from oracle import step_ref, prompt_ref
+from pixray_amd import _lib, cutouts as pc, weights
+from pixray_amd.engine import Session
+from pixray_amd.interfaces import DrawingInterface, FilterInterface, LossInterface, install_compat_modules
+from pixray_amd.pixel_grid_drawer import PixelGridDrawer
+from pixray_amd.settings import apply_overlay, get_file_path, get_learning_rate_drops, parse_unit, split_pipes
+
+
+# ------------------------------------------------------------------ reference test-suite port (33 assertions)
+def test_get_file_path_reference_cases():
+    assert get_file_path('/testpath', 'testfile', '.png') == '/testpath/testfile.png'
+    assert get_file_path('/testpath/', 'testfile', '.png') == '/testpath/testfile.png'
+    with pytest.raises(ValueError):
+        get_file_path('/testpath/', '\\test\\filename.png', '.png')
+    with pytest.raises(ValueError):
+        get_file_path('/testpath/', '/test/filename.png', '.png')
+    assert get_file_path('', 'testfile', '.png') == 'testfile.png'
+    with pytest.raises(ValueError):
+        get_file_path('/testpath/', None, '.png')
+    with pytest.raises(ValueError):
+        get_file_path('/testpath/', ' ', '.png')
+    assert get_file_path('/testpath', 'testfile.png', '.mp4') == '/testpath/testfile.mp4'
+
+
+def test_parse_unit_reference_cases():
+    assert parse_unit('200iterations', 500, 'overlay_until') == 200
+    assert parse_unit('200 i', 500, 'overlay_until') == 200
+    assert parse_unit('50%', 500, 'overlay_until') == 250
+    assert parse_unit('33 percent', 500, 'overlay_until') == 165
+    with pytest.raises(ValueError):
+        parse_unit(' percent', 500, 'overlay_until')
+    assert parse_unit(None, 500, 'overlay_until') is None
+    assert parse_unit('200 iterATions    ', 500, 'overlay_until') == 200
+    assert parse_unit('50', 500, 'overlay_until') == 250
+    assert parse_unit('50', 500, 'overlay_until', 'i') == 50
+    assert parse_unit(50, 500, 'overlay_until', 'i') == 50
+    assert parse_unit(.6, 500, 'overlay_until', 'i') == 0
+    assert parse_unit(.5, 500, 'overlay_until', 'p') == 2
+    with pytest.raises(ValueError):
+        parse_unit('67.i', 500, 'overlay_until')
+
+
+def test_split_pipes_reference_cases():
+    assert split_pipes(None) is None
+    assert split_pipes('test|another') == ['test', 'another']
+    assert split_pipes('') == ''
+    assert split_pipes('single') == ['single']
+
+
+def _overlay_args(image, every, offset, until, iterations=250):
+    a = types.SimpleNamespace(overlay_image=image, iterations=iterations)
+    a.overlay_offset = parse_unit(offset, iterations, "overlay_offset")
+    a.overlay_until = parse_unit(until, iterations, "overlay_until")
+    a.overlay_every = parse_unit(every, iterations, "overlay_every")
+    return a
+
+
+def test_apply_overlay_reference_cases():
+    assert apply_overlay(_overlay_args('image.png', '1i', '0i', '100i'), 10) is True
+    assert apply_overlay(_overlay_args(None, '1i', '0i', '100i'), 10) is False
+    assert apply_overlay(_overlay_args('image.png', '5i', '10i', '100i'), 10) is False
+    assert apply_overlay(_overlay_args('image.png', '5i', '10i', None), 10) is False
+    assert apply_overlay(_overlay_args('image.png', '1i', '0i', '5i'), 10) is False
+
+
+def test_get_learning_rate_drops_reference_cases():
+    assert get_learning_rate_drops(None, 300) == []
+    assert get_learning_rate_drops([75], 300) == [224]
+    assert get_learning_rate_drops([50, 22.5], 300) == [149, 67]
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH) if False else _lib.load()
+    for name in protos:
+        assert hasattr(lib, name), f"{name} declared in include/prx.h but not exported"
+    assert lib.prx_abi_version() == 1
+    for must in ("prx_vqgan_synth", "prx_vqgan_synth_backward", "prx_cutouts_forward", "prx_cutouts_backward",
+                 "prx_clip_vit_encode", "prx_clip_vit_backward_reduce", "prx_clip_vit_backward_finish",
+                 "prx_prompt_loss_fwd_bwd", "prx_adam_clamp_step", "prx_last_error"):
+        assert must in protos
+
+
+def test_ops_fail_loudly_without_a_gpu():
+    from pixray_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.PrxError):
+        ops.prompt_loss(torch.randn(4, 64), torch.randn(1, 64))
+    with pytest.raises(_lib.PrxError):
+        ops.make_cutouts(torch.rand(1, 3, 32, 32), torch.zeros(2, 32, dtype=torch.float64), None, 16)
+    from pixray_amd import api
+    with pytest.raises(_lib.PrxError):
+        api.build_vqgan_clip_session()
+
+
+# ------------------------------------------------------------------ cutout parameters
+def test_cutout_params_follow_the_reference_distributions():
+    g = torch.Generator().manual_seed(0)
+    p = pc.sample_cutout_params(64, 224, g, iteration=3)
+    assert int(0.6 * 64) == 38 and p["z_persp_rand"].shape == (38, 4, 2) and p["w_trans"].shape == (26, 2)
+    assert int(p["reflect"]) == 0                       # odd iteration -> border (pixray.py:1250-1253)
+    crop = p["z_crop"]
+    area = crop[:, 2] * crop[:, 3] / (224 * 224)
+    assert ((area > 0.2) & (area < 1.0)).all()
+    assert (crop[:, 0] + crop[:, 2] <= 224).all() and (crop[:, 1] + crop[:, 3] <= 224).all()
+    assert (p["z_sat"] >= 0.9).all() and (p["z_sat"] <= 1.1).all() and (p["w_hue"].abs() <= 0.1).all()
+    assert (p["w_trans"].abs() <= 0.025 * 224).all() and (p["noise_fac"] <= 0.1).all()
+    d = pc.build_descriptors(p, 224)
+    assert d.shape == (64, 32) and d.dtype == torch.float64 and torch.isfinite(d).all()
+    # same seed -> same draws (ranks must agree when the batch is sharded)
+    p2 = pc.sample_cutout_params(64, 224, torch.Generator().manual_seed(0), iteration=3)
+    assert torch.equal(pc.build_descriptors(p2, 224), d)
+
+
+def test_descriptor_geometry_matches_oracle_grids():
+    """the pixel positions implied by a descriptor equal the oracle's kornia-style sampling grid"""
+    from oracle import cutouts_ref as cr
+    S = 32
+    g = torch.Generator().manual_seed(4)
+    p = pc.sample_cutout_params(10, S, g, iteration=0)
+    d = pc.build_descriptors(p, S)
+    nz = 6
+    # zoom stage A (perspective, GRID_MESH): compare against kornia-style normalised grid
+    Mp = cr._persp_matrix(p["z_persp_rand"], 0.4, S)
+    sn_dn = torch.linalg.inv(cr.normalize_homography(Mp, (S, S), (S, S)))
+    for i in range(nz):
+        if bool(p["z_persp_apply"][i]):
+            assert torch.allclose(d[i, 0:9].reshape(3, 3), sn_dn[i], atol=1e-9)
+        else:
+            assert int(d[i, 18]) == pc.MODE_IDENT
+
+
+# ------------------------------------------------------------------ configs[0]: plumbing on the CPU
+class _Settings(types.SimpleNamespace):
+    pass
+
+
+def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0, group=None, seed=0):
+    cfg = weights.CLIP_CONFIGS["ViT-B/32"]
+    params = weights.synthetic_clip_vit_params(cfg, 1)
+    st = _Settings(size=(256, 256), pixel_size=(16, 16), pixel_scale=None)
+    drawer = PixelGridDrawer(st)
+    drawer.load_model(st, "cpu")
+    g = torch.Generator().manual_seed(7)
+    drawer.init_from_tensor(torch.rand(1, 3, 256, 256, generator=g) * 2 - 1)
+    perceptor = step_ref.OraclePerceptor(cfg, params)
+
+    def sampler(iteration, fill):
+        gg = torch.Generator().manual_seed(1000 + iteration)
+        prm = pc.sample_cutout_params(cutn, 224, gg, iteration=iteration, fill=fill)
+        prm["noise"] = torch.randn(cutn, 3, 224, 224, generator=gg)
+        return prm
+    mk = step_ref.OracleMakeCutouts(224, cutn, sampler)
+    e = torch.randn(1, 512, generator=g)
+    pm = prompt_ref.Prompt(e / e.norm(), 1.0, float("-inf"))
+    pm.denom = None
+    args = _Settings(saturation_weight=1.0, symmetry_weight=1.0)
+    return Session(drawer, {"ViT-B/32": perceptor}, {224: mk}, {"ViT-B/32": [pm]}, learning_rate=0.03, iterations=iters,
+                   custom_losses=custom_losses, filters=filters, args=args, seed=seed, world_size=world, rank=rank,
+                   group=group)
+
+
+def test_config0_pixel_grid_vit_b32_cutn2_10_iterations_cpu():
+    sess = _cpu_session()
+    z0 = sess.drawer.get_z_copy()
+    losses = []
+    for it in range(10):
+        assert sess.train(it)
+        losses.append(float(sum(sess.last_losses)))
+        assert all(torch.isfinite(l).all() for l in sess.last_losses)
+    assert isinstance(sess.opts[0], torch.optim.Adam)        # drawer.get_opts() is None -> Adam([z], lr) (pixray.py:537-553)
+    assert (sess.drawer.get_z() - z0).abs().max() > 1e-3     # z moved
+    assert min(losses[5:]) < losses[0]                       # and the prompt loss went down
+    assert sess.drawer.get_z().min() >= 0 and sess.drawer.get_z().max() <= 1      # clip_z
+    img = sess.drawer.to_image()
+    assert img.size == (256, 256)
+
+
+def _load_reference_plugin(relpath, clsname):
+    install_compat_modules()
+    spec = importlib.util.spec_from_file_location("refplugin_" + clsname, os.path.join(rx.REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return getattr(mod, clsname)
+
+
+@pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
+def test_unmodified_reference_plugins_drop_in():
+    Sat = _load_reference_plugin("Losses/SaturationLoss.py", "SaturationLoss")
+    Sym = _load_reference_plugin("Losses/SymmetryLoss.py", "SymmetryLoss")
+    assert issubclass(Sat, LossInterface) and issubclass(Sym, LossInterface)      # bound to OUR interface module
+    parser = Sat.add_settings(Sym.add_settings(argparse.ArgumentParser()))
+    ns = parser.parse_args([])
+    assert ns.saturation_weight == 1 and ns.symmetry_weight == 1
+    losses = [{"loss": Sat(device="cpu"), "weight": 0.5}, {"loss": Sym(device="cpu"), "weight": 2.0}]
+    sess = _cpu_session(custom_losses=losses, iters=2)
+    out = sess.ascend_txt()
+    assert len(out) == 3 and all(o.requires_grad for o in out)       # prompt + saturation (list of 1) + symmetry
+    sum(out).backward()
+    assert sess.drawer.get_z().grad.abs().sum() > 0
+
+
+class _HalfBrightFilter(FilterInterface):
+    def forward(self, img):
+        return img * 0.5, img.mean() * 0.1
+
+
+class _CustomDrawer(DrawingInterface):
+    """a third-party drawer written only against the duck-typed API"""
+
+    def __init__(self, settings):
+        self.z = None
+
+    def load_model(self, settings, device):
+        pass
+
+    def get_opts(self, decay_divisor):
+        return [torch.optim.SGD([self.z], lr=0.5 / decay_divisor)]
+
+    def init_from_tensor(self, t):
+        self.z = torch.full((1, 3, 64, 64), 0.3, requires_grad=True)
+
+    def synth(self, cur_iteration):
+        return torch.sigmoid(self.z)
+
+    def clip_z(self):
+        pass
+
+    def get_z(self):
+        return self.z
+
+    def get_z_copy(self):
+        return self.z.clone()
+
+
+def test_filters_and_custom_drawers_drop_in():
+    sess = _cpu_session(filters=[{"filter": _HalfBrightFilter(None), "weight": 1.0}], iters=1)
+    out = sess.ascend_txt()
+    assert len(out) == 2
+    d = _CustomDrawer(None)
+    d.init_from_tensor(None)
+    sess.drawer = d
+    sess.opts = sess.rebuild_optimisers()
+    assert isinstance(sess.opts[0], torch.optim.SGD)         # drawer-provided optimisers win (pixray.py:525)
+    z0 = d.get_z_copy()
+    sess.train(0)
+    assert not torch.equal(d.get_z(), z0)
+
+
+def test_learning_rate_drop_rebuilds_optimisers():
+    sess = _cpu_session(iters=4)
+    sess.learning_rate_drops = [1]
+    sess.train(0)
+    assert sess.opts[0].param_groups[0]["lr"] == pytest.approx(0.03)
+    sess.train(1)
+    assert sess.num_loss_drop == 1 and sess.opts[0].param_groups[0]["lr"] == pytest.approx(0.003)

@@ -1,0 +1,131 @@
+"""CPU tests (no GPU): pin the oracle.
+
+1. against the committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from pixray's OWN
+   fragments executed out of /root/reference and from independent HF implementations of the un-vendored towers);
+2. live against those same sources when they are present in this container (skipped on the GPU box).
+Tolerances: fp32 CPU vs fp32 CPU of the same formula: 1e-5-class."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import _refextract as rx
+from oracle import clip_vit_ref, prompt_ref, vqgan_ref
+from pixray_amd import weights
+
+G = os.path.join(HERE, "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) if v.ndim else v for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_prompt_oracle_matches_reference_golden():
+    d = load("prompt_golden.npz")
+    for tag in "abc":
+        w, stop = float(d[f"w_{tag}"]), float(d[f"stop_{tag}"])
+        x = d["x"].clone().requires_grad_(True)
+        loss = prompt_ref.Prompt(d["embed"], w, stop)(x)
+        (g,) = torch.autograd.grad(loss, x)
+        assert abs(loss.item() - float(d[f"loss_{tag}"])) < 1e-6
+        assert rel(g, d[f"grad_{tag}"]) < 1e-6
+    assert rel(prompt_ref.spherical_dist_loss(d["x"], d["embed"][:1].expand(8, -1)), d["sdl"]) < 1e-6
+
+
+def test_vq_and_clamp_oracle_match_reference_golden():
+    d = load("vq_clamp_golden.npz")
+    x = d["x"].clone().requires_grad_(True)
+    q = vqgan_ref.vector_quantize(x, d["codebook"])
+    (gx,) = torch.autograd.grad(q, x, d["gq"])
+    assert torch.equal(q.detach(), d["q"]) and torch.equal(gx, d["gx"])          # selection + straight-through: exact
+    u = d["u"].clone().requires_grad_(True)
+    c = vqgan_ref.clamp_with_grad(u, 0, 1)
+    (gu,) = torch.autograd.grad(c, u, d["gc"])
+    assert torch.equal(c.detach(), d["c"]) and torch.equal(gu, d["gu"])
+
+
+def _golden_cfgs():
+    import make_golden as mg
+    return mg
+
+
+def test_clip_vit_oracle_matches_independent_golden():
+    mg = _golden_cfgs()
+    d = load("clip_vit_golden.npz")
+    cfg = mg.GOLDEN_CLIP
+    p = weights.synthetic_clip_vit_params(cfg, int(d["seed"]))
+    x = d["x"].clone().requires_grad_(True)
+    emb = clip_vit_ref.vit_forward(p, x, patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers)
+    (gx,) = torch.autograd.grad(emb, x, d["ge"])
+    assert rel(emb.detach(), d["emb"]) < 1e-5, rel(emb.detach(), d["emb"])
+    assert rel(gx, d["gx"]) < 1e-5
+
+
+def test_decoder_oracle_matches_independent_golden():
+    mg = _golden_cfgs()
+    d = load("decoder_golden.npz")
+    cfg = mg.GOLDEN_VQ
+    p = weights.synthetic_vqgan_params(cfg, int(d["seed"]))
+    p = dict(p)
+    # the independent decoder has no post_quant_conv: make the oracle's an identity
+    p["post_quant_conv.weight"] = torch.eye(cfg.z_channels).reshape(cfg.z_channels, cfg.z_channels, 1, 1)
+    p["post_quant_conv.bias"] = torch.zeros(cfg.z_channels)
+    z = d["z"].clone().requires_grad_(True)
+    img = vqgan_ref.decode(p, z, cfg.oracle_cfg())
+    (gz,) = torch.autograd.grad(img, z, d["gi"])
+    assert rel(img.detach(), d["img"]) < 1e-5, rel(img.detach(), d["img"])
+    assert rel(gz, d["gz"]) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------- live cross-checks
+@pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
+def test_oracle_fragments_vs_live_reference():
+    ns = rx.pixray_prompt_ns()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 512, generator=g)
+    e = torch.randn(2, 512, generator=g)
+    for (w, stop) in [(1.0, float("-inf")), (-2.0, float("-inf")), (0.5, 1.4)]:
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        la = ns["Prompt"](e, w, stop)(a)
+        lb = prompt_ref.Prompt(e, w, stop)(b)
+        assert la.item() == lb.item()
+        assert torch.equal(torch.autograd.grad(la, a)[0], torch.autograd.grad(lb, b)[0])
+    assert ns["parse_prompt"]("a cat:2:0.5") == ("a cat", 2.0, 0.5)
+    vs = rx.vqgan_ns()
+    xq = torch.randn(1, 8, 8, 32, generator=g)
+    cb = torch.randn(128, 32, generator=g)
+    assert torch.equal(vs["vector_quantize"](xq, cb), vqgan_ref.vector_quantize(xq, cb))
+
+
+@pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
+def test_reference_vector_prompt_fixture_shape():
+    """vectors/textoff.json is the only real-model-derived data in the reference: [1, 512] for ViT-B/32"""
+    import json
+    v = json.load(open(os.path.join(rx.REF, "vectors", "textoff.json")))
+    t = torch.tensor(v["ViT-B/32"])
+    assert t.shape == (1, 512) and torch.isfinite(t).all()
+
+
+def test_oracle_vs_hf_live():
+    """same comparison as the golden, but at the headline tower's width on fresh inputs (HF is in the image)"""
+    transformers = pytest.importorskip("transformers")
+    mg = _golden_cfgs()
+    cfg = weights.ClipVitConfig("x", 64, 32, 768, 2, 12, 512)
+    p = weights.synthetic_clip_vit_params(cfg, 3)
+    m = mg.hf_clip_from_params(cfg, p)
+    x = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        ref = m(pixel_values=x).image_embeds
+        out = clip_vit_ref.vit_forward(p, x, patch=32, heads=12, layers=2)
+    assert rel(out, ref) < 1e-5
