@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cutn", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the iteration from a captured hipGraph (measured neutral on MI355X: the loop is GPU-bound)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=3)
     args = ap.parse_args()
@@ -69,7 +71,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     it = 0
-    for _ in range(args.warmup):
+    graphed = False
+    if args.graph and world == 1:
+        graphed = sess.enable_graph(warmup=max(args.warmup - 1, 1))      # warm-up iterations run inside
+        it = sess.cur_iteration
+    for _ in range(0 if graphed else args.warmup):
         sess.train(it); it += 1
     barrier()
     t0 = time.perf_counter()
@@ -87,7 +93,9 @@ def main():
     loss = float(sum(sess.last_losses))
 
     # ---- roofline leg: per-launch HIP-event timing of the GEMM engine over a few extra steps ------------------
+    # (eager launches: events cannot be recorded around the nodes of a replayed graph)
     roofline = None
+    sess._graph = None
     if rank == 0:
         lib = _lib.load()
         import ctypes
@@ -132,7 +140,8 @@ def main():
             "config": {"workload": "vqgan imagenet_f16_16384 256x256 + CLIP ViT-B/32 + %d cutouts, 1 prompt, Adam lr 0.2"
                                    % args.cutn,
                        "weights": "seeded random, real architectures", "cutouts_per_gpu": args.cutn // world,
-                       "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU"},
+                       "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU",
+                       "launch": "hipGraph replay" if graphed else "eager"},
             "final_loss": round(loss, 5),
             "per_gpu_gflop_per_step": round(per_gpu_gflop, 1),
             "iter_mfma_frac": round(iter_frac, 4),

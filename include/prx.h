@@ -212,6 +212,12 @@ int prx_adam_clamp_step(float* z, float* exp_avg, float* exp_avg_sq, const float
                         const float* zmax, int hw, size_t n, float lr, float beta1, float beta2, float eps, int step,
                         prx_stream_t s);
 
+/* same step with the step-dependent scalars read from device memory: hyper = {lr / (1 - beta1^t), sqrt(1 - beta2^t)}.
+ * Used when the whole iteration is captured in a hipGraph and replayed (kernel arguments are frozen at capture). */
+int prx_adam_clamp_step_dev(float* z, float* exp_avg, float* exp_avg_sq, const float* grad, const float* zmin,
+                            const float* zmax, int hw, size_t n, const float* hyper, float beta1, float beta2, float eps,
+                            prx_stream_t s);
+
 int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook,
                      const float* cnorm, int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq,
                      prx_stream_t s);

@@ -94,6 +94,13 @@ int prx_adam_clamp_step(float* z, float* exp_avg, float* exp_avg_sq, const float
     return prx_adam_clamp(z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, n, lr, beta1, beta2, eps, step, S_(s));
 }
 
+int prx_adam_clamp_step_dev(float* z, float* exp_avg, float* exp_avg_sq, const float* grad, const float* zmin,
+                            const float* zmax, int hw, size_t n, const float* hyper, float beta1, float beta2, float eps,
+                            prx_stream_t s) {
+    PRX_REQUIRE(z && exp_avg && exp_avg_sq && grad && hyper, "prx_adam_clamp_step_dev: null argument");
+    return prx_adam_clamp_dev(z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, n, hyper, beta1, beta2, eps, S_(s));
+}
+
 // kernel-level entries for the pieces above (tests)
 int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook,
                      const float* cnorm, int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq,

@@ -13,5 +13,7 @@ int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf
                        int HW, hipStream_t s);
 int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
                    size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t s);
+int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
+                       size_t n, const float* hyper, float b1, float b2, float eps, hipStream_t s);
 int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);

@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ z, 
                                                          float* __restrict__ v, const float* __restrict__ g,
                                                          const float* __restrict__ zmin, const float* __restrict__ zmax,
                                                          int hw, size_t n, float lr, float b1, float b2, float eps,
-                                                         float bc1, float bc2_sqrt) {
+                                                         float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+    // hyper (optional, device): {lr / bias_correction1, sqrt(bias_correction2)} -- lets a captured hipGraph be
+    // replayed with the step-dependent scalars updated in place
+    if (hyper) { lr = hyper[0]; bc1 = 1.f; bc2_sqrt = hyper[1]; }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i];
         float mi = b1 * m[i] + (1.f - b1) * gi;          // exp_avg.lerp_(grad, 1-beta1)
@@ -265,7 +268,15 @@ int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zm
     const double bc1 = 1.0 - pow((double)b1, step);
     const double bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, s, z, m, v, g, zmin, zmax, hw, n, lr, b1, b2,
-                       eps, (float)bc1, (float)sqrt(bc2));
+                       eps, (float)bc1, (float)sqrt(bc2), (const float*)nullptr);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
+                       size_t n, const float* hyper, float b1, float b2, float eps, hipStream_t s) {
+    PRX_REQUIRE(hyper != nullptr, "adam: null hyper buffer");
+    hipLaunchKernelGGL(adam_clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, s, z, m, v, g, zmin, zmax, hw, n, 0.f, b1, b2,
+                       eps, 1.f, 1.f, hyper);
     PRX_LAUNCH_CHECK();
     return 0;
 }

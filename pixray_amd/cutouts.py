@@ -205,17 +205,47 @@ class MakeCutouts(nn.Module):
         self.last_params = None
         self.fixed_params = None   # tests / parity: use these draws instead of sampling
 
-    def forward(self, input, spot=None):
-        if spot is not None:
-            raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
+    # -- host part: draw this iteration's parameters and stage the descriptor table ---------------------------------
+    def enable_static_buffers(self, device):
+        """Keep the descriptor table in a fixed device buffer (fed from a pinned host buffer) so the device part of
+        the iteration can be captured in a hipGraph and replayed."""
+        lo, hi = (0, self.cutn) if self.shard is None else self.shard
+        self._pinned = torch.empty(hi - lo, DESC_WORDS, dtype=torch.float64).pin_memory()
+        self._static_desc = torch.empty(hi - lo, DESC_WORDS, dtype=torch.float64, device=device)
+
+    def prepare(self, iteration=None, fill=None, device=None):
+        if iteration is not None:
+            self.iteration = iteration
+        if fill is not None:
+            self.fill = fill
         S = self.cut_size
         prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
             self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill)
         self.last_params = prm
         desc = build_descriptors(prm, S)
-        lo, hi = (0, self.cutn) if self.shard is None else self.shard
-        desc_dev = desc[lo:hi].contiguous().to(input.device, non_blocking=True)
         self.transforms = desc[:, 0:18]
+        lo, hi = (0, self.cutn) if self.shard is None else self.shard
+        if getattr(self, "_static_desc", None) is not None:
+            self._pinned.copy_(desc[lo:hi])
+            self._static_desc.copy_(self._pinned, non_blocking=True)       # stream-ordered before the replay
+            self._desc_dev = self._static_desc
+        else:
+            self._desc_dev = desc[lo:hi].contiguous()
+        self._prepared = True
+
+    # -- device part -----------------------------------------------------------------------------------------------------
+    def forward(self, input, spot=None):
+        if spot is not None:
+            raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
+        if not getattr(self, "_prepared", False):
+            self.prepare()
+        self._prepared = False
+        S = self.cut_size
+        prm = self.last_params
+        lo, hi = (0, self.cutn) if self.shard is None else self.shard
+        desc_dev = self._desc_dev
+        if desc_dev.device != input.device:
+            desc_dev = desc_dev.to(input.device, non_blocking=True)
         noise = prm.get("noise")
         if noise is None and self.noise_fac:
             # device-side N(0,1) draws, as the reference's randn_like (pixray.py:510)

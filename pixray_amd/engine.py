@@ -31,15 +31,39 @@ def spherical_dist_loss(x, y):
 
 
 class HipAdam(torch.optim.Optimizer):
-    """`optim.Adam([z], lr)` (pixray.py:539) on the fused HIP Adam(+clip_z) kernel. One fp32 tensor."""
+    """`optim.Adam([z], lr)` (pixray.py:539) on the fused HIP Adam(+clip_z) kernel. One fp32 tensor.
+
+    The step-dependent scalars (lr / bias_correction1, sqrt(bias_correction2)) live in a small device tensor that
+    `prepare_step()` refreshes from a pinned host buffer, so `step()` launches the same kernel with the same
+    arguments every iteration and can be replayed from a captured hipGraph."""
 
     def __init__(self, params, lr=0.2, betas=(0.9, 0.999), eps=1e-8, bounds=None):
         super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps))
         self.bounds = bounds   # (zmin[C], zmax[C]) or None
+        self._t = 0
+        self._pending = False
+        p = self.param_groups[0]["params"][0]
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if p.is_cuda else None
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=p.device)
+
+    def prepare_step(self):
+        """host side of the next step(): advance t and stage {lr/bc1, sqrt(bc2)} (stream-ordered H2D)"""
+        g = self.param_groups[0]
+        self._t += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self._t
+        bc2 = 1.0 - b2 ** self._t
+        self._hyper_host[0] = g["lr"] / bc1
+        self._hyper_host[1] = bc2 ** 0.5
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._pending = True
 
     @torch.no_grad()
     def step(self, closure=None):
         from . import ops
+        if not self._pending:
+            self.prepare_step()
+        self._pending = False
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -49,10 +73,15 @@ class HipAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
+                elif int(st["step"]) != self._t - 1:
+                    # state was set from outside (tests teacher-force the moments): follow its step count
+                    self._t = int(st["step"])
+                    self.prepare_step()
+                    self._pending = False
+                st["step"] = self._t
                 zmin, zmax = self.bounds if self.bounds is not None else (None, None)
-                ops.adam_clamp_step(p, st["exp_avg"], st["exp_avg_sq"], p.grad.contiguous(), zmin, zmax, group["lr"],
-                                    st["step"], group["betas"], group["eps"])
+                ops.adam_clamp_step_dev(p, st["exp_avg"], st["exp_avg_sq"], p.grad.contiguous(), zmin, zmax, self._hyper,
+                                        group["betas"], group["eps"])
 
 
 class Session:
@@ -90,6 +119,8 @@ class Session:
         self.rng = torch.Generator().manual_seed(seed)       # fill colour stream (python random in the reference)
         self.last_losses: Optional[List[torch.Tensor]] = None
         self.last_embeds = None
+        self._graph = None
+        self._host_ready = False
         self._shard_cutouts()
         self.opts = self.rebuild_optimisers()
 
@@ -144,7 +175,9 @@ class Session:
     def ascend_txt(self):
         """pixray.py:1243-1406"""
         it = self.cur_iteration
-        fill = float(torch.rand((), generator=self.rng, dtype=torch.float64))       # pixray.py:1255-1258
+        if not self._host_ready:
+            self._host_prep(it)
+        self._host_ready = False
         result: List[torch.Tensor] = []
         out = self.do_synth_and_filter(result)
         if self.world_size > 1 and out.requires_grad:
@@ -157,9 +190,6 @@ class Session:
             out.register_hook(_allreduce)
         cur_cutouts = {}
         for size, mk in self.cutoutsTable.items():
-            if hasattr(mk, "iteration"):
-                mk.iteration = it              # padding mode parity, pixray.py:1250-1253
-                mk.fill = fill
             cur_cutouts[size] = mk(out)
         iii = None
         for name, perceptor in self.perceptors.items():
@@ -186,6 +216,66 @@ class Session:
         self.last_embeds = iii
         return result
 
+    def _host_prep(self, it):
+        """Host side of an iteration: the random draws the reference makes in Python / kornia (fill colour
+        pixray.py:1255-1258, padding-mode parity 1250-1253, augmentation parameters) and their staging to the device."""
+        fill = float(torch.rand((), generator=self.rng, dtype=torch.float64))
+        for mk in self.cutoutsTable.values():
+            if hasattr(mk, "prepare"):
+                mk.prepare(iteration=it, fill=fill)
+            else:
+                mk.iteration, mk.fill = it, fill
+        self._host_ready = True
+
+    def _device_step(self):
+        """Device side of train(): zero_grad -> ascend_txt -> backward -> step -> clip_z (no host decisions inside,
+        so it can be captured once and replayed)."""
+        for opt in self.opts:
+            opt.zero_grad(set_to_none=True)
+        for i in range(self.batches):
+            lossAll = self.ascend_txt()
+            loss = sum(lossAll)
+            loss.backward()
+            self.last_losses = lossAll
+        for opt in self.opts:
+            opt.step()
+        self.drawer.clip_z()
+
+    # ------------------------------------------------------------------ hipGraph capture
+    def enable_graph(self, warmup: int = 3):
+        """Capture the device side of one iteration (≈590 kernel launches) in a hipGraph and replay it from then on.
+        Host-drawn inputs reach the graph through fixed device buffers (cutout descriptors, Adam scalars).  Falls back
+        to eager launches when something in the session cannot be captured (custom optimisers, batches > 1, ...)."""
+        z = self.drawer.get_z()
+        if not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
+            return False
+        dev = z.device
+        for mk in self.cutoutsTable.values():
+            if not hasattr(mk, "enable_static_buffers") or getattr(mk, "fixed_params", None) is not None:
+                return False
+            mk.enable_static_buffers(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._host_prep(self.cur_iteration)
+                for o in self.opts:
+                    o.prepare_step()
+                self._device_step()
+                self.cur_iteration += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._host_prep(self.cur_iteration)
+        for o in self.opts:
+            o.prepare_step()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._device_step()
+        self.cur_iteration += 1          # the capture pass does not execute; account for the prepared iteration below
+        self._graph = graph
+        graph.replay()                   # run the iteration whose inputs were staged for the capture
+        return True
+
     # ------------------------------------------------------------------ one optimiser step
     def train(self, cur_it: Optional[int] = None) -> bool:
         """pixray.py:1436-1512 (image saving / overlays / animation are outside the hot path)"""
@@ -194,21 +284,31 @@ class Session:
         self.cur_iteration = cur_it
         rebuild = False
         if cur_it < self.iterations:
-            for opt in self.opts:
-                opt.zero_grad()
-            for i in range(self.batches):
-                lossAll = self.ascend_txt()
-                if i == 0:
-                    if cur_it in self.learning_rate_drops:
-                        rebuild = True
-                    elif self.auto_stop:
+            if cur_it in self.learning_rate_drops:
+                rebuild = True
+            if self._graph is not None:
+                self._host_prep(cur_it)
+                for opt in self.opts:
+                    opt.prepare_step()
+                self._graph.replay()
+                for opt in self.opts:               # keep the Python-side step count in sync with the replayed kernels
+                    for st in opt.state.values():
+                        st["step"] = opt._t
+            elif self.auto_stop or self.batches != 1:
+                for opt in self.opts:
+                    opt.zero_grad()
+                for i in range(self.batches):
+                    lossAll = self.ascend_txt()
+                    if i == 0 and not rebuild and self.auto_stop:
                         rebuild = self.checkdrop(cur_it, lossAll)
-                loss = sum(lossAll)
-                loss.backward()
-                self.last_losses = lossAll
-            for opt in self.opts:
-                opt.step()
-            self.drawer.clip_z()
+                    loss = sum(lossAll)
+                    loss.backward()
+                    self.last_losses = lossAll
+                for opt in self.opts:
+                    opt.step()
+                self.drawer.clip_z()
+            else:
+                self._device_step()
         if cur_it == self.iterations:
             return False
         if rebuild:
@@ -218,6 +318,7 @@ class Session:
             self.best_iter = cur_it
             self.best_loss = None
             self.opts = self.rebuild_optimisers()
+            self._graph = None               # captured kernels reference the old optimiser state: back to eager
         self.cur_iteration = cur_it + 1
         return True
 

@@ -261,6 +261,14 @@ def prompt_loss(input, embed, weight=1.0, stop=float("-inf"), denom=None):
 
 
 # --------------------------------------------------------------------------------------- optimiser
+def adam_clamp_step_dev(z, exp_avg, exp_avg_sq, grad, zmin, zmax, hyper, betas=(0.9, 0.999), eps=1e-8):
+    """Same, with {lr / bias_correction1, sqrt(bias_correction2)} read from the device tensor `hyper` (graph replay)."""
+    _need_cuda(z, grad, hyper)
+    hw = z.shape[-1] * z.shape[-2]
+    call("prx_adam_clamp_step_dev", z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, z.numel(), hyper, float(betas[0]),
+         float(betas[1]), float(eps), _stream())
+
+
 def adam_clamp_step(z, exp_avg, exp_avg_sq, grad, zmin, zmax, lr, step, betas=(0.9, 0.999), eps=1e-8):
     """In-place Adam step on z fused with the per-channel clip_z clamp."""
     _need_cuda(z, grad)
