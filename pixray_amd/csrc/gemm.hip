@@ -21,6 +21,7 @@ struct GemmArgs {
     GemmDesc d;
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
+    int xcd_swizzle;
     float* ws;
 };
 
@@ -286,7 +287,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int bid = blockIdx.x;
+    // XCD-aware tile order (T1): workgroup b runs on XCD b % 8, each with a private 4 MB L2.  Give every XCD a
+    // contiguous range of tiles (bijective for any tile count) so the A row panels / B column panels it touches are a
+    // 1/8 slice of the operands instead of all of them.
+    int bid = blockIdx.x;
+    if (p.xcd_swizzle) {
+        const int nwg = gridDim.x, xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
     const int tm = bid / p.tiles_n;
     const int tn = bid - tm * p.tiles_n;
     const int split = blockIdx.y;
@@ -537,13 +546,17 @@ struct ProfRec { hipEvent_t a, b; double flop; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 bool g_use_glds = true;
-int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
+int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+int g_xcd_swizzle = 1;   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
 
 }  // namespace
 
 void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
-void prx_gemm_force_tile(int bm, int bn, int splits) { g_force_bm = bm; g_force_bn = bn; g_force_splits = splits; }
+void prx_gemm_force_tile(int bm, int bn, int splits) {
+    if (bm < 0) { g_xcd_swizzle = splits; return; }     // (-1, x, on/off): toggle the XCD-aware tile order
+    g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
+}
 
 void prx_gemm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -620,6 +633,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         splits = std::min(g_force_splits, a.kt_total);
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
+    a.xcd_swizzle = g_xcd_swizzle && tiles >= 16;
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;

@@ -31,6 +31,17 @@ def run(M, N, K, conv, cfgs, iters=20):
     best = min(range(len(res)), key=lambda i: res[i])
     print(f"M={M:6d} N={N:5d} K={K:5d} conv={str(conv):20s} " + "  ".join(f"{c}:{t:6.1f}" for c, t in zip(cfgs, res)) + f"   best {cfgs[best]} {2.0*M*N*K/res[best]/1e6:.0f} TF", flush=True)
 
+import sys as _s
+if len(_s.argv) > 1 and _s.argv[1] == "xcd":
+    for sw in (0, 1):
+        lib.prx_gemm_tile_override(-1, 0, sw)
+        print("== xcd swizzle", sw)
+        for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
+            run(M, N, K, None, [(0, 0, 0)])
+        for (H, C, Co, up) in [(64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0), (256, 128, 128, 0), (256, 128, 128, 1)]:
+            run(H * H, Co, 9 * C, (H, H, C, up), [(0, 0, 0)])
+    lib.prx_gemm_tile_override(-1, 0, 1)
+    _s.exit(0)
 cfgs = [(0, 0, 0), (128, 128, 1), (128, 128, 2), (128, 64, 1), (128, 64, 2), (64, 64, 1)]
 for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (3200, 3072, 768)]:
     run(M, N, K, None, cfgs)
