@@ -11,6 +11,7 @@
 #include "gemm.h"
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -547,7 +548,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 bool g_use_glds = true;
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
-int g_xcd_swizzle = 1;   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
+int g_xcd_swizzle = (getenv("PRX_XCD_SWIZZLE") ? atoi(getenv("PRX_XCD_SWIZZLE")) : 2);   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
 
 }  // namespace
@@ -633,7 +634,9 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         splits = std::min(g_force_splits, a.kt_total);
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
-    a.xcd_swizzle = g_xcd_swizzle && tiles >= 16;
+    // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative
+    // on the implicit-conv shapes -> mode 2 (default) applies it to narrow row-major problems only
+    a.xcd_swizzle = tiles >= 16 && (g_xcd_swizzle == 1 || (g_xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;
