@@ -144,30 +144,31 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const bf16_t* __restrict__ 
 
 __global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                      bf16_t* __restrict__ dqkv, int T, int C, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[7 * TILE];
-    bf16_t* Qs = smem;              // later: dS^T
-    bf16_t* Ks = smem + TILE;
-    bf16_t* Vs = smem + 2 * TILE;   // later: P^T
-    bf16_t* dOs = smem + 3 * TILE;  // later: dS
-    bf16_t* Qt = smem + 4 * TILE;
-    bf16_t* Kt = smem + 5 * TILE;
-    bf16_t* dOt = smem + 6 * TILE;
+    // Four [64][72] bf16 LDS tiles (36.9 KB -> 4 workgroups per CU, all 768 (image, head) pairs resident at once):
+    //   phase 1: T0=Q T1=K T2=V T3=dO           -> S = QK^T, P (registers), dP = dO V^T, dS (registers)
+    //   phase 2: T0=dS T1=dS^T T2=P^T, T3 = K^T / Q^T / dO^T in turn (re-read from L2) -> dQ, dK, dV
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];
+    bf16_t* T0 = smem;
+    bf16_t* T1 = smem + TILE;
+    bf16_t* T2 = smem + 2 * TILE;
+    bf16_t* T3 = smem + 3 * TILE;
     const int lane = threadIdx.x;
     const int h = blockIdx.x, n = blockIdx.y;
     const long long ld = 3LL * C;
     const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
-    load_tile(base, ld, T, Qs, Qt, lane);
-    load_tile(base + C, ld, T, Ks, Kt, lane);
-    load_tile(base + 2 * C, ld, T, Vs, nullptr, lane);
-    load_tile(dout + (long long)n * T * C + h * 64, C, T, dOs, dOt, lane);
+    const bf16_t* dobase = dout + (long long)n * T * C + h * 64;
+    load_tile(base, ld, T, T0, nullptr, lane);
+    load_tile(base + C, ld, T, T1, nullptr, lane);
+    load_tile(base + 2 * C, ld, T, T2, nullptr, lane);
+    load_tile(dobase, C, T, T3, nullptr, lane);
     __syncthreads();
 
     f32x16 p[2][2], dp[2][2];
     zero_acc(p);
-    mma_64x64x64(Qs, Ks, p, lane);
+    mma_64x64x64(T0, T1, p, lane);
     softmax_c_layout(p, scale, T, lane);
     zero_acc(dp);
-    mma_64x64x64(dOs, Vs, dp, lane);
+    mma_64x64x64(T3, T2, dp, lane);
     // dS = scale * P o (dP - rowsum(P o dP))
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -177,21 +178,28 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ 
             dp[mi][0][r] = scale * p[mi][0][r] * (dp[mi][0][r] - dot);
             dp[mi][1][r] = scale * p[mi][1][r] * (dp[mi][1][r] - dot);
         }
-    __syncthreads();  // all reads of Qs/Ks/Vs/dOs done
-    store_c_tile(p, nullptr, Vs, lane);   // Vs <- P^T
-    store_c_tile(dp, dOs, Qs, lane);      // dOs <- dS, Qs <- dS^T
+    __syncthreads();  // all reads of Q/K/V/dO tiles done
+    store_c_tile(dp, T0, T1, lane);        // T0 <- dS, T1 <- dS^T
+    store_c_tile(p, nullptr, T2, lane);    // T2 <- P^T
+    load_tile(base + C, ld, T, nullptr, T3, lane);      // T3 <- K^T
     __syncthreads();
 
     bf16_t* obase = dqkv + (long long)n * T * ld + h * 64;
     f32x16 acc[2][2];
     zero_acc(acc);
-    mma_64x64x64(dOs, Kt, acc, lane);     // dQ = dS K
+    mma_64x64x64(T0, T3, acc, lane);       // dQ = dS K
     store_c_global(acc, obase, ld, T, lane);
+    __syncthreads();
+    load_tile(base, ld, T, nullptr, T3, lane);           // T3 <- Q^T
+    __syncthreads();
     zero_acc(acc);
-    mma_64x64x64(Qs, Qt, acc, lane);      // dK = dS^T Q
+    mma_64x64x64(T1, T3, acc, lane);       // dK = dS^T Q
     store_c_global(acc, obase + C, ld, T, lane);
+    __syncthreads();
+    load_tile(dobase, C, T, nullptr, T3, lane);          // T3 <- dO^T
+    __syncthreads();
     zero_acc(acc);
-    mma_64x64x64(Vs, dOt, acc, lane);     // dV = P^T dO
+    mma_64x64x64(T2, T3, acc, lane);       // dV = P^T dO
     store_c_global(acc, obase + 2 * C, ld, T, lane);
 }
 

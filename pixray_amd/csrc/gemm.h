@@ -33,6 +33,11 @@ struct GemmDesc {
     bf16_t* out_bf16 = nullptr;      // post-activation
     bf16_t* out_bf16_pre = nullptr;  // pre-activation (QUICKGELU only)
     int ldc_bf16 = 0;
+    // optional: accumulate GroupNorm statistics of the fp32 output (sum, sum of squares per group of `gn_gs`
+    // consecutive columns) into gn_stats[group*2 + {0,1}] (double, pre-zeroed) -- saves the separate stats pass over
+    // the conv output.  Needs the vector epilogue (N % 4 == 0, gn_gs % 4 == 0).
+    double* gn_stats = nullptr;
+    int gn_gs = 0;
 };
 
 // Launch on `stream`.  `ws` is a scratch buffer for split-K partials (may be

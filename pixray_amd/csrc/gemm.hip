@@ -51,7 +51,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
 }
 
 // 4 consecutive columns at once (all pointers / leading dimensions checked 16-byte friendly by the host)
-__device__ __forceinline__ void epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
+__device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
     v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
     if (d.bias_n) {
         const float4 b = *reinterpret_cast<const float4*>(d.bias_n + col);
@@ -80,6 +80,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmDesc& d, int row, int 
         o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
         *reinterpret_cast<bf16x4*>(d.out_bf16 + (size_t)row * d.ldc_bf16 + col) = o;
     }
+    return v;
 }
 
 template <typename TA>
@@ -431,6 +432,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
         constexpr int LPR = CW / 4;           // lanes per row
         constexpr int RPP = 64 / LPR;         // rows per pass
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
+        float* gacc = reinterpret_cast<float*>(lds) + 4 * (32 * LDW);      // [BN/4][2] per-column-quad partial sums
+        const bool do_stats = d.gn_stats != nullptr && p.splits == 1;
+        if (do_stats && tid < BN / 2) gacc[tid] = 0.f;
+        float gs0 = 0.f, gs1 = 0.f;
         const int rbase = tm * BM + wm * (BM / 2);
         const int cbase = tn * BN + wn * (BN / 2);
 #pragma unroll
@@ -450,11 +455,36 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
                 if (row < d.M && col < d.N) {
                     if (p.splits > 1)
                         *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
-                    else
-                        epilogue_store4(d, row, col, v);
+                    else {
+                        const float4 o = epilogue_store4(d, row, col, v);
+                        gs0 += (o.x + o.y) + (o.z + o.w);
+                        gs1 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                    }
                 }
             }
             __syncthreads();
+        }
+        if (do_stats) {
+            // lanes with the same column quad (lane % LPR) -> one value, then the block's two M-waves via LDS
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) { gs0 += __shfl_xor(gs0, o, 64); gs1 += __shfl_xor(gs1, o, 64); }
+            if (lane < LPR) {
+                const int q = wn * LPR + lane;            // column quad within the block tile
+                atomicAdd(&gacc[q * 2], gs0);
+                atomicAdd(&gacc[q * 2 + 1], gs1);
+            }
+            __syncthreads();
+            const int qpg = d.gn_gs >> 2;                  // quads per group
+            const int ngrp = BN / d.gn_gs;                 // groups covered by this block tile
+            if (tid < ngrp * 2) {
+                const int gl = tid >> 1, mom = tid & 1;
+                const int col = tn * BN + gl * d.gn_gs;
+                if (col < d.N) {
+                    double a2 = 0.0;
+                    for (int q = 0; q < qpg; ++q) a2 += (double)gacc[(gl * qpg + q) * 2 + mom];
+                    atomicAdd(&d.gn_stats[(size_t)(col / d.gn_gs) * 2 + mom], a2);
+                }
+            }
         }
         return;
     }
@@ -482,6 +512,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const GemmDesc& d = p.d;
     const size_t total = (size_t)d.M * d.N;
     if (p.vec_epi) {
+        __shared__ float gacc[64];          // 32 groups x {sum, sumsq} for this block
+        const bool do_stats = d.gn_stats != nullptr;
+        if (do_stats && threadIdx.x < 64) gacc[threadIdx.x] = 0.f;
+        if (do_stats) __syncthreads();
         const size_t total4 = total >> 2;
         for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -491,7 +525,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             }
             const size_t idx = i4 << 2;
             const int row = (int)(idx / d.N);
-            epilogue_store4(d, row, (int)(idx - (size_t)row * d.N), v);
+            const int col = (int)(idx - (size_t)row * d.N);
+            const float4 o = epilogue_store4(d, row, col, v);
+            if (do_stats) {
+                const int g = col / d.gn_gs;
+                atomicAdd(&gacc[g * 2], (o.x + o.y) + (o.z + o.w));
+                atomicAdd(&gacc[g * 2 + 1], (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+            }
+        }
+        if (do_stats) {
+            __syncthreads();
+            if (threadIdx.x < 64 && gacc[threadIdx.x] != 0.f) atomicAdd(&d.gn_stats[threadIdx.x], (double)gacc[threadIdx.x]);
         }
         return;
     }
@@ -637,6 +681,10 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative
     // on the implicit-conv shapes -> mode 2 (default) applies it to narrow row-major problems only
     a.xcd_swizzle = tiles >= 16 && (g_xcd_swizzle == 1 || (g_xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
+    if (d.gn_stats) {
+        PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && g_use_glds,
+                    "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
+    }
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;

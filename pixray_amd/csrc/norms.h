@@ -3,7 +3,8 @@
 #include <algorithm>
 // GroupNorm(32 groups) on NHWC fp32 x[NB][P][C]; stats = double[NB][32][2] workspace (sum, sumsq).
 int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, double* stats, bf16_t* out_bf16,
-                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats = 1);
+                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats = 1,
+                      int stats_ready = 0);
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
                       float eps, hipStream_t s, int zero_stats = 1);

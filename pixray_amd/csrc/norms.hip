@@ -294,15 +294,18 @@ int gn_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 40
 }  // namespace
 
 int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, double* stats, bf16_t* out_bf16,
-                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats) {
+                      float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats,
+                      int stats_ready) {
     PRX_REQUIRE(C % 32 == 0 && (C / 32) % 4 == 0 && 256 % (C / 4) == 0, "groupnorm: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.gamma = gamma; a.beta = beta; a.stats = stats; a.P = P; a.C = C; a.swish = swish; a.eps = eps;
-    if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * NB * 64, s));
-    const int ppb = 256 / (C / 4);
-    int blocks = std::min(ceil_div(P, ppb * 4), 256);   // <= one block per CU: few (contended) double atomics
-    hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(blocks, NB), dim3(256), 0, s, a);
-    PRX_LAUNCH_CHECK();
+    if (!stats_ready) {     // stats_ready: the producing GEMM already accumulated (sum, sumsq) in its epilogue
+        if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * NB * 64, s));
+        const int ppb = 256 / (C / 4);
+        int blocks = std::min(ceil_div(P, ppb * 4), 256);   // <= one block per CU: few (contended) double atomics
+        hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(blocks, NB), dim3(256), 0, s, a);
+        PRX_LAUNCH_CHECK();
+    }
     if (out_bf16 || out_f32) {
         hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, out_bf16,
                            out_f32, NB);

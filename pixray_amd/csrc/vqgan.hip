@@ -291,11 +291,12 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
 static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
 
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int res, bool up, const float* resid,
-                     float* out, int ldc, hipStream_t s, bf16_t* out_bf = nullptr) {
+                     float* out, int ldc, hipStream_t s, bf16_t* out_bf = nullptr, const GN* stats_for = nullptr) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
     d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = res * res; d.N = c.Cout; d.K = 9 * c.Cin;
     d.H = res; d.W = res; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
     d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
+    if (stats_for && stats_for->C == c.Cout) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
@@ -307,8 +308,17 @@ static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, i
     d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
     return vg(v, d, s);
 }
-static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s) {
-    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0);
+// first GroupNorm of stage `si` (whose statistics the producer of that stage's input can accumulate in its epilogue)
+static const GN* first_norm(const PrxVqgan* v, int si) {
+    if (si >= (int)v->stages.size()) return &v->norm_out;
+    const Stage& st = v->stages[si];
+    if (st.kind == 0) return &v->res[st.idx].n1;
+    if (st.kind == 1) return &v->attn[st.idx].n;
+    return nullptr;
+}
+static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s, bool stats_ready = false) {
+    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0,
+                             stats_ready ? 1 : 0);
 }
 static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
                   bf16_t* dx_bf, int P, int swish, hipStream_t s) {
@@ -335,16 +345,21 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     {   GemmDesc d; d.A = v->zq; d.a_is_f32 = 1; d.lda = v->D; d.B = v->pq.W; d.ldb = v->D; d.M = P0; d.N = v->zc; d.K = v->D;
         d.bias_n = v->pq.b; d.out_bf16 = v->pqo_bf; d.ldc_bf16 = v->zc;
         if ((r = vg(v, d, s))) return r; }
-    if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf))) return r;
+    // `sr`: the statistics of the GroupNorm that consumes x next were already accumulated by x's producer
+    const GN* nx = first_norm(v, 0);
+    if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
+    bool sr = nx && nx->C == v->conv_in.Cout;
     float* x = v->h_in;
     bf16_t* x_bf = v->h_in_bf;   // bf16 twin of x (null when no GEMM reads x directly)
-    for (auto& st : v->stages) {
+    for (int si = 0; si < (int)v->stages.size(); ++si) {
+        const Stage& st = v->stages[si];
+        nx = first_norm(v, si + 1);
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
             const int P = b.res * b.res;
             b.x_in = x; b.x_in_bf = x_bf;
-            if ((r = gn_fwd(v, b.n1, x, P, 1, s))) return r;
-            if ((r = conv3_fwd(v, b.c1, v->a, false, b.res, false, nullptr, b.h1, b.Cout, s))) return r;
+            if ((r = gn_fwd(v, b.n1, x, P, 1, s, sr))) return r;
+            if ((r = conv3_fwd(v, b.c1, v->a, false, b.res, false, nullptr, b.h1, b.Cout, s, nullptr, &b.n2))) return r;
             const float* resid = x;
             if (b.has_sc) {
                 PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the shortcut input");
@@ -353,14 +368,15 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 if ((r = vg(v, d, s))) return r;
                 resid = b.scbuf;
             }
-            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s))) return r;
-            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s, b.out_bf))) return r;
+            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, true))) return r;
+            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s, b.out_bf, nx))) return r;
+            sr = nx && nx->C == b.Cout;
             x = b.out; x_bf = b.out_bf;
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
             const int P = b.res * b.res, C = b.C;
             b.x_in = x;
-            if ((r = gn_fwd(v, b.n, x, P, 0, s))) return r;
+            if ((r = gn_fwd(v, b.n, x, P, 0, s, sr))) return r;
             {   GemmDesc d; d.A = v->a; d.lda = C; d.B = b.qkv.W; d.ldb = C; d.M = P; d.N = 3 * C; d.K = C;
                 d.bias_n = b.qkv.b; d.out_bf16 = b.qkvb; d.ldc_bf16 = 3 * C;
                 if ((r = vg(v, d, s))) return r; }
@@ -375,19 +391,22 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
                 d.out_bf16 = b.out_bf; d.ldc_bf16 = C;
+                if (nx && nx->C == C) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
                 if ((r = vg(v, d, s))) return r; }
+            sr = nx && nx->C == C;
             x = b.out; x_bf = b.out_bf;
         } else {
             UpBlock& b = v->ups[st.idx];
             b.x_in = x; b.x_in_bf = x_bf;
             PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the upsample input");
-            if ((r = conv3_fwd(v, b.c, x_bf, false, b.res_out, true, nullptr, b.out, b.C, s, b.out_bf))) return r;
+            if ((r = conv3_fwd(v, b.c, x_bf, false, b.res_out, true, nullptr, b.out, b.C, s, b.out_bf, nx))) return r;
+            sr = nx && nx->C == b.C;
             x = b.out; x_bf = b.out_bf;
         }
     }
     v->x_last = x;
     const int PH = v->H * v->W;
-    if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s))) return r;
+    if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s, sr))) return r;
     if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, false, nullptr, v->y, 4, s))) return r;
     return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
 }
