@@ -223,6 +223,12 @@ int prx_k_vq_nearest(const float* z, long long tok_stride, long long ch_stride, 
                      prx_stream_t s);
 int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t s);
 
+/* same attention for any sequence length (ViT-B/16: 197 tokens, ViT-L/14: 257): 64-token tiles, online softmax;
+ * `out` and `lse` (fp32 [N*heads*T]) are kept for the backward */
+int prx_k_mha_fwd_gen(const void* qkv, void* out, float* lse, int N, int T, int C, int heads, prx_stream_t s);
+int prx_k_mha_bwd_gen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T, int C,
+                      int heads, prx_stream_t s);
+
 /* A/B switch between the two GEMM kernels (1 = direct-to-LDS v2, default; 0 = register-staged v1) */
 void prx_gemm_variant(int use_glds);
 /* tuning override of the tile / split-K heuristic: bm,bn in {(128,128),(128,64),(64,64)}; (0,0,0) = heuristic */

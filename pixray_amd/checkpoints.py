@@ -1,0 +1,59 @@
+"""State-dict adapters for real checkpoints.  No checkpoint can be downloaded offline, so these
+are exercised in tests with randomly initialised upstream-format state dicts; the formats are:
+
+* OpenAI CLIP (`clip.load(name)` state dict, slip.py:175): keys `visual.conv1.weight`, `visual.class_embedding`,
+  `visual.positional_embedding`, `visual.ln_pre.*`, `visual.transformer.resblocks.{i}.*`, `visual.ln_post.*`,
+  `visual.proj` -> strip the `visual.` prefix (weights may be fp16 on CUDA: cast to fp32).
+* HF `CLIPVisionModelWithProjection` -> the same names (q/k/v projections are concatenated into `in_proj_*`).
+* taming-transformers VQGAN Lightning checkpoint (`vqgan.py:124-140`): `state_dict` with `decoder.*`,
+  `post_quant_conv.*`, `quantize.embedding.weight` (the `encoder.*`, `quant_conv.*`, `loss.*` entries are not on the
+  hot path and are dropped, as `del model.loss` does at vqgan.py:139).
+"""
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+
+from .weights import ClipVitConfig, VqganConfig, clip_vit_param_shapes, vqgan_param_shapes
+
+
+def _check(params: Dict[str, torch.Tensor], shapes) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for name, shape in shapes.items():
+        if name not in params:
+            raise KeyError(f"checkpoint is missing {name}")
+        t = params[name].detach().float().contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: checkpoint has shape {tuple(t.shape)}, the configuration needs {tuple(shape)}")
+        out[name] = t
+    return out
+
+
+def clip_visual_from_openai(state_dict: Dict[str, torch.Tensor], cfg: ClipVitConfig):
+    params = {k[len("visual."):]: v for k, v in state_dict.items() if k.startswith("visual.")}
+    return _check(params, clip_vit_param_shapes(cfg))
+
+
+def clip_visual_from_hf(state_dict: Dict[str, torch.Tensor], cfg: ClipVitConfig):
+    sd = state_dict
+    p = {"class_embedding": sd["vision_model.embeddings.class_embedding"],
+         "conv1.weight": sd["vision_model.embeddings.patch_embedding.weight"],
+         "positional_embedding": sd["vision_model.embeddings.position_embedding.weight"],
+         "ln_pre.weight": sd["vision_model.pre_layrnorm.weight"], "ln_pre.bias": sd["vision_model.pre_layrnorm.bias"],
+         "ln_post.weight": sd["vision_model.post_layernorm.weight"], "ln_post.bias": sd["vision_model.post_layernorm.bias"],
+         "proj": sd["visual_projection.weight"].T}
+    for i in range(cfg.layers):
+        a, b = f"transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+        p[a + "attn.in_proj_weight"] = torch.cat([sd[b + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        p[a + "attn.in_proj_bias"] = torch.cat([sd[b + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        p[a + "attn.out_proj.weight"] = sd[b + "self_attn.out_proj.weight"]
+        p[a + "attn.out_proj.bias"] = sd[b + "self_attn.out_proj.bias"]
+        for (x, y) in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            p[a + x + ".weight"] = sd[b + y + ".weight"]
+            p[a + x + ".bias"] = sd[b + y + ".bias"]
+    return _check(p, clip_vit_param_shapes(cfg))
+
+
+def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig):
+    sd = state_dict.get("state_dict", state_dict)
+    return _check(dict(sd), vqgan_param_shapes(cfg))

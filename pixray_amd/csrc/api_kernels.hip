@@ -64,4 +64,12 @@ int prx_k_mha_bwd(const void* qkv, const void* dout, void* dqkv, int N, int T, i
     return prx_mha_bwd(CB_(qkv), CB_(dout), B_(dqkv), N, T, C, heads, S_(s));
 }
 
+int prx_k_mha_fwd_gen(const void* qkv, void* out, float* lse, int N, int T, int C, int heads, prx_stream_t s) {
+    return prx_mha_fwd_gen(CB_(qkv), B_(out), lse, N, T, C, heads, S_(s));
+}
+int prx_k_mha_bwd_gen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T, int C,
+                      int heads, prx_stream_t s) {
+    return prx_mha_bwd_gen(CB_(qkv), CB_(out), CB_(dout), lse, B_(dqkv), N, T, C, heads, S_(s));
+}
+
 }  // extern "C"

@@ -3,3 +3,7 @@
 // qkv: bf16 [N*T, 3C] (q | k | v, head h at columns h*64..), out/dout: bf16 [N*T, C]
 int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s);
 int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int T, int C, int heads, hipStream_t s);
+// any sequence length (64-token tiles, online softmax); out must be kept for the backward, lse: fp32 [N*heads*T]
+int prx_mha_fwd_gen(const bf16_t* qkv, bf16_t* out, float* lse, int N, int T, int C, int heads, hipStream_t s);
+int prx_mha_bwd_gen(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int N, int T,
+                    int C, int heads, hipStream_t s);

@@ -203,6 +203,216 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ 
     store_c_global(acc, obase + 2 * C, ld, T, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// General sequence length (T > 64: ViT-B/16 has 197 tokens, ViT-L/14 257), head dim 64: flash-style tiling over
+// 64-token tiles with an online softmax.  One wave per (64-query tile, head, image).
+//   forward : O = softmax(QK^T/8) V, also writes LSE_i = m_i + log(l_i) (fp32) for the backward
+//   backward: dQ kernel (one wave per query tile, loops over key tiles) and dK/dV kernel (one wave per key tile,
+//             loops over query tiles); both recompute P from LSE.  D_i = sum_d dO_id * O_id is recomputed per tile.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_rows(const bf16_t* src, long long ld, int t0, int T, bf16_t* dst, bf16_t* dstT, int lane) {
+    // rows t0 .. t0+63 of a [T][64] matrix (zero beyond T)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c >> 3, kc = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + row < T) v = *reinterpret_cast<const bf16x8*>(src + (long long)(t0 + row) * ld + kc * 8);
+        if (dst) *reinterpret_cast<bf16x8*>(&dst[row * LD + kc * 8]) = v;
+        if (dstT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dstT[(kc * 8 + e) * LD + row] = v[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void mha_fwd_gen_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                         float* __restrict__ lse, int T, int C, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];
+    bf16_t* Qs = smem; bf16_t* Ks = smem + TILE; bf16_t* Vt = smem + 2 * TILE; bf16_t* Ps = smem + 3 * TILE;
+    const int lane = threadIdx.x;
+    const int qt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const int q0 = qt * 64;
+    load_rows(base, ld, q0, T, Qs, nullptr, lane);
+    f32x16 o[2][2];
+    zero_acc(o);
+    float m_run[2][16], l_run[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { m_run[mi][r] = -INFINITY; l_run[mi][r] = 0.f; }
+    const int j0l = lane & 31;
+    for (int k0 = 0; k0 < T; k0 += 64) {
+        __syncthreads();
+        load_rows(base + C, ld, k0, T, Ks, nullptr, lane);
+        load_rows(base + 2 * C, ld, k0, T, nullptr, Vt, lane);
+        __syncthreads();
+        f32x16 s[2][2];
+        zero_acc(s);
+        mma_64x64x64(Qs, Ks, s, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v0 = (k0 + j0l < T) ? s[mi][0][r] * scale : -INFINITY;
+                const float v1 = (k0 + j0l + 32 < T) ? s[mi][1][r] * scale : -INFINITY;
+                const float mx = fmaxf(m_run[mi][r], half_max(fmaxf(v0, v1)));
+                const float alpha = __expf(m_run[mi][r] - mx);          // 0 on the first tile (m = -inf)
+                const float e0 = __expf(v0 - mx), e1 = __expf(v1 - mx);
+                l_run[mi][r] = l_run[mi][r] * alpha + half_sum(e0 + e1);
+                m_run[mi][r] = mx;
+                s[mi][0][r] = e0; s[mi][1][r] = e1;
+                o[mi][0][r] *= alpha; o[mi][1][r] *= alpha;
+            }
+        store_c_tile(s, Ps, nullptr, lane);
+        __syncthreads();
+        mma_64x64x64(Ps, Vt, o, lane);
+    }
+    const int col = lane & 31, rb = 4 * (lane >> 5);
+    bf16_t* obase = out + (long long)n * T * C + h * 64;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = q0 + mi * 32 + (r & 3) + 8 * (r >> 2) + rb;
+            if (i < T) {
+                const float inv = 1.f / l_run[mi][r];
+                obase[(long long)i * C + col] = (bf16_t)(o[mi][0][r] * inv);
+                obase[(long long)i * C + 32 + col] = (bf16_t)(o[mi][1][r] * inv);
+                if (col == 0) lse[((long long)n * heads + h) * T + i] = m_run[mi][r] + __logf(l_run[mi][r]);
+            }
+        }
+}
+
+// P (C layout, rows = this wave's queries) from LSE, and dS = scale * P o (dP - D)
+__device__ __forceinline__ void probs_from_lse(f32x16 (&s)[2][2], const float (&lse_r)[2][16], float scale, int k0, int T, int lane) {
+    const int j0l = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[mi][0][r] = (k0 + j0l < T) ? __expf(s[mi][0][r] * scale - lse_r[mi][r]) : 0.f;
+            s[mi][1][r] = (k0 + j0l + 32 < T) ? __expf(s[mi][1][r] * scale - lse_r[mi][r]) : 0.f;
+        }
+}
+
+// per-row quantities of the 64 query rows starting at q0 in the C layout: LSE and D = rowsum(dO o O)
+__device__ __forceinline__ void row_stats(const float* lse_h, const bf16_t* o_h, const bf16_t* do_h, long long ldo, int q0, int T,
+                                          float (&lse_r)[2][16], float (&d_r)[2][16], int lane) {
+    const int rb = 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = q0 + mi * 32 + (r & 3) + 8 * (r >> 2) + rb;
+            float dsum = 0.f, l = 0.f;
+            if (i < T) {
+                l = lse_h[i];
+                // 32 lanes of the half-wave share row i: each handles 2 of the 64 columns
+                const int c = (lane & 31) * 2;
+                dsum = (float)do_h[(long long)i * ldo + c] * (float)o_h[(long long)i * ldo + c] +
+                       (float)do_h[(long long)i * ldo + c + 1] * (float)o_h[(long long)i * ldo + c + 1];
+            }
+            d_r[mi][r] = half_sum(dsum);
+            lse_r[mi][r] = (i < T) ? l : INFINITY;     // exp(x - inf) = 0 for padded query rows
+        }
+}
+
+__global__ __launch_bounds__(64) void mha_bwd_dq_gen_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int T, int C, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[5 * TILE];
+    bf16_t* Qs = smem; bf16_t* dOs = smem + TILE; bf16_t* Ks = smem + 2 * TILE; bf16_t* Vs = smem + 3 * TILE; bf16_t* Kt = smem + 4 * TILE;
+    const int lane = threadIdx.x;
+    const int qt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const bf16_t* dob = dout + (long long)n * T * C + h * 64;
+    const bf16_t* ob = o + (long long)n * T * C + h * 64;
+    const int q0 = qt * 64;
+    load_rows(base, ld, q0, T, Qs, nullptr, lane);
+    load_rows(dob, C, q0, T, dOs, nullptr, lane);
+    float lse_r[2][16], d_r[2][16];
+    row_stats(lse + ((long long)n * heads + h) * T, ob, dob, C, q0, T, lse_r, d_r, lane);
+    f32x16 dq[2][2];
+    zero_acc(dq);
+    for (int k0 = 0; k0 < T; k0 += 64) {
+        __syncthreads();
+        load_rows(base + C, ld, k0, T, Ks, Kt, lane);
+        load_rows(base + 2 * C, ld, k0, T, Vs, nullptr, lane);
+        __syncthreads();
+        f32x16 p[2][2], dp[2][2];
+        zero_acc(p);
+        mma_64x64x64(Qs, Ks, p, lane);
+        probs_from_lse(p, lse_r, scale, k0, T, lane);
+        zero_acc(dp);
+        mma_64x64x64(dOs, Vs, dp, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dp[mi][0][r] = scale * p[mi][0][r] * (dp[mi][0][r] - d_r[mi][r]);
+                dp[mi][1][r] = scale * p[mi][1][r] * (dp[mi][1][r] - d_r[mi][r]);
+            }
+        __syncthreads();
+        store_c_tile(dp, Ks, nullptr, lane);         // Ks <- dS [i][j]  (K itself is no longer needed, K^T is)
+        __syncthreads();
+        mma_64x64x64(Ks, Kt, dq, lane);              // dQ += dS K
+    }
+    store_c_global(dq, dqkv + (long long)n * T * ld + h * 64 + (long long)q0 * ld, ld, T - q0, lane);
+}
+
+__global__ __launch_bounds__(64) void mha_bwd_dkv_gen_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, int T, int C, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[6 * TILE];
+    bf16_t* Ks = smem; bf16_t* Vs = smem + TILE; bf16_t* Qs = smem + 2 * TILE; bf16_t* dOs = smem + 3 * TILE;
+    bf16_t* Qt = smem + 4 * TILE; bf16_t* dOt = smem + 5 * TILE;
+    const int lane = threadIdx.x;
+    const int kt = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const bf16_t* dob = dout + (long long)n * T * C + h * 64;
+    const bf16_t* ob = o + (long long)n * T * C + h * 64;
+    const int k0 = kt * 64;
+    load_rows(base + C, ld, k0, T, Ks, nullptr, lane);
+    load_rows(base + 2 * C, ld, k0, T, Vs, nullptr, lane);
+    f32x16 dk[2][2], dv[2][2];
+    zero_acc(dk); zero_acc(dv);
+    for (int q0 = 0; q0 < T; q0 += 64) {
+        __syncthreads();
+        load_rows(base, ld, q0, T, Qs, Qt, lane);
+        load_rows(dob, C, q0, T, dOs, dOt, lane);
+        __syncthreads();
+        float lse_r[2][16], d_r[2][16];
+        row_stats(lse + ((long long)n * heads + h) * T, ob, dob, C, q0, T, lse_r, d_r, lane);
+        f32x16 p[2][2], dp[2][2];
+        zero_acc(p);
+        mma_64x64x64(Qs, Ks, p, lane);
+        probs_from_lse(p, lse_r, scale, k0, T, lane);
+        zero_acc(dp);
+        mma_64x64x64(dOs, Vs, dp, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dp[mi][0][r] = scale * p[mi][0][r] * (dp[mi][0][r] - d_r[mi][r]);
+                dp[mi][1][r] = scale * p[mi][1][r] * (dp[mi][1][r] - d_r[mi][r]);
+            }
+        __syncthreads();
+        store_c_tile(p, nullptr, Qs, lane);          // Qs  <- P^T  [j][i]
+        store_c_tile(dp, nullptr, dOs, lane);        // dOs <- dS^T [j][i]
+        __syncthreads();
+        mma_64x64x64(Qs, dOt, dv, lane);             // dV += P^T dO
+        mma_64x64x64(dOs, Qt, dk, lane);             // dK += dS^T Q
+    }
+    bf16_t* ob2 = dqkv + (long long)n * T * ld + h * 64 + (long long)k0 * ld;
+    store_c_global(dk, ob2 + C, ld, T - k0, lane);
+    store_c_global(dv, ob2 + 2 * C, ld, T - k0, lane);
+}
+
 }  // namespace
 
 int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s) {
@@ -215,6 +425,23 @@ int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, 
 int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha bwd: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
     hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(64), 0, s, qkv, dout, dqkv, T, C, 0.125f);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+
+int prx_mha_fwd_gen(const bf16_t* qkv, bf16_t* out, float* lse, int N, int T, int C, int heads, hipStream_t s) {
+    PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(gen): needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
+    hipLaunchKernelGGL(mha_fwd_gen_kernel, dim3(ceil_div(T, 64), heads, N), dim3(64), 0, s, qkv, out, lse, T, C, heads, 0.125f);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_mha_bwd_gen(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int N, int T,
+                    int C, int heads, hipStream_t s) {
+    PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(gen) bwd: needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
+    dim3 grid(ceil_div(T, 64), heads, N);
+    hipLaunchKernelGGL(mha_bwd_dq_gen_kernel, grid, dim3(64), 0, s, qkv, out, dout, lse, dqkv, T, C, heads, 0.125f);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mha_bwd_dkv_gen_kernel, grid, dim3(64), 0, s, qkv, out, dout, lse, dqkv, T, C, heads, 0.125f);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -526,29 +526,43 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restri
 __constant__ float c_clip_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
 __constant__ float c_clip_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
-// A[(n*T + 1 + gy*G + gx)][c*P*P + py*P + px] = ((x - mn)/(mx - mn) - mean_c)/std_c ; row n*T is zero (class token)
+// A[(n*T + 1 + gy*G + gx)][c*P*P + py*P + px] = ((x - mn)/(mx - mn) - mean_c)/std_c ; row n*T is zero (class token).
+// Kp = 3*P*P rounded up to a multiple of 8 (zero columns): ViT-L/14 has 588 -> 592.
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
-                                                           bf16_t* __restrict__ A, int N, int S, int P, int T) {
+                                                           bf16_t* __restrict__ A, int N, int S, int P, int T, int Kp) {
     const int G = S / P;
     const int K = 3 * P * P;
-    const int K8 = K / 8;
+    const int K8 = Kp / 8;
     const size_t total = (size_t)N * T * K8;
     const float mn = mm[0];
     const float range = mm[1] - mm[0];
     const float inv = range != 0.f ? 1.f / range : 1.f;
+    const bool fast = (P % 8) == 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int k8 = (int)(idx % K8);
         const size_t row = idx / K8;
         const int tok = (int)(row % T), n = (int)(row / T);
         bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
         if (tok > 0) {
-            const int k = k8 * 8;
-            const int c = k / (P * P), py = (k / P) % P, px = k % P;
             const int gy = (tok - 1) / G, gx = (tok - 1) % G;
-            const float* src = cut + (((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px;
-            const float im = c_clip_mean[c], is = 1.f / c_clip_std[c];
+            if (fast) {
+                const int k = k8 * 8;
+                const int c = k / (P * P), py = (k / P) % P, px = k % P;
+                const float* src = cut + (((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px;
+                const float im = c_clip_mean[c], is = 1.f / c_clip_std[c];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((((src[e] - mn) * inv) - im) * is);
+                for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((((src[e] - mn) * inv) - im) * is);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k8 * 8 + e;
+                    if (k < K) {
+                        const int c = k / (P * P), py = (k / P) % P, px = k % P;
+                        const float v = cut[(((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px];
+                        r[e] = (bf16_t)((((v - mn) * inv) - c_clip_mean[c]) / c_clip_std[c]);
+                    }
+                }
+            }
         }
         reinterpret_cast<bf16x8*>(A)[idx] = r;
     }
@@ -558,9 +572,8 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void patchify_bwd_reduce_kernel(const float* __restrict__ cut,
                                                                   const float* __restrict__ mm,
                                                                   const float* __restrict__ dA, double* __restrict__ acc,
-                                                                  int N, int S, int P, int T) {
+                                                                  int N, int S, int P, int T, int K) {
     const int G = S / P;
-    const int K = 3 * P * P;
     const size_t total = (size_t)N * 3 * S * S;
     const float mn = mm[0], mx = mm[1];
     const float range = mx - mn;
@@ -590,9 +603,8 @@ __global__ __launch_bounds__(256) void patchify_bwd_apply_kernel(const float* __
                                                                  const float* __restrict__ mm,
                                                                  const float* __restrict__ dA,
                                                                  const double* __restrict__ acc, float* __restrict__ gcut,
-                                                                 int N, int S, int P, int T) {
+                                                                 int N, int S, int P, int T, int K) {
     const int G = S / P;
-    const int K = 3 * P * P;
     const size_t total = (size_t)N * 3 * S * S;
     const float mn = mm[0], mx = mm[1];
     const float range = mx - mn;
@@ -665,10 +677,12 @@ int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hip
     PRX_LAUNCH_CHECK();
     return 0;
 }
+static inline int patch_kp(int P) { return (3 * P * P + 7) / 8 * 8; }
+
 int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S, int P, int T, hipStream_t s) {
-    PRX_REQUIRE(S % P == 0 && P % 8 == 0 && T == (S / P) * (S / P) + 1, "patchify: bad geometry S=%d P=%d T=%d", S, P, T);
-    hipLaunchKernelGGL(patchify_fwd_kernel, dim3(ew_grid((size_t)N * T * 3 * P * P / 8)), dim3(256), 0, s, cut, mm, A, N,
-                       S, P, T);
+    PRX_REQUIRE(S % P == 0 && T == (S / P) * (S / P) + 1, "patchify: bad geometry S=%d P=%d T=%d", S, P, T);
+    const int Kp = patch_kp(P);
+    hipLaunchKernelGGL(patchify_fwd_kernel, dim3(ew_grid((size_t)N * T * Kp / 8)), dim3(256), 0, s, cut, mm, A, N, S, P, T, Kp);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -676,14 +690,14 @@ int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, 
                             hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
     hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 512)), dim3(256), 0, s,
-                       cut, mm, dA, acc, N, S, P, T);
+                       cut, mm, dA, acc, N, S, P, T, patch_kp(P));
     PRX_LAUNCH_CHECK();
     return 0;
 }
 int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, const double* acc, float* gcut, int N,
                            int S, int P, int T, hipStream_t s) {
     hipLaunchKernelGGL(patchify_bwd_apply_kernel, dim3(ew_grid((size_t)N * 3 * S * S)), dim3(256), 0, s, cut, mm, dA, acc,
-                       gcut, N, S, P, T);
+                       gcut, N, S, P, T, patch_kp(P));
     PRX_LAUNCH_CHECK();
     return 0;
 }

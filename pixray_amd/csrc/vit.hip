@@ -61,6 +61,8 @@ struct VitLayer {
     // saved activations
     float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
     bf16_t *qkv, *t;
+    bf16_t* o_save;   // attention output, kept for the general-T backward (T > 64)
+    float* lse;
 };
 
 struct PrxVit {
@@ -107,13 +109,20 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     PRX_REQUIRE(res % patch == 0 && width == heads * 64 && width % 256 == 0, "vit_create: unsupported geometry");
     const int G = res / patch;
     const int T = G * G + 1;
-    PRX_REQUIRE(T <= 64, "vit_create: this build supports sequences of <= 64 tokens (T=%d)", T);
     PrxVit* v = new PrxVit();
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
-    v->T = T; v->max_n = max_n; v->KP = 3 * patch * patch; v->cur_n = 0;
+    v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
-    if ((r = pack_both(v, &v->Wp, &v->WpT, w[0], W, KP, s))) return r;
+    {   // conv1.weight [W, 3*P*P] -> zero-padded to KP columns, both orientations
+        const int K0 = 3 * patch * patch;
+        float* padded;
+        ALLOC(padded, (size_t)W * KP);
+        PRX_CHECK_HIP(hipMemsetAsync(padded, 0, sizeof(float) * (size_t)W * KP, s));
+        PRX_CHECK_HIP(hipMemcpy2DAsync(padded, sizeof(float) * KP, w[0], sizeof(float) * K0, sizeof(float) * K0, W,
+                                       hipMemcpyDeviceToDevice, s));
+        if ((r = pack_both(v, &v->Wp, &v->WpT, padded, W, KP, s))) return r;
+    }
     if ((r = copy_f32(v, &v->cls, w[1], W, s))) return r;
     if ((r = copy_f32(v, &v->pos, w[2], (size_t)T * W, s))) return r;
     if ((r = copy_f32(v, &v->lnpre_g, w[3], W, s))) return r;
@@ -138,6 +147,8 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
         ALLOC(y.x_in, R * W); ALLOC(y.x_mid, R * W);
         ALLOC(y.mean1, R); ALLOC(y.rstd1, R); ALLOC(y.mean2, R); ALLOC(y.rstd2, R);
         ALLOC(y.qkv, R * 3 * W); ALLOC(y.t, R * 4 * W);
+        y.o_save = nullptr; y.lse = nullptr;
+        if (T > 64) { ALLOC(y.o_save, R * W); ALLOC(y.lse, (size_t)max_n * heads * T); }
     }
     const float* const* q = w + 5 + 12 * layers;
     if ((r = copy_f32(v, &v->lnpost_g, q[0], W, s))) return r;
@@ -191,8 +202,10 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.Wqkv; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W;
             d.bias_n = y.bqkv; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_mha_fwd(y.qkv, v->att_o, n, T, W, v->heads, s))) return r;
-        {   GemmDesc d; d.A = v->att_o; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
+        const bf16_t* att = v->att_o;
+        if (T <= 64) { if ((r = prx_mha_fwd(y.qkv, v->att_o, n, T, W, v->heads, s))) return r; }
+        else { if ((r = prx_mha_fwd_gen(y.qkv, y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
+        {   GemmDesc d; d.A = att; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.bias_n = y.bo; d.resid = y.x_in; d.ldr = W; d.out_f32 = y.x_mid; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
         if ((r = prx_layernorm_fwd(y.x_mid, W, y.ln2_g, y.ln2_b, v->h, nullptr, y.mean2, y.rstd2, R, W, 1e-5f, s))) return r;
@@ -244,7 +257,8 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.out_bf16 = v->do_; d.ldc_bf16 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_mha_bwd(y.qkv, v->do_, v->dqkv, n, T, W, v->heads, s))) return r;
+        if (T <= 64) { if ((r = prx_mha_bwd(y.qkv, v->do_, v->dqkv, n, T, W, v->heads, s))) return r; }
+        else { if ((r = prx_mha_bwd_gen(y.qkv, y.o_save, v->do_, y.lse, v->dqkv, n, T, W, v->heads, s))) return r; }
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }

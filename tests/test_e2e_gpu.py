@@ -218,3 +218,28 @@ def test_hipgraph_replay_matches_eager_launches():
         assert (d > 1e-3).float().mean().item() < 2e-3, (it, d.max().item())
         assert d.max().item() <= 0.4 + 1e-6
     assert b._graph is not None
+
+
+def test_hf_clip_checkpoint_loads_and_matches():
+    """real-checkpoint path: an upstream-format state dict (HF CLIPVisionModelWithProjection, random
+    init -- no weights exist offline) goes through pixray_amd.checkpoints into the HIP tower and reproduces HF's own
+    output on the same preprocessed batch"""
+    transformers = pytest.importorskip("transformers")
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from pixray_amd import checkpoints
+    from oracle import clip_vit_ref
+    cfg = weights.ClipVitConfig("hf-test", 224, 32, 768, 2, 12, 512)
+    hc = CLIPVisionConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=12, image_size=224,
+                          patch_size=32, projection_dim=512, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    torch.manual_seed(0)
+    m = CLIPVisionModelWithProjection(hc).eval()
+    params = checkpoints.clip_visual_from_hf(m.state_dict(), cfg)
+    h = ops.ClipVitHandle(cfg, params, max_batch=4, device=DEV)
+    cut = torch.rand(4, 3, 224, 224)
+    emb = ops.clip_encode_image(cut.to(DEV), h).cpu()
+    with torch.no_grad():
+        ref = m(pixel_values=clip_vit_ref.preprocess(cut)).image_embeds
+    ref = ref / ref.norm(dim=-1, keepdim=True)
+    assert rel(emb, ref) < 1e-2 and torch.nn.functional.cosine_similarity(emb, ref).min() > 0.9999
+    with pytest.raises(KeyError):
+        checkpoints.clip_visual_from_openai({"visual.conv1.weight": torch.zeros(1)}, cfg)

@@ -271,3 +271,32 @@ def test_mha_fwd_bwd(N, T):
     for i, nm in enumerate("qkv"):
         e = rel_l2(dqkv[:, i * C:(i + 1) * C], refd[:, i * C:(i + 1) * C])
         assert e < 1.2e-2, (nm, e)
+
+
+@pytest.mark.parametrize("N,T", [(2, 65), (3, 197), (2, 257), (4, 50)])
+def test_mha_general_fwd_bwd(N, T):
+    """flash-style attention for any sequence length (ViT-B/16: 197 tokens, ViT-L/14: 257)"""
+    torch.manual_seed(N * T + 1)
+    C, heads = 256, 4
+    qkv = bf(torch.randn(N * T, 3 * C, device=DEV))
+    out = torch.full((N * T, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((N * heads * T,), float("nan"), device=DEV)
+    call("prx_k_mha_fwd_gen", qkv, out, lse, N, T, C, heads, stream())
+    q, k, v = [t.reshape(N, T, heads, 64).permute(0, 2, 1, 3).float().requires_grad_(True)
+               for t in qkv.float().split(C, dim=1)]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    att = torch.softmax(sc, dim=-1)
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(N * T, C)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 8e-3, rel_l2(out, ref)
+    assert rel_l2(lse.reshape(N, heads, T), torch.logsumexp(sc, dim=-1)) < 1e-5
+    do = bf(torch.randn(N * T, C, device=DEV))
+    dqkv = torch.full((N * T, 3 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call("prx_k_mha_bwd_gen", qkv, out, do, lse, dqkv, N, T, C, heads, stream())
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), do.float())
+    refd = torch.cat([t.permute(0, 2, 1, 3).reshape(N * T, C) for t in (gq, gk, gv)], dim=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dqkv.float()).all()
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(dqkv[:, i * C:(i + 1) * C], refd[:, i * C:(i + 1) * C])
+        assert e < 1.5e-2, (nm, e)

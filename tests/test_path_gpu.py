@@ -183,7 +183,11 @@ def _clip_case(name, n, seed):
     return ref, out, gref, gd
 
 
-@pytest.mark.parametrize("name,n", [("tiny-B/32", 4), ("ViT-B/32", 8)])
+weights.CLIP_CONFIGS.setdefault("test-B/16", weights.ClipVitConfig("test-B/16", 224, 16, 256, 2, 4, 128))   # 197 tokens
+weights.CLIP_CONFIGS.setdefault("test-L/14", weights.ClipVitConfig("test-L/14", 224, 14, 256, 2, 4, 128))   # 257 tokens, K=588
+
+
+@pytest.mark.parametrize("name,n", [("tiny-B/32", 4), ("ViT-B/32", 8), ("test-B/16", 3), ("test-L/14", 2)])
 def test_clip_vit_vs_oracle(name, n):
     ref, out, gref, gd = _clip_case(name, n, 5)
     assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
