@@ -54,18 +54,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    force_dist = os.environ.get("PRX_FORCE_DIST") == "1"      # exercise the RCCL code path on a single GPU (tests)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
+    torch.manual_seed(1234 + rank)          # per-rank device noise streams (host-side draws are seeded identically)
 
     sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
                                         num_cuts=args.cutn, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev,
                                         group=group, rank=rank, world_size=world)
+    if force_dist and world == 1:
+        sess.world_size = 1
+        for p_ in sess.perceptors.values():
+            p_.group = group              # min/max + renorm-gradient all-reduces over the 1-rank group
+        sess._force_hook_group = group
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             dist.barrier(group=group)
         torch.cuda.synchronize(dev)
@@ -90,7 +98,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.steps / elapsed
-    loss = float(sum(sess.last_losses))
+    loss = float(sum(l.detach() for l in sess.last_losses))
 
     # ---- roofline leg: per-launch HIP-event timing of the GEMM engine over a few extra steps ------------------
     # (eager launches: events cannot be recorded around the nodes of a replayed graph)
@@ -151,10 +159,12 @@ def main():
             "iter_mfma_frac": round(iter_frac, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # RCCL prints its version banner here: keep the JSON line last
+    sys.stderr.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -180,12 +180,12 @@ class Session:
         self._host_ready = False
         result: List[torch.Tensor] = []
         out = self.do_synth_and_filter(result)
-        if self.world_size > 1 and out.requires_grad:
+        if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and out.requires_grad:
             import torch.distributed as dist
 
             def _allreduce(g):
                 g = g.contiguous()
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group if self.group is not None else self._force_hook_group)
                 return g
             out.register_hook(_allreduce)
         cur_cutouts = {}

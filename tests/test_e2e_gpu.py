@@ -241,5 +241,7 @@ def test_hf_clip_checkpoint_loads_and_matches():
         ref = m(pixel_values=clip_vit_ref.preprocess(cut)).image_embeds
     ref = ref / ref.norm(dim=-1, keepdim=True)
     assert rel(emb, ref) < 1e-2 and torch.nn.functional.cosine_similarity(emb, ref).min() > 0.9999
-    with pytest.raises(KeyError):
+    with pytest.raises(ValueError):       # wrong shape
         checkpoints.clip_visual_from_openai({"visual.conv1.weight": torch.zeros(1)}, cfg)
+    with pytest.raises(KeyError):         # missing tensor
+        checkpoints.clip_visual_from_openai({"visual.conv1.weight": torch.zeros(768, 3, 32, 32)}, cfg)
