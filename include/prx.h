@@ -150,6 +150,10 @@ int prx_vqgan_z_bounds(prx_vqgan* h, float* zmin, float* zmax, prx_stream_t s);
 int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int quantize, prx_stream_t s);
 /* d loss / d img -> d loss / d z of the forward in flight on this handle */
 int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s);
+/* Diagnostic (tools/debug_repeat.py, tests): copies one intermediate of the last forward, fp32, to dst and returns the
+ * number of floats copied (-1: bad stage).  stage -2 quantised latent, -1 conv_in output, 0..n-1 decoder stage outputs,
+ * n conv_out output [H*W,4], n+1 the forward GroupNorm sums. */
+long long prx_vqgan_debug_stage(prx_vqgan* h, int stage, float* dst, long long max_floats, prx_stream_t stream);
 
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):

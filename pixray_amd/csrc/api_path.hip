@@ -29,6 +29,10 @@ int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int 
     PRX_REQUIRE(h && z && img, "prx_vqgan_synth: null argument");
     return prx_vqgan_synth_impl((PrxVqgan*)h, z, img, indices, quantize, S_(s));
 }
+long long prx_vqgan_debug_stage(prx_vqgan* h, int stage, float* dst, long long max_floats, prx_stream_t s) {
+    if (!h || !dst) return -1;
+    return prx_vqgan_debug_stage_impl((PrxVqgan*)h, stage, dst, max_floats, S_(s));
+}
 int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s) {
     PRX_REQUIRE(h && g_img && dz, "prx_vqgan_synth_backward: null argument");
     return prx_vqgan_backward_impl((PrxVqgan*)h, g_img, dz, S_(s));

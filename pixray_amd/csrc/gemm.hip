@@ -14,6 +14,8 @@
 #include <stdlib.h>
 
 namespace {
+int g_conv_c64 = (getenv("PRX_CONV_C64") ? atoi(getenv("PRX_CONV_C64")) : 1);   // A/B switch for the scalar-tap conv gather
+
 
 constexpr int BK = 64;
 constexpr int LDS_LD = BK + 8;  // elements; 144-byte rows
@@ -273,15 +275,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
-    constexpr int A_IN = BM / 32;   // DMA instructions (8 rows x 128 B each) per wave per K tile
-    constexpr int B_IN = BN / 32;
-    constexpr int MT = BM / 64;
+// NWM = waves along M (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads for the 256-row tiles); two waves along N.
+template <int BM, int BN, int AMODE, int STAGES, bool C64 = false, int NWM = 2>
+__global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
+    constexpr int NW = NWM * 2;
+    constexpr int A_IN = BM / (8 * NW);   // DMA instructions (8 rows x 128 B each) per wave per K tile
+    constexpr int B_IN = BN / (8 * NW);
+    constexpr int MT = BM / (32 * NWM);
     constexpr int NT = BN / 64;
+    static_assert(A_IN >= 1 && B_IN >= 1 && MT >= 1 && NT >= 1, "tile too small for the wave grid");
     constexpr int TILE = (BM + BN) * BK;   // bf16 elements per stage
 
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * TILE];
+    __shared__ __attribute__((aligned(16))) bf16_t lds[STAGES * TILE];
 
     const GemmDesc& d = p.d;
     const int tid = threadIdx.x;
@@ -330,6 +335,35 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
             a_base[i] = 0;
         }
     }
+    // C64 (implicit conv with Cin % 64 == 0, i.e. every K tile lies inside ONE filter tap): the tap is wave-uniform,
+    // so the per-lane gather address is "row term[ky] + column term[kx]" picked from six values computed once here.
+    // Without this the tap/bounds/pixel arithmetic (two integer divisions per DMA instruction) costs ~10x the VALU
+    // time of the MFMAs it feeds and the conv kernels are VALU-bound.
+    // term(ky) = mid + (ky == 0 ? d0 : 0) + (ky == 2 ? d2 : 0), evaluated with scalar masks (no per-lane selects or
+    // indexed register arrays, which hipcc would spill to scratch)
+    int c_r1[C64 ? A_IN : 1], c_rd0[C64 ? A_IN : 1], c_rd2[C64 ? A_IN : 1];
+    int c_c1[C64 ? A_IN : 1], c_cd0[C64 ? A_IN : 1], c_cd2[C64 ? A_IN : 1], c_ok[C64 ? A_IN : 1];
+    if constexpr (C64) {
+        const int Hs = d.up ? (d.H >> 1) : d.H, Ws = d.up ? (d.W >> 1) : d.W;
+#pragma unroll
+        for (int i = 0; i < A_IN; ++i) {
+            int okm = 0, ro[3], co[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int yy = a_y[i] + t - 1, xx = a_x[i] + t - 1;
+                if (a_ok[i] && yy >= 0 && yy < d.H) okm |= 1 << t;
+                if (xx >= 0 && xx < d.W) okm |= 8 << t;
+                ro[t] = (a_b[i] * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
+                co[t] = d.up ? (xx >> 1) : xx;
+            }
+            c_ok[i] = okm;
+            c_r1[i] = ro[1]; c_rd0[i] = ro[0] - ro[1]; c_rd2[i] = ro[2] - ro[1];
+            c_c1[i] = co[1]; c_cd0[i] = co[0] - co[1]; c_cd2[i] = co[2] - co[1];
+        }
+    }
+    int c_tap = 0, c_c0 = 0;            // running (tap, first channel) of the next K tile to issue (C64)
+    if constexpr (C64) { c_tap = (kt0 * BK) / d.Cin; c_c0 = kt0 * BK - c_tap * d.Cin; }
+
     long long b_base[B_IN];
     int b_sw[B_IN];
     bool b_ok[B_IN];
@@ -345,6 +379,22 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
     auto issue = [&](int kt, int buf) {
         bf16_t* As = lds + buf * TILE;
         bf16_t* Bs = As + BM * BK;
+        if constexpr (C64) {
+            // tiles are issued in K order, so (tap, c0) advance incrementally; all of this is scalar
+            const int ky = c_tap >= 6 ? 2 : (c_tap >= 3 ? 1 : 0);
+            const int kx = c_tap - 3 * ky;
+            const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
+#pragma unroll
+            for (int i = 0; i < A_IN; ++i) {
+                const int ro = c_r1[i] + (my0 & c_rd0[i]) + (my2 & c_rd2[i]);
+                const int co = c_c1[i] + (mx0 & c_cd0[i]) + (mx2 & c_cd2[i]);
+                const bool ok = ((c_ok[i] >> ky) & (c_ok[i] >> (3 + kx)) & 1) != 0;
+                const bf16_t* src = ok ? Ap + (long long)(ro + co) * d.lda + (c_c0 + a_sw[i] * 8) : zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * A_IN + i) * 8 * BK), 16, 0, 0);
+            }
+            c_c0 += BK;
+            if (c_c0 >= d.Cin) { c_c0 = 0; ++c_tap; }
+        } else
 #pragma unroll
         for (int i = 0; i < A_IN; ++i) {
             const int k = kt * BK + a_sw[i] * 8;
@@ -382,15 +432,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) issue(kt0, 0);
-    __syncthreads();
-
     const int frag_row = lane & 31;
     const int khalf = lane >> 5;
     int a_off[MT], a_key[MT], b_off[NT], b_key[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int r = wm * (BM / 2) + i * 32 + frag_row;
+        const int r = wm * (BM / NWM) + i * 32 + frag_row;
         a_off[i] = r * BK; a_key[i] = (r >> 1) & 7;
     }
 #pragma unroll
@@ -398,11 +445,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
         const int r = wn * (BN / 2) + j * 32 + frag_row;
         b_off[j] = r * BK; b_key[j] = (r >> 1) & 7;
     }
-
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
-        const bf16_t* As = lds + cur * TILE;
+    auto compute = [&](int buf) {
+        const bf16_t* As = lds + buf * TILE;
         const bf16_t* Bs = As + BM * BK;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -420,7 +464,36 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    if constexpr (STAGES == 2) {
+        // double buffer, one barrier per K tile (hipcc drains the DMA queue -- vmcnt(0) -- in front of the barrier)
+        if (kt0 < kt1) issue(kt0, 0);
         __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // STAGES-deep ring with COUNTED waits: STAGES-1 K tiles of DMA stay in flight across the (raw) barrier, so a
+        // workgroup that is alone on its CU no longer pays one L2 round trip per K tile.  Each wave issues
+        // LPT = A_IN + B_IN DMA instructions per tile; "vmcnt(LPT*(STAGES-2))" = everything but the newest
+        // STAGES-2 tiles has landed.
+        constexpr int LPT = A_IN + B_IN;
+        const int nk = kt1 - kt0;
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) issue(kt0 + t, t);
+        for (int t = 0; t < nk; ++t) {
+            if (t + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (STAGES - 2)) : "memory");
+            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // tile t complete for every wave; everyone is done reading tile t-1
+            if (t + STAGES - 1 < nk) issue(kt0 + t + STAGES - 1, (t + STAGES - 1) % STAGES);
+            compute(t % STAGES);
+        }
+        __builtin_amdgcn_s_barrier();          // LDS is reused by the epilogue
     }
 
     if (p.vec_epi) {
@@ -432,11 +505,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
         constexpr int LPR = CW / 4;           // lanes per row
         constexpr int RPP = 64 / LPR;         // rows per pass
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * LDW);
-        float* gacc = reinterpret_cast<float*>(lds) + 4 * (32 * LDW);      // [BN/4][2] per-column-quad partial sums
+        float* gacc = reinterpret_cast<float*>(lds) + NW * (32 * LDW);      // [BN/4][2] per-column-quad partial sums
         const bool do_stats = d.gn_stats != nullptr && p.splits == 1;
         if (do_stats && tid < BN / 2) gacc[tid] = 0.f;
         float gs0 = 0.f, gs1 = 0.f;
-        const int rbase = tm * BM + wm * (BM / 2);
+        const int rbase = tm * BM + wm * (BM / NWM);
         const int cbase = tn * BN + wn * (BN / 2);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -488,7 +561,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const GemmArgs p, const 
         }
         return;
     }
-    const int row0 = tm * BM + wm * (BM / 2) + 4 * (lane >> 5);
+    const int row0 = tm * BM + wm * (BM / NWM) + 4 * (lane >> 5);
     const int col0 = tn * BN + wn * (BN / 2) + (lane & 31);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -512,30 +585,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const GemmDesc& d = p.d;
     const size_t total = (size_t)d.M * d.N;
     if (p.vec_epi) {
-        __shared__ float gacc[64];          // 32 groups x {sum, sumsq} for this block
+        // 32 groups x {sum, sumsq} for this block, in DOUBLE: the order of the LDS atomics varies from run to run, and a
+        // float accumulator would make the statistics (hence a few bf16 roundings downstream, which the decoder then
+        // amplifies to its bf16 noise floor) irreproducible; double keeps the order effect ~1e-16
+        __shared__ double gacc[64];
         const bool do_stats = d.gn_stats != nullptr;
-        if (do_stats && threadIdx.x < 64) gacc[threadIdx.x] = 0.f;
+        if (do_stats && threadIdx.x < 64) gacc[threadIdx.x] = 0.0;
         if (do_stats) __syncthreads();
+        const int run = do_stats ? (d.gn_gs >> 2) : 1;      // consecutive lanes (4 columns each) sharing a group: 1, 2, 4, ...
         const size_t total4 = total >> 2;
-        for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < p.splits; ++s) {
-                const float4 w = reinterpret_cast<const float4*>(p.ws + (size_t)s * total)[i4];
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        const size_t base = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const size_t iters = (total4 + stride - 1) / stride;        // uniform trip count: the shuffles below need full waves
+        for (size_t it = 0; it < iters; ++it) {
+            const size_t i4 = base + it * stride;
+            const bool live = i4 < total4;
+            float s0 = 0.f, s1 = 0.f;
+            int col = 0;
+            if (live) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s = 0; s < p.splits; ++s) {
+                    const float4 w = reinterpret_cast<const float4*>(p.ws + (size_t)s * total)[i4];
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                const size_t idx = i4 << 2;
+                const int row = (int)(idx / d.N);
+                col = (int)(idx - (size_t)row * d.N);
+                const float4 o = epilogue_store4(d, row, col, v);
+                s0 = (o.x + o.y) + (o.z + o.w);
+                s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
             }
-            const size_t idx = i4 << 2;
-            const int row = (int)(idx / d.N);
-            const int col = (int)(idx - (size_t)row * d.N);
-            const float4 o = epilogue_store4(d, row, col, v);
             if (do_stats) {
-                const int g = col / d.gn_gs;
-                atomicAdd(&gacc[g * 2], (o.x + o.y) + (o.z + o.w));
-                atomicAdd(&gacc[g * 2 + 1], (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
+                // lanes of one group are an aligned run (N and the block offset are multiples of gn_gs): fixed-order butterfly
+                for (int o = 1; o < run && o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+                if (live && (threadIdx.x & (run - 1)) == 0) {
+                    const int g = col / d.gn_gs;
+                    atomicAdd(&gacc[g * 2], (double)s0);
+                    atomicAdd(&gacc[g * 2 + 1], (double)s1);
+                }
             }
         }
         if (do_stats) {
             __syncthreads();
-            if (threadIdx.x < 64 && gacc[threadIdx.x] != 0.f) atomicAdd(&d.gn_stats[threadIdx.x], (double)gacc[threadIdx.x]);
+            if (threadIdx.x < 64 && gacc[threadIdx.x] != 0.0) atomicAdd(&d.gn_stats[threadIdx.x], gacc[threadIdx.x]);
         }
         return;
     }
@@ -561,12 +653,30 @@ void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
 }
 
-template <int BM, int BN>
-void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
+template <int BM, int BN, int STAGES>
+void launch_glds_s(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
     if (a.d.a_mode == PRX_A_ROWMAJOR)
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a, zero_page);
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR, STAGES>), grid, dim3(256), 0, s, a, zero_page);
+    else if (a.d.Cin % BK == 0 && g_conv_c64)
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES, true>), grid, dim3(256), 0, s, a, zero_page);
     else
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a, zero_page);
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES>), grid, dim3(256), 0, s, a, zero_page);
+}
+// 256x128 tile, 8 waves (wave tile 64x64 like the 128x128 kernel): 1.5 MFMA-flops per L2->LDS byte more than 128x128
+template <int STAGES>
+void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR)
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_ROWMAJOR, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
+    else if (a.d.Cin % BK == 0 && g_conv_c64)
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, true, 4>), grid, dim3(512), 0, s, a, zero_page);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
+}
+template <int BM, int BN>
+void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages) {
+    if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page);
+    else if (stages >= 3) launch_glds_s<BM, BN, 3>(a, grid, s, zero_page);
+    else launch_glds_s<BM, BN, 2>(a, grid, s, zero_page);
 }
 
 std::mutex g_zero_mu;
@@ -587,11 +697,12 @@ const bf16_t* zero_page_for_current_device() {
 }
 
 // ---- optional per-launch profiling (bench.py roofline leg) -------------------
-struct ProfRec { hipEvent_t a, b; double flop; };
+struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, mode, bm, bn, splits; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 bool g_use_glds = true;
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+int g_force_stages = (getenv("PRX_GEMM_STAGES") ? atoi(getenv("PRX_GEMM_STAGES")) : 0);
 int g_xcd_swizzle = (getenv("PRX_XCD_SWIZZLE") ? atoi(getenv("PRX_XCD_SWIZZLE")) : 2);   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
 
@@ -599,7 +710,10 @@ std::vector<ProfRec> g_prof;
 
 void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
 void prx_gemm_force_tile(int bm, int bn, int splits) {
-    if (bm < 0) { g_xcd_swizzle = splits; return; }     // (-1, x, on/off): toggle the XCD-aware tile order
+    if (bm == -1) { g_xcd_swizzle = splits; return; }   // (-1, x, on/off): toggle the XCD-aware tile order
+    if (bm == -2) { g_force_stages = splits; return; }  // (-2, x, n): LDS pipeline depth (0 = heuristic)
+    if (bm == -5) { g_conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
+    if (bm < 0) return;
     g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
 }
 
@@ -611,13 +725,17 @@ void prx_gemm_profile_enable(int on) {
 int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double ms = 0, fl = 0;
+    // PRX_GEMM_PROFILE_DUMP=<path>: one CSV row per launch (tools/gemm_shapes.py aggregates them)
+    FILE* dump = getenv("PRX_GEMM_PROFILE_DUMP") ? fopen(getenv("PRX_GEMM_PROFILE_DUMP"), "a") : nullptr;
     for (auto& r : g_prof) {
         if (hipEventSynchronize(r.b) != hipSuccess) return -1;
         float t = 0;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
         ms += t; fl += r.flop;
-        hipEventDestroy(r.a); hipEventDestroy(r.b);
+        if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.2f\n", r.M, r.N, r.K, r.mode, r.bm, r.bn, r.splits, t * 1e3);
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
+    if (dump) fclose(dump);
     if (total_ms) *total_ms = ms;
     if (total_flop) *total_flop = fl;
     if (launches) *launches = (long long)g_prof.size();
@@ -703,6 +821,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         PRX_CHECK_HIP(hipEventCreate(&rec.a));
         PRX_CHECK_HIP(hipEventCreate(&rec.b));
         rec.flop = 2.0 * d.M * d.N * d.K;
+        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32; rec.bm = BM; rec.bn = BN; rec.splits = splits;
         PRX_CHECK_HIP(hipEventRecord(rec.a, stream));
     }
 
@@ -710,9 +829,17 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     if (!d.a_is_f32 && g_use_glds) {
         const bf16_t* zp = zero_page_for_current_device();
         PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
-        if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp);
-        else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp);
-        else launch_glds<64, 64>(a, grid, stream, zp);
+        // LDS pipeline depth, tuned IN the iteration (tools/gemm_shapes.py), not on hot-cache microbenchmarks: every
+        // weight matrix is touched once per iteration (520 MB of packs > the 256 MB MALL), so each K tile of B comes
+        // from HBM and a 2-deep ring exposes that latency once per K tile.  A third stage on the 64x64 tiles (48 KB,
+        // still 3 workgroups/CU) gives -30 % on the 64^2 decoder convs and -8..-20 % on the other 64x64 launches; on
+        // the 128-wide tiles it halves the occupancy and loses 15-25 %.
+        int stages = (BM == 64 && BN == 64) ? 3 : 2;
+        if (g_force_stages) stages = g_force_stages;
+        if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp); else launch_glds_256<2>(a, grid, stream, zp); }
+        else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages);
+        else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages);
+        else launch_glds<64, 64>(a, grid, stream, zp, stages);
     } else if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);
     else if (BM == 128 && BN == 64) launch_cfg<128, 64>(a, grid, stream);
     else launch_cfg<64, 64>(a, grid, stream);

@@ -8,3 +8,4 @@ void prx_vqgan_destroy_impl(PrxVqgan* v);
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s);
 int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, int quantize, hipStream_t s);
 int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStream_t s);
+long long prx_vqgan_debug_stage_impl(PrxVqgan* v, int stage, float* dst, long long max_floats, hipStream_t s);

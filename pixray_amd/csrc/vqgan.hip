@@ -288,6 +288,9 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
     delete v;
 }
 
+// the GEMM epilogue can accumulate the next GroupNorm's sums only for power-of-two group sizes >= 4 channels
+static bool fusable(int C) { const int gs = C / 32; return C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0; }
+
 static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
 
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int res, bool up, const float* resid,
@@ -296,7 +299,7 @@ static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int
     d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = res * res; d.N = c.Cout; d.K = 9 * c.Cin;
     d.H = res; d.W = res; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
     d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
-    if (stats_for && stats_for->C == c.Cout) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
+    if (stats_for && stats_for->C == c.Cout && fusable(c.Cout)) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
@@ -348,7 +351,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     // `sr`: the statistics of the GroupNorm that consumes x next were already accumulated by x's producer
     const GN* nx = first_norm(v, 0);
     if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
-    bool sr = nx && nx->C == v->conv_in.Cout;
+    bool sr = nx && nx->C == v->conv_in.Cout && fusable(nx->C);
     float* x = v->h_in;
     bf16_t* x_bf = v->h_in_bf;   // bf16 twin of x (null when no GEMM reads x directly)
     for (int si = 0; si < (int)v->stages.size(); ++si) {
@@ -368,9 +371,9 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 if ((r = vg(v, d, s))) return r;
                 resid = b.scbuf;
             }
-            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, true))) return r;
+            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, fusable(b.Cout)))) return r;
             if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s, b.out_bf, nx))) return r;
-            sr = nx && nx->C == b.Cout;
+            sr = nx && nx->C == b.Cout && fusable(b.Cout);
             x = b.out; x_bf = b.out_bf;
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
@@ -391,16 +394,16 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
                 d.out_bf16 = b.out_bf; d.ldc_bf16 = C;
-                if (nx && nx->C == C) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
+                if (nx && nx->C == C && fusable(C)) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
                 if ((r = vg(v, d, s))) return r; }
-            sr = nx && nx->C == C;
+            sr = nx && nx->C == C && fusable(C);
             x = b.out; x_bf = b.out_bf;
         } else {
             UpBlock& b = v->ups[st.idx];
             b.x_in = x; b.x_in_bf = x_bf;
             PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the upsample input");
             if ((r = conv3_fwd(v, b.c, x_bf, false, b.res_out, true, nullptr, b.out, b.C, s, b.out_bf, nx))) return r;
-            sr = nx && nx->C == b.C;
+            sr = nx && nx->C == b.C && fusable(b.C);
             x = b.out; x_bf = b.out_bf;
         }
     }
@@ -409,6 +412,26 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s, sr))) return r;
     if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, false, nullptr, v->y, 4, s))) return r;
     return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
+}
+
+// Diagnostic: copy one intermediate of the last forward (fp32) to dst.  stage -2: quantised latent, -1: conv_in output,
+// 0..n-1: output of decoder stage i, n: conv_out output [H*W,4], n+1: the forward GroupNorm sums (doubles, as floats).
+long long prx_vqgan_debug_stage_impl(PrxVqgan* v, int stage, float* dst, long long max_floats, hipStream_t s) {
+    const float* src = nullptr; long long n = 0;
+    const int ns = (int)v->stages.size();
+    if (stage == -2) { src = v->zq; n = (long long)v->h0 * v->w0 * v->D; }
+    else if (stage == -1) { src = v->h_in; n = (long long)v->h0 * v->w0 * v->conv_in.Cout; }
+    else if (stage >= 0 && stage < ns) {
+        const Stage& st = v->stages[stage];
+        if (st.kind == 0) { const ResBlock& b = v->res[st.idx]; src = b.out; n = (long long)b.res * b.res * b.Cout; }
+        else if (st.kind == 1) { const AttnBlock& b = v->attn[st.idx]; src = b.out; n = (long long)b.res * b.res * b.C; }
+        else { const UpBlock& b = v->ups[st.idx]; src = b.out; n = (long long)b.res_out * b.res_out * b.C; }
+    } else if (stage == ns) { src = v->y; n = (long long)v->H * v->W * 4; }
+    else if (stage == ns + 1) { src = reinterpret_cast<const float*>(v->all_stats); n = (long long)v->n_gn * 64 * 2; }
+    else return -1;
+    if (n > max_floats) n = max_floats;
+    if (hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    return n;
 }
 
 // g_img: NCHW [1, out_ch, H, W] -> dz: NCHW [1, zc, h0, w0] (straight-through over the quantiser)

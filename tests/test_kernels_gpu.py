@@ -111,6 +111,45 @@ def test_gemm_f32_A_and_epilogues(gemm_variant):
     assert rel_l2(out3, 0.5 * (bf(A32).float() @ Bt.float().T) + bm[:, None]) < 2e-5
 
 
+@pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
+@pytest.mark.parametrize("stages", [2, 3, 4])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
+    """every tile shape x LDS pipeline depth x split-K of the direct-to-LDS kernel (normally picked by the heuristic),
+    on ragged row-major shapes with the fused epilogue, and on an implicit conv that uses the scalar-tap gather"""
+    lib = _lib.load()
+    torch.manual_seed(7)
+    try:
+        lib.prx_gemm_tile_override(tile[0], tile[1], splits)
+        lib.prx_gemm_tile_override(-2, 0, stages)
+        for (M, N, K) in [(3200, 768, 768), (1000, 200, 1096), (257, 136, 64)]:
+            A = bf(torch.randn(M, K, device=DEV))
+            Bt = bf(torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K))
+            bias = torch.randn(N, device=DEV)
+            resid = torch.randn(M, N, device=DEV)
+            out, ob, _ = run_gemm(A, Bt, M, N, K, bias_n=bias, resid=resid, want_bf16=True)
+            ref = A.float() @ Bt.float().T + bias + resid
+            assert rel_l2(out, ref) < 2e-5, (M, N, K, rel_l2(out, ref))
+            assert rel_l2(ob, ref) < 4e-3
+        for (H, W, Cin, Cout, up, NB) in [(32, 32, 128, 128, 1, 1), (24, 40, 64, 72, 0, 2), (16, 16, 40, 64, 0, 1)]:
+            hin, win = (H // 2, W // 2) if up else (H, W)
+            x = torch.randn(NB, Cin, hin, win, device=DEV)
+            w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(9 * Cin)
+            bias = torch.randn(Cout, device=DEV)
+            x_nhwc = bf(x.permute(0, 2, 3, 1).contiguous())
+            w_pack = bf(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous())
+            out, _, _ = run_gemm(x_nhwc, w_pack, NB * H * W, Cout, 9 * Cin, a_mode=1, lda=Cin, H=H, W=W, Cin=Cin, up=up,
+                                 bias_n=bias)
+            xr = bf(x).float()
+            if up:
+                xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+            ref = F.conv2d(xr, bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
+            assert rel_l2(out, ref) < 2e-5, (H, W, Cin, Cout, up, rel_l2(out, ref))
+    finally:
+        lib.prx_gemm_tile_override(0, 0, 0)
+        lib.prx_gemm_tile_override(-2, 0, 0)
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [
     (16, 16, 256, 512, 0, 1), (32, 32, 512, 256, 1, 1), (64, 64, 128, 128, 0, 1), (8, 12, 32, 40, 1, 2),
     (256, 256, 128, 128, 0, 1), (64, 64, 8, 128, 0, 1),

@@ -1,0 +1,46 @@
+"""Per-shape table of the GEMM-engine launches of one optimisation iteration (run on the GPU box).
+
+Enables the engine's HIP-event profiling for a few iterations of the headline session, dumps one row per launch
+(PRX_GEMM_PROFILE_DUMP) and aggregates by (M, N, K, A mode, tile, split-K)."""
+import collections
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+path = os.path.join(tempfile.gettempdir(), "prx_gemm_dump.csv")
+if os.path.exists(path):
+    os.remove(path)
+os.environ["PRX_GEMM_PROFILE_DUMP"] = path
+import ctypes
+import torch
+from pixray_amd import _lib, api
+
+dev = torch.device("cuda", 0)
+sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
+                                    num_cuts=64, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev)
+for i in range(3):
+    sess.train(i)
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.prx_profile_gemm_enable(1)
+for i in range(steps):
+    sess.train(3 + i)
+torch.cuda.synchronize()
+lib.prx_profile_gemm_enable(0)
+ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+agg = collections.OrderedDict()
+for line in open(path):
+    M, N, K, mode, bm, bn, sp, us = line.strip().split(",")
+    key = (int(M), int(N), int(K), int(mode), int(bm), int(bn), int(sp))
+    a = agg.setdefault(key, [0, 0.0])
+    a[0] += 1; a[1] += float(us)
+print(f"total {ms.value / steps:.3f} ms/iter, {fl.value / steps / 1e9:.0f} GFLOP/iter, {n.value // steps} launches/iter, "
+      f"{fl.value / ms.value / 1e9:.0f} TFLOP/s")
+print(f"{'M':>6} {'N':>5} {'K':>5} mode tile    sp  n/it  avg_us  ms/it   TF")
+for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    M, N, K, mode, bm, bn, sp = key
+    avg = us / cnt
+    print(f"{M:6d} {N:5d} {K:5d} {mode:4d} {bm:3d}x{bn:<3d} {sp:3d} {cnt / steps:5.1f} {avg:7.1f} {us / steps / 1e3:6.3f} {2.0 * M * N * K / avg / 1e6:5.0f}")
