@@ -116,13 +116,13 @@ def main():
         rc = lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
         if rc == 0 and ms.value > 0:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,TA,AMODE> (bf16 MFMA GEMM / implicit conv)",
+            roofline = {"bound": "mfma", "kernel": "gemm_glds_kernel<BM,BN,AMODE,STAGES,..> (bf16 MFMA GEMM / implicit 3x3 conv, all launches)",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                        # HBM-side bytes per GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic.csv
+                        # HBM-side bytes per GEMM launch from the PMC passes committed in profiles/r01_e_pmc_hbm_traffic.csv
                         # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH doubled per the gfx950
                         # correction of MI355X_MICROARCH.md); not re-measured live
-                        "traffic": 39.9e6, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv",
+                        "traffic": 40.9e6, "traffic_source": "profiles/r01_e_pmc_hbm_traffic.csv",
                         "launches_per_step": n.value // args.profile_steps,
                         "gemm_gflop_per_step": round(fl.value / args.profile_steps / 1e9, 1),
                         "gemm_ms_per_step": round(ms.value / args.profile_steps, 3),
