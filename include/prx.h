@@ -62,7 +62,8 @@ typedef struct prx_gemm_args {
     const void* B;      /* device bf16 [N, K], K contiguous */
     int ldb;
     int M, N, K;
-    int H, W, Cin, up;  /* conv geometry (a_mode == PRX_A_CONV3X3) */
+    int H, W, Cin, up;  /* conv geometry (a_mode == PRX_A_CONV3X3): output H x W; up = 0 source H x W, 1 source H/2 x W/2 read through
+                         * a nearest-2x upsample, 2 source 2H x 2W read with stride 2 and taming's (0,1,0,1) Downsample padding */
     float alpha;
     const float* bias_n;
     const float* bias_m;
@@ -154,6 +155,22 @@ int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_st
  * number of floats copied (-1: bad stage).  stage -2 quantised latent, -1 conv_in output, 0..n-1 decoder stage outputs,
  * n conv_out output [H*W,4], n+1 the forward GroupNorm sums. */
 long long prx_vqgan_debug_stage(prx_vqgan* h, int stage, float* dst, long long max_floats, prx_stream_t stream);
+
+/* --- VqganDrawer.init_from_tensor / reapply_from_tensor / get_z_from_tensor (vqgan.py:174-185):
+ *     `z, *_ = model.encode(img)` = taming Encoder -> quant_conv -> VectorQuantizer2 nearest code [UPSTREAM].  Forward only.
+ * cfg: the same prx_vqgan_config (out_ch unused; latent_h/latent_w ignored: the latent is H/f x W/f).
+ * weights[]: fp32 device tensors in this order:
+ *   quantize.embedding.weight [n_embed, embed_dim]; encoder.conv_in.{weight,bias};
+ *   for level = 0 .. n_mult-1: num_res_blocks x [ResnetBlock (+ AttnBlock at attn_resolution)], then
+ *     downsample.conv.{weight,bias} when level != n_mult-1;
+ *   mid.block_1, mid.attn_1, mid.block_2; norm_out.{weight,bias}; conv_out.{weight,bias}; quant_conv.{weight,bias}.
+ * img: NCHW [1, in_channels, H, W] fp32 in [-1,1] (pixray.py:718-727); z: NCHW [1, embed_dim, H/f, W/f] = the chosen code
+ * vectors; z_pre (optional): the latent before quantisation; indices (optional): int32 [H/f * W/f]. */
+typedef struct prx_vqgan_enc prx_vqgan_enc;
+int prx_vqgan_enc_create(prx_vqgan_enc** out, const prx_vqgan_config* cfg, int in_channels, int H, int W,
+                         const float* const* weights, int n_weights, prx_stream_t s);
+void prx_vqgan_enc_destroy(prx_vqgan_enc* h);
+int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre, int* indices, prx_stream_t s);
 
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):

@@ -146,6 +146,43 @@ def decode(p: Dict[str, torch.Tensor], z_q: torch.Tensor, cfg: dict) -> torch.Te
     return _conv(p, "decoder.conv_out", h, 1)
 
 
+# ---- taming Encoder + VQModel.encode [UPSTREAM] ----------------------------------------------
+def encoder_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """taming `Encoder.forward` (taming/modules/diffusionmodules/model.py, double_z=False): conv_in; per level
+    num_res_blocks ResnetBlocks (+AttnBlock where the NOMINAL resolution is in attn_resolutions), Downsample = zero pad
+    (0,1,0,1) + 3x3 stride-2 conv except after the last level; mid block_1/attn_1/block_2; GroupNorm+swish; conv_out."""
+    ch, ch_mult = cfg["ch"], cfg["ch_mult"]
+    nres = len(ch_mult)
+    curr_res = cfg["resolution"]
+    h = _conv(p, "encoder.conv_in", x, 1)
+    for lvl in range(nres):
+        for b in range(cfg["num_res_blocks"]):
+            h = _resblock(p, f"encoder.down.{lvl}.block.{b}", h)
+            if curr_res in cfg["attn_resolutions"]:
+                h = _attnblock(p, f"encoder.down.{lvl}.attn.{b}", h)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, p[f"encoder.down.{lvl}.downsample.conv.weight"], p[f"encoder.down.{lvl}.downsample.conv.bias"], stride=2)
+            curr_res //= 2
+    h = _resblock(p, "encoder.mid.block_1", h)
+    h = _attnblock(p, "encoder.mid.attn_1", h)
+    h = _resblock(p, "encoder.mid.block_2", h)
+    h = _swish(_norm(p, "encoder.norm_out", h))
+    return _conv(p, "encoder.conv_out", h, 1)
+
+
+def encode(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: dict):
+    """`z, *_ = model.encode(x)` as VqganDrawer uses it (vqgan.py:174-185): taming `VQModel.encode` = encoder ->
+    quant_conv -> VectorQuantizer2 (argmin of the same distance as vqgan.py:60-64; the returned tensor is numerically
+    the code vectors, `z + (z_q - z).detach()`).  Returns (z_q NCHW, indices [h*w], pre-quantisation latent NCHW)."""
+    h = _conv(p, "quant_conv", encoder_forward(p, x, cfg), 0)
+    cb = p["quantize.embedding.weight"]
+    hl = h.movedim(1, 3)
+    idx, _ = vq_indices(hl, cb)
+    z_q = cb[idx.reshape(-1)].reshape(hl.shape).movedim(3, 1)
+    return z_q, idx.reshape(-1), h
+
+
 def synth(p, z, cfg):
     """VqganDrawer.synth (vqgan.py:190-195), non-gumbel branch."""
     z_q = vector_quantize(z.movedim(1, 3), p["quantize.embedding.weight"]).movedim(3, 1)

@@ -6,15 +6,15 @@ are exercised in tests with randomly initialised upstream-format state dicts; th
   `visual.proj` -> strip the `visual.` prefix (weights may be fp16 on CUDA: cast to fp32).
 * HF `CLIPVisionModelWithProjection` -> the same names (q/k/v projections are concatenated into `in_proj_*`).
 * taming-transformers VQGAN Lightning checkpoint (`vqgan.py:124-140`): `state_dict` with `decoder.*`,
-  `post_quant_conv.*`, `quantize.embedding.weight` (the `encoder.*`, `quant_conv.*`, `loss.*` entries are not on the
-  hot path and are dropped, as `del model.loss` does at vqgan.py:139).
+  `post_quant_conv.*`, `quantize.embedding.weight` for the decoder runner, plus `encoder.*` / `quant_conv.*` for the
+  encoder runner when the checkpoint has them (`loss.*` is dropped, as `del model.loss` does at vqgan.py:139).
 """
 from collections import OrderedDict
 from typing import Dict
 
 import torch
 
-from .weights import ClipVitConfig, VqganConfig, clip_vit_param_shapes, vqgan_param_shapes
+from .weights import ClipVitConfig, VqganConfig, clip_vit_param_shapes, vqgan_encoder_param_shapes, vqgan_param_shapes
 
 
 def _check(params: Dict[str, torch.Tensor], shapes) -> "OrderedDict[str, torch.Tensor]":
@@ -54,6 +54,13 @@ def clip_visual_from_hf(state_dict: Dict[str, torch.Tensor], cfg: ClipVitConfig)
     return _check(p, clip_vit_param_shapes(cfg))
 
 
-def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig):
-    sd = state_dict.get("state_dict", state_dict)
-    return _check(dict(sd), vqgan_param_shapes(cfg))
+def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig, with_encoder: bool = None):
+    """-> one ordered dict usable as `settings.vqgan_state_dict`: the decoder entries, and the encoder entries when the
+    checkpoint has them (`with_encoder=None`: if present; True: required; False: dropped)."""
+    sd = dict(state_dict.get("state_dict", state_dict))
+    out = _check(sd, vqgan_param_shapes(cfg))
+    if with_encoder is None:
+        with_encoder = any(k.startswith("encoder.") for k in sd)
+    if with_encoder:
+        out.update(_check(sd, vqgan_encoder_param_shapes(cfg)))
+    return out

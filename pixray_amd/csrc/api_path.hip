@@ -2,6 +2,7 @@
 #include "common.h"
 #include "vit.h"
 #include "vqgan.h"
+#include "vqgan_enc.h"
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "elementwise.h"
@@ -32,6 +33,19 @@ int prx_vqgan_synth(prx_vqgan* h, const float* z, float* img, int* indices, int 
 long long prx_vqgan_debug_stage(prx_vqgan* h, int stage, float* dst, long long max_floats, prx_stream_t s) {
     if (!h || !dst) return -1;
     return prx_vqgan_debug_stage_impl((PrxVqgan*)h, stage, dst, max_floats, S_(s));
+}
+int prx_vqgan_enc_create(prx_vqgan_enc** out, const prx_vqgan_config* c, int in_channels, int H, int W,
+                         const float* const* weights, int n_weights, prx_stream_t s) {
+    PRX_REQUIRE(out && c && weights, "prx_vqgan_enc_create: null argument");
+    PRX_REQUIRE(c->n_mult >= 1 && c->n_mult <= 8, "prx_vqgan_enc_create: bad n_mult %d", c->n_mult);
+    return prx_vqgan_enc_create_impl((PrxVqganEnc**)out, c->ch, c->ch_mult, c->n_mult, c->num_res_blocks, c->attn_resolution,
+                                     c->resolution, in_channels, c->z_channels, c->embed_dim, c->n_embed, H, W, weights,
+                                     n_weights, S_(s));
+}
+void prx_vqgan_enc_destroy(prx_vqgan_enc* h) { prx_vqgan_enc_destroy_impl((PrxVqganEnc*)h); }
+int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre, int* indices, prx_stream_t s) {
+    PRX_REQUIRE(h && img && z, "prx_vqgan_encode: null argument");
+    return prx_vqgan_encode_impl((PrxVqganEnc*)h, img, z, z_pre, indices, S_(s));
 }
 int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_stream_t s) {
     PRX_REQUIRE(h && g_img && dz, "prx_vqgan_synth_backward: null argument");

@@ -344,17 +344,28 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
     int c_r1[C64 ? A_IN : 1], c_rd0[C64 ? A_IN : 1], c_rd2[C64 ? A_IN : 1];
     int c_c1[C64 ? A_IN : 1], c_cd0[C64 ? A_IN : 1], c_cd2[C64 ? A_IN : 1], c_ok[C64 ? A_IN : 1];
     if constexpr (C64) {
-        const int Hs = d.up ? (d.H >> 1) : d.H, Ws = d.up ? (d.W >> 1) : d.W;
+        // source map: up == 1 nearest-2x upsampled (H/2 x W/2), up == 2 stride-2 "down" conv with taming's (0,1,0,1)
+        // padding (source 2H x 2W, tap t reads 2y+t / 2x+t, only the bottom/right edge is padded)
+        const int Hs = d.up == 1 ? (d.H >> 1) : (d.up == 2 ? 2 * d.H : d.H);
+        const int Ws = d.up == 1 ? (d.W >> 1) : (d.up == 2 ? 2 * d.W : d.W);
 #pragma unroll
         for (int i = 0; i < A_IN; ++i) {
             int okm = 0, ro[3], co[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int yy = a_y[i] + t - 1, xx = a_x[i] + t - 1;
-                if (a_ok[i] && yy >= 0 && yy < d.H) okm |= 1 << t;
-                if (xx >= 0 && xx < d.W) okm |= 8 << t;
-                ro[t] = (a_b[i] * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
-                co[t] = d.up ? (xx >> 1) : xx;
+                if (d.up == 2) {
+                    const int yy = 2 * a_y[i] + t, xx = 2 * a_x[i] + t;
+                    if (a_ok[i] && yy < Hs) okm |= 1 << t;
+                    if (xx < Ws) okm |= 8 << t;
+                    ro[t] = (a_b[i] * Hs + yy) * Ws;
+                    co[t] = xx;
+                } else {
+                    const int yy = a_y[i] + t - 1, xx = a_x[i] + t - 1;
+                    if (a_ok[i] && yy >= 0 && yy < d.H) okm |= 1 << t;
+                    if (xx >= 0 && xx < d.W) okm |= 8 << t;
+                    ro[t] = (a_b[i] * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
+                    co[t] = d.up ? (xx >> 1) : xx;
+                }
             }
             c_ok[i] = okm;
             c_r1[i] = ro[1]; c_rd0[i] = ro[0] - ro[1]; c_rd2[i] = ro[2] - ro[1];
@@ -751,7 +762,10 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     if (d.a_mode == PRX_A_CONV3X3) {
         PRX_REQUIRE(d.Cin % 8 == 0 && d.K == 9 * d.Cin, "gemm/conv: need Cin %% 8 == 0 and K == 9*Cin (Cin=%d K=%d)", d.Cin, d.K);
         PRX_REQUIRE(d.H > 0 && d.W > 0 && d.M % (d.H * d.W) == 0, "gemm/conv: M (%d) must be NB*H*W (%dx%d)", d.M, d.H, d.W);
-        PRX_REQUIRE(!d.up || (d.H % 2 == 0 && d.W % 2 == 0), "gemm/conv: upsample needs even H, W");
+        PRX_REQUIRE(d.up != 1 || (d.H % 2 == 0 && d.W % 2 == 0), "gemm/conv: upsample needs even H, W");
+        PRX_REQUIRE(d.up >= 0 && d.up <= 2, "gemm/conv: up must be 0 (none), 1 (nearest-2x upsampled source) or 2 (stride-2 source)");
+        PRX_REQUIRE(d.up != 2 || (d.Cin % BK == 0 && !d.a_is_f32 && g_use_glds && g_conv_c64),
+                    "gemm/conv: the stride-2 gather needs a bf16 operand with Cin %% 64 == 0 (Cin=%d)", d.Cin);
     }
     PRX_REQUIRE(d.act != PRX_ACT_MUL_DQUICKGELU || d.aux, "gemm: MUL_DQUICKGELU needs aux");
 

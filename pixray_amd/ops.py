@@ -234,6 +234,65 @@ def vqgan_synth(z, handle: VqganHandle, quantize: bool = True):
     return _VqganSynthFn.apply(z, handle, quantize)
 
 
+class VqganEncHandle:
+    """Owns a `prx_vqgan_enc` (taming Encoder + quant_conv + codebook) for one image size; forward only
+    (VqganDrawer.init_from_tensor / reapply_from_tensor / get_z_from_tensor, vqgan.py:174-185)."""
+
+    def __init__(self, cfg, params, image_hw, device, in_channels: int = 3):
+        from .weights import vqgan_encoder_param_shapes
+        names = list(vqgan_encoder_param_shapes(cfg, in_channels).keys())
+        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        c = _VqganCfg()
+        c.ch = cfg.ch
+        for i, m in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = m
+        c.n_mult = len(cfg.ch_mult)
+        c.num_res_blocks = cfg.num_res_blocks
+        c.attn_resolution = cfg.attn_resolutions[0] if len(cfg.attn_resolutions) else -1
+        c.resolution = cfg.resolution
+        c.z_channels = cfg.z_channels
+        c.embed_dim = cfg.embed_dim
+        c.n_embed = cfg.n_embed
+        c.out_ch = cfg.out_ch
+        self.f = 2 ** (len(cfg.ch_mult) - 1)
+        H, W = image_hw
+        c.latent_h, c.latent_w = H // self.f, W // self.f
+        h = ctypes.c_void_p()
+        call("prx_vqgan_enc_create", ctypes.addressof(h), ctypes.addressof(c), in_channels, H, W, _keep(self, _weight_array(ws)),
+             len(ws), _stream())
+        torch.cuda.synchronize(device)
+        self.h = h
+        self.cfg = cfg
+        self.image_hw = (H, W)
+        self.in_channels = in_channels
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_vqgan_enc_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+@torch.no_grad()
+def vqgan_encode(img, handle: VqganEncHandle, return_pre: bool = False):
+    """img [1,C,H,W] in [-1,1] -> z [1,embed_dim,H/f,W/f] (the selected code vectors), int32 indices
+    [, the latent before quantisation]."""
+    _need_cuda(img)
+    img = img.contiguous().float()
+    H, W = handle.image_hw
+    assert img.shape == (1, handle.in_channels, H, W), f"image must be [1,{handle.in_channels},{H},{W}], got {tuple(img.shape)}"
+    h0, w0 = H // handle.f, W // handle.f
+    z = torch.empty(1, handle.cfg.embed_dim, h0, w0, device=img.device)
+    idx = torch.empty(h0 * w0, device=img.device, dtype=torch.int32)
+    pre = torch.empty_like(z) if return_pre else None
+    call("prx_vqgan_encode", handle.h, img, z, pre, idx, _stream())
+    return (z, idx, pre) if return_pre else (z, idx)
+
+
 # --------------------------------------------------------------------------------------- Prompt loss
 class _PromptLossFn(torch.autograd.Function):
     @staticmethod

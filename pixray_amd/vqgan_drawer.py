@@ -5,14 +5,16 @@ load_model(settings, device) (613), get_num_resolutions (614), init_from_tensor 
 reapply_from_tensor (1420), get_z_from_tensor (843), get_opts (525), synth(cur_iteration) (1206),
 to_image (1413), clip_z (1487), get_z / set_z / get_z_copy (537, 1104, 1346).
 
-Not on the hot path and not provided here: the VQGAN *encoder* (init / overlay images)
-and checkpoint download; `init_from_tensor(None)`-style random initialisation of z is provided instead.
+The VQGAN *encoder* (init / overlay / label images: init_from_tensor, reapply_from_tensor, get_z_from_tensor,
+vqgan.py:174-185) is the first of the "next" rows: it runs on the same HIP engine, forward only, and
+is built lazily on first use.  `init_from_tensor(None)` draws a random z instead (the reference would fail there).
+Checkpoint download is out of scope; `settings.vqgan_state_dict` takes a taming state dict (pixray_amd/checkpoints.py).
 """
 import torch
 
 from . import ops
 from .interfaces import DrawingInterface
-from .weights import VQGAN_CONFIGS, synthetic_vqgan_params
+from .weights import VQGAN_CONFIGS, synthetic_vqgan_params, synthetic_vqgan_encoder_params, vqgan_encoder_param_shapes
 
 
 class VqganDrawer(DrawingInterface):
@@ -43,6 +45,7 @@ class VqganDrawer(DrawingInterface):
         if w % f or h % f:
             raise ValueError(f"size {self.size} must be a multiple of {f} (pixray.py:621-626 rounds it for you)")
         self.latent_hw = (h // f, w // f)
+        self._params = params
         self.handle = ops.VqganHandle(self.cfg, params, self.latent_hw, self.device)
         self.e_dim = self.cfg.embed_dim
         self.n_toks = self.cfg.n_embed
@@ -59,17 +62,42 @@ class VqganDrawer(DrawingInterface):
         z = torch.randn(1, self.cfg.z_channels, *self.latent_hw, generator=g).to(self.device)
         self.z = z.maximum(self.z_min).minimum(self.z_max).requires_grad_(True)
 
+    # -- encoder side (vqgan.py:174-185): `z, *_ = self.model.encode(t)`, t in [-1,1] [1,3,H,W] ---------------------------
+    def _encoder(self):
+        enc = getattr(self, "_enc_handle", None)
+        if enc is None:
+            names = vqgan_encoder_param_shapes(self.cfg).keys()
+            if self.state_dict is not None and all(k in self.state_dict for k in names):
+                params = self.state_dict
+            elif self.state_dict is not None:
+                raise KeyError("the VQGAN state dict has no `encoder.*` / `quant_conv.*` entries: cannot encode an image")
+            else:       # no checkpoints offline: seeded random encoder sharing the decoder's codebook
+                params = synthetic_vqgan_encoder_params(self.cfg, self.weight_seed, codebook=self._params["quantize.embedding.weight"])
+            w, h = self.size
+            enc = self._enc_handle = ops.VqganEncHandle(self.cfg, params, (h, w), self.device)
+        return enc
+
+    def _encode(self, t):
+        if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
+            raise ValueError(f"expected an image tensor [1,3,H,W] in [-1,1], got {tuple(t.shape)}")
+        z, idx = ops.vqgan_encode(t.to(self.device), self._encoder())
+        self.last_encode_indices = idx
+        return z
+
     def init_from_tensor(self, init_tensor):
-        if init_tensor is not None:
-            raise NotImplementedError("encoding an init image needs the VQGAN encoder (vqgan.py:174-176), "
-                                      "which is outside the hot path (SURVEY.md §8f-1)")
-        self.rand_init()
+        if init_tensor is None:
+            self.rand_init()
+            return
+        self.z = self._encode(init_tensor)
+        self.z.requires_grad_(True)
 
     def reapply_from_tensor(self, new_tensor):
-        raise NotImplementedError("VQGAN encoder is outside the hot path (SURVEY.md §8f-1)")
+        new_z = self._encode(new_tensor)
+        with torch.no_grad():
+            self.z.copy_(new_z)
 
     def get_z_from_tensor(self, ref_tensor):
-        raise NotImplementedError("VQGAN encoder is outside the hot path (SURVEY.md §8f-1)")
+        return self._encode(ref_tensor)
 
     def get_num_resolutions(self):
         return self.cfg.num_resolutions

@@ -94,6 +94,86 @@ def vqgan_param_shapes(cfg: VqganConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def vqgan_encoder_param_shapes(cfg: VqganConfig, in_channels: int = 3) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered (name -> shape) list of taming's Encoder + quant_conv (+ the codebook), in the order the C ABI expects
+    (include/prx.h, prx_vqgan_enc_create).  Names are the taming state-dict keys (`encoder.*`, `quant_conv.*`)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        sh[name + ".weight"] = (cout, cin, k, k)
+        sh[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        sh[name + ".weight"] = (c,)
+        sh[name + ".bias"] = (c,)
+
+    def res(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cout, cin, 3)
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".nin_shortcut", cout, cin, 1)
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for t in ("q", "k", "v", "proj_out"):
+            conv(name + "." + t, c, c, 1)
+
+    sh["quantize.embedding.weight"] = (cfg.n_embed, cfg.embed_dim)
+    conv("encoder.conv_in", cfg.ch, in_channels, 3)
+    nres = len(cfg.ch_mult)
+    block_in = cfg.ch
+    curr_res = cfg.resolution
+    for lvl in range(nres):
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            res(f"encoder.down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+            if curr_res in cfg.attn_resolutions:
+                attn(f"encoder.down.{lvl}.attn.{b}", block_in)
+        if lvl != nres - 1:
+            conv(f"encoder.down.{lvl}.downsample.conv", block_in, block_in, 3)
+            curr_res //= 2
+    res("encoder.mid.block_1", block_in, block_in)
+    attn("encoder.mid.attn_1", block_in)
+    res("encoder.mid.block_2", block_in, block_in)
+    norm("encoder.norm_out", block_in)
+    conv("encoder.conv_out", cfg.z_channels, block_in, 3)
+    conv("quant_conv", cfg.embed_dim, cfg.z_channels, 1)
+    return sh
+
+
+def _init_conv_like(name, shape, g):
+    if name == "quantize.embedding.weight":
+        return torch.randn(shape, generator=g)
+    if name.endswith(".weight") and len(shape) == 1:      # GroupNorm gamma
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if name.endswith(".bias") and (".norm" in name or "norm_out" in name):
+        return 0.05 * torch.randn(shape, generator=g)
+    if name.endswith(".bias"):
+        return 0.02 * torch.randn(shape, generator=g)
+    fan_in = shape[1] * shape[2] * shape[3]
+    gain = 1.0
+    if name.endswith("conv2.weight") or name.endswith("proj_out.weight"):
+        gain = 0.5       # residual branches: keep the stream O(1) through 20 blocks
+    if name.endswith("conv_out.weight"):
+        gain = 0.7
+    return torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+
+
+def synthetic_vqgan_encoder_params(cfg: VqganConfig, seed: int = 0, codebook: torch.Tensor = None,
+                                   in_channels: int = 3) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded random Encoder/quant_conv weights.  `codebook`: reuse the decoder's `quantize.embedding.weight` (a taming
+    checkpoint has ONE codebook shared by encode and decode)."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in vqgan_encoder_param_shapes(cfg, in_channels).items():
+        if name == "quantize.embedding.weight" and codebook is not None:
+            out[name] = codebook
+            continue
+        out[name] = _init_conv_like(name, shape, g)
+    return out
+
+
 def synthetic_vqgan_params(cfg: VqganConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     g = torch.Generator().manual_seed(seed)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()

@@ -9,6 +9,7 @@ HF transformers are available):
   clip_vit_golden.npz   an independent implementation of OpenAI's VisionTransformer (HF CLIPVisionModelWithProjection,
                         hidden_act=quick_gelu) on the seeded weights of pixray_amd.weights
   decoder_golden.npz    an independent implementation of taming's Decoder (HF JanusVQVAEDecoder, derived from taming)
+  encoder_golden.npz    the same for taming's Encoder (HF JanusVQVAEEncoder)
                         on the seeded weights of pixray_amd.weights
 Weights are NOT stored: they are re-derived from the seeds by pixray_amd.weights.synthetic_*.
 """
@@ -87,6 +88,19 @@ def hf_decoder_from_params(cfg, p):
     return d
 
 
+def hf_encoder_from_params(cfg, p):
+    """an independent implementation of taming's Encoder: HF JanusVQVAEEncoder (LlamaGen VQGAN, derived from taming;
+    same graph when attention sits only at the lowest resolution, as it does for imagenet_f16_16384)"""
+    from transformers.models.janus.configuration_janus import JanusVQVAEConfig
+    from transformers.models.janus.modeling_janus import JanusVQVAEEncoder
+    jc = JanusVQVAEConfig(base_channels=cfg.ch, channel_multiplier=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks,
+                          latent_channels=cfg.z_channels, in_channels=3, double_latent=False, dropout=0.0)
+    e = JanusVQVAEEncoder(jc).eval()
+    sd = {k[len("encoder."):]: v for k, v in p.items() if k.startswith("encoder.")}
+    e.load_state_dict(sd, strict=True)
+    return e
+
+
 def main():
     out = HERE
     # ---- pixray's own fragments ----------------------------------------------------------------------------------
@@ -139,6 +153,12 @@ def main():
     (gz,) = torch.autograd.grad(img, zr, gi)
     np.savez(os.path.join(out, "decoder_golden.npz"), z=zq.numpy(), img=img.detach().numpy(), gi=gi.numpy(),
              gz=gz.numpy(), seed=np.int64(22))
+    pe = weights.synthetic_vqgan_encoder_params(GOLDEN_VQ, 23)
+    enc = hf_encoder_from_params(GOLDEN_VQ, pe)
+    xi = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
+    with torch.no_grad():
+        hz = enc(xi)
+    np.savez(os.path.join(out, "encoder_golden.npz"), x=xi.numpy(), h=hz.numpy(), seed=np.int64(23))
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)), "bytes")

@@ -177,6 +177,21 @@ def test_gemm_conv3x3(H, W, Cin, Cout, up, NB, gemm_variant):
     assert rel_l2(out2, ref) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,C,Cout,NB", [(16, 16, 128, 128, 1), (12, 20, 64, 72, 2), (128, 128, 128, 128, 1)])
+def test_gemm_conv3x3_stride2_down(H, W, C, Cout, NB):
+    """taming Downsample (encoder): zero pad (0,1,0,1) then 3x3 stride-2 conv, as the engine's up == 2 gather"""
+    torch.manual_seed(H + W + C)
+    x = torch.randn(NB, C, 2 * H, 2 * W, device=DEV)
+    w = torch.randn(Cout, C, 3, 3, device=DEV) / math.sqrt(9 * C)
+    bias = torch.randn(Cout, device=DEV)
+    x_nhwc = bf(x.permute(0, 2, 3, 1).contiguous())
+    w_pack = bf(w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous())
+    out, _, _ = run_gemm(x_nhwc, w_pack, NB * H * W, Cout, 9 * C, a_mode=1, lda=C, H=H, W=W, Cin=C, up=2, bias_n=bias)
+    ref = F.conv2d(F.pad(bf(x).float(), (0, 1, 0, 1)), bf(w).float(), bias, stride=2)
+    ref = ref.permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+
+
 @pytest.mark.parametrize("P,C,swish", [(256, 512, 1), (1024, 256, 1), (4096, 128, 0), (65536, 128, 1)])
 def test_groupnorm_fwd_bwd(P, C, swish):
     torch.manual_seed(P + C)

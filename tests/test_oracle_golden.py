@@ -87,6 +87,24 @@ def test_decoder_oracle_matches_independent_golden():
     assert rel(gz, d["gz"]) < 1e-4
 
 
+def test_encoder_oracle_matches_independent_golden():
+    """taming Encoder restatement vs HF JanusVQVAEEncoder (init_from_tensor path)"""
+    mg = _golden_cfgs()
+    d = load("encoder_golden.npz")
+    cfg = mg.GOLDEN_VQ
+    p = weights.synthetic_vqgan_encoder_params(cfg, int(d["seed"]))
+    with torch.no_grad():
+        h = vqgan_ref.encoder_forward(p, d["x"], cfg.oracle_cfg())
+    assert h.shape == d["h"].shape
+    assert rel(h, d["h"]) < 1e-5, rel(h, d["h"])
+    # VQModel.encode on top: the returned latent is made of codebook rows, chosen by vqgan.py:60-64's distance
+    z_q, idx, pre = vqgan_ref.encode(p, d["x"], cfg.oracle_cfg())
+    cb = p["quantize.embedding.weight"]
+    assert torch.equal(z_q.movedim(1, 3).reshape(-1, cb.shape[1]), cb[idx])
+    dist = (pre.movedim(1, 3).reshape(-1, 1, cb.shape[1]) - cb[None]).pow(2).sum(-1)
+    assert torch.equal(dist.argmin(-1), idx)
+
+
 # ---------------------------------------------------------------------------------------- live cross-checks
 @pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
 def test_oracle_fragments_vs_live_reference():

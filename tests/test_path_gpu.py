@@ -225,3 +225,81 @@ def test_vqgan_synth_vs_oracle(name, hw):
     assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
     assert rel_l2(gd, gref) < 5e-2, rel_l2(gd, gref)
     assert cosine(gd, gref) > 0.998
+
+
+# ------------------------------------------------------------------------------------------ VQGAN encoder
+@pytest.mark.parametrize("name,HW", [("tiny_f4", (64, 64)), ("tiny_f4", (32, 96)), ("imagenet_f16_16384", (256, 256))])
+def test_vqgan_encode_vs_oracle(name, HW):
+    """VqganDrawer.init_from_tensor's `model.encode` (vqgan.py:174-176): taming Encoder -> quant_conv -> nearest code.
+    bf16-operand engine vs the fp32 oracle: the pre-quantisation latent within 2e-2 rel-L2; the chosen codes are exact
+    integer work GIVEN the latent, so wherever they differ from the oracle's the two candidates must be a near-tie in
+    the oracle's own distances."""
+    cfg = weights.VQGAN_CONFIGS[name]
+    p = weights.synthetic_vqgan_encoder_params(cfg, seed=5)
+    eh = ops.VqganEncHandle(cfg, p, HW, DEV)
+    g = torch.Generator().manual_seed(11)
+    low = torch.rand(1, 3, HW[0] // 8, HW[1] // 8, generator=g)
+    img = (torch.nn.functional.interpolate(low, size=HW, mode="bilinear", align_corners=False)
+           + 0.05 * torch.randn(1, 3, *HW, generator=g)).clamp(0, 1) * 2 - 1
+    z, idx, pre = ops.vqgan_encode(img.to(DEV), eh, return_pre=True)
+    with torch.no_grad():
+        z_ref, idx_ref, pre_ref = vqgan_ref.encode(p, img, cfg.oracle_cfg())
+    f = 2 ** (len(cfg.ch_mult) - 1)
+    assert z.shape == (1, cfg.embed_dim, HW[0] // f, HW[1] // f)
+    assert rel_l2(pre, pre_ref) < 2e-2, rel_l2(pre, pre_ref)
+    cb = p["quantize.embedding.weight"]
+    idx = idx.cpu().long()
+    # the output IS codebook rows (bit-exact gather)
+    assert torch.equal(z.cpu().movedim(1, 3).reshape(-1, cfg.embed_dim), cb[idx])
+    # the kernel's argmin is exact for ITS latent (first-index ties, same distance formula as vqgan.py:60-64)
+    own, _ = vqgan_ref.vq_indices(pre.cpu().movedim(1, 3), cb)
+    assert (own.reshape(-1) == idx).float().mean().item() > 0.995
+    agree = (idx == idx_ref).float().mean().item()
+    d = (pre_ref.movedim(1, 3).reshape(-1, 1, cfg.embed_dim) - cb[None]).pow(2).sum(-1)       # oracle distances
+    chosen = d.gather(1, idx[:, None])[:, 0]
+    best = d.min(dim=1).values
+    assert agree > 0.7, agree
+    assert ((chosen - best) / best).max().item() < 3e-2, ((chosen - best) / best).max().item()
+
+
+def test_vqgan_encoder_independent_golden():
+    """the committed HF JanusVQVAEEncoder fixture (tests/golden/encoder_golden.npz) through the HIP encoder"""
+    import os, sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as mg
+    d = np.load(os.path.join(here, "golden", "encoder_golden.npz"))
+    cfg = mg.GOLDEN_VQ
+    p = dict(weights.synthetic_vqgan_encoder_params(cfg, int(d["seed"])))
+    p["quant_conv.weight"] = torch.eye(cfg.z_channels).reshape(cfg.z_channels, cfg.z_channels, 1, 1)   # expose the encoder output
+    p["quant_conv.bias"] = torch.zeros(cfg.z_channels)
+    eh = ops.VqganEncHandle(cfg, p, (16, 16), DEV)
+    _, _, pre = ops.vqgan_encode(torch.from_numpy(d["x"]).to(DEV), eh, return_pre=True)
+    assert rel_l2(pre, torch.from_numpy(d["h"])) < 2e-2, rel_l2(pre, torch.from_numpy(d["h"]))
+
+
+def test_vqgan_drawer_encoder_entry_points():
+    """init_from_tensor / reapply_from_tensor / get_z_from_tensor (vqgan.py:174-185) on the drawer surface"""
+    import types
+    from pixray_amd.vqgan_drawer import VqganDrawer
+    s = types.SimpleNamespace(vqgan_model="tiny_f4", size=(64, 64))
+    dr = VqganDrawer(s)
+    dr.load_model(s, DEV)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    dr.init_from_tensor(img)
+    z = dr.get_z()
+    assert z.is_leaf and z.requires_grad and z.shape == (1, dr.cfg.z_channels, 16, 16)
+    z_ref = dr.get_z_from_tensor(img)
+    assert torch.equal(z.detach(), z_ref)                       # same image -> same codes
+    out = dr.synth(0)                                           # an encoded z is a fixed point of the quantiser
+    assert torch.equal(dr.handle.last_indices.cpu(), dr.last_encode_indices.cpu())
+    out.sum().backward()
+    assert z.grad is not None and torch.isfinite(z.grad).all()
+    img2 = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    zid = id(dr.get_z())
+    dr.reapply_from_tensor(img2)
+    assert id(dr.get_z()) == zid and not torch.equal(dr.get_z().detach(), z_ref)     # in place, as `self.z.copy_(new_z)`
+    with pytest.raises(ValueError):
+        dr.init_from_tensor(torch.zeros(1, 4, 64, 64))
