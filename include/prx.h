@@ -221,6 +221,29 @@ int prx_clip_vit_backward_reduce(prx_clip_vit* h, const float* cutouts, const fl
 int prx_clip_vit_backward_finish(prx_clip_vit* h, const float* cutouts, const float* mm, const double* acc,
                                  float* g_cutouts, prx_stream_t s);
 
+/* --- CLIP_Base.encode_text (slip.py:68-70) = openai/CLIP `CLIP.encode_text` [UPSTREAM clip/model.py] on token ids:
+ *     token_embedding[tokens] + positional_embedding -> causal transformer -> ln_final -> row at argmax(tokens) (the EOT
+ *     token) @ text_projection.  Forward only; the result is NOT normalised (as the reference's, slip.py:70).
+ * weights[]: fp32 device tensors in state-dict order: token_embedding.weight [vocab, width], positional_embedding
+ *   [context, width], transformer.resblocks.{i}.{ln_1.weight, ln_1.bias, attn.in_proj_weight, attn.in_proj_bias,
+ *   attn.out_proj.weight, attn.out_proj.bias, ln_2.weight, ln_2.bias, mlp.c_fc.weight, mlp.c_fc.bias, mlp.c_proj.weight,
+ *   mlp.c_proj.bias}, ln_final.{weight,bias}, text_projection [width, output_dim].
+ * tokens: int32 device [n, context] as `clip.tokenize` returns them (SOT ... EOT, zero padded). */
+typedef struct prx_clip_text prx_clip_text;
+typedef struct prx_clip_text_config {
+    int vocab_size;       /* 49408 */
+    int context_length;   /* 77 */
+    int width;            /* 512 (ViT-B/32, B/16), 768 (ViT-L/14); heads = width / 64 */
+    int layers;           /* 12 */
+    int heads;            /* 8 */
+    int output_dim;       /* 512 */
+    int max_batch;
+} prx_clip_text_config;
+int prx_clip_text_create(prx_clip_text** out, const prx_clip_text_config* cfg, const float* const* weights, int n_weights,
+                         prx_stream_t s);
+void prx_clip_text_destroy(prx_clip_text* h);
+int prx_clip_text_encode(prx_clip_text* h, const int* tokens, int n, float* embeds, prx_stream_t s);
+
 /* --- Prompt.forward (pixray.py:275-280) fused with its backward.
  * rowloss[i] = sum_j sign(w) * 2*asin(|x^_i - e^_j|/2)^2 (forward value: |w| * sum(rowloss)/denom);
  * grad = d/d input of |w| * mean(max(sign(w) d, stop)) with the mean over `denom` (= global n*m) pairs. */

@@ -12,7 +12,7 @@ from . import _lib
 from .cutouts import MakeCutouts
 from .engine import Session
 from .perceptor import get_clip_perceptor
-from .prompt import Prompt
+from .prompt import Prompt, parse_prompt
 from .vqgan_drawer import VqganDrawer
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,9 +27,16 @@ def seeded_unit_vectors(n: int, dim: int, seed: int) -> torch.Tensor:
 def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
                              num_cuts=64, learning_rate=0.2, iterations=250, prompt_embeds: Optional[torch.Tensor] = None,
                              prompt_weight=1.0, extra_prompts: Sequence = (), seed=0, device="cuda", group=None, rank=0,
-                             world_size=1, custom_losses=(), filters=(), learning_rate_drops=()) -> Session:
+                             world_size=1, custom_losses=(), filters=(), learning_rate_drops=(), prompts: Sequence[str] = (),
+                             vector_prompts: Sequence[str] = (), init_image: Optional[torch.Tensor] = None, tokenizer=None,
+                             clip_text_params=None) -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
-    a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z."""
+    a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
+
+    `prompts`: pixray text prompts "text[:weight[:stop]]" (pixray.py:859-877), encoded by the HIP text tower (needs the
+    CLIP merges table, pixray_amd/tokenizer.py); `vector_prompts`: paths of json files {model name: [[...]]} with
+    precomputed CLIP-space vectors, "path[:weight[:stop]]", weighted x0.1 as pixray.py:879-915 does; `init_image`:
+    [1,3,H,W] in [0,1], encoded to the starting z by the HIP VQGAN encoder (pixray.py:696-718)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
@@ -38,13 +45,27 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                                      vqgan_config=None, vqgan_checkpoint=None)
     drawer = VqganDrawer(settings)
     drawer.load_model(settings, dev)
-    drawer.init_from_tensor(None)
+    drawer.init_from_tensor(None if init_image is None else init_image.to(dev) * 2 - 1)
     per_rank = num_cuts // world_size
-    perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group)
+    perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group, tokenizer=tokenizer,
+                                   text_params=clip_text_params)
     mk = MakeCutouts(perceptor.input_resolution, num_cuts, generator=torch.Generator().manual_seed(1000 + seed))
-    if prompt_embeds is None:
+    pms = []
+    for prompt in prompts:                                                              # pixray.py:859-877
+        txt, weight, stop = parse_prompt(prompt)
+        pms.append(Prompt(perceptor.encode_text(txt).float(), weight, stop).to(dev))
+    for vp in vector_prompts:                                                           # pixray.py:879-915
+        path, weight, stop = parse_prompt(vp)
+        with open(path) as f:
+            table = json.load(f)
+        if clip_model not in table:
+            print(f"WARNING: no vector for {clip_model} in {path}!")
+            continue
+        pms.append(Prompt(torch.tensor(table[clip_model], dtype=torch.float32), 0.1 * weight, stop).to(dev))
+    if prompt_embeds is None and not pms:
         prompt_embeds = seeded_unit_vectors(1, perceptor.output_dim, seed + 2)
-    pms = [Prompt(prompt_embeds.to(dev), prompt_weight, float("-inf")).to(dev)]
+    if prompt_embeds is not None:
+        pms.insert(0, Prompt(prompt_embeds.to(dev), prompt_weight, float("-inf")).to(dev))
     for (emb, w, stop) in extra_prompts:
         pms.append(Prompt(emb.to(dev), w, stop).to(dev))
     return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, {clip_model: pms},

@@ -14,7 +14,8 @@ from typing import Dict
 
 import torch
 
-from .weights import ClipVitConfig, VqganConfig, clip_vit_param_shapes, vqgan_encoder_param_shapes, vqgan_param_shapes
+from .weights import (ClipTextConfig, ClipVitConfig, VqganConfig, clip_text_param_shapes, clip_vit_param_shapes,
+                      vqgan_encoder_param_shapes, vqgan_param_shapes)
 
 
 def _check(params: Dict[str, torch.Tensor], shapes) -> "OrderedDict[str, torch.Tensor]":
@@ -52,6 +53,30 @@ def clip_visual_from_hf(state_dict: Dict[str, torch.Tensor], cfg: ClipVitConfig)
             p[a + x + ".weight"] = sd[b + y + ".weight"]
             p[a + x + ".bias"] = sd[b + y + ".bias"]
     return _check(p, clip_vit_param_shapes(cfg))
+
+
+def clip_text_from_openai(state_dict: Dict[str, torch.Tensor], cfg: ClipTextConfig):
+    """text side of an OpenAI CLIP state dict: the un-prefixed entries (`token_embedding.weight`, `positional_embedding`,
+    `transformer.resblocks.*`, `ln_final.*`, `text_projection`)"""
+    return _check(dict(state_dict), clip_text_param_shapes(cfg))
+
+
+def clip_text_from_hf(state_dict: Dict[str, torch.Tensor], cfg: ClipTextConfig):
+    sd = state_dict
+    p = {"token_embedding.weight": sd["text_model.embeddings.token_embedding.weight"],
+         "positional_embedding": sd["text_model.embeddings.position_embedding.weight"],
+         "ln_final.weight": sd["text_model.final_layer_norm.weight"], "ln_final.bias": sd["text_model.final_layer_norm.bias"],
+         "text_projection": sd["text_projection.weight"].T}
+    for i in range(cfg.layers):
+        a, b = f"transformer.resblocks.{i}.", f"text_model.encoder.layers.{i}."
+        p[a + "attn.in_proj_weight"] = torch.cat([sd[b + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        p[a + "attn.in_proj_bias"] = torch.cat([sd[b + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        p[a + "attn.out_proj.weight"] = sd[b + "self_attn.out_proj.weight"]
+        p[a + "attn.out_proj.bias"] = sd[b + "self_attn.out_proj.bias"]
+        for (x, y) in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            p[a + x + ".weight"] = sd[b + y + ".weight"]
+            p[a + x + ".bias"] = sd[b + y + ".bias"]
+    return _check(p, clip_text_param_shapes(cfg))
 
 
 def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig, with_encoder: bool = None):

@@ -3,6 +3,7 @@
 #include "vit.h"
 #include "vqgan.h"
 #include "vqgan_enc.h"
+#include "clip_text.h"
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "elementwise.h"
@@ -129,4 +130,16 @@ int prx_k_sqnorm_rows(const float* w, float* out, int rows, int D, prx_stream_t 
     return prx_sqnorm_rows(w, out, rows, D, S_(s));
 }
 
+// ---- CLIP text tower ------------------------------------------------------------------------
+int prx_clip_text_create(prx_clip_text** out, const prx_clip_text_config* c, const float* const* weights, int n_weights,
+                         prx_stream_t s) {
+    PRX_REQUIRE(out && c && weights, "prx_clip_text_create: null argument");
+    return prx_clip_text_create_impl((PrxClipText**)out, c->vocab_size, c->context_length, c->width, c->layers, c->heads,
+                                     c->output_dim, c->max_batch, weights, n_weights, S_(s));
+}
+void prx_clip_text_destroy(prx_clip_text* h) { prx_clip_text_destroy_impl((PrxClipText*)h); }
+int prx_clip_text_encode(prx_clip_text* h, const int* tokens, int n, float* embeds, prx_stream_t s) {
+    PRX_REQUIRE(h && tokens && embeds, "prx_clip_text_encode: null argument");
+    return prx_clip_text_encode_impl((PrxClipText*)h, tokens, n, embeds, S_(s));
+}
 }  // extern "C"

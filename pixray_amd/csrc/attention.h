@@ -7,3 +7,5 @@ int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int 
 int prx_mha_fwd_gen(const bf16_t* qkv, bf16_t* out, float* lse, int N, int T, int C, int heads, hipStream_t s);
 int prx_mha_bwd_gen(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int N, int T,
                     int C, int heads, hipStream_t s);
+// forward only, causal mask (CLIP text transformer, context 77)
+int prx_mha_fwd_causal(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s);

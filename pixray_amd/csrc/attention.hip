@@ -226,6 +226,8 @@ __device__ __forceinline__ void load_rows(const bf16_t* src, long long ld, int t
     }
 }
 
+// CAUSAL: CLIP's text transformer mask (key j visible to query i iff j <= i); K tiles entirely in the future are skipped
+template <bool CAUSAL>
 __global__ __launch_bounds__(64) void mha_fwd_gen_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, int T, int C, int heads, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(64) void mha_fwd_gen_kernel(const bf16_t* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) { m_run[mi][r] = -INFINITY; l_run[mi][r] = 0.f; }
     const int j0l = lane & 31;
-    for (int k0 = 0; k0 < T; k0 += 64) {
+    const int k_end = CAUSAL ? min(T, q0 + 64) : T;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
         load_rows(base + C, ld, k0, T, Ks, nullptr, lane);
         load_rows(base + 2 * C, ld, k0, T, nullptr, Vt, lane);
@@ -256,8 +259,10 @@ __global__ __launch_bounds__(64) void mha_fwd_gen_kernel(const bf16_t* __restric
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v0 = (k0 + j0l < T) ? s[mi][0][r] * scale : -INFINITY;
-                const float v1 = (k0 + j0l + 32 < T) ? s[mi][1][r] * scale : -INFINITY;
+                const int qi = q0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);     // this accumulator's query row
+                const int lim = CAUSAL ? min(T, qi + 1) : T;
+                const float v0 = (k0 + j0l < lim) ? s[mi][0][r] * scale : -INFINITY;
+                const float v1 = (k0 + j0l + 32 < lim) ? s[mi][1][r] * scale : -INFINITY;
                 const float mx = fmaxf(m_run[mi][r], half_max(fmaxf(v0, v1)));
                 const float alpha = __expf(m_run[mi][r] - mx);          // 0 on the first tile (m = -inf)
                 const float e0 = __expf(v0 - mx), e1 = __expf(v1 - mx);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(64) void mha_fwd_gen_kernel(const bf16_t* __restric
                 const float inv = 1.f / l_run[mi][r];
                 obase[(long long)i * C + col] = (bf16_t)(o[mi][0][r] * inv);
                 obase[(long long)i * C + 32 + col] = (bf16_t)(o[mi][1][r] * inv);
-                if (col == 0) lse[((long long)n * heads + h) * T + i] = m_run[mi][r] + __logf(l_run[mi][r]);
+                if (col == 0 && lse) lse[((long long)n * heads + h) * T + i] = m_run[mi][r] + __logf(l_run[mi][r]);
             }
         }
 }
@@ -431,7 +436,14 @@ int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int 
 
 int prx_mha_fwd_gen(const bf16_t* qkv, bf16_t* out, float* lse, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(gen): needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
-    hipLaunchKernelGGL(mha_fwd_gen_kernel, dim3(ceil_div(T, 64), heads, N), dim3(64), 0, s, qkv, out, lse, T, C, heads, 0.125f);
+    hipLaunchKernelGGL(mha_fwd_gen_kernel<false>, dim3(ceil_div(T, 64), heads, N), dim3(64), 0, s, qkv, out, lse, T, C, heads, 0.125f);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_mha_fwd_causal(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s) {
+    PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(causal): needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
+    hipLaunchKernelGGL(mha_fwd_gen_kernel<true>, dim3(ceil_div(T, 64), heads, N), dim3(64), 0, s, qkv, out, (float*)nullptr, T, C, heads,
+                       0.125f);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -160,6 +160,54 @@ def clip_encode_image(cutouts, handle: ClipVitHandle, group=None):
     return _ClipEncodeFn.apply(cutouts, handle, group)
 
 
+class _ClipTextCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("vocab_size", "context_length", "width", "layers", "heads", "output_dim",
+                                            "max_batch")]
+
+
+class ClipTextHandle:
+    """Owns a `prx_clip_text` (CLIP text transformer, forward only: CLIP_Base.encode_text, slip.py:68-70)."""
+
+    def __init__(self, cfg, params, max_batch: int, device):
+        from .weights import clip_text_param_shapes
+        names = list(clip_text_param_shapes(cfg).keys())
+        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        c = _ClipTextCfg(cfg.vocab_size, cfg.context_length, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch)
+        h = ctypes.c_void_p()
+        call("prx_clip_text_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
+        torch.cuda.synchronize(device)
+        self.h = h
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_clip_text_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+@torch.no_grad()
+def clip_encode_text_tokens(tokens, handle: ClipTextHandle):
+    """tokens: integer tensor [n, context_length] as `clip.tokenize` returns -> fp32 [n, output_dim] (not normalised)."""
+    if tokens.dim() != 2 or tokens.shape[1] != handle.cfg.context_length:
+        raise ValueError(f"tokens must be [n, {handle.cfg.context_length}], got {tuple(tokens.shape)}")
+    n = tokens.shape[0]
+    if n < 1 or n > handle.max_batch:
+        raise ValueError(f"batch {n} outside the text handle capacity 1..{handle.max_batch}")
+    tk = tokens.detach().to("cpu")
+    if int(tk.min()) < 0 or int(tk.max()) >= handle.cfg.vocab_size:
+        raise ValueError(f"token ids must lie in [0, {handle.cfg.vocab_size})")
+    tk = tk.to(device=handle.device, dtype=torch.int32).contiguous()
+    out = torch.empty(n, handle.cfg.output_dim, device=handle.device)
+    call("prx_clip_text_encode", handle.h, tk, n, out, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------- VQGAN
 class VqganHandle:
     def __init__(self, cfg, params, latent_hw, device):

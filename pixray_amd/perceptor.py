@@ -1,15 +1,23 @@
 """Perceptor wrapper with the reference's `CLIP_Base` surface (/root/reference/slip.py:44-74): attributes
 `input_resolution`, `output_dim`; `encode_image(imgs) -> [N, D]` L2-normalised and differentiable; frozen
-weights.  The arithmetic is the HIP CLIP ViT runner (pixray_amd/csrc/vit.hip)."""
+weights; `encode_text(text) -> [n, D]` (raw projection, as slip.py:68-70); `encode_texts`.  The arithmetic is the HIP
+CLIP ViT runner (pixray_amd/csrc/vit.hip) and the HIP text tower (pixray_amd/csrc/clip_text.hip, built on first use)."""
 import torch
 
 from . import ops
-from .weights import CLIP_CONFIGS, ClipVitConfig, synthetic_clip_vit_params
+from .weights import (CLIP_CONFIGS, CLIP_TEXT_CONFIGS, ClipTextConfig, ClipVitConfig, clip_text_param_shapes,
+                      synthetic_clip_text_params, synthetic_clip_vit_params)
 
 
 class ClipVitPerceptor:
-    def __init__(self, cfg: ClipVitConfig, params, device, max_batch: int = 64, group=None):
+    def __init__(self, cfg: ClipVitConfig, params, device, max_batch: int = 64, group=None, text_cfg: ClipTextConfig = None,
+                 text_params=None, tokenizer=None, seed: int = 0):
         self.cfg = cfg
+        self.text_cfg = text_cfg
+        self.text_params = text_params      # OpenAI state-dict entries of the text side (token_embedding.weight, ...)
+        self.tokenizer = tokenizer          # a pixray_amd.tokenizer.BpeTokenizer; default: the process-wide one
+        self._seed = seed
+        self._text_handle = None
         self.device = torch.device(device)
         self.input_resolution = cfg.input_resolution
         self.output_dim = cfg.output_dim
@@ -27,18 +35,52 @@ class ClipVitPerceptor:
             raise ValueError(f"batch {imgs.shape[0]} exceeds the perceptor capacity {self.handle.max_batch}")
         return ops.clip_encode_image(imgs, self.handle, self.group)
 
+    # -- text side (slip.py:68-74) ---------------------------------------------------------------------------------
+    def _text(self):
+        if self._text_handle is None:
+            if self.text_cfg is None:
+                raise NotImplementedError(f"no text tower configuration for perceptor {self.cfg.name!r}")
+            if self.text_cfg.output_dim != self.cfg.output_dim:
+                raise ValueError("text and image towers must share the embedding size")
+            params = self.text_params
+            if params is None:                  # no checkpoints offline: seeded random weights of the real architecture
+                params = synthetic_clip_text_params(self.text_cfg, self._seed)
+            missing = [k for k in clip_text_param_shapes(self.text_cfg) if k not in params]
+            if missing:
+                raise KeyError(f"text tower state dict is missing {missing[0]} (+{len(missing) - 1} more)")
+            self._text_handle = ops.ClipTextHandle(self.text_cfg, params, max_batch=16, device=self.device)
+        return self._text_handle
+
+    def tokenize(self, text):
+        from .tokenizer import default_tokenizer
+        tok = self.tokenizer if self.tokenizer is not None else default_tokenizer()
+        if tok.vocab_size != self.text_cfg.vocab_size:
+            raise ValueError(f"tokenizer has {tok.vocab_size} ids, the text tower expects {self.text_cfg.vocab_size}")
+        return tok.tokenize(text, self.text_cfg.context_length)
+
     def encode_text(self, text):
-        raise NotImplementedError(
-            "the CLIP text tower + BPE tokenizer (slip.py:68-70) are outside the hot path (SURVEY.md §8f-1); "
-            "pass precomputed text embeddings as vector prompts")
+        """slip.py:68-70: `clip.tokenize(text)` -> `model.encode_text` -> `.float()`; `text` may also be an integer tensor
+        of token ids [n, context_length] (what `clip.tokenize` returns; pixray.py:868-870 passes those)."""
+        h = self._text()
+        tokens = text if torch.is_tensor(text) else self.tokenize(text)
+        outs = [ops.clip_encode_text_tokens(tokens[i:i + h.max_batch], h) for i in range(0, tokens.shape[0], h.max_batch)]
+        return torch.cat(outs, 0).float()
+
+    def encode_texts(self, texts):
+        """slip.py:72-74"""
+        e = torch.stack([self.encode_text(t).detach().clone() for t in texts])
+        return e / e.norm(dim=-1, keepdim=True)
 
 
-def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=0, group=None):
-    """slip.py:173-186 equivalent for the ViT family; `params` is an OpenAI `visual.*` state dict (random-init
-    weights of the real architecture are synthesised when none is given: no checkpoints exist offline)."""
+def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=0, group=None, text_params=None,
+                       tokenizer=None):
+    """slip.py:173-186 equivalent for the ViT family; `params` is an OpenAI `visual.*` state dict and `text_params` the
+    text-side entries of the same checkpoint (random-init weights of the real architectures are synthesised when none
+    are given: no checkpoints exist offline)."""
     if clip_model_name not in CLIP_CONFIGS:
         raise KeyError(f"unknown / unsupported perceptor {clip_model_name!r} (supported: {sorted(CLIP_CONFIGS)})")
     cfg = CLIP_CONFIGS[clip_model_name]
     if params is None:
         params = synthetic_clip_vit_params(cfg, seed)
-    return ClipVitPerceptor(cfg, params, device, max_batch=max_batch, group=group)
+    return ClipVitPerceptor(cfg, params, device, max_batch=max_batch, group=group, text_cfg=CLIP_TEXT_CONFIGS.get(clip_model_name),
+                            text_params=text_params, tokenizer=tokenizer, seed=seed)

@@ -268,3 +268,72 @@ def synthetic_clip_vit_params(cfg: ClipVitConfig, seed: int = 0) -> "OrderedDict
             t = 0.02 * torch.randn(shape, generator=g)
         out[name] = t
     return out
+
+
+# --------------------------------------------------------------------------- CLIP text tower config
+@dataclass
+class ClipTextConfig:
+    name: str = "ViT-B/32"
+    vocab_size: int = 49408
+    context_length: int = 77
+    width: int = 512
+    layers: int = 12
+    heads: int = 8
+    output_dim: int = 512
+
+
+# text-side hyper-parameters of the OpenAI checkpoints (clip/model.py `build_model`: heads = width // 64)
+CLIP_TEXT_CONFIGS = {
+    "ViT-B/32": ClipTextConfig(),
+    "ViT-B/16": ClipTextConfig("ViT-B/16"),
+    "ViT-L/14": ClipTextConfig("ViT-L/14", width=768, heads=12, output_dim=768),
+    "tiny-B/32": ClipTextConfig("tiny-B/32", vocab_size=1000, context_length=77, width=256, layers=2, heads=4, output_dim=128),
+}
+
+
+def clip_text_param_shapes(cfg: ClipTextConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """OpenAI state-dict names of the text side, in the order the C ABI expects (include/prx.h, prx_clip_text_create)."""
+    w = cfg.width
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    sh["token_embedding.weight"] = (cfg.vocab_size, w)
+    sh["positional_embedding"] = (cfg.context_length, w)
+    for i in range(cfg.layers):
+        p = f"transformer.resblocks.{i}."
+        sh[p + "ln_1.weight"] = (w,); sh[p + "ln_1.bias"] = (w,)
+        sh[p + "attn.in_proj_weight"] = (3 * w, w); sh[p + "attn.in_proj_bias"] = (3 * w,)
+        sh[p + "attn.out_proj.weight"] = (w, w); sh[p + "attn.out_proj.bias"] = (w,)
+        sh[p + "ln_2.weight"] = (w,); sh[p + "ln_2.bias"] = (w,)
+        sh[p + "mlp.c_fc.weight"] = (4 * w, w); sh[p + "mlp.c_fc.bias"] = (4 * w,)
+        sh[p + "mlp.c_proj.weight"] = (w, 4 * w); sh[p + "mlp.c_proj.bias"] = (w,)
+    sh["ln_final.weight"] = (w,); sh["ln_final.bias"] = (w,)
+    sh["text_projection"] = (w, cfg.output_dim)
+    return sh
+
+
+def synthetic_clip_text_params(cfg: ClipTextConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """OpenAI's initialisation scheme (clip/model.py CLIP.initialize_parameters) with seeded draws."""
+    g = torch.Generator().manual_seed(seed + 104729)
+    w = cfg.width
+    proj_std = (w ** -0.5) * ((2 * cfg.layers) ** -0.5)
+    attn_std = w ** -0.5
+    fc_std = (2 * w) ** -0.5
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in clip_text_param_shapes(cfg).items():
+        if name == "token_embedding.weight":
+            t = torch.randn(shape, generator=g) * 0.02
+        elif name == "positional_embedding":
+            t = torch.randn(shape, generator=g) * 0.01
+        elif name == "text_projection":
+            t = torch.randn(shape, generator=g) * (w ** -0.5)
+        elif name.endswith("in_proj_weight"):
+            t = torch.randn(shape, generator=g) * attn_std
+        elif name.endswith("out_proj.weight") or name.endswith("c_proj.weight"):
+            t = torch.randn(shape, generator=g) * proj_std
+        elif name.endswith("c_fc.weight"):
+            t = torch.randn(shape, generator=g) * fc_std
+        elif name.endswith(".weight"):       # LayerNorm gamma
+            t = 1.0 + 0.05 * torch.randn(shape, generator=g)
+        else:                                # biases / LayerNorm beta
+            t = 0.02 * torch.randn(shape, generator=g)
+        out[name] = t
+    return out

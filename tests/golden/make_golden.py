@@ -10,6 +10,7 @@ HF transformers are available):
                         hidden_act=quick_gelu) on the seeded weights of pixray_amd.weights
   decoder_golden.npz    an independent implementation of taming's Decoder (HF JanusVQVAEDecoder, derived from taming)
   encoder_golden.npz    the same for taming's Encoder (HF JanusVQVAEEncoder)
+  clip_text_golden.npz  an independent implementation of OpenAI's text tower (HF CLIPTextModelWithProjection)
                         on the seeded weights of pixray_amd.weights
 Weights are NOT stored: they are re-derived from the seeds by pixray_amd.weights.synthetic_*.
 """
@@ -88,6 +89,47 @@ def hf_decoder_from_params(cfg, p):
     return d
 
 
+GOLDEN_TEXT = weights.ClipTextConfig("golden-text", vocab_size=300, context_length=24, width=256, layers=2, heads=4, output_dim=64)
+
+
+def golden_tokens(cfg, n, g):
+    """clip.tokenize-shaped ids: SOT (vocab-2), words, EOT (vocab-1, the largest id), zero padding"""
+    tk = torch.zeros(n, cfg.context_length, dtype=torch.long)
+    for i in range(n):
+        L = int(torch.randint(1, cfg.context_length - 2, (1,), generator=g))
+        tk[i, 0] = cfg.vocab_size - 2
+        tk[i, 1:1 + L] = torch.randint(1, cfg.vocab_size - 2, (L,), generator=g)
+        tk[i, 1 + L] = cfg.vocab_size - 1
+    return tk
+
+
+def hf_clip_text_from_params(cfg, p):
+    """an independent implementation of OpenAI's text tower: HF CLIPTextModelWithProjection (eos_token_id=2 selects the
+    OpenAI pooling rule `argmax(input_ids)`)"""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    hc = CLIPTextConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.width, intermediate_size=4 * cfg.width,
+                        projection_dim=cfg.output_dim, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                        max_position_embeddings=cfg.context_length, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                        eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    m = CLIPTextModelWithProjection(hc).eval()
+    w = cfg.width
+    sd = {"text_model.embeddings.token_embedding.weight": p["token_embedding.weight"],
+          "text_model.embeddings.position_embedding.weight": p["positional_embedding"],
+          "text_model.final_layer_norm.weight": p["ln_final.weight"], "text_model.final_layer_norm.bias": p["ln_final.bias"],
+          "text_projection.weight": p["text_projection"].T.contiguous()}
+    for i in range(cfg.layers):
+        a, b = f"transformer.resblocks.{i}.", f"text_model.encoder.layers.{i}."
+        for j, n_ in enumerate("qkv"):
+            sd[b + f"self_attn.{n_}_proj.weight"] = p[a + "attn.in_proj_weight"][j * w:(j + 1) * w]
+            sd[b + f"self_attn.{n_}_proj.bias"] = p[a + "attn.in_proj_bias"][j * w:(j + 1) * w]
+        sd[b + "self_attn.out_proj.weight"] = p[a + "attn.out_proj.weight"]; sd[b + "self_attn.out_proj.bias"] = p[a + "attn.out_proj.bias"]
+        for (x, y) in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            sd[b + y + ".weight"] = p[a + x + ".weight"]; sd[b + y + ".bias"] = p[a + x + ".bias"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
 def hf_encoder_from_params(cfg, p):
     """an independent implementation of taming's Encoder: HF JanusVQVAEEncoder (LlamaGen VQGAN, derived from taming;
     same graph when attention sits only at the lowest resolution, as it does for imagenet_f16_16384)"""
@@ -159,6 +201,12 @@ def main():
     with torch.no_grad():
         hz = enc(xi)
     np.savez(os.path.join(out, "encoder_golden.npz"), x=xi.numpy(), h=hz.numpy(), seed=np.int64(23))
+    pt = weights.synthetic_clip_text_params(GOLDEN_TEXT, 24)
+    mt = hf_clip_text_from_params(GOLDEN_TEXT, pt)
+    tk = golden_tokens(GOLDEN_TEXT, 5, g)
+    with torch.no_grad():
+        te = mt(input_ids=tk).text_embeds
+    np.savez(os.path.join(out, "clip_text_golden.npz"), tokens=tk.numpy(), emb=te.numpy(), seed=np.int64(24))
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)), "bytes")

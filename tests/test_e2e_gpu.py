@@ -247,3 +247,34 @@ def test_hf_clip_checkpoint_loads_and_matches():
         checkpoints.clip_visual_from_openai({"visual.conv1.weight": torch.zeros(1)}, cfg)
     with pytest.raises(KeyError):         # missing tensor
         checkpoints.clip_visual_from_openai({"visual.conv1.weight": torch.zeros(768, 3, 32, 32)}, cfg)
+
+
+def test_text_prompt_vector_prompt_and_init_image_session(tmp_path):
+    """the callers either side of the loop: text prompts through the HIP text tower, a vector-prompt json
+    (pixray.py:879-915), and an init image through the HIP VQGAN encoder (pixray.py:696-718) feed a normal session"""
+    import json
+    from pixray_amd.tokenizer import BpeTokenizer
+    from pixray_amd import weights as W
+    tok = BpeTokenizer([("c", "a"), ("ca", "t</w>"), ("d", "o"), ("do", "g</w>")])
+    W.CLIP_TEXT_CONFIGS["tiny-B/32"].vocab_size = tok.vocab_size
+    try:
+        vec = tmp_path / "vec.json"
+        g = torch.Generator().manual_seed(0)
+        vec.write_text(json.dumps({"tiny-B/32": torch.randn(1, 128, generator=g).tolist()}))
+        init = torch.rand(1, 3, 64, 64, generator=g)
+        sess = api.build_vqgan_clip_session(size=(64, 64), vqgan_model="tiny_f4", clip_model="tiny-B/32", num_cuts=8, seed=1,
+                                            prompts=["a cat:2", "dog:-0.5:0.3"], vector_prompts=[f"{vec}:1.5"], init_image=init,
+                                            tokenizer=tok)
+        pms = sess.pmsTable["tiny-B/32"]
+        assert len(pms) == 3 and float(pms[0].weight) == 2.0 and float(pms[1].weight) == -0.5 and abs(float(pms[1].stop) - 0.3) < 1e-6
+        assert abs(float(pms[2].weight) - 0.15) < 1e-6
+        z0 = sess.drawer.get_z_copy()
+        cb_rows = sess.drawer._params["quantize.embedding.weight"]
+        zr = z0.detach().cpu().movedim(1, 3).reshape(-1, cb_rows.shape[1])
+        assert (zr[:, None, :] == cb_rows[None]).all(-1).any(1).all()            # the start point is made of code vectors
+        for it in range(3):
+            assert sess.train(it)
+        assert len(sess.last_losses) == 3 and all(torch.isfinite(l) for l in sess.last_losses)
+        assert not torch.equal(sess.drawer.get_z(), z0)
+    finally:
+        W.CLIP_TEXT_CONFIGS["tiny-B/32"].vocab_size = 1000

@@ -105,6 +105,18 @@ def test_encoder_oracle_matches_independent_golden():
     assert torch.equal(dist.argmin(-1), idx)
 
 
+def test_clip_text_oracle_matches_independent_golden():
+    """OpenAI `CLIP.encode_text` restatement vs HF CLIPTextModelWithProjection (encode_text path)"""
+    from oracle import clip_text_ref
+    mg = _golden_cfgs()
+    d = load("clip_text_golden.npz")
+    cfg = mg.GOLDEN_TEXT
+    p = weights.synthetic_clip_text_params(cfg, int(d["seed"]))
+    with torch.no_grad():
+        e = clip_text_ref.text_forward(p, d["tokens"].long(), heads=cfg.heads, layers=cfg.layers)
+    assert rel(e, d["emb"]) < 1e-5, rel(e, d["emb"])
+
+
 # ---------------------------------------------------------------------------------------- live cross-checks
 @pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
 def test_oracle_fragments_vs_live_reference():

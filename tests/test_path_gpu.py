@@ -303,3 +303,78 @@ def test_vqgan_drawer_encoder_entry_points():
     assert id(dr.get_z()) == zid and not torch.equal(dr.get_z().detach(), z_ref)     # in place, as `self.z.copy_(new_z)`
     with pytest.raises(ValueError):
         dr.init_from_tensor(torch.zeros(1, 4, 64, 64))
+
+
+# ------------------------------------------------------------------------------------------ CLIP text tower
+def _tokens(cfg, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    tk = torch.zeros(n, cfg.context_length, dtype=torch.long)
+    for i in range(n):
+        L = int(torch.randint(1, cfg.context_length - 2, (1,), generator=g)) if i else cfg.context_length - 2   # row 0: full length
+        tk[i, 0] = cfg.vocab_size - 2
+        tk[i, 1:1 + L] = torch.randint(1, cfg.vocab_size - 2, (L,), generator=g)
+        tk[i, 1 + L] = cfg.vocab_size - 1
+    return tk
+
+
+@pytest.mark.parametrize("name,n", [("tiny-B/32", 5), ("ViT-B/32", 3), ("ViT-L/14", 2)])
+def test_clip_text_tower_vs_oracle(name, n):
+    """CLIP_Base.encode_text (slip.py:68-70) on token ids: causal transformer, EOT pooling, projection.  bf16 operands vs
+    the fp32 oracle: 2e-2 rel-L2 / cosine 0.999 per embedding (same tolerance as the image tower)."""
+    import dataclasses
+    from oracle import clip_text_ref
+    cfg = weights.CLIP_TEXT_CONFIGS[name]
+    if cfg.layers > 4:
+        cfg = dataclasses.replace(cfg, layers=4)          # keep the CPU oracle's share short; same operators
+    p = weights.synthetic_clip_text_params(cfg, seed=9)
+    h = ops.ClipTextHandle(cfg, p, max_batch=8, device=DEV)
+    tk = _tokens(cfg, n, 13)
+    e = ops.clip_encode_text_tokens(tk, h)
+    with torch.no_grad():
+        ref = clip_text_ref.text_forward(p, tk, heads=cfg.heads, layers=cfg.layers)
+    assert e.shape == (n, cfg.output_dim)
+    assert rel_l2(e, ref) < 2e-2, rel_l2(e, ref)
+    for i in range(n):
+        assert cosine(e[i], ref[i]) > 0.999
+    # causality: tokens after the EOT position cannot change the embedding
+    tk2 = tk.clone()
+    eot = int(tk2[1].argmax())
+    tk2[1, eot + 1:] = 7
+    e2 = ops.clip_encode_text_tokens(tk2, h)
+    assert torch.equal(e2[1], e[1])
+    with pytest.raises(ValueError):
+        ops.clip_encode_text_tokens(torch.full((1, cfg.context_length), cfg.vocab_size), h)
+
+
+def test_clip_text_independent_golden_and_perceptor_surface():
+    """the committed HF CLIPTextModelWithProjection fixture through the HIP text tower, and the perceptor's
+    encode_text / encode_texts entry points (slip.py:68-74)"""
+    import os, sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as mg
+    d = np.load(os.path.join(here, "golden", "clip_text_golden.npz"))
+    cfg = mg.GOLDEN_TEXT
+    p = weights.synthetic_clip_text_params(cfg, int(d["seed"]))
+    h = ops.ClipTextHandle(cfg, p, max_batch=8, device=DEV)
+    e = ops.clip_encode_text_tokens(torch.from_numpy(d["tokens"]), h)
+    assert rel_l2(e, torch.from_numpy(d["emb"])) < 2e-2, rel_l2(e, torch.from_numpy(d["emb"]))
+
+    from pixray_amd.perceptor import get_clip_perceptor
+    from pixray_amd.prompt import Prompt
+    from pixray_amd.tokenizer import BpeTokenizer
+    tok = BpeTokenizer([("t", "h"), ("th", "e</w>"), ("c", "a"), ("ca", "t</w>")])
+    tcfg = weights.ClipTextConfig("tiny-B/32", vocab_size=tok.vocab_size, width=256, layers=2, heads=4, output_dim=128)
+    perc = get_clip_perceptor("tiny-B/32", DEV, max_batch=4, tokenizer=tok)
+    perc.text_cfg = tcfg
+    emb = perc.encode_text("the cat")
+    assert emb.shape == (1, 128) and emb.dtype == torch.float32 and emb.is_cuda
+    assert torch.equal(emb, perc.encode_text(tok.tokenize("The  CAT")))
+    both = perc.encode_texts(["the cat", "cat the"])
+    assert both.shape == (2, 1, 128) and torch.allclose(both.norm(dim=-1), torch.ones(2, 1, device=DEV), atol=1e-5)
+    # the text embedding drives a Prompt against image embeddings of the same perceptor (pixray.py:873-877, 1297-1299)
+    img = torch.rand(2, 3, 224, 224, device=DEV, requires_grad=True)
+    loss = Prompt(emb, 1.0, float("-inf")).to(DEV)(perc.encode_image(img).float())
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(img.grad).all()
