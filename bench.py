@@ -163,6 +163,11 @@ def main():
         import torch.distributed as dist
         dist.destroy_process_group()      # RCCL prints its version banner here: keep the JSON line last
     sys.stderr.flush()
+    try:                                   # RCCL writes its banner through C stdio: drain it before the JSON line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
         print(json.dumps(out), flush=True)
 
