@@ -234,3 +234,58 @@ def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> tor
     if "noise" in prm and prm["noise"] is not None:
         batch = batch + prm["noise_fac"].view(-1, 1, 1, 1) * prm["noise"]   # pixray.py:508-510
     return batch
+
+
+# ---- cached-transform path (pixray.py:480-486) ------------------------------------------------
+def composed_transforms(prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+    """`self.transforms` (pixray.py:498): kornia's composed pixel-space 3x3 (source -> output) of the two geometric
+    augmentations of each cutout, identity for a stage whose apply-mask is off.  [cutn,3,3] float64."""
+    cutn = int(prm["cutn"])
+    nz = int(0.6 * cutn)
+    nw = cutn - nz
+    eye = torch.eye(3, dtype=torch.float64)
+    out = []
+    if nz > 0:
+        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, S)
+        Mp = torch.where(prm["z_persp_apply"].view(-1, 1, 1), Mp, eye[None].expand(nz, 3, 3))
+        xs, ys, w, h = [prm["z_crop"][:, i].double() for i in range(4)]
+        src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
+                           torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
+        dst = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
+        Mc = get_perspective_transform(src, dst[None].expand(nz, 4, 2)).clone()
+        Mc[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)          # the crop is applied as an affine map
+        out.append(Mc @ Mp)
+    if nw > 0:
+        s = 0.95
+        c = S / 2.0 - 0.5
+        Ma = eye[None].repeat(nw, 1, 1)
+        Ma[:, 0, 0] = s
+        Ma[:, 1, 1] = s
+        Ma[:, 0, 2] = (1 - s) * c + prm["w_trans"][:, 0].double()
+        Ma[:, 1, 2] = (1 - s) * c + prm["w_trans"][:, 1].double()
+        Mp = _persp_matrix(prm["w_persp_rand"], 0.2, S)
+        Mp = torch.where(prm["w_persp_apply"].view(-1, 1, 1), Mp, eye[None].expand(nw, 3, 3))
+        out.append(Mp @ Ma)
+    return torch.cat(out, dim=0)
+
+
+def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None) -> torch.Tensor:
+    """MakeCutouts.forward when `.transforms` is cached (pixray.py:480-486; image prompts, pixray.py:1318-1333): ONE
+    `kornia.warp_perspective(pooled, T, (S,S), padding_mode=...)` per set -- kornia 0.6.2's default align_corners=True
+    [UPSTREAM, from knowledge: parity unpinned], zoom set with the iteration's reflection/border padding, wide set filled
+    with the iteration's gray -- no ColorJitter, then fresh noise."""
+    cutn = int(prm["cutn"])
+    nz = int(0.6 * cutn)
+    T = composed_transforms(prm, S)
+    base = pooled_image(img, S)
+    pad_mode = "reflection" if int(prm["reflect"]) else "border"
+    fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)
+    outs = []
+    if nz > 0:
+        outs.append(warp_perspective(base.expand(nz, -1, -1, -1), T[:nz], (S, S), pad_mode, align_corners=True))
+    if cutn - nz > 0:
+        outs.append(warp_perspective(base.expand(cutn - nz, -1, -1, -1), T[nz:], (S, S), "fill", align_corners=True, fill_value=fill))
+    batch = torch.cat(outs, dim=0)
+    if noise is not None:
+        batch = batch + noise_fac.view(-1, 1, 1, 1).to(batch) * noise
+    return batch

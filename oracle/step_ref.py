@@ -79,8 +79,12 @@ class OracleMakeCutouts(torch.nn.Module):
         self.last_params = None
 
     def forward(self, input, spot=None):
+        if self.transforms is not None:          # cached path (pixray.py:480-486): same geometry, no jitter, no noise here
+            out = cutouts_ref.make_cutouts_cached(input, self.last_params, self.cut_size)
+            return out if self.shard is None else out[self.shard[0]:self.shard[1]]
         prm = self.sampler(self.iteration, self.fill)
         self.last_params = prm
+        self.transforms = cutouts_ref.composed_transforms(prm, self.cut_size)
         out = cutouts_ref.make_cutouts(input, prm, self.cut_size)
         if self.shard is not None:
             out = out[self.shard[0]:self.shard[1]]

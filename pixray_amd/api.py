@@ -29,14 +29,18 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                              prompt_weight=1.0, extra_prompts: Sequence = (), seed=0, device="cuda", group=None, rank=0,
                              world_size=1, custom_losses=(), filters=(), learning_rate_drops=(), prompts: Sequence[str] = (),
                              vector_prompts: Sequence[str] = (), init_image: Optional[torch.Tensor] = None, tokenizer=None,
-                             clip_text_params=None) -> Session:
+                             clip_text_params=None, image_prompts: Sequence[torch.Tensor] = (), image_prompt_weight=None,
+                             image_prompt_shuffle: bool = False, init_weight: float = 0.0, init_weight_dist: float = 0.0,
+                             init_weight_pix: float = 0.0, init_weight_cos: float = 0.0) -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
     a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
 
     `prompts`: pixray text prompts "text[:weight[:stop]]" (pixray.py:859-877), encoded by the HIP text tower (needs the
     CLIP merges table, pixray_amd/tokenizer.py); `vector_prompts`: paths of json files {model name: [[...]]} with
     precomputed CLIP-space vectors, "path[:weight[:stop]]", weighted x0.1 as pixray.py:879-915 does; `init_image`:
-    [1,3,H,W] in [0,1], encoded to the starting z by the HIP VQGAN encoder (pixray.py:696-718)."""
+    [1,3,H,W] in [0,1], encoded to the starting z by the HIP VQGAN encoder (pixray.py:696-718); `image_prompts`: target
+    images [1,3,H,W] in [0,1] turned into per-iteration throwaway Prompts through the cached cutout transforms
+    (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
@@ -70,4 +74,9 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
         pms.append(Prompt(emb.to(dev), w, stop).to(dev))
     return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, {clip_model: pms},
                    learning_rate=learning_rate, iterations=iterations, custom_losses=custom_losses, filters=filters,
-                   seed=seed, group=group, rank=rank, world_size=world_size, learning_rate_drops=learning_rate_drops)
+                   seed=seed, group=group, rank=rank, world_size=world_size, learning_rate_drops=learning_rate_drops,
+                   image_prompts={clip_model: [t.to(dev).float() for t in image_prompts]} if len(image_prompts) else None,
+                   image_prompt_weight=image_prompt_weight, image_prompt_shuffle=image_prompt_shuffle,
+                   init_weight=init_weight, init_weight_dist=init_weight_dist, init_weight_pix=init_weight_pix,
+                   init_weight_cos=init_weight_cos, z_orig=drawer.get_z_copy().detach() if init_image is not None else None,
+                   init_image_tensor=None if init_image is None else init_image.to(dev).float())

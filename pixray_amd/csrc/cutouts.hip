@@ -25,7 +25,8 @@ constexpr int DESC_WORDS = 32;
 enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
        D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27 };
 enum { GRID_MESH = 0, GRID_AFFINE = 1 };
-enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4 };
+enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4,
+       MODE_REFLECT_AC = 5 };   // reflection as F.grid_sample does it with align_corners=True (the cached-transform path)
 
 inline int ew_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 16384); }
 
@@ -84,6 +85,16 @@ __device__ __forceinline__ float reflect_coord(float in, float size) {
     return (flips & 1) ? (span - extra + mn) : (extra + mn);
 }
 
+__device__ __forceinline__ float reflect_coord_ac(float in, float size) {
+    // F.grid_sample reflection, align_corners=True: reflect about the pixel centres [0, size-1]
+    const float span = size - 1.f;
+    if (span <= 0.f) return 0.f;
+    in = fabsf(in);
+    float extra = fmodf(in, span);
+    int flips = (int)floorf(in / span);
+    return (flips & 1) ? (span - extra) : extra;
+}
+
 __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, int mode) {
     if (mode == MODE_BORDER) {
         u = fminf(fmaxf(u, 0.f), (float)(W - 1));
@@ -91,6 +102,9 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, int mo
     } else if (mode == MODE_REFLECT) {
         u = fminf(fmaxf(reflect_coord(u, (float)W), 0.f), (float)(W - 1));
         v = fminf(fmaxf(reflect_coord(v, (float)H), 0.f), (float)(H - 1));
+    } else if (mode == MODE_REFLECT_AC) {
+        u = fminf(fmaxf(reflect_coord_ac(u, (float)W), 0.f), (float)(W - 1));
+        v = fminf(fmaxf(reflect_coord_ac(v, (float)H), 0.f), (float)(H - 1));
     }
     Taps t;
     float fx = floorf(u), fy = floorf(v);

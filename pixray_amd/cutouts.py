@@ -20,7 +20,7 @@ from torch import nn
 from . import ops
 
 DESC_WORDS = 32
-MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL = 0, 1, 2, 3, 4
+MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL, MODE_REFLECT_AC = 0, 1, 2, 3, 4, 5
 GRID_MESH, GRID_AFFINE = 0, 1
 
 
@@ -181,6 +181,34 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     return torch.from_numpy(desc)
 
 
+def build_cached_descriptors(transforms: torch.Tensor, cutn: int, S: int, reflect: bool, fill: float,
+                             noise_fac: torch.Tensor) -> torch.Tensor:
+    """Descriptor table of the reference's CACHED-transform path (pixray.py:480-486): when `.transforms` is set (second
+    and later calls inside one iteration: image prompts, pixray.py:1318-1333) the pooled image is warped ONCE with the
+    composed 3x3 of the two augmentation stages, `kornia.warp_perspective(x, T, (S,S), padding_mode=...)` with kornia
+    0.6.2's default `align_corners=True` [UPSTREAM], zoom set padded by the iteration's reflection/border mode, wide set
+    filled with the iteration's gray; no ColorJitter; fresh noise.
+
+    `transforms` = columns 0:18 of the live descriptor table (the two `src_norm <- dst_norm` maps).  Their product is the
+    composed map; scaling its first two rows by (S-1)/S turns the kernel's align_corners=False pixel mapping
+    `(g+1)*S/2 - 0.5` into align_corners=True's `(g+1)*(S-1)/2`."""
+    t = transforms.double().numpy()
+    M = t[:, 0:9].reshape(-1, 3, 3) @ t[:, 9:18].reshape(-1, 3, 3)
+    M[:, :2, :] *= (S - 1.0) / S
+    nz = int(0.6 * cutn)
+    desc = np.zeros((cutn, DESC_WORDS))
+    desc[:, 0:9] = M.reshape(-1, 9)
+    desc[:, 9:18] = np.eye(3).reshape(9)
+    desc[:nz, 18] = MODE_REFLECT_AC if reflect else MODE_BORDER
+    desc[nz:, 18] = MODE_FILL
+    desc[:, 19] = MODE_IDENT
+    desc[:, 20] = float(fill)
+    desc[:, 25] = _np(noise_fac)
+    desc[:, 26] = GRID_MESH
+    desc[:, 27] = GRID_MESH
+    return torch.from_numpy(desc)
+
+
 class MakeCutouts(nn.Module):
     """Drop-in for the reference's `MakeCutouts(cut_size, cutn, cut_pow=1.)` (pixray.py:400-511):
     `forward(input[1,3,H,W]) -> [cutn,3,S,S]`, autograd-connected to `input`.
@@ -237,12 +265,19 @@ class MakeCutouts(nn.Module):
     def forward(self, input, spot=None):
         if spot is not None:
             raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
+        S = self.cut_size
+        lo, hi = (0, self.cutn) if self.shard is None else self.shard
+        if self.transforms is not None and not getattr(self, "_prepared", False):
+            # cached path (pixray.py:480-486): a further call inside the same iteration re-uses this iteration's geometry
+            prm = self.last_params
+            facs = _uniform(self.generator, (self.cutn,), 0.0, self.noise_fac).float()
+            desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs)
+            noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32) if self.noise_fac else None
+            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S)
         if not getattr(self, "_prepared", False):
             self.prepare()
         self._prepared = False
-        S = self.cut_size
         prm = self.last_params
-        lo, hi = (0, self.cutn) if self.shard is None else self.shard
         desc_dev = self._desc_dev
         if desc_dev.device != input.device:
             desc_dev = desc_dev.to(input.device, non_blocking=True)

@@ -22,6 +22,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from .prompt import Prompt
+
 
 def spherical_dist_loss(x, y):
     """pixray.py:262-265 (used by the z regularisers, 1344-1356)"""
@@ -90,7 +92,10 @@ class Session:
                  batches: int = 1, learning_rate_drops: Sequence[int] = (), custom_losses: Sequence[dict] = (),
                  filters: Sequence[dict] = (), args=None, init_weight: float = 0.0, init_weight_dist: float = 0.0,
                  z_orig=None, optimiser_factory=None, seed: int = 0, group=None, rank: int = 0, world_size: int = 1,
-                 auto_stop: bool = False):
+                 auto_stop: bool = False, image_prompts: Optional[Dict[str, Sequence[torch.Tensor]]] = None,
+                 image_prompt_weight: Optional[float] = None, image_prompt_shuffle: bool = False,
+                 z_labels: Sequence[torch.Tensor] = (), image_label_weight: float = 1.0, init_weight_pix: float = 0.0,
+                 init_weight_cos: float = 0.0, init_image_tensor: Optional[torch.Tensor] = None):
         self.drawer = drawer
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
@@ -106,6 +111,16 @@ class Session:
         self.init_weight = init_weight
         self.init_weight_dist = init_weight_dist
         self.z_orig = z_orig
+        # image prompts (pixray.py:823-835, 1307-1336): target images [1,3,H,W] in [0,1], cut out every iteration with the
+        # iteration's cached transforms so their cutouts line up with the current ones
+        self.pmsImageTable = {k: list(v) for k, v in (image_prompts or {}).items()}
+        self.image_prompt_weight = image_prompt_weight
+        self.image_prompt_shuffle = image_prompt_shuffle
+        self.z_labels = list(z_labels)                   # pixray.py:837-849, 1344-1349
+        self.image_label_weight = image_label_weight
+        self.init_weight_pix = init_weight_pix           # pixray.py:1363-1368
+        self.init_weight_cos = init_weight_cos           # pixray.py:1370-1375
+        self.init_image_tensor = init_image_tensor
         self.optimiser_factory = optimiser_factory
         self.group, self.rank, self.world_size = group, rank, world_size
         self.auto_stop = auto_stop
@@ -196,14 +211,44 @@ class Session:
             iii = perceptor.encode_image(cur_cutouts[self.cutoutSizeTable[name]]).float()     # pixray.py:1295
             for prompt in self.pmsTable[name]:
                 result.append(prompt(iii))                                                     # pixray.py:1297-1299
+            # image prompts: throwaway Prompts from this iteration's cutouts of each target image (pixray.py:1307-1336)
+            mk = self.cutoutsTable[self.cutoutSizeTable[name]]
+            for timg in self.pmsImageTable.get(name, ()):
+                if self.image_prompt_shuffle:
+                    mk.transforms = None
+                with torch.no_grad():
+                    embed = perceptor.encode_image(mk(timg)).float()
+                    if self.world_size > 1:      # every rank needs ALL target embeddings: each cutout is compared with all
+                        import torch.distributed as dist
+                        parts = [torch.empty_like(embed) for _ in range(self.world_size)]
+                        dist.all_gather(parts, embed.contiguous(), group=self.group)
+                        embed = torch.cat(parts, 0)
+                w = self.image_prompt_weight if self.image_prompt_weight is not None else 1.0
+                pm = Prompt(embed, w).to(embed.device)
+                if self.world_size > 1 and hasattr(pm, "denom"):
+                    pm.denom = float(mk.cutn * embed.shape[0])
+                result.append(pm(iii))
         for mk in self.cutoutsTable.values():
             mk.transforms = None                                                               # pixray.py:1339-1342
         # regularisers on z are replicated on every rank (they do not pass through `out`)
+        for z_label in self.z_labels:                                                          # pixray.py:1344-1349
+            f = self.drawer.get_z().reshape(1, -1)
+            result.append(spherical_dist_loss(f, z_label.reshape(1, -1)) * self.image_label_weight)
         if self.init_weight and self.z_orig is not None:
             f = self.drawer.get_z().reshape(1, -1)
             result.append((spherical_dist_loss(f, self.z_orig.reshape(1, -1)) * self.init_weight)[0])
         if self.init_weight_dist and self.z_orig is not None:
             result.append(F.mse_loss(self.drawer.get_z(), self.z_orig) * self.init_weight_dist / 2)
+        if self.init_weight_pix:                                                               # pixray.py:1363-1368
+            if self.init_image_tensor is None:
+                print("OOPS IIT is 0")
+            else:
+                w = self.init_weight_pix / self.world_size if self.world_size > 1 else self.init_weight_pix
+                result.append(F.l1_loss(out, self.init_image_tensor.to(out.device)) * w / 2)
+        if self.init_weight_cos and self.z_orig is not None:                                   # pixray.py:1370-1375
+            f = self.drawer.get_z().reshape(1, -1)
+            f2 = self.z_orig.reshape(1, -1)
+            result.append(F.cosine_embedding_loss(f, f2, torch.ones_like(f[0])) * self.init_weight_cos)
         needed_globals = {"cur_iteration": it, "embeds": iii}                                  # pixray.py:1377-1381
         for t in self.custom_losses:
             w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]

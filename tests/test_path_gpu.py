@@ -378,3 +378,31 @@ def test_clip_text_independent_golden_and_perceptor_surface():
     loss = Prompt(emb, 1.0, float("-inf")).to(DEV)(perc.encode_image(img).float())
     loss.backward()
     assert torch.isfinite(loss) and torch.isfinite(img.grad).all()
+
+
+# ------------------------------------------------------------------------------------------ cached cutout transforms (a6)
+@pytest.mark.parametrize("it", [0, 1])
+def test_make_cutouts_cached_transform_path_vs_oracle(it):
+    """pixray.py:480-486: a second MakeCutouts call inside one iteration (image prompts, pixray.py:1318-1333) re-uses the
+    iteration's composed 3x3 transforms in ONE warp (kornia default align_corners=True), zoom set with the iteration's
+    reflection (even) / border (odd) padding, wide set gray-filled, no ColorJitter.  fp32 gather: 1e-4-class."""
+    cutn, S, HW = 10, 224, 256
+    g = torch.Generator().manual_seed(40 + it)
+    img = _test_image("smooth", HW, g)
+    target = _test_image("smooth", HW, g)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=it, noise_fac=0.0)
+    mk = pc.MakeCutouts(S, cutn, noise_fac=0.0)
+    mk.fixed_params = prm
+    mk.iteration = it
+    live = mk(img.to(DEV))
+    assert mk.transforms is not None
+    cached = mk(target.to(DEV))
+    ref_live = cutouts_ref.make_cutouts(img, prm, S)
+    ref_cached = cutouts_ref.make_cutouts_cached(target, prm, S)
+    assert rel_l2(live, ref_live) < 1e-4
+    assert rel_l2(cached, ref_cached) < 1e-4, rel_l2(cached, ref_cached)
+    assert (cached.cpu() - ref_cached).abs().max().item() < 5e-3
+    # and it is a different resampling from the live path of the same image (single warp, no jitter)
+    assert rel_l2(mk(img.to(DEV)), ref_live) > 1e-3
+    mk.transforms = None                                   # what the loop does at the end of every iteration
+    assert rel_l2(mk(img.to(DEV)), ref_live) < 1e-4
