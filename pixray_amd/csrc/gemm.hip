@@ -789,7 +789,8 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         }
         // wide row-major problems (FC1 / W2^T: M=3200, N=3072): the fill model over-rates 64x64 (LDS-bound tiles);
         // sweeps give 128x64 28 us vs 64x64 31 us vs 128x128 31.5 us
-        if (d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
+        static const int wide_tile = getenv("PRX_WIDE_TILE") ? atoi(getenv("PRX_WIDE_TILE")) : 128;     // tuning A/B
+        if (wide_tile == 128 && d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
     }
     if (g_force_bm) { BM = g_force_bm; BN = g_force_bn; }
     GemmArgs a;

@@ -322,3 +322,44 @@ def test_image_prompts_and_init_regularisers_vs_oracle():
     for it in range(2):
         assert sess.train(it)
     assert all(torch.isfinite(l) for l in sess.last_losses)
+
+
+def test_two_perceptors_share_one_decoder_pass():
+    """pixray.py:1266-1299 / SURVEY §8f-2: a perceptor ensemble (two towers with different input resolutions, hence two
+    cutout tables) hangs off ONE drawer.synth; dL/dz is the sum of what each tower alone produces"""
+    import types
+    from pixray_amd.cutouts import MakeCutouts
+    from pixray_amd.engine import Session
+    from pixray_amd.perceptor import ClipVitPerceptor
+    from pixray_amd.prompt import Prompt
+    from pixray_amd.vqgan_drawer import VqganDrawer
+
+    def build(which):
+        s = types.SimpleNamespace(vqgan_model="tiny_f4", size=(64, 64), weight_seed=0)
+        dr = VqganDrawer(s); dr.load_model(s, DEV); dr.init_from_tensor(None)
+        cfgs = {"A": weights.CLIP_CONFIGS["tiny-B/32"], "B": weights.ClipVitConfig("tiny-B/16@128", 128, 16, 256, 2, 4, 128)}
+        percs, cuts, pms = {}, {}, {}
+        for i, name in enumerate(which):
+            cfg = cfgs[name]
+            percs[name] = ClipVitPerceptor(cfg, weights.synthetic_clip_vit_params(cfg, 10 + ord(name)), DEV, max_batch=6)
+            mk = MakeCutouts(cfg.input_resolution, 6, generator=torch.Generator().manual_seed(99 + ord(name)), noise_fac=0.0)
+            cuts[cfg.input_resolution] = mk
+            pms[name] = [Prompt(api.seeded_unit_vectors(1, cfg.output_dim, 5 + ord(name)).to(DEV), 1.0, float("-inf")).to(DEV)]
+        return Session(dr, percs, cuts, pms, seed=4)
+
+    grads, losses = {}, {}
+    for which in ("A", "B", "AB"):
+        sess = build(which)
+        sess._host_prep(0)
+        ls = sess.ascend_txt()
+        sum(ls).backward()
+        grads[which] = sess.drawer.get_z().grad.clone()
+        losses[which] = [float(l.detach()) for l in ls]
+    assert len(losses["AB"]) == 2
+    assert abs(losses["AB"][0] - losses["A"][0]) < 1e-6 and abs(losses["AB"][1] - losses["B"][0]) < 1e-6
+    # forward identical.  Backward is NOT exactly additive: ClampWithGrad (vqgan.py:76-79) masks by the sign of the SUMMED
+    # image gradient on out-of-range pixels, and the decoder backward rounds the summed gradient to bf16 once
+    g_sum = grads["A"] + grads["B"]
+    assert rel(grads["AB"], g_sum) < 6e-2
+    a, b = grads["AB"].flatten(), g_sum.flatten()
+    assert float(a @ b / (a.norm() * b.norm())) > 0.998
