@@ -215,7 +215,8 @@ def _vqgan_case(name, hw, seed):
     return ref, out, gref, gd, idx_ref, h.last_indices.cpu().long()
 
 
-@pytest.mark.parametrize("name,hw", [("tiny_f4", 16), ("imagenet_f16_16384", 16)])
+@pytest.mark.parametrize("name,hw", [("tiny_f4", 16), ("imagenet_f16_16384", 16),
+                                     ("imagenet_f16_16384", 32)])        # 32: the 512x512 decoder of BASELINE.json configs[2]
 def test_vqgan_synth_vs_oracle(name, hw):
     ref, out, gref, gd, idx_ref, idx = _vqgan_case(name, hw, 9)
     assert torch.equal(idx, idx_ref), "VQ code selection differs"
