@@ -54,22 +54,24 @@ __global__ __launch_bounds__(256) void colminmax_kernel(const float* __restrict_
 
 }  // namespace
 
+static inline int pad8(int P) { return (P + 7) & ~7; }   // row pitch of [*, P] GEMM operands (see zero_if_padded)
+
 struct Conv3 { int Cin, Cout, CoP; bf16_t *Wf, *Wd; float* b; };
 struct Conv1 { int Cin, Cout; bf16_t *W, *WT; float* b; };
 struct GN { int C; float *g, *b; double *stats, *bstats; int id; };
 
 struct ResBlock {
-    int Cin, Cout, res;
+    int Cin, Cout, rh, rw;   // feature-map height x width (pixray sizes need not be square)
     GN n1, n2; Conv3 c1, c2; Conv1 sc; bool has_sc;
     float *x_in, *h1, *scbuf, *out;
     bf16_t *x_in_bf, *out_bf;   // bf16 twins (only where a GEMM consumes the tensor)
 };
 struct AttnBlock {
-    int C, res;
+    int C, rh, rw;
     GN n; Conv1 qkv, proj;   // qkv = [3C, C] concatenated q|k|v
     float* x_in; bf16_t *qkvb, *Pm, *PT; float* out; bf16_t* out_bf;
 };
-struct UpBlock { int C, res_out; Conv3 c; float *x_in, *out; bf16_t *x_in_bf, *out_bf; };
+struct UpBlock { int C, rh, rw; Conv3 c; float *x_in, *out; bf16_t *x_in_bf, *out_bf; };
 
 struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
 
@@ -138,15 +140,15 @@ int make_conv1(PrxVqgan* v, Conv1& c, int Cin, int Cout, WCursor& cur, hipStream
     if ((r = prx_pack_transpose_bf16(w, c.WT, Cout, Cin, s))) return r;
     return copyf(v, &c.b, b, Cout, s);
 }
-int make_res(PrxVqgan* v, int Cin, int Cout, int res, WCursor& cur, hipStream_t s) {
+int make_res(PrxVqgan* v, int Cin, int Cout, int rh, int rw, WCursor& cur, hipStream_t s) {
     ResBlock rb{};
-    rb.Cin = Cin; rb.Cout = Cout; rb.res = res; rb.has_sc = Cin != Cout;
+    rb.Cin = Cin; rb.Cout = Cout; rb.rh = rh; rb.rw = rw; rb.has_sc = Cin != Cout;
     int r;
     if ((r = make_gn(v, rb.n1, Cin, cur, s))) return r;
     if ((r = make_conv3(v, rb.c1, Cin, Cout, cur, s))) return r;
     if ((r = make_gn(v, rb.n2, Cout, cur, s))) return r;
     if ((r = make_conv3(v, rb.c2, Cout, Cout, cur, s))) return r;
-    const size_t P = (size_t)res * res;
+    const size_t P = (size_t)rh * rw;
     if (rb.has_sc) {
         if ((r = make_conv1(v, rb.sc, Cin, Cout, cur, s))) return r;
         VALLOC(rb.scbuf, P * Cout);
@@ -156,9 +158,9 @@ int make_res(PrxVqgan* v, int Cin, int Cout, int res, WCursor& cur, hipStream_t 
     v->res.push_back(rb);
     return 0;
 }
-int make_attn(PrxVqgan* v, int C, int res, WCursor& cur, hipStream_t s) {
+int make_attn(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
     AttnBlock ab{};
-    ab.C = C; ab.res = res;
+    ab.C = C; ab.rh = rh; ab.rw = rw;
     int r;
     if ((r = make_gn(v, ab.n, C, cur, s))) return r;
     // q, k, v 1x1 convs are concatenated into one [3C, C] GEMM
@@ -176,18 +178,21 @@ int make_attn(PrxVqgan* v, int C, int res, WCursor& cur, hipStream_t s) {
     if ((r = prx_pack_bf16(wcat, ab.qkv.W, (size_t)3 * C * C, s))) return r;
     if ((r = prx_pack_transpose_bf16(wcat, ab.qkv.WT, 3 * C, C, s))) return r;
     if ((r = make_conv1(v, ab.proj, C, C, cur, s))) return r;
-    const size_t P = (size_t)res * res;
-    VALLOC(ab.qkvb, P * 3 * C); VALLOC(ab.Pm, P * P); VALLOC(ab.PT, P * P); VALLOC(ab.out, P * C);
+    const size_t P = (size_t)rh * rw;
+    const size_t P8 = (size_t)pad8((int)P);
+    VALLOC(ab.qkvb, P * 3 * C); VALLOC(ab.Pm, P * P8); VALLOC(ab.PT, P * P8); VALLOC(ab.out, P * C);
+    PRX_CHECK_HIP(hipMemsetAsync(ab.Pm, 0, P * P8 * sizeof(bf16_t), s));      // pad columns stay zero: the kernels never write them
+    PRX_CHECK_HIP(hipMemsetAsync(ab.PT, 0, P * P8 * sizeof(bf16_t), s));
     v->stages.push_back({1, (int)v->attn.size()});
     v->attn.push_back(ab);
     return 0;
 }
-int make_up(PrxVqgan* v, int C, int res_out, WCursor& cur, hipStream_t s) {
+int make_up(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
     UpBlock ub{};
-    ub.C = C; ub.res_out = res_out;
+    ub.C = C; ub.rh = rh; ub.rw = rw;
     int r;
     if ((r = make_conv3(v, ub.c, C, C, cur, s))) return r;
-    VALLOC(ub.out, (size_t)res_out * res_out * C);
+    VALLOC(ub.out, (size_t)rh * rw * C);
     v->stages.push_back({2, (int)v->ups.size()});
     v->ups.push_back(ub);
     return 0;
@@ -197,7 +202,7 @@ int make_up(PrxVqgan* v, int C, int res_out, WCursor& cur, hipStream_t s) {
 int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult, int num_res_blocks, int attn_res,
                           int resolution, int z_channels, int embed_dim, int n_embed, int out_ch, int h0, int w0,
                           const float* const* w, int n_w, hipStream_t s) {
-    PRX_REQUIRE(h0 == w0, "vqgan_create: only square latents are supported in this build (h0=%d w0=%d)", h0, w0);
+    PRX_REQUIRE(h0 >= 1 && w0 >= 1, "vqgan_create: bad latent size %dx%d", h0, w0);
     PRX_REQUIRE(embed_dim == z_channels, "vqgan_create: embed_dim must equal z_channels");
     PrxVqgan* v = new PrxVqgan();
     std::unique_ptr<PrxVqgan> guard(v);
@@ -213,35 +218,35 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     PRX_LAUNCH_CHECK();
     if ((r = make_conv1(v, v->pq, embed_dim, z_channels, cur, s))) return r;
     int block_in = ch * ch_mult[n_mult - 1];
-    int res = h0;
+    int rh = h0, rw = w0;
     if ((r = make_conv3(v, v->conv_in, z_channels, block_in, cur, s))) return r;
-    if ((r = make_res(v, block_in, block_in, res, cur, s))) return r;
-    if ((r = make_attn(v, block_in, res, cur, s))) return r;
-    if ((r = make_res(v, block_in, block_in, res, cur, s))) return r;
+    if ((r = make_res(v, block_in, block_in, rh, rw, cur, s))) return r;
+    if ((r = make_attn(v, block_in, rh, rw, cur, s))) return r;
+    if ((r = make_res(v, block_in, block_in, rh, rw, cur, s))) return r;
     // taming decides AttnBlock placement from the config's NOMINAL resolution, not the actual latent size
     int nominal = resolution >> (n_mult - 1);
     for (int lvl = n_mult - 1; lvl >= 0; --lvl) {
         int block_out = ch * ch_mult[lvl];
         for (int b = 0; b < num_res_blocks + 1; ++b) {
-            if ((r = make_res(v, block_in, block_out, res, cur, s))) return r;
+            if ((r = make_res(v, block_in, block_out, rh, rw, cur, s))) return r;
             block_in = block_out;
-            if (nominal == attn_res) { if ((r = make_attn(v, block_in, res, cur, s))) return r; }
+            if (nominal == attn_res) { if ((r = make_attn(v, block_in, rh, rw, cur, s))) return r; }
         }
         if (lvl != 0) {
-            res *= 2; nominal *= 2;
-            if ((r = make_up(v, block_in, res, cur, s))) return r;
+            rh *= 2; rw *= 2; nominal *= 2;
+            if ((r = make_up(v, block_in, rh, rw, cur, s))) return r;
         }
     }
-    v->H = res; v->W = res;
+    v->H = rh; v->W = rw;
     if ((r = make_gn(v, v->norm_out, block_in, cur, s))) return r;
     if ((r = make_conv3(v, v->conv_out, block_in, out_ch, cur, s))) return r;
     PRX_REQUIRE(cur.pos == n_w, "vqgan_create: %d weight tensors given, %d consumed", n_w, cur.pos);
     // activations / scratch
-    const size_t P0 = (size_t)h0 * w0, PH = (size_t)res * res;
+    const size_t P0 = (size_t)h0 * w0, PH = (size_t)rh * rw;
     size_t maxPC = 0, maxAttnPC = 1;
-    for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.res * rb.res * std::max(rb.Cin, rb.Cout));
-    for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.res_out * ub.res_out * ub.C);
-    for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)ab.res * ab.res * (size_t)std::max(ab.C, ab.res * ab.res));
+    for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.rh * rb.rw * std::max(rb.Cin, rb.Cout));
+    for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.rh * ub.rw * ub.C);
+    for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)pad8(ab.rh * ab.rw) * (size_t)std::max(ab.C, pad8(ab.rh * ab.rw)));
     VALLOC(v->zq, P0 * embed_dim); VALLOC(v->pqo_bf, P0 * z_channels); VALLOC(v->dpq_bf, P0 * z_channels);
     VALLOC(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
     VALLOC(v->y, PH * 4); VALLOC(v->idx, P0);
@@ -263,9 +268,9 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
         if (i == 0) { slot = &v->h_in_bf; cnt = P0 * (size_t)(ch * ch_mult[n_mult - 1]); }
         else {
             const Stage& pr = v->stages[i - 1];
-            if (pr.kind == 0) { ResBlock& b = v->res[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res * b.res * b.Cout; }
-            else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res * b.res * b.C; }
-            else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.res_out * b.res_out * b.C; }
+            if (pr.kind == 0) { ResBlock& b = v->res[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.Cout; }
+            else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; }
+            else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; }
         }
         VALLOC(*slot, cnt);
     }
@@ -291,23 +296,31 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
 // the GEMM epilogue can accumulate the next GroupNorm's sums only for power-of-two group sizes >= 4 channels
 static bool fusable(int C) { const int gs = C / 32; return C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0; }
 
+// Token counts of the attention maps (P = h*w of the latent) are arbitrary (pixray sizes are multiples of 16 pixels, so
+// e.g. 25x14 = 350 tokens), but GEMM K dimensions and leading dimensions must be multiples of 8: every [*, P] operand is
+// laid out with a row pitch of P8 = round_up(P, 8) and zero columns beyond P.
+static int zero_if_padded(bf16_t* buf, size_t rows, int P, hipStream_t s) {
+    if (pad8(P) != P) PRX_CHECK_HIP(hipMemsetAsync(buf, 0, rows * (size_t)pad8(P) * sizeof(bf16_t), s));
+    return 0;
+}
+
 static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
 
-static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int res, bool up, const float* resid,
+static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const float* resid,
                      float* out, int ldc, hipStream_t s, bf16_t* out_bf = nullptr, const GN* stats_for = nullptr) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
-    d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = res * res; d.N = c.Cout; d.K = 9 * c.Cin;
-    d.H = res; d.W = res; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
+    d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = rh * rw; d.N = c.Cout; d.K = 9 * c.Cin;
+    d.H = rh; d.W = rw; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
     d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
     if (stats_for && stats_for->C == c.Cout && fusable(c.Cout)) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
-static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int res, float* dx, hipStream_t s,
+static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, float* dx, hipStream_t s,
                      bf16_t* dx_bf = nullptr) {
     GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
-    d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = res * res; d.N = c.Cin; d.K = 9 * c.CoP;
-    d.H = res; d.W = res; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
+    d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = rh * rw; d.N = c.Cin; d.K = 9 * c.CoP;
+    d.H = rh; d.W = rw; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
     d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
     return vg(v, d, s);
 }
@@ -350,7 +363,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
         if ((r = vg(v, d, s))) return r; }
     // `sr`: the statistics of the GroupNorm that consumes x next were already accumulated by x's producer
     const GN* nx = first_norm(v, 0);
-    if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
+    if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, v->w0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
     bool sr = nx && nx->C == v->conv_in.Cout && fusable(nx->C);
     float* x = v->h_in;
     bf16_t* x_bf = v->h_in_bf;   // bf16 twin of x (null when no GEMM reads x directly)
@@ -359,10 +372,10 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
         nx = first_norm(v, si + 1);
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
-            const int P = b.res * b.res;
+            const int P = b.rh * b.rw;
             b.x_in = x; b.x_in_bf = x_bf;
             if ((r = gn_fwd(v, b.n1, x, P, 1, s, sr))) return r;
-            if ((r = conv3_fwd(v, b.c1, v->a, false, b.res, false, nullptr, b.h1, b.Cout, s, nullptr, &b.n2))) return r;
+            if ((r = conv3_fwd(v, b.c1, v->a, false, b.rh, b.rw, false, nullptr, b.h1, b.Cout, s, nullptr, &b.n2))) return r;
             const float* resid = x;
             if (b.has_sc) {
                 PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the shortcut input");
@@ -372,23 +385,25 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 resid = b.scbuf;
             }
             if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, fusable(b.Cout)))) return r;
-            if ((r = conv3_fwd(v, b.c2, v->a, false, b.res, false, resid, b.out, b.Cout, s, b.out_bf, nx))) return r;
+            if ((r = conv3_fwd(v, b.c2, v->a, false, b.rh, b.rw, false, resid, b.out, b.Cout, s, b.out_bf, nx))) return r;
             sr = nx && nx->C == b.Cout && fusable(b.Cout);
             x = b.out; x_bf = b.out_bf;
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
-            const int P = b.res * b.res, C = b.C;
+            const int P = b.rh * b.rw, C = b.C;
             b.x_in = x;
             if ((r = gn_fwd(v, b.n, x, P, 0, s, sr))) return r;
             {   GemmDesc d; d.A = v->a; d.lda = C; d.B = b.qkv.W; d.ldb = C; d.M = P; d.N = 3 * C; d.K = C;
                 d.bias_n = b.qkv.b; d.out_bf16 = b.qkvb; d.ldc_bf16 = 3 * C;
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_bf16(b.qkvb + 2 * C, 3 * C, v->tA, P, P, C, s))) return r;   // tA = v^T [C, P]
+            const int P8 = pad8(P);
+            if ((r = zero_if_padded(v->tA, C, P, s))) return r;
+            if ((r = prx_transpose_bf16(b.qkvb + 2 * C, 3 * C, v->tA, P8, P, C, s))) return r;  // tA = v^T [C, P8]
             {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = b.qkvb + C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P, b.PT, P, P, P, s))) return r;
-            {   GemmDesc d; d.A = b.Pm; d.lda = P; d.B = v->tA; d.ldb = P; d.M = P; d.N = C; d.K = P;
+            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, s))) return r;
+            {   GemmDesc d; d.A = b.Pm; d.lda = P8; d.B = v->tA; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->tB; d.ldc_bf16 = C;
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
@@ -402,7 +417,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             UpBlock& b = v->ups[st.idx];
             b.x_in = x; b.x_in_bf = x_bf;
             PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the upsample input");
-            if ((r = conv3_fwd(v, b.c, x_bf, false, b.res_out, true, nullptr, b.out, b.C, s, b.out_bf, nx))) return r;
+            if ((r = conv3_fwd(v, b.c, x_bf, false, b.rh, b.rw, true, nullptr, b.out, b.C, s, b.out_bf, nx))) return r;
             sr = nx && nx->C == b.C && fusable(b.C);
             x = b.out; x_bf = b.out_bf;
         }
@@ -410,7 +425,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     v->x_last = x;
     const int PH = v->H * v->W;
     if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s, sr))) return r;
-    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, false, nullptr, v->y, 4, s))) return r;
+    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, v->W, false, nullptr, v->y, 4, s))) return r;
     return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
 }
 
@@ -423,9 +438,9 @@ long long prx_vqgan_debug_stage_impl(PrxVqgan* v, int stage, float* dst, long lo
     else if (stage == -1) { src = v->h_in; n = (long long)v->h0 * v->w0 * v->conv_in.Cout; }
     else if (stage >= 0 && stage < ns) {
         const Stage& st = v->stages[stage];
-        if (st.kind == 0) { const ResBlock& b = v->res[st.idx]; src = b.out; n = (long long)b.res * b.res * b.Cout; }
-        else if (st.kind == 1) { const AttnBlock& b = v->attn[st.idx]; src = b.out; n = (long long)b.res * b.res * b.C; }
-        else { const UpBlock& b = v->ups[st.idx]; src = b.out; n = (long long)b.res_out * b.res_out * b.C; }
+        if (st.kind == 0) { const ResBlock& b = v->res[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.Cout; }
+        else if (st.kind == 1) { const AttnBlock& b = v->attn[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.C; }
+        else { const UpBlock& b = v->ups[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.C; }
     } else if (stage == ns) { src = v->y; n = (long long)v->H * v->W * 4; }
     else if (stage == ns + 1) { src = reinterpret_cast<const float*>(v->all_stats); n = (long long)v->n_gn * 64 * 2; }
     else return -1;
@@ -443,16 +458,16 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
     struct GB { float* f; bf16_t* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
-    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, t1.f, s))) return r;
+    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s))) return r;
     if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s))) return r;
     for (int si = (int)v->stages.size() - 1; si >= 0; --si) {
         const Stage& st = v->stages[si];
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
-            const int P = b.res * b.res;
-            if ((r = conv3_bwd(v, b.c2, g.b, false, b.res, t1.f, s))) return r;                // d a2
+            const int P = b.rh * b.rw;
+            if ((r = conv3_bwd(v, b.c2, g.b, false, b.rh, b.rw, t1.f, s))) return r;                // d a2
             if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, t2.f, t2.b, P, 1, s))) return r;     // d h1
-            if ((r = conv3_bwd(v, b.c1, t2.b, false, b.res, t1.f, s))) return r;               // d a1
+            if ((r = conv3_bwd(v, b.c1, t2.b, false, b.rh, b.rw, t1.f, s))) return r;               // d a1
             const float* add = g.f;
             if (b.has_sc) {
                 GemmDesc d; d.A = g.b; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
@@ -466,24 +481,28 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             if (&dst != &g) std::swap(g, t2);
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
-            const int P = b.res * b.res, C = b.C;
+            const int P = b.rh * b.rw, C = b.C;
             {   GemmDesc d; d.A = g.b; d.lda = C; d.B = b.proj.WT; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.out_bf16 = v->tA; d.ldc_bf16 = C;                                      // tA = d o [P, C]
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tA; d.lda = C; d.B = b.qkvb + 2 * C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;                                         // dP = do v^T
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_softmax_rows_bwd(b.Pm, P, v->S, P, 1.f / sqrtf((float)C), v->tB, P, v->tC, P, P, P, s))) return r;  // tB = dS, tC = dS^T
-            if ((r = prx_transpose_bf16(b.qkvb + C, 3 * C, v->tD, P, P, C, s))) return r;        // tD = k^T [C, P]
-            {   GemmDesc d; d.A = v->tB; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+            const int P8 = pad8(P);
+            if ((r = zero_if_padded(v->tB, P, P, s))) return r;
+            if ((r = zero_if_padded(v->tC, P, P, s))) return r;
+            if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, s))) return r;  // tB = dS, tC = dS^T
+            if ((r = zero_if_padded(v->tD, C, P, s))) return r;
+            if ((r = prx_transpose_bf16(b.qkvb + C, 3 * C, v->tD, P8, P, C, s))) return r;       // tD = k^T [C, P8]
+            {   GemmDesc d; d.A = v->tB; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->dqkv; d.ldc_bf16 = 3 * C;                               // dq = dS k
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_bf16(b.qkvb, 3 * C, v->tD, P, P, C, s))) return r;            // tD = q^T
-            {   GemmDesc d; d.A = v->tC; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+            if ((r = prx_transpose_bf16(b.qkvb, 3 * C, v->tD, P8, P, C, s))) return r;           // tD = q^T (pad columns still zero)
+            {   GemmDesc d; d.A = v->tC; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->dqkv + C; d.ldc_bf16 = 3 * C;                           // dk = dS^T q
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_bf16(v->tA, C, v->tD, P, P, C, s))) return r;                 // tD = do^T
-            {   GemmDesc d; d.A = b.PT; d.lda = P; d.B = v->tD; d.ldb = P; d.M = P; d.N = C; d.K = P;
+            if ((r = prx_transpose_bf16(v->tA, C, v->tD, P8, P, C, s))) return r;                // tD = do^T
+            {   GemmDesc d; d.A = b.PT; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->dqkv + 2 * C; d.ldc_bf16 = 3 * C;                       // dv = P^T do
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
@@ -493,13 +512,13 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             std::swap(g, t2);
         } else {
             UpBlock& b = v->ups[st.idx];
-            if ((r = conv3_bwd(v, b.c, g.b, false, b.res_out, t1.f, s))) return r;       // d up(x) at high res
-            if ((r = prx_upsample2x_bwd(t1.f, t2.f, t2.b, 1, b.res_out / 2, b.res_out / 2, b.C, s))) return r;
+            if ((r = conv3_bwd(v, b.c, g.b, false, b.rh, b.rw, t1.f, s))) return r;       // d up(x) at high res
+            if ((r = prx_upsample2x_bwd(t1.f, t2.f, t2.b, 1, b.rh / 2, b.rw / 2, b.C, s))) return r;
             std::swap(g, t2);
         }
     }
     // conv_in, post_quant_conv, straight-through VQ (ReplaceGrad, vqgan.py:48-58)
-    if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, t1.f, s, v->dpq_bf))) return r;
+    if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, v->w0, t1.f, s, v->dpq_bf))) return r;
     const int P0 = v->h0 * v->w0;
     {   GemmDesc d; d.A = v->dpq_bf; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
         d.out_f32 = t2.f; d.ldc_f32 = v->D;

@@ -195,8 +195,9 @@ int prx_vqgan_enc_create_impl(PrxVqganEnc** out, int ch, const int* ch_mult, int
     EALLOC(e->img8, (size_t)H * W * 8);
     EALLOC(e->a, maxPC); EALLOC(e->xb0, maxPC); EALLOC(e->xb1, maxPC);
     EALLOC(e->x0, maxPC); EALLOC(e->x1, maxPC); EALLOC(e->h1, maxPC); EALLOC(e->sc, maxPC);
-    EALLOC(e->qkvb, maxP * 3 * maxAttnC); EALLOC(e->tA, maxP * maxAttnC); EALLOC(e->tB, maxP * maxAttnC);
-    EALLOC(e->Pm, maxP * maxP); EALLOC(e->PT, maxP * maxP); EALLOC(e->S, maxP * maxP);
+    const size_t maxP8 = (maxP + 7) & ~(size_t)7;
+    EALLOC(e->qkvb, maxP * 3 * maxAttnC); EALLOC(e->tA, maxP8 * maxAttnC); EALLOC(e->tB, maxP * maxAttnC);
+    EALLOC(e->Pm, maxP * maxP8); EALLOC(e->PT, maxP * maxP8); EALLOC(e->S, maxP * maxP);
     EALLOC(e->co_bf, P0 * z_channels); EALLOC(e->hq, P0 * embed_dim); EALLOC(e->zq, P0 * embed_dim); EALLOC(e->idx, P0);
     const int ntiles = ceil_div(n_embed, 64);
     EALLOC(e->pmin, P0 * ntiles); EALLOC(e->pidx, P0 * ntiles);
@@ -244,12 +245,17 @@ int prx_vqgan_encode_impl(PrxVqganEnc* e, const float* img, float* z, float* z_p
             {   GemmDesc d; d.A = e->a; d.lda = C; d.B = b.qkv.W; d.ldb = C; d.M = Pc; d.N = 3 * C; d.K = C;
                 d.bias_n = b.qkv.b; d.out_bf16 = e->qkvb; d.ldc_bf16 = 3 * C;
                 if ((r = eg(e, d, s))) return r; }
-            if ((r = prx_transpose_bf16(e->qkvb + 2 * C, 3 * C, e->tA, Pc, Pc, C, s))) return r;      // tA = v^T [C, P]
+            const int P8 = (Pc + 7) & ~7;            // [*, P] operands use a row pitch of round_up(P, 8) with zero pad columns
+            if (P8 != Pc) {
+                PRX_CHECK_HIP(hipMemsetAsync(e->tA, 0, sizeof(bf16_t) * (size_t)C * P8, s));
+                PRX_CHECK_HIP(hipMemsetAsync(e->Pm, 0, sizeof(bf16_t) * (size_t)Pc * P8, s));
+            }
+            if ((r = prx_transpose_bf16(e->qkvb + 2 * C, 3 * C, e->tA, P8, Pc, C, s))) return r;      // tA = v^T [C, P8]
             {   GemmDesc d; d.A = e->qkvb; d.lda = 3 * C; d.B = e->qkvb + C; d.ldb = 3 * C; d.M = Pc; d.N = Pc; d.K = C;
                 d.out_f32 = e->S; d.ldc_f32 = Pc;
                 if ((r = eg(e, d, s))) return r; }
-            if ((r = prx_softmax_rows(e->S, Pc, 1.f / sqrtf((float)C), e->Pm, Pc, e->PT, Pc, Pc, Pc, s))) return r;
-            {   GemmDesc d; d.A = e->Pm; d.lda = Pc; d.B = e->tA; d.ldb = Pc; d.M = Pc; d.N = C; d.K = Pc;
+            if ((r = prx_softmax_rows(e->S, Pc, 1.f / sqrtf((float)C), e->Pm, P8, e->PT, P8, Pc, Pc, s))) return r;
+            {   GemmDesc d; d.A = e->Pm; d.lda = P8; d.B = e->tA; d.ldb = P8; d.M = Pc; d.N = C; d.K = P8;
                 d.out_bf16 = e->tB; d.ldc_bf16 = C;
                 if ((r = eg(e, d, s))) return r; }
             {   GemmDesc d; d.A = e->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = Pc; d.N = C; d.K = C;

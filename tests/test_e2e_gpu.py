@@ -62,6 +62,15 @@ def test_reduced_config_one_iteration_vs_oracle():
     assert r["dz_rel_l2"] < 8e-2 and r["dz_cosine"] > 0.997, r
 
 
+def test_widescreen_one_iteration_vs_oracle():
+    """pixray's default aspect is widescreen: a non-square canvas through every stage (rectangular latent, decoder,
+    adaptive pooling of a W != H image into square cutouts)"""
+    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(112, 64), cutn=8, seed=3)
+    assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
+    assert r["image_rel_l2"] < 1e-2
+    assert r["dz_rel_l2"] < 8e-2 and r["dz_cosine"] > 0.997, r
+
+
 # ------------------------------------------------------------------------------------------- golden fixtures
 def test_prompt_kernel_vs_reference_golden():
     d = np.load(os.path.join(G, "prompt_golden.npz"))
