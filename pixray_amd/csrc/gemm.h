@@ -38,6 +38,16 @@ struct GemmDesc {
     // the conv output.  Needs the vector epilogue (N % 4 == 0, gn_gs % 4 == 0).
     double* gn_stats = nullptr;
     int gn_gs = 0;
+    // ... or, when gnb_x is set, the BACKWARD sums of the GroupNorm(+swish) whose output gradient this GEMM produces
+    // (batch 1: M pixels): with xhat = (gnb_x - mean) * rstd from gnb_fstats and dxhat = out * swish'(xhat*gamma+beta)
+    // * gamma, accumulate (sum dxhat, sum dxhat*xhat) per group into gn_stats -- saves the stats pass of the GroupNorm
+    // backward (8 bytes read per element) for 4 bytes read in this epilogue.
+    const float* gnb_x = nullptr;        // [M, N] fp32, the GroupNorm's forward input
+    const double* gnb_fstats = nullptr;  // its forward sums [32][2]
+    const float* gnb_gamma = nullptr;
+    const float* gnb_beta = nullptr;
+    int gnb_swish = 0;
+    float gnb_eps = 1e-6f;
 };
 
 // Launch on `stream`.  `ws` is a scratch buffer for split-K partials (may be

@@ -34,6 +34,40 @@ __device__ __forceinline__ float dquickgelu_f(float t) {
     return s * (1.f + 1.702f * t * (1.f - s));
 }
 
+// ---- fused GroupNorm-backward sums (GemmDesc::gnb_*) --------------------------------------------------------------
+struct GnbConst { float mean, rstd; float4 ga, be; };
+__device__ __forceinline__ GnbConst gnb_load(const GemmDesc& d, int col) {
+    GnbConst c;
+    const int g = col / d.gn_gs;
+    const double n = (double)d.M * d.gn_gs;
+    const double m = d.gnb_fstats[g * 2] / n;
+    double var = d.gnb_fstats[g * 2 + 1] / n - m * m;
+    if (var < 0) var = 0;
+    c.mean = (float)m;
+    c.rstd = (float)(1.0 / sqrt(var + (double)d.gnb_eps));
+    c.ga = *reinterpret_cast<const float4*>(d.gnb_gamma + col);
+    c.be = *reinterpret_cast<const float4*>(d.gnb_beta + col);
+    return c;
+}
+__device__ __forceinline__ void gnb_accum(const GemmDesc& d, const GnbConst& c, int row, int col, const float4& o, float& s0, float& s1) {
+    const float4 x = *reinterpret_cast<const float4*>(d.gnb_x + (size_t)row * d.N + col);
+    const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
+    const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - c.mean) * c.rstd;
+        float gy = gv[i];
+        if (d.gnb_swish) {
+            const float y = xh * gav[i] + bev[i];
+            const float sg = sigmoidf_(y);
+            gy *= sg * (1.f + y * (1.f - sg));
+        }
+        const float dxh = gy * gav[i];
+        s0 += dxh;
+        s1 += dxh * xh;
+    }
+}
+
 __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int col, float v) {
     v *= d.alpha;
     if (d.bias_n) v += d.bias_n[col];
@@ -522,6 +556,9 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         float gs0 = 0.f, gs1 = 0.f;
         const int rbase = tm * BM + wm * (BM / NWM);
         const int cbase = tn * BN + wn * (BN / 2);
+        const bool gnb = do_stats && d.gnb_x != nullptr;
+        GnbConst gc{};
+        if (gnb && cbase + (lane % LPR) * 4 < d.N) gc = gnb_load(d, cbase + (lane % LPR) * 4);   // this lane's column quad is fixed
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -541,8 +578,11 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                         *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
                     else {
                         const float4 o = epilogue_store4(d, row, col, v);
-                        gs0 += (o.x + o.y) + (o.z + o.w);
-                        gs1 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                        if (gnb) gnb_accum(d, gc, row, col, o, gs0, gs1);
+                        else {
+                            gs0 += (o.x + o.y) + (o.z + o.w);
+                            gs1 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                        }
                     }
                 }
             }
@@ -623,8 +663,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 const int row = (int)(idx / d.N);
                 col = (int)(idx - (size_t)row * d.N);
                 const float4 o = epilogue_store4(d, row, col, v);
-                s0 = (o.x + o.y) + (o.z + o.w);
-                s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                if (do_stats && d.gnb_x) gnb_accum(d, gnb_load(d, col), row, col, o, s0, s1);
+                else {
+                    s0 = (o.x + o.y) + (o.z + o.w);
+                    s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                }
             }
             if (do_stats) {
                 // lanes of one group are an aligned run (N and the block offset are multiples of gn_gs): fixed-order butterfly
@@ -817,6 +860,12 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative
     // on the implicit-conv shapes -> mode 2 (default) applies it to narrow row-major problems only
     a.xcd_swizzle = tiles >= 16 && (g_xcd_swizzle == 1 || (g_xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
+    if (d.gnb_x) {
+        PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
+                    "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");
+        PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
+                    "gemm: gnb operands must be 16-byte aligned");
+    }
     if (d.gn_stats) {
         PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && g_use_glds,
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");

@@ -7,7 +7,7 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
                       int stats_ready = 0);
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
-                      float eps, hipStream_t s, int zero_stats = 1);
+                      float eps, hipStream_t s, int zero_stats = 1, int stats_ready = 0);
 // LayerNorm on rows of width C.
 int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, bf16_t* out_bf16,
                       float* out_f32, float* mean, float* rstd, int rows, int C, float eps, hipStream_t s);

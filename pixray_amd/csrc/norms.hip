@@ -316,16 +316,18 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
 
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
-                      float eps, hipStream_t s, int zero_stats) {
+                      float eps, hipStream_t s, int zero_stats, int stats_ready) {
     PRX_REQUIRE(256 % (C / 4) == 0 && (C / 32) % 4 == 0, "groupnorm bwd: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.g = g; a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.stats = bstats;
     a.P = P; a.C = C; a.swish = swish; a.eps = eps;
-    if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(bstats, 0, sizeof(double) * NB * 64, s));
-    const int ppb = 256 / (C / 4);
-    int blocks = std::min(ceil_div(P, ppb * 4), 256);
-    hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(blocks, NB), dim3(256), 0, s, a);
-    PRX_LAUNCH_CHECK();
+    if (!stats_ready) {      // stats_ready: the GEMM that produced `g` already accumulated the sums in its epilogue (gemm.h gnb_*)
+        if (zero_stats) PRX_CHECK_HIP(hipMemsetAsync(bstats, 0, sizeof(double) * NB * 64, s));
+        const int ppb = 256 / (C / 4);
+        int blocks = std::min(ceil_div(P, ppb * 4), 256);
+        hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(blocks, NB), dim3(256), 0, s, a);
+        PRX_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,
                        dx_bf16, NB);
     PRX_LAUNCH_CHECK();

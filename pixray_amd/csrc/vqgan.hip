@@ -316,12 +316,20 @@ static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
+// `gnb` (+ its forward input gnb_x): the GroupNorm whose output gradient this dgrad produces -- its backward sums are
+// accumulated in the GEMM epilogue (gemm.h gnb_*), so gn_bwd can skip its statistics pass
+static void set_gnb(GemmDesc& d, const GN* gnb, const float* gnb_x, int swish) {
+    if (!gnb || !fusable(gnb->C) || d.N != gnb->C) return;
+    d.gn_stats = gnb->bstats; d.gn_gs = gnb->C / 32;
+    d.gnb_x = gnb_x; d.gnb_fstats = gnb->stats; d.gnb_gamma = gnb->g; d.gnb_beta = gnb->b; d.gnb_swish = swish; d.gnb_eps = 1e-6f;
+}
 static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, float* dx, hipStream_t s,
-                     bf16_t* dx_bf = nullptr) {
+                     bf16_t* dx_bf = nullptr, const GN* gnb = nullptr, const float* gnb_x = nullptr, int gnb_swish = 1) {
     GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
     d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = rh * rw; d.N = c.Cin; d.K = 9 * c.CoP;
     d.H = rh; d.W = rw; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
     d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
+    set_gnb(d, gnb, gnb_x, gnb_swish);
     return vg(v, d, s);
 }
 // first GroupNorm of stage `si` (whose statistics the producer of that stage's input can accumulate in its epilogue)
@@ -337,8 +345,9 @@ static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hi
                              stats_ready ? 1 : 0);
 }
 static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
-                  bf16_t* dx_bf, int P, int swish, hipStream_t s) {
-    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0);
+                  bf16_t* dx_bf, int P, int swish, hipStream_t s, bool stats_ready = false) {
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0,
+                             stats_ready && fusable(g.C) ? 1 : 0);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -458,16 +467,16 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
     struct GB { float* f; bf16_t* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
-    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s))) return r;
-    if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s))) return r;
+    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
+    if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s, true))) return r;
     for (int si = (int)v->stages.size() - 1; si >= 0; --si) {
         const Stage& st = v->stages[si];
         if (st.kind == 0) {
             ResBlock& b = v->res[st.idx];
             const int P = b.rh * b.rw;
-            if ((r = conv3_bwd(v, b.c2, g.b, false, b.rh, b.rw, t1.f, s))) return r;                // d a2
-            if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, t2.f, t2.b, P, 1, s))) return r;     // d h1
-            if ((r = conv3_bwd(v, b.c1, t2.b, false, b.rh, b.rw, t1.f, s))) return r;               // d a1
+            if ((r = conv3_bwd(v, b.c2, g.b, false, b.rh, b.rw, t1.f, s, nullptr, &b.n2, b.h1, 1))) return r;     // d a2
+            if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, t2.f, t2.b, P, 1, s, true))) return r;            // d h1
+            if ((r = conv3_bwd(v, b.c1, t2.b, false, b.rh, b.rw, t1.f, s, nullptr, &b.n1, b.x_in, 1))) return r;   // d a1
             const float* add = g.f;
             if (b.has_sc) {
                 GemmDesc d; d.A = g.b; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
@@ -477,7 +486,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             }
             // dx = GN1_bwd(d a1) + shortcut grad ; written into a buffer that is neither `add` nor `t1`
             GB& dst = (add == g.f) ? t2 : g;
-            if ((r = gn_bwd(v, b.n1, t1.f, b.x_in, add, dst.f, dst.b, P, 1, s))) return r;
+            if ((r = gn_bwd(v, b.n1, t1.f, b.x_in, add, dst.f, dst.b, P, 1, s, true))) return r;
             if (&dst != &g) std::swap(g, t2);
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
@@ -507,8 +516,9 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
                 d.out_f32 = t1.f; d.ldc_f32 = C;                                         // d GN(x)
+                set_gnb(d, &b.n, b.x_in, 0);
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = gn_bwd(v, b.n, t1.f, b.x_in, g.f, t2.f, t2.b, P, 0, s))) return r;
+            if ((r = gn_bwd(v, b.n, t1.f, b.x_in, g.f, t2.f, t2.b, P, 0, s, true))) return r;
             std::swap(g, t2);
         } else {
             UpBlock& b = v->ups[st.idx];
