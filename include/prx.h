@@ -50,6 +50,8 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
 #define PRX_ACT_NONE 0
 #define PRX_ACT_QUICKGELU 1      /* CLIP QuickGELU, x*sigmoid(1.702x)  [UPSTREAM clip/model.py] */
 #define PRX_ACT_MUL_DQUICKGELU 2 /* multiply by QuickGELU'(aux) (backward) */
+#define PRX_ACT_RELU 3           /* max(v, 0) after bias / residual (CLIP ModifiedResNet [UPSTREAM clip/model.py]) */
+#define PRX_ACT_MUL_RELUMASK 4   /* multiply by (aux > 0): ReLU backward, aux = the forward output */
 #define PRX_A_ROWMAJOR 0
 #define PRX_A_CONV3X3 1          /* implicit im2col of an NHWC tensor, 3x3 pad 1 */
 
@@ -220,6 +222,33 @@ int prx_clip_vit_backward_reduce(prx_clip_vit* h, const float* cutouts, const fl
                                  double* acc, prx_stream_t s);
 int prx_clip_vit_backward_finish(prx_clip_vit* h, const float* cutouts, const float* mm, const double* acc,
                                  float* g_cutouts, prx_stream_t s);
+
+/* --- CLIP_Base.encode_image for a ModifiedResNet visual tower (RN50x4, RN50, ...) [UPSTREAM clip/model.py: ModifiedResNet,
+ *     Bottleneck, AttentionPool2d].  Same call sequence and min/max contract as the ViT entry points above.
+ * weights[]: fp32 device tensors with the eval-mode BatchNorms folded into their convolutions on the host
+ *   (pixray_amd/weights.py::fold_clip_resnet_params, from the `visual.*` state dict):
+ *   stem conv1 {weight [w/2,3,3,3], bias}, stem conv2 {weight, bias}, stem conv3 {weight, bias};
+ *   per Bottleneck: conv1 {weight [planes,in,1,1], bias}, conv2 {weight [planes,planes,3,3], bias}, conv3 {weight
+ *   [4*planes,planes,1,1], bias} [, downsample {weight [4*planes,in,1,1], bias}];
+ *   attnpool.positional_embedding [(R/32)^2+1, 32w], in_proj {weight [3*32w, 32w] = q|k|v, bias}, c_proj {weight, bias}. */
+typedef struct prx_clip_resnet prx_clip_resnet;
+typedef struct prx_clip_resnet_config {
+    int input_resolution;  /* 288 (RN50x4) */
+    int width;             /* 80 */
+    int layers[4];         /* {4, 6, 10, 6} */
+    int heads;             /* 40 = width * 32 / 64 */
+    int output_dim;        /* 640 */
+    int max_batch;
+} prx_clip_resnet_config;
+int prx_clip_resnet_create(prx_clip_resnet** out, const prx_clip_resnet_config* cfg, const float* const* weights, int n_weights,
+                           prx_stream_t s);
+void prx_clip_resnet_destroy(prx_clip_resnet* h);
+int prx_clip_resnet_minmax(prx_clip_resnet* h, const float* cutouts, int n, float* mm, prx_stream_t s);
+int prx_clip_resnet_encode(prx_clip_resnet* h, const float* cutouts, int n, const float* mm, float* embeds, prx_stream_t s);
+int prx_clip_resnet_backward_reduce(prx_clip_resnet* h, const float* cutouts, const float* mm, const float* d_embeds,
+                                    double* acc, prx_stream_t s);
+int prx_clip_resnet_backward_finish(prx_clip_resnet* h, const float* cutouts, const float* mm, const double* acc,
+                                    float* g_cutouts, prx_stream_t s);
 
 /* --- CLIP_Base.encode_text (slip.py:68-70) = openai/CLIP `CLIP.encode_text` [UPSTREAM clip/model.py] on token ids:
  *     token_embedding[tokens] + positional_embedding -> causal transformer -> ln_final -> row at argmax(tokens) (the EOT

@@ -51,31 +51,39 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     drawer.load_model(settings, dev)
     drawer.init_from_tensor(None if init_image is None else init_image.to(dev) * 2 - 1)
     per_rank = num_cuts // world_size
-    perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group, tokenizer=tokenizer,
-                                   text_params=clip_text_params)
-    mk = MakeCutouts(perceptor.input_resolution, num_cuts, generator=torch.Generator().manual_seed(1000 + seed))
-    pms = []
-    for prompt in prompts:                                                              # pixray.py:859-877
-        txt, weight, stop = parse_prompt(prompt)
-        pms.append(Prompt(perceptor.encode_text(txt).float(), weight, stop).to(dev))
-    for vp in vector_prompts:                                                           # pixray.py:879-915
-        path, weight, stop = parse_prompt(vp)
-        with open(path) as f:
-            table = json.load(f)
-        if clip_model not in table:
-            print(f"WARNING: no vector for {clip_model} in {path}!")
-            continue
-        pms.append(Prompt(torch.tensor(table[clip_model], dtype=torch.float32), 0.1 * weight, stop).to(dev))
-    if prompt_embeds is None and not pms:
-        prompt_embeds = seeded_unit_vectors(1, perceptor.output_dim, seed + 2)
-    if prompt_embeds is not None:
-        pms.insert(0, Prompt(prompt_embeds.to(dev), prompt_weight, float("-inf")).to(dev))
-    for (emb, w, stop) in extra_prompts:
-        pms.append(Prompt(emb.to(dev), w, stop).to(dev))
-    return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, {clip_model: pms},
+    clip_models = [clip_model] if isinstance(clip_model, str) else list(clip_model)      # an ensemble shares one decoder pass
+    perceptors, cutouts, pms_table = {}, {}, {}
+    for mi, name in enumerate(clip_models):
+        perceptor = get_clip_perceptor(name, dev, max_batch=per_rank, seed=seed + 1 + 10 * mi, group=group, tokenizer=tokenizer,
+                                       text_params=clip_text_params)
+        perceptors[name] = perceptor
+        if perceptor.input_resolution not in cutouts:                                   # pixray.py:643-649: one table per size
+            cutouts[perceptor.input_resolution] = MakeCutouts(perceptor.input_resolution, num_cuts,
+                                                              generator=torch.Generator().manual_seed(1000 + seed + mi))
+        pms = []
+        for prompt in prompts:                                                              # pixray.py:859-877
+            txt, weight, stop = parse_prompt(prompt)
+            pms.append(Prompt(perceptor.encode_text(txt).float(), weight, stop).to(dev))
+        for vp in vector_prompts:                                                           # pixray.py:879-915
+            path, weight, stop = parse_prompt(vp)
+            with open(path) as f:
+                table = json.load(f)
+            if name not in table:
+                print(f"WARNING: no vector for {name} in {path}!")
+                continue
+            pms.append(Prompt(torch.tensor(table[name], dtype=torch.float32), 0.1 * weight, stop).to(dev))
+        pe = prompt_embeds[name] if isinstance(prompt_embeds, dict) else (prompt_embeds if mi == 0 else None)
+        if pe is None and not pms:
+            pe = seeded_unit_vectors(1, perceptor.output_dim, seed + 2 + mi)
+        if pe is not None:
+            pms.insert(0, Prompt(pe.to(dev), prompt_weight, float("-inf")).to(dev))
+        for (emb, w, stop) in (extra_prompts if mi == 0 else ()):
+            pms.append(Prompt(emb.to(dev), w, stop).to(dev))
+        pms_table[name] = pms
+    return Session(drawer, perceptors, cutouts, pms_table,
                    learning_rate=learning_rate, iterations=iterations, custom_losses=custom_losses, filters=filters,
                    seed=seed, group=group, rank=rank, world_size=world_size, learning_rate_drops=learning_rate_drops,
-                   image_prompts={clip_model: [t.to(dev).float() for t in image_prompts]} if len(image_prompts) else None,
+                   image_prompts={name: [t.to(dev).float() for t in image_prompts] for name in clip_models} if len(image_prompts) else None,
                    image_prompt_weight=image_prompt_weight, image_prompt_shuffle=image_prompt_shuffle,
                    init_weight=init_weight, init_weight_dist=init_weight_dist, init_weight_pix=init_weight_pix,
                    init_weight_cos=init_weight_cos, z_orig=drawer.get_z_copy().detach() if init_image is not None else None,

@@ -4,6 +4,7 @@
 #include "vqgan.h"
 #include "vqgan_enc.h"
 #include "clip_text.h"
+#include "resnet.h"
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "elementwise.h"
@@ -141,5 +142,31 @@ void prx_clip_text_destroy(prx_clip_text* h) { prx_clip_text_destroy_impl((PrxCl
 int prx_clip_text_encode(prx_clip_text* h, const int* tokens, int n, float* embeds, prx_stream_t s) {
     PRX_REQUIRE(h && tokens && embeds, "prx_clip_text_encode: null argument");
     return prx_clip_text_encode_impl((PrxClipText*)h, tokens, n, embeds, S_(s));
+}
+// ---- CLIP ModifiedResNet tower -----------------------------------------------------------------
+int prx_clip_resnet_create(prx_clip_resnet** out, const prx_clip_resnet_config* c, const float* const* weights, int n_weights,
+                           prx_stream_t s) {
+    PRX_REQUIRE(out && c && weights, "prx_clip_resnet_create: null argument");
+    return prx_resnet_create_impl((PrxResNet**)out, c->input_resolution, c->width, c->layers, c->heads, c->output_dim,
+                                  c->max_batch, weights, n_weights, S_(s));
+}
+void prx_clip_resnet_destroy(prx_clip_resnet* h) { prx_resnet_destroy_impl((PrxResNet*)h); }
+int prx_clip_resnet_minmax(prx_clip_resnet* h, const float* cutouts, int n, float* mm, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm, "prx_clip_resnet_minmax: null argument");
+    return prx_resnet_minmax_impl((PrxResNet*)h, cutouts, n, mm, S_(s));
+}
+int prx_clip_resnet_encode(prx_clip_resnet* h, const float* cutouts, int n, const float* mm, float* embeds, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && embeds, "prx_clip_resnet_encode: null argument");
+    return prx_resnet_forward_impl((PrxResNet*)h, cutouts, n, mm, embeds, S_(s));
+}
+int prx_clip_resnet_backward_reduce(prx_clip_resnet* h, const float* cutouts, const float* mm, const float* d_embeds,
+                                    double* acc, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && d_embeds && acc, "prx_clip_resnet_backward_reduce: null argument");
+    return prx_resnet_backward_a_impl((PrxResNet*)h, cutouts, mm, d_embeds, acc, S_(s));
+}
+int prx_clip_resnet_backward_finish(prx_clip_resnet* h, const float* cutouts, const float* mm, const double* acc,
+                                    float* g_cutouts, prx_stream_t s) {
+    PRX_REQUIRE(h && cutouts && mm && acc && g_cutouts, "prx_clip_resnet_backward_finish: null argument");
+    return prx_resnet_backward_b_impl((PrxResNet*)h, cutouts, mm, acc, g_cutouts, S_(s));
 }
 }  // extern "C"

@@ -14,3 +14,7 @@ int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, 
                             hipStream_t s);
 int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, const double* acc, float* gcut, int N,
                            int S, int P, int T, hipStream_t s);
+// gradient through slip.py:21-42 (batch-global min/max renorm + mean/std) for an image-layout gradient dY[N][3][S][S]
+int prx_preproc_bwd_reduce(const float* cut, const float* mm, const float* dY, double* acc, int N, int S, hipStream_t s);
+int prx_preproc_bwd_apply(const float* cut, const float* mm, const float* dY, const double* acc, float* gcut, int N, int S,
+                          hipStream_t s);

@@ -715,3 +715,23 @@ int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, c
     PRX_LAUNCH_CHECK();
     return 0;
 }
+
+// The same two passes for a gradient held in IMAGE layout dY[N][3][S][S] (CLIP ModifiedResNet: the stem convolution
+// consumes the normalised image directly): the patch kernels with one "patch" = the whole image (P = S, one token per
+// image); their token index is 1-based, hence the pointer shifted back by one row of K = 3*S*S.
+int prx_preproc_bwd_reduce(const float* cut, const float* mm, const float* dY, double* acc, int N, int S, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
+    const int K = 3 * S * S;
+    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 512)), dim3(256), 0, s,
+                       cut, mm, dY - K, acc, N, S, S, 1, K);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_preproc_bwd_apply(const float* cut, const float* mm, const float* dY, const double* acc, float* gcut, int N, int S,
+                          hipStream_t s) {
+    const int K = 3 * S * S;
+    hipLaunchKernelGGL(patchify_bwd_apply_kernel, dim3(ew_grid((size_t)N * 3 * S * S)), dim3(256), 0, s, cut, mm, dY - K, acc,
+                       gcut, N, S, S, 1, K);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}

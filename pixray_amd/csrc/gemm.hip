@@ -76,7 +76,9 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
         float t = bf16_to_f32(d.aux[(size_t)row * d.ldaux + col]);
         v *= dquickgelu_f(t);
     }
+    if (d.act == PRX_ACT_MUL_RELUMASK && !(bf16_to_f32(d.aux[(size_t)row * d.ldaux + col]) > 0.f)) v = 0.f;
     if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
+    if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
         bf16_t pre = f32_to_bf16(v);
         if (d.out_bf16_pre) d.out_bf16_pre[(size_t)row * d.ldc_bf16 + col] = pre;
@@ -99,10 +101,18 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
         v.x *= dquickgelu_f((float)t[0]); v.y *= dquickgelu_f((float)t[1]);
         v.z *= dquickgelu_f((float)t[2]); v.w *= dquickgelu_f((float)t[3]);
     }
+    if (d.act == PRX_ACT_MUL_RELUMASK) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(d.aux + (size_t)row * d.ldaux + col);
+        if (!((float)t[0] > 0.f)) v.x = 0.f;
+        if (!((float)t[1] > 0.f)) v.y = 0.f;
+        if (!((float)t[2] > 0.f)) v.z = 0.f;
+        if (!((float)t[3] > 0.f)) v.w = 0.f;
+    }
     if (d.resid) {
         const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
+    if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (d.act == PRX_ACT_QUICKGELU) {
         bf16x4 pre;
         pre[0] = (bf16_t)v.x; pre[1] = (bf16_t)v.y; pre[2] = (bf16_t)v.z; pre[3] = (bf16_t)v.w;
@@ -810,7 +820,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         PRX_REQUIRE(d.up != 2 || (d.Cin % BK == 0 && !d.a_is_f32 && g_use_glds && g_conv_c64),
                     "gemm/conv: the stride-2 gather needs a bf16 operand with Cin %% 64 == 0 (Cin=%d)", d.Cin);
     }
-    PRX_REQUIRE(d.act != PRX_ACT_MUL_DQUICKGELU || d.aux, "gemm: MUL_DQUICKGELU needs aux");
+    PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK) || d.aux, "gemm: MUL_DQUICKGELU / MUL_RELUMASK need aux");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
     // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the

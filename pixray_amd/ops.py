@@ -75,6 +75,7 @@ def make_cutouts(img, desc, noise, S):
 # --------------------------------------------------------------------------------------- CLIP ViT
 class ClipVitHandle:
     """Owns a `prx_clip_vit` (packed bf16 weights + activation workspace for `max_batch` cutouts)."""
+    abi = "prx_clip_vit"
 
     def __init__(self, cfg, params, max_batch: int, device):
         from .weights import clip_vit_param_shapes
@@ -104,6 +105,42 @@ def _keep(obj, arr):
     return ctypes.addressof(arr)
 
 
+class _ClipResNetCfg(ctypes.Structure):
+    _fields_ = [("input_resolution", ctypes.c_int), ("width", ctypes.c_int), ("layers", ctypes.c_int * 4), ("heads", ctypes.c_int),
+                ("output_dim", ctypes.c_int), ("max_batch", ctypes.c_int)]
+
+
+class ClipResNetHandle:
+    """Owns a `prx_clip_resnet` (CLIP ModifiedResNet tower: RN50x4, ...); same protocol as ClipVitHandle.  `params` is
+    the OpenAI `visual.*` state dict (BatchNorm un-folded); the fold happens here."""
+    abi = "prx_clip_resnet"
+
+    def __init__(self, cfg, params, max_batch: int, device):
+        from .weights import fold_clip_resnet_params
+        folded = fold_clip_resnet_params(cfg, params)
+        ws = [t.to(device=device, dtype=torch.float32).contiguous() for t in folded.values()]
+        c = _ClipResNetCfg()
+        c.input_resolution, c.width, c.heads, c.output_dim, c.max_batch = cfg.input_resolution, cfg.width, cfg.heads, cfg.output_dim, max_batch
+        for i, l in enumerate(cfg.layers):
+            c.layers[i] = l
+        h = ctypes.c_void_p()
+        call("prx_clip_resnet_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
+        torch.cuda.synchronize(device)
+        self.h = h
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_clip_resnet_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
 class _ClipCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("input_resolution", "patch_size", "width", "layers", "heads",
                                             "output_dim", "max_batch")]
@@ -126,7 +163,7 @@ class _ClipEncodeFn(torch.autograd.Function):
         assert cutouts.shape[1:] == (3, R, R), f"perceptor expects [n,3,{R},{R}] cutouts"
         dev = cutouts.device
         mm = torch.empty(2, device=dev)
-        call("prx_clip_vit_minmax", handle.h, cutouts, n, mm, _stream())
+        call(handle.abi + "_minmax", handle.h, cutouts, n, mm, _stream())
         if group is not None:
             # batch-global renorm couples every cutout (slip.py:21-36): min/max over all ranks
             import torch.distributed as dist
@@ -134,7 +171,7 @@ class _ClipEncodeFn(torch.autograd.Function):
             dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
             mm[0].neg_()
         emb = torch.empty(n, handle.cfg.output_dim, device=dev)
-        call("prx_clip_vit_encode", handle.h, cutouts, n, mm, emb, _stream())
+        call(handle.abi + "_encode", handle.h, cutouts, n, mm, emb, _stream())
         ctx.save_for_backward(cutouts, mm)
         ctx.handle = handle
         ctx.group = group
@@ -147,12 +184,12 @@ class _ClipEncodeFn(torch.autograd.Function):
         g = g.contiguous().float()
         dev = g.device
         acc = torch.empty(4, device=dev, dtype=torch.float64)
-        call("prx_clip_vit_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
+        call(handle.abi + "_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
         if ctx.group is not None:
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=ctx.group)
         gc = torch.empty_like(cutouts)
-        call("prx_clip_vit_backward_finish", handle.h, cutouts, mm, acc, gc, _stream())
+        call(handle.abi + "_backward_finish", handle.h, cutouts, mm, acc, gc, _stream())
         return gc, None, None
 
 

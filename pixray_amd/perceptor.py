@@ -5,7 +5,7 @@ CLIP ViT runner (pixray_amd/csrc/vit.hip) and the HIP text tower (pixray_amd/csr
 import torch
 
 from . import ops
-from .weights import (CLIP_CONFIGS, CLIP_TEXT_CONFIGS, ClipTextConfig, ClipVitConfig, clip_text_param_shapes,
+from .weights import (CLIP_CONFIGS, CLIP_RESNET_CONFIGS, CLIP_TEXT_CONFIGS, ClipResNetConfig, synthetic_clip_resnet_params, ClipTextConfig, ClipVitConfig, clip_text_param_shapes,
                       synthetic_clip_text_params, synthetic_clip_vit_params)
 
 
@@ -22,7 +22,10 @@ class ClipVitPerceptor:
         self.input_resolution = cfg.input_resolution
         self.output_dim = cfg.output_dim
         self.group = group          # torch.distributed group when the cutout batch is sharded
-        self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device)
+        if isinstance(cfg, ClipResNetConfig):       # ModifiedResNet family (RN50x4, ...): same protocol, different runner
+            self.handle = ops.ClipResNetHandle(cfg, params, max_batch, self.device)
+        else:
+            self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device)
 
     def preprocess(self, imgs, input_range=None):
         raise NotImplementedError("preprocessing (slip.py:21-42,58-60) is fused into encode_image on this path")
@@ -77,8 +80,15 @@ def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=
     """slip.py:173-186 equivalent for the ViT family; `params` is an OpenAI `visual.*` state dict and `text_params` the
     text-side entries of the same checkpoint (random-init weights of the real architectures are synthesised when none
     are given: no checkpoints exist offline)."""
+    if clip_model_name in CLIP_RESNET_CONFIGS:
+        cfg = CLIP_RESNET_CONFIGS[clip_model_name]
+        if params is None:
+            params = synthetic_clip_resnet_params(cfg, seed)
+        return ClipVitPerceptor(cfg, params, device, max_batch=max_batch, group=group, text_cfg=CLIP_TEXT_CONFIGS.get(clip_model_name),
+                                text_params=text_params, tokenizer=tokenizer, seed=seed)
     if clip_model_name not in CLIP_CONFIGS:
-        raise KeyError(f"unknown / unsupported perceptor {clip_model_name!r} (supported: {sorted(CLIP_CONFIGS)})")
+        raise KeyError(f"unknown / unsupported perceptor {clip_model_name!r} "
+                       f"(supported: {sorted(CLIP_CONFIGS) + sorted(CLIP_RESNET_CONFIGS)})")
     cfg = CLIP_CONFIGS[clip_model_name]
     if params is None:
         params = synthetic_clip_vit_params(cfg, seed)

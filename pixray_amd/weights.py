@@ -288,6 +288,8 @@ CLIP_TEXT_CONFIGS = {
     "ViT-B/16": ClipTextConfig("ViT-B/16"),
     "ViT-L/14": ClipTextConfig("ViT-L/14", width=768, heads=12, output_dim=768),
     "tiny-B/32": ClipTextConfig("tiny-B/32", vocab_size=1000, context_length=77, width=256, layers=2, heads=4, output_dim=128),
+    "RN50x4": ClipTextConfig("RN50x4", width=640, heads=10, output_dim=640),
+    "RN50": ClipTextConfig("RN50", width=512, heads=8, output_dim=1024),
 }
 
 
@@ -336,4 +338,122 @@ def synthetic_clip_text_params(cfg: ClipTextConfig, seed: int = 0) -> "OrderedDi
         else:                                # biases / LayerNorm beta
             t = 0.02 * torch.randn(shape, generator=g)
         out[name] = t
+    return out
+
+
+# --------------------------------------------------------------------------- CLIP ModifiedResNet config (RN50x4, ...)
+@dataclass
+class ClipResNetConfig:
+    name: str = "RN50x4"
+    input_resolution: int = 288
+    width: int = 80
+    layers: Tuple[int, ...] = (4, 6, 10, 6)
+    heads: int = 40                 # width * 32 // 64
+    output_dim: int = 640
+
+    @property
+    def embed_dim(self) -> int:     # channels entering the attention pool
+        return self.width * 32
+
+    @property
+    def final_grid(self) -> int:
+        return self.input_resolution // 32
+
+
+CLIP_RESNET_CONFIGS = {
+    "RN50x4": ClipResNetConfig(),
+    "RN50": ClipResNetConfig("RN50", 224, 64, (3, 4, 6, 3), 32, 1024),
+    # reduced tower with the same operator mix (stem, stride-1 and stride-2 bottlenecks, attention pool)
+    "tiny-RN": ClipResNetConfig("tiny-RN", 96, 16, (1, 2, 1, 1), 8, 64),
+}
+
+
+def clip_resnet_param_shapes(cfg: ClipResNetConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """OpenAI `visual.*` state-dict names of a ModifiedResNet (prefix stripped), in definition order."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    w = cfg.width
+
+    def bn(name, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            sh[f"{name}.{k}"] = (c,)
+
+    sh["conv1.weight"] = (w // 2, 3, 3, 3); bn("bn1", w // 2)
+    sh["conv2.weight"] = (w // 2, w // 2, 3, 3); bn("bn2", w // 2)
+    sh["conv3.weight"] = (w, w // 2, 3, 3); bn("bn3", w)
+    inplanes = w
+    for li, nblocks in enumerate(cfg.layers):
+        planes = w * 2 ** li
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            pre = f"layer{li + 1}.{b}"
+            sh[pre + ".conv1.weight"] = (planes, inplanes, 1, 1); bn(pre + ".bn1", planes)
+            sh[pre + ".conv2.weight"] = (planes, planes, 3, 3); bn(pre + ".bn2", planes)
+            sh[pre + ".conv3.weight"] = (planes * 4, planes, 1, 1); bn(pre + ".bn3", planes * 4)
+            if stride > 1 or inplanes != planes * 4:
+                sh[pre + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1); bn(pre + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    C = cfg.embed_dim
+    sh["attnpool.positional_embedding"] = (cfg.final_grid ** 2 + 1, C)
+    for n_ in ("k_proj", "q_proj", "v_proj"):
+        sh[f"attnpool.{n_}.weight"] = (C, C); sh[f"attnpool.{n_}.bias"] = (C,)
+    sh["attnpool.c_proj.weight"] = (cfg.output_dim, C); sh["attnpool.c_proj.bias"] = (cfg.output_dim,)
+    return sh
+
+
+def synthetic_clip_resnet_params(cfg: ClipResNetConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded random weights; BatchNorm running statistics are non-trivial so that the fold is exercised."""
+    g = torch.Generator().manual_seed(seed + 31337)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in clip_resnet_param_shapes(cfg).items():
+        if name.endswith("running_mean"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith("running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif ".bn" in name or name.startswith("bn") or "downsample.1" in name:
+            t = (1.0 + 0.1 * torch.randn(shape, generator=g)) if name.endswith("weight") else 0.05 * torch.randn(shape, generator=g)
+            if name.endswith("bn3.weight") and name.startswith("layer"):
+                t = t * 0.5                        # keep the residual stream O(1)
+        elif name == "attnpool.positional_embedding":
+            t = torch.randn(shape, generator=g) * (shape[1] ** -0.5)
+        elif name.endswith(".bias"):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        else:
+            t = torch.randn(shape, generator=g) * (shape[1] ** -0.5)
+        out[name] = t
+    return out
+
+
+def fold_clip_resnet_params(cfg: ClipResNetConfig, p) -> "OrderedDict[str, torch.Tensor]":
+    """Frozen eval-mode BatchNorm folded into the preceding bias-free conv (w' = w * gamma / sqrt(var + eps), b' = beta -
+    mean * gamma / sqrt(var + eps)); q/k/v projections of the attention pool concatenated.  Order = what
+    prx_clip_resnet_create expects (include/prx.h)."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def fold(conv, bn, key):
+        w = p[conv + ".weight"].double()
+        s = p[bn + ".weight"].double() / torch.sqrt(p[bn + ".running_var"].double() + 1e-5)
+        out[key + ".weight"] = (w * s.view(-1, 1, 1, 1)).float()
+        out[key + ".bias"] = (p[bn + ".bias"].double() - p[bn + ".running_mean"].double() * s).float()
+
+    fold("conv1", "bn1", "stem1"); fold("conv2", "bn2", "stem2"); fold("conv3", "bn3", "stem3")
+    inplanes = cfg.width
+    for li, nblocks in enumerate(cfg.layers):
+        planes = cfg.width * 2 ** li
+        for b in range(nblocks):
+            stride = 2 if (li > 0 and b == 0) else 1
+            pre = f"layer{li + 1}.{b}"
+            fold(pre + ".conv1", pre + ".bn1", pre + ".c1")
+            fold(pre + ".conv2", pre + ".bn2", pre + ".c2")
+            fold(pre + ".conv3", pre + ".bn3", pre + ".c3")
+            if stride > 1 or inplanes != planes * 4:
+                fold(pre + ".downsample.0", pre + ".downsample.1", pre + ".ds")
+            inplanes = planes * 4
+    out["attnpool.positional_embedding"] = p["attnpool.positional_embedding"].float()
+    out["attnpool.in_proj_weight"] = torch.cat([p[f"attnpool.{n_}.weight"] for n_ in ("q_proj", "k_proj", "v_proj")], 0).float()
+    out["attnpool.in_proj_bias"] = torch.cat([p[f"attnpool.{n_}.bias"] for n_ in ("q_proj", "k_proj", "v_proj")], 0).float()
+    out["attnpool.c_proj.weight"] = p["attnpool.c_proj.weight"].float()
+    out["attnpool.c_proj.bias"] = p["attnpool.c_proj.bias"].float()
     return out

@@ -372,3 +372,20 @@ def test_two_perceptors_share_one_decoder_pass():
     assert rel(grads["AB"], g_sum) < 6e-2
     a, b = grads["AB"].flatten(), g_sum.flatten()
     assert float(a @ b / (a.norm() * b.norm())) > 0.998
+
+
+def test_config2_vqgan512_vitb16_rn50x4_ensemble_runs():
+    """BASELINE.json configs[2] at a reduced cutout count: VQGAN 512x512 + the ViT-B/16 / RN50x4 perceptor ensemble
+    (224- and 288-pixel cutout tables hanging off one decoder pass), a few optimisation steps"""
+    sess = api.build_vqgan_clip_session(size=(512, 512), vqgan_model="imagenet_f16_16384", clip_model=["ViT-B/16", "RN50x4"],
+                                        num_cuts=8, seed=5)
+    assert sorted(sess.cutoutsTable) == [224, 288] and sess.drawer.get_z().shape == (1, 256, 32, 32)
+    z0 = sess.drawer.get_z_copy()
+    first = None
+    for it in range(3):
+        assert sess.train(it)
+        assert len(sess.last_losses) == 2 and all(torch.isfinite(l) for l in sess.last_losses)
+        if first is None:
+            first = [float(l.detach()) for l in sess.last_losses]
+    assert not torch.equal(sess.drawer.get_z(), z0)
+    assert torch.isfinite(sess.drawer.get_z()).all()
