@@ -174,6 +174,7 @@ def test_cutout_shards_reproduce_the_unsharded_gradient():
     # the same batch in two slices with the global-mean denominator; min/max agree because both slices see the same
     # extreme pixels only if they are in the slice -- so feed the full-batch statistics by encoding the full batch's
     # cutouts slice-by-slice through a handle that was given the full-batch min/max
+    mk.transforms = None              # a new "iteration": without this the call would take the cached-transform path
     cuts = mk(img).detach()
     mm = torch.stack([cuts.min(), cuts.max()])
     acc_total = torch.zeros(4, dtype=torch.float64, device=DEV)
@@ -197,6 +198,7 @@ def test_cutout_shards_reproduce_the_unsharded_gradient():
         call("prx_clip_vit_backward_finish", hs[r].h, locals_[r], mm, acc_total, gc, ops._stream())
         gcuts.append(gc)
     x2 = img.clone().requires_grad_(True)
+    mk.transforms = None
     mk(x2).backward(torch.cat(gcuts))
     assert rel(x2.grad, g_full) < 2e-3, rel(x2.grad, g_full)
 

@@ -96,6 +96,7 @@ def test_make_cutouts_shard_matches_full():
     parts = []
     for r in range(4):
         mk.shard = (r * 4, r * 4 + 4)
+        mk.transforms = None          # each rank's call is the first of its iteration (else: cached-transform path)
         parts.append(mk(img))
     assert torch.equal(torch.cat(parts), full)
 
