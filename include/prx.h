@@ -181,15 +181,19 @@ int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre,
  *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill),
  *   [20] fill gray, [21] jitter on/off, [22] saturation factor, [23] hue shift (rad), [24] saturation-first,
  *   [25] noise factor, [26]/[27] stage-A/B grid flavour (0 = create_meshgrid + transform_points as in
- *   kornia warp_perspective, 1 = F.affine_grid as in kornia warp_affine).
- * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/stage_a are caller-owned save-for-backward
- * buffers ([3,S,S] f32, [3,S,S] i32, [n_cut,3,S,S] f32). */
-int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S,
-                        float* pooled, int* argmax, float* stage_a, float* out, prx_stream_t s);
-/* scratch: g_stage_a and g_pooled_priv are [n_cut,3,S,S] fp32 each, g_pooled is [3,S,S] */
-int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int H, int W, const float* stage_a,
-                         const int* argmax, float* g_stage_a, float* g_pooled_priv, float* g_pooled, float* g_img,
-                         prx_stream_t s);
+ *   kornia warp_perspective, 1 = F.affine_grid as in kornia warp_affine),
+ *   [28..31] stage-B source window (x, y, width, height) inside the stage-A image.
+ * Geometry: the canvas is pooled to [3,S,S] (pixray.py:463); on a W != H canvas the reference rescales that to the
+ * canvas aspect (pixray.py:468-472): the "base" image [3,Hb,Wb] with Hb == S or Wb == S (Hb = Wb = S on a square
+ * canvas, `base` may then be NULL).  Stage A renders [n_cut,3,Hb,Wb] from the base, stage B the S x S cutouts.
+ * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/base/stage_a are caller-owned save-for-backward
+ * buffers ([3,S,S] f32, [3,S,S] i32, [3,Hb,Wb] f32, [n_cut,3,Hb,Wb] f32). */
+int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S, int Hb, int Wb,
+                        float* pooled, int* argmax, float* base, float* stage_a, float* out, prx_stream_t s);
+/* scratch: g_stage_a and g_base_priv are [n_cut,3,Hb,Wb] fp32 each, g_base is [3,Hb,Wb], g_pooled is [3,S,S] */
+int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int Hb, int Wb, int H, int W,
+                         const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base,
+                         float* g_pooled, float* g_img, prx_stream_t s);
 
 /* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].
  * weights[]: fp32 device tensors in OpenAI state-dict order under `visual.`:

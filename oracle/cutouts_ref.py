@@ -181,30 +181,65 @@ def pooled_image(img, S):
     return (F.adaptive_avg_pool2d(img, (S, S)) + F.adaptive_max_pool2d(img, (S, S))) / 2
 
 
-def _persp_matrix(rand, dscale, S):
+def _persp_matrix(rand, dscale, S, W=None):
+    """kornia random_perspective_generator on an S x W image (W defaults to S): corner i moves inwards by
+    rand * distortion_scale * (W/2, S/2)"""
+    W = S if W is None else W
     B = rand.shape[0]
-    start = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
+    start = torch.tensor([[0.0, 0.0], [W - 1.0, 0.0], [W - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
     start = start[None].expand(B, 4, 2)
-    fx = dscale * S / 2
+    f = torch.tensor([dscale * W / 2, dscale * S / 2], dtype=torch.float64)
     pts_norm = torch.tensor([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]], dtype=torch.float64)
-    end = start + fx * rand.double() * pts_norm[None]
+    end = start + f * rand.double() * pts_norm[None]
     return get_perspective_transform(start, end)
+
+
+def base_size(S, aspect):
+    """size of the pooled cutout after the aspect rescale (pixray.py:468-472; kornia rescale -> int(size * factor))"""
+    if aspect == 1:
+        return S, S
+    return (S, int(S * aspect)) if aspect > 1 else (int(S * (1 / aspect)), S)
+
+
+def base_image(img, S, aspect):
+    """pooled cutout (pixray.py:463), rescaled to the canvas aspect when it is not square (pixray.py:468-472:
+    kornia.geometry.transform.rescale = bilinear F.interpolate, align_corners=False)"""
+    base = pooled_image(img, S)
+    Hb, Wb = base_size(S, aspect)
+    if (Hb, Wb) != (S, S):
+        base = F.interpolate(base, size=(Hb, Wb), mode="bilinear", align_corners=False)
+    return base
+
+
+def _wide_affine(prm, nw, Hb, Wb):
+    """MyRandomAffine (pixray.py:420-431): isotropic scale about the image centre (w/2 - 0.5, h/2 - 0.5) + translation"""
+    sc = prm["w_scale"].double() if "w_scale" in prm else torch.full((nw,), 0.95, dtype=torch.float64)
+    cx, cy = Wb / 2.0 - 0.5, Hb / 2.0 - 0.5
+    Ma = torch.zeros(nw, 3, 3, dtype=torch.float64)
+    Ma[:, 0, 0] = sc
+    Ma[:, 1, 1] = sc
+    Ma[:, 2, 2] = 1.0
+    Ma[:, 0, 2] = (1 - sc) * cx + prm["w_trans"][:, 0].double()
+    Ma[:, 1, 2] = (1 - sc) * cy + prm["w_trans"][:, 1].double()
+    return Ma
 
 
 def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     """MakeCutouts.forward(img[1,3,H,W]) -> [cutn,3,S,S] with explicit randomness `prm`
-    (see pixray_amd.cutouts.sample_cutout_params for the fields)."""
+    (see pixray_amd.cutouts.sample_cutout_params for the fields; prm["aspect"] = canvas width / height)."""
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)                                   # pixray.py:407
     nw = cutn - nz
-    base = pooled_image(img, S)                            # pixray.py:463
+    aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
+    base = base_image(img, S, aspect)                      # pixray.py:463-472
+    Hb, Wb = base.shape[-2:]
     pad_mode = "reflection" if int(prm["reflect"]) else "border"   # pixray.py:1250-1253
     fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)   # pixray.py:1255-1258
     outs = []
     if nz > 0:
         x = base.expand(nz, -1, -1, -1)
-        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, S)
-        warped = warp_perspective(x, Mp, (S, S), pad_mode, align_corners=False)
+        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, Hb, Wb)
+        warped = warp_perspective(x, Mp, (Hb, Wb), pad_mode, align_corners=False)
         x = torch.where(prm["z_persp_apply"].view(-1, 1, 1, 1), warped, x)
         xs, ys, w, h = [prm["z_crop"][:, i].double() for i in range(4)]
         src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
@@ -216,15 +251,12 @@ def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> tor
         outs.append(x)
     if nw > 0:
         x = base.expand(nw, -1, -1, -1)
-        s = 0.95
-        c = S / 2.0 - 0.5
-        Ma = torch.zeros(nw, 2, 3, dtype=torch.float64)
-        Ma[:, 0, 0] = s
-        Ma[:, 1, 1] = s
-        Ma[:, 0, 2] = (1 - s) * c + prm["w_trans"][:, 0].double()
-        Ma[:, 1, 2] = (1 - s) * c + prm["w_trans"][:, 1].double()
-        x = warp_affine(x, Ma, (S, S), "fill", align_corners=False, fill_value=fill)
-        # CenterCrop(S) of an SxS image with align_corners=True is the identity resampling.
+        Ma = _wide_affine(prm, nw, Hb, Wb)
+        x = warp_affine(x, Ma[:, :2, :], (Hb, Wb), "fill", align_corners=False, fill_value=fill)
+        # CenterCrop(S) (pixray.py:433): the centred S x S window (an exact copy for integer offsets; kornia resamples at
+        # half pixels when (Wb - S) is odd, which this restatement floors)
+        oy, ox = (Hb - S) // 2, (Wb - S) // 2
+        x = x[:, :, oy:oy + S, ox:ox + S]
         Mp = _persp_matrix(prm["w_persp_rand"], 0.2, S)
         warped = warp_perspective(x, Mp, (S, S), "fill", align_corners=False, fill_value=fill)
         x = torch.where(prm["w_persp_apply"].view(-1, 1, 1, 1), warped, x)
@@ -238,15 +270,17 @@ def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> tor
 
 # ---- cached-transform path (pixray.py:480-486) ------------------------------------------------
 def composed_transforms(prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
-    """`self.transforms` (pixray.py:498): kornia's composed pixel-space 3x3 (source -> output) of the two geometric
-    augmentations of each cutout, identity for a stage whose apply-mask is off.  [cutn,3,3] float64."""
+    """`self.transforms` (pixray.py:498): kornia's composed pixel-space 3x3 (aspect-rescaled cutout -> output) of the
+    geometric augmentations of each cutout, identity for a stage whose apply-mask is off.  [cutn,3,3] float64."""
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)
     nw = cutn - nz
+    aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
+    Hb, Wb = base_size(S, aspect)
     eye = torch.eye(3, dtype=torch.float64)
     out = []
     if nz > 0:
-        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, S)
+        Mp = _persp_matrix(prm["z_persp_rand"], 0.4, Hb, Wb)
         Mp = torch.where(prm["z_persp_apply"].view(-1, 1, 1), Mp, eye[None].expand(nz, 3, 3))
         xs, ys, w, h = [prm["z_crop"][:, i].double() for i in range(4)]
         src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
@@ -256,28 +290,26 @@ def composed_transforms(prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         Mc[:, 2, :] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)          # the crop is applied as an affine map
         out.append(Mc @ Mp)
     if nw > 0:
-        s = 0.95
-        c = S / 2.0 - 0.5
-        Ma = eye[None].repeat(nw, 1, 1)
-        Ma[:, 0, 0] = s
-        Ma[:, 1, 1] = s
-        Ma[:, 0, 2] = (1 - s) * c + prm["w_trans"][:, 0].double()
-        Ma[:, 1, 2] = (1 - s) * c + prm["w_trans"][:, 1].double()
+        Ma = _wide_affine(prm, nw, Hb, Wb)
+        crop = eye[None].repeat(nw, 1, 1)                                          # CenterCrop: shift by the window origin
+        crop[:, 0, 2] = -float((Wb - S) // 2)
+        crop[:, 1, 2] = -float((Hb - S) // 2)
         Mp = _persp_matrix(prm["w_persp_rand"], 0.2, S)
         Mp = torch.where(prm["w_persp_apply"].view(-1, 1, 1), Mp, eye[None].expand(nw, 3, 3))
-        out.append(Mp @ Ma)
+        out.append(Mp @ crop @ Ma)
     return torch.cat(out, dim=0)
 
 
 def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None) -> torch.Tensor:
     """MakeCutouts.forward when `.transforms` is cached (pixray.py:480-486; image prompts, pixray.py:1318-1333): ONE
-    `kornia.warp_perspective(pooled, T, (S,S), padding_mode=...)` per set -- kornia 0.6.2's default align_corners=True
+    `kornia.warp_perspective(cutout, T, (S,S), padding_mode=...)` per set -- kornia 0.6.2's default align_corners=True
     [UPSTREAM, from knowledge: parity unpinned], zoom set with the iteration's reflection/border padding, wide set filled
     with the iteration's gray -- no ColorJitter, then fresh noise."""
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)
+    aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
     T = composed_transforms(prm, S)
-    base = pooled_image(img, S)
+    base = base_image(img, S, aspect)
     pad_mode = "reflection" if int(prm["reflect"]) else "border"
     fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)
     outs = []

@@ -130,10 +130,10 @@ def _oracle_inputs(vqgan_model, clip_model, seed):
     return vq_cfg, clip_cfg, vq_params, clip_params
 
 
-def _draws(cutn, S, seed, iteration, with_noise=True):
+def _draws(cutn, S, seed, iteration, with_noise=True, aspect=1.0):
     from pixray_amd import cutouts as pc
     g = torch.Generator().manual_seed(5000 + 17 * seed + iteration)
-    prm = pc.sample_cutout_params(cutn, S, g, iteration=iteration)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=iteration, aspect=aspect)
     if with_noise:
         prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
     return prm
@@ -146,7 +146,7 @@ def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device)
     vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
     S = clip_cfg.input_resolution
-    prm = _draws(cutn, S, seed, 0)
+    prm = _draws(cutn, S, seed, 0, aspect=size[0] / size[1])      # pixray.py:1931: global_aspect_width
     mk = sess.cutoutsTable[S]
     mk.fixed_params = prm
     z0 = sess.drawer.get_z().detach().cpu().clone()
@@ -188,7 +188,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
     dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free = [], [], [], [], [], []
     for it in range(k):
-        prm = _draws(cutn, S, seed, it)
+        prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
         mk.fixed_params = prm
         mk_free.fixed_params = prm
         # ---- HIP side, started from the oracle's state -------------------------------------------------------------
@@ -242,7 +242,7 @@ def time_oracle_iterations(n_iters=3, warmup=1, vqgan_model="imagenet_f16_16384"
     times = []
     for it in range(warmup + n_iters):
         t0 = time.perf_counter()
-        prm = _draws(cutn, S, seed, it)
+        prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
         opt.zero_grad()
         losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, [(emb_p, 1.0, float("-inf"))], S)
         sum(losses).backward()

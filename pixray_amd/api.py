@@ -59,7 +59,8 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
         perceptors[name] = perceptor
         if perceptor.input_resolution not in cutouts:                                   # pixray.py:643-649: one table per size
             cutouts[perceptor.input_resolution] = MakeCutouts(perceptor.input_resolution, num_cuts,
-                                                              generator=torch.Generator().manual_seed(1000 + seed + mi))
+                                                              generator=torch.Generator().manual_seed(1000 + seed + mi),
+                                                              aspect_width=size[0] / size[1])     # pixray.py:1931
         pms = []
         for prompt in prompts:                                                              # pixray.py:859-877
             txt, weight, stop = parse_prompt(prompt)

@@ -3,11 +3,16 @@
 #define PRX_CUT_DESC_WORDS 32
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s);
 int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s);
-int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int S, hipStream_t s);
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int S,
+// stage A renders Ha x Wa images from the shared Hs x Ws source; stage B reads them through the descriptor's window
+int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int Ha, int Wa, hipStream_t s);
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,
                    hipStream_t s);
-int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s);
-int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s);
+int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const float* noise, float* out, int n_cut, int S,
+                   hipStream_t s);
+int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s);
+// bilinear resize of the pooled [C,S,S] image to the canvas aspect [C,Hb,Wb] (pixray.py:468-472) and its gradient
+int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int Wb, hipStream_t s);
+int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s);
 int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hipStream_t s);
 int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S, int P, int T, hipStream_t s);
 int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,

@@ -23,7 +23,8 @@ constexpr int DESC_WORDS = 32;
 // descriptor word offsets (all stored as fp64; the two 3x3 matrices map NORMALISED destination coordinates to
 // NORMALISED source coordinates exactly as kornia builds them, so sampling positions round like the oracle's)
 enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
-       D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27 };
+       D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27,
+       D_WOX = 28, D_WOY = 29, D_WW = 30, D_WH = 31 };   // stage-B source window inside the stage-A image (x, y, width, height)
 enum { GRID_MESH = 0, GRID_AFFINE = 1 };
 enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4,
        MODE_REFLECT_AC = 5 };   // reflection as F.grid_sample does it with align_corners=True (the cached-transform path)
@@ -117,6 +118,14 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int W, int H, int mo
     return t;
 }
 
+// the tap set of an exact copy of pixel (x, y): weight 1 on the north-west tap, the other three masked off
+__device__ __forceinline__ Taps ident_taps(int x, int y) {
+    Taps t;
+    t.x0 = x; t.y0 = y; t.wx = 0.f; t.wy = 0.f;
+    t.vx0 = true; t.vy0 = true; t.vx1 = false; t.vy1 = false;
+    return t;
+}
+
 // torch.linspace(-1, 1, n) in fp32 (ATen's symmetric two-sided formula)
 __device__ __forceinline__ float linspace_pm1(int i, int n) {
     const float step = 2.f / (float)(n - 1);
@@ -163,6 +172,13 @@ __device__ __forceinline__ float coverage(const Taps& t) {
     if (t.vx0 && t.vy1) c += (1.f - t.wx) * t.wy;
     if (t.vx1 && t.vy1) c += t.wx * t.wy;
     return c;
+}
+// gray fill of the uncovered part of the bilinear footprint (kornia's `padding_mode="fill"`: zeros padding + (1 - warp(ones)) * fill).
+// Branch-free on purpose: hipcc miscompiled the `mode == MODE_FILL ? ... : 0` form of this inside warp_b_fwd_kernel (the
+// divergent select clobbered live tap-pointer registers; MODE_ZEROS was fine, MODE_FILL returned garbage).
+__device__ __forceinline__ float fill_term(const Taps& t, int mode, const double* d) {
+    const float fillv = (mode == MODE_FILL) ? (float)d[D_FILL] : 0.f;
+    return (1.f - coverage(t)) * fillv;
 }
 __device__ __forceinline__ void scatter_plane(float* __restrict__ p, int W, const Taps& t, float g) {
     if (t.vx0 && t.vy0) atomicAdd(&p[t.y0 * W + t.x0], g * (1.f - t.wx) * (1.f - t.wy));
@@ -291,28 +307,31 @@ __device__ __forceinline__ void jitter_d(Dual<ND> (&rgb)[3], float sat, float hu
 }
 
 // ------------------------------------------------------------------ warp stages
-// Stage A: out[n][c][y][x] from the shared source src[c][Hs][Ws]
+// Stage A: out[n][c][y][x] (Ha x Wa) from the shared source src[c][Hs][Ws].  On a square canvas all three sizes are S x S;
+// on a W != H canvas (pixray.py:468-472) the source is the pooled image rescaled to the canvas aspect and stage A keeps
+// that size.
 __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict__ src, int Hs, int Ws,
                                                          const double* __restrict__ desc, float* __restrict__ out,
-                                                         int n_cut, int S) {
-    const size_t total = (size_t)n_cut * S * S;
+                                                         int n_cut, int Ha, int Wa) {
+    const size_t plane = (size_t)Ha * Wa;
+    const size_t total = (size_t)n_cut * plane;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / ((size_t)S * S));
+        const int x = (int)(idx % Wa), y = (int)((idx / Wa) % Ha), n = (int)(idx / plane);
         const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE1];
-        float* o = out + ((size_t)n * 3) * S * S + (size_t)y * S + x;
+        float* o = out + ((size_t)n * 3) * plane + (size_t)y * Wa + x;
         if (mode == MODE_IDENT) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o[(size_t)c * S * S] = src[(size_t)c * Hs * Ws + (size_t)y * Ws + x];
+            for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = src[(size_t)c * Hs * Ws + (size_t)y * Ws + x];
             continue;
         }
         float u, v;
-        project(d + D_M1, (int)d[D_GRID1], x, y, S, S, Ws, Hs, u, v);
+        project(d + D_M1, (int)d[D_GRID1], x, y, Wa, Ha, Ws, Hs, u, v);
         Taps t = make_taps(u, v, Ws, Hs, mode);
-        const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
+        const float fillc = fill_term(t, mode, d);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[(size_t)c * S * S] = sample_plane(src + (size_t)c * Hs * Ws, Ws, t) + fillc;
+        for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = sample_plane(src + (size_t)c * Hs * Ws, Ws, t) + fillc;
     }
 }
 
@@ -351,8 +370,8 @@ __device__ __forceinline__ void win_scatter(ScatterWin& w, float* __restrict__ p
     if (t.vx0 && t.vy1) win_add(w, plane, W, c, t.x0, t.y0 + 1, g * (1.f - t.wx) * t.wy);
     if (t.vx1 && t.vy1) win_add(w, plane, W, c, t.x0 + 1, t.y0 + 1, g * t.wx * t.wy);
 }
-// flush the window into the 3 planes at `base` (plane stride Hs*Ws)
-__device__ __forceinline__ void win_flush(ScatterWin& w, float* __restrict__ base, int Hs, int Ws) {
+// flush the window into the 3 planes at `base` (a Hs x Ws image with row pitch `pitch` and plane stride `pstride`)
+__device__ __forceinline__ void win_flush(ScatterWin& w, float* __restrict__ base, int Hs, int Ws, int pitch, size_t pstride) {
     __syncthreads();
     const int ox = w.org[0], oy = w.org[1];
     if (ox == 0x7fffffff) return;
@@ -361,44 +380,45 @@ __device__ __forceinline__ void win_flush(ScatterWin& w, float* __restrict__ bas
         if (v == 0.f) continue;
         const int c = i / (WIN * WIN), r = (i / WIN) % WIN, q = i % WIN;
         const int x = ox + q, y = oy + r;
-        if (x < Ws && y < Hs) atomicAdd(&base[(size_t)c * Hs * Ws + (size_t)y * Ws + x], v);
+        if (x < Ws && y < Hs) atomicAdd(&base[(size_t)c * pstride + (size_t)y * pitch + x], v);
     }
 }
 
-// Stage A backward: g[n][3][S][S] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws]
+// Stage A backward: g[n][3][Ha][Wa] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws]
 // (summed over n afterwards by reduce_planes_kernel: no cross-cutout atomic contention on the shared image)
 __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
                                                          const double* __restrict__ desc, float* __restrict__ gsrc,
-                                                         int n_cut, int S) {
+                                                         int n_cut, int Ha, int Wa) {
     __shared__ ScatterWin w;
-    const int tiles = (S + TILE_W - 1) / TILE_W;
+    const int tiles = (Wa + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
     const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
     const int y = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
-    const bool valid = x < S && y < S;
+    const bool valid = x < Wa && y < Ha;
+    const size_t plane = (size_t)Ha * Wa;
     const double* d = desc + (size_t)n * DESC_WORDS;
     const int mode = (int)d[D_MODE1];
     float* gs = gsrc + (size_t)n * 3 * Hs * Ws;
-    const float* gi = g + ((size_t)n * 3) * S * S + (size_t)y * S + x;
+    const float* gi = g + ((size_t)n * 3) * plane + (size_t)y * Wa + x;
     if (mode == MODE_IDENT) {      // 1:1 copy: each source pixel has exactly one writer
         if (valid) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gs[(size_t)c * Hs * Ws + (size_t)y * Ws + x] = gi[(size_t)c * S * S];
+            for (int c = 0; c < 3; ++c) gs[(size_t)c * Hs * Ws + (size_t)y * Ws + x] = gi[(size_t)c * plane];
         }
         return;
     }
     Taps t{};
     if (valid) {
         float u, v;
-        project(d + D_M1, (int)d[D_GRID1], x, y, S, S, Ws, Hs, u, v);
+        project(d + D_M1, (int)d[D_GRID1], x, y, Wa, Ha, Ws, Hs, u, v);
         t = make_taps(u, v, Ws, Hs, mode);
     }
     win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
     if (valid) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) win_scatter(w, gs + (size_t)c * Hs * Ws, Ws, c, t, gi[(size_t)c * S * S]);
+        for (int c = 0; c < 3; ++c) win_scatter(w, gs + (size_t)c * Hs * Ws, Ws, c, t, gi[(size_t)c * plane]);
     }
-    win_flush(w, gs, Hs, Ws);
+    win_flush(w, gs, Hs, Ws, Ws, (size_t)Hs * Ws);
 }
 
 // out[i] = sum_n planes[n][i]
@@ -411,30 +431,38 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
     }
 }
 
-// Stage B (+ ColorJitter + noise): out[n] from a[n] (per-cutout source, same S x S geometry)
-__global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, const double* __restrict__ desc,
+// Stage B (+ ColorJitter + noise): out[n] (S x S) from this cutout's stage-A image a[n] (Ha x Wa), read through the
+// descriptor's source window (x0, y0, w, h): the whole image on a square canvas and for the zoom set; for the wide set
+// on a W != H canvas the centred S x S crop the reference takes (CenterCrop, pixray.py:433) -- out-of-window taps are
+// out-of-image taps, exactly as if the crop had been materialised.
+struct SrcWin { int ox, oy, ww, wh; };
+__device__ __forceinline__ SrcWin src_window(const double* d) {
+    SrcWin q; q.ox = (int)d[D_WOX]; q.oy = (int)d[D_WOY]; q.ww = (int)d[D_WW]; q.wh = (int)d[D_WH];
+    return q;
+}
+
+__global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, int Ha, int Wa, const double* __restrict__ desc,
                                                          const float* __restrict__ noise, float* __restrict__ out,
                                                          int n_cut, int S) {
     const size_t total = (size_t)n_cut * S * S;
-    const size_t plane = (size_t)S * S;
+    const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % S), y = (int)((idx / S) % S), n = (int)(idx / plane);
         const double* d = desc + (size_t)n * DESC_WORDS;
         const int mode = (int)d[D_MODE2];
-        const float* an = a + (size_t)n * 3 * plane;
+        const SrcWin q = src_window(d);
+        const float* an = a + (size_t)n * 3 * aplane + (size_t)q.oy * Wa + q.ox;     // window origin
         const size_t pix = (size_t)y * S + x;
         Dual<0> rgb[3];
-        if (mode == MODE_IDENT) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c].v = an[c * plane + pix];
-        } else {
+        Taps t = ident_taps(x, y);                 // MODE_IDENT: one tap of weight 1 (same code path, no divergent select)
+        if (mode != MODE_IDENT) {
             float u, v;
-            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, S, S, u, v);
-            Taps t = make_taps(u, v, S, S, mode);
-            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c].v = sample_plane(an + c * plane, S, t) + fillc;
+            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, q.ww, q.wh, u, v);
+            t = make_taps(u, v, q.ww, q.wh, mode);
         }
+        const float fillc = fill_term(t, mode, d);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c].v = sample_plane(an + c * aplane, Wa, t) + fillc;
         if (d[D_JIT] != 0.0) jitter_d<0>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
         const float nf = (float)d[D_NOISE];
         float* o = out + (size_t)n * 3 * plane + pix;
@@ -447,11 +475,11 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, const double* __restrict__ desc,
+__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, int Ha, int Wa, const double* __restrict__ desc,
                                                          const float* __restrict__ g, float* __restrict__ ga, int n_cut,
                                                          int S) {
     __shared__ ScatterWin w;
-    const size_t plane = (size_t)S * S;
+    const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     const int tiles = (S + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
     const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
@@ -459,10 +487,11 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict
     const bool valid = x < S && y < S;
     const double* d = desc + (size_t)n * DESC_WORDS;
     const int mode = (int)d[D_MODE2];
-    const float* an = a + (size_t)n * 3 * plane;
-    float* gan = ga + (size_t)n * 3 * plane;
+    const SrcWin q = src_window(d);
+    const float* an = a + (size_t)n * 3 * aplane + (size_t)q.oy * Wa + q.ox;
+    float* gan = ga + (size_t)n * 3 * aplane + (size_t)q.oy * Wa + q.ox;
     const size_t pix = (size_t)y * S + x;
-    Taps t{};
+    Taps t = ident_taps(valid ? x : 0, valid ? y : 0);
     float grgb[3] = {0.f, 0.f, 0.f};
     if (valid) {
         float gin[3];
@@ -471,15 +500,15 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict
         grgb[0] = gin[0]; grgb[1] = gin[1]; grgb[2] = gin[2];
         if (mode != MODE_IDENT) {
             float u, v;
-            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, S, S, u, v);
-            t = make_taps(u, v, S, S, mode);
+            project(d + D_M2, (int)d[D_GRID2], x, y, S, S, q.ww, q.wh, u, v);
+            t = make_taps(u, v, q.ww, q.wh, mode);
         }
         if (d[D_JIT] != 0.0) {
             Dual<3> rgb[3];
-            const float fillc = (mode == MODE_FILL) ? (1.f - coverage(t)) * (float)d[D_FILL] : 0.f;
+            const float fillc = fill_term(t, mode, d);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                rgb[c] = cst<3>(mode == MODE_IDENT ? an[c * plane + pix] : sample_plane(an + c * plane, S, t) + fillc);
+                rgb[c] = cst<3>(sample_plane(an + c * aplane, Wa, t) + fillc);
                 rgb[c].d[c] = 1.f;
             }
             jitter_d<3>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
@@ -487,19 +516,51 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict
             for (int i = 0; i < 3; ++i) grgb[i] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
         }
     }
-    if (mode == MODE_IDENT) {      // 1:1: one writer per source pixel
+    if (mode == MODE_IDENT) {      // 1:1: one writer per source pixel (the rest of the stage-A gradient stays zero)
         if (valid) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gan[c * plane + pix] = grgb[c];
+            for (int c = 0; c < 3; ++c) gan[c * aplane + (size_t)y * Wa + x] = grgb[c];
         }
         return;
     }
     win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
     if (valid) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) win_scatter(w, gan + c * plane, S, c, t, grgb[c]);
+        for (int c = 0; c < 3; ++c) win_scatter(w, gan + c * aplane, Wa, c, t, grgb[c]);
     }
-    win_flush(w, gan, S, S);
+    win_flush(w, gan, q.wh, q.ww, Wa, aplane);
+}
+
+// F.interpolate(bilinear, align_corners=False) of the pooled image [C,S,S] to the canvas aspect [C,Hb,Wb]
+// (kornia.geometry.transform.rescale, pixray.py:468-472) and its gradient
+__device__ __forceinline__ void resize_taps(int o, int in, int outn, int& i0, int& i1, float& w1) {
+    float src = ((float)o + 0.5f) * ((float)in / (float)outn) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void rescale_fwd_kernel(const float* __restrict__ p, float* __restrict__ out, int C, int S, int Hb, int Wb) {
+    const size_t total = (size_t)C * Hb * Wb;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wb), y = (int)((idx / Wb) % Hb), c = (int)(idx / ((size_t)Hb * Wb));
+        int x0, x1, y0, y1; float wx, wy;
+        resize_taps(x, S, Wb, x0, x1, wx); resize_taps(y, S, Hb, y0, y1, wy);
+        const float* q = p + (size_t)c * S * S;
+        out[idx] = (1.f - wy) * ((1.f - wx) * q[y0 * S + x0] + wx * q[y0 * S + x1]) + wy * ((1.f - wx) * q[y1 * S + x0] + wx * q[y1 * S + x1]);
+    }
+}
+__global__ __launch_bounds__(256) void rescale_bwd_kernel(const float* __restrict__ g, float* __restrict__ gp, int C, int S, int Hb, int Wb) {
+    const size_t total = (size_t)C * Hb * Wb;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wb), y = (int)((idx / Wb) % Hb), c = (int)(idx / ((size_t)Hb * Wb));
+        int x0, x1, y0, y1; float wx, wy;
+        resize_taps(x, S, Wb, x0, x1, wx); resize_taps(y, S, Hb, y0, y1, wy);
+        float* q = gp + (size_t)c * S * S;
+        const float v = g[idx];
+        atomicAdd(&q[y0 * S + x0], v * (1.f - wy) * (1.f - wx)); atomicAdd(&q[y0 * S + x1], v * (1.f - wy) * wx);
+        atomicAdd(&q[y1 * S + x0], v * wy * (1.f - wx)); atomicAdd(&q[y1 * S + x1], v * wy * wx);
+    }
 }
 
 // ------------------------------------------------------------------ batch min/max + CLIP normalise + patchify
@@ -653,34 +714,46 @@ int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, i
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int S, hipStream_t s) {
-    hipLaunchKernelGGL(warp_a_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, src, Hs, Ws, desc, out,
-                       n_cut, S);
+int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int Ha, int Wa, hipStream_t s) {
+    hipLaunchKernelGGL(warp_a_fwd_kernel, dim3(ew_grid((size_t)n_cut * Ha * Wa)), dim3(256), 0, s, src, Hs, Ws, desc, out,
+                       n_cut, Ha, Wa);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int S,
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,
                    hipStream_t s) {
     // gsrc_priv: [n_cut][3][Hs][Ws] per-cutout private planes (scratch); gsrc: [3][Hs][Ws] their sum
     PRX_CHECK_HIP(hipMemsetAsync(gsrc_priv, 0, sizeof(float) * (size_t)n_cut * 3 * Hs * Ws, s));
-    const int tiles = (S + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, gsrc_priv, n_cut, S);
+    const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
+    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, gsrc_priv, n_cut, Ha, Wa);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
                        (size_t)3 * Hs * Ws);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_fwd(const float* a, const double* desc, const float* noise, float* out, int n_cut, int S, hipStream_t s) {
-    hipLaunchKernelGGL(warp_b_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, desc, noise, out,
+int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const float* noise, float* out, int n_cut, int S,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(warp_b_fwd_kernel, dim3(ew_grid((size_t)n_cut * S * S)), dim3(256), 0, s, a, Ha, Wa, desc, noise, out,
                        n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_bwd(const float* a, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
-    PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * S * S, s));
+int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * Ha * Wa, s));
     const int tiles = (S + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, a, desc, g, ga, n_cut, S);
+    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, a, Ha, Wa, desc, g, ga, n_cut, S);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int Wb, hipStream_t s) {
+    hipLaunchKernelGGL(rescale_fwd_kernel, dim3(ew_grid((size_t)C * Hb * Wb)), dim3(256), 0, s, pooled, base, C, S, Hb, Wb);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s) {
+    PRX_CHECK_HIP(hipMemsetAsync(g_pooled, 0, sizeof(float) * (size_t)C * S * S, s));
+    hipLaunchKernelGGL(rescale_bwd_kernel, dim3(ew_grid((size_t)C * Hb * Wb)), dim3(256), 0, s, g_base, g_pooled, C, S, Hb, Wb);
     PRX_LAUNCH_CHECK();
     return 0;
 }

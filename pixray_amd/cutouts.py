@@ -28,8 +28,18 @@ def _uniform(gen, shape, lo=0.0, hi=1.0):
     return torch.rand(shape, generator=gen, dtype=torch.float64) * (hi - lo) + lo
 
 
+def base_size(S: int, aspect: float = 1.0):
+    """(Hb, Wb) of the pooled cutout after the reference's aspect rescale (pixray.py:468-472; kornia `rescale` =
+    F.interpolate to `int(size * factor)`): width * aspect on a wide canvas, height / aspect on a tall one."""
+    if aspect == 1:
+        return S, S
+    if aspect > 1:
+        return S, int(S * aspect)
+    return int(S * (1 / aspect)), S
+
+
 def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int = 0, noise_fac: float = 0.1,
-                         fill: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                         fill: Optional[float] = None, aspect: float = 1.0) -> Dict[str, torch.Tensor]:
     """Host-side mirror of the reference's per-iteration draws.
 
     zoom set (first int(0.6*cutn), pixray.py:407): RandomPerspective(0.4, p=.7) corner offsets,
@@ -37,7 +47,13 @@ def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int
     saturation U(.9,1.1) / hue U(-.1,.1) and the order of the two; wide set: RandomAffine
     translate U(+-2.5%), RandomPerspective(0.2, p=.7), ColorJitter; per-cutout noise factor
     U(0, noise_fac) (pixray.py:508-510); padding mode by iteration parity (1250-1253); gray fill
-    U(0,1) (1255-1258)."""
+    U(0,1) (1255-1258).
+
+    `aspect` = canvas width / height (pixray.py:1931 `global_aspect_width`).  When it is not 1 the augmentations run on
+    the aspect-rescaled cutout (Hb x Wb, `base_size`): crop boxes are positioned inside it, and the wide set's RandomAffine
+    becomes scale U(0.9 n_s, n_s), n_s = min(aspect, 1/aspect), translated by up to +-(1-n_s)/2 of the size along the canvas' short axis only
+    (pixray.py:420-431)."""
+    Hb, Wb = base_size(S, aspect)
     nz = int(0.6 * cutn)
     nw = cutn - nz
     p: Dict[str, torch.Tensor] = {"cutn": torch.tensor(cutn)}
@@ -48,16 +64,16 @@ def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int
     p["z_persp_rand"] = _uniform(gen, (nz, 4, 2))
     area = _uniform(gen, (nz, 10), 0.25, 0.95) * S * S
     log_ratio = _uniform(gen, (nz, 10), math.log(0.85), math.log(1.2))
-    aspect = torch.exp(log_ratio)
-    w = torch.sqrt(area * aspect).round().floor()
-    h = torch.sqrt(area / aspect).round().floor()
+    crop_ratio = torch.exp(log_ratio)
+    w = torch.sqrt(area * crop_ratio).round().floor()
+    h = torch.sqrt(area / crop_ratio).round().floor()
     ok = (w > 0) & (w < S) & (h > 0) & (h < S)
     first = torch.where(ok.any(1), ok.float().argmax(1), torch.zeros(nz, dtype=torch.long))
     ar = torch.arange(nz)
     cw = torch.where(ok.any(1), w[ar, first], torch.full((nz,), float(S), dtype=torch.float64))
     chh = torch.where(ok.any(1), h[ar, first], torch.full((nz,), float(S), dtype=torch.float64))
-    xs = (_uniform(gen, (nz,)) * (S - cw + 1)).floor()
-    ys = (_uniform(gen, (nz,)) * (S - chh + 1)).floor()
+    xs = (_uniform(gen, (nz,)) * (Wb - cw + 1)).floor()
+    ys = (_uniform(gen, (nz,)) * (Hb - chh + 1)).floor()
     p["z_crop"] = torch.stack([xs, ys, cw, chh], dim=1)
     p["z_jit_apply"] = _uniform(gen, (nz,)) < 0.8
     p["z_sat"] = _uniform(gen, (nz,), 0.9, 1.1).float()
@@ -73,6 +89,16 @@ def sample_cutout_params(cutn: int, S: int, gen: torch.Generator, iteration: int
     p["w_sat_first"] = torch.tensor(bool(_uniform(gen, ()).item() < 0.5))
     p["noise_fac"] = _uniform(gen, (cutn,), 0.0, noise_fac).float()
     p["noise"] = None
+    p["aspect"] = torch.tensor(float(aspect), dtype=torch.float64)
+    p["w_scale"] = torch.full((nw,), 0.95, dtype=torch.float64)
+    if aspect != 1:         # drawn last so that the square-canvas streams are unchanged
+        n_s = (1.0 / aspect) if aspect > 1 else aspect
+        n_t = (1.0 - n_s) / 2
+        p["w_scale"] = _uniform(gen, (nw,), 0.9 * n_s, n_s)
+        t = _uniform(gen, (nw,), -1.0, 1.0)
+        zeros = torch.zeros(nw, dtype=torch.float64)
+        # kornia RandomAffine translate=(tx, ty): |dx| <= tx * width, |dy| <= ty * height
+        p["w_trans"] = torch.stack([zeros, t * n_t * Hb], 1) if aspect > 1 else torch.stack([t * n_t * Wb, zeros], 1)
     return p
 
 
@@ -91,16 +117,24 @@ def _dlt(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
     return np.concatenate([X, np.ones((B, 1))], axis=1).reshape(B, 3, 3)
 
 
-def _corners(S: int, B: int) -> np.ndarray:
-    c = np.array([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]])
+def _corners(S: int, B: int, W: int = None) -> np.ndarray:
+    """corner points of an S x W image (W defaults to S), kornia order"""
+    W = S if W is None else W
+    c = np.array([[0.0, 0.0], [W - 1.0, 0.0], [W - 1.0, S - 1.0], [0.0, S - 1.0]])
     return np.repeat(c[None], B, axis=0)
 
 
-def _src_norm_from_dst_norm(M: np.ndarray, S: int) -> np.ndarray:
-    """inverse of kornia normalize_homography(M): maps normalised destination coords to normalised source coords
-    (kornia normal_transform_pixel: pixel [0, S-1] -> [-1, 1])"""
-    nk = np.array([[2.0 / (S - 1), 0.0, -1.0], [0.0, 2.0 / (S - 1), -1.0], [0.0, 0.0, 1.0]])
-    return np.linalg.inv(nk @ (M @ np.linalg.inv(nk)))
+def _norm_pixel(h: int, w: int) -> np.ndarray:
+    """kornia normal_transform_pixel: pixel [0, w-1] x [0, h-1] -> [-1, 1]^2"""
+    return np.array([[2.0 / (w - 1), 0.0, -1.0], [0.0, 2.0 / (h - 1), -1.0], [0.0, 0.0, 1.0]])
+
+
+def _src_norm_from_dst_norm(M: np.ndarray, S, dst=None) -> np.ndarray:
+    """inverse of kornia normalize_homography(M, src_hw, dst_hw): maps normalised destination coords to normalised source
+    coords.  `S` / `dst`: an int (square) or (h, w); dst defaults to the source size."""
+    src = (S, S) if isinstance(S, int) else S
+    dst = src if dst is None else ((dst, dst) if isinstance(dst, int) else dst)
+    return np.linalg.inv(_norm_pixel(*dst) @ (M @ np.linalg.inv(_norm_pixel(*src))))
 
 
 _PTS_NORM = np.array([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0], [1.0, -1.0]])
@@ -123,23 +157,29 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     cutn = int(p["cutn"])
     nz = int(0.6 * cutn)
     nw = cutn - nz
+    aspect = float(p["aspect"]) if "aspect" in p else 1.0
+    Hb, Wb = base_size(S, aspect)                 # the aspect-rescaled pooled image = source of stage A = size of stage A
     desc = np.zeros((cutn, DESC_WORDS))
     desc[:, 20] = float(p["fill"])
     eye = np.eye(3).reshape(9)
     desc[:, 0:9] = eye
     desc[:, 9:18] = eye
+    desc[:, 28:32] = (0.0, 0.0, float(Wb), float(Hb))          # stage B reads the whole stage-A image ...
 
-    def affine_theta(M):
-        t = _src_norm_from_dst_norm(M, S)
+    def affine_theta(M, src, dst=None):
+        t = _src_norm_from_dst_norm(M, src, dst)
         t[:, :2, :] = t[:, :2, :].astype(np.float32).astype(np.float64)   # F.affine_grid receives theta in fp32
         t[:, 2, :] = (0.0, 0.0, 1.0)
         return t.reshape(-1, 9)
 
+    def persp_offsets(rand, dscale, h, w):
+        return np.array([dscale * w / 2, dscale * h / 2])[None, None, :] * _np(rand) * _PTS_NORM[None]
+
     if nz > 0:
-        start = _corners(S, nz)
-        end = start + (0.4 * S / 2) * _np(p["z_persp_rand"]) * _PTS_NORM[None]
+        start = _corners(Hb, nz, Wb)
+        end = start + persp_offsets(p["z_persp_rand"], 0.4, Hb, Wb)
         app = _np(p["z_persp_apply"]) != 0
-        desc[:nz, 0:9] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nz, 9), eye[None])
+        desc[:nz, 0:9] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), (Hb, Wb)).reshape(nz, 9), eye[None])
         pad = MODE_REFLECT if int(p["reflect"]) else MODE_BORDER
         desc[:nz, 18] = np.where(app, float(pad), float(MODE_IDENT))
         desc[:nz, 26] = GRID_MESH
@@ -149,7 +189,7 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
                         np.stack([xs + w - 1, ys + h - 1], 1), np.stack([xs, ys + h - 1], 1)], axis=1)
         Mc = _dlt(src, _corners(S, nz))
         Mc[:, 2, :] = (0.0, 0.0, 1.0)                                      # warp_affine drops the last row
-        desc[:nz, 9:18] = affine_theta(Mc)
+        desc[:nz, 9:18] = affine_theta(Mc, (Hb, Wb), (S, S))
         desc[:nz, 19] = MODE_ZEROS
         desc[:nz, 27] = GRID_AFFINE
         desc[:nz, 21] = _np(p["z_jit_apply"])
@@ -157,18 +197,20 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         desc[:nz, 23] = (p["z_hue"].float() * (2.0 * math.pi)).double().numpy()   # kornia: hue_factor * 2*pi in fp32
         desc[:nz, 24] = float(bool(p["z_sat_first"]))
     if nw > 0:
-        s = 0.95
-        c = S / 2.0 - 0.5
+        sc = _np(p["w_scale"]) if "w_scale" in p else np.full(nw, 0.95)
+        cx, cy = Wb / 2.0 - 0.5, Hb / 2.0 - 0.5
         tr = _np(p["w_trans"])
         Ma = np.zeros((nw, 3, 3))
-        Ma[:, 0, 0] = s; Ma[:, 1, 1] = s; Ma[:, 2, 2] = 1.0
-        Ma[:, 0, 2] = (1 - s) * c + tr[:, 0]
-        Ma[:, 1, 2] = (1 - s) * c + tr[:, 1]
-        desc[nz:, 0:9] = affine_theta(Ma)
+        Ma[:, 0, 0] = sc; Ma[:, 1, 1] = sc; Ma[:, 2, 2] = 1.0
+        Ma[:, 0, 2] = (1 - sc) * cx + tr[:, 0]
+        Ma[:, 1, 2] = (1 - sc) * cy + tr[:, 1]
+        desc[nz:, 0:9] = affine_theta(Ma, (Hb, Wb))
         desc[nz:, 18] = MODE_FILL
         desc[nz:, 26] = GRID_AFFINE
+        # ... except the wide set on a non-square canvas: CenterCrop(S) (pixray.py:433) = the centred S x S window
+        desc[nz:, 28:32] = (float((Wb - S) // 2), float((Hb - S) // 2), float(S), float(S))
         start = _corners(S, nw)
-        end = start + (0.2 * S / 2) * _np(p["w_persp_rand"]) * _PTS_NORM[None]
+        end = start + persp_offsets(p["w_persp_rand"], 0.2, S, S)
         app = _np(p["w_persp_apply"]) != 0
         desc[nz:, 9:18] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nw, 9), eye[None])
         desc[nz:, 19] = np.where(app, float(MODE_FILL), float(MODE_IDENT))
@@ -181,31 +223,43 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     return torch.from_numpy(desc)
 
 
-def build_cached_descriptors(transforms: torch.Tensor, cutn: int, S: int, reflect: bool, fill: float,
-                             noise_fac: torch.Tensor) -> torch.Tensor:
+def build_cached_descriptors(live: torch.Tensor, cutn: int, S: int, reflect: bool, fill: float, noise_fac: torch.Tensor,
+                             aspect: float = 1.0) -> torch.Tensor:
     """Descriptor table of the reference's CACHED-transform path (pixray.py:480-486): when `.transforms` is set (second
-    and later calls inside one iteration: image prompts, pixray.py:1318-1333) the pooled image is warped ONCE with the
-    composed 3x3 of the two augmentation stages, `kornia.warp_perspective(x, T, (S,S), padding_mode=...)` with kornia
-    0.6.2's default `align_corners=True` [UPSTREAM], zoom set padded by the iteration's reflection/border mode, wide set
-    filled with the iteration's gray; no ColorJitter; fresh noise.
+    and later calls inside one iteration: image prompts, pixray.py:1318-1333) the (aspect-rescaled) pooled image is
+    warped ONCE with the composed 3x3 of the augmentation stages, `kornia.warp_perspective(x, T, (S,S),
+    padding_mode=...)` with kornia 0.6.2's default `align_corners=True` [UPSTREAM], zoom set padded by the iteration's
+    reflection/border mode, wide set filled with the iteration's gray; no ColorJitter; fresh noise.
 
-    `transforms` = columns 0:18 of the live descriptor table (the two `src_norm <- dst_norm` maps).  Their product is the
-    composed map; scaling its first two rows by (S-1)/S turns the kernel's align_corners=False pixel mapping
-    `(g+1)*S/2 - 0.5` into align_corners=True's `(g+1)*(S-1)/2`."""
-    t = transforms.double().numpy()
-    M = t[:, 0:9].reshape(-1, 3, 3) @ t[:, 9:18].reshape(-1, 3, 3)
-    M[:, :2, :] *= (S - 1.0) / S
+    `live` = the live descriptor table of this iteration.  Stage A degenerates to a copy of the base image and stage B
+    carries the composed map: M1 @ C @ M2 with C = the change of normalised coordinates between the stage-B source
+    window and the stage-A image.  Scaling its rows by (Wb-1)/Wb and (Hb-1)/Hb turns the kernel's align_corners=False
+    pixel mapping `(g+1)*W/2 - 0.5` into align_corners=True's `(g+1)*(W-1)/2`."""
+    t = live.double().numpy()
+    Hb, Wb = base_size(S, aspect)
+    M1 = t[:, 0:9].reshape(-1, 3, 3)
+    M2 = t[:, 9:18].reshape(-1, 3, 3)
+    win = t[:, 28:32]
+    C = np.zeros((cutn, 3, 3))
+    for i in range(cutn):
+        ox, oy, ww, wh = win[i]
+        shift = np.array([[1.0, 0.0, ox], [0.0, 1.0, oy], [0.0, 0.0, 1.0]])
+        C[i] = _norm_pixel(Hb, Wb) @ shift @ np.linalg.inv(_norm_pixel(int(wh), int(ww)))
+    M = M1 @ C @ M2
+    M[:, 0, :] *= (Wb - 1.0) / Wb
+    M[:, 1, :] *= (Hb - 1.0) / Hb
     nz = int(0.6 * cutn)
     desc = np.zeros((cutn, DESC_WORDS))
-    desc[:, 0:9] = M.reshape(-1, 9)
-    desc[:, 9:18] = np.eye(3).reshape(9)
-    desc[:nz, 18] = MODE_REFLECT_AC if reflect else MODE_BORDER
-    desc[nz:, 18] = MODE_FILL
-    desc[:, 19] = MODE_IDENT
+    desc[:, 0:9] = np.eye(3).reshape(9)
+    desc[:, 18] = MODE_IDENT
+    desc[:, 9:18] = M.reshape(-1, 9)
+    desc[:nz, 19] = MODE_REFLECT_AC if reflect else MODE_BORDER
+    desc[nz:, 19] = MODE_FILL
     desc[:, 20] = float(fill)
     desc[:, 25] = _np(noise_fac)
     desc[:, 26] = GRID_MESH
     desc[:, 27] = GRID_MESH
+    desc[:, 28:32] = (0.0, 0.0, float(Wb), float(Hb))
     return torch.from_numpy(desc)
 
 
@@ -216,10 +270,13 @@ class MakeCutouts(nn.Module):
     Extra (optional) knobs the reference keeps in module globals: `iteration` (padding-mode parity,
     pixray.py:1250-1253), the RNG `generator`, and `shard=(lo, hi)` to produce only a slice of the
     cutout batch (multi-GPU sharding).  `last_params` / `transforms` hold the draws of
-    the latest call (the reference's `.transforms` cache, pixray.py:480-498, is cleared the same way)."""
+    the latest call (the reference's `.transforms` cache, pixray.py:480-498, is cleared the same way).
+    `aspect_width` != 1 selects the reference's non-square-canvas augmentation family (pixray.py:420-431, 468-472)."""
 
-    def __init__(self, cut_size, cutn, cut_pow=1., generator: Optional[torch.Generator] = None, noise_fac: float = 0.1):
+    def __init__(self, cut_size, cutn, cut_pow=1., generator: Optional[torch.Generator] = None, noise_fac: float = 0.1,
+                 aspect_width: float = 1.0):
         super().__init__()
+        self.aspect_width = aspect_width   # canvas width / height: the reference's module global `global_aspect_width` (pixray.py:1931)
         self.cut_size = cut_size
         self.cutn = cutn
         self.cutn_zoom = int(0.6 * cutn)
@@ -248,10 +305,10 @@ class MakeCutouts(nn.Module):
             self.fill = fill
         S = self.cut_size
         prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
-            self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill)
+            self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill, aspect=self.aspect_width)
         self.last_params = prm
         desc = build_descriptors(prm, S)
-        self.transforms = desc[:, 0:18]
+        self.transforms = desc          # this iteration's geometry (opaque, like the reference's composed 3x3 cache)
         lo, hi = (0, self.cutn) if self.shard is None else self.shard
         if getattr(self, "_static_desc", None) is not None:
             self._pinned.copy_(desc[lo:hi])
@@ -270,10 +327,11 @@ class MakeCutouts(nn.Module):
         if self.transforms is not None and not getattr(self, "_prepared", False):
             # cached path (pixray.py:480-486): a further call inside the same iteration re-uses this iteration's geometry
             prm = self.last_params
+            asp = float(prm["aspect"]) if "aspect" in prm else 1.0
             facs = _uniform(self.generator, (self.cutn,), 0.0, self.noise_fac).float()
-            desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs)
+            desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp)
             noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32) if self.noise_fac else None
-            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S)
+            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S, base_size(S, asp))
         if not getattr(self, "_prepared", False):
             self.prepare()
         self._prepared = False
@@ -287,4 +345,4 @@ class MakeCutouts(nn.Module):
             noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32)
         elif noise is not None:
             noise = noise[lo:hi].to(input.device, dtype=torch.float32).contiguous()
-        return ops.make_cutouts(input, desc_dev, noise, S)
+        return ops.make_cutouts(input, desc_dev, noise, S, base_size(S, float(prm["aspect"]) if "aspect" in prm else 1.0))

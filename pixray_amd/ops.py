@@ -38,38 +38,42 @@ def _weight_array(tensors: Sequence[torch.Tensor]):
 # --------------------------------------------------------------------------------------- cutouts
 class _MakeCutoutsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, desc, noise, S):
+    def forward(ctx, img, desc, noise, S, base_hw):
         _need_cuda(img, desc, noise)
         assert img.dim() == 4 and img.shape[0] == 1 and img.shape[1] == 3, "MakeCutouts expects [1,3,H,W]"
         img = img.contiguous().float()
         n = desc.shape[0]
         H, W = img.shape[2], img.shape[3]
+        Hb, Wb = base_hw
         dev = img.device
         pooled = torch.empty(3, S, S, device=dev)
         argmax = torch.empty(3, S, S, device=dev, dtype=torch.int32)
-        stage_a = torch.empty(n, 3, S, S, device=dev)
+        base = torch.empty(3, Hb, Wb, device=dev) if (Hb, Wb) != (S, S) else None
+        stage_a = torch.empty(n, 3, Hb, Wb, device=dev)
         out = torch.empty(n, 3, S, S, device=dev)
-        call("prx_cutouts_forward", img, H, W, desc, noise, n, S, pooled, argmax, stage_a, out, _stream())
+        call("prx_cutouts_forward", img, H, W, desc, noise, n, S, Hb, Wb, pooled, argmax, base, stage_a, out, _stream())
         ctx.save_for_backward(desc, argmax, stage_a)
-        ctx.geom = (n, S, H, W)
+        ctx.geom = (n, S, Hb, Wb, H, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
         desc, argmax, stage_a = ctx.saved_tensors
-        n, S, H, W = ctx.geom
+        n, S, Hb, Wb, H, W = ctx.geom
         g = g.contiguous().float()
         dev = g.device
-        g_a = torch.empty(n, 3, S, S, device=dev)
-        g_priv = torch.empty(n, 3, S, S, device=dev)
+        g_a = torch.empty(n, 3, Hb, Wb, device=dev)
+        g_priv = torch.empty(n, 3, Hb, Wb, device=dev)
+        g_base = torch.empty(3, Hb, Wb, device=dev)
         g_pooled = torch.empty(3, S, S, device=dev)
         g_img = torch.empty(1, 3, H, W, device=dev)
-        call("prx_cutouts_backward", g, desc, n, S, H, W, stage_a, argmax, g_a, g_priv, g_pooled, g_img, _stream())
-        return g_img, None, None, None
+        call("prx_cutouts_backward", g, desc, n, S, Hb, Wb, H, W, stage_a, argmax, g_a, g_priv, g_base, g_pooled, g_img, _stream())
+        return g_img, None, None, None, None
 
 
-def make_cutouts(img, desc, noise, S):
-    return _MakeCutoutsFn.apply(img, desc, noise, S)
+def make_cutouts(img, desc, noise, S, base_hw=None):
+    """`base_hw`: size of the aspect-rescaled pooled image ((S, S) on a square canvas; pixray_amd.cutouts.base_size)."""
+    return _MakeCutoutsFn.apply(img, desc, noise, S, tuple(base_hw) if base_hw is not None else (S, S))
 
 
 # --------------------------------------------------------------------------------------- CLIP ViT

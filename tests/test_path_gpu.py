@@ -445,3 +445,42 @@ def test_clip_resnet_vs_oracle(name, n):
     tol_rel, tol_cos = (6e-2, 0.997) if name == "tiny-RN" else (1.6e-1, 0.985)
     assert rel_l2(gd, gref) < tol_rel, rel_l2(gd, gref)
     assert cosine(gd, gref) > tol_cos, cosine(gd, gref)
+
+
+# ------------------------------------------------------------------------------------------ non-square canvases (a6)
+@pytest.mark.parametrize("H,W,S,it", [(144, 256, 224, 0), (144, 256, 224, 1), (256, 144, 224, 0), (64, 112, 64, 1)])
+def test_make_cutouts_non_square_canvas_vs_oracle(H, W, S, it):
+    """pixray.py:420-431, 468-472: on a W != H canvas the pooled cutout is rescaled to the canvas aspect, the zoom set is
+    warped / cropped inside that rectangle, and the wide set shrinks the whole rectangle (scale U(.9,1)/aspect, shift along
+    the short axis), takes the centred S x S crop and then the padded perspective.  Live and cached paths, forward and the
+    gradient w.r.t. the canvas."""
+    cutn = 10
+    aspect = W / H
+    g = torch.Generator().manual_seed(300 + H + it)
+    low = torch.rand(1, 3, max(H // 8, 4), max(W // 8, 4), generator=g)
+    img = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    target = torch.rand(1, 3, H, W, generator=g)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=it, aspect=aspect)
+    prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    Hb, Wb = pc.base_size(S, aspect)
+    assert (Hb == S) != (Wb == S) and (Wb > S if aspect > 1 else Hb > S)
+    img_ref = img.clone().requires_grad_(True)
+    ref = cutouts_ref.make_cutouts(img_ref, prm, S)
+    gout = torch.randn(cutn, 3, S, S, generator=g)
+    (gref,) = torch.autograd.grad(ref, img_ref, gout)
+    mk = pc.MakeCutouts(S, cutn, aspect_width=aspect)
+    mk.fixed_params = prm
+    mk.iteration = it
+    img_d = img.to(DEV).requires_grad_(True)
+    out = mk(img_d)
+    assert out.shape == (cutn, 3, S, S)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 2e-4
+    assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    (gd,) = torch.autograd.grad(out, img_d, gout.to(DEV))
+    assert rel_l2(gd, gref) < 3e-3, rel_l2(gd, gref)
+    assert cosine(gd, gref) > 0.99999
+    # cached-transform path on the same iteration's geometry (image prompts)
+    mk.noise_fac = 0.0
+    cached = mk(target.to(DEV))
+    ref_cached = cutouts_ref.make_cutouts_cached(target, prm, S)
+    assert rel_l2(cached, ref_cached) < 1e-4, rel_l2(cached, ref_cached)
