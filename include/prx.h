@@ -187,12 +187,14 @@ int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre,
  * canvas aspect (pixray.py:468-472): the "base" image [3,Hb,Wb] with Hb == S or Wb == S (Hb = Wb = S on a square
  * canvas, `base` may then be NULL).  Stage A renders [n_cut,3,Hb,Wb] from the base, stage B the S x S cutouts.
  * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/base/stage_a are caller-owned save-for-backward
- * buffers ([3,S,S] f32, [3,S,S] i32, [3,Hb,Wb] f32, [n_cut,3,Hb,Wb] f32). */
-int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S, int Hb, int Wb,
-                        float* pooled, int* argmax, float* base, float* stage_a, float* out, prx_stream_t s);
+ * buffers ([3,S,S] f32, [3,S,S] i32, [3,Hb,Wb] f32, [n_cut,3,Hb,Wb] f32).
+ * spot_mask (optional): uint8 [3,S,S]; pooled pixels where it is non-zero are set to 0 (spot prompts, pixray.py:453-466). */
+int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, const unsigned char* spot_mask,
+                        int n_cut, int S, int Hb, int Wb, float* pooled, int* argmax, float* base, float* stage_a, float* out,
+                        prx_stream_t s);
 /* scratch: g_stage_a and g_base_priv are [n_cut,3,Hb,Wb] fp32 each, g_base is [3,Hb,Wb], g_pooled is [3,S,S] */
-int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int Hb, int Wb, int H, int W,
-                         const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base,
+int prx_cutouts_backward(const float* g_out, const double* desc, const unsigned char* spot_mask, int n_cut, int S, int Hb, int Wb,
+                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base,
                          float* g_pooled, float* g_img, prx_stream_t s);
 
 /* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].

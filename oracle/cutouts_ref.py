@@ -201,10 +201,13 @@ def base_size(S, aspect):
     return (S, int(S * aspect)) if aspect > 1 else (int(S * (1 / aspect)), S)
 
 
-def base_image(img, S, aspect):
-    """pooled cutout (pixray.py:463), rescaled to the canvas aspect when it is not square (pixray.py:468-472:
-    kornia.geometry.transform.rescale = bilinear F.interpolate, align_corners=False)"""
+def base_image(img, S, aspect, spot_mask=None):
+    """pooled cutout (pixray.py:463), blanked where the spot mask is set (pixray.py:465-466), rescaled to the canvas aspect
+    when it is not square (pixray.py:468-472: kornia.geometry.transform.rescale = bilinear F.interpolate,
+    align_corners=False)"""
     base = pooled_image(img, S)
+    if spot_mask is not None:
+        base = torch.where(spot_mask[None], torch.zeros_like(base), base)
     Hb, Wb = base_size(S, aspect)
     if (Hb, Wb) != (S, S):
         base = F.interpolate(base, size=(Hb, Wb), mode="bilinear", align_corners=False)
@@ -224,14 +227,14 @@ def _wide_affine(prm, nw, Hb, Wb):
     return Ma
 
 
-def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, spot_mask=None) -> torch.Tensor:
     """MakeCutouts.forward(img[1,3,H,W]) -> [cutn,3,S,S] with explicit randomness `prm`
     (see pixray_amd.cutouts.sample_cutout_params for the fields; prm["aspect"] = canvas width / height)."""
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)                                   # pixray.py:407
     nw = cutn - nz
     aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
-    base = base_image(img, S, aspect)                      # pixray.py:463-472
+    base = base_image(img, S, aspect, spot_mask)           # pixray.py:463-472
     Hb, Wb = base.shape[-2:]
     pad_mode = "reflection" if int(prm["reflect"]) else "border"   # pixray.py:1250-1253
     fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)   # pixray.py:1255-1258
@@ -300,7 +303,7 @@ def composed_transforms(prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     return torch.cat(out, dim=0)
 
 
-def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None) -> torch.Tensor:
+def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None, spot_mask=None) -> torch.Tensor:
     """MakeCutouts.forward when `.transforms` is cached (pixray.py:480-486; image prompts, pixray.py:1318-1333): ONE
     `kornia.warp_perspective(cutout, T, (S,S), padding_mode=...)` per set -- kornia 0.6.2's default align_corners=True
     [UPSTREAM, from knowledge: parity unpinned], zoom set with the iteration's reflection/border padding, wide set filled
@@ -309,7 +312,7 @@ def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int,
     nz = int(0.6 * cutn)
     aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
     T = composed_transforms(prm, S)
-    base = base_image(img, S, aspect)
+    base = base_image(img, S, aspect, spot_mask)
     pad_mode = "reflection" if int(prm["reflect"]) else "border"
     fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)
     outs = []

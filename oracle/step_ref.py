@@ -161,6 +161,7 @@ def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     rel, cos = _metrics(dz, ref["dz"])
     erel, _ = _metrics(sess.last_embeds, ref["emb"])
     irel, _ = _metrics(img_hip, ref["img"])
+    loss = loss.detach()
     return dict(loss_hip=float(loss), loss_ref=float(ref["loss"]), loss_abs_err=abs(float(loss) - float(ref["loss"])),
                 dz_rel_l2=rel, dz_cosine=cos, embeds_rel_l2=erel, image_rel_l2=irel,
                 indices_equal=bool(torch.equal(sess.drawer.handle.last_indices.cpu().long(), idx_ref)))

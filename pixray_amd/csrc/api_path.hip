@@ -55,12 +55,13 @@ int prx_vqgan_synth_backward(prx_vqgan* h, const float* g_img, float* dz, prx_st
 }
 
 // ---- MakeCutouts ------------------------------------------------------------------------------
-int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, int n_cut, int S, int Hb, int Wb,
-                        float* pooled, int* argmax, float* base, float* stage_a, float* out, prx_stream_t s) {
+int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, const unsigned char* spot_mask,
+                        int n_cut, int S, int Hb, int Wb, float* pooled, int* argmax, float* base, float* stage_a, float* out,
+                        prx_stream_t s) {
     PRX_REQUIRE(img && desc && pooled && argmax && stage_a && out, "prx_cutouts_forward: null argument");
     PRX_REQUIRE(Hb >= S && Wb >= S && (Hb == S || Wb == S), "prx_cutouts_forward: base %dx%d must be S=%d on one side", Hb, Wb, S);
     int r;
-    if ((r = prx_pool_fwd(img, pooled, argmax, 3, H, W, S, S_(s)))) return r;
+    if ((r = prx_pool_fwd(img, pooled, argmax, spot_mask, 3, H, W, S, S_(s)))) return r;
     const float* src = pooled;
     if (Hb != S || Wb != S) {
         PRX_REQUIRE(base, "prx_cutouts_forward: a non-square canvas needs the `base` buffer");
@@ -70,8 +71,8 @@ int prx_cutouts_forward(const float* img, int H, int W, const double* desc, cons
     if ((r = prx_warp_a_fwd(src, Hb, Wb, desc, stage_a, n_cut, Hb, Wb, S_(s)))) return r;
     return prx_warp_b_fwd(stage_a, Hb, Wb, desc, noise, out, n_cut, S, S_(s));
 }
-int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int S, int Hb, int Wb, int H, int W, const float* stage_a,
-                         const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base, float* g_pooled, float* g_img,
+int prx_cutouts_backward(const float* g_out, const double* desc, const unsigned char* spot_mask, int n_cut, int S, int Hb, int Wb,
+                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base, float* g_pooled, float* g_img,
                          prx_stream_t s) {
     PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_base_priv && g_base && g_pooled && g_img,
                 "prx_cutouts_backward: null argument");
@@ -80,7 +81,7 @@ int prx_cutouts_backward(const float* g_out, const double* desc, int n_cut, int 
     const bool rect = Hb != S || Wb != S;
     if ((r = prx_warp_a_bwd(g_stage_a, Hb, Wb, desc, g_base_priv, rect ? g_base : g_pooled, n_cut, Hb, Wb, S_(s)))) return r;
     if (rect && (r = prx_rescale_bwd(g_base, g_pooled, 3, S, Hb, Wb, S_(s)))) return r;
-    return prx_pool_bwd(g_pooled, argmax, g_img, 3, H, W, S, S_(s));
+    return prx_pool_bwd(g_pooled, argmax, spot_mask, g_img, 3, H, W, S, S_(s));
 }
 
 // ---- CLIP visual tower ------------------------------------------------------------------------

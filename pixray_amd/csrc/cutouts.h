@@ -1,8 +1,8 @@
 #pragma once
 #include "common.h"
 #define PRX_CUT_DESC_WORDS 32
-int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s);
-int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s);
+int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned char* mask, int C, int H, int W, int S, hipStream_t s);
+int prx_pool_bwd(const float* g, const int* argmax, const unsigned char* mask, float* gimg, int C, int H, int W, int S, hipStream_t s);
 // stage A renders Ha x Wa images from the shared Hs x Ws source; stage B reads them through the descriptor's window
 int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int Ha, int Wa, hipStream_t s);
 int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,

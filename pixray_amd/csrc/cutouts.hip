@@ -35,8 +35,10 @@ inline int ew_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 
 __device__ __forceinline__ int win_start(int i, int in, int out) { return (int)(((long long)i * in) / out); }
 __device__ __forceinline__ int win_end(int i, int in, int out) { return (int)((((long long)(i + 1)) * in + out - 1) / out); }
 
+// `mask` (optional, uint8 [C,S,S]): spot prompts (pixray.py:453-466) zero the pooled cutout where the mask is set
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ img, float* __restrict__ pooled,
-                                                       int* __restrict__ argmax, int C, int H, int W, int S) {
+                                                       int* __restrict__ argmax, const unsigned char* __restrict__ mask,
+                                                       int C, int H, int W, int S) {
     const int total = C * S * S;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int x = idx % S, y = (idx / S) % S, c = idx / (S * S);
@@ -50,18 +52,20 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                 sum += v;
                 if (v > mx || v != v) { mx = v; am = yy * W + xx; }   // first max wins (torch CPU scan order)
             }
-        pooled[idx] = 0.5f * (sum / (float)((y1 - y0) * (x1 - x0)) + mx);
+        pooled[idx] = (mask && mask[idx]) ? 0.f : 0.5f * (sum / (float)((y1 - y0) * (x1 - x0)) + mx);
         argmax[idx] = am;
     }
 }
 
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const int* __restrict__ argmax,
-                                                       float* __restrict__ gimg, int C, int H, int W, int S) {
+                                                       const unsigned char* __restrict__ mask, float* __restrict__ gimg, int C, int H,
+                                                       int W, int S) {
     const int total = C * S * S;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int x = idx % S, y = (idx / S) % S, c = idx / (S * S);
         const int y0 = win_start(y, H, S), y1 = win_end(y, H, S);
         const int x0 = win_start(x, W, S), x1 = win_end(x, W, S);
+        if (mask && mask[idx]) continue;            // masked pooled pixels are constants
         const float gv = 0.5f * g[idx];
         const float ga = gv / (float)((y1 - y0) * (x1 - x0));
         for (int yy = y0; yy < y1; ++yy)
@@ -703,14 +707,14 @@ __global__ __launch_bounds__(256) void patchify_bwd_apply_kernel(const float* __
 
 }  // namespace
 
-int prx_pool_fwd(const float* img, float* pooled, int* argmax, int C, int H, int W, int S, hipStream_t s) {
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, img, pooled, argmax, C, H, W, S);
+int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned char* mask, int C, int H, int W, int S, hipStream_t s) {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, img, pooled, argmax, mask, C, H, W, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_pool_bwd(const float* g, const int* argmax, float* gimg, int C, int H, int W, int S, hipStream_t s) {
+int prx_pool_bwd(const float* g, const int* argmax, const unsigned char* mask, float* gimg, int C, int H, int W, int S, hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * C * H * W, s));
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, g, argmax, gimg, C, H, W, S);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, g, argmax, mask, gimg, C, H, W, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -320,8 +320,15 @@ class MakeCutouts(nn.Module):
 
     # -- device part -----------------------------------------------------------------------------------------------------
     def forward(self, input, spot=None):
+        spot_mask = None
         if spot is not None:
-            raise NotImplementedError("spot prompts (pixray.py:370-394) are outside the hot-path scope")
+            # pixray.py:453-458: spot == 0 blanks the pooled pixels OUTSIDE the spot image's bright region, anything else
+            # the pixels inside it.  `spot_masks` = (inside, outside) bool [3,S,S] tensors (fetch_spot_indexes, pixray.py:370-394;
+            # loading / resizing the spot image is I/O and left to the caller)
+            masks = getattr(self, "spot_masks", None)
+            if masks is None:
+                raise ValueError("spot prompts need MakeCutouts.spot_masks = (inside_mask, outside_mask), bool [3,S,S]")
+            spot_mask = (masks[1] if spot == 0 else masks[0]).to(input.device)
         S = self.cut_size
         lo, hi = (0, self.cutn) if self.shard is None else self.shard
         if self.transforms is not None and not getattr(self, "_prepared", False):
@@ -331,7 +338,7 @@ class MakeCutouts(nn.Module):
             facs = _uniform(self.generator, (self.cutn,), 0.0, self.noise_fac).float()
             desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp)
             noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32) if self.noise_fac else None
-            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S, base_size(S, asp))
+            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S, base_size(S, asp), spot_mask)
         if not getattr(self, "_prepared", False):
             self.prepare()
         self._prepared = False
@@ -345,4 +352,4 @@ class MakeCutouts(nn.Module):
             noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32)
         elif noise is not None:
             noise = noise[lo:hi].to(input.device, dtype=torch.float32).contiguous()
-        return ops.make_cutouts(input, desc_dev, noise, S, base_size(S, float(prm["aspect"]) if "aspect" in prm else 1.0))
+        return ops.make_cutouts(input, desc_dev, noise, S, base_size(S, float(prm["aspect"]) if "aspect" in prm else 1.0), spot_mask)

@@ -95,7 +95,9 @@ class Session:
                  auto_stop: bool = False, image_prompts: Optional[Dict[str, Sequence[torch.Tensor]]] = None,
                  image_prompt_weight: Optional[float] = None, image_prompt_shuffle: bool = False,
                  z_labels: Sequence[torch.Tensor] = (), image_label_weight: float = 1.0, init_weight_pix: float = 0.0,
-                 init_weight_cos: float = 0.0, init_image_tensor: Optional[torch.Tensor] = None):
+                 init_weight_cos: float = 0.0, init_image_tensor: Optional[torch.Tensor] = None,
+                 spot_prompts: Optional[Dict[str, Sequence[object]]] = None,
+                 spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None):
         self.drawer = drawer
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
@@ -121,6 +123,10 @@ class Session:
         self.init_weight_pix = init_weight_pix           # pixray.py:1363-1368
         self.init_weight_cos = init_weight_cos           # pixray.py:1370-1375
         self.init_image_tensor = init_image_tensor
+        # spot prompts (pixray.py:1270-1292): Prompts scored on cutouts whose spot region (spotPmsTable) or its complement
+        # (spotOffPmsTable) was blanked; the cutout tables need `.spot_masks`
+        self.spotPmsTable = {k: list(v) for k, v in (spot_prompts or {}).items()}
+        self.spotOffPmsTable = {k: list(v) for k, v in (spot_prompts_off or {}).items()}
         self.optimiser_factory = optimiser_factory
         self.group, self.rank, self.world_size = group, rank, world_size
         self.auto_stop = auto_stop
@@ -206,8 +212,20 @@ class Session:
         cur_cutouts = {}
         for size, mk in self.cutoutsTable.items():
             cur_cutouts[size] = mk(out)
+        cur_spot, cur_spot_off = {}, {}
+        if any(self.spotPmsTable.values()):                                                    # pixray.py:1270-1276
+            for size, mk in self.cutoutsTable.items():
+                cur_spot[size] = mk(out, spot=1)
+        if any(self.spotOffPmsTable.values()):
+            for size, mk in self.cutoutsTable.items():
+                cur_spot_off[size] = mk(out, spot=0)
         iii = None
         for name, perceptor in self.perceptors.items():
+            for table, cuts in ((self.spotPmsTable, cur_spot), (self.spotOffPmsTable, cur_spot_off)):   # pixray.py:1282-1292
+                if table.get(name):
+                    iii_s = perceptor.encode_image(cuts[self.cutoutSizeTable[name]]).float()
+                    for prompt in table[name]:
+                        result.append(prompt(iii_s))
             iii = perceptor.encode_image(cur_cutouts[self.cutoutSizeTable[name]]).float()     # pixray.py:1295
             for prompt in self.pmsTable[name]:
                 result.append(prompt(iii))                                                     # pixray.py:1297-1299

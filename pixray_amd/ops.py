@@ -38,8 +38,8 @@ def _weight_array(tensors: Sequence[torch.Tensor]):
 # --------------------------------------------------------------------------------------- cutouts
 class _MakeCutoutsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, desc, noise, S, base_hw):
-        _need_cuda(img, desc, noise)
+    def forward(ctx, img, desc, noise, S, base_hw, spot_mask):
+        _need_cuda(img, desc, noise, spot_mask)
         assert img.dim() == 4 and img.shape[0] == 1 and img.shape[1] == 3, "MakeCutouts expects [1,3,H,W]"
         img = img.contiguous().float()
         n = desc.shape[0]
@@ -51,8 +51,12 @@ class _MakeCutoutsFn(torch.autograd.Function):
         base = torch.empty(3, Hb, Wb, device=dev) if (Hb, Wb) != (S, S) else None
         stage_a = torch.empty(n, 3, Hb, Wb, device=dev)
         out = torch.empty(n, 3, S, S, device=dev)
-        call("prx_cutouts_forward", img, H, W, desc, noise, n, S, Hb, Wb, pooled, argmax, base, stage_a, out, _stream())
+        if spot_mask is not None:
+            spot_mask = spot_mask.to(torch.uint8).contiguous()
+            assert spot_mask.shape == (3, S, S), f"spot mask must be [3,{S},{S}]"
+        call("prx_cutouts_forward", img, H, W, desc, noise, spot_mask, n, S, Hb, Wb, pooled, argmax, base, stage_a, out, _stream())
         ctx.save_for_backward(desc, argmax, stage_a)
+        ctx.spot_mask = spot_mask
         ctx.geom = (n, S, Hb, Wb, H, W)
         return out
 
@@ -67,13 +71,15 @@ class _MakeCutoutsFn(torch.autograd.Function):
         g_base = torch.empty(3, Hb, Wb, device=dev)
         g_pooled = torch.empty(3, S, S, device=dev)
         g_img = torch.empty(1, 3, H, W, device=dev)
-        call("prx_cutouts_backward", g, desc, n, S, Hb, Wb, H, W, stage_a, argmax, g_a, g_priv, g_base, g_pooled, g_img, _stream())
-        return g_img, None, None, None, None
+        call("prx_cutouts_backward", g, desc, ctx.spot_mask, n, S, Hb, Wb, H, W, stage_a, argmax, g_a, g_priv, g_base, g_pooled, g_img,
+             _stream())
+        return g_img, None, None, None, None, None
 
 
-def make_cutouts(img, desc, noise, S, base_hw=None):
-    """`base_hw`: size of the aspect-rescaled pooled image ((S, S) on a square canvas; pixray_amd.cutouts.base_size)."""
-    return _MakeCutoutsFn.apply(img, desc, noise, S, tuple(base_hw) if base_hw is not None else (S, S))
+def make_cutouts(img, desc, noise, S, base_hw=None, spot_mask=None):
+    """`base_hw`: size of the aspect-rescaled pooled image ((S, S) on a square canvas; pixray_amd.cutouts.base_size);
+    `spot_mask`: bool/uint8 [3,S,S], pooled pixels to blank (spot prompts, pixray.py:453-466)."""
+    return _MakeCutoutsFn.apply(img, desc, noise, S, tuple(base_hw) if base_hw is not None else (S, S), spot_mask)
 
 
 # --------------------------------------------------------------------------------------- CLIP ViT

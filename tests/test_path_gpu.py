@@ -484,3 +484,37 @@ def test_make_cutouts_non_square_canvas_vs_oracle(H, W, S, it):
     cached = mk(target.to(DEV))
     ref_cached = cutouts_ref.make_cutouts_cached(target, prm, S)
     assert rel_l2(cached, ref_cached) < 1e-4, rel_l2(cached, ref_cached)
+
+
+def test_make_cutouts_spot_masks_vs_oracle():
+    """spot prompts (pixray.py:453-466, 1270-1292): the pooled cutout is blanked inside (spot=1) or outside (spot=0) the
+    spot mask before the augmentations; the calls come after the iteration's first MakeCutouts call, i.e. through the
+    cached transforms"""
+    cutn, S, HW = 10, 64, 96
+    g = torch.Generator().manual_seed(77)
+    img = torch.rand(1, 3, HW, HW, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    inside = (((yy - S / 2) ** 2 + (xx - S / 2) ** 2) < (S / 4) ** 2)[None].expand(3, S, S).contiguous()
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=1, noise_fac=0.0)
+    mk = pc.MakeCutouts(S, cutn, noise_fac=0.0)
+    mk.fixed_params = prm
+    mk.iteration = 1
+    mk.spot_masks = (inside, ~inside)
+    img_d = img.to(DEV).requires_grad_(True)
+    live = mk(img_d)
+    on = mk(img_d, spot=1)
+    off = mk(img_d, spot=0)
+    assert rel_l2(live, cutouts_ref.make_cutouts(img, prm, S)) < 1e-5
+    assert rel_l2(on, cutouts_ref.make_cutouts_cached(img, prm, S, spot_mask=inside)) < 1e-4
+    assert rel_l2(off, cutouts_ref.make_cutouts_cached(img, prm, S, spot_mask=~inside)) < 1e-4
+    # masked pooled pixels are constants: no gradient reaches the canvas through them
+    (g_on,) = torch.autograd.grad(on.sum(), img_d, retain_graph=True)
+    imr = img.clone().requires_grad_(True)
+    (g_ref,) = torch.autograd.grad(cutouts_ref.make_cutouts_cached(imr, prm, S, spot_mask=inside).sum(), imr)
+    assert rel_l2(g_on, g_ref) < 1e-3, rel_l2(g_on, g_ref)
+    # a live call with a mask (first call of an iteration) works too
+    mk.transforms = None
+    assert rel_l2(mk(img_d, spot=0), cutouts_ref.make_cutouts(img, prm, S, spot_mask=~inside)) < 1e-5
+    mk2 = pc.MakeCutouts(S, cutn)
+    with pytest.raises(ValueError):
+        mk2(img_d, spot=1)
