@@ -115,13 +115,19 @@ __device__ __forceinline__ void store_c_global(const f32x16 (&a)[2][2], bf16_t* 
             }
 }
 
+// Forward, "swapped" formulation: S^T = K Q^T puts one QUERY per lane column (C layout: lane l holds query l&31 of the
+// tile, 16 of its keys in registers, the other 16 in lane l^32), so the softmax is an in-register reduction plus ONE
+// cross-half exchange per statistic instead of a 5-step butterfly per row; and the normalised P^T accumulators are
+// already the A operand of O = P V (rows = queries = this lane, k slots = the keys it holds) -- P never goes through
+// LDS.  The MFMA only needs A and B to agree on which key sits in which k slot: slot 8h+s of step (mi, G) is key
+// 32mi + 16G + 8(s>>2) + 4h + (s&3), which for the B operand (rows = head-dim d of V^T) is two 8-byte reads of the
+// transposed V image.
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T,
                                                      int C, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * TILE];
     bf16_t* Qs = smem;
     bf16_t* Ks = smem + TILE;
     bf16_t* Vt = smem + 2 * TILE;
-    bf16_t* Ps = smem + 3 * TILE;
     const int lane = threadIdx.x;
     const int h = blockIdx.x, n = blockIdx.y;
     const long long ld = 3LL * C;
@@ -130,77 +136,219 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const bf16_t* __restrict__ 
     load_tile(base + C, ld, T, Ks, nullptr, lane);
     load_tile(base + 2 * C, ld, T, nullptr, Vt, lane);
     __syncthreads();
-    f32x16 s[2][2];
-    zero_acc(s);
-    mma_64x64x64(Qs, Ks, s, lane);
-    softmax_c_layout(s, scale, T, lane);
-    store_c_tile(s, Ps, nullptr, lane);
-    __syncthreads();
-    f32x16 o[2][2];
+    f32x16 st[2][2];                       // st[mi][nj]: keys 32mi.., queries 32nj..
+    zero_acc(st);
+    mma_64x64x64(Ks, Qs, st, lane);
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = (j < T) ? st[mi][nj][r] * scale : -INFINITY;
+                st[mi][nj][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[mi][nj][r] - m);
+                st[mi][nj][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mi][nj][r] *= inv;
+    }
+    f32x16 o[2][2];                        // o[nj][dj]: queries 32nj.., head-dim 32dj..
     zero_acc(o);
-    mma_64x64x64(Ps, Vt, o, lane);
-    store_c_global(o, out + (long long)n * T * C + h * 64, C, T, lane);
-}
-
-__global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                     bf16_t* __restrict__ dqkv, int T, int C, float scale) {
-    // Four [64][72] bf16 LDS tiles (36.9 KB -> 4 workgroups per CU, all 768 (image, head) pairs resident at once):
-    //   phase 1: T0=Q T1=K T2=V T3=dO           -> S = QK^T, P (registers), dP = dO V^T, dS (registers)
-    //   phase 2: T0=dS T1=dS^T T2=P^T, T3 = K^T / Q^T / dO^T in turn (re-read from L2) -> dQ, dK, dV
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE];
-    bf16_t* T0 = smem;
-    bf16_t* T1 = smem + TILE;
-    bf16_t* T2 = smem + 2 * TILE;
-    bf16_t* T3 = smem + 3 * TILE;
-    const int lane = threadIdx.x;
-    const int h = blockIdx.x, n = blockIdx.y;
-    const long long ld = 3LL * C;
-    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
-    const bf16_t* dobase = dout + (long long)n * T * C + h * 64;
-    load_tile(base, ld, T, T0, nullptr, lane);
-    load_tile(base + C, ld, T, T1, nullptr, lane);
-    load_tile(base + 2 * C, ld, T, T2, nullptr, lane);
-    load_tile(dobase, C, T, T3, nullptr, lane);
-    __syncthreads();
-
-    f32x16 p[2][2], dp[2][2];
-    zero_acc(p);
-    mma_64x64x64(T0, T1, p, lane);
-    softmax_c_layout(p, scale, T, lane);
-    zero_acc(dp);
-    mma_64x64x64(T3, T2, dp, lane);
-    // dS = scale * P o (dP - rowsum(P o dP))
+    const int c = lane & 31;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float dot = half_sum(p[mi][0][r] * dp[mi][0][r] + p[mi][1][r] * dp[mi][1][r]);
-            dp[mi][0][r] = scale * p[mi][0][r] * (dp[mi][0][r] - dot);
-            dp[mi][1][r] = scale * p[mi][1][r] * (dp[mi][1][r] - dot);
+        for (int G = 0; G < 2; ++G) {
+            bf16x8 pa[2], vb[2];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) pa[nj][s] = (bf16_t)st[mi][nj][8 * G + s];
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const bf16_t* row = Vt + (dj * 32 + c) * LD + 32 * mi + 16 * G + 4 * hh;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 8);
+                vb[dj] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) o[nj][dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[nj], vb[dj], o[nj][dj], 0, 0, 0);
         }
-    __syncthreads();  // all reads of Q/K/V/dO tiles done
-    store_c_tile(dp, T0, T1, lane);        // T0 <- dS, T1 <- dS^T
-    store_c_tile(p, nullptr, T2, lane);    // T2 <- P^T
-    load_tile(base + C, ld, T, nullptr, T3, lane);      // T3 <- K^T
-    __syncthreads();
+    store_c_global(o, out + (long long)n * T * C + h * 64, C, T, lane);
+}
 
+// k-slot convention shared by the register-resident A operands below and the transposed-image B operands: slot 8h + s of
+// step (mi, G) is row 32mi + 16G + 8(s>>2) + 4h + (s&3) of the contraction axis (h = lane >> 5)
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int G) {
+    bf16x8 f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = (bf16_t)a[8 * G + s];
+    return f;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* Tt, int dj, int mi, int G, int lane) {
+    const bf16_t* row = Tt + (dj * 32 + (lane & 31)) * LD + 32 * mi + 16 * G + 4 * (lane >> 5);
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 8);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// out[nj][dj] = sum over the contraction axis of A (accumulators, rows = this lane's column index) x B^T image
+__device__ __forceinline__ void mma_acc_tr(const f32x16 (&a)[2][2], const bf16_t* Tt, f32x16 (&o)[2][2], int lane) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) fa[nj] = acc_frag(a[mi][nj], G);
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) fb[dj] = tr_frag(Tt, dj, mi, G, lane);
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) o[nj][dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nj], fb[dj], o[nj][dj], 0, 0, 0);
+        }
+}
+
+// Backward, same register-resident scheme as the forward, in two orientations:
+//   (1) queries on lanes:  P^T = softmax(K Q^T), dP^T = V dO^T, D_i = sum_j P dP, dS^T  ->  dQ = dS K   (A = dS^T accumulators)
+//   (2) keys on lanes:     P = exp(Q K^T / 8 - lse_i), dP = dO V^T, dS               ->  dK = dS^T Q, dV = P^T dO
+// Orientation 2 recomputes the two score products (32 MFMAs) instead of transposing dS / P through LDS; it gets the
+// per-query log-sum-exp and D_i from orientation 1 through two 64-float LDS arrays.  The B operands K^T, Q^T, dO^T are
+// transposed LDS images built one after the other in the fifth tile.
+__global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                     bf16_t* __restrict__ dqkv, int T, int C, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[5 * TILE];
+    __shared__ __attribute__((aligned(16))) float s_lse[64], s_D[64];
+    bf16_t* Qs = smem;
+    bf16_t* Ks = smem + TILE;
+    bf16_t* Vs = smem + 2 * TILE;
+    bf16_t* dOs = smem + 3 * TILE;
+    bf16_t* Tt = smem + 4 * TILE;
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x, n = blockIdx.y;
+    const int hh = lane >> 5;
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const bf16_t* dobase = dout + (long long)n * T * C + h * 64;
+    load_tile(base, ld, T, Qs, nullptr, lane);
+    load_tile(base + C, ld, T, Ks, Tt, lane);            // K row-major and K^T
+    load_tile(base + 2 * C, ld, T, Vs, nullptr, lane);
+    load_tile(dobase, C, T, dOs, nullptr, lane);
+    __syncthreads();
     bf16_t* obase = dqkv + (long long)n * T * ld + h * 64;
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    mma_64x64x64(T0, T3, acc, lane);       // dQ = dS K
-    store_c_global(acc, obase, ld, T, lane);
+    {   // ---- orientation 1: [key j][query i], lane column = query
+        f32x16 pt[2][2], dpt[2][2];
+        zero_acc(pt);
+        mma_64x64x64(Ks, Qs, pt, lane);
+        zero_acc(dpt);
+        mma_64x64x64(Vs, dOs, dpt, lane);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float v = (j < T) ? pt[mi][nj][r] * scale : -INFINITY;
+                    pt[mi][nj][r] = v;
+                    m = fmaxf(m, v);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __expf(pt[mi][nj][r] - m);
+                    pt[mi][nj][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            float dot = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pt[mi][nj][r] *= inv;
+                    dot += pt[mi][nj][r] * dpt[mi][nj][r];
+                }
+            dot += __shfl_xor(dot, 32, 64);
+            if (hh == 0) { s_lse[nj * 32 + lane] = m + __logf(sum); s_D[nj * 32 + lane] = dot; }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpt[mi][nj][r] = scale * pt[mi][nj][r] * (dpt[mi][nj][r] - dot);   // dS^T
+        }
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        mma_acc_tr(dpt, Tt, acc, lane);                  // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        store_c_global(acc, obase, ld, T, lane);
+    }
+    __syncthreads();                                      // s_lse / s_D visible, K^T image free
+    load_tile(base, ld, T, nullptr, Tt, lane);            // Q^T
+    // ---- orientation 2: [query i][key j], lane column = key
+    f32x16 p[2][2], dp[2][2];
+    zero_acc(p);
+    mma_64x64x64(Qs, Ks, p, lane);
+    zero_acc(dp);
+    mma_64x64x64(dOs, Vs, dp, lane);
+    const int jcol = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int i0 = mi * 32 + 8 * rg + 4 * hh;
+            const float4 l4 = *reinterpret_cast<const float4*>(&s_lse[i0]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&s_D[i0]);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q;
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    const float pv = (nj * 32 + jcol < T) ? __expf(p[mi][nj][r] * scale - lv[q]) : 0.f;
+                    p[mi][nj][r] = pv;
+                    dp[mi][nj][r] = scale * pv * (dp[mi][nj][r] - dv[q]);   // dS
+                }
+            }
+        }
+    __syncthreads();                                      // Q^T image complete
+    {
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        mma_acc_tr(dp, Tt, acc, lane);                    // dK[j][d] = sum_i dS[i][j] Q[i][d]
+        store_c_global(acc, obase + C, ld, T, lane);
+    }
     __syncthreads();
-    load_tile(base, ld, T, nullptr, T3, lane);           // T3 <- Q^T
+    load_tile(dobase, C, T, nullptr, Tt, lane);            // dO^T
     __syncthreads();
-    zero_acc(acc);
-    mma_64x64x64(T1, T3, acc, lane);       // dK = dS^T Q
-    store_c_global(acc, obase + C, ld, T, lane);
-    __syncthreads();
-    load_tile(dobase, C, T, nullptr, T3, lane);          // T3 <- dO^T
-    __syncthreads();
-    zero_acc(acc);
-    mma_64x64x64(T2, T3, acc, lane);       // dV = P^T dO
-    store_c_global(acc, obase + 2 * C, ld, T, lane);
+    {
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        mma_acc_tr(p, Tt, acc, lane);                     // dV[j][d] = sum_i P[i][j] dO[i][d]
+        store_c_global(acc, obase + 2 * C, ld, T, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
