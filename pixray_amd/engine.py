@@ -312,6 +312,9 @@ class Session:
         z = self.drawer.get_z()
         if not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
             return False
+        # image / spot prompts go through the cached-transform path, which stages a fresh descriptor table per call
+        if any(self.pmsImageTable.values()) or any(self.spotPmsTable.values()) or any(self.spotOffPmsTable.values()):
+            return False
         dev = z.device
         for mk in self.cutoutsTable.values():
             if not hasattr(mk, "enable_static_buffers") or getattr(mk, "fixed_params", None) is not None:
