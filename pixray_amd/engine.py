@@ -310,7 +310,7 @@ class Session:
         Host-drawn inputs reach the graph through fixed device buffers (cutout descriptors, Adam scalars).  Falls back
         to eager launches when something in the session cannot be captured (custom optimisers, batches > 1, ...)."""
         z = self.drawer.get_z()
-        if not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
+        if z is None or not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
             return False
         # image / spot prompts go through the cached-transform path, which stages a fresh descriptor table per call
         if any(self.pmsImageTable.values()) or any(self.spotPmsTable.values()) or any(self.spotOffPmsTable.values()):

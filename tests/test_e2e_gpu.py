@@ -391,3 +391,37 @@ def test_config2_vqgan512_vitb16_rn50x4_ensemble_runs():
             first = [float(l.detach()) for l in sess.last_losses]
     assert not torch.equal(sess.drawer.get_z(), z0)
     assert torch.isfinite(sess.drawer.get_z()).all()
+
+
+def test_fft_drawer_plugin_on_the_hip_path():
+    """BASELINE.json configs[3] shape at small size: a spectrum drawer plugin (own optimiser, no z) + a custom loss stack
+    feeding the HIP cutouts / tower / loss; its image gradient comes back through torch.fft"""
+    from pixray_amd.cutouts import MakeCutouts
+    from pixray_amd.engine import Session
+    from pixray_amd.fft_drawer import FftDrawer
+    from pixray_amd.perceptor import get_clip_perceptor
+    from pixray_amd.prompt import Prompt
+
+    class _Saturation(LossInterface):        # batch-coupled like Losses/SaturationLoss.py: std over all cutout pixels
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            cut = next(iter(cur_cutouts.values()))
+            return -cut.std(dim=1).mean() * 0.2
+
+    st = types.SimpleNamespace(size=(160, 96), fft_use="fft", fft_decay=1.5, fft_lrate=0.3)
+    dr = FftDrawer(st)
+    dr.load_model(st, DEV)
+    dr.init_from_tensor(None)
+    perc = get_clip_perceptor("tiny-B/32", DEV, max_batch=8)
+    mk = MakeCutouts(224, 8, generator=torch.Generator().manual_seed(3), aspect_width=160 / 96)
+    pm = Prompt(api.seeded_unit_vectors(1, 128, 9).to(DEV), 1.0, float("-inf")).to(DEV)
+    sess = Session(dr, {"tiny-B/32": perc}, {224: mk}, {"tiny-B/32": [pm]}, custom_losses=[{"loss": _Saturation(device=DEV), "weight": 1.0}],
+                   seed=1)
+    assert not sess.enable_graph()                      # foreign optimiser: stays on eager launches
+    p0 = dr.params[0].detach().clone()
+    first = None
+    for it in range(6):
+        assert sess.train(it)
+        assert len(sess.last_losses) == 2 and all(torch.isfinite(l) for l in sess.last_losses)
+        first = first if first is not None else float(sess.last_losses[0].detach())
+    assert (dr.params[0].detach() - p0).abs().max() > 1e-3
+    assert float(sess.last_losses[0].detach()) < first + 0.05

@@ -166,14 +166,17 @@ class _Settings(types.SimpleNamespace):
     pass
 
 
-def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0, group=None, seed=0):
+def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0, group=None, seed=0, drawer=None):
     cfg = weights.CLIP_CONFIGS["ViT-B/32"]
     params = weights.synthetic_clip_vit_params(cfg, 1)
-    st = _Settings(size=(256, 256), pixel_size=(16, 16), pixel_scale=None)
-    drawer = PixelGridDrawer(st)
-    drawer.load_model(st, "cpu")
     g = torch.Generator().manual_seed(7)
-    drawer.init_from_tensor(torch.rand(1, 3, 256, 256, generator=g) * 2 - 1)
+    if drawer is None:
+        st = _Settings(size=(256, 256), pixel_size=(16, 16), pixel_scale=None)
+        drawer = PixelGridDrawer(st)
+        drawer.load_model(st, "cpu")
+        drawer.init_from_tensor(torch.rand(1, 3, 256, 256, generator=g) * 2 - 1)
+    else:
+        torch.rand(1, 3, 256, 256, generator=g)
     perceptor = step_ref.OraclePerceptor(cfg, params)
 
     def sampler(iteration, fill):
@@ -205,6 +208,38 @@ def test_config0_pixel_grid_vit_b32_cutn2_10_iterations_cpu():
     assert sess.drawer.get_z().min() >= 0 and sess.drawer.get_z().max() <= 1      # clip_z
     img = sess.drawer.to_image()
     assert img.size == (256, 256)
+
+
+def test_fft_drawer_plugin_runs_with_its_own_optimiser_cpu():
+    """BASELINE.json configs[3]'s drawer as a plugin (fftdrawer.py:13-110): get_opts() returns its own Adam over the
+    spectrum (pixray.py:525-527), get_z() is None, clip_z() is a no-op -- the loop must cope with all of that"""
+    from pixray_amd.fft_drawer import FftDrawer, rfft2d_freqs
+    st = _Settings(size=(96, 64), fft_use="fft", fft_decay=1.5, fft_lrate=0.3)
+    dr = FftDrawer(st)
+    dr.load_model(st, "cpu")
+    dr.init_from_tensor(None)
+    assert dr.params[0].shape == (1, 3, 64, 96 // 2 + 1, 2) and rfft2d_freqs(64, 96).shape == (64, 49)
+    img = dr.synth(0)
+    assert img.shape == (1, 3, 64, 96) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+    sess = _cpu_session(cutn=2, drawer=dr)
+    assert sess.opts is dr.opts and sess.opts[0].param_groups[0]["lr"] == 0.3
+    p0 = dr.params[0].detach().clone()
+    for it in range(3):
+        assert sess.train(it)
+        assert all(torch.isfinite(l).all() for l in sess.last_losses)
+    assert (dr.params[0].detach() - p0).abs().max() > 1e-3
+    assert dr.get_z() is None and dr.get_num_resolutions() is None
+    assert dr.to_image().size == (96, 64)
+    # starting from an image reproduces it (up to the contrast normalisation synth applies)
+    g = torch.Generator().manual_seed(0)
+    t = torch.rand(1, 3, 64, 96, generator=g)
+    dr.reapply_from_tensor(t * 2 - 1)
+    with torch.no_grad():
+        spec = torch.view_as_complex((dr._scale * dr.params[0]).contiguous())
+        rec = torch.sigmoid(torch.einsum("nchw,cd->ndhw", torch.fft.irfftn(spec, s=(64, 96), dim=(-2, -1), norm="ortho"), dr._colors))
+    assert (rec - t.clamp(1e-3, 1 - 1e-3)).abs().max() < 1e-4
+    with pytest.raises(ValueError):
+        bad = FftDrawer(_Settings(size=(32, 32), fft_use="dwt")); bad.load_model(None, "cpu"); bad.init_from_tensor(None)
 
 
 def _load_reference_plugin(relpath, clsname):
