@@ -131,10 +131,10 @@ def main():
             roofline = {"bound": "mfma", "kernel": "gemm_glds_kernel<BM,BN,AMODE,STAGES,..> (bf16 MFMA GEMM / implicit 3x3 conv, all launches)",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                        # HBM-side bytes per GEMM launch from the PMC passes committed in profiles/r01_e_pmc_hbm_traffic.csv
+                        # HBM-side bytes per GEMM launch from the PMC passes committed in profiles/r01_h_pmc_hbm_traffic.csv
                         # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH doubled per the gfx950
                         # correction of MI355X_MICROARCH.md); not re-measured live
-                        "traffic": 40.9e6, "traffic_source": "profiles/r01_e_pmc_hbm_traffic.csv",
+                        "traffic": 42.5e6, "traffic_source": "profiles/r01_h_pmc_hbm_traffic.csv",
                         "launches_per_step": n.value // args.profile_steps,
                         "gemm_gflop_per_step": round(fl.value / args.profile_steps / 1e9, 1),
                         "gemm_ms_per_step": round(ms.value / args.profile_steps, 3),
