@@ -312,6 +312,9 @@ int prx_k_mha_bwd_gen(const void* qkv, const void* out, const void* dout, const 
 void prx_gemm_variant(int use_glds);
 /* tuning override of the tile / split-K heuristic: bm,bn in {(128,128),(128,64),(64,64)}; (0,0,0) = heuristic */
 void prx_gemm_tile_override(int bm, int bn, int splits);
+/* the same per problem shape (tools/gemm_rules.py): mode = a_mode + 2*up + 4*a_is_f32; splits 0 = heuristic; bm = 0 drops
+ * the rule, M = 0 drops all rules */
+void prx_gemm_tile_rule(int M, int N, int K, int mode, int bm, int bn, int splits);
 
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
 void prx_profile_gemm_enable(int on);

@@ -56,6 +56,7 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
 void prx_profile_gemm_enable(int on) { prx_gemm_profile_enable(on); }
 void prx_gemm_variant(int use_glds) { prx_gemm_set_variant(use_glds); }
 void prx_gemm_tile_override(int bm, int bn, int splits) { prx_gemm_force_tile(bm, bn, splits); }
+void prx_gemm_tile_rule(int M, int N, int K, int mode, int bm, int bn, int splits) { prx_gemm_tile_rule_set(M, N, K, mode, bm, bn, splits); }
 int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches) {
     return prx_gemm_profile_collect(total_ms, total_flop, launches);
 }

@@ -60,5 +60,6 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
 // launch stream).  When enabled every prx_gemm_launch is bracketed by events.
 void prx_gemm_set_variant(int use_glds);   // 1 (default): direct-to-LDS v2 kernel for bf16 A; 0: register-staged v1
 void prx_gemm_force_tile(int bm, int bn, int splits);   // tuning override; (0,0,0) restores the heuristic
+void prx_gemm_tile_rule_set(int M, int N, int K, int mode, int bm, int bn, int splits);   // per-shape override; bm=0 drops it, M=0 drops all
 void prx_gemm_profile_enable(int on);
 int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches);

@@ -769,8 +769,18 @@ int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
 int g_force_stages = (getenv("PRX_GEMM_STAGES") ? atoi(getenv("PRX_GEMM_STAGES")) : 0);
 int g_xcd_swizzle = (getenv("PRX_XCD_SWIZZLE") ? atoi(getenv("PRX_XCD_SWIZZLE")) : 2);   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
 std::vector<ProfRec> g_prof;
+// per-shape tuning rules (tools/gemm_rules.py): (M, N, K, mode) -> tile / split-K, consulted before the heuristic
+struct TileRule { int M, N, K, mode, bm, bn, splits; };
+std::vector<TileRule> g_rules;
 
 }  // namespace
+
+void prx_gemm_tile_rule_set(int M, int N, int K, int mode, int bm, int bn, int splits) {
+    if (M <= 0) { g_rules.clear(); return; }
+    for (size_t i = 0; i < g_rules.size(); ++i)
+        if (g_rules[i].M == M && g_rules[i].N == N && g_rules[i].K == K && g_rules[i].mode == mode) { g_rules.erase(g_rules.begin() + i); break; }
+    if (bm > 0) g_rules.push_back({M, N, K, mode, bm, bn, splits});
+}
 
 void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
 void prx_gemm_force_tile(int bm, int bn, int splits) {
@@ -846,6 +856,12 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         if (wide_tile == 128 && d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
     }
     if (g_force_bm) { BM = g_force_bm; BN = g_force_bn; }
+    int rule_splits = 0;
+    if (!g_rules.empty()) {
+        const int mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32;
+        for (const TileRule& r : g_rules)
+            if (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode) { BM = r.bm; BN = r.bn; rule_splits = r.splits; }
+    }
     GemmArgs a;
     a.d = d;
     a.tiles_m = ceil_div(d.M, BM);
@@ -863,8 +879,8 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
                 al(d.aux, 8) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
                 (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, 8) && al(d.out_bf16_pre, 8) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
-    if (g_force_splits > 0 && ws) {
-        splits = std::min(g_force_splits, a.kt_total);
+    if ((g_force_splits > 0 || rule_splits > 0) && ws) {
+        splits = std::min(rule_splits > 0 ? rule_splits : g_force_splits, a.kt_total);
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
     // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative

@@ -1,0 +1,98 @@
+"""In-pipeline tile / split-K sweep per GEMM shape (run on the GPU box).
+
+For each of the heaviest problem shapes of the headline iteration, try every tile shape x a few split-K factors through
+`prx_gemm_tile_rule`, time that shape's launches with the engine's HIP events while the rest of the iteration runs
+unchanged (cold weights, real neighbours), and print what beats the heuristic by more than the noise."""
+import collections
+import ctypes
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+top = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+path = os.path.join(tempfile.gettempdir(), "prx_gemm_rules.csv")
+os.environ["PRX_GEMM_PROFILE_DUMP"] = path
+import torch
+from pixray_amd import _lib, api
+
+dev = torch.device("cuda", 0)
+sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
+                                    num_cuts=64, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev)
+lib = _lib.load()
+it = [0]
+
+
+def run(n):
+    for _ in range(n):
+        sess.train(it[0]); it[0] += 1
+    torch.cuda.synchronize()
+
+
+def measure():
+    """{(M,N,K,mode): (launches/iter, us per launch, (bm,bn,splits))}, total ms/iter"""
+    if os.path.exists(path):
+        os.remove(path)
+    lib.prx_profile_gemm_enable(1)
+    run(steps)
+    lib.prx_profile_gemm_enable(0)
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+    agg = collections.OrderedDict()
+    for line in open(path):
+        M, N, K, mode, bm, bn, sp, us = line.strip().split(",")
+        a = agg.setdefault((int(M), int(N), int(K), int(mode)), [0, 0.0, None])
+        a[0] += 1; a[1] += float(us); a[2] = (int(bm), int(bn), int(sp))
+    return {k: (v[0] / steps, v[1] / v[0], v[2]) for k, v in agg.items()}, ms.value / steps
+
+
+run(4)
+base, base_ms = measure()
+base2, base_ms2 = measure()
+print(f"baseline GEMM engine {base_ms:.3f} / {base_ms2:.3f} ms per iteration (two passes = the noise)")
+order = sorted(base, key=lambda k: -base[k][0] * base[k][1])[:top]
+wins = []
+for key in order:
+    M, N, K, mode = key
+    cnt, us0, cfg0 = base[key]
+    us0b = base2[key][1]
+    kt = (K + 63) // 64
+    row = f"{M:6d} {N:5d} {K:5d} m{mode} x{cnt:4.1f}  heuristic {cfg0[0]}x{cfg0[1]} s{cfg0[2]}: {us0:6.1f} / {us0b:6.1f} us |"
+    best = (min(us0, us0b), cfg0)
+    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+        if N <= 64 and bn > 64:
+            continue
+        tiles = -(-M // bm) * -(-N // bn)
+        cands = {1}
+        if tiles <= 256:
+            for tgt in (192, 256, 320, 448, 640):
+                s = max(1, min(round(tgt / tiles), kt // 2, 32))
+                cands.add(s)
+        for sp in sorted(cands):
+            if (bm, bn, sp) == cfg0:
+                continue
+            lib.prx_gemm_tile_rule(M, N, K, mode, bm, bn, sp)
+            try:
+                r, _ = measure()
+            except Exception as e:                      # a shape a tile cannot take (fused-stat constraints)
+                print("   skip", key, bm, bn, sp, str(e)[:80])
+                lib.prx_gemm_tile_rule(M, N, K, mode, 0, 0, 0)
+                continue
+            lib.prx_gemm_tile_rule(M, N, K, mode, 0, 0, 0)
+            us = r[key][1]
+            row += f" {bm}x{bn}s{sp}:{us:6.1f}"
+            if us < best[0]:
+                best = (us, (bm, bn, sp))
+    print(row)
+    if best[1] != cfg0 and best[0] < 0.96 * min(us0, us0b):
+        wins.append((key, cfg0, best[1], us0, best[0], cnt))
+print("\nbeats the heuristic by > 4 %:")
+for key, c0, c1, u0, u1, cnt in wins:
+    print(f"  {key}: {c0} {u0:.1f} us -> {c1} {u1:.1f} us  (x{cnt:.0f}/iter = {(u0 - u1) * cnt / 1e3:.3f} ms)")
+# confirm the winners together
+for key, c0, c1, *_ in wins:
+    lib.prx_gemm_tile_rule(*key, *c1)
+if wins:
+    _, ms_all = measure()
+    print(f"all winners applied: GEMM engine {ms_all:.3f} ms per iteration (baseline {base_ms:.3f} / {base_ms2:.3f})")
