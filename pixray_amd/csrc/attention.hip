@@ -50,7 +50,15 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-// load a [T][64] bf16 tile (row stride ld) into dst[t][d] and optionally dstT[d][t]; rows >= T are zero
+// Column swizzle of the transposed images written by load_tile and read by tr_frag: element (d, t) lives at column
+// t ^ tr_swz(d).  Unswizzled, the 64 two-byte writes of one instruction land in 8 banks (rows 8 apart are 1152 B = 0 mod
+// 128 apart) and the 8-byte fragment reads of rows d and d+16 collide; with bits 4-5 of d moved into bits 2-4 of the
+// column both are conflict-free in a 64-bank model (exhaustive search over the linear swizzles; the unswizzled kernel showed
+// SQ_LDS_BANK_CONFLICT = 18 % of its wave cycles, profiles/r01_h_pmc_sq_stalls.csv).  Worth 0.02 ms per iteration.
+// Only bits >= 2 of t change, so the 4-element groups the reader fetches stay contiguous.
+__device__ __forceinline__ int tr_swz(int d) { return (((d >> 4) & 1) * 12) ^ (((d >> 5) & 1) * 16); }
+
+// load a [T][64] bf16 tile (row stride ld) into dst[t][d] and optionally dstT[d][t ^ tr_swz(d)]; rows >= T are zero
 __device__ __forceinline__ void load_tile(const bf16_t* src, long long ld, int T, bf16_t* dst, bf16_t* dstT, int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -61,7 +69,7 @@ __device__ __forceinline__ void load_tile(const bf16_t* src, long long ld, int T
         if (dst) *reinterpret_cast<bf16x8*>(&dst[row * LD + kc * 8]) = v;
         if (dstT) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dstT[(kc * 8 + e) * LD + row] = v[e];
+            for (int e = 0; e < 8; ++e) dstT[(kc * 8 + e) * LD + (row ^ tr_swz(kc * 8))] = v[e];
         }
     }
 }
@@ -183,9 +191,9 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const bf16_t* __restrict__ 
                 for (int s = 0; s < 8; ++s) pa[nj][s] = (bf16_t)st[mi][nj][8 * G + s];
 #pragma unroll
             for (int dj = 0; dj < 2; ++dj) {
-                const bf16_t* row = Vt + (dj * 32 + c) * LD + 32 * mi + 16 * G + 4 * hh;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 8);
+                const int d = dj * 32 + c, t0 = 32 * mi + 16 * G + 4 * hh, sw = tr_swz(d);
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Vt + d * LD + (t0 ^ sw));
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Vt + d * LD + ((t0 + 8) ^ sw));
                 vb[dj] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
@@ -205,9 +213,9 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int G) {
     return f;
 }
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* Tt, int dj, int mi, int G, int lane) {
-    const bf16_t* row = Tt + (dj * 32 + (lane & 31)) * LD + 32 * mi + 16 * G + 4 * (lane >> 5);
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 8);
+    const int d = dj * 32 + (lane & 31), t0 = 32 * mi + 16 * G + 4 * (lane >> 5), sw = tr_swz(d);
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Tt + d * LD + (t0 ^ sw));
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Tt + d * LD + ((t0 + 8) ^ sw));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 // out[nj][dj] = sum over the contraction axis of A (accumulators, rows = this lane's column index) x B^T image
