@@ -32,6 +32,29 @@ def spherical_dist_loss(x, y):
     return (x - y).norm(dim=-1).div(2).arcsin().pow(2).mul(2)
 
 
+class _GatherShards(torch.autograd.Function):
+    """all-gather of the ranks' cutout (or embedding) shards along dim 0 for batch-coupled custom losses (SURVEY.md §8e:
+    `SaturationLoss` takes a std over all cutout pixels, `AestheticLoss` sizes its target by num_cuts).  Every rank then
+    evaluates the same full-batch loss; its backward keeps only the gradient of the rank's own shard, so the
+    all-reduce of dL/d(image) that follows adds the shards' contributions up exactly once."""
+
+    @staticmethod
+    def forward(ctx, x, group, rank, world):
+        import torch.distributed as dist
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        ctx.rank, ctx.n = rank, x.shape[0]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None, None, None
+
+
+# custom losses that couple the whole cutout batch (class names; a loss can also set `needs_full_batch = True`)
+FULL_BATCH_LOSSES = {"SaturationLoss", "AestheticLoss", "ResmemLoss"}
+
+
 class HipAdam(torch.optim.Optimizer):
     """`optim.Adam([z], lr)` (pixray.py:539) on the fused HIP Adam(+clip_z) kernel. One fp32 tensor.
 
@@ -268,9 +291,20 @@ class Session:
             f2 = self.z_orig.reshape(1, -1)
             result.append(F.cosine_embedding_loss(f, f2, torch.ones_like(f[0])) * self.init_weight_cos)
         needed_globals = {"cur_iteration": it, "embeds": iii}                                  # pixray.py:1377-1381
+        full_cutouts = full_globals = None
         for t in self.custom_losses:
             w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]
-            new_losses = t["loss"].get_loss(cur_cutouts, out, self.args, globals=needed_globals,
+            cuts, glb = cur_cutouts, needed_globals
+            if self.world_size > 1 and (getattr(t["loss"], "needs_full_batch", False)
+                                        or type(t["loss"]).__name__ in FULL_BATCH_LOSSES):
+                # batch-coupled loss: every rank scores the FULL cutout batch (gathered, differentiable through the rank's
+                # own shard only), so its weight is not divided by the world size.  Such a loss must not also read `out`.
+                if full_cutouts is None:
+                    gather = lambda x: _GatherShards.apply(x, self.group, self.rank, self.world_size)
+                    full_cutouts = {size: gather(c) for size, c in cur_cutouts.items()}
+                    full_globals = dict(needed_globals, embeds=gather(iii) if iii is not None else None)
+                cuts, glb, w = full_cutouts, full_globals, t["weight"]
+            new_losses = t["loss"].get_loss(cuts, out, self.args, globals=glb,
                                             lossGlobals=self.lossGlobals)
             if not isinstance(new_losses, (list, tuple)):
                 result.append(w * new_losses)

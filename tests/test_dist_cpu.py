@@ -27,7 +27,23 @@ def _free_port():
     return p
 
 
-def _build(cutn, world, rank, group):
+class SaturationLoss:
+    """same arithmetic as the reference plugin of that name (Losses/SaturationLoss.py:15-30): a colourfulness score from
+    std / mean over ALL cutout pixels -- batch-coupled, so sharded runs must gather the batch for it"""
+
+    def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+        res = []
+        for _, cutouts in cur_cutouts.items():
+            px = cutouts.permute(0, 2, 3, 1).reshape(-1, 3)
+            rg = px[:, 0] - px[:, 1]
+            yb = 0.5 * (px[:, 0] + px[:, 1]) - px[:, 2]
+            rg_std, rg_mean = torch.std_mean(rg)
+            yb_std, yb_mean = torch.std_mean(yb)
+            res.append(-(torch.sqrt(rg_std ** 2 + yb_std ** 2) + 0.3 * torch.sqrt(rg_mean ** 2 + yb_mean ** 2)) / 10.0)
+        return res
+
+
+def _build(cutn, world, rank, group, coupled_loss=False):
     from oracle import prompt_ref, step_ref
     from pixray_amd import cutouts as pc, weights
     from pixray_amd.engine import Session
@@ -61,16 +77,17 @@ def _build(cutn, world, rank, group):
             if self.denom is None:
                 return full
             return full * (x.shape[0] * e.shape[0]) / self.denom      # rescale to the global mean
+    custom = [{"loss": SaturationLoss(), "weight": 3.0}] if coupled_loss else []
     return Session(drawer, {"tiny-B/32": perceptor}, {224: mk}, {"tiny-B/32": [_P()]}, learning_rate=0.05, iterations=10,
-                   seed=3, world_size=world, rank=rank, group=group)
+                   seed=3, world_size=world, rank=rank, group=group, custom_losses=custom)
 
 
-def _worker(rank, world, port, cutn, q):
+def _worker(rank, world, port, cutn, q, coupled_loss=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    sess = _build(cutn, world, rank, dist.group.WORLD)
+    sess = _build(cutn, world, rank, dist.group.WORLD, coupled_loss)
     for it in range(2):
         sess.train(it)
     q.put((rank, sess.drawer.get_z().detach().numpy().copy(), sess.drawer.get_z().grad.detach().numpy().copy(),
@@ -105,6 +122,35 @@ def test_world2_gloo_matches_single_process():
     assert (z0 - z_ref).abs().max().item() < 1e-5
     # each rank's loss is its share of the global mean; the shares add up to the full-batch loss
     assert abs((l0 + l1) - float(sum(l.detach() for l in ref.last_losses))) < 1e-5
+
+
+def test_world2_batch_coupled_custom_loss_is_scored_on_the_gathered_batch():
+    """a SaturationLoss-style plugin (std over all cutout pixels) on 2 ranks: the loop gathers the cutout shards for it,
+    so z, its gradient and the loss value equal the single-process run (the per-shard std would not)"""
+    cutn, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cutn, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None, True)
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    (_, z0, g0, l0), (_, z1, g1, l1) = res
+    z0, g0, z1, g1 = [torch.from_numpy(t) for t in (z0, g0, z1, g1)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (z0 - z_ref).abs().max().item() < 1e-5
+    # the prompt shares add up; the coupled loss is the same full-batch value on both ranks (counted once)
+    sat_ref = float(ref.last_losses[-1].detach())
+    assert abs((l0 + l1) - (float(sum(l.detach() for l in ref.last_losses)) + sat_ref)) < 1e-5
 
 
 def test_cutn_must_divide_world_size():
