@@ -174,6 +174,22 @@ int prx_vqgan_enc_create(prx_vqgan_enc** out, const prx_vqgan_config* cfg, int i
 void prx_vqgan_enc_destroy(prx_vqgan_enc* h);
 int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre, int* indices, prx_stream_t s);
 
+/* --- VGG16 feature extractor of the StyleLoss plugin (Losses/StyleLoss.py:24-47: torchvision `vgg16().features`, frozen,
+ * the nine captured ReLU outputs at features[1,3,6,8,11,13,15,22,29]).  Batch 1, any H x W in [16, max] x [16, max].
+ * weights: fp32 device pointers in torchvision order {features.N.weight [Cout,Cin,3,3], features.N.bias} for the 13 convs.
+ * x: [3,H,W] fp32, already in the extractor's input space (StyleLoss.py:41-45 normalises outside this call).
+ * feats[k] (k = 0..8, or NULL when not wanted): fp32 NHWC [h_k*w_k, C_k], shape from prx_vgg16_feature_shape.
+ * workspace: caller-owned device buffer of prx_vgg16_workspace_bytes(H, W) bytes holding this forward's activations; the
+ * matching backward reads it, so any number of forward passes can be alive at once.
+ * backward: g_feats[k] fp32 NHWC gradient of feature k (or NULL); g_x: [3,H,W] fp32, overwritten. */
+typedef struct prx_vgg16 prx_vgg16;
+int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, prx_stream_t s);
+void prx_vgg16_destroy(prx_vgg16* h);
+long long prx_vgg16_workspace_bytes(int H, int W);
+int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c);
+int prx_vgg16_forward(prx_vgg16* h, const float* x, int H, int W, void* workspace, float* const* feats, prx_stream_t s);
+int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, prx_stream_t s);
+
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
  *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination

@@ -3,6 +3,7 @@
 #include "vit.h"
 #include "vqgan.h"
 #include "vqgan_enc.h"
+#include "vgg.h"
 #include "clip_text.h"
 #include "resnet.h"
 #include "cutouts.h"
@@ -45,6 +46,22 @@ int prx_vqgan_enc_create(prx_vqgan_enc** out, const prx_vqgan_config* c, int in_
                                      n_weights, S_(s));
 }
 void prx_vqgan_enc_destroy(prx_vqgan_enc* h) { prx_vqgan_enc_destroy_impl((PrxVqganEnc*)h); }
+
+int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, prx_stream_t s) {
+    return prx_vgg16_create_impl((PrxVgg16**)out, weights, n_weights, max_h, max_w, S_(s));
+}
+void prx_vgg16_destroy(prx_vgg16* h) { prx_vgg16_destroy_impl((PrxVgg16*)h); }
+long long prx_vgg16_workspace_bytes(int H, int W) { return prx_vgg16_workspace_bytes_impl(H, W); }
+int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c) {
+    PRX_REQUIRE(h && w && c, "prx_vgg16_feature_shape: null argument");
+    return prx_vgg16_feature_shape_impl(H, W, k, h, w, c);
+}
+int prx_vgg16_forward(prx_vgg16* h, const float* x, int H, int W, void* workspace, float* const* feats, prx_stream_t s) {
+    return prx_vgg16_forward_impl((PrxVgg16*)h, x, H, W, workspace, feats, S_(s));
+}
+int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, prx_stream_t s) {
+    return prx_vgg16_backward_impl((PrxVgg16*)h, H, W, workspace, g_feats, g_x, S_(s));
+}
 int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre, int* indices, prx_stream_t s) {
     PRX_REQUIRE(h && img && z, "prx_vqgan_encode: null argument");
     return prx_vqgan_encode_impl((PrxVqganEnc*)h, img, z, z_pre, indices, S_(s));

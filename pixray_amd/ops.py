@@ -430,3 +430,76 @@ def adam_clamp_step(z, exp_avg, exp_avg_sq, grad, zmin, zmax, lr, step, betas=(0
     hw = z.shape[-1] * z.shape[-2]
     call("prx_adam_clamp_step", z, exp_avg, exp_avg_sq, grad, zmin, zmax, hw, z.numel(), float(lr), float(betas[0]),
          float(betas[1]), float(eps), int(step), _stream())
+
+
+# --------------------------------------------------------------------------------------- VGG16 features (StyleLoss plugin)
+VGG16_CONV_INDICES = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)       # torchvision vgg16().features conv layers
+VGG16_CAPTURE_LAYERS = (1, 3, 6, 8, 11, 13, 15, 22, 29)                     # Losses/StyleLoss.py:31
+
+
+class Vgg16Handle:
+    """Owns a `prx_vgg16` (torchvision VGG16 `features` up to relu5_3, frozen) for inputs up to `max_hw`.
+    `params`: {"features.N.weight", "features.N.bias"} (torchvision state-dict names)."""
+
+    def __init__(self, params, max_hw, device):
+        ws = []
+        for i in VGG16_CONV_INDICES:
+            ws.append(params[f"features.{i}.weight"].to(device=device, dtype=torch.float32).contiguous())
+            ws.append(params[f"features.{i}.bias"].to(device=device, dtype=torch.float32).contiguous())
+        h = ctypes.c_void_p()
+        call("prx_vgg16_create", ctypes.addressof(h), _keep(self, _weight_array(ws)), len(ws), int(max_hw[0]), int(max_hw[1]), _stream())
+        torch.cuda.synchronize(device)
+        self.h = h
+        self.max_hw = (int(max_hw[0]), int(max_hw[1]))
+        self.device = device
+
+    def feature_shape(self, H, W, k):
+        h, w, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        call("prx_vgg16_feature_shape", int(H), int(W), int(k), ctypes.addressof(h), ctypes.addressof(w), ctypes.addressof(c))
+        return h.value, w.value, c.value
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().prx_vgg16_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class _Vgg16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, handle):
+        _need_cuda(x)
+        assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3, "the VGG16 extractor takes one [1,3,H,W] image"
+        H, W = int(x.shape[2]), int(x.shape[3])
+        x = x.detach().to(torch.float32).contiguous()
+        nbytes = call("prx_vgg16_workspace_bytes", H, W)
+        if nbytes <= 0:
+            raise PrxError(f"VGG16 extractor: input {H}x{W} is too small")
+        work = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+        feats = []
+        for k in range(len(VGG16_CAPTURE_LAYERS)):
+            h, w, c = handle.feature_shape(H, W, k)
+            feats.append(torch.empty(1, h, w, c, dtype=torch.float32, device=x.device))
+        arr = (ctypes.c_void_p * len(feats))(*[f.data_ptr() for f in feats])
+        call("prx_vgg16_forward", handle.h, x, H, W, work, ctypes.addressof(arr), _stream())
+        ctx.handle, ctx.work, ctx.hw = handle, work, (H, W)
+        ctx.mark_non_differentiable()
+        return tuple(feats)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        H, W = ctx.hw
+        keep = [None if g is None else g.to(torch.float32).contiguous() for g in gs]
+        arr = (ctypes.c_void_p * len(keep))(*[None if g is None else g.data_ptr() for g in keep])
+        gx = torch.empty(1, 3, H, W, dtype=torch.float32, device=ctx.work.device)
+        call("prx_vgg16_backward", ctx.handle.h, H, W, ctx.work, ctypes.addressof(arr), gx, _stream())
+        return gx, None
+
+
+def vgg16_features(x, handle: Vgg16Handle):
+    """x [1,3,H,W] (already normalised for VGG) -> the nine captured feature maps as NHWC fp32 tensors [1,h,w,C]
+    (channels-last is the engine's layout; `f.permute(0,3,1,2)` is the reference's NCHW view)."""
+    return _Vgg16Fn.apply(x, handle)

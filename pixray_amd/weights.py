@@ -457,3 +457,34 @@ def fold_clip_resnet_params(cfg: ClipResNetConfig, p) -> "OrderedDict[str, torch
     out["attnpool.c_proj.weight"] = p["attnpool.c_proj.weight"].float()
     out["attnpool.c_proj.bias"] = p["attnpool.c_proj.bias"].float()
     return out
+
+
+# ------------------------------------------------------------------------------------------ VGG16 (StyleLoss plugin)
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)   # torchvision cfg "D" to relu5_3
+
+
+def vgg16_param_shapes() -> "OrderedDict[str, tuple]":
+    """torchvision `vgg16().features` state-dict names and shapes (conv layers 0,2,5,...,28)."""
+    sh: "OrderedDict[str, tuple]" = OrderedDict()
+    idx, cin = 0, 3
+    for v in VGG16_CFG:
+        if v == "M":
+            idx += 1
+            continue
+        sh[f"features.{idx}.weight"] = (v, cin, 3, 3)
+        sh[f"features.{idx}.bias"] = (v,)
+        cin = v
+        idx += 2
+    return sh
+
+
+def synthetic_vgg16_params(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded He-initialised weights (no checkpoint exists offline): activations stay O(1) through the 13 ReLU layers."""
+    g = torch.Generator().manual_seed(seed + 1616)
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in vgg16_param_shapes().items():
+        if name.endswith("bias"):
+            out[name] = 0.05 * torch.randn(shape, generator=g)
+        else:
+            out[name] = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[1] * 9))
+    return out

@@ -6,6 +6,7 @@ Stated tolerances for the bf16-operand / fp32-accumulate path:
 0.999 at the headline config, at every step of a teacher-forced multi-step run (free-running trajectories of this
 chaotic loop -- hard VQ argmin + Adam at lr 0.2 -- decorrelate after a few steps in ANY two fp implementations).
 """
+import math
 import os
 import sys
 import types
@@ -425,3 +426,51 @@ def test_fft_drawer_plugin_on_the_hip_path():
         first = first if first is not None else float(sess.last_losses[0].detach())
     assert (dr.params[0].detach() - p0).abs().max() > 1e-3
     assert float(sess.last_losses[0].detach()) < first + 0.05
+
+
+def test_config3_custom_loss_stack_styleloss_plus_saturation_on_the_fft_drawer():
+    """BASELINE.json configs[3] at small size: fft drawer + ViT perceptor + the StyleLoss (HIP VGG16 extractor, STROTSS) and
+    SaturationLoss plugins stacked through the unchanged LossInterface; StyleLoss starts at --styleloss_skip"""
+    import argparse
+    import warnings
+    from pixray_amd import style_loss as sl
+    from pixray_amd.cutouts import MakeCutouts
+    from pixray_amd.engine import Session
+    from pixray_amd.fft_drawer import FftDrawer
+    from pixray_amd.perceptor import get_clip_perceptor
+    from pixray_amd.prompt import Prompt
+
+    class SaturationLoss(LossInterface):     # Losses/SaturationLoss.py:15-30
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            res = []
+            for _, cutouts in cur_cutouts.items():
+                px = cutouts.permute(0, 2, 3, 1).reshape(-1, 3)
+                rg, yb = px[:, 0] - px[:, 1], 0.5 * (px[:, 0] + px[:, 1]) - px[:, 2]
+                rg_std, rg_mean = torch.std_mean(rg)
+                yb_std, yb_mean = torch.std_mean(yb)
+                res.append(-(torch.sqrt(rg_std ** 2 + yb_std ** 2) + .3 * torch.sqrt(rg_mean ** 2 + yb_mean ** 2)) / 10.0)
+            return res
+
+    st = types.SimpleNamespace(size=(96, 80), fft_use="fft", fft_decay=1.5, fft_lrate=0.3)
+    dr = FftDrawer(st)
+    dr.load_model(st, DEV)
+    dr.init_from_tensor(None)
+    perc = get_clip_perceptor("tiny-B/32", DEV, max_batch=8)
+    mk = MakeCutouts(224, 8, generator=torch.Generator().manual_seed(3), aspect_width=96 / 80)
+    pm = Prompt(api.seeded_unit_vectors(1, 128, 9).to(DEV), 1.0, float("-inf")).to(DEV)
+    args = sl.StyleLoss.add_settings(argparse.ArgumentParser()).parse_args(["--styleloss_skip", "2", "--styleloss_content_weight", "8"])
+    style = sl.StyleLoss(vgg_params=weights.synthetic_vgg16_params(0), style_image=torch.rand(1, 3, 50, 60, generator=torch.Generator().manual_seed(4)),
+                         device=DEV)
+    args = style.parse_settings(args)
+    sess = Session(dr, {"tiny-B/32": perc}, {224: mk}, {"tiny-B/32": [pm]}, args=args, seed=1,
+                   custom_losses=[{"loss": style, "weight": 1.0}, {"loss": SaturationLoss(device=DEV), "weight": 1.0}])
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(4):
+            p0 = dr.params[0].detach().clone()
+            assert sess.train(it)
+            vals = [float(l.detach()) for l in sess.last_losses]
+            assert len(vals) == 3 and all(math.isfinite(v) for v in vals)
+            assert (vals[1] == 0.0) == (it < 2)              # StyleLoss is silent before --styleloss_skip
+            assert (dr.params[0].detach() - p0).abs().max() > 0

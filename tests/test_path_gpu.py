@@ -518,3 +518,75 @@ def test_make_cutouts_spot_masks_vs_oracle():
     mk2 = pc.MakeCutouts(S, cutn)
     with pytest.raises(ValueError):
         mk2(img_d, spot=1)
+
+
+# ------------------------------------------------------------------------------------------ VGG16 extractor (StyleLoss plugin)
+@pytest.mark.parametrize("H,W", [(64, 48), (50, 70), (128, 128)])
+def test_vgg16_features_and_input_gradient_match_the_oracle(H, W):
+    """the nine captured ReLU maps (Losses/StyleLoss.py:31) and d(sum_k <feat_k, r_k>)/dx against the fp32 oracle; odd
+    sizes exercise the floor of the 2x2 pools.  bf16 operands through up to 13 conv+ReLU layers: 2e-2 on the maps; the
+    gradient additionally sees ReLU masks flip where a bf16-rounded pre-activation changes sign (cosine bound)."""
+    from oracle import vgg_ref
+    params = weights.synthetic_vgg16_params(0)
+    handle = ops.Vgg16Handle(params, (128, 128), torch.device(DEV))
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(1, 3, H, W, generator=g) * 2 - 1)
+    xn = vgg_ref.normalise(x)
+    xo = xn.clone().requires_grad_(True)
+    ref = vgg_ref.forward_base(params, xo)[1:]
+    xd = xn.to(DEV).requires_grad_(True)
+    got = ops.vgg16_features(xd, handle)
+    assert len(got) == 9
+    rs = []
+    for k, (f, r) in enumerate(zip(got, ref)):
+        assert tuple(f.shape) == (1, r.shape[2], r.shape[3], r.shape[1]), (k, f.shape, r.shape)
+        assert rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()) < 2e-2, (k, rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()))
+        rs.append(torch.randn(r.shape, generator=g) / math.sqrt(r.numel()))
+    sum((r_ * f_).sum() for r_, f_ in zip(rs, ref)).backward()
+    sum((r_.permute(0, 2, 3, 1).to(DEV) * f_).sum() for r_, f_ in zip(rs, got)).backward()
+    cs, rl = cosine(xd.grad.cpu(), xo.grad), rel_l2(xd.grad.cpu(), xo.grad)
+    assert cs > 0.98 and rl < 2e-1, (cs, rl)
+    # a gradient on one early feature only: the layers above it are skipped
+    xd2 = xn.to(DEV).requires_grad_(True)
+    f2 = ops.vgg16_features(xd2, handle)
+    (rs[1].permute(0, 2, 3, 1).to(DEV) * f2[1]).sum().backward()
+    xo.grad = None
+    ref2 = vgg_ref.forward_base(params, xo)[1:]
+    (rs[1] * ref2[1]).sum().backward()
+    cs, rl = cosine(xd2.grad.cpu(), xo.grad), rel_l2(xd2.grad.cpu(), xo.grad)
+    assert cs > 0.995 and rl < 8e-2, (cs, rl)       # two bf16 conv layers + the mask flips of relu1_1
+
+
+def test_style_loss_on_the_hip_extractor_tracks_the_oracle_extractor():
+    """the StyleLoss plugin's STROTSS loss (arithmetic pinned to the reference's own code on CPU, tests/test_style_loss.py)
+    with the HIP VGG16 extractor against the same plugin on the CPU oracle's features, same numpy seed -> same sampled
+    positions.  bf16 features move the nearest-neighbour choices of the relaxed EMD a little: 3 % on the value, cosine
+    0.9 on the image gradient."""
+    import warnings
+    import numpy as np
+    from oracle import vgg_ref
+    from pixray_amd import style_loss as sl
+    params = weights.synthetic_vgg16_params(0)
+
+    class OracleExtractor:
+        def __call__(self, x):
+            return [f.permute(0, 2, 3, 1).contiguous() for f in vgg_ref.forward(params, x, "uniform")]
+
+        def forward_samples_hypercolumn(self, X, samps=100):
+            return sl.sample_hypercolumns(self(X), samps)
+
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(1, 3, 96, 80, generator=g)
+    style = torch.rand(1, 3, 96, 80, generator=g)
+    a = img.clone().requires_grad_(True)
+    b = img.clone().to(DEV).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(3)
+        la = sl.strotss_loss(a, style, 16.0, extractor=OracleExtractor())
+        np.random.seed(3)
+        lb = sl.strotss_loss(b, style.to(DEV), 16.0, extractor=sl.Vgg16Extractor(params=params, device=DEV, max_hw=(96, 80)))
+    (ga,) = torch.autograd.grad(la, a)
+    (gb,) = torch.autograd.grad(lb, b)
+    assert abs(float(la.detach()) - float(lb.detach())) < 3e-2 * abs(float(la.detach())), (float(la.detach()), float(lb.detach()))
+    assert cosine(gb.cpu(), ga) > 0.9, cosine(gb.cpu(), ga)

@@ -1,0 +1,119 @@
+"""CPU tests (no GPU) of the StyleLoss plugin's STROTSS arithmetic (pixray_amd/style_loss.py) against the golden vectors
+produced by the REFERENCE'S OWN code (tests/golden/styleloss_golden.npz, made by tests/golden/make_golden.py from
+Losses/StyleLoss.py) -- and, when /root/reference is present, against that code run live.  The VGG16 features come from the
+CPU oracle here (test infrastructure); the HIP extractor is tested in test_path_gpu.py / test_e2e_gpu.py."""
+import argparse
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import _refextract as rx  # noqa: E402
+from oracle import vgg_ref  # noqa: E402
+from pixray_amd import style_loss as sl  # noqa: E402
+from pixray_amd import weights  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "styleloss_golden.npz"))
+
+
+class OracleExtractor:
+    """the plugin's extractor surface on the CPU oracle's VGG16 (channels-last maps, like the HIP extractor's)"""
+
+    def __init__(self, params, space="uniform"):
+        self.params, self.space = params, space
+
+    def __call__(self, x):
+        return [f.permute(0, 2, 3, 1).contiguous() for f in vgg_ref.forward(self.params, x, self.space)]
+
+    def forward_samples_hypercolumn(self, X, samps=100):
+        return sl.sample_hypercolumns(self(X), samps)
+
+
+@pytest.fixture(scope="module")
+def extractor():
+    return OracleExtractor(weights.synthetic_vgg16_params(0))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_strotss_loss_and_gradient_match_the_reference_goldens(extractor, tag):
+    img = torch.from_numpy(GOLD[f"img_{tag}"]).requires_grad_(True)
+    style = torch.from_numpy(GOLD[f"style_{tag}"])
+    np.random.seed(int(GOLD[f"seed_{tag}"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = sl.strotss_loss(img, style, float(GOLD[f"cw_{tag}"]), extractor=extractor)
+    (g,) = torch.autograd.grad(loss, img)
+    assert abs(float(loss.detach()) - float(GOLD[f"loss_{tag}"])) < 1e-5 * max(1.0, abs(float(GOLD[f"loss_{tag}"])))
+    gr = torch.from_numpy(GOLD[f"grad_{tag}"])
+    assert float((g - gr).norm() / gr.norm()) < 1e-4
+
+
+def test_hypercolumn_sampling_matches_the_reference_golden(extractor):
+    np.random.seed(5)
+    cols = extractor.forward_samples_hypercolumn(torch.from_numpy(GOLD["style_a"]), samps=40)
+    assert tuple(cols.shape) == (1, sl.N_FEATURE_CHANNELS, 40)
+    assert float((cols - torch.from_numpy(GOLD["hyper"])).abs().max()) < 1e-5
+
+
+@pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
+def test_strotss_against_the_reference_code_run_live(extractor):
+    """another size (three scales) and seed than the fixtures, the reference's functions executed here"""
+    ns = rx.styleloss_ns()
+    ref_ex = rx.reference_vgg_extractor(ns, weights.synthetic_vgg16_params(0))
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(1, 3, 132, 140, generator=g)
+    style = torch.rand(1, 3, 132, 140, generator=g)
+    a = img.clone().requires_grad_(True)
+    b = img.clone().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(77)
+        la = ns["strotss_loss"](a, style, 8.0, extractor=ref_ex)
+        np.random.seed(77)
+        lb = sl.strotss_loss(b, style, 8.0, extractor=extractor)
+    (ga,) = torch.autograd.grad(la, a)
+    (gb,) = torch.autograd.grad(lb, b)
+    assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(la)))
+    assert float((ga - gb).norm() / ga.norm()) < 1e-4
+
+
+def test_plugin_settings_skip_schedule_and_style_file(tmp_path, extractor):
+    """StyleLoss.py:458-500: argparse settings, the style image read from --style_file and resized (bicubic) to the canvas,
+    zero loss before --styleloss_skip and off the --styleloss_every grid, STROTSS otherwise"""
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    Image.fromarray((rng.rand(40, 52, 3) * 255).astype(np.uint8)).save(tmp_path / "style.png")
+    parser = sl.StyleLoss.add_settings(argparse.ArgumentParser())
+    args = parser.parse_args(["--style_file", str(tmp_path / "style.png"), "--styleloss_skip", "2", "--styleloss_every", "2",
+                              "--styleloss_content_weight", "4"])
+    loss = sl.StyleLoss(extractor=extractor, device="cpu")
+    args = loss.parse_settings(args)
+    out = torch.rand(1, 3, 72, 66, requires_grad=True)
+    assert float(loss.get_loss({}, out, args, globals={"cur_iteration": 1})) == 0.0
+    assert float(loss.get_loss({}, out, args, globals={"cur_iteration": 3})) == 0.0
+    assert tuple(loss.resized.shape) == (1, 3, 72, 66)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        val = loss.get_loss({}, out, args, globals={"cur_iteration": 4})
+    (g,) = torch.autograd.grad(val, out)
+    assert torch.isfinite(val) and float(val) > 0 and float(g.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        sl.StyleLoss(extractor=extractor).get_loss({}, out, args, globals={"cur_iteration": 4})      # no style image
+
+
+def test_extractor_without_weights_or_gpu_fails_loudly(monkeypatch):
+    monkeypatch.delenv("PIXRAY_VGG16_CKPT", raising=False)
+    with pytest.raises(RuntimeError, match="VGG16 weights"):
+        sl.Vgg16Extractor()
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            sl.Vgg16Extractor(params=weights.synthetic_vgg16_params(0), device="cpu")      # no CPU fallback
