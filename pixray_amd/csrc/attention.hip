@@ -58,11 +58,11 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // Only bits >= 2 of t change, so the 4-element groups the reader fetches stay contiguous.
 __device__ __forceinline__ int tr_swz(int d) { return (((d >> 4) & 1) * 12) ^ (((d >> 5) & 1) * 16); }
 
-// load a [T][64] bf16 tile (row stride ld) into dst[t][d] and optionally dstT[d][t ^ tr_swz(d)]; rows >= T are zero
-__device__ __forceinline__ void load_tile(const bf16_t* src, long long ld, int T, bf16_t* dst, bf16_t* dstT, int lane) {
+// 128 threads load a [T][64] bf16 tile (row stride ld) into dst[t][d] and optionally dstT[d][t ^ tr_swz(d)]; rows >= T are zero
+__device__ __forceinline__ void load_tile(const bf16_t* src, long long ld, int T, bf16_t* dst, bf16_t* dstT, int tid) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 128 * i;
         const int row = c >> 3, kc = c & 7;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (row < T) v = *reinterpret_cast<const bf16x8*>(src + (long long)row * ld + kc * 8);
@@ -72,6 +72,37 @@ __device__ __forceinline__ void load_tile(const bf16_t* src, long long ld, int T
             for (int e = 0; e < 8; ++e) dstT[(kc * 8 + e) * LD + (row ^ tr_swz(kc * 8))] = v[e];
         }
     }
+}
+
+// acc[mi] += A[(mi*32 + r)][k] * B[(nb*32 + c)][k] over k in [0,64): the 64 x 32 column block `nb` of A B^T
+__device__ __forceinline__ void mma_64x32x64(const bf16_t* A, const bf16_t* B, int nb, f32x16 (&acc)[2], int lane) {
+    const int fr = lane & 31, fk = 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&B[(nb * 32 + fr) * LD + ks * 16 + fk]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&A[(i * 32 + fr) * LD + ks * 16 + fk]);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void zero_acc2(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+// write the C-layout rows 32*rb .. 32*rb+31 of a [t][64] result (a[dj] = columns 32dj ..) to global rows < T
+__device__ __forceinline__ void store_rows_global(const f32x16 (&a)[2], int rb, bf16_t* out, long long ld, int T, int lane) {
+    const int col = lane & 31, r0 = 32 * rb + 4 * (lane >> 5);
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = r0 + (r & 3) + 8 * (r >> 2);
+            if (i < T) out[(long long)i * ld + dj * 32 + col] = (bf16_t)a[dj][r];
+        }
 }
 
 // softmax over j in the C layout; s holds raw q.k sums; returns p in s.
@@ -123,89 +154,16 @@ __device__ __forceinline__ void store_c_global(const f32x16 (&a)[2][2], bf16_t* 
             }
 }
 
-// Forward, "swapped" formulation: S^T = K Q^T puts one QUERY per lane column (C layout: lane l holds query l&31 of the
-// tile, 16 of its keys in registers, the other 16 in lane l^32), so the softmax is an in-register reduction plus ONE
+// Forward, "swapped" formulation: S^T = K Q^T puts one QUERY per lane column (C layout: lane l holds query l&31 of its
+// block, 16 of its keys in registers, the other 16 in lane l^32), so the softmax is an in-register reduction plus ONE
 // cross-half exchange per statistic instead of a 5-step butterfly per row; and the normalised P^T accumulators are
 // already the A operand of O = P V (rows = queries = this lane, k slots = the keys it holds) -- P never goes through
 // LDS.  The MFMA only needs A and B to agree on which key sits in which k slot: slot 8h+s of step (mi, G) is key
 // 32mi + 16G + 8(s>>2) + 4h + (s&3), which for the B operand (rows = head-dim d of V^T) is two 8-byte reads of the
 // transposed V image.
-__global__ __launch_bounds__(64) void mha_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T,
-                                                     int C, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * TILE];
-    bf16_t* Qs = smem;
-    bf16_t* Ks = smem + TILE;
-    bf16_t* Vt = smem + 2 * TILE;
-    const int lane = threadIdx.x;
-    const int h = blockIdx.x, n = blockIdx.y;
-    const long long ld = 3LL * C;
-    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
-    load_tile(base, ld, T, Qs, nullptr, lane);
-    load_tile(base + C, ld, T, Ks, nullptr, lane);
-    load_tile(base + 2 * C, ld, T, nullptr, Vt, lane);
-    __syncthreads();
-    f32x16 st[2][2];                       // st[mi][nj]: keys 32mi.., queries 32nj..
-    zero_acc(st);
-    mma_64x64x64(Ks, Qs, st, lane);
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float v = (j < T) ? st[mi][nj][r] * scale : -INFINITY;
-                st[mi][nj][r] = v;
-                m = fmaxf(m, v);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[mi][nj][r] - m);
-                st[mi][nj][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[mi][nj][r] *= inv;
-    }
-    f32x16 o[2][2];                        // o[nj][dj]: queries 32nj.., head-dim 32dj..
-    zero_acc(o);
-    const int c = lane & 31;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int G = 0; G < 2; ++G) {
-            bf16x8 pa[2], vb[2];
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) pa[nj][s] = (bf16_t)st[mi][nj][8 * G + s];
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj) {
-                const int d = dj * 32 + c, t0 = 32 * mi + 16 * G + 4 * hh, sw = tr_swz(d);
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Vt + d * LD + (t0 ^ sw));
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Vt + d * LD + ((t0 + 8) ^ sw));
-                vb[dj] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-                for (int dj = 0; dj < 2; ++dj) o[nj][dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[nj], vb[dj], o[nj][dj], 0, 0, 0);
-        }
-    store_c_global(o, out + (long long)n * T * C + h * 64, C, T, lane);
-}
-
-// k-slot convention shared by the register-resident A operands below and the transposed-image B operands: slot 8h + s of
-// step (mi, G) is row 32mi + 16G + 8(s>>2) + 4h + (s&3) of the contraction axis (h = lane >> 5)
+// Two waves per (image, head): wave w owns queries 32w .. 32w+31 (its column block of S^T, its rows of O).  768
+// one-wave workgroups left every CU with 3 waves in flight and each of them latency-bound; the split halves the MFMA
+// chain per wave and doubles the waves a CU can interleave.
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int G) {
     bf16x8 f;
 #pragma unroll
@@ -218,32 +176,79 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* Tt, int dj, int mi, int 
     const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Tt + d * LD + ((t0 + 8) ^ sw));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// out[nj][dj] = sum over the contraction axis of A (accumulators, rows = this lane's column index) x B^T image
-__device__ __forceinline__ void mma_acc_tr(const f32x16 (&a)[2][2], const bf16_t* Tt, f32x16 (&o)[2][2], int lane) {
+// o[dj] += sum over the contraction axis of A (accumulators a[mi], rows = this lane's column index) x B^T image
+__device__ __forceinline__ void mma_acc_tr(const f32x16 (&a)[2], const bf16_t* Tt, f32x16 (&o)[2], int lane) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
-            bf16x8 fa[2], fb[2];
+            const bf16x8 fa = acc_frag(a[mi], G);
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj) fa[nj] = acc_frag(a[mi][nj], G);
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj) fb[dj] = tr_frag(Tt, dj, mi, G, lane);
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-                for (int dj = 0; dj < 2; ++dj) o[nj][dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nj], fb[dj], o[nj][dj], 0, 0, 0);
+            for (int dj = 0; dj < 2; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, tr_frag(Tt, dj, mi, G, lane), o[dj], 0, 0, 0);
         }
+}
+
+__global__ __launch_bounds__(128) void mha_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T,
+                                                      int C, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * TILE];
+    bf16_t* Qs = smem;
+    bf16_t* Ks = smem + TILE;
+    bf16_t* Vt = smem + 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = blockIdx.x, n = blockIdx.y;
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    load_tile(base, ld, T, Qs, nullptr, tid);
+    load_tile(base + C, ld, T, Ks, nullptr, tid);
+    load_tile(base + 2 * C, ld, T, nullptr, Vt, tid);
+    __syncthreads();
+    f32x16 st[2];                          // st[mi]: keys 32mi.., queries 32w..
+    zero_acc2(st);
+    mma_64x32x64(Ks, Qs, w, st, lane);
+    const int hh = lane >> 5;
+    {
+        float m = -INFINITY;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = (j < T) ? st[mi][r] * scale : -INFINITY;
+                st[mi][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[mi][r] - m);
+                st[mi][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mi][r] *= inv;
+    }
+    f32x16 o[2];                           // o[dj]: queries 32w.., head-dim 32dj..
+    zero_acc2(o);
+    mma_acc_tr(st, Vt, o, lane);
+    store_rows_global(o, w, out + (long long)n * T * C + h * 64, C, T, lane);
 }
 
 // Backward, same register-resident scheme as the forward, in two orientations:
 //   (1) queries on lanes:  P^T = softmax(K Q^T), dP^T = V dO^T, D_i = sum_j P dP, dS^T  ->  dQ = dS K   (A = dS^T accumulators)
 //   (2) keys on lanes:     P = exp(Q K^T / 8 - lse_i), dP = dO V^T, dS               ->  dK = dS^T Q, dV = P^T dO
-// Orientation 2 recomputes the two score products (32 MFMAs) instead of transposing dS / P through LDS; it gets the
-// per-query log-sum-exp and D_i from orientation 1 through two 64-float LDS arrays.  The B operands K^T, Q^T, dO^T are
-// transposed LDS images built one after the other in the fifth tile.
-__global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                     bf16_t* __restrict__ dqkv, int T, int C, float scale) {
+// Orientation 2 recomputes the two score products instead of transposing dS / P through LDS; it gets the per-query
+// log-sum-exp and D_i from orientation 1 through two 64-float LDS arrays.  The B operands K^T, Q^T, dO^T are transposed
+// LDS images built one after the other in the fifth tile.  Two waves per (image, head), as in the forward: wave w owns
+// queries 32w.. in orientation 1 (its rows of dQ) and keys 32w.. in orientation 2 (its rows of dK and dV).
+__global__ __launch_bounds__(128) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                      bf16_t* __restrict__ dqkv, int T, int C, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[5 * TILE];
     __shared__ __attribute__((aligned(16))) float s_lse[64], s_D[64];
     bf16_t* Qs = smem;
@@ -251,77 +256,74 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ 
     bf16_t* Vs = smem + 2 * TILE;
     bf16_t* dOs = smem + 3 * TILE;
     bf16_t* Tt = smem + 4 * TILE;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, n = blockIdx.y;
     const int hh = lane >> 5;
     const long long ld = 3LL * C;
     const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
     const bf16_t* dobase = dout + (long long)n * T * C + h * 64;
-    load_tile(base, ld, T, Qs, nullptr, lane);
-    load_tile(base + C, ld, T, Ks, Tt, lane);            // K row-major and K^T
-    load_tile(base + 2 * C, ld, T, Vs, nullptr, lane);
-    load_tile(dobase, C, T, dOs, nullptr, lane);
+    load_tile(base, ld, T, Qs, nullptr, tid);
+    load_tile(base + C, ld, T, Ks, Tt, tid);             // K row-major and K^T
+    load_tile(base + 2 * C, ld, T, Vs, nullptr, tid);
+    load_tile(dobase, C, T, dOs, nullptr, tid);
     __syncthreads();
     bf16_t* obase = dqkv + (long long)n * T * ld + h * 64;
-    {   // ---- orientation 1: [key j][query i], lane column = query
-        f32x16 pt[2][2], dpt[2][2];
-        zero_acc(pt);
-        mma_64x64x64(Ks, Qs, pt, lane);
-        zero_acc(dpt);
-        mma_64x64x64(Vs, dOs, dpt, lane);
+    {   // ---- orientation 1: [key j][query i], lane column = query 32w + (lane & 31)
+        f32x16 pt[2], dpt[2];
+        zero_acc2(pt);
+        mma_64x32x64(Ks, Qs, w, pt, lane);
+        zero_acc2(dpt);
+        mma_64x32x64(Vs, dOs, w, dpt, lane);
+        float m = -INFINITY;
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            float m = -INFINITY;
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int r = 0; r < 16; ++r) {
+                const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = (j < T) ? pt[mi][r] * scale : -INFINITY;
+                pt[mi][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const float v = (j < T) ? pt[mi][nj][r] * scale : -INFINITY;
-                    pt[mi][nj][r] = v;
-                    m = fmaxf(m, v);
-                }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float sum = 0.f;
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(pt[mi][r] - m);
+                pt[mi][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        float dot = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __expf(pt[mi][nj][r] - m);
-                    pt[mi][nj][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.f / sum;
-            float dot = 0.f;
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int r = 0; r < 16; ++r) {
+                pt[mi][r] *= inv;
+                dot += pt[mi][r] * dpt[mi][r];
+            }
+        dot += __shfl_xor(dot, 32, 64);
+        if (hh == 0) { s_lse[w * 32 + lane] = m + __logf(sum); s_D[w * 32 + lane] = dot; }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pt[mi][nj][r] *= inv;
-                    dot += pt[mi][nj][r] * dpt[mi][nj][r];
-                }
-            dot += __shfl_xor(dot, 32, 64);
-            if (hh == 0) { s_lse[nj * 32 + lane] = m + __logf(sum); s_D[nj * 32 + lane] = dot; }
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dpt[mi][nj][r] = scale * pt[mi][nj][r] * (dpt[mi][nj][r] - dot);   // dS^T
-        }
-        f32x16 acc[2][2];
-        zero_acc(acc);
+            for (int r = 0; r < 16; ++r) dpt[mi][r] = scale * pt[mi][r] * (dpt[mi][r] - dot);   // dS^T
+        f32x16 acc[2];
+        zero_acc2(acc);
         mma_acc_tr(dpt, Tt, acc, lane);                  // dQ[i][d] = sum_j dS[i][j] K[j][d]
-        store_c_global(acc, obase, ld, T, lane);
+        store_rows_global(acc, w, obase, ld, T, lane);
     }
     __syncthreads();                                      // s_lse / s_D visible, K^T image free
-    load_tile(base, ld, T, nullptr, Tt, lane);            // Q^T
-    // ---- orientation 2: [query i][key j], lane column = key
-    f32x16 p[2][2], dp[2][2];
-    zero_acc(p);
-    mma_64x64x64(Qs, Ks, p, lane);
-    zero_acc(dp);
-    mma_64x64x64(dOs, Vs, dp, lane);
-    const int jcol = lane & 31;
+    load_tile(base, ld, T, nullptr, Tt, tid);             // Q^T
+    // ---- orientation 2: [query i][key j], lane column = key 32w + (lane & 31)
+    f32x16 p[2], dp[2];
+    zero_acc2(p);
+    mma_64x32x64(Qs, Ks, w, p, lane);
+    zero_acc2(dp);
+    mma_64x32x64(dOs, Vs, w, dp, lane);
+    const bool key_ok = w * 32 + (lane & 31) < T;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -333,29 +335,26 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = rg * 4 + q;
-#pragma unroll
-                for (int nj = 0; nj < 2; ++nj) {
-                    const float pv = (nj * 32 + jcol < T) ? __expf(p[mi][nj][r] * scale - lv[q]) : 0.f;
-                    p[mi][nj][r] = pv;
-                    dp[mi][nj][r] = scale * pv * (dp[mi][nj][r] - dv[q]);   // dS
-                }
+                const float pv = key_ok ? __expf(p[mi][r] * scale - lv[q]) : 0.f;
+                p[mi][r] = pv;
+                dp[mi][r] = scale * pv * (dp[mi][r] - dv[q]);   // dS
             }
         }
     __syncthreads();                                      // Q^T image complete
     {
-        f32x16 acc[2][2];
-        zero_acc(acc);
+        f32x16 acc[2];
+        zero_acc2(acc);
         mma_acc_tr(dp, Tt, acc, lane);                    // dK[j][d] = sum_i dS[i][j] Q[i][d]
-        store_c_global(acc, obase + C, ld, T, lane);
+        store_rows_global(acc, w, obase + C, ld, T, lane);
     }
     __syncthreads();
-    load_tile(dobase, C, T, nullptr, Tt, lane);            // dO^T
+    load_tile(dobase, C, T, nullptr, Tt, tid);             // dO^T
     __syncthreads();
     {
-        f32x16 acc[2][2];
-        zero_acc(acc);
+        f32x16 acc[2];
+        zero_acc2(acc);
         mma_acc_tr(p, Tt, acc, lane);                     // dV[j][d] = sum_i P[i][j] dO[i][d]
-        store_c_global(acc, obase + 2 * C, ld, T, lane);
+        store_rows_global(acc, w, obase + 2 * C, ld, T, lane);
     }
 }
 
@@ -578,14 +577,14 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_gen_kernel(const bf16_t* __res
 
 int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(64), 0, s, qkv, out, T, C, 0.125f);
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, out, T, C, 0.125f);
     PRX_LAUNCH_CHECK();
     return 0;
 }
 
 int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha bwd: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(64), 0, s, qkv, dout, dqkv, T, C, 0.125f);
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, dout, dqkv, T, C, 0.125f);
     PRX_LAUNCH_CHECK();
     return 0;
 }
