@@ -1,6 +1,6 @@
 """per-cutout forward / backward error of MakeCutouts vs the oracle (diagnostic; run on the GPU box)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pixray_amd import cutouts as pc
 from oracle import cutouts_ref

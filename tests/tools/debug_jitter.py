@@ -1,5 +1,5 @@
 import sys, os, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import cutouts_ref as cr
 from pixray_amd import ops

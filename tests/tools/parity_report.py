@@ -1,6 +1,6 @@
 """Print the parity metrics of the HIP path vs the CPU oracle (run on the GPU box)."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import step_ref
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
