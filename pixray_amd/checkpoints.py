@@ -8,6 +8,8 @@ are exercised in tests with randomly initialised upstream-format state dicts; th
 * taming-transformers VQGAN Lightning checkpoint (`vqgan.py:124-140`): `state_dict` with `decoder.*`,
   `post_quant_conv.*`, `quantize.embedding.weight` for the decoder runner, plus `encoder.*` / `quant_conv.*` for the
   encoder runner when the checkpoint has them (`loss.*` is dropped, as `del model.loss` does at vqgan.py:139).
+* torchvision `vgg16` (`models.vgg16(pretrained=True)`, Losses/StyleLoss.py:27): `features.{0,2,5,...,28}.{weight,bias}`;
+  the `classifier.*` tensors are dropped (the StyleLoss extractor stops at relu5_3).
 """
 from collections import OrderedDict
 from typing import Dict
@@ -15,7 +17,7 @@ from typing import Dict
 import torch
 
 from .weights import (ClipTextConfig, ClipVitConfig, VqganConfig, clip_text_param_shapes, clip_vit_param_shapes,
-                      vqgan_encoder_param_shapes, vqgan_param_shapes)
+                      vgg16_param_shapes, vqgan_encoder_param_shapes, vqgan_param_shapes)
 
 
 def _check(params: Dict[str, torch.Tensor], shapes) -> "OrderedDict[str, torch.Tensor]":
@@ -89,3 +91,11 @@ def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig, wit
     if with_encoder:
         out.update(_check(sd, vqgan_encoder_param_shapes(cfg)))
     return out
+
+
+def vgg16_from_torchvision(state_dict: Dict[str, torch.Tensor]):
+    """torchvision VGG16 state dict (optionally wrapped as {"state_dict": ...} or prefixed `module.`) -> the 26 tensors the
+    StyleLoss extractor needs (`pixray_amd.style_loss.Vgg16Extractor(params=...)`)"""
+    sd = state_dict.get("state_dict", state_dict)
+    params = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return _check(params, vgg16_param_shapes())

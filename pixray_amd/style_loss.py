@@ -43,7 +43,8 @@ class Vgg16Extractor:
             if not path:
                 raise RuntimeError("StyleLoss needs VGG16 weights: pass params= (torchvision state dict) or set "
                                    "PIXRAY_VGG16_CKPT to a torchvision vgg16 checkpoint (no download is attempted)")
-            params = torch.load(path, map_location="cpu")
+            from .checkpoints import vgg16_from_torchvision
+            params = vgg16_from_torchvision(torch.load(path, map_location="cpu"))
         self.params = params
         self.handle = None
         self.max_hw = (0, 0)

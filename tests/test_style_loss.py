@@ -117,3 +117,20 @@ def test_extractor_without_weights_or_gpu_fails_loudly(monkeypatch):
     if not torch.cuda.is_available():
         with pytest.raises(Exception):
             sl.Vgg16Extractor(params=weights.synthetic_vgg16_params(0), device="cpu")      # no CPU fallback
+
+
+def test_torchvision_vgg16_checkpoint_adapter():
+    """a torchvision-format state dict (features.* + classifier.*, optionally DataParallel-prefixed) is reduced to the 26
+    feature-extractor tensors; a wrong shape or a missing tensor is an error"""
+    from pixray_amd import checkpoints
+    sd = {("module." + k): v.half() for k, v in weights.synthetic_vgg16_params(1).items()}
+    sd["module.classifier.0.weight"] = torch.zeros(8, 8)
+    out = checkpoints.vgg16_from_torchvision({"state_dict": sd})
+    assert list(out) == list(weights.vgg16_param_shapes()) and all(t.dtype == torch.float32 for t in out.values())
+    bad = dict(sd)
+    bad["module.features.5.weight"] = torch.zeros(128, 64, 1, 1)
+    with pytest.raises(ValueError):
+        checkpoints.vgg16_from_torchvision(bad)
+    del sd["module.features.28.bias"]
+    with pytest.raises(KeyError):
+        checkpoints.vgg16_from_torchvision(sd)
