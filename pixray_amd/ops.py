@@ -486,7 +486,6 @@ class _Vgg16Fn(torch.autograd.Function):
         arr = (ctypes.c_void_p * len(feats))(*[f.data_ptr() for f in feats])
         call("prx_vgg16_forward", handle.h, x, H, W, work, ctypes.addressof(arr), _stream())
         ctx.handle, ctx.work, ctx.hw = handle, work, (H, W)
-        ctx.mark_non_differentiable()
         return tuple(feats)
 
     @staticmethod
