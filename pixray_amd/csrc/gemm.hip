@@ -665,8 +665,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             int col = 0;
             if (live) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int s = 0; s < p.splits; ++s) {
-                    const float4 w = reinterpret_cast<const float4*>(p.ws + (size_t)s * total)[i4];
+                // four partials in flight at a time (a plain loop compiles to load / s_waitcnt vmcnt(0) / add per split: one L2
+                // round trip per partial); the additions keep their order, so the sum is bit-identical to the serial loop
+                const float4* part = reinterpret_cast<const float4*>(p.ws) + i4;
+                const size_t pstride = total >> 2;
+                int s = 0;
+                for (; s + 4 <= p.splits; s += 4) {
+                    const float4 w0 = part[(size_t)s * pstride], w1 = part[(size_t)(s + 1) * pstride];
+                    const float4 w2 = part[(size_t)(s + 2) * pstride], w3 = part[(size_t)(s + 3) * pstride];
+                    v.x += w0.x; v.y += w0.y; v.z += w0.z; v.w += w0.w;
+                    v.x += w1.x; v.y += w1.y; v.z += w1.z; v.w += w1.w;
+                    v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
+                    v.x += w3.x; v.y += w3.y; v.z += w3.z; v.w += w3.w;
+                }
+                for (; s < p.splits; ++s) {
+                    const float4 w = part[(size_t)s * pstride];
                     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                 }
                 const size_t idx = i4 << 2;
