@@ -658,11 +658,16 @@ __global__ __launch_bounds__(256) void patchify_bwd_reduce_kernel(const float* _
     const float range = mx - mn;
     const float inv = range != 0.f ? 1.f / range : 1.f;
     double s1 = 0, s2 = 0, cmin = 0, cmax = 0;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), c = (int)((idx / ((size_t)S * S)) % 3);
-        const int n = (int)(idx / ((size_t)3 * S * S));
-        const int tok = 1 + (y / P) * G + (x / P);
-        const int k = c * P * P + (y % P) * P + (x % P);
+    // 32-bit index arithmetic (the host checks total < 2^31): the size_t div/mod chain of the first version cost more than
+    // the memory traffic
+    const unsigned S2 = (unsigned)S * S, total32 = (unsigned)total, stride = gridDim.x * blockDim.x;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total32; idx += stride) {
+        const unsigned pl = idx / S2, rem = idx - pl * S2;
+        const int y = (int)(rem / (unsigned)S), x = (int)(rem - (unsigned)y * S);
+        const int n = (int)(pl / 3u), c = (int)(pl - 3u * n);
+        const int ty = y / P, tx = x / P;
+        const int tok = 1 + ty * G + tx;
+        const int k = c * P * P + (y - ty * P) * P + (x - tx * P);
         const float gy = dA[((size_t)n * T + tok) * K + k] / c_clip_std[c];
         const float xv = cut[idx];
         s1 += gy; s2 += gy * ((xv - mn) * inv);
@@ -691,11 +696,14 @@ __global__ __launch_bounds__(256) void patchify_bwd_apply_kernel(const float* __
     const float inv = live ? 1.f / range : 1.f;
     const float gmin = live ? (float)((acc[1] - acc[0]) * inv / fmax(acc[2], 1.0)) : 0.f;
     const float gmax = live ? (float)(-acc[1] * inv / fmax(acc[3], 1.0)) : 0.f;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), c = (int)((idx / ((size_t)S * S)) % 3);
-        const int n = (int)(idx / ((size_t)3 * S * S));
-        const int tok = 1 + (y / P) * G + (x / P);
-        const int k = c * P * P + (y % P) * P + (x % P);
+    const unsigned S2 = (unsigned)S * S, total32 = (unsigned)total, stride = gridDim.x * blockDim.x;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total32; idx += stride) {
+        const unsigned pl = idx / S2, rem = idx - pl * S2;
+        const int y = (int)(rem / (unsigned)S), x = (int)(rem - (unsigned)y * S);
+        const int n = (int)(pl / 3u), c = (int)(pl - 3u * n);
+        const int ty = y / P, tx = x / P;
+        const int tok = 1 + ty * G + tx;
+        const int k = c * P * P + (y - ty * P) * P + (x - tx * P);
         const float gy = dA[((size_t)n * T + tok) * K + k] / c_clip_std[c];
         const float xv = cut[idx];
         float g = gy * inv;
@@ -779,8 +787,9 @@ int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S,
 }
 int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,
                             hipStream_t s) {
+    PRX_REQUIRE((size_t)N * 3 * S * S < ((size_t)1 << 31), "patchify backward: %d cutouts of %dx%d exceed the 32-bit index range", N, S, S);
     PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
-    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 512)), dim3(256), 0, s,
+    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 2048)), dim3(256), 0, s,
                        cut, mm, dA, acc, N, S, P, T, patch_kp(P));
     PRX_LAUNCH_CHECK();
     return 0;
@@ -798,8 +807,9 @@ int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, c
 // image); their token index is 1-based, hence the pointer shifted back by one row of K = 3*S*S.
 int prx_preproc_bwd_reduce(const float* cut, const float* mm, const float* dY, double* acc, int N, int S, hipStream_t s) {
     PRX_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, s));
+    PRX_REQUIRE((size_t)N * 3 * S * S < ((size_t)1 << 31), "preprocessing backward: %d cutouts of %dx%d exceed the 32-bit index range", N, S, S);
     const int K = 3 * S * S;
-    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 512)), dim3(256), 0, s,
+    hipLaunchKernelGGL(patchify_bwd_reduce_kernel, dim3(std::min(ew_grid((size_t)N * 3 * S * S), 2048)), dim3(256), 0, s,
                        cut, mm, dY - K, acc, N, S, S, 1, K);
     PRX_LAUNCH_CHECK();
     return 0;
