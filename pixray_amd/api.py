@@ -31,7 +31,9 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                              vector_prompts: Sequence[str] = (), init_image: Optional[torch.Tensor] = None, tokenizer=None,
                              clip_text_params=None, image_prompts: Sequence[torch.Tensor] = (), image_prompt_weight=None,
                              image_prompt_shuffle: bool = False, init_weight: float = 0.0, init_weight_dist: float = 0.0,
-                             init_weight_pix: float = 0.0, init_weight_cos: float = 0.0) -> Session:
+                             init_weight_pix: float = 0.0, init_weight_cos: float = 0.0, overlay_image=None,
+                             overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
+                             overlay_alpha: Optional[int] = None) -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
     a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
 
@@ -40,7 +42,9 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     precomputed CLIP-space vectors, "path[:weight[:stop]]", weighted x0.1 as pixray.py:879-915 does; `init_image`:
     [1,3,H,W] in [0,1], encoded to the starting z by the HIP VQGAN encoder (pixray.py:696-718); `image_prompts`: target
     images [1,3,H,W] in [0,1] turned into per-iteration throwaway Prompts through the cached cutout transforms
-    (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`)."""
+    (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`);
+    `overlay_*`: a PIL image (or path) pasted over the current image every `overlay_every` iterations and re-encoded by the HIP
+    VQGAN encoder (pixray.py:731-747, 1408-1420)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
@@ -88,4 +92,6 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                    image_prompt_weight=image_prompt_weight, image_prompt_shuffle=image_prompt_shuffle,
                    init_weight=init_weight, init_weight_dist=init_weight_dist, init_weight_pix=init_weight_pix,
                    init_weight_cos=init_weight_cos, z_orig=drawer.get_z_copy().detach() if init_image is not None else None,
-                   init_image_tensor=None if init_image is None else init_image.to(dev).float())
+                   init_image_tensor=None if init_image is None else init_image.to(dev).float(),
+                   overlay_image=overlay_image, overlay_every=overlay_every, overlay_offset=overlay_offset,
+                   overlay_until=overlay_until, overlay_alpha=overlay_alpha)

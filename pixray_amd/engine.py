@@ -120,7 +120,9 @@ class Session:
                  z_labels: Sequence[torch.Tensor] = (), image_label_weight: float = 1.0, init_weight_pix: float = 0.0,
                  init_weight_cos: float = 0.0, init_image_tensor: Optional[torch.Tensor] = None,
                  spot_prompts: Optional[Dict[str, Sequence[object]]] = None,
-                 spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None):
+                 spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None,
+                 overlay_image=None, overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
+                 overlay_alpha: Optional[int] = None):
         self.drawer = drawer
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
@@ -150,6 +152,18 @@ class Session:
         # (spotOffPmsTable) was blanked; the cutout tables need `.spot_masks`
         self.spotPmsTable = {k: list(v) for k, v in (spot_prompts or {}).items()}
         self.spotOffPmsTable = {k: list(v) for k, v in (spot_prompts_off or {}).items()}
+        # overlay (pixray.py:731-747, 1408-1420, 1431-1434, 1457-1461): every `overlay_every` iterations the current image gets a
+        # PIL RGBA image pasted over it (its alpha as mask) and is re-encoded into the drawer (`reapply_from_tensor`)
+        self.overlay_image_rgba = None
+        self.overlay_every, self.overlay_offset, self.overlay_until = overlay_every, overlay_offset, overlay_until
+        if overlay_image is not None:
+            from PIL import Image
+            size = drawer.to_image().size                       # (sideX, sideY)
+            img = overlay_image if isinstance(overlay_image, Image.Image) else Image.open(overlay_image)
+            img = img.convert("RGBA").resize(size, Image.LANCZOS)
+            if overlay_alpha:
+                img.putalpha(overlay_alpha)
+            self.overlay_image_rgba = img
         self.optimiser_factory = optimiser_factory
         self.group, self.rank, self.world_size = group, rank, world_size
         self.auto_stop = auto_stop
@@ -376,14 +390,34 @@ class Session:
         graph.replay()                   # run the iteration whose inputs were staged for the capture
         return True
 
+    def apply_overlay(self, cur_it: int) -> bool:
+        """pixray.py:1431-1434"""
+        return self.overlay_image_rgba is not None and (cur_it % self.overlay_every) == self.overlay_offset and \
+            (self.overlay_until is None or cur_it < self.overlay_until)
+
+    def re_average_z(self):
+        """pixray.py:1408-1420: current image -> paste the overlay through its alpha -> back into the drawer (for the VQGAN
+        drawer that is the HIP encoder + nearest-code lookup); the optimiser state is kept, as in the reference"""
+        import numpy as np
+        from PIL import Image
+        cur = self.drawer.to_image().convert("RGB")
+        size = cur.size
+        cur.paste(self.overlay_image_rgba, (0, 0), mask=self.overlay_image_rgba)
+        cur = cur.resize(size, Image.LANCZOS)
+        t = torch.from_numpy(np.asarray(cur, dtype=np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+        z = self.drawer.get_z()
+        self.drawer.reapply_from_tensor((t.to(z.device) if z is not None else t) * 2 - 1)
+
     # ------------------------------------------------------------------ one optimiser step
     def train(self, cur_it: Optional[int] = None) -> bool:
-        """pixray.py:1436-1512 (image saving / overlays / animation are outside the hot path)"""
+        """pixray.py:1436-1512 (image saving and the animation ring are outside the hot path)"""
         if cur_it is None:
             cur_it = self.cur_iteration
         self.cur_iteration = cur_it
         rebuild = False
         if cur_it < self.iterations:
+            if self.apply_overlay(cur_it):
+                self.re_average_z()
             if cur_it in self.learning_rate_drops:
                 rebuild = True
             if self._graph is not None:

@@ -474,3 +474,20 @@ def test_config3_custom_loss_stack_styleloss_plus_saturation_on_the_fft_drawer()
             assert len(vals) == 3 and all(math.isfinite(v) for v in vals)
             assert (vals[1] == 0.0) == (it < 2)              # StyleLoss is silent before --styleloss_skip
             assert (dr.params[0].detach() - p0).abs().max() > 0
+
+
+def test_overlay_image_goes_through_the_hip_encoder():
+    """the overlay path (pixray.py:1408-1420) on the VQGAN drawer: the pasted image is re-encoded by the HIP encoder, so after
+    an overlay step the decoded image is close to the overlay where it is opaque"""
+    from PIL import Image
+    rgba = np.zeros((64, 64, 4), dtype=np.uint8)
+    rgba[:, :32] = (40, 200, 90, 255)
+    sess = api.build_vqgan_clip_session(size=(64, 64), vqgan_model="tiny_f4", clip_model="tiny-B/32", num_cuts=8, seed=3,
+                                        overlay_image=Image.fromarray(rgba, "RGBA"), overlay_every=2, overlay_offset=1)
+    z0 = sess.drawer.get_z_copy()
+    sess.train(0)
+    z1 = sess.drawer.get_z_copy()
+    sess.re_average_z()
+    z2 = sess.drawer.get_z_copy()
+    assert (z1 - z0).abs().max() > 0 and (z2 - z1).abs().max() > 0 and torch.isfinite(z2).all()
+    assert sess.train(1) and all(torch.isfinite(l) for l in sess.last_losses)

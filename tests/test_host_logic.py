@@ -166,7 +166,7 @@ class _Settings(types.SimpleNamespace):
     pass
 
 
-def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0, group=None, seed=0, drawer=None):
+def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0, group=None, seed=0, drawer=None, **extra):
     cfg = weights.CLIP_CONFIGS["ViT-B/32"]
     params = weights.synthetic_clip_vit_params(cfg, 1)
     g = torch.Generator().manual_seed(7)
@@ -191,7 +191,7 @@ def _cpu_session(cutn=2, iters=10, custom_losses=(), filters=(), world=1, rank=0
     args = _Settings(saturation_weight=1.0, symmetry_weight=1.0)
     return Session(drawer, {"ViT-B/32": perceptor}, {224: mk}, {"ViT-B/32": [pm]}, learning_rate=0.03, iterations=iters,
                    custom_losses=custom_losses, filters=filters, args=args, seed=seed, world_size=world, rank=rank,
-                   group=group)
+                   group=group, **extra)
 
 
 def test_config0_pixel_grid_vit_b32_cutn2_10_iterations_cpu():
@@ -320,3 +320,32 @@ def test_learning_rate_drop_rebuilds_optimisers():
     assert sess.opts[0].param_groups[0]["lr"] == pytest.approx(0.03)
     sess.train(1)
     assert sess.num_loss_drop == 1 and sess.opts[0].param_groups[0]["lr"] == pytest.approx(0.003)
+
+
+def test_overlay_image_is_pasted_and_re_encoded_on_schedule():
+    """pixray.py:731-747, 1408-1420, 1431-1434, 1457-1461: every `overlay_every` iterations (offset, until) the current image
+    gets the RGBA overlay pasted through its alpha and goes back into the drawer via reapply_from_tensor"""
+    import numpy as np
+    from PIL import Image
+    rgba = np.zeros((64, 64, 4), dtype=np.uint8)
+    rgba[:, :32] = (255, 0, 0, 255)                       # opaque red left half, transparent right half
+    sess = _cpu_session(iters=10, overlay_image=Image.fromarray(rgba, "RGBA"), overlay_every=3, overlay_offset=1, overlay_until=6)
+    assert sess.overlay_image_rgba.size == (256, 256)     # resized to the canvas (LANCZOS), like pixray.py:742
+    assert [it for it in range(10) if sess.apply_overlay(it)] == [1, 4]
+    calls = []
+    orig = sess.drawer.reapply_from_tensor
+    sess.drawer.reapply_from_tensor = lambda t: (calls.append(t.clone()), orig(t))[1]
+    before = np.asarray(sess.drawer.to_image()).astype(np.int32)
+    sess.train(0)
+    assert not calls
+    cur = np.asarray(sess.drawer.to_image()).astype(np.int32)
+    sess.train(1)                                         # overlay first, then the optimiser step
+    assert len(calls) == 1 and tuple(calls[0].shape) == (1, 3, 256, 256)
+    t = calls[0]
+    assert float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    left, right = ((t[0, :, :, :100] + 1) / 2 * 255).round(), ((t[0, :, :, 160:] + 1) / 2 * 255).round()
+    assert torch.equal(left[0], torch.full_like(left[0], 255)) and float(left[1:].abs().max()) == 0      # red where opaque
+    assert np.abs(right.permute(1, 2, 0).numpy() - cur[:, 160:]).max() <= 1                              # untouched where transparent
+    for it in range(2, 10):
+        sess.train(it)
+    assert len(calls) == 2                                # iterations 1 and 4 only (until = 6)
