@@ -122,7 +122,7 @@ class Session:
                  spot_prompts: Optional[Dict[str, Sequence[object]]] = None,
                  spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None,
                  overlay_image=None, overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
-                 overlay_alpha: Optional[int] = None):
+                 overlay_alpha: Optional[int] = None, prompt_factory=None):
         self.drawer = drawer
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
@@ -165,6 +165,9 @@ class Session:
                 img.putalpha(overlay_alpha)
             self.overlay_image_rgba = img
         self.optimiser_factory = optimiser_factory
+        # class of the throwaway Prompts built per iteration for image prompts (pixray.py:1331-1333); the HIP Prompt unless a
+        # caller assembles the loop from other parts (CPU tests)
+        self.prompt_factory = prompt_factory if prompt_factory is not None else Prompt
         self.group, self.rank, self.world_size = group, rank, world_size
         self.auto_stop = auto_stop
         self.cur_iteration = 0
@@ -279,7 +282,7 @@ class Session:
                         dist.all_gather(parts, embed.contiguous(), group=self.group)
                         embed = torch.cat(parts, 0)
                 w = self.image_prompt_weight if self.image_prompt_weight is not None else 1.0
-                pm = Prompt(embed, w).to(embed.device)
+                pm = self.prompt_factory(embed, w).to(embed.device)
                 if self.world_size > 1 and hasattr(pm, "denom"):
                     pm.denom = float(mk.cutn * embed.shape[0])
                 result.append(pm(iii))

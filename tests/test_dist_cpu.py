@@ -19,6 +19,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 
+def _collect(q, procs, world, timeout=240):
+    """results of all ranks, failing fast when a worker died instead of waiting out the queue timeout"""
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=2))
+        except _queue.Empty:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker exited with {dead[0].exitcode}"
+            assert time.time() - t0 < timeout, "workers timed out"
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -43,7 +58,22 @@ class SaturationLoss:
         return res
 
 
-def _build(cutn, world, rank, group, coupled_loss=False):
+class GlobalMeanPrompt(torch.nn.Module):
+    """the oracle Prompt with the global-mean denominator the Session sets on sharded runs (what the HIP Prompt does natively)"""
+
+    def __init__(self, embed, weight=1.0, stop=float("-inf")):
+        super().__init__()
+        self.embed, self.weight, self.stop, self.denom = embed, weight, stop, None
+
+    def forward(self, x):
+        from oracle import prompt_ref
+        full = prompt_ref.Prompt(self.embed, self.weight, self.stop)(x)                     # mean over the local pairs
+        if self.denom is None:
+            return full
+        return full * (x.shape[0] * self.embed.shape[0]) / self.denom                        # rescale to the global mean
+
+
+def _build(cutn, world, rank, group, coupled_loss=False, extras=False):
     from oracle import prompt_ref, step_ref
     from pixray_amd import cutouts as pc, weights
     from pixray_amd.engine import Session
@@ -67,27 +97,24 @@ def _build(cutn, world, rank, group, coupled_loss=False):
     pm = prompt_ref.Prompt(e, 1.0, float("-inf"))
     pm.denom = None
 
-    class _P(torch.nn.Module):      # Prompt with the global-mean denominator the Session sets on sharded runs
-        def __init__(self):
-            super().__init__()
-            self.embed, self.denom = e, None
-
-        def forward(self, x):
-            full = prompt_ref.Prompt(e, 1.0, float("-inf"))(x)        # mean over the local pairs
-            if self.denom is None:
-                return full
-            return full * (x.shape[0] * e.shape[0]) / self.denom      # rescale to the global mean
     custom = [{"loss": SaturationLoss(), "weight": 3.0}] if coupled_loss else []
-    return Session(drawer, {"tiny-B/32": perceptor}, {224: mk}, {"tiny-B/32": [_P()]}, learning_rate=0.05, iterations=10,
-                   seed=3, world_size=world, rank=rank, group=group, custom_losses=custom)
+    kw = {}
+    if extras:      # image prompt (cached transforms, embeddings all-gathered) + the z / pixel regularisers of pixray.py:1344-1375
+        target = torch.rand(1, 3, 96, 96, generator=g)
+        init = torch.rand(1, 3, 96, 96, generator=g)
+        kw = dict(image_prompts={"tiny-B/32": [target]}, image_prompt_weight=0.7, z_orig=drawer.get_z_copy().detach() * 0.9,
+                  init_weight=0.3, init_weight_dist=0.2, init_weight_pix=0.4, init_weight_cos=0.1, init_image_tensor=init)
+    return Session(drawer, {"tiny-B/32": perceptor}, {224: mk}, {"tiny-B/32": [GlobalMeanPrompt(e)]}, learning_rate=0.05,
+                   iterations=10, seed=3, world_size=world, rank=rank, group=group, custom_losses=custom,
+                   prompt_factory=GlobalMeanPrompt, **kw)
 
 
-def _worker(rank, world, port, cutn, q, coupled_loss=False):
+def _worker(rank, world, port, cutn, q, coupled_loss=False, extras=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    sess = _build(cutn, world, rank, dist.group.WORLD, coupled_loss)
+    sess = _build(cutn, world, rank, dist.group.WORLD, coupled_loss, extras)
     for it in range(2):
         sess.train(it)
     q.put((rank, sess.drawer.get_z().detach().numpy().copy(), sess.drawer.get_z().grad.detach().numpy().copy(),
@@ -96,18 +123,29 @@ def _worker(rank, world, port, cutn, q, coupled_loss=False):
     dist.destroy_process_group()
 
 
-def test_world2_gloo_matches_single_process():
-    cutn, world = 4, 2
+def _run_world(world, cutn, coupled_loss=False, extras=False):
+    """spawn `world` gloo ranks, return their (rank, z, grad, loss) sorted by rank; never leaves a worker behind"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cutn, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cutn, q, coupled_loss, extras)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted(_collect(q, procs, world), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+
+
+def test_world2_gloo_matches_single_process():
+    cutn, world = 4, 2
+    res = _run_world(world, cutn)
     # single process, full batch
     torch.set_num_threads(4)
     ref = _build(cutn, 1, 0, None)
@@ -128,16 +166,7 @@ def test_world2_batch_coupled_custom_loss_is_scored_on_the_gathered_batch():
     """a SaturationLoss-style plugin (std over all cutout pixels) on 2 ranks: the loop gathers the cutout shards for it,
     so z, its gradient and the loss value equal the single-process run (the per-shard std would not)"""
     cutn, world = 4, 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cutn, q, True)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(world, cutn, True)
     torch.set_num_threads(4)
     ref = _build(cutn, 1, 0, None, True)
     for it in range(2):
@@ -151,6 +180,23 @@ def test_world2_batch_coupled_custom_loss_is_scored_on_the_gathered_batch():
     # the prompt shares add up; the coupled loss is the same full-batch value on both ranks (counted once)
     sat_ref = float(ref.last_losses[-1].detach())
     assert abs((l0 + l1) - (float(sum(l.detach() for l in ref.last_losses)) + sat_ref)) < 1e-5
+
+
+def test_world2_image_prompts_and_regularisers_match_single_process():
+    """image prompts (every rank compares its cutouts with ALL target embeddings: all-gather) and the z / pixel regularisers
+    (replicated on z, split over the ranks on the image) on 2 ranks equal the single-process run"""
+    cutn, world = 4, 2
+    res = _run_world(world, cutn, False, True)
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None, False, True)
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    (_, z0, g0, _), (_, z1, g1, _) = res
+    z0, g0, z1, g1 = [torch.from_numpy(t) for t in (z0, g0, z1, g1)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (z0 - z_ref).abs().max().item() < 1e-5
 
 
 def test_cutn_must_divide_world_size():
