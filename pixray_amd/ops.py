@@ -8,7 +8,7 @@ path: tensors must live on a ROCm device and the shared library must be built.
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Sequence
+from typing import Sequence
 
 import torch
 

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import numpy as np
 import torch
