@@ -459,6 +459,26 @@ class Session:
         self.cur_iteration = cur_it + 1
         return True
 
+    def do_run(self, return_display: bool = False, display_every: int = 20) -> bool:
+        """The outer loop of `do_run` without the animation ring (pixray.py:1614-1631): train until `iterations` (or until the
+        learning-rate drops run out); with `return_display` it returns False every `display_every` iterations so that a
+        serving front end can show progress and call again (cogrun.py:47-52); True when the run is complete."""
+        keep_going = True
+        while keep_going:
+            it = self.cur_iteration
+            try:
+                keep_going = self.train(it)
+            except RuntimeError as e:
+                print("Oops: runtime error: ", e)
+                print("Try reducing --num-cuts to save memory")
+                raise
+            if it == self.iterations:
+                break
+            self.cur_iteration = it + 1
+            if keep_going and return_display and self.cur_iteration % display_every == 0:
+                return False
+        return True
+
     def checkdrop(self, it, losses) -> bool:
         """pixray.py:1091-1109 -- the comparison forces a device->host sync, exactly as in the reference; it only
         runs when auto_stop is enabled."""

@@ -349,3 +349,23 @@ def test_overlay_image_is_pasted_and_re_encoded_on_schedule():
     for it in range(2, 10):
         sess.train(it)
     assert len(calls) == 2                                # iterations 1 and 4 only (until = 6)
+
+
+def test_do_run_outer_loop_and_display_returns():
+    """pixray.py:1614-1631: run to `iterations`; with return_display the loop hands control back every display_every
+    iterations and resumes where it stopped"""
+    sess = _cpu_session(iters=5)
+    calls = []
+    orig = sess.train
+    sess.train = lambda it=None: (calls.append(it), orig(it))[1]
+    assert sess.do_run() is True
+    assert calls == [0, 1, 2, 3, 4, 5] and sess.cur_iteration == 5
+    sess2 = _cpu_session(iters=5)
+    steps = []
+    while not sess2.do_run(return_display=True, display_every=2):
+        steps.append(sess2.cur_iteration)
+    assert steps == [2, 4] and sess2.cur_iteration == 5
+    boom = _cpu_session(iters=3)
+    boom.train = lambda it=None: (_ for _ in ()).throw(RuntimeError("out of memory"))
+    with pytest.raises(RuntimeError):
+        boom.do_run()
