@@ -182,6 +182,7 @@ class Session:
         self.last_embeds = None
         self._graph = None
         self._host_ready = False
+        self.cur_fill = 0.0
         self._shard_cutouts()
         self.opts = self.rebuild_optimisers()
 
@@ -221,7 +222,9 @@ class Session:
 
     # ------------------------------------------------------------------ forward of one iteration
     def do_synth_and_filter(self, loss_list):
-        """pixray.py:1203-1241 (RGBA flattening is a diffvg-drawer feature and is not provided)"""
+        """pixray.py:1203-1241; returns (image [1,3,H,W], alpha or None).  A drawer may return RGBA: with `args.transparent` the
+        colours are composited over this iteration's gray fill (the random squash of pixray.py:1231-1236), otherwise the
+        alpha channel is dropped."""
         out = self.drawer.synth(self.cur_iteration)
         for f in self.filters:
             out, new_losses = f["filter"](out)
@@ -229,9 +232,15 @@ class Session:
                 loss_list.append(f["weight"] * new_losses)
             else:
                 loss_list += [f["weight"] * l for l in new_losses]
+        alpha = None
         if out.shape[1] == 4:
-            out = out[:, 0:3, :, :]
-        return out
+            colors = out[:, 0:3, :, :]
+            if getattr(self.args, "transparent", False):
+                alpha = out[:, 3, :, :]
+                out = alpha[:, None] * colors + (1 - alpha[:, None]) * float(self.cur_fill)
+            else:
+                out = colors
+        return out, alpha
 
     def ascend_txt(self):
         """pixray.py:1243-1406"""
@@ -240,7 +249,7 @@ class Session:
             self._host_prep(it)
         self._host_ready = False
         result: List[torch.Tensor] = []
-        out = self.do_synth_and_filter(result)
+        out, img_alpha = self.do_synth_and_filter(result)
         if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and out.requires_grad:
             import torch.distributed as dist
 
@@ -308,6 +317,9 @@ class Session:
             f2 = self.z_orig.reshape(1, -1)
             result.append(F.cosine_embedding_loss(f, f2, torch.ones_like(f[0])) * self.init_weight_cos)
         needed_globals = {"cur_iteration": it, "embeds": iii}                                  # pixray.py:1377-1381
+        t_w = getattr(self.args, "transparent_weight", 0.0)
+        if img_alpha is not None and t_w != 0:                                                 # pixray.py:1383-1386
+            result.append((t_w / self.world_size if self.world_size > 1 else t_w) * torch.mean(img_alpha))
         full_cutouts = full_globals = None
         for t in self.custom_losses:
             w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]
@@ -334,6 +346,7 @@ class Session:
         """Host side of an iteration: the random draws the reference makes in Python / kornia (fill colour
         pixray.py:1255-1258, padding-mode parity 1250-1253, augmentation parameters) and their staging to the device."""
         fill = float(torch.rand((), generator=self.rng, dtype=torch.float64))
+        self.cur_fill = fill
         for mk in self.cutoutsTable.values():
             if hasattr(mk, "prepare"):
                 mk.prepare(iteration=it, fill=fill)
@@ -362,6 +375,8 @@ class Session:
         to eager launches when something in the session cannot be captured (custom optimisers, batches > 1, ...)."""
         z = self.drawer.get_z()
         if z is None or not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
+            return False
+        if getattr(self.args, "transparent", False):      # the RGBA squash uses this iteration's host-drawn gray as a constant
             return False
         # image / spot prompts go through the cached-transform path, which stages a fresh descriptor table per call
         if any(self.pmsImageTable.values()) or any(self.spotPmsTable.values()) or any(self.spotOffPmsTable.values()):

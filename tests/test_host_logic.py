@@ -369,3 +369,53 @@ def test_do_run_outer_loop_and_display_returns():
     boom.train = lambda it=None: (_ for _ in ()).throw(RuntimeError("out of memory"))
     with pytest.raises(RuntimeError):
         boom.do_run()
+
+
+class _RgbaDrawer(DrawingInterface):
+    """a drawer plugin that returns RGBA (pixray's diffvg drawers do): 4 x 8 x 8 parameters upsampled to the canvas"""
+
+    def __init__(self, settings=None):
+        self.z = torch.full((1, 4, 8, 8), 0.5).requires_grad_(True)
+
+    def load_model(self, settings, device):
+        pass
+
+    def get_opts(self, decay_divisor):
+        return None
+
+    def get_z(self):
+        return self.z
+
+    def synth(self, cur_iteration):
+        return torch.nn.functional.interpolate(self.z, size=(256, 256), mode="nearest").clamp(0, 1)
+
+    def clip_z(self):
+        with torch.no_grad():
+            self.z.clamp_(0, 1)
+
+
+def test_rgba_drawers_are_flattened_over_the_iteration_fill_and_the_transparent_loss():
+    """pixray.py:1225-1241, 1383-1386: with --transparent an RGBA image is composited over this iteration's random gray and
+    mean(alpha) * transparent_weight joins the loss list; without it the alpha channel is dropped"""
+    dr = _RgbaDrawer()
+    with torch.no_grad():
+        dr.z[:, 3] = 0.25
+        dr.z[:, 0] = 1.0
+    sess = _cpu_session(drawer=dr)
+    sess.args.transparent, sess.args.transparent_weight = True, 0.5
+    sess._host_prep(0)
+    fill = sess.cur_fill
+    assert 0.0 <= fill <= 1.0
+    out, alpha = sess.do_synth_and_filter([])
+    assert tuple(out.shape) == (1, 3, 256, 256) and tuple(alpha.shape) == (1, 256, 256)
+    assert torch.allclose(out[0, 0], torch.full((256, 256), 0.25 * 1.0 + 0.75 * fill), atol=1e-6)
+    assert torch.allclose(out[0, 1], torch.full((256, 256), 0.25 * 0.5 + 0.75 * fill), atol=1e-6)
+    sess._host_ready = False
+    assert sess.train(0)
+    assert len(sess.last_losses) == 2 and abs(float(sess.last_losses[-1].detach()) - 0.5 * 0.25) < 1e-6
+    assert dr.z.grad[:, 3].abs().sum() > 0                      # the alpha channel is trained through both terms
+    assert sess.enable_graph() is False
+    plain = _cpu_session(drawer=_RgbaDrawer())
+    out, alpha = plain.do_synth_and_filter([])
+    assert alpha is None and tuple(out.shape) == (1, 3, 256, 256)
+    assert plain.train(0) and len(plain.last_losses) == 1
