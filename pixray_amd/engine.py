@@ -122,7 +122,7 @@ class Session:
                  spot_prompts: Optional[Dict[str, Sequence[object]]] = None,
                  spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None,
                  overlay_image=None, overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
-                 overlay_alpha: Optional[int] = None, prompt_factory=None):
+                 overlay_alpha: Optional[int] = None, prompt_factory=None, loss_globals: Optional[dict] = None):
         self.drawer = drawer
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
@@ -176,7 +176,7 @@ class Session:
         self.iter_drop_delay = 20
         self.best_loss = None
         self.best_iter = 0
-        self.lossGlobals = {}
+        self.lossGlobals = dict(loss_globals or {})      # pixray.py:993-995 (plugins.setup_custom_losses builds it)
         self.rng = torch.Generator().manual_seed(seed)       # fill colour stream (python random in the reference)
         self.last_losses: Optional[List[torch.Tensor]] = None
         self.last_embeds = None

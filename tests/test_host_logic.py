@@ -419,3 +419,47 @@ def test_rgba_drawers_are_flattened_over_the_iteration_fill_and_the_transparent_
     out, alpha = plain.do_synth_and_filter([])
     assert alpha is None and tuple(out.shape) == (1, 3, 256, 256)
     assert plain.train(0) and len(plain.last_losses) == 1
+
+
+def test_custom_loss_registration_flow():
+    """pixray.py:131-140, 961-995, 2104-2109: name[:weight] chunks, `->` instance arguments, parse_settings / add_globals of
+    every instance, KeyError for an unknown name, the TypeError hint for a constructor without device=, and the globals
+    reaching get_loss through the Session"""
+    from pixray_amd import plugins
+
+    class Tint(LossInterface):
+        def instance_settings(self, arglist):
+            self.channel = int(arglist[0]) if arglist else 0
+
+        def parse_settings(self, args):
+            args.tint_seen = True
+            return args
+
+        def add_globals(self, args):
+            return {"tint_target": 0.25}
+
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            assert args.tint_seen and globals["cur_iteration"] >= 0
+            return (out[:, self.channel].mean() - lossGlobals["tint_target"]) ** 2
+
+    class NoDevice(LossInterface):
+        def __init__(self):
+            pass
+
+    plugins.add_custom_loss("tint", Tint)
+    with pytest.raises(AssertionError):
+        plugins.add_custom_loss("bad", object)
+    args = _Settings(saturation_weight=1.0)
+    losses, loss_globals, args = plugins.setup_custom_losses("tint:0.5->2, tint", args, device="cpu")
+    assert [t["weight"] for t in losses] == [0.5, 1] and losses[0]["loss"].channel == 2 and losses[1]["loss"].channel == 0
+    assert loss_globals == {"tint_target": 0.25} and args.tint_seen
+    assert "style" in plugins.loss_class_table
+    with pytest.raises(KeyError):
+        plugins.setup_custom_losses("nonexistent", args)
+    plugins.add_custom_loss("nodev", NoDevice)
+    with pytest.raises(TypeError):
+        plugins.setup_custom_losses("nodev", args)
+    assert plugins.setup_custom_losses(None, args)[:2] == ([], {})
+    sess = _cpu_session(custom_losses=losses, loss_globals=loss_globals)
+    sess.args = args
+    assert sess.train(0) and len(sess.last_losses) == 3 and all(torch.isfinite(l) for l in sess.last_losses)
