@@ -463,3 +463,32 @@ def test_custom_loss_registration_flow():
     sess = _cpu_session(custom_losses=losses, loss_globals=loss_globals)
     sess.args = args
     assert sess.train(0) and len(sess.last_losses) == 3 and all(torch.isfinite(l) for l in sess.last_losses)
+
+
+def test_drawer_and_filter_tables():
+    """pixray.py:72-99 / 612-626 (drawer table, size rounding by num_resolutions) and 54-58 / 650-669 (filter table,
+    ValueError for an unknown filter, weights parsed like prompts)"""
+    from pixray_amd import plugins
+    assert {"vqgan", "fft", "fast_pixel"} <= set(plugins.class_table)
+
+    class ThreeLevels(_CustomDrawer):
+        def get_num_resolutions(self):
+            return 3
+
+    plugins.add_custom_drawer("three", ThreeLevels)
+    with pytest.raises(AssertionError):
+        plugins.add_custom_drawer("bad", dict)
+    st = _Settings(drawer="three", size=(130, 67))
+    drawer, side = plugins.make_drawer(st, "cpu")
+    assert isinstance(drawer, ThreeLevels) and side == (128, 64)
+    st = _Settings(drawer="fast_pixel", size=(130, 67), pixel_size=(13, 6), pixel_scale=None)
+    drawer, side = plugins.make_drawer(st, "cpu")
+    assert side == (130, 67)                                   # no resolutions: the size is kept
+    with pytest.raises(KeyError):
+        plugins.make_drawer(_Settings(drawer="nope", size=(8, 8)), "cpu")
+    plugins.add_custom_filter("half", _HalfBrightFilter)
+    fl = plugins.setup_filters("half:0.25, half", _Settings(), device="cpu")
+    assert [f["weight"] for f in fl] == [0.25, 1] and all(isinstance(f["filter"], _HalfBrightFilter) for f in fl)
+    with pytest.raises(ValueError, match="Requested filter not found"):
+        plugins.setup_filters("sepia", _Settings())
+    assert plugins.setup_filters(None, _Settings()) == []
