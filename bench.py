@@ -103,17 +103,18 @@ def main():
     # ---- roofline leg: per-launch HIP-event timing of the GEMM engine over a few extra steps ------------------
     # (eager launches: events cannot be recorded around the nodes of a replayed graph)
     roofline = None
-    sess._graph = None
+    sess._drop_graph()
     if rank == 0:
-        lib = _lib.load()
         import ctypes
-        lib.prx_profile_gemm_enable(1)
+        prof = api.GemmProfile(sess)
+        prof.enable(True)
         for _ in range(args.profile_steps):
             sess.train(it); it += 1
         torch.cuda.synchronize(dev)
-        lib.prx_profile_gemm_enable(0)
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-        rc = lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+        prof.enable(False)
+        _ms, _fl, _n = prof.collect()
+        ms, fl, n = ctypes.c_double(_ms), ctypes.c_double(_fl), ctypes.c_longlong(_n)
+        rc = 0
         # A bracket [event, kernel, event] also times the events' own timestamp packets.  An EMPTY bracket on this stream
         # measures ~5 us; around a kernel about half of that is hidden behind the kernel's own dispatch/drain, and taking
         # half of the empty-bracket time off every launch reproduces rocprofv3's kernel durations for the same command

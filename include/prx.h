@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PRX_ABI_VERSION 1
+#define PRX_ABI_VERSION 2
 
 typedef void* prx_stream_t; /* hipStream_t */
 
@@ -55,7 +55,21 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
 #define PRX_A_ROWMAJOR 0
 #define PRX_A_CONV3X3 1          /* implicit im2col of an NHWC tensor, 3x3 pad 1 */
 
-/* C[M,N] = epilogue(alpha * A[M,K] * Bt[N,K]^T); bf16 MFMA, fp32 accumulate.
+/* Operand precision of a runner handle (the `precision` field of the *_config structs below):
+ *   PRX_PREC_BF16  GEMM operands (inter-kernel activations, weight packs) bf16, fp32 accumulate on
+ *                  v_mfma_f32_32x32x16_bf16; residual streams, norms, softmax statistics, loss, optimiser fp32.
+ *   PRX_PREC_F32   every operand fp32 end to end on v_mfma_f32_32x32x2_f32 (exact f32 = what the reference's CPU
+ *                  path computes, pixray.py:275-280, vqgan.py:60-79, slip.py:21-66): the parity mode, 1/16 of the rate. */
+#define PRX_PREC_BF16 0
+#define PRX_PREC_F32 1
+
+/* Engine state of ONE handle: tile / split-K overrides and the optional per-launch timing log.  Each runner handle owns
+ * one (prx_*_gemm_ctx below); the library has no process-global mutable state. */
+typedef struct prx_gemm_ctx prx_gemm_ctx;
+prx_gemm_ctx* prx_gemm_ctx_create(void);
+void prx_gemm_ctx_destroy(prx_gemm_ctx* c);
+
+/* C[M,N] = epilogue(alpha * A[M,K] * Bt[N,K]^T); MFMA, fp32 accumulate.
  * Replaces torch.nn.functional.linear / conv2d under clip.model.* and
  * taming Decoder (call sites slip.py:65, vqgan.py:195). */
 typedef struct prx_gemm_args {
@@ -76,6 +90,8 @@ typedef struct prx_gemm_args {
     int act;
     float* out_f32; int ldc_f32;
     void* out_bf16; void* out_bf16_pre; int ldc_bf16;
+    int f32;            /* PRX_PREC_F32: A, B, aux, out_bf16, out_bf16_pre are all fp32 and the product is exact f32 */
+    prx_gemm_ctx* ctx;  /* tuning / timing context or NULL (built-in heuristics) */
 } prx_gemm_args;
 int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream);
 
@@ -142,6 +158,7 @@ typedef struct prx_vqgan_config {
     int n_embed;           /* 16384 */
     int out_ch;            /* 3 */
     int latent_h, latent_w;/* z is [1, z_channels, latent_h, latent_w] */
+    int precision;         /* PRX_PREC_BF16 (fast path) | PRX_PREC_F32 (exact-f32 MFMA parity mode); the encoder ignores it */
 } prx_vqgan_config;
 int prx_vqgan_create(prx_vqgan** out, const prx_vqgan_config* cfg, const float* const* weights, int n_weights,
                      prx_stream_t s);
@@ -180,12 +197,14 @@ int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre,
  * x: [3,H,W] fp32, already in the extractor's input space (StyleLoss.py:41-45 normalises outside this call).
  * feats[k] (k = 0..8, or NULL when not wanted): fp32 NHWC [h_k*w_k, C_k], shape from prx_vgg16_feature_shape.
  * workspace: caller-owned device buffer of prx_vgg16_workspace_bytes(H, W) bytes holding this forward's activations; the
- * matching backward reads it, so any number of forward passes can be alive at once.
+ * matching backward reads it, so any number of forward passes can be alive at once.  precision: PRX_PREC_BF16 | PRX_PREC_F32
+ * (the workspace of the exact mode is twice as large).
  * backward: g_feats[k] fp32 NHWC gradient of feature k (or NULL); g_x: [3,H,W] fp32, overwritten. */
 typedef struct prx_vgg16 prx_vgg16;
-int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, prx_stream_t s);
+int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, int precision,
+                     prx_stream_t s);
 void prx_vgg16_destroy(prx_vgg16* h);
-long long prx_vgg16_workspace_bytes(int H, int W);
+long long prx_vgg16_workspace_bytes(int H, int W, int precision);
 int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c);
 int prx_vgg16_forward(prx_vgg16* h, const float* x, int H, int W, void* workspace, float* const* feats, prx_stream_t s);
 int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, prx_stream_t s);
@@ -234,6 +253,7 @@ typedef struct prx_clip_vit_config {
     int heads;             /* 12 */
     int output_dim;        /* 512 */
     int max_batch;         /* capacity in cutouts */
+    int precision;         /* PRX_PREC_BF16 | PRX_PREC_F32 */
 } prx_clip_vit_config;
 int prx_clip_vit_create(prx_clip_vit** out, const prx_clip_vit_config* cfg, const float* const* weights, int n_weights,
                         prx_stream_t s);
@@ -261,6 +281,7 @@ typedef struct prx_clip_resnet_config {
     int heads;             /* 40 = width * 32 / 64 */
     int output_dim;        /* 640 */
     int max_batch;
+    int precision;         /* PRX_PREC_BF16 | PRX_PREC_F32 */
 } prx_clip_resnet_config;
 int prx_clip_resnet_create(prx_clip_resnet** out, const prx_clip_resnet_config* cfg, const float* const* weights, int n_weights,
                            prx_stream_t s);
@@ -324,17 +345,28 @@ int prx_k_mha_fwd_gen(const void* qkv, void* out, float* lse, int N, int T, int 
 int prx_k_mha_bwd_gen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T, int C,
                       int heads, prx_stream_t s);
 
-/* A/B switch between the two GEMM kernels (1 = direct-to-LDS v2, default; 0 = register-staged v1) */
-void prx_gemm_variant(int use_glds);
-/* tuning override of the tile / split-K heuristic: bm,bn in {(128,128),(128,64),(64,64)}; (0,0,0) = heuristic */
-void prx_gemm_tile_override(int bm, int bn, int splits);
+/* the exact-f32 attention of the PRX_PREC_F32 mode (fp32 qkv / out / dout / dqkv, any T, head dim 64) */
+int prx_k_mha_fwd_f32(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, prx_stream_t s);
+int prx_k_mha_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int N, int T, int C,
+                      int heads, prx_stream_t s);
+
+/* tuning override of the tile / split-K heuristic of one context: bm,bn in {(128,128),(128,64),(64,64),(256,128)};
+ * (0,0,0) = heuristic.  Negative bm selects a switch: (-1,_,v) XCD-aware tile order 0/1/2; (-2,_,n) LDS pipeline depth;
+ * (-3,_,v) 1 = direct-to-LDS v2 kernel (default), 0 = register-staged v1; (-5,_,v) scalar-tap conv gather. */
+void prx_gemm_tile_override(prx_gemm_ctx* c, int bm, int bn, int splits);
 /* the same per problem shape (tools/gemm_rules.py): mode = a_mode + 2*up + 4*a_is_f32; splits 0 = heuristic; bm = 0 drops
  * the rule, M = 0 drops all rules */
-void prx_gemm_tile_rule(int M, int N, int K, int mode, int bm, int bn, int splits);
+void prx_gemm_tile_rule(prx_gemm_ctx* c, int M, int N, int K, int mode, int bm, int bn, int splits);
 
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
-void prx_profile_gemm_enable(int on);
-int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches);
+void prx_profile_gemm_enable(prx_gemm_ctx* c, int on);
+int prx_profile_gemm_collect(prx_gemm_ctx* c, double* total_ms, double* total_flop, long long* launches);
+
+/* the engine context owned by a runner handle (valid for the handle's lifetime; do not destroy) */
+prx_gemm_ctx* prx_vqgan_gemm_ctx(prx_vqgan* h);
+prx_gemm_ctx* prx_clip_vit_gemm_ctx(prx_clip_vit* h);
+prx_gemm_ctx* prx_clip_resnet_gemm_ctx(prx_clip_resnet* h);
+prx_gemm_ctx* prx_vgg16_gemm_ctx(prx_vgg16* h);
 
 #ifdef __cplusplus
 }

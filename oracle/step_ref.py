@@ -79,13 +79,16 @@ class OracleMakeCutouts(torch.nn.Module):
         self.last_params = None
 
     def forward(self, input, spot=None):
+        mask = None
+        if spot is not None:                     # pixray.py:453-458; `spot_masks` = (inside, outside) bool [3,S,S]
+            mask = self.spot_masks[1] if spot == 0 else self.spot_masks[0]
         if self.transforms is not None:          # cached path (pixray.py:480-486): same geometry, no jitter, no noise here
-            out = cutouts_ref.make_cutouts_cached(input, self.last_params, self.cut_size)
+            out = cutouts_ref.make_cutouts_cached(input, self.last_params, self.cut_size, spot_mask=mask)
             return out if self.shard is None else out[self.shard[0]:self.shard[1]]
         prm = self.sampler(self.iteration, self.fill)
         self.last_params = prm
         self.transforms = cutouts_ref.composed_transforms(prm, self.cut_size)
-        out = cutouts_ref.make_cutouts(input, prm, self.cut_size)
+        out = cutouts_ref.make_cutouts(input, prm, self.cut_size, spot_mask=mask)
         if self.shard is not None:
             out = out[self.shard[0]:self.shard[1]]
         return out
@@ -115,10 +118,10 @@ def _metrics(a: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
     return rel, cos
 
 
-def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2):
+def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2, precision="bf16"):
     from pixray_amd import api
     return api.build_vqgan_clip_session(size=size, vqgan_model=vqgan_model, clip_model=clip_model, num_cuts=cutn,
-                                        seed=seed, device=device, learning_rate=lr)
+                                        seed=seed, device=device, learning_rate=lr, precision=precision)
 
 
 def _oracle_inputs(vqgan_model, clip_model, seed):
@@ -140,10 +143,11 @@ def _draws(cutn, S, seed, iteration, with_noise=True, aspect=1.0):
 
 
 def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                          device="cuda:0") -> Dict[str, float]:
-    """dL/dz (and the intermediate image / embeddings / loss) of the HIP path vs the oracle after ONE iteration."""
+                          device="cuda:0", precision="bf16") -> Dict[str, float]:
+    """dL/dz (and the intermediate image / embeddings / loss) of the HIP path vs the oracle after ONE iteration.
+    `precision`: "bf16" (the fast path) or "f32" (the exact-f32 MFMA parity mode)."""
     from pixray_amd import api
-    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device)
+    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, precision=precision)
     vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
     S = clip_cfg.input_resolution
     prm = _draws(cutn, S, seed, 0, aspect=size[0] / size[1])      # pixray.py:1931: global_aspect_width
@@ -167,8 +171,32 @@ def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
                 indices_equal=bool(torch.equal(sess.drawer.handle.last_indices.cpu().long(), idx_ref)))
 
 
+def compare_precisions(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
+                       device="cuda:0") -> Dict[str, float]:
+    """The bf16 fast path against the exact-f32 MFMA mode ON THE DEVICE, same weights / z / augmentation draws / noise:
+    what the bf16 operand rounding alone costs (no oracle involved; both sides are the product's kernels)."""
+    out = {}
+    res = {}
+    for prec in ("f32", "bf16"):
+        sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, precision=prec)
+        S = next(iter(sess.cutoutsTable))
+        sess.cutoutsTable[S].fixed_params = _draws(cutn, S, seed, 0, aspect=size[0] / size[1])
+        loss = sum(sess.ascend_txt())
+        loss.backward()
+        res[prec] = dict(dz=sess.drawer.get_z().grad.detach().cpu(), emb=sess.last_embeds.detach().cpu(),
+                         img=sess.drawer.synth(0).detach().cpu(), loss=float(loss.detach()),
+                         idx=sess.drawer.handle.last_indices.cpu().long())
+        del sess
+    out["dz_rel_l2"], out["dz_cosine"] = _metrics(res["bf16"]["dz"], res["f32"]["dz"])
+    out["embeds_rel_l2"], _ = _metrics(res["bf16"]["emb"], res["f32"]["emb"])
+    out["image_rel_l2"], _ = _metrics(res["bf16"]["img"], res["f32"]["img"])
+    out["loss_abs_err"] = abs(res["bf16"]["loss"] - res["f32"]["loss"])
+    out["indices_equal"] = bool(torch.equal(res["bf16"]["idx"], res["f32"]["idx"]))
+    return out
+
+
 def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                    device="cuda:0", lr=0.2) -> Dict[str, float]:
+                    device="cuda:0", lr=0.2, precision="bf16") -> Dict[str, float]:
     """k optimiser steps (train(): synth .. Adam .. clip_z) of the HIP path vs the oracle.
 
     The loop is chaotic in the dynamical-systems sense: Adam with lr 0.2 moves every component of z by ~0.2 per step
@@ -178,8 +206,8 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     oracle's z (and, for the HIP optimiser, the oracle's Adam moments), the per-step dL/dz and the resulting z are
     compared, and the free-running HIP loss curve is reported next to the oracle's for information."""
     from pixray_amd import api
-    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr)
-    free = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr)      # free-running copy
+    sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr, precision=precision)
+    free = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr, precision=precision)      # free-running copy
     vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)
     S = clip_cfg.input_resolution
     mk, mk_free = sess.cutoutsTable[S], free.cutoutsTable[S]

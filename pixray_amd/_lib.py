@@ -36,7 +36,28 @@ class GemmArgs(ctypes.Structure):
         ("act", ctypes.c_int),
         ("out_f32", ctypes.c_void_p), ("ldc_f32", ctypes.c_int),
         ("out_bf16", ctypes.c_void_p), ("out_bf16_pre", ctypes.c_void_p), ("ldc_bf16", ctypes.c_int),
+        ("f32", ctypes.c_int), ("ctx", ctypes.c_void_p),
     ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if not self.ctx:               # tests / tools time and tune their bare GEMM calls through one context of their own
+            try:
+                self.ctx = tool_ctx()
+            except PrxError:
+                pass
+
+
+PREC_BF16, PREC_F32 = 0, 1
+
+
+def precision_code(precision) -> int:
+    """'bf16' | 'f32' (or the PRX_PREC_* integers) -> PRX_PREC_*"""
+    if precision in (PREC_BF16, "bf16", None):
+        return PREC_BF16
+    if precision in (PREC_F32, "f32", "fp32", "float32"):
+        return PREC_F32
+    raise ValueError(f"unknown precision {precision!r} (want 'bf16' or 'f32')")
 
 
 _SCALARS = {
@@ -77,6 +98,16 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
 
 _lib = None
 _protos = None
+_tool_ctx = None
+
+
+def tool_ctx():
+    """A `prx_gemm_ctx` owned by this Python process for bare `prx_k_gemm` calls (tests, tools/gemm_*.py): tile overrides
+    and per-launch timing live in a context, never in the library (include/prx.h).  Runner handles have their own."""
+    global _tool_ctx
+    if _tool_ctx is None:
+        _tool_ctx = load().prx_gemm_ctx_create()
+    return _tool_ctx
 
 
 def load() -> ctypes.CDLL:

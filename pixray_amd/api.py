@@ -33,7 +33,7 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                              image_prompt_shuffle: bool = False, init_weight: float = 0.0, init_weight_dist: float = 0.0,
                              init_weight_pix: float = 0.0, init_weight_cos: float = 0.0, overlay_image=None,
                              overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
-                             overlay_alpha: Optional[int] = None) -> Session:
+                             overlay_alpha: Optional[int] = None, precision: str = "bf16") -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
     a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
 
@@ -44,13 +44,14 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     images [1,3,H,W] in [0,1] turned into per-iteration throwaway Prompts through the cached cutout transforms
     (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`);
     `overlay_*`: a PIL image (or path) pasted over the current image every `overlay_every` iterations and re-encoded by the HIP
-    VQGAN encoder (pixray.py:731-747, 1408-1420)."""
+    VQGAN encoder (pixray.py:731-747, 1408-1420); `precision`: "bf16" (bf16 MFMA operands, the fast path) or "f32" (every
+    contraction on the exact-f32 MFMA: the parity mode the bf16 numbers are measured against)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
     dev = torch.device(device)
     settings = types.SimpleNamespace(vqgan_model=vqgan_model, size=tuple(size), weight_seed=seed,
-                                     vqgan_config=None, vqgan_checkpoint=None)
+                                     vqgan_config=None, vqgan_checkpoint=None, precision=precision)
     drawer = VqganDrawer(settings)
     drawer.load_model(settings, dev)
     drawer.init_from_tensor(None if init_image is None else init_image.to(dev) * 2 - 1)
@@ -59,7 +60,7 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     perceptors, cutouts, pms_table = {}, {}, {}
     for mi, name in enumerate(clip_models):
         perceptor = get_clip_perceptor(name, dev, max_batch=per_rank, seed=seed + 1 + 10 * mi, group=group, tokenizer=tokenizer,
-                                       text_params=clip_text_params)
+                                       text_params=clip_text_params, precision=precision)
         perceptors[name] = perceptor
         if perceptor.input_resolution not in cutouts:                                   # pixray.py:643-649: one table per size
             cutouts[perceptor.input_resolution] = MakeCutouts(perceptor.input_resolution, num_cuts,
@@ -95,3 +96,51 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                    init_image_tensor=None if init_image is None else init_image.to(dev).float(),
                    overlay_image=overlay_image, overlay_every=overlay_every, overlay_offset=overlay_offset,
                    overlay_until=overlay_until, overlay_alpha=overlay_alpha)
+
+
+def session_gemm_contexts(sess: Session):
+    """The `prx_gemm_ctx` of every runner handle a session drives (drawer, perceptors, HIP-backed custom losses): bench.py
+    and tools/gemm_*.py enable per-launch timing / tile rules on these (the library itself has no global switch)."""
+    ctxs = []
+    h = getattr(sess.drawer, "handle", None)
+    if h is not None and hasattr(h, "gemm_ctx"):
+        ctxs.append(h.gemm_ctx)
+    for p in sess.perceptors.values():
+        h = getattr(p, "handle", None)
+        if h is not None and hasattr(h, "gemm_ctx"):
+            ctxs.append(h.gemm_ctx)
+    for t in sess.custom_losses:
+        owner = getattr(t["loss"], "extractor", None) or t["loss"]       # StyleLoss keeps its VGG16 runner in `.extractor`
+        h = getattr(owner, "handle", None)
+        if h is not None and hasattr(h, "gemm_ctx"):
+            ctxs.append(h.gemm_ctx)
+    return ctxs
+
+
+class GemmProfile:
+    """Per-launch GEMM timing (HIP events on the launch stream, include/prx.h prx_profile_gemm_*) over every runner
+    handle of a session; `tile_rule` applies a per-shape tile / split-K override to all of them (tools/gemm_rules.py)."""
+
+    def __init__(self, sess: Session):
+        self.lib = _lib.load()
+        self.ctxs = session_gemm_contexts(sess)
+
+    def enable(self, on: bool = True):
+        for c in self.ctxs:
+            self.lib.prx_profile_gemm_enable(c, int(bool(on)))
+
+    def collect(self):
+        """-> (total ms, total flop, launches) since the last collect"""
+        import ctypes
+        tot_ms = tot_fl = 0.0
+        tot_n = 0
+        for c in self.ctxs:
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+            if self.lib.prx_profile_gemm_collect(c, ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n)) != 0:
+                raise _lib.PrxError("prx_profile_gemm_collect failed: " + _lib.last_error())
+            tot_ms += ms.value; tot_fl += fl.value; tot_n += n.value
+        return tot_ms, tot_fl, tot_n
+
+    def tile_rule(self, M, N, K, mode, bm, bn, splits):
+        for c in self.ctxs:
+            self.lib.prx_gemm_tile_rule(c, M, N, K, mode, bm, bn, splits)

@@ -38,27 +38,31 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
     hipStream_t stream = (hipStream_t)stream_;
     PRX_REQUIRE(g != nullptr, "prx_k_gemm: null args");
     GemmDesc d;
+    d.f32 = g->f32;
     d.A = g->A; d.a_is_f32 = g->a_is_f32; d.a_mode = g->a_mode; d.lda = g->lda;
-    d.B = (const bf16_t*)g->B; d.ldb = g->ldb;
+    d.B = g->B; d.ldb = g->ldb;
     d.M = g->M; d.N = g->N; d.K = g->K;
     d.H = g->H; d.W = g->W; d.Cin = g->Cin; d.up = g->up;
     d.alpha = g->alpha;
     d.bias_n = g->bias_n; d.bias_m = g->bias_m;
-    d.aux = (const bf16_t*)g->aux; d.ldaux = g->ldaux;
+    d.aux = g->aux; d.ldaux = g->ldaux;
     d.resid = g->resid; d.ldr = g->ldr;
     d.act = g->act;
     d.out_f32 = g->out_f32; d.ldc_f32 = g->ldc_f32;
-    d.out_bf16 = (bf16_t*)g->out_bf16; d.out_bf16_pre = (bf16_t*)g->out_bf16_pre;
+    d.out_bf16 = g->out_bf16; d.out_bf16_pre = g->out_bf16_pre;
     d.ldc_bf16 = g->ldc_bf16;
-    return prx_gemm_launch(d, (float*)ws, ws_bytes, stream);
+    return prx_gemm_launch(d, (float*)ws, ws_bytes, stream, (GemmCtx*)g->ctx);
 }
 
-void prx_profile_gemm_enable(int on) { prx_gemm_profile_enable(on); }
-void prx_gemm_variant(int use_glds) { prx_gemm_set_variant(use_glds); }
-void prx_gemm_tile_override(int bm, int bn, int splits) { prx_gemm_force_tile(bm, bn, splits); }
-void prx_gemm_tile_rule(int M, int N, int K, int mode, int bm, int bn, int splits) { prx_gemm_tile_rule_set(M, N, K, mode, bm, bn, splits); }
-int prx_profile_gemm_collect(double* total_ms, double* total_flop, long long* launches) {
-    return prx_gemm_profile_collect(total_ms, total_flop, launches);
+prx_gemm_ctx* prx_gemm_ctx_create(void) { return (prx_gemm_ctx*)new GemmCtx(); }
+void prx_gemm_ctx_destroy(prx_gemm_ctx* c) { delete (GemmCtx*)c; }
+void prx_profile_gemm_enable(prx_gemm_ctx* c, int on) { prx_gemm_ctx_profile_enable((GemmCtx*)c, on); }
+void prx_gemm_tile_override(prx_gemm_ctx* c, int bm, int bn, int splits) { prx_gemm_ctx_force_tile((GemmCtx*)c, bm, bn, splits); }
+void prx_gemm_tile_rule(prx_gemm_ctx* c, int M, int N, int K, int mode, int bm, int bn, int splits) {
+    prx_gemm_ctx_tile_rule((GemmCtx*)c, M, N, K, mode, bm, bn, splits);
+}
+int prx_profile_gemm_collect(prx_gemm_ctx* c, double* total_ms, double* total_flop, long long* launches) {
+    return prx_gemm_ctx_profile_collect((GemmCtx*)c, total_ms, total_flop, launches);
 }
 
 }  // extern "C"

@@ -30,15 +30,15 @@ int prx_k_layernorm_bwd(const float* g, long long ldg, const float* x, long long
     return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, nullptr, 0, rows, C, S_(s));
 }
 int prx_k_transpose_bf16(const void* in, int ldin, void* out, int ldout, int R, int C, prx_stream_t s) {
-    return prx_transpose_bf16(CB_(in), ldin, B_(out), ldout, R, C, S_(s));
+    return prx_transpose_op(in, ldin, out, ldout, R, C, PRX_PREC_BF16, S_(s));
 }
 int prx_k_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, void* PT, int ldpt, int rows, int cols,
                        prx_stream_t s) {
-    return prx_softmax_rows(S, lds_, scale, B_(P), ldp, B_(PT), ldpt, rows, cols, S_(s));
+    return prx_softmax_rows(S, lds_, scale, P, ldp, PT, ldpt, rows, cols, PRX_PREC_BF16, S_(s));
 }
 int prx_k_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
                            void* dST, int lddst, int rows, int cols, prx_stream_t s) {
-    return prx_softmax_rows_bwd(CB_(P), ldp, dP, lddp, scale, B_(dS), ldds, B_(dST), lddst, rows, cols, S_(s));
+    return prx_softmax_rows_bwd(P, ldp, dP, lddp, scale, dS, ldds, dST, lddst, rows, cols, PRX_PREC_BF16, S_(s));
 }
 int prx_k_upsample2x_bwd(const float* hi, float* low, int NB, int Hl, int Wl, int C, prx_stream_t s) {
     return prx_upsample2x_bwd(hi, low, nullptr, NB, Hl, Wl, C, S_(s));
@@ -70,6 +70,14 @@ int prx_k_mha_fwd_gen(const void* qkv, void* out, float* lse, int N, int T, int 
 int prx_k_mha_bwd_gen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int N, int T, int C,
                       int heads, prx_stream_t s) {
     return prx_mha_bwd_gen(CB_(qkv), CB_(out), CB_(dout), lse, B_(dqkv), N, T, C, heads, S_(s));
+}
+
+int prx_k_mha_fwd_f32(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, prx_stream_t s) {
+    return prx_mha_fwd_f32(qkv, out, lse, N, T, C, heads, S_(s));
+}
+int prx_k_mha_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int N, int T, int C,
+                      int heads, prx_stream_t s) {
+    return prx_mha_bwd_f32(qkv, out, dout, lse, dqkv, N, T, C, heads, S_(s));
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "elementwise.h"
+#include "gemm.h"
 #include "../../include/prx.h"
 
 #define S_(x) ((hipStream_t)(x))
@@ -22,9 +23,10 @@ int prx_vqgan_create(prx_vqgan** out, const prx_vqgan_config* c, const float* co
     PRX_REQUIRE(c->n_mult >= 1 && c->n_mult <= 8, "prx_vqgan_create: bad n_mult %d", c->n_mult);
     return prx_vqgan_create_impl((PrxVqgan**)out, c->ch, c->ch_mult, c->n_mult, c->num_res_blocks, c->attn_resolution,
                                  c->resolution, c->z_channels, c->embed_dim, c->n_embed, c->out_ch, c->latent_h,
-                                 c->latent_w, weights, n_weights, S_(s));
+                                 c->latent_w, c->precision, weights, n_weights, S_(s));
 }
 void prx_vqgan_destroy(prx_vqgan* h) { prx_vqgan_destroy_impl((PrxVqgan*)h); }
+prx_gemm_ctx* prx_vqgan_gemm_ctx(prx_vqgan* h) { return (prx_gemm_ctx*)prx_vqgan_gemm_ctx_impl((PrxVqgan*)h); }
 int prx_vqgan_z_bounds(prx_vqgan* h, float* zmin, float* zmax, prx_stream_t s) {
     PRX_REQUIRE(h, "null handle");
     return prx_vqgan_bounds_impl((PrxVqgan*)h, zmin, zmax, S_(s));
@@ -47,11 +49,13 @@ int prx_vqgan_enc_create(prx_vqgan_enc** out, const prx_vqgan_config* c, int in_
 }
 void prx_vqgan_enc_destroy(prx_vqgan_enc* h) { prx_vqgan_enc_destroy_impl((PrxVqganEnc*)h); }
 
-int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, prx_stream_t s) {
-    return prx_vgg16_create_impl((PrxVgg16**)out, weights, n_weights, max_h, max_w, S_(s));
+int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, int precision,
+                     prx_stream_t s) {
+    return prx_vgg16_create_impl((PrxVgg16**)out, weights, n_weights, max_h, max_w, precision, S_(s));
 }
 void prx_vgg16_destroy(prx_vgg16* h) { prx_vgg16_destroy_impl((PrxVgg16*)h); }
-long long prx_vgg16_workspace_bytes(int H, int W) { return prx_vgg16_workspace_bytes_impl(H, W); }
+prx_gemm_ctx* prx_vgg16_gemm_ctx(prx_vgg16* h) { return (prx_gemm_ctx*)prx_vgg16_gemm_ctx_impl((PrxVgg16*)h); }
+long long prx_vgg16_workspace_bytes(int H, int W, int precision) { return prx_vgg16_workspace_bytes_impl(H, W, precision); }
 int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c) {
     PRX_REQUIRE(h && w && c, "prx_vgg16_feature_shape: null argument");
     return prx_vgg16_feature_shape_impl(H, W, k, h, w, c);
@@ -106,9 +110,10 @@ int prx_clip_vit_create(prx_clip_vit** out, const prx_clip_vit_config* c, const 
                         prx_stream_t s) {
     PRX_REQUIRE(out && c && weights, "prx_clip_vit_create: null argument");
     return prx_vit_create_impl((PrxVit**)out, c->input_resolution, c->patch_size, c->width, c->layers, c->heads,
-                               c->output_dim, c->max_batch, weights, n_weights, S_(s));
+                               c->output_dim, c->max_batch, c->precision, weights, n_weights, S_(s));
 }
 void prx_clip_vit_destroy(prx_clip_vit* h) { prx_vit_destroy_impl((PrxVit*)h); }
+prx_gemm_ctx* prx_clip_vit_gemm_ctx(prx_clip_vit* h) { return (prx_gemm_ctx*)prx_vit_gemm_ctx_impl((PrxVit*)h); }
 int prx_clip_vit_minmax(prx_clip_vit* h, const float* cutouts, int n, float* mm, prx_stream_t s) {
     PRX_REQUIRE(h && cutouts && mm, "prx_clip_vit_minmax: null argument");
     return prx_vit_minmax_impl((PrxVit*)h, cutouts, n, mm, S_(s));
@@ -175,9 +180,10 @@ int prx_clip_resnet_create(prx_clip_resnet** out, const prx_clip_resnet_config* 
                            prx_stream_t s) {
     PRX_REQUIRE(out && c && weights, "prx_clip_resnet_create: null argument");
     return prx_resnet_create_impl((PrxResNet**)out, c->input_resolution, c->width, c->layers, c->heads, c->output_dim,
-                                  c->max_batch, weights, n_weights, S_(s));
+                                  c->max_batch, c->precision, weights, n_weights, S_(s));
 }
 void prx_clip_resnet_destroy(prx_clip_resnet* h) { prx_resnet_destroy_impl((PrxResNet*)h); }
+prx_gemm_ctx* prx_clip_resnet_gemm_ctx(prx_clip_resnet* h) { return (prx_gemm_ctx*)prx_resnet_gemm_ctx_impl((PrxResNet*)h); }
 int prx_clip_resnet_minmax(prx_clip_resnet* h, const float* cutouts, int n, float* mm, prx_stream_t s) {
     PRX_REQUIRE(h && cutouts && mm, "prx_clip_resnet_minmax: null argument");
     return prx_resnet_minmax_impl((PrxResNet*)h, cutouts, n, mm, S_(s));

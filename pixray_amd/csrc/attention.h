@@ -9,3 +9,8 @@ int prx_mha_bwd_gen(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
                     int C, int heads, hipStream_t s);
 // forward only, causal mask (CLIP text transformer, context 77)
 int prx_mha_fwd_causal(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s);
+// exact-f32 attention of the PRX_PREC_F32 parity mode (attention_f32.hip): any T, fp32 operands; `out` and `lse`
+// ([N*heads*T]) are kept for the backward
+int prx_mha_fwd_f32(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, hipStream_t s);
+int prx_mha_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int N, int T, int C,
+                    int heads, hipStream_t s);

@@ -13,6 +13,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define PRX_WAVE 64
 
+// ---- operand precision of a runner handle ------------------------------------
+// PRX_PREC_BF16: GEMM operands (activations handed from kernel to kernel, weight packs) are bf16, MFMA 32x32x16 bf16.
+// PRX_PREC_F32 : the same buffers hold fp32 and every contraction runs on v_mfma_f32_32x32x2_f32 (exact f32, the
+//                f32 vector rate) -- the parity mode the bf16 numbers are measured against.
+// Operand buffers are untyped (`void*`); kernels that read or write them are instantiated for both element types.
+enum { PRX_PREC_BF16 = 0, PRX_PREC_F32 = 1 };
+static inline size_t op_esz(int f32) { return f32 ? 4 : 2; }
+static inline void* op_off(void* p, size_t elems, int f32) { return p ? (char*)p + elems * op_esz(f32) : nullptr; }
+static inline const void* op_off(const void* p, size_t elems, int f32) { return p ? (const char*)p + elems * op_esz(f32) : nullptr; }
+
 // ---- error plumbing (never throw across the C ABI) -------------------------
 void prx_set_error(const char* fmt, ...);
 #define PRX_CHECK_HIP(expr)                                                        \
@@ -50,6 +60,28 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
     return r;
+}
+
+// operand element access, generic over {bf16_t, float}
+template <typename T> __device__ __forceinline__ float op_ld(const T* p, size_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void op_st(T* p, size_t i, float v) { p[i] = (T)v; }
+template <typename T> __device__ __forceinline__ void op_ld4(const T* p, size_t i, float* v);
+template <> __device__ __forceinline__ void op_ld4<bf16_t>(const bf16_t* p, size_t i, float* v) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + i);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <> __device__ __forceinline__ void op_ld4<float>(const float* p, size_t i, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p + i);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <typename T> __device__ __forceinline__ void op_st4(T* p, size_t i, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void op_st4<bf16_t>(bf16_t* p, size_t i, float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16_t)a; r[1] = (bf16_t)b; r[2] = (bf16_t)c; r[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4*>(p + i) = r;
+}
+template <> __device__ __forceinline__ void op_st4<float>(float* p, size_t i, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(a, b, c, d);
 }
 
 // ---- wave / block reductions -----------------------------------------------

@@ -607,8 +607,10 @@ __constant__ float c_clip_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 
 // A[(n*T + 1 + gy*G + gx)][c*P*P + py*P + px] = ((x - mn)/(mx - mn) - mean_c)/std_c ; row n*T is zero (class token).
 // Kp = 3*P*P rounded up to a multiple of 8 (zero columns): ViT-L/14 has 588 -> 592.
+// TOp: operand precision of A (bf16, or fp32 in the exact mode)
+template <typename TOp>
 __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
-                                                           bf16_t* __restrict__ A, int N, int S, int P, int T, int Kp) {
+                                                           TOp* __restrict__ A, int N, int S, int P, int T, int Kp) {
     const int G = S / P;
     const int K = 3 * P * P;
     const int K8 = Kp / 8;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
         const int k8 = (int)(idx % K8);
         const size_t row = idx / K8;
         const int tok = (int)(row % T), n = (int)(row / T);
-        bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (tok > 0) {
             const int gy = (tok - 1) / G, gx = (tok - 1) % G;
             if (fast) {
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
                 const float* src = cut + (((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px;
                 const float im = c_clip_mean[c], is = 1.f / c_clip_std[c];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) r[e] = (bf16_t)((((src[e] - mn) * inv) - im) * is);
+                for (int e = 0; e < 8; ++e) r[e] = (((src[e] - mn) * inv) - im) * is;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -638,12 +640,13 @@ __global__ __launch_bounds__(256) void patchify_fwd_kernel(const float* __restri
                     if (k < K) {
                         const int c = k / (P * P), py = (k / P) % P, px = k % P;
                         const float v = cut[(((size_t)n * 3 + c) * S + gy * P + py) * S + gx * P + px];
-                        r[e] = (bf16_t)((((v - mn) * inv) - c_clip_mean[c]) / c_clip_std[c]);
+                        r[e] = (((v - mn) * inv) - c_clip_mean[c]) / c_clip_std[c];
                     }
                 }
             }
         }
-        reinterpret_cast<bf16x8*>(A)[idx] = r;
+        op_st4(A, idx * 8, r[0], r[1], r[2], r[3]);
+        op_st4(A, idx * 8 + 4, r[4], r[5], r[6], r[7]);
     }
 }
 
@@ -778,10 +781,12 @@ int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hip
 }
 static inline int patch_kp(int P) { return (3 * P * P + 7) / 8 * 8; }
 
-int prx_patchify_fwd(const float* cut, const float* mm, bf16_t* A, int N, int S, int P, int T, hipStream_t s) {
+int prx_patchify_fwd(const float* cut, const float* mm, void* A, int f32, int N, int S, int P, int T, hipStream_t s) {
     PRX_REQUIRE(S % P == 0 && T == (S / P) * (S / P) + 1, "patchify: bad geometry S=%d P=%d T=%d", S, P, T);
     const int Kp = patch_kp(P);
-    hipLaunchKernelGGL(patchify_fwd_kernel, dim3(ew_grid((size_t)N * T * Kp / 8)), dim3(256), 0, s, cut, mm, A, N, S, P, T, Kp);
+    const dim3 grid(ew_grid((size_t)N * T * Kp / 8));
+    if (f32) hipLaunchKernelGGL(patchify_fwd_kernel<float>, grid, dim3(256), 0, s, cut, mm, (float*)A, N, S, P, T, Kp);
+    else     hipLaunchKernelGGL(patchify_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, cut, mm, (bf16_t*)A, N, S, P, T, Kp);
     PRX_LAUNCH_CHECK();
     return 0;
 }

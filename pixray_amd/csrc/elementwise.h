@@ -1,10 +1,11 @@
 #pragma once
 #include "common.h"
-int prx_transpose_bf16(const bf16_t* in, int ldin, bf16_t* out, int ldout, int R, int C, hipStream_t s);
-int prx_softmax_rows(const float* S, int lds_, float scale, bf16_t* P, int ldp, bf16_t* PT, int ldpt, int rows,
-                     int cols, hipStream_t s);
-int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, float scale, bf16_t* dS, int ldds,
-                         bf16_t* dST, int lddst, int rows, int cols, hipStream_t s);
+// `f32`: operand precision of the untyped buffers (PRX_PREC_*)
+int prx_transpose_op(const void* in, int ldin, void* out, int ldout, int R, int C, int f32, hipStream_t s);
+int prx_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, void* PT, int ldpt, int rows,
+                     int cols, int f32, hipStream_t s);
+int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
+                         void* dST, int lddst, int rows, int cols, int f32, hipStream_t s);
 int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s);
 int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s);
 int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);

@@ -9,16 +9,17 @@ namespace {
 
 inline int ew_grid(size_t total, int per = 256) { return (int)std::min<size_t>((total + per - 1) / per, 8192); }
 
-// out[c][r] = in[r][c]   (bf16), tiled through LDS
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int ldin,
-                                                             bf16_t* __restrict__ out, int ldout, int R, int C) {
-    __shared__ bf16_t tile[32][33];
+// out[c][r] = in[r][c]   (operand precision: bf16 or fp32), tiled through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_op_kernel(const T* __restrict__ in, int ldin,
+                                                           T* __restrict__ out, int ldout, int R, int C) {
+    __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : (bf16_t)0.f;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : (T)0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -28,9 +29,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
-// P = softmax(scale * S) per row; one wave per row; writes bf16 P (and optionally P^T)
+// P = softmax(scale * S) per row; one wave per row; writes P (and optionally P^T) at operand precision
+template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds_, float scale,
-                                                           bf16_t* __restrict__ P, int ldp, bf16_t* __restrict__ PT,
+                                                           T* __restrict__ P, int ldp, T* __restrict__ PT,
                                                            int ldpt, int rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -44,27 +46,28 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int c = lane; c < cols; c += 64) {
-        bf16_t p = (bf16_t)(__expf(s[c] * scale - mx) * inv);
+        T p = (T)(__expf(s[c] * scale - mx) * inv);
         P[(size_t)row * ldp + c] = p;
         if (PT) PT[(size_t)c * ldpt + row] = p;
     }
 }
 
-// dS = scale * P o (dP - rowsum(dP o P));  writes bf16 dS and dS^T
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ P, int ldp,
+// dS = scale * P o (dP - rowsum(dP o P));  writes dS and dS^T at operand precision
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restrict__ P, int ldp,
                                                                const float* __restrict__ dP, int lddp, float scale,
-                                                               bf16_t* __restrict__ dS, int ldds,
-                                                               bf16_t* __restrict__ dST, int lddst, int rows, int cols) {
+                                                               T* __restrict__ dS, int ldds,
+                                                               T* __restrict__ dST, int lddst, int rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float dot = 0.f;
     for (int c = lane; c < cols; c += 64)
-        dot += bf16_to_f32(P[(size_t)row * ldp + c]) * dP[(size_t)row * lddp + c];
+        dot += (float)P[(size_t)row * ldp + c] * dP[(size_t)row * lddp + c];
     dot = wave_sum(dot);
     for (int c = lane; c < cols; c += 64) {
-        float p = bf16_to_f32(P[(size_t)row * ldp + c]);
-        bf16_t v = (bf16_t)(scale * p * (dP[(size_t)row * lddp + c] - dot));
+        float p = (float)P[(size_t)row * ldp + c];
+        T v = (T)(scale * p * (dP[(size_t)row * lddp + c] - dot));
         dS[(size_t)row * ldds + c] = v;
         if (dST) dST[(size_t)c * lddst + row] = v;
     }
@@ -209,23 +212,28 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
 
 }  // namespace
 
-int prx_transpose_bf16(const bf16_t* in, int ldin, bf16_t* out, int ldout, int R, int C, hipStream_t s) {
+int prx_transpose_op(const void* in, int ldin, void* out, int ldout, int R, int C, int f32, hipStream_t s) {
     dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, in, ldin, out, ldout, R, C);
+    if (f32) hipLaunchKernelGGL(transpose_op_kernel<float>, grid, dim3(256), 0, s, (const float*)in, ldin, (float*)out, ldout, R, C);
+    else     hipLaunchKernelGGL(transpose_op_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, ldin, (bf16_t*)out, ldout, R, C);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_softmax_rows(const float* S, int lds_, float scale, bf16_t* P, int ldp, bf16_t* PT, int ldpt, int rows,
-                     int cols, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, P, ldp, PT, ldpt,
-                       rows, cols);
+int prx_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, void* PT, int ldpt, int rows,
+                     int cols, int f32, hipStream_t s) {
+    if (f32) hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, (float*)P, ldp,
+                                (float*)PT, ldpt, rows, cols);
+    else     hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, (bf16_t*)P, ldp,
+                                (bf16_t*)PT, ldpt, rows, cols);
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_softmax_rows_bwd(const bf16_t* P, int ldp, const float* dP, int lddp, float scale, bf16_t* dS, int ldds,
-                         bf16_t* dST, int lddst, int rows, int cols, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, P, ldp, dP, lddp, scale, dS,
-                       ldds, dST, lddst, rows, cols);
+int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
+                         void* dST, int lddst, int rows, int cols, int f32, hipStream_t s) {
+    if (f32) hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, (const float*)P, ldp, dP, lddp,
+                                scale, (float*)dS, ldds, (float*)dST, lddst, rows, cols);
+    else     hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, (const bf16_t*)P, ldp, dP,
+                                lddp, scale, (bf16_t*)dS, ldds, (bf16_t*)dST, lddst, rows, cols);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -1,12 +1,16 @@
-// bf16 MFMA GEMM / implicit-GEMM convolution engine (gfx950).
+// MFMA GEMM / implicit-GEMM convolution engine (gfx950).
 //   C[M,N] = epilogue( A[M,K] * Bt[N,K]^T )
-// A is either a row-major matrix (bf16, or f32 converted on load) or the
-// implicit im2col view of an NHWC activation for a 3x3/pad-1 convolution
-// (optionally reading through a fused nearest-2x upsample).  Bt is always the
-// bf16 weight pack, K contiguous.  Accumulation is fp32 on
-// v_mfma_f32_32x32x16_bf16.
+// A is either a row-major matrix or the implicit im2col view of an NHWC
+// activation for a 3x3/pad-1 convolution (optionally reading through a fused
+// nearest-2x upsample or a stride-2 window).  Bt is the weight pack, K contiguous.
+// Two operand precisions (GemmDesc::f32):
+//   0  bf16 operands (A may be f32, converted on load), fp32 accumulate on v_mfma_f32_32x32x16_bf16 -- the fast path;
+//   1  fp32 operands end to end on v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain, the f32 vector rate = 1/16 of
+//      the bf16 MFMA rate) -- the exact parity mode.  Every "bf16" pointer below then addresses fp32 data.
 #pragma once
 #include "common.h"
+#include <vector>
+#include <mutex>
 
 enum { PRX_ACT_NONE = 0, PRX_ACT_QUICKGELU = 1, PRX_ACT_MUL_DQUICKGELU = 2,
        PRX_ACT_RELU = 3,            // max(v, 0) after bias / residual (CLIP ModifiedResNet)
@@ -15,11 +19,12 @@ enum { PRX_A_ROWMAJOR = 0, PRX_A_CONV3X3 = 1 };
 
 struct GemmDesc {
     // operands
+    int f32 = 0;               // operand precision (PRX_PREC_*): 1 = A, B, aux, out_bf16, out_bf16_pre are all fp32
     const void* A = nullptr;   // bf16 or f32 (a_is_f32)
     int a_is_f32 = 0;
     int a_mode = PRX_A_ROWMAJOR;
     int lda = 0;               // row stride (row-major) or pixel stride (conv), elements
-    const bf16_t* B = nullptr; // [N, K], ldb
+    const void* B = nullptr;   // [N, K], ldb (operand precision)
     int ldb = 0;
     int M = 0, N = 0, K = 0;
     // conv geometry: M = NB*H*W output pixels, K = 9*Cin; `up` reads an (H/2)x(W/2) input
@@ -28,12 +33,12 @@ struct GemmDesc {
     float alpha = 1.f;
     const float* bias_n = nullptr;
     const float* bias_m = nullptr;
-    const bf16_t* aux = nullptr; int ldaux = 0;
+    const void* aux = nullptr; int ldaux = 0;   // operand precision
     const float* resid = nullptr; int ldr = 0;
     int act = PRX_ACT_NONE;
     float* out_f32 = nullptr; int ldc_f32 = 0;
-    bf16_t* out_bf16 = nullptr;      // post-activation
-    bf16_t* out_bf16_pre = nullptr;  // pre-activation (QUICKGELU only)
+    void* out_bf16 = nullptr;        // post-activation, operand precision (the next GEMM's A)
+    void* out_bf16_pre = nullptr;    // pre-activation (QUICKGELU only), operand precision
     int ldc_bf16 = 0;
     // optional: accumulate GroupNorm statistics of the fp32 output (sum, sum of squares per group of `gn_gs`
     // consecutive columns) into gn_stats[group*2 + {0,1}] (double, pre-zeroed) -- saves the separate stats pass over
@@ -52,14 +57,28 @@ struct GemmDesc {
     float gnb_eps = 1e-6f;
 };
 
+// Per-handle engine state: tuning overrides and the optional per-launch timing log.  Every runner handle owns one, so two
+// handles (or two threads driving different handles) never share mutable state; a null ctx means "built-in heuristics,
+// no profiling" and touches nothing mutable.
+struct GemmTileRule { int M, N, K, mode, bm, bn, splits; };
+struct GemmProfRec { hipEvent_t a, b; double flop; int M, N, K, mode, bm, bn, splits; };
+struct GemmCtx {
+    int use_glds = 1;                 // 1: direct-to-LDS v2 kernel for bf16 A; 0: register-staged v1 (A/B comparisons)
+    int force_bm = 0, force_bn = 0, force_splits = 0, force_stages = 0;
+    int xcd_swizzle = 2;              // 0 off, 1 on, 2 narrow row-major problems only
+    int conv_c64 = 1;                 // scalar-tap conv gather when Cin % 64 == 0
+    int wide_tile = 128;
+    std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic
+    bool prof_on = false;
+    std::vector<GemmProfRec> prof;
+    std::mutex mu;                    // guards prof / prof_on (collect may run on another thread than the launches)
+    GemmCtx();                        // reads the PRX_* tuning environment variables once
+};
+void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits);   // (0,0,0) restores the heuristic; bm < 0: switches, see .hip
+void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, int bn, int splits);   // bm=0 drops it, M=0 drops all
+void prx_gemm_ctx_profile_enable(GemmCtx* c, int on);
+int prx_gemm_ctx_profile_collect(GemmCtx* c, double* total_ms, double* total_flop, long long* launches);
+
 // Launch on `stream`.  `ws` is a scratch buffer for split-K partials (may be
 // null -> split-K disabled).  Returns 0 or a negative error code.
-int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);
-
-// Per-launch timing hook used by bench.py's roofline leg (HIP events on the
-// launch stream).  When enabled every prx_gemm_launch is bracketed by events.
-void prx_gemm_set_variant(int use_glds);   // 1 (default): direct-to-LDS v2 kernel for bf16 A; 0: register-staged v1
-void prx_gemm_force_tile(int bm, int bn, int splits);   // tuning override; (0,0,0) restores the heuristic
-void prx_gemm_tile_rule_set(int M, int N, int K, int mode, int bm, int bn, int splits);   // per-shape override; bm=0 drops it, M=0 drops all
-void prx_gemm_profile_enable(int on);
-int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches);
+int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx = nullptr);

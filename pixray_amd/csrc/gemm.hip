@@ -14,8 +14,6 @@
 #include <stdlib.h>
 
 namespace {
-int g_conv_c64 = (getenv("PRX_CONV_C64") ? atoi(getenv("PRX_CONV_C64")) : 1);   // A/B switch for the scalar-tap conv gather
-
 
 constexpr int BK = 64;
 constexpr int LDS_LD = BK + 8;  // elements; 144-byte rows
@@ -68,28 +66,30 @@ __device__ __forceinline__ void gnb_accum(const GemmDesc& d, const GnbConst& c, 
     }
 }
 
+// TOp = element type of the operand-precision pointers (aux, out_bf16, out_bf16_pre): bf16_t, or float in the exact mode
+template <typename TOp>
 __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int col, float v) {
+    const TOp* aux = reinterpret_cast<const TOp*>(d.aux);
     v *= d.alpha;
     if (d.bias_n) v += d.bias_n[col];
     if (d.bias_m) v += d.bias_m[row];
-    if (d.act == PRX_ACT_MUL_DQUICKGELU) {
-        float t = bf16_to_f32(d.aux[(size_t)row * d.ldaux + col]);
-        v *= dquickgelu_f(t);
-    }
-    if (d.act == PRX_ACT_MUL_RELUMASK && !(bf16_to_f32(d.aux[(size_t)row * d.ldaux + col]) > 0.f)) v = 0.f;
+    if (d.act == PRX_ACT_MUL_DQUICKGELU) v *= dquickgelu_f(op_ld(aux, (size_t)row * d.ldaux + col));
+    if (d.act == PRX_ACT_MUL_RELUMASK && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f)) v = 0.f;
     if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
-        bf16_t pre = f32_to_bf16(v);
-        if (d.out_bf16_pre) d.out_bf16_pre[(size_t)row * d.ldc_bf16 + col] = pre;
-        v = quickgelu_f(bf16_to_f32(pre));
+        const TOp pre = (TOp)v;     // the saved pre-activation is what the backward differentiates: activate its rounded value
+        if (d.out_bf16_pre) reinterpret_cast<TOp*>(d.out_bf16_pre)[(size_t)row * d.ldc_bf16 + col] = pre;
+        v = quickgelu_f((float)pre);
     }
     if (d.out_f32) d.out_f32[(size_t)row * d.ldc_f32 + col] = v;
-    if (d.out_bf16) d.out_bf16[(size_t)row * d.ldc_bf16 + col] = f32_to_bf16(v);
+    if (d.out_bf16) op_st(reinterpret_cast<TOp*>(d.out_bf16), (size_t)row * d.ldc_bf16 + col, v);
 }
 
 // 4 consecutive columns at once (all pointers / leading dimensions checked 16-byte friendly by the host)
+template <typename TOp>
 __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
+    const TOp* aux = reinterpret_cast<const TOp*>(d.aux);
     v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
     if (d.bias_n) {
         const float4 b = *reinterpret_cast<const float4*>(d.bias_n + col);
@@ -97,16 +97,17 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     }
     if (d.bias_m) { const float b = d.bias_m[row]; v.x += b; v.y += b; v.z += b; v.w += b; }
     if (d.act == PRX_ACT_MUL_DQUICKGELU) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(d.aux + (size_t)row * d.ldaux + col);
-        v.x *= dquickgelu_f((float)t[0]); v.y *= dquickgelu_f((float)t[1]);
-        v.z *= dquickgelu_f((float)t[2]); v.w *= dquickgelu_f((float)t[3]);
+        float t[4];
+        op_ld4(aux, (size_t)row * d.ldaux + col, t);
+        v.x *= dquickgelu_f(t[0]); v.y *= dquickgelu_f(t[1]); v.z *= dquickgelu_f(t[2]); v.w *= dquickgelu_f(t[3]);
     }
     if (d.act == PRX_ACT_MUL_RELUMASK) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(d.aux + (size_t)row * d.ldaux + col);
-        if (!((float)t[0] > 0.f)) v.x = 0.f;
-        if (!((float)t[1] > 0.f)) v.y = 0.f;
-        if (!((float)t[2] > 0.f)) v.z = 0.f;
-        if (!((float)t[3] > 0.f)) v.w = 0.f;
+        float t[4];
+        op_ld4(aux, (size_t)row * d.ldaux + col, t);
+        if (!(t[0] > 0.f)) v.x = 0.f;
+        if (!(t[1] > 0.f)) v.y = 0.f;
+        if (!(t[2] > 0.f)) v.z = 0.f;
+        if (!(t[3] > 0.f)) v.w = 0.f;
     }
     if (d.resid) {
         const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
@@ -114,18 +115,13 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     }
     if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (d.act == PRX_ACT_QUICKGELU) {
-        bf16x4 pre;
-        pre[0] = (bf16_t)v.x; pre[1] = (bf16_t)v.y; pre[2] = (bf16_t)v.z; pre[3] = (bf16_t)v.w;
-        if (d.out_bf16_pre) *reinterpret_cast<bf16x4*>(d.out_bf16_pre + (size_t)row * d.ldc_bf16 + col) = pre;
-        v.x = quickgelu_f((float)pre[0]); v.y = quickgelu_f((float)pre[1]);
-        v.z = quickgelu_f((float)pre[2]); v.w = quickgelu_f((float)pre[3]);
+        const TOp p0 = (TOp)v.x, p1 = (TOp)v.y, p2 = (TOp)v.z, p3 = (TOp)v.w;
+        if (d.out_bf16_pre)
+            op_st4(reinterpret_cast<TOp*>(d.out_bf16_pre), (size_t)row * d.ldc_bf16 + col, (float)p0, (float)p1, (float)p2, (float)p3);
+        v.x = quickgelu_f((float)p0); v.y = quickgelu_f((float)p1); v.z = quickgelu_f((float)p2); v.w = quickgelu_f((float)p3);
     }
     if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + (size_t)row * d.ldc_f32 + col) = v;
-    if (d.out_bf16) {
-        bf16x4 o;
-        o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
-        *reinterpret_cast<bf16x4*>(d.out_bf16 + (size_t)row * d.ldc_bf16 + col) = o;
-    }
+    if (d.out_bf16) op_st4(reinterpret_cast<TOp*>(d.out_bf16), (size_t)row * d.ldc_bf16 + col, v.x, v.y, v.z, v.w);
     return v;
 }
 
@@ -169,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int kt1 = min(p.kt_total, kt0 + p.kt_per_split);
 
     const TA* __restrict__ Ap = reinterpret_cast<const TA*>(d.A);
-    const bf16_t* __restrict__ Bp = d.B;
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(d.B);
 
     // ---- per-thread loader coordinates (fixed across the K loop) ------------
     int a_row[A_CH];          // row within the tile
@@ -304,7 +300,190 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 if (p.splits > 1)
                     p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
                 else
-                    epilogue_store(d, row, col, acc[i][j][r]);
+                    epilogue_store<bf16_t>(d, row, col, acc[i][j][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-f32 variant (GemmDesc::f32): A and B stay fp32 from HBM to the matrix core, v_mfma_f32_32x32x2_f32
+// (D = fma chain over k, bit-for-bit f32; 64 cycles per instruction = the f32 vector rate, 157 TFLOP/s peak).
+// Same structure as the register-staged kernel above with BK = 32 floats (128-byte rows, 144-byte LDS pitch): one
+// ds_read_b128 per fragment fetches 4 consecutive k for the lane's row; the lower half-wave (k slot 0 of the
+// instruction) holds k = 8s..8s+3 and the upper half (k slot 1) k = 8s+4..8s+7, so four MFMAs consume the 8 k of
+// step s -- the assignment of k values to the instruction's two slots is free as long as A and B agree.
+// This is the parity mode, not the fast path: it is MFMA-bound at 1/16 of the bf16 rate by construction.
+// ---------------------------------------------------------------------------------------------
+constexpr int BKF = 32;
+constexpr int LDS_LDF = BKF + 4;   // floats; 144-byte rows
+
+template <int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
+    constexpr int A_CH = BM * 8 / 256;  // 16-byte chunks (4 floats) per thread per K tile
+    constexpr int B_CH = BN * 8 / 256;
+    constexpr int MT = BM / 64;
+    constexpr int NT = BN / 64;
+
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LDF];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LDF];
+
+    const GemmDesc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int bid = blockIdx.x;
+    const int tm = bid / p.tiles_n;
+    const int tn = bid - tm * p.tiles_n;
+    const int split = blockIdx.y;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(p.kt_total, kt0 + p.kt_per_split);
+
+    const float* __restrict__ Ap = reinterpret_cast<const float*>(d.A);
+    const float* __restrict__ Bp = reinterpret_cast<const float*>(d.B);
+
+    int a_row[A_CH];
+    long long a_base[A_CH];
+    int a_y[A_CH], a_x[A_CH], a_b[A_CH];
+    bool a_ok[A_CH];
+    const int kc = tid & 7;   // which 4-float chunk of the 32-wide K tile
+    // source geometry of the implicit conv (see the v2 kernel): up == 1 nearest-2x upsampled, up == 2 stride-2 window
+    const int Hs = d.up == 1 ? (d.H >> 1) : (d.up == 2 ? 2 * d.H : d.H);
+    const int Ws = d.up == 1 ? (d.W >> 1) : (d.up == 2 ? 2 * d.W : d.W);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        a_row[i] = row;
+        const int gm = tm * BM + row;
+        a_ok[i] = gm < d.M;
+        if (AMODE == PRX_A_ROWMAJOR) {
+            a_base[i] = (long long)gm * d.lda;
+            a_y[i] = a_x[i] = a_b[i] = 0;
+        } else {
+            const int hw = d.H * d.W;
+            const int b = gm / hw;
+            const int rem = gm - b * hw;
+            const int y = rem / d.W;
+            a_b[i] = b; a_y[i] = y; a_x[i] = rem - y * d.W;
+            a_base[i] = 0;
+        }
+    }
+    int b_row[B_CH];
+    long long b_base[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        b_row[i] = row;
+        const int gn = tn * BN + row;
+        b_ok[i] = gn < d.N;
+        b_base[i] = (long long)gn * d.ldb;
+    }
+
+    f32x4 a_reg[A_CH], b_reg[B_CH];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BKF + kc * 4;
+        const bool k_ok = k < d.K;
+        if (AMODE == PRX_A_ROWMAJOR) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i)
+                a_reg[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const f32x4*>(Ap + a_base[i] + k) : zero4;
+        } else {
+            const int tap = k / d.Cin;
+            const int c = k - tap * d.Cin;
+            const int ky = tap / 3;
+            const int kx = tap - 3 * ky;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int yy, xx;
+                bool ok = a_ok[i] && k_ok;
+                if (d.up == 2) {          // taming Downsample: pad (0,1,0,1), stride 2
+                    yy = 2 * a_y[i] + ky; xx = 2 * a_x[i] + kx;
+                    ok = ok && yy < Hs && xx < Ws;
+                } else {
+                    yy = a_y[i] + ky - 1; xx = a_x[i] + kx - 1;
+                    ok = ok && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+                    if (d.up == 1) { yy >>= 1; xx >>= 1; }
+                }
+                const long long pix = ((long long)a_b[i] * Hs + yy) * Ws + xx;
+                a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(Ap + pix * d.lda + c) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const f32x4*>(Bp + b_base[i] + k) : zero4;
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            *reinterpret_cast<f32x4*>(&As[a_row[i] * LDS_LDF + kc * 4]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[b_row[i] * LDS_LDF + kc * 4]) = b_reg[i];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tiles(kt0);
+        store_tiles();
+    }
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = 4 * (lane >> 5);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) load_tiles(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BKF / 8; ++ks) {
+            f32x4 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[(wm * (BM / 2) + i * 32 + frag_row) * LDS_LDF + ks * 8 + frag_k]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * (BN / 2) + j * 32 + frag_row) * LDS_LDF + ks * 8 + frag_k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    const int row0 = tm * BM + wm * (BM / 2) + 4 * (lane >> 5);
+    const int col0 = tn * BN + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + j * 32;
+            if (col >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= d.M) continue;
+                if (p.splits > 1)
+                    p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
+                else
+                    epilogue_store<float>(d, row, col, acc[i][j][r]);
             }
         }
 }
@@ -354,7 +533,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
     const int kt1 = min(p.kt_total, kt0 + p.kt_per_split);
 
     const bf16_t* __restrict__ Ap = reinterpret_cast<const bf16_t*>(d.A);
-    const bf16_t* __restrict__ Bp = d.B;
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(d.B);
 
     // ---- per-lane DMA coordinates (fixed across the K loop) -------------------
     const int lrow = lane >> 3, cpos = lane & 7;
@@ -587,7 +766,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                     if (p.splits > 1)
                         *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
                     else {
-                        const float4 o = epilogue_store4(d, row, col, v);
+                        const float4 o = epilogue_store4<bf16_t>(d, row, col, v);
                         if (gnb) gnb_accum(d, gc, row, col, o, gs0, gs1);
                         else {
                             gs0 += (o.x + o.y) + (o.z + o.w);
@@ -637,11 +816,12 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                 if (p.splits > 1)
                     p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
                 else
-                    epilogue_store(d, row, col, acc[i][j][r]);
+                    epilogue_store<bf16_t>(d, row, col, acc[i][j][r]);
             }
         }
 }
 
+template <typename TOp>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const GemmDesc& d = p.d;
     const size_t total = (size_t)d.M * d.N;
@@ -685,7 +865,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 const size_t idx = i4 << 2;
                 const int row = (int)(idx / d.N);
                 col = (int)(idx - (size_t)row * d.N);
-                const float4 o = epilogue_store4(d, row, col, v);
+                const float4 o = epilogue_store4<TOp>(d, row, col, v);
                 if (do_stats && d.gnb_x) gnb_accum(d, gnb_load(d, col), row, col, o, s0, s1);
                 else {
                     s0 = (o.x + o.y) + (o.z + o.w);
@@ -714,7 +894,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         for (int s = 0; s < p.splits; ++s) v += p.ws[(size_t)s * total + idx];
         int row = (int)(idx / d.N);
         int col = (int)(idx - (size_t)row * d.N);
-        epilogue_store(d, row, col, v);
+        epilogue_store<TOp>(d, row, col, v);
     }
 }
 
@@ -729,37 +909,43 @@ void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
         else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
     }
 }
+template <int BM, int BN>
+void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a);
+    else                              hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
+}
 
 template <int BM, int BN, int STAGES>
-void launch_glds_s(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
+void launch_glds_s(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
     if (a.d.a_mode == PRX_A_ROWMAJOR)
         hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR, STAGES>), grid, dim3(256), 0, s, a, zero_page);
-    else if (a.d.Cin % BK == 0 && g_conv_c64)
+    else if (c64)
         hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES, true>), grid, dim3(256), 0, s, a, zero_page);
     else
         hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES>), grid, dim3(256), 0, s, a, zero_page);
 }
 // 256x128 tile, 8 waves (wave tile 64x64 like the 128x128 kernel): 1.5 MFMA-flops per L2->LDS byte more than 128x128
 template <int STAGES>
-void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page) {
+void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
     if (a.d.a_mode == PRX_A_ROWMAJOR)
         hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_ROWMAJOR, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
-    else if (a.d.Cin % BK == 0 && g_conv_c64)
+    else if (c64)
         hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, true, 4>), grid, dim3(512), 0, s, a, zero_page);
     else
         hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
 }
 template <int BM, int BN>
-void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages) {
-    if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page);
-    else if (stages >= 3) launch_glds_s<BM, BN, 3>(a, grid, s, zero_page);
-    else launch_glds_s<BM, BN, 2>(a, grid, s, zero_page);
+void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages, bool c64) {
+    if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page, c64);
+    else if (stages >= 3) launch_glds_s<BM, BN, 3>(a, grid, s, zero_page, c64);
+    else launch_glds_s<BM, BN, 2>(a, grid, s, zero_page, c64);
 }
 
+// A 256-byte page of zeros per device (source of the DMA for out-of-range / padded operand chunks).  Created once per
+// device and never written again: a cache, not state.
 std::mutex g_zero_mu;
 bf16_t* g_zero_page[16] = {nullptr};
 
-// a 256-byte page of zeros per device (source of the DMA for out-of-range / padded operand chunks)
 const bf16_t* zero_page_for_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -773,77 +959,90 @@ const bf16_t* zero_page_for_current_device() {
     return g_zero_page[dev];
 }
 
-// ---- optional per-launch profiling (bench.py roofline leg) -------------------
-struct ProfRec { hipEvent_t a, b; double flop; int M, N, K, mode, bm, bn, splits; };
-std::mutex g_prof_mu;
-bool g_prof_on = false;
-bool g_use_glds = true;
-int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
-int g_force_stages = (getenv("PRX_GEMM_STAGES") ? atoi(getenv("PRX_GEMM_STAGES")) : 0);
-int g_xcd_swizzle = (getenv("PRX_XCD_SWIZZLE") ? atoi(getenv("PRX_XCD_SWIZZLE")) : 2);   // tuning overrides (tools/gemm_bench.py)   // PRX_GEMM_V1=1 forces the register-staged v1 kernel (A/B comparisons)
-std::vector<ProfRec> g_prof;
-// per-shape tuning rules (tools/gemm_rules.py): (M, N, K, mode) -> tile / split-K, consulted before the heuristic
-struct TileRule { int M, N, K, mode, bm, bn, splits; };
-std::vector<TileRule> g_rules;
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 }  // namespace
 
-void prx_gemm_tile_rule_set(int M, int N, int K, int mode, int bm, int bn, int splits) {
-    if (M <= 0) { g_rules.clear(); return; }
-    for (size_t i = 0; i < g_rules.size(); ++i)
-        if (g_rules[i].M == M && g_rules[i].N == N && g_rules[i].K == K && g_rules[i].mode == mode) { g_rules.erase(g_rules.begin() + i); break; }
-    if (bm > 0) g_rules.push_back({M, N, K, mode, bm, bn, splits});
+// ---- per-handle engine state (gemm.h) -------------------------------------------------------------------------------
+GemmCtx::GemmCtx() {
+    // tuning A/B switches (tools/gemm_bench.py, tools/gemm_tune.py); read once per context
+    force_stages = env_int("PRX_GEMM_STAGES", 0);
+    xcd_swizzle = env_int("PRX_XCD_SWIZZLE", 2);
+    conv_c64 = env_int("PRX_CONV_C64", 1);
+    wide_tile = env_int("PRX_WIDE_TILE", 128);
+    use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
-void prx_gemm_set_variant(int use_glds) { g_use_glds = use_glds != 0; }
-void prx_gemm_force_tile(int bm, int bn, int splits) {
-    if (bm == -1) { g_xcd_swizzle = splits; return; }   // (-1, x, on/off): toggle the XCD-aware tile order
-    if (bm == -2) { g_force_stages = splits; return; }  // (-2, x, n): LDS pipeline depth (0 = heuristic)
-    if (bm == -5) { g_conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
+void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, int bn, int splits) {
+    if (!c) return;
+    if (M <= 0) { c->rules.clear(); return; }
+    for (size_t i = 0; i < c->rules.size(); ++i)
+        if (c->rules[i].M == M && c->rules[i].N == N && c->rules[i].K == K && c->rules[i].mode == mode) { c->rules.erase(c->rules.begin() + i); break; }
+    if (bm > 0) c->rules.push_back({M, N, K, mode, bm, bn, splits});
+}
+
+void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
+    if (!c) return;
+    if (bm == -1) { c->xcd_swizzle = splits; return; }   // (-1, x, on/off): toggle the XCD-aware tile order
+    if (bm == -2) { c->force_stages = splits; return; }  // (-2, x, n): LDS pipeline depth (0 = heuristic)
+    if (bm == -3) { c->use_glds = splits; return; }      // (-3, x, on/off): direct-to-LDS v2 kernel vs register-staged v1
+    if (bm == -5) { c->conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
     if (bm < 0) return;
-    g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
+    c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
 
-void prx_gemm_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+void prx_gemm_ctx_profile_enable(GemmCtx* c, int on) {
+    if (!c) return;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->prof_on = on != 0;
 }
 
-int prx_gemm_profile_collect(double* total_ms, double* total_flop, long long* launches) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+int prx_gemm_ctx_profile_collect(GemmCtx* c, double* total_ms, double* total_flop, long long* launches) {
     double ms = 0, fl = 0;
-    // PRX_GEMM_PROFILE_DUMP=<path>: one CSV row per launch (tools/gemm_shapes.py aggregates them)
-    FILE* dump = getenv("PRX_GEMM_PROFILE_DUMP") ? fopen(getenv("PRX_GEMM_PROFILE_DUMP"), "a") : nullptr;
-    for (auto& r : g_prof) {
-        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
-        float t = 0;
-        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
-        ms += t; fl += r.flop;
-        if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.2f\n", r.M, r.N, r.K, r.mode, r.bm, r.bn, r.splits, t * 1e3);
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    long long n = 0;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        // PRX_GEMM_PROFILE_DUMP=<path>: one CSV row per launch (tools/gemm_shapes.py aggregates them)
+        FILE* dump = getenv("PRX_GEMM_PROFILE_DUMP") ? fopen(getenv("PRX_GEMM_PROFILE_DUMP"), "a") : nullptr;
+        for (auto& r : c->prof) {
+            float t = 0;
+            if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+                if (dump) fclose(dump);
+                return -1;
+            }
+            ms += t; fl += r.flop;
+            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%d,%d,%.2f\n", r.M, r.N, r.K, r.mode, r.bm, r.bn, r.splits, t * 1e3);
+            (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        }
+        if (dump) fclose(dump);
+        n = (long long)c->prof.size();
+        c->prof.clear();
     }
-    if (dump) fclose(dump);
     if (total_ms) *total_ms = ms;
     if (total_flop) *total_flop = fl;
-    if (launches) *launches = (long long)g_prof.size();
-    g_prof.clear();
+    if (launches) *launches = n;
     return 0;
 }
 
-int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
+int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
+    static const GemmCtx k_default;      // immutable: heuristics only
+    const GemmCtx& cx = ctx ? *ctx : k_default;
     PRX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
-    PRX_REQUIRE(d.K % 8 == 0 && d.ldb % 8 == 0, "gemm: K (%d) and ldb (%d) must be multiples of 8", d.K, d.ldb);
-    PRX_REQUIRE(d.lda % 8 == 0, "gemm: lda (%d) must be a multiple of 8", d.lda);
+    const int kq = d.f32 ? 4 : 8;        // elements per 16-byte operand chunk
+    PRX_REQUIRE(d.K % kq == 0 && d.ldb % kq == 0, "gemm: K (%d) and ldb (%d) must be multiples of %d", d.K, d.ldb, kq);
+    PRX_REQUIRE(d.lda % kq == 0, "gemm: lda (%d) must be a multiple of %d", d.lda, kq);
     PRX_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
+    const bool c64 = d.a_mode == PRX_A_CONV3X3 && d.Cin % BK == 0 && cx.conv_c64 != 0;
     if (d.a_mode == PRX_A_CONV3X3) {
-        PRX_REQUIRE(d.Cin % 8 == 0 && d.K == 9 * d.Cin, "gemm/conv: need Cin %% 8 == 0 and K == 9*Cin (Cin=%d K=%d)", d.Cin, d.K);
+        PRX_REQUIRE(d.Cin % kq == 0 && d.K == 9 * d.Cin, "gemm/conv: need Cin %% %d == 0 and K == 9*Cin (Cin=%d K=%d)", kq, d.Cin, d.K);
         PRX_REQUIRE(d.H > 0 && d.W > 0 && d.M % (d.H * d.W) == 0, "gemm/conv: M (%d) must be NB*H*W (%dx%d)", d.M, d.H, d.W);
         PRX_REQUIRE(d.up != 1 || (d.H % 2 == 0 && d.W % 2 == 0), "gemm/conv: upsample needs even H, W");
         PRX_REQUIRE(d.up >= 0 && d.up <= 2, "gemm/conv: up must be 0 (none), 1 (nearest-2x upsampled source) or 2 (stride-2 source)");
-        PRX_REQUIRE(d.up != 2 || (d.Cin % BK == 0 && !d.a_is_f32 && g_use_glds && g_conv_c64),
+        PRX_REQUIRE(d.up != 2 || d.f32 || (c64 && !d.a_is_f32 && cx.use_glds),
                     "gemm/conv: the stride-2 gather needs a bf16 operand with Cin %% 64 == 0 (Cin=%d)", d.Cin);
     }
     PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK) || d.aux, "gemm: MUL_DQUICKGELU / MUL_RELUMASK need aux");
+    PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
     // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the
@@ -865,21 +1064,22 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         }
         // wide row-major problems (FC1 / W2^T: M=3200, N=3072): the fill model over-rates 64x64 (LDS-bound tiles);
         // sweeps give 128x64 28 us vs 64x64 31 us vs 128x128 31.5 us
-        static const int wide_tile = getenv("PRX_WIDE_TILE") ? atoi(getenv("PRX_WIDE_TILE")) : 128;     // tuning A/B
-        if (wide_tile == 128 && d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
+        if (cx.wide_tile == 128 && d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
     }
-    if (g_force_bm) { BM = g_force_bm; BN = g_force_bn; }
+    if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; }
     int rule_splits = 0;
-    if (!g_rules.empty()) {
+    if (!cx.rules.empty()) {
         const int mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32;
-        for (const TileRule& r : g_rules)
+        for (const GemmTileRule& r : cx.rules)
             if (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode) { BM = r.bm; BN = r.bn; rule_splits = r.splits; }
     }
+    if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
+    const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
     a.d = d;
     a.tiles_m = ceil_div(d.M, BM);
     a.tiles_n = ceil_div(d.N, BN);
-    a.kt_total = ceil_div(d.K, BK);
+    a.kt_total = ceil_div(d.K, bk);
     int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
     if (ws && tiles <= n_cu / 2 && a.kt_total >= 16) {
@@ -888,17 +1088,18 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
     auto al = [](const void* p, size_t a_) { return p == nullptr || ((uintptr_t)p % a_) == 0; };
+    const size_t opa = d.f32 ? 16 : 8;   // alignment of a 4-element operand-precision access
     a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && (d.resid == nullptr || d.ldr % 4 == 0) &&
-                al(d.aux, 8) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
-                (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, 8) && al(d.out_bf16_pre, 8) &&
+                al(d.aux, opa) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
+                (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, opa) && al(d.out_bf16_pre, opa) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
-    if ((g_force_splits > 0 || rule_splits > 0) && ws) {
-        splits = std::min(rule_splits > 0 ? rule_splits : g_force_splits, a.kt_total);
+    if ((cx.force_splits > 0 || rule_splits > 0) && ws) {
+        splits = std::min(rule_splits > 0 ? rule_splits : cx.force_splits, a.kt_total);
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
     // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative
     // on the implicit-conv shapes -> mode 2 (default) applies it to narrow row-major problems only
-    a.xcd_swizzle = tiles >= 16 && (g_xcd_swizzle == 1 || (g_xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
+    a.xcd_swizzle = tiles >= 16 && (cx.xcd_swizzle == 1 || (cx.xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
     if (d.gnb_x) {
         PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
                     "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");
@@ -906,7 +1107,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
                     "gemm: gnb operands must be 16-byte aligned");
     }
     if (d.gn_stats) {
-        PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && g_use_glds,
+        PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && cx.use_glds,
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
     a.kt_per_split = ceil_div(a.kt_total, splits);
@@ -914,22 +1115,26 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     a.splits = splits;
     a.ws = ws;
 
-    ProfRec rec{};
+    GemmProfRec rec{};
     bool prof = false;
-    {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        prof = g_prof_on;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        prof = ctx->prof_on;
     }
     if (prof) {
         PRX_CHECK_HIP(hipEventCreate(&rec.a));
         PRX_CHECK_HIP(hipEventCreate(&rec.b));
         rec.flop = 2.0 * d.M * d.N * d.K;
-        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32; rec.bm = BM; rec.bn = BN; rec.splits = splits;
+        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32 + 8 * d.f32; rec.bm = BM; rec.bn = BN; rec.splits = splits;
         PRX_CHECK_HIP(hipEventRecord(rec.a, stream));
     }
 
     dim3 grid(tiles, splits);
-    if (!d.a_is_f32 && g_use_glds) {
+    if (d.f32) {
+        if (BM == 128 && BN == 128) launch_f32<128, 128>(a, grid, stream);
+        else if (BM == 128 && BN == 64) launch_f32<128, 64>(a, grid, stream);
+        else launch_f32<64, 64>(a, grid, stream);
+    } else if (!d.a_is_f32 && cx.use_glds) {
         const bf16_t* zp = zero_page_for_current_device();
         PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
         // LDS pipeline depth, tuned IN the iteration (tools/gemm_shapes.py), not on hot-cache microbenchmarks: every
@@ -938,11 +1143,11 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         // still 3 workgroups/CU) gives -30 % on the 64^2 decoder convs and -8..-20 % on the other 64x64 launches; on
         // the 128-wide tiles it halves the occupancy and loses 15-25 %.
         int stages = (BM == 64 && BN == 64) ? 3 : 2;
-        if (g_force_stages) stages = g_force_stages;
-        if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp); else launch_glds_256<2>(a, grid, stream, zp); }
-        else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages);
-        else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages);
-        else launch_glds<64, 64>(a, grid, stream, zp, stages);
+        if (cx.force_stages) stages = cx.force_stages;
+        if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp, c64); else launch_glds_256<2>(a, grid, stream, zp, c64); }
+        else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
+        else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages, c64);
+        else launch_glds<64, 64>(a, grid, stream, zp, stages, c64);
     } else if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);
     else if (BM == 128 && BN == 64) launch_cfg<128, 64>(a, grid, stream);
     else launch_cfg<64, 64>(a, grid, stream);
@@ -950,13 +1155,14 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     if (splits > 1) {
         size_t total = (size_t)d.M * d.N;
         int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        if (d.f32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
+        else       hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
         PRX_LAUNCH_CHECK();
     }
     if (prof) {
         PRX_CHECK_HIP(hipEventRecord(rec.b, stream));
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        g_prof.push_back(rec);
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->prof.push_back(rec);
     }
     return 0;
 }

@@ -3,8 +3,10 @@
 #include "common.h"
 
 struct PrxResNet;
+struct GemmCtx;
+GemmCtx* prx_resnet_gemm_ctx_impl(PrxResNet* r);
 int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layers, int heads, int out_dim, int max_n,
-                           const float* const* w, int n_w, hipStream_t s);
+                           int precision, const float* const* w, int n_w, hipStream_t s);
 void prx_resnet_destroy_impl(PrxResNet* r);
 int prx_resnet_minmax_impl(PrxResNet* r, const float* cutouts, int n, float* mm, hipStream_t s);
 int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const float* mm, float* embeds, hipStream_t s);

@@ -24,26 +24,31 @@ __constant__ float r_clip_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
 inline int rgrid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 16384); }
 
 // Wf[co][tap*Cin + ci] = w[co][ci][ky][kx];  Wd[ci][tap'*Cout + co] = w[co][ci][2-ky][2-kx]
-__global__ __launch_bounds__(256) void rn_pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ Wf, bf16_t* __restrict__ Wd,
+template <typename TOp>
+__global__ __launch_bounds__(256) void rn_pack_conv3x3_kernel(const float* __restrict__ w, void* __restrict__ Wf_, void* __restrict__ Wd_,
                                                               int Cout, int Cin) {
+    TOp* Wf = reinterpret_cast<TOp*>(Wf_);
+    TOp* Wd = reinterpret_cast<TOp*>(Wd_);
     const size_t total = (size_t)Cout * 9 * Cin;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < total) {
             const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / ((size_t)9 * Cin));
-            Wf[i] = (bf16_t)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+            Wf[i] = (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
         } else {
             const size_t j = i - total;
             const int co = (int)(j % Cout), tap = (int)((j / Cout) % 9), ci = (int)(j / ((size_t)9 * Cout));
-            Wd[j] = (bf16_t)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)];
+            Wd[j] = (TOp)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)];
         }
     }
 }
 
 // stem conv1: y = relu(conv3x3 stride 2 pad 1 (normalise(cutouts)) + b) -> NHWC bf16 [n, Ho*Wo, Co]
 // normalise = slip.py:21-42: (x - min) / (max - min) with the batch-global min / max, then CLIP mean / std
+template <typename TOp>
 __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        bf16_t* __restrict__ out, int N, int S, int Co) {
+                                                        void* __restrict__ out_, int N, int S, int Co) {
+    TOp* out = reinterpret_cast<TOp*>(out_);
     const int So = S / 2;
     const float mn = mm[0], range = mm[1] - mm[0];
     const float inv = range != 0.f ? 1.f / range : 1.f;
@@ -69,14 +74,16 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
                 }
             }
         }
-        out[idx] = (bf16_t)fmaxf(acc, 0.f);
+        out[idx] = (TOp)fmaxf(acc, 0.f);
     }
 }
 
 // dY[n][c][y][x] = sum over (co, ky, kx) with y = 2*yo + ky - 1, x = 2*xo + kx - 1 of g[n][yo][xo][co] * w[co][c][ky][kx]
 // (g already masked by the ReLU of the stem conv1 output)
-__global__ __launch_bounds__(256) void stem1_bwd_kernel(const bf16_t* __restrict__ g, const float* __restrict__ w, float* __restrict__ dY,
+template <typename TOp>
+__global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__ g_, const float* __restrict__ w, float* __restrict__ dY,
                                                         int N, int S, int Co) {
+    const TOp* g = reinterpret_cast<const TOp*>(g_);
     const int So = S / 2;
     const size_t total = (size_t)N * 3 * S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void stem1_bwd_kernel(const bf16_t* __restrict
                 if (u < 0 || (u & 1)) continue;
                 const int xo = u >> 1;
                 if (xo >= So) continue;
-                const bf16_t* gp = g + (((size_t)n * So + yo) * So + xo) * Co;
+                const TOp* gp = g + (((size_t)n * So + yo) * So + xo) * Co;
                 for (int co = 0; co < Co; ++co) acc += (float)gp[co] * w[((co * 3 + c) * 3 + ky) * 3 + kx];
             }
         }
@@ -102,21 +109,27 @@ __global__ __launch_bounds__(256) void stem1_bwd_kernel(const bf16_t* __restrict
 }
 
 // 2x2 average pooling of an NHWC bf16 map
-__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int N, int H, int W, int C) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const void* __restrict__ x_, void* __restrict__ out_, int N, int H, int W, int C) {
+    const TOp* x = reinterpret_cast<const TOp*>(x_);
+    TOp* out = reinterpret_cast<TOp*>(out_);
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)N * Ho * Wo * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         const size_t pix = idx / C;
         const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Ho * Wo));
-        const bf16_t* p = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
+        const TOp* p = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
         const float v = ((float)p[0] + (float)p[C]) + ((float)p[(size_t)W * C] + (float)p[(size_t)W * C + C]);
-        out[idx] = (bf16_t)(0.25f * v);
+        out[idx] = (TOp)(0.25f * v);
     }
 }
 // backward: dx[n][y][x][c] = 0.25 * g[n][y/2][x/2][c]  (* [mask > 0] when `mask` is given); fp32 and/or bf16 outputs
-__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ g, const bf16_t* __restrict__ mask,
-                                                           float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf, int N, int H, int W, int C) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ g, const void* __restrict__ mask_,
+                                                           float* __restrict__ dx_f32, void* __restrict__ dx_bf_, int N, int H, int W, int C) {
+    const TOp* mask = reinterpret_cast<const TOp*>(mask_);
+    TOp* dx_bf = reinterpret_cast<TOp*>(dx_bf_);
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)N * H * W * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -126,36 +139,43 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         float v = 0.25f * g[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
         if (mask && !((float)mask[idx] > 0.f)) v = 0.f;
         if (dx_f32) dx_f32[idx] = v;
-        if (dx_bf) dx_bf[idx] = (bf16_t)v;
+        if (dx_bf) dx_bf[idx] = (TOp)v;
     }
 }
 // g <- g * [out > 0] in place (fp32) and as bf16
-__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, const bf16_t* __restrict__ out, bf16_t* __restrict__ g_bf, size_t n) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, const void* __restrict__ out_, void* __restrict__ g_bf_, size_t n) {
+    const TOp* out = reinterpret_cast<const TOp*>(out_);
+    TOp* g_bf = reinterpret_cast<TOp*>(g_bf_);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = ((float)out[i] > 0.f) ? g[i] : 0.f;
         g[i] = v;
-        g_bf[i] = (bf16_t)v;
+        g_bf[i] = (TOp)v;
     }
 }
 // AttentionPool2d tokens: t[n][0] = mean_p x[n][p] + pos[0]; t[n][1+p] = x[n][p] + pos[1+p]   (x fp32 [n, P, C]) -> bf16
-__global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, bf16_t* __restrict__ t,
+template <typename TOp>
+__global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, void* __restrict__ t_,
                                                          int N, int P, int C) {
+    TOp* t = reinterpret_cast<TOp*>(t_);
     const size_t total = (size_t)N * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C), n = (int)(idx / C);
         const float* xp = x + (size_t)n * P * C + c;
-        bf16_t* tp = t + (size_t)n * (P + 1) * C + c;
+        TOp* tp = t + (size_t)n * (P + 1) * C + c;
         float sum = 0.f;
         for (int p = 0; p < P; ++p) {
             const float v = xp[(size_t)p * C];
             sum += v;
-            tp[(size_t)(p + 1) * C] = (bf16_t)(v + pos[(size_t)(p + 1) * C + c]);
+            tp[(size_t)(p + 1) * C] = (TOp)(v + pos[(size_t)(p + 1) * C + c]);
         }
-        tp[0] = (bf16_t)(sum / (float)P + pos[c]);
+        tp[0] = (TOp)(sum / (float)P + pos[c]);
     }
 }
 // dx[n][p] = dt[n][1+p] + dt[n][0] / P   (fp32 + bf16 twin)
+template <typename TOp>
 __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dt, float* __restrict__ dx, int N, int P, int C) {
+
     const size_t total = (size_t)N * P * C;
     const float ip = 1.f / (float)P;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -167,44 +187,53 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict
     }
 }
 // rows of token 0: out[n][c] = t[n][0][c]; and the reverse (zero everywhere else)
-__global__ __launch_bounds__(256) void tok0_gather_kernel(const bf16_t* __restrict__ t, bf16_t* __restrict__ out, int N, int T, int C) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void tok0_gather_kernel(const void* __restrict__ t_, void* __restrict__ out_, int N, int T, int C) {
+    const TOp* t = reinterpret_cast<const TOp*>(t_);
+    TOp* out = reinterpret_cast<TOp*>(out_);
     const size_t total = (size_t)N * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
         out[idx] = t[(idx / C) * (size_t)T * C + idx % C];
 }
-__global__ __launch_bounds__(256) void tok0_scatter_kernel(const bf16_t* __restrict__ g0, bf16_t* __restrict__ dt, int N, int T, int C) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void tok0_scatter_kernel(const void* __restrict__ g0_, void* __restrict__ dt_, int N, int T, int C) {
+    const TOp* g0 = reinterpret_cast<const TOp*>(g0_);
+    TOp* dt = reinterpret_cast<TOp*>(dt_);
     const size_t total = (size_t)N * T * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         const size_t nt = idx / C;
         const int tok = (int)(nt % T), n = (int)(nt / T);
-        dt[idx] = tok == 0 ? g0[(size_t)n * C + c] : (bf16_t)0.f;
+        dt[idx] = tok == 0 ? g0[(size_t)n * C + c] : (TOp)0.f;
     }
 }
 
-struct RConv1 { int Cin, Cout; bf16_t *W, *WT; float* b; };
-struct RConv3 { int Cin, Cout; bf16_t *Wf, *Wd; float* b; };
+// `void*` members: operand-precision buffers (bf16 | fp32, PrxResNet::f32)
+struct RConv1 { int Cin, Cout; void *W, *WT; float* b; };
+struct RConv3 { int Cin, Cout; void *Wf, *Wd; float* b; };
 struct RBlock {
     int Cin, planes, Hin, stride; bool has_ds;
     RConv1 c1, c3, ds; RConv3 c2;
     // saved forward activations (bf16 post-ReLU) and the fp32 block output
-    bf16_t *a1, *a2, *p2, *xp, *out_bf; float* out_f32;
-    const bf16_t* xin_bf; const float* xin_f32;
+    void *a1, *a2, *p2, *xp, *out_bf; float* out_f32;
+    const void* xin_bf; const float* xin_f32;
 };
 
 }  // namespace
 
 struct PrxResNet {
     int res, width, heads, out_dim, max_n, C, G, T, cur_n;
+    int f32;          // PRX_PREC_*
+    GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *w1, *b1;                      // stem conv1 (fp32, BN folded)
     RConv3 s2, s3;
     std::vector<RBlock> blocks;
-    float* pos; bf16_t *Win, *WinT, *Wc, *WcT; float *bin, *bc;
+    float* pos; void *Win, *WinT, *Wc, *WcT; float *bin, *bc;
     // activations
-    bf16_t *s1, *s2a, *s3a, *s0_bf; float* s0_f32;     // stem outputs; s0 = pooled stem output (layer1 input)
-    bf16_t *tok, *qkv, *att, *o0, *dtok, *dqkv, *do0; float *lse, *e, *de, *dtokf;
-    float *gA, *gB, *tf; bf16_t *tb1, *tb2, *gbf;      // backward ping-pong / temporaries
+    void *s1, *s2a, *s3a, *s0_bf; float* s0_f32;     // stem outputs; s0 = pooled stem output (layer1 input)
+    void *tok, *qkv, *att, *o0, *dtok, *dqkv, *do0; float *lse, *e, *de, *dtokf;
+    float *gA, *gB, *tf; void *tb1, *tb2, *gbf;      // backward ping-pong / temporaries
     float *dY, *mm_part, *ws; size_t ws_bytes;
 };
 
@@ -218,6 +247,21 @@ int ralloc(PrxResNet* r, Tp** p, size_t count) {
     return 0;
 }
 #define RALLOC(ptr, count) do { int _e = ralloc(r, &(ptr), (count)); if (_e) return _e; } while (0)
+int ralloc_op(PrxResNet* r, void** p, size_t count) {   // `count` operand elements
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * op_esz(r->f32)));
+    r->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+#define RALLOC_OP(ptr, count) do { int _e = ralloc_op(r, &(ptr), (count)); if (_e) return _e; } while (0)
+// launch an operand-typed kernel template for this handle's precision
+#define RLAUNCH(kernel, total, ...)                                                                                      \
+    do {                                                                                                                 \
+        if (r->f32) hipLaunchKernelGGL(kernel<float>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);                 \
+        else        hipLaunchKernelGGL(kernel<bf16_t>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);                \
+        PRX_LAUNCH_CHECK();                                                                                              \
+    } while (0)
 struct RCur { const float* const* w; int n, pos; };
 #define RNEXT(cur, dst) do { PRX_REQUIRE((cur).pos < (cur).n, "resnet_create: weight list too short"); (dst) = (cur).w[(cur).pos++]; } while (0)
 
@@ -229,32 +273,34 @@ int rcopy(PrxResNet* r, float** dst, const float* src, size_t n, hipStream_t s) 
 int mk1(PrxResNet* r, RConv1& c, int Cin, int Cout, RCur& cur, hipStream_t s) {
     const float *w, *b; RNEXT(cur, w); RNEXT(cur, b);
     c.Cin = Cin; c.Cout = Cout;
-    RALLOC(c.W, (size_t)Cout * Cin); RALLOC(c.WT, (size_t)Cout * Cin);
+    RALLOC_OP(c.W, (size_t)Cout * Cin); RALLOC_OP(c.WT, (size_t)Cout * Cin);
     int e;
-    if ((e = prx_pack_bf16(w, c.W, (size_t)Cout * Cin, s))) return e;
-    if ((e = prx_pack_transpose_bf16(w, c.WT, Cout, Cin, s))) return e;
+    if ((e = prx_pack_op(w, c.W, (size_t)Cout * Cin, r->f32, s))) return e;
+    if ((e = prx_pack_transpose_op(w, c.WT, Cout, Cin, r->f32, s))) return e;
     return rcopy(r, &c.b, b, Cout, s);
 }
 int mk3(PrxResNet* r, RConv3& c, int Cin, int Cout, RCur& cur, hipStream_t s) {
     const float *w, *b; RNEXT(cur, w); RNEXT(cur, b);
     c.Cin = Cin; c.Cout = Cout;
-    RALLOC(c.Wf, (size_t)Cout * 9 * Cin); RALLOC(c.Wd, (size_t)Cout * 9 * Cin);
-    hipLaunchKernelGGL(rn_pack_conv3x3_kernel, dim3(1024), dim3(256), 0, s, w, c.Wf, c.Wd, Cout, Cin);
-    PRX_LAUNCH_CHECK();
+    RALLOC_OP(c.Wf, (size_t)Cout * 9 * Cin); RALLOC_OP(c.Wd, (size_t)Cout * 9 * Cin);
+    RLAUNCH(rn_pack_conv3x3_kernel, (size_t)1024 * 256, w, c.Wf, c.Wd, Cout, Cin);
     return rcopy(r, &c.b, b, Cout, s);
 }
-int rg(PrxResNet* r, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, r->ws, r->ws_bytes, s); }
+int rg(PrxResNet* r, GemmDesc& d, hipStream_t s) {
+    if (r->f32) { d.f32 = 1; d.a_is_f32 = 0; }
+    return prx_gemm_launch(d, r->ws, r->ws_bytes, s, &r->gctx);
+}
 
 // 1x1 conv forward / dgrad as GEMMs
-int lin(PrxResNet* r, const bf16_t* A, int M, int K, const bf16_t* Bt, int N, const float* bias, const float* resid, int act,
-        const bf16_t* aux, float* of, bf16_t* ob, hipStream_t s) {
+int lin(PrxResNet* r, const void* A, int M, int K, const void* Bt, int N, const float* bias, const float* resid, int act,
+        const void* aux, float* of, void* ob, hipStream_t s) {
     GemmDesc d; d.A = A; d.lda = K; d.B = Bt; d.ldb = K; d.M = M; d.N = N; d.K = K;
     d.bias_n = bias; d.resid = resid; d.ldr = N; d.act = act; d.aux = aux; d.ldaux = N;
     d.out_f32 = of; d.ldc_f32 = N; d.out_bf16 = ob; d.ldc_bf16 = N;
     return rg(r, d, s);
 }
-int conv3(PrxResNet* r, const bf16_t* x, int NB, int H, int Cin, const bf16_t* Bt, int Cout, const float* bias, int act,
-          const bf16_t* aux, float* of, bf16_t* ob, hipStream_t s) {
+int conv3(PrxResNet* r, const void* x, int NB, int H, int Cin, const void* Bt, int Cout, const float* bias, int act,
+          const void* aux, float* of, void* ob, hipStream_t s) {
     GemmDesc d; d.A = x; d.a_mode = PRX_A_CONV3X3; d.lda = Cin; d.B = Bt; d.ldb = 9 * Cin; d.M = NB * H * H; d.N = Cout; d.K = 9 * Cin;
     d.H = H; d.W = H; d.Cin = Cin; d.bias_n = bias; d.act = act; d.aux = aux; d.ldaux = Cout;
     d.out_f32 = of; d.ldc_f32 = Cout; d.out_bf16 = ob; d.ldc_bf16 = Cout;
@@ -264,12 +310,16 @@ int conv3(PrxResNet* r, const bf16_t* x, int NB, int H, int Cin, const bf16_t* B
 
 // weights (fp32 device, BatchNorm folded on the host, pixray_amd/weights.py::fold_clip_resnet_params): stem1 {w,b}, stem2,
 // stem3, per Bottleneck c1, c2, c3 [, ds], attnpool positional_embedding, in_proj {w [3C,C], b}, c_proj {w, b}
+GemmCtx* prx_resnet_gemm_ctx_impl(PrxResNet* r) { return r ? &r->gctx : nullptr; }
+
 int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layers, int heads, int out_dim, int max_n,
-                           const float* const* w, int n_w, hipStream_t s) {
+                           int precision, const float* const* w, int n_w, hipStream_t s) {
+    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "resnet_create: unknown precision %d", precision);
     PRX_REQUIRE(res % 32 == 0 && width % 16 == 0 && max_n >= 1, "resnet_create: unsupported geometry (res %d width %d)", res, width);
     PRX_REQUIRE(width * 32 == heads * 64, "resnet_create: the attention pool needs head dim 64 (width %d heads %d)", width, heads);
     PrxResNet* r = new PrxResNet();
     std::unique_ptr<PrxResNet> guard(r);
+    r->f32 = precision;
     r->res = res; r->width = width; r->heads = heads; r->out_dim = out_dim; r->max_n = max_n; r->cur_n = 0;
     r->C = width * 32; r->G = res / 32; r->T = r->G * r->G + 1;
     RCur cur{w, n_w, 0};
@@ -293,10 +343,10 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
             if ((e = mk1(r, k.c3, planes, planes * 4, cur, s))) return e;
             if (k.has_ds && (e = mk1(r, k.ds, inplanes, planes * 4, cur, s))) return e;
             const size_t Min = N * H * H, Ho = H / k.stride, Mout = N * Ho * Ho;
-            RALLOC(k.a1, Min * planes); RALLOC(k.a2, Min * planes);
+            RALLOC_OP(k.a1, Min * planes); RALLOC_OP(k.a2, Min * planes);
             k.p2 = k.a2; k.xp = nullptr;
-            if (k.stride > 1) { RALLOC(k.p2, Mout * planes); RALLOC(k.xp, Mout * inplanes); }
-            RALLOC(k.out_bf, Mout * planes * 4); RALLOC(k.out_f32, Mout * planes * 4);
+            if (k.stride > 1) { RALLOC_OP(k.p2, Mout * planes); RALLOC_OP(k.xp, Mout * inplanes); }
+            RALLOC_OP(k.out_bf, Mout * planes * 4); RALLOC(k.out_f32, Mout * planes * 4);
             maxMC = std::max(maxMC, std::max(Min * (size_t)std::max(inplanes, planes), Mout * (size_t)planes * 4));
             r->blocks.push_back(k);
             inplanes = planes * 4; H = (int)Ho;
@@ -308,22 +358,22 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     PRX_REQUIRE(cur.pos == n_w, "resnet_create: %d weight tensors given, %d consumed", n_w, cur.pos);
     const int C = r->C, T = r->T;
     if ((e = rcopy(r, &r->pos, pos, (size_t)T * C, s))) return e;
-    RALLOC(r->Win, (size_t)3 * C * C); RALLOC(r->WinT, (size_t)3 * C * C);
-    if ((e = prx_pack_bf16(win, r->Win, (size_t)3 * C * C, s))) return e;
-    if ((e = prx_pack_transpose_bf16(win, r->WinT, 3 * C, C, s))) return e;
+    RALLOC_OP(r->Win, (size_t)3 * C * C); RALLOC_OP(r->WinT, (size_t)3 * C * C);
+    if ((e = prx_pack_op(win, r->Win, (size_t)3 * C * C, r->f32, s))) return e;
+    if ((e = prx_pack_transpose_op(win, r->WinT, 3 * C, C, r->f32, s))) return e;
     if ((e = rcopy(r, &r->bin, bin, 3 * C, s))) return e;
-    RALLOC(r->Wc, (size_t)out_dim * C); RALLOC(r->WcT, (size_t)out_dim * C);
-    if ((e = prx_pack_bf16(wc, r->Wc, (size_t)out_dim * C, s))) return e;
-    if ((e = prx_pack_transpose_bf16(wc, r->WcT, out_dim, C, s))) return e;
+    RALLOC_OP(r->Wc, (size_t)out_dim * C); RALLOC_OP(r->WcT, (size_t)out_dim * C);
+    if ((e = prx_pack_op(wc, r->Wc, (size_t)out_dim * C, r->f32, s))) return e;
+    if ((e = prx_pack_transpose_op(wc, r->WcT, out_dim, C, r->f32, s))) return e;
     if ((e = rcopy(r, &r->bc, bc, out_dim, s))) return e;
     const size_t S2 = (size_t)(res / 2) * (res / 2), S4 = (size_t)(res / 4) * (res / 4);
-    RALLOC(r->s1, N * S2 * (width / 2)); RALLOC(r->s2a, N * S2 * (width / 2)); RALLOC(r->s3a, N * S2 * width);
-    RALLOC(r->s0_bf, N * S4 * width); RALLOC(r->s0_f32, N * S4 * width);
-    RALLOC(r->tok, N * T * C); RALLOC(r->qkv, N * T * 3 * C); RALLOC(r->att, N * T * C); RALLOC(r->o0, N * C);
-    RALLOC(r->dtok, N * T * C); RALLOC(r->dqkv, N * T * 3 * C); RALLOC(r->do0, N * C); RALLOC(r->dtokf, N * T * C);
+    RALLOC_OP(r->s1, N * S2 * (width / 2)); RALLOC_OP(r->s2a, N * S2 * (width / 2)); RALLOC_OP(r->s3a, N * S2 * width);
+    RALLOC_OP(r->s0_bf, N * S4 * width); RALLOC(r->s0_f32, N * S4 * width);
+    RALLOC_OP(r->tok, N * T * C); RALLOC_OP(r->qkv, N * T * 3 * C); RALLOC_OP(r->att, N * T * C); RALLOC_OP(r->o0, N * C);
+    RALLOC_OP(r->dtok, N * T * C); RALLOC_OP(r->dqkv, N * T * 3 * C); RALLOC_OP(r->do0, N * C); RALLOC(r->dtokf, N * T * C);
     RALLOC(r->lse, N * heads * T); RALLOC(r->e, N * out_dim); RALLOC(r->de, N * out_dim);
     RALLOC(r->gA, maxMC); RALLOC(r->gB, maxMC); RALLOC(r->tf, maxMC);
-    RALLOC(r->tb1, maxMC); RALLOC(r->tb2, maxMC); RALLOC(r->gbf, maxMC);
+    RALLOC_OP(r->tb1, maxMC); RALLOC_OP(r->tb2, maxMC); RALLOC_OP(r->gbf, maxMC);
     RALLOC(r->dY, N * 3 * (size_t)res * res); RALLOC(r->mm_part, 2 * 1024);
     r->ws_bytes = (size_t)64 << 20;
     RALLOC(r->ws, r->ws_bytes / sizeof(float));
@@ -347,29 +397,25 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     const int S = r->res, S2 = S / 2, S4 = S / 4, w = r->width, wh = w / 2;
     int e;
     r->cur_n = n;
-    hipLaunchKernelGGL(stem1_fwd_kernel, dim3(rgrid((size_t)n * S2 * S2 * wh)), dim3(256), 0, s, cutouts, mm, r->w1, r->b1, r->s1, n, S, wh);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(stem1_fwd_kernel, (size_t)n * S2 * S2 * wh, cutouts, mm, r->w1, r->b1, r->s1, n, S, wh);
     if ((e = conv3(r, r->s1, n, S2, wh, r->s2.Wf, wh, r->s2.b, PRX_ACT_RELU, nullptr, nullptr, r->s2a, s))) return e;
     if ((e = conv3(r, r->s2a, n, S2, wh, r->s3.Wf, w, r->s3.b, PRX_ACT_RELU, nullptr, nullptr, r->s3a, s))) return e;
-    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(rgrid((size_t)n * S4 * S4 * w)), dim3(256), 0, s, r->s3a, r->s0_bf, n, S2, S2, w);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(avgpool2_fwd_kernel, (size_t)n * S4 * S4 * w, r->s3a, r->s0_bf, n, S2, S2, w);
     // the identity path of layer1.0 goes through its downsample conv, so no fp32 copy of the stem output is needed
-    const bf16_t* x_bf = r->s0_bf; const float* x_f32 = nullptr;
+    const void* x_bf = r->s0_bf; const float* x_f32 = nullptr;
     for (RBlock& k : r->blocks) {
         const int H = k.Hin, Ho = H / k.stride, Min = n * H * H, Mout = n * Ho * Ho, p = k.planes;
         k.xin_bf = x_bf; k.xin_f32 = x_f32;
         if ((e = lin(r, x_bf, Min, k.Cin, k.c1.W, p, k.c1.b, nullptr, PRX_ACT_RELU, nullptr, nullptr, k.a1, s))) return e;
         if ((e = conv3(r, k.a1, n, H, p, k.c2.Wf, p, k.c2.b, PRX_ACT_RELU, nullptr, nullptr, k.a2, s))) return e;
         if (k.stride > 1) {
-            hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(rgrid((size_t)Mout * p)), dim3(256), 0, s, k.a2, k.p2, n, H, H, p);
-            PRX_LAUNCH_CHECK();
+            RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * p, k.a2, k.p2, n, H, H, p);
         }
         const float* idn = x_f32;
         if (k.has_ds) {
-            const bf16_t* xi = x_bf;
+            const void* xi = x_bf;
             if (k.stride > 1) {
-                hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(rgrid((size_t)Mout * k.Cin)), dim3(256), 0, s, x_bf, k.xp, n, H, H, k.Cin);
-                PRX_LAUNCH_CHECK();
+                RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * k.Cin, x_bf, k.xp, n, H, H, k.Cin);
                 xi = k.xp;
             }
             if ((e = lin(r, xi, Mout, k.Cin, k.ds.W, 4 * p, k.ds.b, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
@@ -381,12 +427,11 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     }
     // attention pool
     const int C = r->C, T = r->T, P = T - 1;
-    hipLaunchKernelGGL(tokens_fwd_kernel, dim3(rgrid((size_t)n * C)), dim3(256), 0, s, x_f32, r->pos, r->tok, n, P, C);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(tokens_fwd_kernel, (size_t)n * C, x_f32, r->pos, r->tok, n, P, C);
     if ((e = lin(r, r->tok, n * T, C, r->Win, 3 * C, r->bin, nullptr, PRX_ACT_NONE, nullptr, nullptr, r->qkv, s))) return e;
-    if ((e = prx_mha_fwd_gen(r->qkv, r->att, r->lse, n, T, C, r->heads, s))) return e;
-    hipLaunchKernelGGL(tok0_gather_kernel, dim3(rgrid((size_t)n * C)), dim3(256), 0, s, r->att, r->o0, n, T, C);
-    PRX_LAUNCH_CHECK();
+    if (r->f32) { if ((e = prx_mha_fwd_f32((const float*)r->qkv, (float*)r->att, r->lse, n, T, C, r->heads, s))) return e; }
+    else if ((e = prx_mha_fwd_gen((const bf16_t*)r->qkv, (bf16_t*)r->att, r->lse, n, T, C, r->heads, s))) return e;
+    RLAUNCH(tok0_gather_kernel, (size_t)n * C, r->att, r->o0, n, T, C);
     if ((e = lin(r, r->o0, n, C, r->Wc, r->out_dim, r->bc, nullptr, PRX_ACT_NONE, nullptr, r->e, nullptr, s))) return e;
     return prx_l2norm_fwd(r->e, embeds, n, r->out_dim, s);
 }
@@ -404,24 +449,21 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     {   GemmDesc d; d.A = r->de; d.a_is_f32 = 1; d.lda = r->out_dim; d.B = r->WcT; d.ldb = r->out_dim; d.M = n; d.N = C; d.K = r->out_dim;
         d.out_bf16 = r->do0; d.ldc_bf16 = C;
         if ((e = rg(r, d, s))) return e; }
-    hipLaunchKernelGGL(tok0_scatter_kernel, dim3(rgrid((size_t)n * T * C)), dim3(256), 0, s, r->do0, r->dtok, n, T, C);
-    PRX_LAUNCH_CHECK();
-    if ((e = prx_mha_bwd_gen(r->qkv, r->att, r->dtok, r->lse, r->dqkv, n, T, C, r->heads, s))) return e;
+    RLAUNCH(tok0_scatter_kernel, (size_t)n * T * C, r->do0, r->dtok, n, T, C);
+    if (r->f32) { if ((e = prx_mha_bwd_f32((const float*)r->qkv, (const float*)r->att, (const float*)r->dtok, r->lse, (float*)r->dqkv, n, T, C, r->heads, s))) return e; }
+    else if ((e = prx_mha_bwd_gen((const bf16_t*)r->qkv, (const bf16_t*)r->att, (const bf16_t*)r->dtok, r->lse, (bf16_t*)r->dqkv, n, T, C, r->heads, s))) return e;
     if ((e = lin(r, r->dqkv, n * T, 3 * C, r->WinT, C, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->dtokf, nullptr, s))) return e;
     float* g = r->gA; float* g2 = r->gB;
-    hipLaunchKernelGGL(tokens_bwd_kernel, dim3(rgrid((size_t)n * P * C)), dim3(256), 0, s, r->dtokf, g, n, P, C);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(tokens_bwd_kernel, (size_t)n * P * C, r->dtokf, g, n, P, C);
     for (int bi = (int)r->blocks.size() - 1; bi >= 0; --bi) {
         RBlock& k = r->blocks[bi];
         const int H = k.Hin, Ho = H / k.stride, Min = n * H * H, Mout = n * Ho * Ho, p = k.planes;
         // through the final ReLU: g (fp32, in place) and its bf16 twin
-        hipLaunchKernelGGL(relu_mask_kernel, dim3(rgrid((size_t)Mout * 4 * p)), dim3(256), 0, s, g, k.out_bf, r->gbf, (size_t)Mout * 4 * p);
-        PRX_LAUNCH_CHECK();
+        RLAUNCH(relu_mask_kernel, (size_t)Mout * 4 * p, g, k.out_bf, r->gbf, (size_t)Mout * 4 * p);
         // main branch: conv3 (1x1) dgrad [-> avgpool bwd] -> ReLU mask of a2
         if (k.stride > 1) {
             if ((e = lin(r, r->gbf, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-            hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(rgrid((size_t)Min * p)), dim3(256), 0, s, r->tf, k.a2, (float*)nullptr, r->tb1, n, H, H, p);
-            PRX_LAUNCH_CHECK();
+            RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * p, r->tf, k.a2, (float*)nullptr, r->tb1, n, H, H, p);
         } else {
             if ((e = lin(r, r->gbf, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_MUL_RELUMASK, k.a2, nullptr, r->tb1, s))) return e;
         }
@@ -432,9 +474,8 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
         if (k.has_ds) {
             if (k.stride > 1) {
                 if ((e = lin(r, r->gbf, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-                hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(rgrid((size_t)Min * k.Cin)), dim3(256), 0, s, r->tf, (const bf16_t*)nullptr, g2,
-                                   (bf16_t*)nullptr, n, H, H, k.Cin);
-                PRX_LAUNCH_CHECK();
+                RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * k.Cin, r->tf, (const void*)nullptr, g2,
+                                   (void*)nullptr, n, H, H, k.Cin);
                 gid = g2;
             } else {
                 if ((e = lin(r, r->gbf, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
@@ -449,12 +490,10 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     }
     // stem: avgpool -> relu3 mask -> conv3 dgrad -> relu2 mask -> conv2 dgrad -> relu1 mask -> conv1 input gradient
     const int S = r->res, S2 = S / 2, w = r->width, wh = w / 2;
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(rgrid((size_t)n * S2 * S2 * w)), dim3(256), 0, s, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
     if ((e = conv3(r, r->tb1, n, S2, w, r->s3.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s2a, nullptr, r->tb2, s))) return e;
     if ((e = conv3(r, r->tb2, n, S2, wh, r->s2.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s1, nullptr, r->tb1, s))) return e;
-    hipLaunchKernelGGL(stem1_bwd_kernel, dim3(rgrid((size_t)n * 3 * S * S)), dim3(256), 0, s, r->tb1, r->w1, r->dY, n, S, wh);
-    PRX_LAUNCH_CHECK();
+    RLAUNCH(stem1_bwd_kernel, (size_t)n * 3 * S * S, r->tb1, r->w1, r->dY, n, S, wh);
     return prx_preproc_bwd_reduce(cutouts, mm, r->dY, acc, n, S, s);
 }
 

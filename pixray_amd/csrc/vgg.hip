@@ -34,17 +34,18 @@ struct VLayout {
     size_t arg[4];             // uint8 argmax of those pools
     size_t total;
 };
-VLayout vlayout(int H, int W) {
+VLayout vlayout(int H, int W, int f32) {
+    const size_t es = op_esz(f32);       // operand element size: bf16, or fp32 in the exact mode
     VLayout L;
     L.h[0] = H; L.w[0] = W;
     for (int s = 1; s < 5; ++s) { L.h[s] = L.h[s - 1] / 2; L.w[s] = L.w[s - 1] / 2; }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    L.x0 = take((size_t)H * W * 8 * 2);
-    for (int l = 0; l < NCONV; ++l) L.act[l] = take((size_t)L.h[kStage[l]] * L.w[kStage[l]] * kCout[l] * 2);
+    L.x0 = take((size_t)H * W * 8 * es);
+    for (int l = 0; l < NCONV; ++l) L.act[l] = take((size_t)L.h[kStage[l]] * L.w[kStage[l]] * kCout[l] * es);
     const int pool_c[4] = {64, 128, 256, 512};
     for (int p = 0; p < 4; ++p) {
-        L.pooled[p] = take((size_t)L.h[p + 1] * L.w[p + 1] * pool_c[p] * 2);
+        L.pooled[p] = take((size_t)L.h[p + 1] * L.w[p + 1] * pool_c[p] * es);
         L.arg[p] = take((size_t)L.h[p + 1] * L.w[p + 1] * pool_c[p]);
     }
     L.total = off;
@@ -52,27 +53,31 @@ VLayout vlayout(int H, int W) {
 }
 
 // Wf[co][tap*CiP + ci] = w[co][ci][ky][kx] (ci zero-padded to CiP);  Wd[ci][tap'*Cout + co] = w[co][ci][2-ky][2-kx]
-__global__ __launch_bounds__(256) void vgg_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ Wf, bf16_t* __restrict__ Wd,
+template <typename TOp>
+__global__ __launch_bounds__(256) void vgg_pack_kernel(const float* __restrict__ w, void* __restrict__ Wf_, void* __restrict__ Wd_,
                                                        int Cout, int Cin, int CiP) {
+    TOp* Wf = reinterpret_cast<TOp*>(Wf_);
+    TOp* Wd = reinterpret_cast<TOp*>(Wd_);
     const size_t total = (size_t)Cout * 9 * CiP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < total) {
             const int ci = (int)(i % CiP), tap = (int)((i / CiP) % 9), co = (int)(i / ((size_t)9 * CiP));
-            Wf[i] = ci < Cin ? (bf16_t)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : (bf16_t)0.f;
+            Wf[i] = ci < Cin ? (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : (TOp)0.f;
         } else {
             const size_t j = i - total;
             const int co = (int)(j % Cout), tap = (int)((j / Cout) % 9), ci = (int)(j / ((size_t)9 * Cout));
-            Wd[j] = ci < Cin ? (bf16_t)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)] : (bf16_t)0.f;
+            Wd[j] = ci < Cin ? (TOp)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)] : (TOp)0.f;
         }
     }
 }
 
 // x [3][H][W] fp32 -> NHWC bf16 with 8 channels (5 zeros)
-__global__ __launch_bounds__(256) void vgg_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int HW) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void vgg_input_kernel(const float* __restrict__ x, void* __restrict__ out_, int HW) {
+    TOp* out = reinterpret_cast<TOp*>(out_);
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        v[0] = (bf16_t)x[p]; v[1] = (bf16_t)x[HW + p]; v[2] = (bf16_t)x[2 * (size_t)HW + p];
-        *reinterpret_cast<bf16x8*>(out + (size_t)p * 8) = v;
+        op_st4(out, (size_t)p * 8, x[p], x[HW + p], x[2 * (size_t)HW + p], 0.f);
+        op_st4(out, (size_t)p * 8 + 4, 0.f, 0.f, 0.f, 0.f);
     }
 }
 // dgrad of conv1_1 [HW][8] fp32 -> g_x [3][H][W]
@@ -83,20 +88,23 @@ __global__ __launch_bounds__(256) void vgg_input_grad_kernel(const float* __rest
 }
 
 // 2x2 stride-2 max pooling (floor), first maximum wins on ties like torch's max_pool2d backward
-__global__ __launch_bounds__(256) void vgg_maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, unsigned char* __restrict__ arg,
+template <typename TOp>
+__global__ __launch_bounds__(256) void vgg_maxpool_kernel(const void* __restrict__ x_, void* __restrict__ out_, unsigned char* __restrict__ arg,
                                                           int H, int W, int C) {
+    const TOp* x = reinterpret_cast<const TOp*>(x_);
+    TOp* out = reinterpret_cast<TOp*>(out_);
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)Ho * Wo * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         const size_t pix = idx / C;
         const int xo = (int)(pix % Wo), yo = (int)(pix / Wo);
-        const bf16_t* p = x + (((size_t)2 * yo) * W + 2 * xo) * C + c;
+        const TOp* p = x + (((size_t)2 * yo) * W + 2 * xo) * C + c;
         float best = (float)p[0]; int a = 0;
         float v = (float)p[C]; if (v > best) { best = v; a = 1; }
         v = (float)p[(size_t)W * C]; if (v > best) { best = v; a = 2; }
         v = (float)p[(size_t)W * C + C]; if (v > best) { best = v; a = 3; }
-        out[idx] = (bf16_t)best;
+        out[idx] = (TOp)best;
         arg[idx] = (unsigned char)a;
     }
 }
@@ -104,9 +112,12 @@ __global__ __launch_bounds__(256) void vgg_maxpool_kernel(const bf16_t* __restri
 // gpre = [act > 0] * (above + gcap) as bf16, for one conv layer's output map [H*W][C].
 //   above: fp32 gradient w.r.t. what the next conv read -- this map itself (arg == nullptr), or its 2x2 max-pooled
 //   version [H/2*W/2][C] routed through `arg`; may be null.  gcap: fp32 gradient of the captured feature; may be null.
+template <typename TOp>
 __global__ __launch_bounds__(256) void vgg_combine_kernel(const float* __restrict__ above, const unsigned char* __restrict__ arg,
-                                                          const float* __restrict__ gcap, const bf16_t* __restrict__ act,
-                                                          bf16_t* __restrict__ gpre, int H, int W, int C) {
+                                                          const float* __restrict__ gcap, const void* __restrict__ act_,
+                                                          void* __restrict__ gpre_, int H, int W, int C) {
+    const TOp* act = reinterpret_cast<const TOp*>(act_);
+    TOp* gpre = reinterpret_cast<TOp*>(gpre_);
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)H * W * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -125,20 +136,22 @@ __global__ __launch_bounds__(256) void vgg_combine_kernel(const float* __restric
             }
         }
         if (gcap) v += gcap[idx];
-        gpre[idx] = ((float)act[idx] > 0.f) ? (bf16_t)v : (bf16_t)0.f;
+        gpre[idx] = ((float)act[idx] > 0.f) ? (TOp)v : (TOp)0.f;
     }
 }
 
-struct VConv { int Cin, CiP, Cout; bf16_t *Wf, *Wd; float* b; };
+struct VConv { int Cin, CiP, Cout; void *Wf, *Wd; float* b; };   // weight packs at operand precision
 
 }  // namespace
 
 struct PrxVgg16 {
     int max_h, max_w;
+    int f32;          // PRX_PREC_*
+    GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     VConv conv[NCONV];
     float *dA, *dB, *ws;       // dgrad ping-pong (fp32), split-K scratch
-    bf16_t* gpre;
+    void* gpre;       // operand precision
     size_t ws_bytes;
 };
 
@@ -152,46 +165,61 @@ int valloc(PrxVgg16* v, Tp** p, size_t count) {
     return 0;
 }
 #define VALLOC(ptr, count) do { int _e = valloc(v, &(ptr), (count)); if (_e) return _e; } while (0)
+int valloc_op(PrxVgg16* v, void** p, size_t count) {
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * op_esz(v->f32)));
+    v->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+#define VLAUNCH(kernel, total, ...)                                                                                      \
+    do {                                                                                                                 \
+        if (v->f32) hipLaunchKernelGGL(kernel<float>, dim3(vgrid(total)), dim3(256), 0, s, __VA_ARGS__);                 \
+        else        hipLaunchKernelGGL(kernel<bf16_t>, dim3(vgrid(total)), dim3(256), 0, s, __VA_ARGS__);                \
+    } while (0)
 
-int vconv(PrxVgg16* v, const bf16_t* x, int H, int W, int Cin, const bf16_t* Bt, int Cout, const float* bias, int act,
-          float* of, bf16_t* ob, hipStream_t s) {
+int vconv(PrxVgg16* v, const void* x, int H, int W, int Cin, const void* Bt, int Cout, const float* bias, int act,
+          float* of, void* ob, hipStream_t s) {
     GemmDesc d; d.A = x; d.a_mode = PRX_A_CONV3X3; d.lda = Cin; d.B = Bt; d.ldb = 9 * Cin; d.M = H * W; d.N = Cout; d.K = 9 * Cin;
     d.H = H; d.W = W; d.Cin = Cin; d.bias_n = bias; d.act = act;
     d.out_f32 = of; d.ldc_f32 = Cout; d.out_bf16 = ob; d.ldc_bf16 = Cout;
-    return prx_gemm_launch(d, v->ws, v->ws_bytes, s);
+    d.f32 = v->f32;
+    return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
 }
 }  // namespace
 
-long long prx_vgg16_workspace_bytes_impl(int H, int W) { return (H < 16 || W < 16) ? -1 : (long long)vlayout(H, W).total; }
+long long prx_vgg16_workspace_bytes_impl(int H, int W, int precision) { return (H < 16 || W < 16) ? -1 : (long long)vlayout(H, W, precision).total; }
+GemmCtx* prx_vgg16_gemm_ctx_impl(PrxVgg16* v) { return v ? &v->gctx : nullptr; }
 
 int prx_vgg16_feature_shape_impl(int H, int W, int k, int* h, int* w, int* c) {
     PRX_REQUIRE(k >= 0 && k < NFEAT && H >= 16 && W >= 16, "vgg16_feature_shape: feature %d of a %dx%d input", k, H, W);
-    const VLayout L = vlayout(H, W);
+    const VLayout L = vlayout(H, W, 0);
     for (int l = 0; l < NCONV; ++l)
         if (kFeat[l] == k) { *h = L.h[kStage[l]]; *w = L.w[kStage[l]]; *c = kCout[l]; }
     return 0;
 }
 
 // weights: torchvision order, {weight [Cout,Cin,3,3], bias [Cout]} for the 13 convs (fp32, device)
-int prx_vgg16_create_impl(PrxVgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, hipStream_t s) {
+int prx_vgg16_create_impl(PrxVgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, int precision, hipStream_t s) {
+    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vgg16_create: unknown precision %d", precision);
     PRX_REQUIRE(out && weights && n_weights == 2 * NCONV, "vgg16_create: expected %d weight tensors, got %d", 2 * NCONV, n_weights);
     PRX_REQUIRE(max_h >= 16 && max_w >= 16, "vgg16_create: the input must be at least 16x16 (got %dx%d)", max_h, max_w);
     PrxVgg16* v = new PrxVgg16();
-    v->max_h = max_h; v->max_w = max_w;
+    v->max_h = max_h; v->max_w = max_w; v->f32 = precision;
     auto fail = [&](int e) { prx_vgg16_destroy_impl(v); return e; };
     for (int l = 0; l < NCONV; ++l) {
         VConv& c = v->conv[l];
         c.Cin = kCin[l]; c.CiP = cpad(kCin[l]); c.Cout = kCout[l];
         const size_t n = (size_t)c.Cout * 9 * c.CiP;
         int e;
-        if ((e = valloc(v, &c.Wf, n)) || (e = valloc(v, &c.Wd, n)) || (e = valloc(v, &c.b, (size_t)c.Cout))) return fail(e);
-        hipLaunchKernelGGL(vgg_pack_kernel, dim3(1024), dim3(256), 0, s, weights[2 * l], c.Wf, c.Wd, c.Cout, c.Cin, c.CiP);
+        if ((e = valloc_op(v, &c.Wf, n)) || (e = valloc_op(v, &c.Wd, n)) || (e = valloc(v, &c.b, (size_t)c.Cout))) return fail(e);
+        VLAUNCH(vgg_pack_kernel, (size_t)1024 * 256, weights[2 * l], c.Wf, c.Wd, c.Cout, c.Cin, c.CiP);
         if (hipGetLastError() != hipSuccess) return fail(-1);
         if (hipMemcpyAsync(c.b, weights[2 * l + 1], sizeof(float) * c.Cout, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(-1);
     }
     const size_t big = (size_t)max_h * max_w * 64;
     int e;
-    if ((e = valloc(v, &v->dA, big)) || (e = valloc(v, &v->dB, big)) || (e = valloc(v, &v->gpre, big))) return fail(e);
+    if ((e = valloc(v, &v->dA, big)) || (e = valloc(v, &v->dB, big)) || (e = valloc_op(v, &v->gpre, big))) return fail(e);
     v->ws_bytes = (size_t)64 << 20;
     if ((e = valloc(v, &v->ws, v->ws_bytes / sizeof(float)))) return fail(e);
     *out = v;
@@ -208,23 +236,23 @@ void prx_vgg16_destroy_impl(PrxVgg16* v) {
 int prx_vgg16_forward_impl(PrxVgg16* v, const float* x, int H, int W, void* workspace, float* const* feats, hipStream_t s) {
     PRX_REQUIRE(v && x && workspace && feats, "vgg16_forward: null argument");
     PRX_REQUIRE(H >= 16 && W >= 16 && H <= v->max_h && W <= v->max_w, "vgg16_forward: input %dx%d outside [16x16, %dx%d]", H, W, v->max_h, v->max_w);
-    const VLayout L = vlayout(H, W);
+    const VLayout L = vlayout(H, W, v->f32);
     char* base = (char*)workspace;
-    bf16_t* cur = (bf16_t*)(base + L.x0);
-    hipLaunchKernelGGL(vgg_input_kernel, dim3(vgrid((size_t)H * W)), dim3(256), 0, s, x, cur, H * W);
+    void* cur = base + L.x0;
+    VLAUNCH(vgg_input_kernel, (size_t)H * W, x, cur, H * W);
     PRX_LAUNCH_CHECK();
     for (int l = 0; l < NCONV; ++l) {
         const VConv& c = v->conv[l];
         const int st = kStage[l];
         if (l > 0 && kStage[l - 1] != st) {      // pool the previous activation
             const int p = st - 1;
-            bf16_t* pooled = (bf16_t*)(base + L.pooled[p]);
-            hipLaunchKernelGGL(vgg_maxpool_kernel, dim3(vgrid((size_t)L.h[st] * L.w[st] * c.Cin)), dim3(256), 0, s, cur, pooled,
-                               (unsigned char*)(base + L.arg[p]), L.h[st - 1], L.w[st - 1], c.Cin);
+            void* pooled = base + L.pooled[p];
+            VLAUNCH(vgg_maxpool_kernel, (size_t)L.h[st] * L.w[st] * c.Cin, (const void*)cur, pooled,
+                    (unsigned char*)(base + L.arg[p]), L.h[st - 1], L.w[st - 1], c.Cin);
             PRX_LAUNCH_CHECK();
             cur = pooled;
         }
-        bf16_t* act = (bf16_t*)(base + L.act[l]);
+        void* act = base + L.act[l];
         int e = vconv(v, cur, L.h[st], L.w[st], c.CiP, c.Wf, c.Cout, c.b, PRX_ACT_RELU, kFeat[l] >= 0 ? feats[kFeat[l]] : nullptr, act, s);
         if (e) return e;
         cur = act;
@@ -236,7 +264,7 @@ int prx_vgg16_forward_impl(PrxVgg16* v, const float* x, int H, int W, void* work
 int prx_vgg16_backward_impl(PrxVgg16* v, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, hipStream_t s) {
     PRX_REQUIRE(v && workspace && g_feats && g_x, "vgg16_backward: null argument");
     PRX_REQUIRE(H >= 16 && W >= 16 && H <= v->max_h && W <= v->max_w, "vgg16_backward: input %dx%d outside [16x16, %dx%d]", H, W, v->max_h, v->max_w);
-    const VLayout L = vlayout(H, W);
+    const VLayout L = vlayout(H, W, v->f32);
     const char* base = (const char*)workspace;
     const float* above = nullptr;     // gradient w.r.t. the input of conv l+1
     float* bufs[2] = {v->dA, v->dB};
@@ -249,8 +277,7 @@ int prx_vgg16_backward_impl(PrxVgg16* v, int H, int W, const void* workspace, co
         const bool pooled_above = above && l + 1 < NCONV && kStage[l + 1] != st;
         const unsigned char* arg = pooled_above ? (const unsigned char*)(base + L.arg[st]) : nullptr;
         const size_t n = (size_t)L.h[st] * L.w[st] * c.Cout;
-        hipLaunchKernelGGL(vgg_combine_kernel, dim3(vgrid(n)), dim3(256), 0, s, above, arg, gcap, (const bf16_t*)(base + L.act[l]),
-                           v->gpre, L.h[st], L.w[st], c.Cout);
+        VLAUNCH(vgg_combine_kernel, n, above, arg, gcap, (const void*)(base + L.act[l]), v->gpre, L.h[st], L.w[st], c.Cout);
         PRX_LAUNCH_CHECK();
         float* dst = bufs[flip]; flip ^= 1;
         int e = vconv(v, v->gpre, L.h[st], L.w[st], c.Cout, c.Wd, c.CiP, nullptr, PRX_ACT_NONE, dst, nullptr, s);

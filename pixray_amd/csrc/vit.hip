@@ -1,9 +1,10 @@
 // CLIP visual tower runner (clip.model.VisionTransformer [UPSTREAM openai/CLIP], as called by
 // CLIP_Base.encode_image, slip.py:62-66): forward and activation-gradient backward on the
-// bf16 MFMA engine.  Residual stream and LayerNorm statistics stay fp32; every GEMM operand
+// MFMA engine.  Residual stream and LayerNorm statistics stay fp32; every GEMM operand
 // (LN outputs, qkv, attention output, MLP hidden) is bf16; weights are packed once to bf16 in
 // both orientations (forward Bt = W[out,in], dgrad Bt = W^T[in,out]) because they are frozen
-// (slip.py:176).
+// (slip.py:176).  With precision == PRX_PREC_F32 the same operand buffers hold fp32, the GEMMs run on
+// v_mfma_f32_32x32x2_f32 and attention on the fp32 kernels of attention_f32.hip: the exact parity mode.
 #include "vit.h"
 #include "gemm.h"
 #include "norms.h"
@@ -15,9 +16,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+template <typename TOp>
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ in, TOp* __restrict__ out,
                                                              int R, int C) {
-    // out[c][r] = bf16(in[r][c])
+    // out[c][r] = TOp(in[r][c])
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < C && r < R) out[(size_t)c * R + r] = (bf16_t)tile[tx][ty + 8 * i];
+        if (c < C && r < R) out[(size_t)c * R + r] = (TOp)tile[tx][ty + 8 * i];
     }
 }
 
@@ -48,31 +50,41 @@ __global__ __launch_bounds__(256) void add_cls_pos_kernel(float* __restrict__ x,
 
 }  // namespace
 
-int prx_pack_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { return prx_f32_to_bf16(in, out, n, s); }
-int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStream_t s) {
-    hipLaunchKernelGGL(pack_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, s, in, out, R, C);
+int prx_pack_op(const float* in, void* out, size_t n, int f32, hipStream_t s) {
+    if (!f32) return prx_f32_to_bf16(in, (bf16_t*)out, n, s);
+    PRX_CHECK_HIP(hipMemcpyAsync(out, in, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int prx_pack_transpose_op(const float* in, void* out, int R, int C, int f32, hipStream_t s) {
+    const dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
+    if (f32) hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, R, C);
+    else     hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, R, C);
     PRX_LAUNCH_CHECK();
     return 0;
 }
+int prx_pack_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { return prx_pack_op(in, out, n, 0, s); }
+int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStream_t s) { return prx_pack_transpose_op(in, out, R, C, 0, s); }
 
 struct VitLayer {
     float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *b1, *b2;
-    bf16_t *Wqkv, *WqkvT, *Wo, *WoT, *W1, *W1T, *W2, *W2T;
+    void *Wqkv, *WqkvT, *Wo, *WoT, *W1, *W1T, *W2, *W2T;   // operand precision (bf16 | fp32)
     // saved activations
     float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
-    bf16_t *qkv, *t;
-    bf16_t* o_save;   // attention output, kept for the general-T backward (T > 64)
+    void *qkv, *t;    // operand precision
+    void* o_save;     // attention output, kept for the general-T backward (T > 64) and the fp32 attention
     float* lse;
 };
 
 struct PrxVit {
     int res, patch, width, layers, heads, out_dim, T, max_n, KP;
+    int f32;          // PRX_PREC_*: element type of every operand buffer below (void*)
+    GemmCtx gctx;     // this handle's engine state (tile overrides, timing log)
     std::vector<void*> allocs;
-    bf16_t *Wp, *WpT, *projT, *proj;
+    void *Wp, *WpT, *projT, *proj;
     float *cls, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
     std::vector<VitLayer> L;
     // workspace
-    bf16_t *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf;
+    void *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf;   // operand precision
     float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
     float* ws; size_t ws_bytes;
     int cur_n;
@@ -88,29 +100,39 @@ int dev_alloc(PrxVit* v, Tp** p, size_t count) {
     return 0;
 }
 #define ALLOC(ptr, count) do { int _r = dev_alloc(v, &(ptr), (count)); if (_r) return _r; } while (0)
+int dev_alloc_op(PrxVit* v, void** p, size_t count) {   // `count` operand elements
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, count * op_esz(v->f32)));
+    v->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+#define ALLOC_OP(ptr, count) do { int _r = dev_alloc_op(v, &(ptr), (count)); if (_r) return _r; } while (0)
 
 int copy_f32(PrxVit* v, float** dst, const float* src, size_t n, hipStream_t s) {
     ALLOC(*dst, n);
     PRX_CHECK_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
-int pack_both(PrxVit* v, bf16_t** W, bf16_t** WT, const float* src, int out, int in, hipStream_t s) {
-    ALLOC(*W, (size_t)out * in);
-    ALLOC(*WT, (size_t)out * in);
-    int r = prx_pack_bf16(src, *W, (size_t)out * in, s);
+int pack_both(PrxVit* v, void** W, void** WT, const float* src, int out, int in, hipStream_t s) {
+    ALLOC_OP(*W, (size_t)out * in);
+    ALLOC_OP(*WT, (size_t)out * in);
+    int r = prx_pack_op(src, *W, (size_t)out * in, v->f32, s);
     if (r) return r;
-    return prx_pack_transpose_bf16(src, *WT, out, in, s);
+    return prx_pack_transpose_op(src, *WT, out, in, v->f32, s);
 }
 }  // namespace
 
 int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers, int heads, int out_dim, int max_n,
-                        const float* const* w, int n_w, hipStream_t s) {
+                        int precision, const float* const* w, int n_w, hipStream_t s) {
+    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vit_create: unknown precision %d", precision);
     PRX_REQUIRE(n_w == 5 + 12 * layers + 3, "vit_create: expected %d weight tensors, got %d", 5 + 12 * layers + 3, n_w);
     PRX_REQUIRE(res % patch == 0 && width == heads * 64 && width % 256 == 0, "vit_create: unsupported geometry");
     const int G = res / patch;
     const int T = G * G + 1;
     PrxVit* v = new PrxVit();
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
+    v->f32 = precision;
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -146,20 +168,23 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
         if ((r = copy_f32(v, &y.b2, q[11], W, s))) return r;
         ALLOC(y.x_in, R * W); ALLOC(y.x_mid, R * W);
         ALLOC(y.mean1, R); ALLOC(y.rstd1, R); ALLOC(y.mean2, R); ALLOC(y.rstd2, R);
-        ALLOC(y.qkv, R * 3 * W); ALLOC(y.t, R * 4 * W);
+        ALLOC_OP(y.qkv, R * 3 * W); ALLOC_OP(y.t, R * 4 * W);
         y.o_save = nullptr; y.lse = nullptr;
-        if (T > 64) { ALLOC(y.o_save, R * W); ALLOC(y.lse, (size_t)max_n * heads * T); }
+        if (T > 64 || v->f32) { ALLOC_OP(y.o_save, R * W); ALLOC(y.lse, (size_t)max_n * heads * T); }
     }
     const float* const* q = w + 5 + 12 * layers;
     if ((r = copy_f32(v, &v->lnpost_g, q[0], W, s))) return r;
     if ((r = copy_f32(v, &v->lnpost_b, q[1], W, s))) return r;
     // proj is [width, out]: forward Bt = proj^T [out, width]; dgrad Bt = proj [width, out]
     if ((r = pack_both(v, &v->proj, &v->projT, q[2], W, out_dim, s))) return r;
-    ALLOC(v->A0, R * KP); ALLOC(v->h, R * W); ALLOC(v->att_o, R * W); ALLOC(v->u, R * 4 * W);
-    ALLOC(v->hpost, (size_t)max_n * W); ALLOC(v->dt, R * 4 * W); ALLOC(v->do_, R * W); ALLOC(v->dqkv, R * 3 * W);
+    ALLOC_OP(v->A0, R * KP); ALLOC_OP(v->h, R * W); ALLOC_OP(v->att_o, R * W); ALLOC_OP(v->u, R * 4 * W);
+    ALLOC_OP(v->hpost, (size_t)max_n * W); ALLOC_OP(v->dt, R * 4 * W); ALLOC_OP(v->do_, R * W); ALLOC_OP(v->dqkv, R * 3 * W);
     ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R); ALLOC(v->x_final, R * W);
     ALLOC(v->mean_post, max_n); ALLOC(v->rstd_post, max_n); ALLOC(v->e, (size_t)max_n * out_dim);
-    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dx_bf, R * W); ALLOC(v->dh_bf, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
+    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
+    // bf16 twins of the fp32 gradient streams (the dgrad GEMMs' A operands); the exact mode reads the fp32 streams themselves
+    if (v->f32) { v->dx_bf = v->dx; v->dh_bf = v->dh; }
+    else { ALLOC_OP(v->dx_bf, R * W); ALLOC_OP(v->dh_bf, R * W); }
     ALLOC(v->dhpost, (size_t)max_n * W); ALLOC(v->mm_part, 2 * 1024);
     v->ws_bytes = (size_t)64 << 20;
     ALLOC(v->ws, v->ws_bytes / sizeof(float));
@@ -173,7 +198,25 @@ void prx_vit_destroy_impl(PrxVit* v) {
     delete v;
 }
 
-static int vit_gemm(PrxVit* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
+static int vit_gemm(PrxVit* v, GemmDesc& d, hipStream_t s) {
+    if (v->f32) { d.f32 = 1; d.a_is_f32 = 0; }
+    return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
+}
+GemmCtx* prx_vit_gemm_ctx_impl(PrxVit* v) { return v ? &v->gctx : nullptr; }
+
+// LayerNorm whose output is a GEMM operand: bf16, or fp32 in the exact mode (the kernel has both outputs)
+static int ln_op(PrxVit* v, const float* x, long long ldx, const float* g, const float* b, void* out, float* mean, float* rstd,
+                 int rows, hipStream_t s) {
+    return prx_layernorm_fwd(x, ldx, g, b, v->f32 ? nullptr : (bf16_t*)out, v->f32 ? (float*)out : nullptr, mean, rstd, rows,
+                             v->width, 1e-5f, s);
+}
+// LayerNorm backward producing the fp32 gradient stream + its operand twin (the same buffer in the exact mode)
+static int ln_bwd_op(PrxVit* v, const float* g, long long ldg, const float* x, long long ldx, const float* gamma, const float* mean,
+                     const float* rstd, const float* add, long long ldadd, float* dx, long long lddx, void* dx_op, int rows,
+                     hipStream_t s) {
+    return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, v->f32 ? nullptr : (bf16_t*)dx_op, lddx, rows,
+                             v->width, s);
+}
 
 int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
     PRX_REQUIRE(n >= 1 && n <= v->max_n, "vit: batch %d exceeds handle capacity %d", n, v->max_n);
@@ -185,7 +228,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
     const int W = v->width, T = v->T, R = n * T, KP = v->KP;
     int r;
     v->cur_n = n;
-    if ((r = prx_patchify_fwd(cutouts, mm, v->A0, n, v->res, v->patch, T, s))) return r;
+    if ((r = prx_patchify_fwd(cutouts, mm, v->A0, v->f32, n, v->res, v->patch, T, s))) return r;
     {   // conv1 (patch embed) as GEMM
         GemmDesc d; d.A = v->A0; d.lda = KP; d.B = v->Wp; d.ldb = KP; d.M = R; d.N = W; d.K = KP;
         d.out_f32 = v->xpre; d.ldc_f32 = W;
@@ -198,17 +241,18 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
     for (int l = 0; l < v->layers; ++l) {
         VitLayer& y = v->L[l];
         float* x_next = (l + 1 < v->layers) ? v->L[l + 1].x_in : v->x_final;
-        if ((r = prx_layernorm_fwd(y.x_in, W, y.ln1_g, y.ln1_b, v->h, nullptr, y.mean1, y.rstd1, R, W, 1e-5f, s))) return r;
+        if ((r = ln_op(v, y.x_in, W, y.ln1_g, y.ln1_b, v->h, y.mean1, y.rstd1, R, s))) return r;
         {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.Wqkv; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W;
             d.bias_n = y.bqkv; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        const bf16_t* att = v->att_o;
-        if (T <= 64) { if ((r = prx_mha_fwd(y.qkv, v->att_o, n, T, W, v->heads, s))) return r; }
-        else { if ((r = prx_mha_fwd_gen(y.qkv, y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
+        const void* att = v->att_o;
+        if (v->f32) { if ((r = prx_mha_fwd_f32((const float*)y.qkv, (float*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
+        else if (T <= 64) { if ((r = prx_mha_fwd((const bf16_t*)y.qkv, (bf16_t*)v->att_o, n, T, W, v->heads, s))) return r; }
+        else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
         {   GemmDesc d; d.A = att; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.bias_n = y.bo; d.resid = y.x_in; d.ldr = W; d.out_f32 = y.x_mid; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_layernorm_fwd(y.x_mid, W, y.ln2_g, y.ln2_b, v->h, nullptr, y.mean2, y.rstd2, R, W, 1e-5f, s))) return r;
+        if ((r = ln_op(v, y.x_mid, W, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, R, s))) return r;
         {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
             d.bias_n = y.b1; d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
@@ -217,8 +261,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
             if ((r = vit_gemm(v, d, s))) return r; }
     }
     // ln_post on the class token, projection, L2 normalisation (slip.py:66)
-    if ((r = prx_layernorm_fwd(v->x_final, (long long)T * W, v->lnpost_g, v->lnpost_b, v->hpost, nullptr, v->mean_post,
-                               v->rstd_post, n, W, 1e-5f, s))) return r;
+    if ((r = ln_op(v, v->x_final, (long long)T * W, v->lnpost_g, v->lnpost_b, v->hpost, v->mean_post, v->rstd_post, n, s))) return r;
     {   GemmDesc d; d.A = v->hpost; d.lda = W; d.B = v->projT; d.ldb = W; d.M = n; d.N = v->out_dim; d.K = W;
         d.out_f32 = v->e; d.ldc_f32 = v->out_dim;
         if ((r = vit_gemm(v, d, s))) return r; }
@@ -240,9 +283,9 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         if ((r = vit_gemm(v, d, s))) return r; }
     // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
     PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
-    PRX_CHECK_HIP(hipMemsetAsync(v->dx_bf, 0, sizeof(bf16_t) * (size_t)R * W, s));
-    if ((r = prx_layernorm_bwd(v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
-                               nullptr, 0, v->dx, (long long)T * W, v->dx_bf, (long long)T * W, n, W, s))) return r;
+    if (!v->f32) PRX_CHECK_HIP(hipMemsetAsync(v->dx_bf, 0, sizeof(bf16_t) * (size_t)R * W, s));
+    if ((r = ln_bwd_op(v, v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
+                       nullptr, 0, v->dx, (long long)T * W, v->dx_bf, n, s))) return r;
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
         // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
@@ -252,20 +295,21 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_layernorm_bwd(v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, v->dx_bf, W, R, W, s))) return r;
+        if ((r = ln_bwd_op(v, v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, v->dx_bf, R, s))) return r;
         // attention: x_mid = x_in + out_proj(mha(ln_1(x_in)))
         {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.out_bf16 = v->do_; d.ldc_bf16 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if (T <= 64) { if ((r = prx_mha_bwd(y.qkv, v->do_, v->dqkv, n, T, W, v->heads, s))) return r; }
-        else { if ((r = prx_mha_bwd_gen(y.qkv, y.o_save, v->do_, y.lse, v->dqkv, n, T, W, v->heads, s))) return r; }
+        if (v->f32) { if ((r = prx_mha_bwd_f32((const float*)y.qkv, (const float*)y.o_save, (const float*)v->do_, y.lse, (float*)v->dqkv, n, T, W, v->heads, s))) return r; }
+        else if (T <= 64) { if ((r = prx_mha_bwd((const bf16_t*)y.qkv, (const bf16_t*)v->do_, (bf16_t*)v->dqkv, n, T, W, v->heads, s))) return r; }
+        else { if ((r = prx_mha_bwd_gen((const bf16_t*)y.qkv, (const bf16_t*)y.o_save, (const bf16_t*)v->do_, y.lse, (bf16_t*)v->dqkv, n, T, W, v->heads, s))) return r; }
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = prx_layernorm_bwd(v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, W, R, W, s))) return r;
+        if ((r = ln_bwd_op(v, v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, R, s))) return r;
     }
     // ln_pre backward (in place on dx), then patch-embed dgrad
-    if ((r = prx_layernorm_bwd(v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, W, R, W, s))) return r;
+    if ((r = ln_bwd_op(v, v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s))) return r;
     {   GemmDesc d; d.A = v->dh_bf; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
         d.out_f32 = v->dA0; d.ldc_f32 = KP;
         if ((r = vit_gemm(v, d, s))) return r; }

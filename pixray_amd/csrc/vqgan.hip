@@ -21,8 +21,9 @@ namespace {
 
 // Wf[co][tap*Cin + ci] = w[co][ci][ky][kx]           (forward pack)
 // Wd[ci][tap*CoP + co] = w[co][ci][2-ky][2-kx]       (dgrad pack; co padded with zeros to CoP)
-__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ Wf,
-                                                           bf16_t* __restrict__ Wd, int Cout, int Cin, int CoP) {
+template <typename TOp>
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, TOp* __restrict__ Wf,
+                                                           TOp* __restrict__ Wd, int Cout, int Cin, int CoP) {
     const size_t total_f = (size_t)Cout * 9 * Cin;
     const size_t total_d = (size_t)Cin * 9 * CoP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d;
@@ -31,14 +32,14 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
             int ci = (int)(i % Cin);
             int tap = (int)((i / Cin) % 9);
             int co = (int)(i / ((size_t)9 * Cin));
-            Wf[i] = (bf16_t)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+            Wf[i] = (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
         } else {
             size_t j = i - total_f;
             int co = (int)(j % CoP);
             int tap = (int)((j / CoP) % 9);
             int ci = (int)(j / ((size_t)9 * CoP));
             int ky = 2 - tap / 3, kx = 2 - tap % 3;
-            Wd[j] = (co < Cout) ? (bf16_t)w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : (bf16_t)0.f;
+            Wd[j] = (co < Cout) ? (TOp)w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : (TOp)0.f;
         }
     }
 }
@@ -56,38 +57,41 @@ __global__ __launch_bounds__(256) void colminmax_kernel(const float* __restrict_
 
 static inline int pad8(int P) { return (P + 7) & ~7; }   // row pitch of [*, P] GEMM operands (see zero_if_padded)
 
-struct Conv3 { int Cin, Cout, CoP; bf16_t *Wf, *Wd; float* b; };
-struct Conv1 { int Cin, Cout; bf16_t *W, *WT; float* b; };
+// `void*` members are operand-precision buffers: bf16, or fp32 when the handle was created with PRX_PREC_F32
+struct Conv3 { int Cin, Cout, CoP; void *Wf, *Wd; float* b; };
+struct Conv1 { int Cin, Cout; void *W, *WT; float* b; };
 struct GN { int C; float *g, *b; double *stats, *bstats; int id; };
 
 struct ResBlock {
     int Cin, Cout, rh, rw;   // feature-map height x width (pixray sizes need not be square)
     GN n1, n2; Conv3 c1, c2; Conv1 sc; bool has_sc;
     float *x_in, *h1, *scbuf, *out;
-    bf16_t *x_in_bf, *out_bf;   // bf16 twins (only where a GEMM consumes the tensor)
+    void *x_in_bf, *out_bf;     // operand twins (only where a GEMM consumes the tensor); the fp32 tensor itself in the exact mode
 };
 struct AttnBlock {
     int C, rh, rw;
     GN n; Conv1 qkv, proj;   // qkv = [3C, C] concatenated q|k|v
-    float* x_in; bf16_t *qkvb, *Pm, *PT; float* out; bf16_t* out_bf;
+    float* x_in; void *qkvb, *Pm, *PT; float* out; void* out_bf;
 };
-struct UpBlock { int C, rh, rw; Conv3 c; float *x_in, *out; bf16_t *x_in_bf, *out_bf; };
+struct UpBlock { int C, rh, rw; Conv3 c; float *x_in, *out; void *x_in_bf, *out_bf; };
 
 struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
 
 struct PrxVqgan {
     int zc, D, NC, ch, out_ch, h0, w0, H, W, nstage;
+    int f32;          // PRX_PREC_*
+    GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *codebook, *cnorm, *zmin, *zmax;
     Conv1 pq; Conv3 conv_in, conv_out; GN norm_out;
     std::vector<ResBlock> res; std::vector<AttnBlock> attn; std::vector<UpBlock> ups; std::vector<Stage> stages;
     // activations
-    float *zq, *h_in, *y; int* idx; bf16_t *pqo_bf, *h_in_bf, *dpq_bf;
+    float *zq, *h_in, *y; int* idx; void *pqo_bf, *h_in_bf, *dpq_bf;
     float *pmin; int* pidx;
-    bf16_t* a;             // GN(+swish) operand, max size
-    bf16_t *tA, *tB, *tC, *tD, *dqkv, *dy8;  // attention temporaries [P*C max], dgrad head input
+    void* a;               // GN(+swish) operand, max size
+    void *tA, *tB, *tC, *tD, *dqkv, *dy8;    // attention temporaries [P*C max], dgrad head input
     float *S, *g0, *g1, *g2; // score matrix; gradient ping-pong buffers (max P*C)
-    bf16_t *g0b, *g1b, *g2b; // their bf16 twins (dgrad GEMM operands)
+    void *g0b, *g1b, *g2b;   // their operand twins (dgrad GEMM operands); aliases of g0..g2 in the exact mode
     double* all_stats; int n_gn;   // [n_gn][64] forward stats followed by [n_gn][64] backward stats
     float* ws; size_t ws_bytes;
     float* x_last;  // input of norm_out
@@ -103,6 +107,14 @@ int dalloc(PrxVqgan* v, Tp** p, size_t count) {
     return 0;
 }
 #define VALLOC(ptr, count) do { int _r = dalloc(v, &(ptr), (count)); if (_r) return _r; } while (0)
+int dalloc_op(PrxVqgan* v, void** p, size_t count) {   // `count` operand elements
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * op_esz(v->f32)));
+    v->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+#define VALLOC_OP(ptr, count) do { int _r = dalloc_op(v, &(ptr), (count)); if (_r) return _r; } while (0)
 
 struct WCursor { const float* const* w; int n, pos; };
 #define NEXTW(cur, dst) do { PRX_REQUIRE((cur).pos < (cur).n, "vqgan_create: weight list too short"); (dst) = (cur).w[(cur).pos++]; } while (0)
@@ -125,19 +137,20 @@ int make_gn(PrxVqgan* v, GN& g, int C, WCursor& cur, hipStream_t s) {
 int make_conv3(PrxVqgan* v, Conv3& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
     const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
     c.Cin = Cin; c.Cout = Cout; c.CoP = (Cout + 7) / 8 * 8;
-    VALLOC(c.Wf, (size_t)Cout * 9 * Cin);
-    VALLOC(c.Wd, (size_t)Cin * 9 * c.CoP);
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(1024), dim3(256), 0, s, w, c.Wf, c.Wd, Cout, Cin, c.CoP);
+    VALLOC_OP(c.Wf, (size_t)Cout * 9 * Cin);
+    VALLOC_OP(c.Wd, (size_t)Cin * 9 * c.CoP);
+    if (v->f32) hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(1024), dim3(256), 0, s, w, (float*)c.Wf, (float*)c.Wd, Cout, Cin, c.CoP);
+    else        hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(1024), dim3(256), 0, s, w, (bf16_t*)c.Wf, (bf16_t*)c.Wd, Cout, Cin, c.CoP);
     PRX_LAUNCH_CHECK();
     return copyf(v, &c.b, b, Cout, s);
 }
 int make_conv1(PrxVqgan* v, Conv1& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
     const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
     c.Cin = Cin; c.Cout = Cout;
-    VALLOC(c.W, (size_t)Cout * Cin); VALLOC(c.WT, (size_t)Cout * Cin);
+    VALLOC_OP(c.W, (size_t)Cout * Cin); VALLOC_OP(c.WT, (size_t)Cout * Cin);
     int r;
-    if ((r = prx_pack_bf16(w, c.W, (size_t)Cout * Cin, s))) return r;
-    if ((r = prx_pack_transpose_bf16(w, c.WT, Cout, Cin, s))) return r;
+    if ((r = prx_pack_op(w, c.W, (size_t)Cout * Cin, v->f32, s))) return r;
+    if ((r = prx_pack_transpose_op(w, c.WT, Cout, Cin, v->f32, s))) return r;
     return copyf(v, &c.b, b, Cout, s);
 }
 int make_res(PrxVqgan* v, int Cin, int Cout, int rh, int rw, WCursor& cur, hipStream_t s) {
@@ -174,15 +187,15 @@ int make_attn(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
         PRX_CHECK_HIP(hipMemcpyAsync(bcat + i * C, bs_[i], sizeof(float) * C, hipMemcpyDeviceToDevice, s));
     }
     ab.qkv.Cin = C; ab.qkv.Cout = 3 * C; ab.qkv.b = bcat;
-    VALLOC(ab.qkv.W, (size_t)3 * C * C); VALLOC(ab.qkv.WT, (size_t)3 * C * C);
-    if ((r = prx_pack_bf16(wcat, ab.qkv.W, (size_t)3 * C * C, s))) return r;
-    if ((r = prx_pack_transpose_bf16(wcat, ab.qkv.WT, 3 * C, C, s))) return r;
+    VALLOC_OP(ab.qkv.W, (size_t)3 * C * C); VALLOC_OP(ab.qkv.WT, (size_t)3 * C * C);
+    if ((r = prx_pack_op(wcat, ab.qkv.W, (size_t)3 * C * C, v->f32, s))) return r;
+    if ((r = prx_pack_transpose_op(wcat, ab.qkv.WT, 3 * C, C, v->f32, s))) return r;
     if ((r = make_conv1(v, ab.proj, C, C, cur, s))) return r;
     const size_t P = (size_t)rh * rw;
     const size_t P8 = (size_t)pad8((int)P);
-    VALLOC(ab.qkvb, P * 3 * C); VALLOC(ab.Pm, P * P8); VALLOC(ab.PT, P * P8); VALLOC(ab.out, P * C);
-    PRX_CHECK_HIP(hipMemsetAsync(ab.Pm, 0, P * P8 * sizeof(bf16_t), s));      // pad columns stay zero: the kernels never write them
-    PRX_CHECK_HIP(hipMemsetAsync(ab.PT, 0, P * P8 * sizeof(bf16_t), s));
+    VALLOC_OP(ab.qkvb, P * 3 * C); VALLOC_OP(ab.Pm, P * P8); VALLOC_OP(ab.PT, P * P8); VALLOC(ab.out, P * C);
+    PRX_CHECK_HIP(hipMemsetAsync(ab.Pm, 0, P * P8 * op_esz(v->f32), s));      // pad columns stay zero: the kernels never write them
+    PRX_CHECK_HIP(hipMemsetAsync(ab.PT, 0, P * P8 * op_esz(v->f32), s));
     v->stages.push_back({1, (int)v->attn.size()});
     v->attn.push_back(ab);
     return 0;
@@ -201,11 +214,13 @@ int make_up(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
 
 int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult, int num_res_blocks, int attn_res,
                           int resolution, int z_channels, int embed_dim, int n_embed, int out_ch, int h0, int w0,
-                          const float* const* w, int n_w, hipStream_t s) {
+                          int precision, const float* const* w, int n_w, hipStream_t s) {
     PRX_REQUIRE(h0 >= 1 && w0 >= 1, "vqgan_create: bad latent size %dx%d", h0, w0);
+    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vqgan_create: unknown precision %d", precision);
     PRX_REQUIRE(embed_dim == z_channels, "vqgan_create: embed_dim must equal z_channels");
     PrxVqgan* v = new PrxVqgan();
     std::unique_ptr<PrxVqgan> guard(v);
+    v->f32 = precision;
     v->n_gn = 0; v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
     WCursor cur{w, n_w, 0};
     int r;
@@ -247,32 +262,34 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.rh * rb.rw * std::max(rb.Cin, rb.Cout));
     for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.rh * ub.rw * ub.C);
     for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)pad8(ab.rh * ab.rw) * (size_t)std::max(ab.C, pad8(ab.rh * ab.rw)));
-    VALLOC(v->zq, P0 * embed_dim); VALLOC(v->pqo_bf, P0 * z_channels); VALLOC(v->dpq_bf, P0 * z_channels);
+    VALLOC(v->zq, P0 * embed_dim); VALLOC_OP(v->pqo_bf, P0 * z_channels); VALLOC_OP(v->dpq_bf, P0 * z_channels);
     VALLOC(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
     VALLOC(v->y, PH * 4); VALLOC(v->idx, P0);
     const int ntiles = ceil_div(n_embed, 64);
     VALLOC(v->pmin, P0 * ntiles); VALLOC(v->pidx, P0 * ntiles);
-    VALLOC(v->a, maxPC);
-    VALLOC(v->tA, maxAttnPC); VALLOC(v->tB, maxAttnPC); VALLOC(v->tC, maxAttnPC); VALLOC(v->tD, maxAttnPC);
-    VALLOC(v->dqkv, maxAttnPC * 3); VALLOC(v->dy8, PH * 8);
+    VALLOC_OP(v->a, maxPC);
+    VALLOC_OP(v->tA, maxAttnPC); VALLOC_OP(v->tB, maxAttnPC); VALLOC_OP(v->tC, maxAttnPC); VALLOC_OP(v->tD, maxAttnPC);
+    VALLOC_OP(v->dqkv, maxAttnPC * 3); VALLOC_OP(v->dy8, PH * 8);
     VALLOC(v->S, maxAttnPC);
     VALLOC(v->g0, maxPC); VALLOC(v->g1, maxPC); VALLOC(v->g2, maxPC);
-    VALLOC(v->g0b, maxPC); VALLOC(v->g1b, maxPC); VALLOC(v->g2b, maxPC);
+    if (v->f32) { v->g0b = v->g0; v->g1b = v->g1; v->g2b = v->g2; }     // the fp32 gradient streams are the dgrad operands
+    else { VALLOC_OP(v->g0b, maxPC); VALLOC_OP(v->g1b, maxPC); VALLOC_OP(v->g2b, maxPC); }
     // bf16 twins of stage outputs that feed a GEMM directly (1x1 shortcut or upsample conv of the next stage)
     v->h_in_bf = nullptr;
     for (size_t i = 0; i < v->stages.size(); ++i) {
         const Stage& st = v->stages[i];
         const bool need = (st.kind == 0 && v->res[st.idx].has_sc) || st.kind == 2;
         if (!need) continue;
-        bf16_t** slot; size_t cnt;
-        if (i == 0) { slot = &v->h_in_bf; cnt = P0 * (size_t)(ch * ch_mult[n_mult - 1]); }
+        void** slot; size_t cnt; float* self;
+        if (i == 0) { slot = &v->h_in_bf; cnt = P0 * (size_t)(ch * ch_mult[n_mult - 1]); self = v->h_in; }
         else {
             const Stage& pr = v->stages[i - 1];
-            if (pr.kind == 0) { ResBlock& b = v->res[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.Cout; }
-            else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; }
-            else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; }
+            if (pr.kind == 0) { ResBlock& b = v->res[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.Cout; self = b.out; }
+            else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; self = b.out; }
+            else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; self = b.out; }
         }
-        VALLOC(*slot, cnt);
+        if (v->f32) *slot = self;          // exact mode: the fp32 stage output is the operand
+        else VALLOC_OP(*slot, cnt);
     }
     {   // one contiguous stats slab: forward stats of every GroupNorm, then the backward stats
         VALLOC(v->all_stats, (size_t)2 * v->n_gn * 64);
@@ -294,42 +311,50 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
 }
 
 // the GEMM epilogue can accumulate the next GroupNorm's sums only for power-of-two group sizes >= 4 channels
-static bool fusable(int C) { const int gs = C / 32; return C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0; }
+// (a bf16-path epilogue: the exact mode runs the separate statistics kernels)
+static bool fusable(const PrxVqgan* v, int C) { const int gs = C / 32; return !v->f32 && C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0; }
 
 // Token counts of the attention maps (P = h*w of the latent) are arbitrary (pixray sizes are multiples of 16 pixels, so
 // e.g. 25x14 = 350 tokens), but GEMM K dimensions and leading dimensions must be multiples of 8: every [*, P] operand is
 // laid out with a row pitch of P8 = round_up(P, 8) and zero columns beyond P.
-static int zero_if_padded(bf16_t* buf, size_t rows, int P, hipStream_t s) {
-    if (pad8(P) != P) PRX_CHECK_HIP(hipMemsetAsync(buf, 0, rows * (size_t)pad8(P) * sizeof(bf16_t), s));
+static int zero_if_padded(const PrxVqgan* v, void* buf, size_t rows, int P, hipStream_t s) {
+    if (pad8(P) != P) PRX_CHECK_HIP(hipMemsetAsync(buf, 0, rows * (size_t)pad8(P) * op_esz(v->f32), s));
     return 0;
 }
 
-static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) { return prx_gemm_launch(d, v->ws, v->ws_bytes, s); }
+static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) {
+    if (v->f32) {
+        d.f32 = 1; d.a_is_f32 = 0;
+        if (d.out_bf16 == (void*)d.out_f32) d.out_bf16 = nullptr;   // the "twin" is the fp32 output itself
+    }
+    return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
+}
+GemmCtx* prx_vqgan_gemm_ctx_impl(PrxVqgan* v) { return v ? &v->gctx : nullptr; }
 
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const float* resid,
-                     float* out, int ldc, hipStream_t s, bf16_t* out_bf = nullptr, const GN* stats_for = nullptr) {
+                     float* out, int ldc, hipStream_t s, void* out_bf = nullptr, const GN* stats_for = nullptr) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
     d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = rh * rw; d.N = c.Cout; d.K = 9 * c.Cin;
     d.H = rh; d.W = rw; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
     d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
-    if (stats_for && stats_for->C == c.Cout && fusable(c.Cout)) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
+    if (stats_for && stats_for->C == c.Cout && fusable(v, c.Cout)) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
 // `gnb` (+ its forward input gnb_x): the GroupNorm whose output gradient this dgrad produces -- its backward sums are
 // accumulated in the GEMM epilogue (gemm.h gnb_*), so gn_bwd can skip its statistics pass
-static void set_gnb(GemmDesc& d, const GN* gnb, const float* gnb_x, int swish) {
-    if (!gnb || !fusable(gnb->C) || d.N != gnb->C) return;
+static void set_gnb(const PrxVqgan* v, GemmDesc& d, const GN* gnb, const float* gnb_x, int swish) {
+    if (!gnb || !fusable(v, gnb->C) || d.N != gnb->C) return;
     d.gn_stats = gnb->bstats; d.gn_gs = gnb->C / 32;
     d.gnb_x = gnb_x; d.gnb_fstats = gnb->stats; d.gnb_gamma = gnb->g; d.gnb_beta = gnb->b; d.gnb_swish = swish; d.gnb_eps = 1e-6f;
 }
 static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, float* dx, hipStream_t s,
-                     bf16_t* dx_bf = nullptr, const GN* gnb = nullptr, const float* gnb_x = nullptr, int gnb_swish = 1) {
+                     void* dx_bf = nullptr, const GN* gnb = nullptr, const float* gnb_x = nullptr, int gnb_swish = 1) {
     GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
     d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = rh * rw; d.N = c.Cin; d.K = 9 * c.CoP;
     d.H = rh; d.W = rw; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
     d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
-    set_gnb(d, gnb, gnb_x, gnb_swish);
+    set_gnb(v, d, gnb, gnb_x, gnb_swish);
     return vg(v, d, s);
 }
 // first GroupNorm of stage `si` (whose statistics the producer of that stage's input can accumulate in its epilogue)
@@ -341,13 +366,13 @@ static const GN* first_norm(const PrxVqgan* v, int si) {
     return nullptr;
 }
 static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s, bool stats_ready = false) {
-    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->a, nullptr, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0,
-                             stats_ready ? 1 : 0);
+    return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->f32 ? nullptr : (bf16_t*)v->a, v->f32 ? (float*)v->a : nullptr, 1, P, g.C, swish,
+                             1e-6f, s, /*zero_stats=*/0, stats_ready ? 1 : 0);
 }
 static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
-                  bf16_t* dx_bf, int P, int swish, hipStream_t s, bool stats_ready = false) {
-    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, dx_bf, 1, P, g.C, swish, 1e-6f, s, /*zero_stats=*/0,
-                             stats_ready && fusable(g.C) ? 1 : 0);
+                  void* dx_bf, int P, int swish, hipStream_t s, bool stats_ready = false) {
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, v->f32 ? nullptr : (bf16_t*)dx_bf, 1, P, g.C, swish, 1e-6f, s,
+                             /*zero_stats=*/0, stats_ready && fusable(v, g.C) ? 1 : 0);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -373,9 +398,9 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     // `sr`: the statistics of the GroupNorm that consumes x next were already accumulated by x's producer
     const GN* nx = first_norm(v, 0);
     if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, v->w0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
-    bool sr = nx && nx->C == v->conv_in.Cout && fusable(nx->C);
+    bool sr = nx && nx->C == v->conv_in.Cout && fusable(v, nx->C);
     float* x = v->h_in;
-    bf16_t* x_bf = v->h_in_bf;   // bf16 twin of x (null when no GEMM reads x directly)
+    void* x_bf = v->h_in_bf;     // operand twin of x (null when no GEMM reads x directly)
     for (int si = 0; si < (int)v->stages.size(); ++si) {
         const Stage& st = v->stages[si];
         nx = first_norm(v, si + 1);
@@ -393,9 +418,9 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 if ((r = vg(v, d, s))) return r;
                 resid = b.scbuf;
             }
-            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, fusable(b.Cout)))) return r;
+            if ((r = gn_fwd(v, b.n2, b.h1, P, 1, s, fusable(v, b.Cout)))) return r;
             if ((r = conv3_fwd(v, b.c2, v->a, false, b.rh, b.rw, false, resid, b.out, b.Cout, s, b.out_bf, nx))) return r;
-            sr = nx && nx->C == b.Cout && fusable(b.Cout);
+            sr = nx && nx->C == b.Cout && fusable(v, b.Cout);
             x = b.out; x_bf = b.out_bf;
         } else if (st.kind == 1) {
             AttnBlock& b = v->attn[st.idx];
@@ -406,28 +431,28 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 d.bias_n = b.qkv.b; d.out_bf16 = b.qkvb; d.ldc_bf16 = 3 * C;
                 if ((r = vg(v, d, s))) return r; }
             const int P8 = pad8(P);
-            if ((r = zero_if_padded(v->tA, C, P, s))) return r;
-            if ((r = prx_transpose_bf16(b.qkvb + 2 * C, 3 * C, v->tA, P8, P, C, s))) return r;  // tA = v^T [C, P8]
-            {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = b.qkvb + C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
+            if ((r = zero_if_padded(v, v->tA, C, P, s))) return r;
+            if ((r = prx_transpose_op(op_off(b.qkvb, 2 * C, v->f32), 3 * C, v->tA, P8, P, C, v->f32, s))) return r;  // tA = v^T [C, P8]
+            {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = op_off(b.qkvb, C, v->f32); d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, s))) return r;
+            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, v->f32, s))) return r;
             {   GemmDesc d; d.A = b.Pm; d.lda = P8; d.B = v->tA; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->tB; d.ldc_bf16 = C;
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
                 d.out_bf16 = b.out_bf; d.ldc_bf16 = C;
-                if (nx && nx->C == C && fusable(C)) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
+                if (nx && nx->C == C && fusable(v, C)) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
                 if ((r = vg(v, d, s))) return r; }
-            sr = nx && nx->C == C && fusable(C);
+            sr = nx && nx->C == C && fusable(v, C);
             x = b.out; x_bf = b.out_bf;
         } else {
             UpBlock& b = v->ups[st.idx];
             b.x_in = x; b.x_in_bf = x_bf;
             PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the upsample input");
             if ((r = conv3_fwd(v, b.c, x_bf, false, b.rh, b.rw, true, nullptr, b.out, b.C, s, b.out_bf, nx))) return r;
-            sr = nx && nx->C == b.C && fusable(b.C);
+            sr = nx && nx->C == b.C && fusable(v, b.C);
             x = b.out; x_bf = b.out_bf;
         }
     }
@@ -464,8 +489,9 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     int r;
     PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
     PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
-    if ((r = prx_image_head_bwd(v->y, 4, g_img, nullptr, v->dy8, v->conv_out.CoP, 1, v->out_ch, PH, s))) return r;
-    struct GB { float* f; bf16_t* b; };
+    if ((r = prx_image_head_bwd(v->y, 4, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
+                                v->out_ch, PH, s))) return r;
+    struct GB { float* f; void* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
     if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
     if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s, true))) return r;
@@ -494,36 +520,36 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             {   GemmDesc d; d.A = g.b; d.lda = C; d.B = b.proj.WT; d.ldb = C; d.M = P; d.N = C; d.K = C;
                 d.out_bf16 = v->tA; d.ldc_bf16 = C;                                      // tA = d o [P, C]
                 if ((r = vg(v, d, s))) return r; }
-            {   GemmDesc d; d.A = v->tA; d.lda = C; d.B = b.qkvb + 2 * C; d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
+            {   GemmDesc d; d.A = v->tA; d.lda = C; d.B = op_off(b.qkvb, 2 * C, v->f32); d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;                                         // dP = do v^T
                 if ((r = vg(v, d, s))) return r; }
             const int P8 = pad8(P);
-            if ((r = zero_if_padded(v->tB, P, P, s))) return r;
-            if ((r = zero_if_padded(v->tC, P, P, s))) return r;
-            if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, s))) return r;  // tB = dS, tC = dS^T
-            if ((r = zero_if_padded(v->tD, C, P, s))) return r;
-            if ((r = prx_transpose_bf16(b.qkvb + C, 3 * C, v->tD, P8, P, C, s))) return r;       // tD = k^T [C, P8]
+            if ((r = zero_if_padded(v, v->tB, P, P, s))) return r;
+            if ((r = zero_if_padded(v, v->tC, P, P, s))) return r;
+            if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, v->f32, s))) return r;  // tB = dS, tC = dS^T
+            if ((r = zero_if_padded(v, v->tD, C, P, s))) return r;
+            if ((r = prx_transpose_op(op_off(b.qkvb, C, v->f32), 3 * C, v->tD, P8, P, C, v->f32, s))) return r;       // tD = k^T [C, P8]
             {   GemmDesc d; d.A = v->tB; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->dqkv; d.ldc_bf16 = 3 * C;                               // dq = dS k
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_bf16(b.qkvb, 3 * C, v->tD, P8, P, C, s))) return r;           // tD = q^T (pad columns still zero)
+            if ((r = prx_transpose_op(b.qkvb, 3 * C, v->tD, P8, P, C, v->f32, s))) return r;           // tD = q^T (pad columns still zero)
             {   GemmDesc d; d.A = v->tC; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
-                d.out_bf16 = v->dqkv + C; d.ldc_bf16 = 3 * C;                           // dk = dS^T q
+                d.out_bf16 = op_off(v->dqkv, C, v->f32); d.ldc_bf16 = 3 * C;            // dk = dS^T q
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_bf16(v->tA, C, v->tD, P8, P, C, s))) return r;                // tD = do^T
+            if ((r = prx_transpose_op(v->tA, C, v->tD, P8, P, C, v->f32, s))) return r;                // tD = do^T
             {   GemmDesc d; d.A = b.PT; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
-                d.out_bf16 = v->dqkv + 2 * C; d.ldc_bf16 = 3 * C;                       // dv = P^T do
+                d.out_bf16 = op_off(v->dqkv, 2 * C, v->f32); d.ldc_bf16 = 3 * C;        // dv = P^T do
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
                 d.out_f32 = t1.f; d.ldc_f32 = C;                                         // d GN(x)
-                set_gnb(d, &b.n, b.x_in, 0);
+                set_gnb(v, d, &b.n, b.x_in, 0);
                 if ((r = vg(v, d, s))) return r; }
             if ((r = gn_bwd(v, b.n, t1.f, b.x_in, g.f, t2.f, t2.b, P, 0, s, true))) return r;
             std::swap(g, t2);
         } else {
             UpBlock& b = v->ups[st.idx];
             if ((r = conv3_bwd(v, b.c, g.b, false, b.rh, b.rw, t1.f, s))) return r;       // d up(x) at high res
-            if ((r = prx_upsample2x_bwd(t1.f, t2.f, t2.b, 1, b.rh / 2, b.rw / 2, b.C, s))) return r;
+            if ((r = prx_upsample2x_bwd(t1.f, t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s))) return r;
             std::swap(g, t2);
         }
     }

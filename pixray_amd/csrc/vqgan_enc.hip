@@ -250,11 +250,11 @@ int prx_vqgan_encode_impl(PrxVqganEnc* e, const float* img, float* z, float* z_p
                 PRX_CHECK_HIP(hipMemsetAsync(e->tA, 0, sizeof(bf16_t) * (size_t)C * P8, s));
                 PRX_CHECK_HIP(hipMemsetAsync(e->Pm, 0, sizeof(bf16_t) * (size_t)Pc * P8, s));
             }
-            if ((r = prx_transpose_bf16(e->qkvb + 2 * C, 3 * C, e->tA, P8, Pc, C, s))) return r;      // tA = v^T [C, P8]
+            if ((r = prx_transpose_op(e->qkvb + 2 * C, 3 * C, e->tA, P8, Pc, C, PRX_PREC_BF16, s))) return r;      // tA = v^T [C, P8]
             {   GemmDesc d; d.A = e->qkvb; d.lda = 3 * C; d.B = e->qkvb + C; d.ldb = 3 * C; d.M = Pc; d.N = Pc; d.K = C;
                 d.out_f32 = e->S; d.ldc_f32 = Pc;
                 if ((r = eg(e, d, s))) return r; }
-            if ((r = prx_softmax_rows(e->S, Pc, 1.f / sqrtf((float)C), e->Pm, P8, e->PT, P8, Pc, Pc, s))) return r;
+            if ((r = prx_softmax_rows(e->S, Pc, 1.f / sqrtf((float)C), e->Pm, P8, e->PT, P8, Pc, Pc, PRX_PREC_BF16, s))) return r;
             {   GemmDesc d; d.A = e->Pm; d.lda = P8; d.B = e->tA; d.ldb = P8; d.M = Pc; d.N = C; d.K = P8;
                 d.out_bf16 = e->tB; d.ldc_bf16 = C;
                 if ((r = eg(e, d, s))) return r; }

@@ -263,6 +263,32 @@ def build_cached_descriptors(live: torch.Tensor, cutn: int, S: int, reflect: boo
     return torch.from_numpy(desc)
 
 
+class PinnedRing:
+    """Host staging for values the host redraws every iteration and the device reads from ONE fixed buffer (so the
+    iteration can be replayed from a hipGraph): a small ring of pinned buffers, each guarded by the event recorded after
+    its last H2D copy.  The host may run several iterations ahead of the GPU; without the ring it would overwrite a
+    pinned buffer whose copy is still queued, and an earlier iteration would see a later iteration's values."""
+
+    def __init__(self, shape, dtype, device, slots: int = 4):
+        self.host = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.dev = torch.empty(shape, dtype=dtype, device=device)
+        self._i = 0
+
+    def stage(self, value: torch.Tensor) -> torch.Tensor:
+        """value (CPU) -> the fixed device buffer, stream-ordered on the current stream"""
+        i = self._i
+        self._i = (i + 1) % len(self.host)
+        if self.events[i] is not None:
+            self.events[i].synchronize()          # that slot's previous copy has executed: safe to overwrite
+        self.host[i].copy_(value)
+        self.dev.copy_(self.host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev.device))
+        self.events[i] = ev
+        return self.dev
+
+
 class MakeCutouts(nn.Module):
     """Drop-in for the reference's `MakeCutouts(cut_size, cutn, cut_pow=1.)` (pixray.py:400-511):
     `forward(input[1,3,H,W]) -> [cutn,3,S,S]`, autograd-connected to `input`.
@@ -295,8 +321,8 @@ class MakeCutouts(nn.Module):
         """Keep the descriptor table in a fixed device buffer (fed from a pinned host buffer) so the device part of
         the iteration can be captured in a hipGraph and replayed."""
         lo, hi = (0, self.cutn) if self.shard is None else self.shard
-        self._pinned = torch.empty(hi - lo, DESC_WORDS, dtype=torch.float64).pin_memory()
-        self._static_desc = torch.empty(hi - lo, DESC_WORDS, dtype=torch.float64, device=device)
+        self._ring = PinnedRing((hi - lo, DESC_WORDS), torch.float64, device)
+        self._static_desc = self._ring.dev
 
     def prepare(self, iteration=None, fill=None, device=None):
         if iteration is not None:
@@ -311,9 +337,7 @@ class MakeCutouts(nn.Module):
         self.transforms = desc          # this iteration's geometry (opaque, like the reference's composed 3x3 cache)
         lo, hi = (0, self.cutn) if self.shard is None else self.shard
         if getattr(self, "_static_desc", None) is not None:
-            self._pinned.copy_(desc[lo:hi])
-            self._static_desc.copy_(self._pinned, non_blocking=True)       # stream-ordered before the replay
-            self._desc_dev = self._static_desc
+            self._desc_dev = self._ring.stage(desc[lo:hi])                  # stream-ordered before the replay
         else:
             self._desc_dev = desc[lo:hi].contiguous()
         self._prepared = True

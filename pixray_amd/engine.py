@@ -51,8 +51,25 @@ class _GatherShards(torch.autograd.Function):
         return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None, None, None
 
 
-# custom losses that couple the whole cutout batch (class names; a loss can also set `needs_full_batch = True`)
-FULL_BATCH_LOSSES = {"SaturationLoss", "AestheticLoss", "ResmemLoss"}
+def needs_full_batch(loss) -> bool:
+    """A custom loss that couples the whole cutout batch (a statistic over all cutouts, a target sized by `num_cuts`, ...)
+    declares it with a class or instance attribute `needs_full_batch = True`.  Under cutout sharding
+    such a loss is scored on the all-gathered batch; every other loss is scored on the local shard with weight / world.
+    The reference's own batch-coupled plugins (`SaturationLoss`: std over all cutout pixels, Losses/SaturationLoss.py:19-28;
+    `AestheticLoss`: target sized by num_cuts, Losses/AestheticLoss.py:26; `ResmemLoss`) predate the attribute, so
+    `plugins.register_reference_loss` / `mark_full_batch` set it on those classes when they are loaded -- there is no
+    matching by class name at scoring time."""
+    return bool(getattr(loss, "needs_full_batch", False))
+
+
+# reference plugin classes that are batch-coupled but cannot declare it themselves (see needs_full_batch)
+REFERENCE_FULL_BATCH_LOSSES = ("SaturationLoss", "AestheticLoss", "ResmemLoss")
+
+
+def mark_full_batch(loss_or_class):
+    """Declare a (reference) loss class or instance batch-coupled; returns it.  Called when a plugin is REGISTERED."""
+    loss_or_class.needs_full_batch = True
+    return loss_or_class
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -68,8 +85,10 @@ class HipAdam(torch.optim.Optimizer):
         self._t = 0
         self._pending = False
         p = self.param_groups[0]["params"][0]
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if p.is_cuda else None
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=p.device)
+        from .cutouts import PinnedRing
+        self._ring = PinnedRing((4,), torch.float32, p.device) if p.is_cuda else None
+        self._hyper = self._ring.dev if self._ring is not None else torch.zeros(4, dtype=torch.float32, device=p.device)
+        self.clamped_last_step = False   # did the last step() apply the fused clip_z bounds?
 
     def prepare_step(self):
         """host side of the next step(): advance t and stage {lr/bc1, sqrt(bc2)} (stream-ordered H2D)"""
@@ -78,9 +97,8 @@ class HipAdam(torch.optim.Optimizer):
         b1, b2 = g["betas"]
         bc1 = 1.0 - b1 ** self._t
         bc2 = 1.0 - b2 ** self._t
-        self._hyper_host[0] = g["lr"] / bc1
-        self._hyper_host[1] = bc2 ** 0.5
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        # through a ring of pinned buffers: the host may be iterations ahead of the queued H2D copies
+        self._ring.stage(torch.tensor([g["lr"] / bc1, bc2 ** 0.5, 0.0, 0.0], dtype=torch.float32))
         self._pending = True
 
     @torch.no_grad()
@@ -89,6 +107,7 @@ class HipAdam(torch.optim.Optimizer):
         if not self._pending:
             self.prepare_step()
         self._pending = False
+        self.clamped_last_step = False
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -107,6 +126,7 @@ class HipAdam(torch.optim.Optimizer):
                 zmin, zmax = self.bounds if self.bounds is not None else (None, None)
                 ops.adam_clamp_step_dev(p, st["exp_avg"], st["exp_avg_sq"], p.grad.contiguous(), zmin, zmax, self._hyper,
                                         group["betas"], group["eps"])
+                self.clamped_last_step = zmin is not None
 
 
 class Session:
@@ -195,11 +215,14 @@ class Session:
                     raise ValueError(f"num_cuts {cutn} must be divisible by the number of GPUs {self.world_size}")
                 per = cutn // self.world_size
                 mk.shard = (self.rank * per, (self.rank + 1) * per)
-        for name, pms in self.pmsTable.items():
-            cutn = self.cutoutsTable[self.cutoutSizeTable[name]].cutn
-            for pm in pms:
-                if self.world_size > 1 and hasattr(pm, "denom"):
-                    pm.denom = float(cutn * pm.embed.shape[0])    # global mean denominator (pixray.py:280)
+        # every Prompt scored on a shard of the cutout batch takes its mean over the GLOBAL (cutn x n_embed) pairs
+        # (pixray.py:280): the main prompts and the spot / spot-off prompts alike
+        for table in (self.pmsTable, self.spotPmsTable, self.spotOffPmsTable):
+            for name, pms in table.items():
+                cutn = self.cutoutsTable[self.cutoutSizeTable[name]].cutn
+                for pm in pms:
+                    if self.world_size > 1 and hasattr(pm, "denom"):
+                        pm.denom = float(cutn * pm.embed.shape[0])
 
     def rebuild_optimisers(self):
         """pixray.py:520-555"""
@@ -208,6 +231,8 @@ class Session:
         if new_opts is None:
             lr = self.learning_rate / drop_divisor
             z = self.drawer.get_z()
+            if hasattr(self.drawer, "_fused_clamp"):
+                self.drawer._fused_clamp = False         # set again below only if THIS optimiser clamps in its kernel
             if self.optimiser_factory is not None:
                 new_opts = [self.optimiser_factory([z], lr)]
             elif z.is_cuda:
@@ -275,11 +300,12 @@ class Session:
                     iii_s = perceptor.encode_image(cuts[self.cutoutSizeTable[name]]).float()
                     for prompt in table[name]:
                         result.append(prompt(iii_s))
-            iii = perceptor.encode_image(cur_cutouts[self.cutoutSizeTable[name]]).float()     # pixray.py:1295
-            for prompt in self.pmsTable[name]:
-                result.append(prompt(iii))                                                     # pixray.py:1297-1299
-            # image prompts: throwaway Prompts from this iteration's cutouts of each target image (pixray.py:1307-1336)
+            # image-prompt targets (pixray.py:1307-1336) are encoded BEFORE the differentiable pass on the current cutouts: a
+            # perceptor handle keeps one forward's activations, so the last forward before backward() should be the one that
+            # is differentiated (ops._ClipEncodeFn re-runs a forward whose activations were replaced, so any order is correct;
+            # this one costs nothing).  The embeddings do not depend on the order.
             mk = self.cutoutsTable[self.cutoutSizeTable[name]]
+            target_embeds = []
             for timg in self.pmsImageTable.get(name, ()):
                 if self.image_prompt_shuffle:
                     mk.transforms = None
@@ -290,6 +316,12 @@ class Session:
                         parts = [torch.empty_like(embed) for _ in range(self.world_size)]
                         dist.all_gather(parts, embed.contiguous(), group=self.group)
                         embed = torch.cat(parts, 0)
+                target_embeds.append(embed)
+            iii = perceptor.encode_image(cur_cutouts[self.cutoutSizeTable[name]]).float()     # pixray.py:1295
+            for prompt in self.pmsTable[name]:
+                result.append(prompt(iii))                                                     # pixray.py:1297-1299
+            # image prompts: throwaway Prompts from this iteration's cutouts of each target image (pixray.py:1331-1336)
+            for embed in target_embeds:
                 w = self.image_prompt_weight if self.image_prompt_weight is not None else 1.0
                 pm = self.prompt_factory(embed, w).to(embed.device)
                 if self.world_size > 1 and hasattr(pm, "denom"):
@@ -319,13 +351,14 @@ class Session:
         needed_globals = {"cur_iteration": it, "embeds": iii}                                  # pixray.py:1377-1381
         t_w = getattr(self.args, "transparent_weight", 0.0)
         if img_alpha is not None and t_w != 0:                                                 # pixray.py:1383-1386
-            result.append((t_w / self.world_size if self.world_size > 1 else t_w) * torch.mean(img_alpha))
+            # replicated term: `img_alpha` is read off the drawer output BEFORE the composite, so its gradient does not pass
+            # through the all-reduce hook on `out` -- every rank holds the whole term, like the z regularisers above
+            result.append(t_w * torch.mean(img_alpha))
         full_cutouts = full_globals = None
         for t in self.custom_losses:
             w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]
             cuts, glb = cur_cutouts, needed_globals
-            if self.world_size > 1 and (getattr(t["loss"], "needs_full_batch", False)
-                                        or type(t["loss"]).__name__ in FULL_BATCH_LOSSES):
+            if self.world_size > 1 and needs_full_batch(t["loss"]):
                 # batch-coupled loss: every rank scores the FULL cutout batch (gathered, differentiable through the rank's
                 # own shard only), so its weight is not divided by the world size.  Such a loss must not also read `out`.
                 if full_cutouts is None:
@@ -366,7 +399,23 @@ class Session:
             self.last_losses = lossAll
         for opt in self.opts:
             opt.step()
+        self._clip_z()
+
+    def _clip_z(self):
+        """drawer.clip_z() (pixray.py:1487); a drawer with a fused Adam+clamp kernel skips its own clamp only when every
+        optimiser reports that it did clamp in this step"""
+        if hasattr(self.drawer, "_fused_clamp"):
+            self.drawer._fused_clamp = bool(self.opts) and all(getattr(o, "clamped_last_step", False) for o in self.opts)
         self.drawer.clip_z()
+
+    def _drop_graph(self):
+        """back to eager launches: the next ascend_txt() must make its own host draws"""
+        self._graph = None
+        self._staged_for_replay = False
+        self._host_ready = False
+        for mk in self.cutoutsTable.values():
+            if hasattr(mk, "_prepared"):
+                mk._prepared = False
 
     # ------------------------------------------------------------------ hipGraph capture
     def enable_graph(self, warmup: int = 3):
@@ -390,22 +439,25 @@ class Session:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._host_prep(self.cur_iteration)
-                for o in self.opts:
-                    o.prepare_step()
-                self._device_step()
-                self.cur_iteration += 1
+                # ordinary train() calls (eager: no graph yet), so learning-rate drops, the overlay schedule and the
+                # iteration limit are honoured during the warm-up exactly as without a graph
+                if not self.train():
+                    break
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if self.cur_iteration >= self.iterations or self.cur_iteration in self.learning_rate_drops or \
+                self.apply_overlay(self.cur_iteration) or not all(isinstance(o, HipAdam) for o in self.opts):
+            return False                 # the next iteration is not a plain one: stay eager (call enable_graph again later)
         self._host_prep(self.cur_iteration)
         for o in self.opts:
             o.prepare_step()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._device_step()
-        self.cur_iteration += 1          # the capture pass does not execute; account for the prepared iteration below
+        # the capture pass does not execute: its staged inputs (cutout descriptors, Adam scalars) are consumed by the first
+        # replay, i.e. by the next train() call, which therefore must not draw again
         self._graph = graph
-        graph.replay()                   # run the iteration whose inputs were staged for the capture
+        self._staged_for_replay = True
         return True
 
     def apply_overlay(self, cur_it: int) -> bool:
@@ -439,10 +491,17 @@ class Session:
             if cur_it in self.learning_rate_drops:
                 rebuild = True
             if self._graph is not None:
-                self._host_prep(cur_it)
-                for opt in self.opts:
-                    opt.prepare_step()
+                if getattr(self, "_staged_for_replay", False):
+                    self._staged_for_replay = False     # inputs staged by enable_graph for the captured iteration
+                else:
+                    self._host_prep(cur_it)
+                    for opt in self.opts:
+                        opt.prepare_step()
                 self._graph.replay()
+                self._host_ready = False            # consumed by the replay (ascend_txt does not run during a replay)
+                for mk in self.cutoutsTable.values():
+                    if hasattr(mk, "_prepared"):
+                        mk._prepared = False
                 for opt in self.opts:               # keep the Python-side step count in sync with the replayed kernels
                     for st in opt.state.values():
                         st["step"] = opt._t
@@ -458,7 +517,7 @@ class Session:
                     self.last_losses = lossAll
                 for opt in self.opts:
                     opt.step()
-                self.drawer.clip_z()
+                self._clip_z()
             else:
                 self._device_step()
         if cur_it == self.iterations:
@@ -470,7 +529,7 @@ class Session:
             self.best_iter = cur_it
             self.best_loss = None
             self.opts = self.rebuild_optimisers()
-            self._graph = None               # captured kernels reference the old optimiser state: back to eager
+            self._drop_graph()               # captured kernels reference the old optimiser state: back to eager
         self.cur_iteration = cur_it + 1
         return True
 

@@ -13,7 +13,7 @@ from typing import Sequence
 import torch
 
 from . import _lib
-from ._lib import PrxError, call
+from ._lib import PrxError, call, precision_code
 
 
 def _need_cuda(*ts):
@@ -84,14 +84,16 @@ def make_cutouts(img, desc, noise, S, base_hw=None, spot_mask=None):
 
 # --------------------------------------------------------------------------------------- CLIP ViT
 class ClipVitHandle:
-    """Owns a `prx_clip_vit` (packed bf16 weights + activation workspace for `max_batch` cutouts)."""
+    """Owns a `prx_clip_vit` (packed weights + activation workspace for `max_batch` cutouts).
+    `precision`: "bf16" (fast path) or "f32" (exact-f32 MFMA parity mode, include/prx.h PRX_PREC_*)."""
     abi = "prx_clip_vit"
 
-    def __init__(self, cfg, params, max_batch: int, device):
+    def __init__(self, cfg, params, max_batch: int, device, precision="bf16"):
         from .weights import clip_vit_param_shapes
         names = list(clip_vit_param_shapes(cfg).keys())
         ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
-        c = _ClipCfg(cfg.input_resolution, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch)
+        self.precision = precision_code(precision)
+        c = _ClipCfg(cfg.input_resolution, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch, self.precision)
         h = ctypes.c_void_p()
         call("prx_clip_vit_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
         torch.cuda.synchronize(device)   # weight tensors may now be released
@@ -99,6 +101,11 @@ class ClipVitHandle:
         self.cfg = cfg
         self.max_batch = max_batch
         self.device = device
+        self.generation = 0              # bumped by every forward: the handle keeps ONE forward's activations (_ClipEncodeFn)
+
+    @property
+    def gemm_ctx(self):
+        return _lib.load().prx_clip_vit_gemm_ctx(self.h)
 
     def __del__(self):
         h = getattr(self, "h", None)
@@ -117,7 +124,7 @@ def _keep(obj, arr):
 
 class _ClipResNetCfg(ctypes.Structure):
     _fields_ = [("input_resolution", ctypes.c_int), ("width", ctypes.c_int), ("layers", ctypes.c_int * 4), ("heads", ctypes.c_int),
-                ("output_dim", ctypes.c_int), ("max_batch", ctypes.c_int)]
+                ("output_dim", ctypes.c_int), ("max_batch", ctypes.c_int), ("precision", ctypes.c_int)]
 
 
 class ClipResNetHandle:
@@ -125,12 +132,14 @@ class ClipResNetHandle:
     the OpenAI `visual.*` state dict (BatchNorm un-folded); the fold happens here."""
     abi = "prx_clip_resnet"
 
-    def __init__(self, cfg, params, max_batch: int, device):
+    def __init__(self, cfg, params, max_batch: int, device, precision="bf16"):
         from .weights import fold_clip_resnet_params
         folded = fold_clip_resnet_params(cfg, params)
         ws = [t.to(device=device, dtype=torch.float32).contiguous() for t in folded.values()]
+        self.precision = precision_code(precision)
         c = _ClipResNetCfg()
         c.input_resolution, c.width, c.heads, c.output_dim, c.max_batch = cfg.input_resolution, cfg.width, cfg.heads, cfg.output_dim, max_batch
+        c.precision = self.precision
         for i, l in enumerate(cfg.layers):
             c.layers[i] = l
         h = ctypes.c_void_p()
@@ -140,6 +149,11 @@ class ClipResNetHandle:
         self.cfg = cfg
         self.max_batch = max_batch
         self.device = device
+        self.generation = 0
+
+    @property
+    def gemm_ctx(self):
+        return _lib.load().prx_clip_resnet_gemm_ctx(self.h)
 
     def __del__(self):
         h = getattr(self, "h", None)
@@ -153,17 +167,25 @@ class ClipResNetHandle:
 
 class _ClipCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("input_resolution", "patch_size", "width", "layers", "heads",
-                                            "output_dim", "max_batch")]
+                                            "output_dim", "max_batch", "precision")]
 
 
 class _VqganCfg(ctypes.Structure):
     _fields_ = [("ch", ctypes.c_int), ("ch_mult", ctypes.c_int * 8), ("n_mult", ctypes.c_int),
                 ("num_res_blocks", ctypes.c_int), ("attn_resolution", ctypes.c_int), ("resolution", ctypes.c_int),
                 ("z_channels", ctypes.c_int), ("embed_dim", ctypes.c_int), ("n_embed", ctypes.c_int),
-                ("out_ch", ctypes.c_int), ("latent_h", ctypes.c_int), ("latent_w", ctypes.c_int)]
+                ("out_ch", ctypes.c_int), ("latent_h", ctypes.c_int), ("latent_w", ctypes.c_int), ("precision", ctypes.c_int)]
 
 
 class _ClipEncodeFn(torch.autograd.Function):
+    """perceptor.encode_image (slip.py:62-66) on a tower handle.
+
+    The handle holds the activations of ONE forward (288 GB make "keep everything" cheap, but per forward).  pixray calls
+    encode_image several times per iteration on the same perceptor (spot prompts pixray.py:1282-1292, image prompts
+    1307-1336) before a single backward, so every forward bumps `handle.generation`, and a backward whose generation is
+    no longer the handle's re-runs its forward (same cutouts, same min/max -> bit-identical activations) before it
+    differentiates.  Nothing is ever differentiated through another call's activations."""
+
     @staticmethod
     def forward(ctx, cutouts, handle, group):
         _need_cuda(cutouts)
@@ -182,6 +204,8 @@ class _ClipEncodeFn(torch.autograd.Function):
             mm[0].neg_()
         emb = torch.empty(n, handle.cfg.output_dim, device=dev)
         call(handle.abi + "_encode", handle.h, cutouts, n, mm, emb, _stream())
+        handle.generation += 1
+        ctx.generation = handle.generation
         ctx.save_for_backward(cutouts, mm)
         ctx.handle = handle
         ctx.group = group
@@ -193,6 +217,12 @@ class _ClipEncodeFn(torch.autograd.Function):
         handle = ctx.handle
         g = g.contiguous().float()
         dev = g.device
+        if handle.generation != ctx.generation:
+            # another forward ran on this handle since ours: restore our activations (deterministic kernels, same inputs)
+            scratch = torch.empty(cutouts.shape[0], handle.cfg.output_dim, device=dev)
+            call(handle.abi + "_encode", handle.h, cutouts, cutouts.shape[0], mm, scratch, _stream())
+            handle.generation += 1
+            ctx.generation = handle.generation
         acc = torch.empty(4, device=dev, dtype=torch.float64)
         call(handle.abi + "_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
         if ctx.group is not None:
@@ -257,7 +287,9 @@ def clip_encode_text_tokens(tokens, handle: ClipTextHandle):
 
 # --------------------------------------------------------------------------------------- VQGAN
 class VqganHandle:
-    def __init__(self, cfg, params, latent_hw, device):
+    """Owns a `prx_vqgan` (codebook, weight packs, activations of one forward).  `precision`: "bf16" | "f32"."""
+
+    def __init__(self, cfg, params, latent_hw, device, precision="bf16"):
         from .weights import vqgan_param_shapes
         names = list(vqgan_param_shapes(cfg).keys())
         ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
@@ -274,6 +306,8 @@ class VqganHandle:
         c.n_embed = cfg.n_embed
         c.out_ch = cfg.out_ch
         c.latent_h, c.latent_w = latent_hw
+        self.precision = precision_code(precision)
+        c.precision = self.precision
         h = ctypes.c_void_p()
         call("prx_vqgan_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
         torch.cuda.synchronize(device)
@@ -283,6 +317,11 @@ class VqganHandle:
         self.f = 2 ** (len(cfg.ch_mult) - 1)
         self.device = device
         self.last_indices = None
+        self.generation = 0              # see _ClipEncodeFn: one forward's activations per handle
+
+    @property
+    def gemm_ctx(self):
+        return _lib.load().prx_vqgan_gemm_ctx(self.h)
 
     def z_bounds(self):
         zmin = torch.empty(self.cfg.embed_dim, device=self.device)
@@ -301,6 +340,10 @@ class VqganHandle:
 
 
 class _VqganSynthFn(torch.autograd.Function):
+    """VqganDrawer.synth (vqgan.py:190-195).  Same one-forward-per-handle rule as `_ClipEncodeFn`: a `to_image()` or a
+    second `synth()` between this forward and its backward bumps the handle's generation, and the backward then re-runs
+    the forward from the saved z before differentiating."""
+
     @staticmethod
     def forward(ctx, z, handle, quantize):
         _need_cuda(z)
@@ -312,14 +355,24 @@ class _VqganSynthFn(torch.autograd.Function):
         idx = torch.empty(hh * ww, device=dev, dtype=torch.int32)
         call("prx_vqgan_synth", handle.h, z, img, idx, int(quantize), _stream())
         handle.last_indices = idx
+        handle.generation += 1
+        ctx.generation = handle.generation
         ctx.handle = handle
+        ctx.quantize = int(quantize)
+        ctx.save_for_backward(z)
         return img
 
     @staticmethod
     def backward(ctx, g):
         handle = ctx.handle
+        (z,) = ctx.saved_tensors
         g = g.contiguous().float()
         hh, ww = handle.latent_hw
+        if handle.generation != ctx.generation:
+            scratch = torch.empty(1, handle.cfg.out_ch, hh * handle.f, ww * handle.f, device=g.device)
+            call("prx_vqgan_synth", handle.h, z, scratch, None, ctx.quantize, _stream())
+            handle.generation += 1
+            ctx.generation = handle.generation
         dz = torch.empty(1, handle.cfg.z_channels, hh, ww, device=g.device)
         call("prx_vqgan_synth_backward", handle.h, g, dz, _stream())
         return dz, None, None
@@ -441,17 +494,23 @@ class Vgg16Handle:
     """Owns a `prx_vgg16` (torchvision VGG16 `features` up to relu5_3, frozen) for inputs up to `max_hw`.
     `params`: {"features.N.weight", "features.N.bias"} (torchvision state-dict names)."""
 
-    def __init__(self, params, max_hw, device):
+    def __init__(self, params, max_hw, device, precision="bf16"):
+        self.precision = precision_code(precision)
         ws = []
         for i in VGG16_CONV_INDICES:
             ws.append(params[f"features.{i}.weight"].to(device=device, dtype=torch.float32).contiguous())
             ws.append(params[f"features.{i}.bias"].to(device=device, dtype=torch.float32).contiguous())
         h = ctypes.c_void_p()
-        call("prx_vgg16_create", ctypes.addressof(h), _keep(self, _weight_array(ws)), len(ws), int(max_hw[0]), int(max_hw[1]), _stream())
+        call("prx_vgg16_create", ctypes.addressof(h), _keep(self, _weight_array(ws)), len(ws), int(max_hw[0]), int(max_hw[1]),
+             self.precision, _stream())
         torch.cuda.synchronize(device)
         self.h = h
         self.max_hw = (int(max_hw[0]), int(max_hw[1]))
         self.device = device
+
+    @property
+    def gemm_ctx(self):
+        return _lib.load().prx_vgg16_gemm_ctx(self.h)
 
     def feature_shape(self, H, W, k):
         h, w, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -475,7 +534,7 @@ class _Vgg16Fn(torch.autograd.Function):
         assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3, "the VGG16 extractor takes one [1,3,H,W] image"
         H, W = int(x.shape[2]), int(x.shape[3])
         x = x.detach().to(torch.float32).contiguous()
-        nbytes = call("prx_vgg16_workspace_bytes", H, W)
+        nbytes = call("prx_vgg16_workspace_bytes", H, W, handle.precision)
         if nbytes <= 0:
             raise PrxError(f"VGG16 extractor: input {H}x{W} is too small")
         work = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)

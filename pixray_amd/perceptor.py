@@ -11,7 +11,7 @@ from .weights import (CLIP_CONFIGS, CLIP_RESNET_CONFIGS, CLIP_TEXT_CONFIGS, Clip
 
 class ClipVitPerceptor:
     def __init__(self, cfg: ClipVitConfig, params, device, max_batch: int = 64, group=None, text_cfg: ClipTextConfig = None,
-                 text_params=None, tokenizer=None, seed: int = 0):
+                 text_params=None, tokenizer=None, seed: int = 0, precision="bf16"):
         self.cfg = cfg
         self.text_cfg = text_cfg
         self.text_params = text_params      # OpenAI state-dict entries of the text side (token_embedding.weight, ...)
@@ -23,9 +23,9 @@ class ClipVitPerceptor:
         self.output_dim = cfg.output_dim
         self.group = group          # torch.distributed group when the cutout batch is sharded
         if isinstance(cfg, ClipResNetConfig):       # ModifiedResNet family (RN50x4, ...): same protocol, different runner
-            self.handle = ops.ClipResNetHandle(cfg, params, max_batch, self.device)
+            self.handle = ops.ClipResNetHandle(cfg, params, max_batch, self.device, precision=precision)
         else:
-            self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device)
+            self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device, precision=precision)
 
     def preprocess(self, imgs, input_range=None):
         raise NotImplementedError("preprocessing (slip.py:21-42,58-60) is fused into encode_image on this path")
@@ -76,16 +76,16 @@ class ClipVitPerceptor:
 
 
 def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=0, group=None, text_params=None,
-                       tokenizer=None):
+                       tokenizer=None, precision="bf16"):
     """slip.py:173-186 equivalent for the ViT family; `params` is an OpenAI `visual.*` state dict and `text_params` the
     text-side entries of the same checkpoint (random-init weights of the real architectures are synthesised when none
-    are given: no checkpoints exist offline)."""
+    are given: no checkpoints exist offline).  `precision`: "bf16" (fast path) | "f32" (exact-f32 MFMA parity mode)."""
     if clip_model_name in CLIP_RESNET_CONFIGS:
         cfg = CLIP_RESNET_CONFIGS[clip_model_name]
         if params is None:
             params = synthetic_clip_resnet_params(cfg, seed)
         return ClipVitPerceptor(cfg, params, device, max_batch=max_batch, group=group, text_cfg=CLIP_TEXT_CONFIGS.get(clip_model_name),
-                                text_params=text_params, tokenizer=tokenizer, seed=seed)
+                                text_params=text_params, tokenizer=tokenizer, seed=seed, precision=precision)
     if clip_model_name not in CLIP_CONFIGS:
         raise KeyError(f"unknown / unsupported perceptor {clip_model_name!r} "
                        f"(supported: {sorted(CLIP_CONFIGS) + sorted(CLIP_RESNET_CONFIGS)})")
@@ -93,4 +93,4 @@ def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=
     if params is None:
         params = synthetic_clip_vit_params(cfg, seed)
     return ClipVitPerceptor(cfg, params, device, max_batch=max_batch, group=group, text_cfg=CLIP_TEXT_CONFIGS.get(clip_model_name),
-                            text_params=text_params, tokenizer=tokenizer, seed=seed)
+                            text_params=text_params, tokenizer=tokenizer, seed=seed, precision=precision)

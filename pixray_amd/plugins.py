@@ -68,9 +68,15 @@ def setup_filters(spec, args, device=None) -> List[dict]:
     return out
 
 
-def add_custom_loss(name: str, customloss: type) -> None:
-    """pixray.py:2104-2109"""
+def add_custom_loss(name: str, customloss: type, needs_full_batch: bool = None) -> None:
+    """pixray.py:2104-2109.  `needs_full_batch`: declare the class batch-coupled (engine.needs_full_batch) -- a loss written
+    for this package sets the class attribute itself; the reference's own batch-coupled plugins (SaturationLoss,
+    AestheticLoss, ResmemLoss) cannot, so they are marked HERE, at registration, by their reference class name."""
     assert issubclass(customloss, LossInterface)
+    from .engine import REFERENCE_FULL_BATCH_LOSSES, mark_full_batch
+    if needs_full_batch or (needs_full_batch is None and "needs_full_batch" not in vars(customloss)
+                            and customloss.__name__ in REFERENCE_FULL_BATCH_LOSSES):
+        mark_full_batch(customloss)
     loss_class_table.update({name: customloss})
 
 

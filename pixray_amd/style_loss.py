@@ -35,8 +35,9 @@ class Vgg16Extractor:
     """`Vgg16_Extractor` (StyleLoss.py:24-81): returns [input, relu1_1, relu1_2, relu2_1, relu2_2, relu3_1, relu3_2, relu3_3,
     relu4_3, relu5_3] as channels-last maps [1,h,w,C]."""
 
-    def __init__(self, space: str = "uniform", params=None, device=None, max_hw=(64, 64)):
+    def __init__(self, space: str = "uniform", params=None, device=None, max_hw=(64, 64), precision="bf16"):
         self.space = space
+        self.precision = precision      # "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         if params is None:
             path = os.environ.get("PIXRAY_VGG16_CKPT")
@@ -55,7 +56,7 @@ class Vgg16Extractor:
         if self.handle is None or H > self.max_hw[0] or W > self.max_hw[1]:
             from . import ops
             self.max_hw = (max(H, self.max_hw[0]), max(W, self.max_hw[1]))
-            self.handle = ops.Vgg16Handle(self.params, self.max_hw, self.device)
+            self.handle = ops.Vgg16Handle(self.params, self.max_hw, self.device, precision=self.precision)
 
     def normalise(self, x):
         """StyleLoss.py:41-45"""

@@ -31,6 +31,7 @@ class VqganDrawer(DrawingInterface):
         self.size = tuple(getattr(settings, "size", (256, 256)))          # (width, height) as in the reference
         self.state_dict = getattr(settings, "vqgan_state_dict", None)     # taming state dict, if the caller has one
         self.weight_seed = getattr(settings, "weight_seed", 0)
+        self.precision = getattr(settings, "precision", "bf16")           # "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.z = None
         self._fused_clamp = False
 
@@ -46,7 +47,7 @@ class VqganDrawer(DrawingInterface):
             raise ValueError(f"size {self.size} must be a multiple of {f} (pixray.py:621-626 rounds it for you)")
         self.latent_hw = (h // f, w // f)
         self._params = params
-        self.handle = ops.VqganHandle(self.cfg, params, self.latent_hw, self.device)
+        self.handle = ops.VqganHandle(self.cfg, params, self.latent_hw, self.device, precision=self.precision)
         self.e_dim = self.cfg.embed_dim
         self.n_toks = self.cfg.n_embed
         zmin, zmax = self.handle.z_bounds()                                # vqgan.py:155-158

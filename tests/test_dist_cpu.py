@@ -44,7 +44,9 @@ def _free_port():
 
 class SaturationLoss:
     """same arithmetic as the reference plugin of that name (Losses/SaturationLoss.py:15-30): a colourfulness score from
-    std / mean over ALL cutout pixels -- batch-coupled, so sharded runs must gather the batch for it"""
+    std / mean over ALL cutout pixels -- batch-coupled, so sharded runs must gather the batch for it.  It says so with the
+    documented plugin attribute (engine.needs_full_batch); class names are not consulted."""
+    needs_full_batch = True
 
     def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
         res = []
@@ -73,6 +75,19 @@ class GlobalMeanPrompt(torch.nn.Module):
         return full * (x.shape[0] * self.embed.shape[0]) / self.denom                        # rescale to the global mean
 
 
+def _rgba_drawer_class():
+    from pixray_amd.pixel_grid_drawer import PixelGridDrawer
+
+    class RgbaGridDrawer(PixelGridDrawer):
+        """an RGBA drawer (pixray.py:1225-1241): the colours of the pixel grid plus an alpha channel derived from z"""
+
+        def synth(self, cur_iteration):
+            rgb = super().synth(cur_iteration)
+            alpha = torch.sigmoid(4.0 * (rgb.mean(dim=1, keepdim=True) - 0.5))
+            return torch.cat([rgb, alpha], dim=1)
+    return RgbaGridDrawer
+
+
 def _build(cutn, world, rank, group, coupled_loss=False, extras=False):
     from oracle import prompt_ref, step_ref
     from pixray_amd import cutouts as pc, weights
@@ -81,7 +96,7 @@ def _build(cutn, world, rank, group, coupled_loss=False, extras=False):
     cfg = weights.CLIP_CONFIGS["tiny-B/32"]
     params = weights.synthetic_clip_vit_params(cfg, 1)
     st = types.SimpleNamespace(size=(96, 96), pixel_size=(12, 12), pixel_scale=None)
-    drawer = PixelGridDrawer(st)
+    drawer = (_rgba_drawer_class() if extras == "spot_rgba" else PixelGridDrawer)(st)
     drawer.load_model(st, "cpu")
     g = torch.Generator().manual_seed(7)
     drawer.init_from_tensor(torch.rand(1, 3, 96, 96, generator=g) * 2.6 - 1.3)     # some pixels start out of range
@@ -99,7 +114,17 @@ def _build(cutn, world, rank, group, coupled_loss=False, extras=False):
 
     custom = [{"loss": SaturationLoss(), "weight": 3.0}] if coupled_loss else []
     kw = {}
-    if extras:      # image prompt (cached transforms, embeddings all-gathered) + the z / pixel regularisers of pixray.py:1344-1375
+    if extras == "spot_rgba":
+        # spot / spot-off prompts (pixray.py:1270-1292) on an RGBA drawer with the transparency term (1383-1386): the spot
+        # tables take the GLOBAL mean denominator under sharding, and the alpha term is a replicated (undivided) one
+        inside = torch.zeros(3, 224, 224, dtype=torch.bool)
+        inside[:, 60:170, 40:150] = True
+        mk.spot_masks = (inside, ~inside)
+        e2 = torch.randn(1, cfg.output_dim, generator=g)
+        e3 = torch.randn(2, cfg.output_dim, generator=g)
+        kw = dict(spot_prompts={"tiny-B/32": [GlobalMeanPrompt(e2, 0.8)]}, spot_prompts_off={"tiny-B/32": [GlobalMeanPrompt(e3, 0.6)]},
+                  args=types.SimpleNamespace(transparent=True, transparent_weight=0.35))
+    elif extras:    # image prompt (cached transforms, embeddings all-gathered) + the z / pixel regularisers of pixray.py:1344-1375
         target = torch.rand(1, 3, 96, 96, generator=g)
         init = torch.rand(1, 3, 96, 96, generator=g)
         kw = dict(image_prompts={"tiny-B/32": [target]}, image_prompt_weight=0.7, z_orig=drawer.get_z_copy().detach() * 0.9,
@@ -197,6 +222,26 @@ def test_world2_image_prompts_and_regularisers_match_single_process():
     assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
     assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
     assert (z0 - z_ref).abs().max().item() < 1e-5
+
+
+def test_world2_spot_prompts_and_rgba_drawer_match_single_process():
+    """spot / spot-off prompts (three differentiable encode_image calls per iteration) and an RGBA drawer with the
+    transparency term on 2 ranks equal the single-process run: z, its gradient, and the summed loss"""
+    cutn, world = 4, 2
+    res = _run_world(world, cutn, False, "spot_rgba")
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None, False, "spot_rgba")
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    (_, z0, g0, l0), (_, z1, g1, l1) = res
+    z0, g0, z1, g1 = [torch.from_numpy(t) for t in (z0, g0, z1, g1)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (z0 - z_ref).abs().max().item() < 1e-5
+    # prompt shares add up; the transparency term is replicated (both ranks hold the whole term): counted once
+    alpha_ref = float(ref.last_losses[-1].detach())
+    assert abs((l0 + l1) - (float(sum(l.detach() for l in ref.last_losses)) + alpha_ref)) < 1e-5
 
 
 def test_cutn_must_divide_world_size():

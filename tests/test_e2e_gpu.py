@@ -212,9 +212,10 @@ def test_hipgraph_replay_matches_eager_launches():
     b = api.build_vqgan_clip_session(**kw)
     for mk in list(a.cutoutsTable.values()) + list(b.cutoutsTable.values()):
         mk.noise_fac = 0.0            # device randn streams differ between capture and eager; compare without noise
-    assert b.enable_graph(warmup=2)   # iterations 0,1 eagerly + iteration 2 from the graph
+    assert b.enable_graph(warmup=2)   # iterations 0,1 through train(); iteration 2 is staged and replayed by the next train()
     for it in range(3):
         a.train(it)
+    b.train(2)
     za, zb = a.drawer.get_z(), b.drawer.get_z()
     oa, ob = a.opts[0], b.opts[0]
     for it in range(3, 7):

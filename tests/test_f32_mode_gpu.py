@@ -1,0 +1,291 @@
+"""The exact-f32 MFMA parity mode (PRX_PREC_F32, include/prx.h; SURVEY.md §7 step 4, §8(d) parity gate).
+
+Every contraction of the path runs on v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain) with fp32 operands end to end,
+so the ONLY differences from the CPU oracle are summation order and the fast exp / rsqrt intrinsics of the fused
+epilogues: the gate is rel-L2 <= 1e-4 on dL/dz -- measured values are printed and recorded in
+DESIGN.md §4.  The bf16 fast path is then measured AGAINST this mode on the device (`compare_precisions`), which is
+where the bf16 tolerances of the other test files come from: they are the bf16-vs-f32 deltas plus margin, not guesses.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import clip_vit_ref, step_ref, vqgan_ref
+from pixray_amd import _lib, ops, weights
+from pixray_amd._lib import GemmArgs, call
+
+DEV = "cuda"
+F32_GATE = 1e-4          # the stated gate for the exact mode
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+
+def cosine(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+
+
+def stream():
+    return _lib.current_stream()
+
+
+def gemm_f32(A, Bt, M, N, K, *, a_mode=0, lda=None, H=0, W=0, Cin=0, up=0, bias_n=None, resid=None, aux=None, act=0,
+             want_op=False, want_pre=False):
+    g = GemmArgs()
+    g.f32 = 1
+    g.A = A.data_ptr(); g.a_mode = a_mode; g.lda = lda if lda is not None else A.shape[-1]
+    g.B = Bt.data_ptr(); g.ldb = Bt.shape[-1]
+    g.M, g.N, g.K = M, N, K
+    g.H, g.W, g.Cin, g.up = H, W, Cin, up
+    g.alpha = 1.0
+    g.bias_n = bias_n.data_ptr() if bias_n is not None else None
+    g.resid = resid.data_ptr() if resid is not None else None
+    g.ldr = N
+    g.aux = aux.data_ptr() if aux is not None else None
+    g.ldaux = N
+    g.act = act
+    out = torch.full((M, N), float("nan"), device=DEV)
+    op = torch.full((M, N), float("nan"), device=DEV) if want_op else None
+    pre = torch.full((M, N), float("nan"), device=DEV) if want_pre else None
+    g.out_f32 = out.data_ptr(); g.ldc_f32 = N
+    g.out_bf16 = op.data_ptr() if want_op else None
+    g.out_bf16_pre = pre.data_ptr() if want_pre else None
+    g.ldc_bf16 = N
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    call("prx_k_gemm", g, ws, ws.numel(), stream())
+    torch.cuda.synchronize()
+    return out, op, pre
+
+
+# ------------------------------------------------------------------------------------------ the engine in the exact mode
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (64, 64, 32), (3200, 768, 768), (1000, 200, 1096), (257, 136, 36),
+                                   (256, 512, 4608),      # split-K
+                                   (8, 512, 768)])
+def test_gemm_f32_rowmajor_matches_float64(M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV)
+    Bt = torch.randn(N, K, device=DEV) / math.sqrt(K)
+    bias = torch.randn(N, device=DEV)
+    resid = torch.randn(M, N, device=DEV)
+    out, op, _ = gemm_f32(A, Bt, M, N, K, bias_n=bias, resid=resid, want_op=True)
+    ref = A.double() @ Bt.double().T + bias.double() + resid.double()
+    assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)          # fp32 round-off of a K-long fma chain
+    assert torch.equal(out, op)                                 # the operand copy is the same fp32 value
+
+
+def test_gemm_f32_is_an_fmaf_chain():
+    """the f32 MFMA keeps full fp32 operands: a product that bf16 (8 mantissa bits) would destroy comes out exact"""
+    M = N = 64; K = 32
+    A = torch.zeros(M, K, device=DEV); Bt = torch.zeros(N, K, device=DEV)
+    A[:, 0] = 1.0 + 2.0 ** -20; Bt[:, 0] = 1.0 + 2.0 ** -20         # representable in fp32, not in bf16
+    A[:, 1] = 3.0; Bt[:, 1] = -1.0 / 3.0
+    out, _, _ = gemm_f32(A, Bt, M, N, K)
+    exp = torch.tensor((1.0 + 2.0 ** -20), dtype=torch.float32)
+    exp = torch.addcmul(torch.tensor(0.0), exp, exp) + torch.tensor(3.0) * torch.tensor(-1.0 / 3.0)
+    assert (out - exp.item()).abs().max().item() < 1e-7
+    assert (out - 0.0).abs().min().item() > 1e-7                    # bf16 operands would give exactly 1 - 1 = 0 here
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [(16, 16, 256, 512, 0, 1), (32, 32, 64, 128, 1, 1), (24, 40, 12, 72, 0, 2),
+                                                (64, 64, 8, 128, 0, 1), (16, 20, 64, 64, 2, 1)])
+def test_gemm_f32_conv3x3_matches_float64(H, W, Cin, Cout, up, NB):
+    """implicit 3x3 conv: plain, through the fused nearest-2x upsample (up=1), and taming's stride-2 Downsample (up=2)"""
+    torch.manual_seed(H * W + Cin + up)
+    hin, win = {0: (H, W), 1: (H // 2, W // 2), 2: (2 * H, 2 * W)}[up]
+    x = torch.randn(NB, Cin, hin, win, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, device=DEV)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    out, _, _ = gemm_f32(x_nhwc, w_pack, NB * H * W, Cout, 9 * Cin, a_mode=1, lda=Cin, H=H, W=W, Cin=Cin, up=up, bias_n=bias)
+    xr = x.double()
+    if up == 1:
+        ref = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), w.double(), bias.double(), padding=1)
+    elif up == 2:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.double(), bias.double(), stride=2)
+    else:
+        ref = F.conv2d(xr, w.double(), bias.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
+    assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
+
+
+def test_gemm_f32_activation_epilogues():
+    torch.manual_seed(3)
+    M, N, K = 300, 256, 128
+    A = torch.randn(M, K, device=DEV); Bt = torch.randn(N, K, device=DEV) / math.sqrt(K)
+    out, op, pre = gemm_f32(A, Bt, M, N, K, act=1, want_op=True, want_pre=True)             # QuickGELU
+    t = A.double() @ Bt.double().T
+    assert rel_l2(pre, t) < 2e-6 and rel_l2(out, t * torch.sigmoid(1.702 * t)) < 2e-6 and torch.equal(out, op)
+    out2, _, _ = gemm_f32(A, Bt, M, N, K, act=2, aux=pre)                                    # * QuickGELU'(aux)
+    s = torch.sigmoid(1.702 * t)
+    assert rel_l2(out2, t * (s * (1 + 1.702 * t * (1 - s)))) < 3e-6
+    out3, _, _ = gemm_f32(A, Bt, M, N, K, act=3)                                             # ReLU
+    assert rel_l2(out3, t.clamp_min(0)) < 2e-6
+    out4, _, _ = gemm_f32(A, Bt, M, N, K, act=4, aux=out3)                                   # * [aux > 0]
+    assert rel_l2(out4, t * (t > 0)) < 2e-6
+
+
+@pytest.mark.parametrize("N,T,heads", [(3, 50, 4), (2, 197, 2), (2, 257, 3), (1, 64, 1)])
+def test_mha_f32_matches_float64(N, T, heads):
+    C = heads * 64
+    torch.manual_seed(T)
+    qkv = torch.randn(N * T, 3 * C, device=DEV)
+    dout = torch.randn(N * T, C, device=DEV)
+    out = torch.empty(N * T, C, device=DEV)
+    lse = torch.empty(N * heads * T, device=DEV)
+    dqkv = torch.full((N * T, 3 * C), float("nan"), device=DEV)
+    call("prx_k_mha_fwd_f32", qkv, out, lse, N, T, C, heads, stream())
+    call("prx_k_mha_bwd_f32", qkv, out, dout, lse, dqkv, N, T, C, heads, stream())
+    x = qkv.double().cpu().requires_grad_(True)
+    q, k, v = [t_.reshape(N, T, heads, 64).transpose(1, 2) for t_ in x.reshape(N, T, 3 * C).split(C, dim=-1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(N * T, C)
+    (gref,) = torch.autograd.grad(ref, x, dout.double().cpu())
+    assert rel_l2(out, ref) < 2e-6, rel_l2(out, ref)
+    assert rel_l2(dqkv, gref) < 5e-6, rel_l2(dqkv, gref)
+
+
+# ------------------------------------------------------------------------------------------ towers in the exact mode
+weights.CLIP_CONFIGS.setdefault("test-B/16", weights.ClipVitConfig("test-B/16", 224, 16, 256, 2, 4, 128))   # 197 tokens
+weights.CLIP_CONFIGS.setdefault("test-L/14", weights.ClipVitConfig("test-L/14", 224, 14, 256, 2, 4, 128))   # 257 tokens, K=588
+
+
+def _clip_case(name, n, seed, precision):
+    cfg = weights.CLIP_CONFIGS[name]
+    params = weights.synthetic_clip_vit_params(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    cut = torch.rand(n, 3, cfg.input_resolution, cfg.input_resolution, generator=g) * 1.2 - 0.1
+    gout = torch.randn(n, cfg.output_dim, generator=g)
+    cr = cut.clone().requires_grad_(True)
+    ref = clip_vit_ref.encode_image(params, cr, patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers)
+    (gref,) = torch.autograd.grad(ref, cr, gout)
+    h = ops.ClipVitHandle(cfg, params, max_batch=n, device=DEV, precision=precision)
+    cd = cut.to(DEV).requires_grad_(True)
+    out = ops.clip_encode_image(cd, h)
+    (gd,) = torch.autograd.grad(out, cd, gout.to(DEV))
+    return ref, out, gref, gd
+
+
+@pytest.mark.parametrize("name,n", [("tiny-B/32", 4), ("ViT-B/32", 8), ("test-B/16", 3), ("test-L/14", 2)])
+def test_clip_vit_f32_vs_oracle(name, n):
+    ref, out, gref, gd = _clip_case(name, n, 5, "f32")
+    print(f"[f32] {name}: embeds rel {rel_l2(out, ref):.2e}  d/dcutouts rel {rel_l2(gd, gref):.2e} cos {cosine(gd, gref):.8f}")
+    assert rel_l2(out, ref) < F32_GATE, rel_l2(out, ref)
+    assert rel_l2(gd, gref) < F32_GATE, rel_l2(gd, gref)
+
+
+def _vqgan_case(name, hw, seed, precision):
+    cfg = weights.VQGAN_CONFIGS[name]
+    params = weights.synthetic_vqgan_params(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    hh, ww = (hw, hw) if isinstance(hw, int) else hw
+    z = torch.randn(1, cfg.z_channels, hh, ww, generator=g)
+    f = 2 ** (len(cfg.ch_mult) - 1)
+    gimg = torch.randn(1, 3, hh * f, ww * f, generator=g)
+    zr = z.clone().requires_grad_(True)
+    ref = vqgan_ref.synth(params, zr, cfg.oracle_cfg())
+    (gref,) = torch.autograd.grad(ref, zr, gimg)
+    h = ops.VqganHandle(cfg, params, (hh, ww), DEV, precision=precision)
+    zd = z.to(DEV).requires_grad_(True)
+    out = ops.vqgan_synth(zd, h)
+    (gd,) = torch.autograd.grad(out, zd, gimg.to(DEV))
+    idx_ref, _ = vqgan_ref.vq_indices(z.movedim(1, 3).reshape(hh * ww, -1), params["quantize.embedding.weight"])
+    return ref, out, gref, gd, idx_ref, h.last_indices.cpu().long()
+
+
+@pytest.mark.parametrize("name,hw", [("tiny_f4", 16), ("imagenet_f16_16384", 16), ("tiny_f4", (12, 20)),
+                                     ("imagenet_f16_16384", (14, 25))])
+def test_vqgan_synth_f32_vs_oracle(name, hw):
+    ref, out, gref, gd, idx_ref, idx = _vqgan_case(name, hw, 9, "f32")
+    assert torch.equal(idx, idx_ref), "VQ code selection differs"
+    print(f"[f32] {name} {hw}: image rel {rel_l2(out, ref):.2e}  dz rel {rel_l2(gd, gref):.2e} cos {cosine(gd, gref):.8f}")
+    assert rel_l2(out, ref) < F32_GATE, rel_l2(out, ref)
+    assert rel_l2(gd, gref) < F32_GATE, rel_l2(gd, gref)
+
+
+@pytest.mark.parametrize("name,n", [("tiny-RN", 3), ("RN50x4", 2)])
+def test_clip_resnet_f32_vs_oracle(name, n):
+    """the RN50x4 tower of BASELINE.json configs[2] through the exact mode: the 0.11 rel-L2 of the bf16 path on
+    d/dcutouts (ReLU masks flipped by bf16 roundings through ~80 layers) is bf16 noise iff this passes the f32 gate"""
+    from oracle import clip_resnet_ref
+    cfg = weights.CLIP_RESNET_CONFIGS[name]
+    p = weights.synthetic_clip_resnet_params(cfg, seed=3)
+    h = ops.ClipResNetHandle(cfg, p, max_batch=4, device=DEV, precision="f32")
+    g = torch.Generator().manual_seed(17)
+    R = cfg.input_resolution
+    low = torch.rand(n, 3, R // 8, R // 8, generator=g)
+    cut = (F.interpolate(low, size=(R, R), mode="bilinear", align_corners=False) + 0.05 * torch.randn(n, 3, R, R, generator=g))
+    ge = torch.randn(n, cfg.output_dim, generator=g)
+    cr = cut.clone().requires_grad_(True)
+    ref = clip_resnet_ref.encode_image(p, cr, layers=cfg.layers, heads=cfg.heads)
+    (gref,) = torch.autograd.grad(ref, cr, ge)
+    cd = cut.to(DEV).requires_grad_(True)
+    emb = ops.clip_encode_image(cd, h)
+    (gd,) = torch.autograd.grad(emb, cd, ge.to(DEV))
+    print(f"[f32] {name}: embeds rel {rel_l2(emb, ref):.2e}  d/dcutouts rel {rel_l2(gd, gref):.2e} cos {cosine(gd, gref):.8f}")
+    assert rel_l2(emb, ref) < F32_GATE, rel_l2(emb, ref)
+    # a ReLU whose pre-activation sits within fp32 round-off of zero may still flip: allow for a handful of them
+    assert rel_l2(gd, gref) < 5 * F32_GATE, rel_l2(gd, gref)
+
+
+@pytest.mark.parametrize("H,W", [(64, 48), (50, 70)])
+def test_vgg16_f32_vs_oracle(H, W):
+    from oracle import vgg_ref
+    params = weights.synthetic_vgg16_params(0)
+    handle = ops.Vgg16Handle(params, (128, 128), torch.device(DEV), precision="f32")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(1, 3, H, W, generator=g) * 2 - 1)
+    xn = vgg_ref.normalise(x)
+    xo = xn.clone().requires_grad_(True)
+    ref = vgg_ref.forward_base(params, xo)[1:]
+    xd = xn.to(DEV).requires_grad_(True)
+    got = ops.vgg16_features(xd, handle)
+    rs = []
+    for k, (f, r) in enumerate(zip(got, ref)):
+        assert rel_l2(f.permute(0, 3, 1, 2), r) < F32_GATE, (k, rel_l2(f.permute(0, 3, 1, 2), r))
+        rs.append(torch.randn(r.shape, generator=g) / math.sqrt(r.numel()))
+    sum((r_ * f_).sum() for r_, f_ in zip(rs, ref)).backward()
+    sum((r_.permute(0, 2, 3, 1).to(DEV) * f_).sum() for r_, f_ in zip(rs, got)).backward()
+    print(f"[f32] vgg16 {H}x{W}: d/dx rel {rel_l2(xd.grad, xo.grad):.2e} cos {cosine(xd.grad, xo.grad):.8f}")
+    assert rel_l2(xd.grad, xo.grad) < 5 * F32_GATE, rel_l2(xd.grad, xo.grad)
+
+
+# ------------------------------------------------------------------------------------------ the whole iteration
+def test_headline_iteration_f32_vs_oracle():
+    """SURVEY.md §8(d) parity gate: dL/dz after one iteration of the headline config, exact mode, <= 1e-4 rel-L2"""
+    r = step_ref.compare_one_iteration(precision="f32")
+    print("[f32] headline:", r)
+    assert r["indices_equal"]
+    assert r["loss_abs_err"] < 1e-5
+    assert r["image_rel_l2"] < F32_GATE and r["embeds_rel_l2"] < F32_GATE
+    assert r["dz_rel_l2"] < F32_GATE and r["dz_cosine"] > 0.99999999, r
+
+
+@pytest.mark.parametrize("cfg", [dict(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0),
+                                 dict(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(112, 64), cutn=8, seed=3)],
+                         ids=["reduced", "widescreen"])
+def test_small_configs_f32_vs_oracle(cfg):
+    """the reduced (smoke) and widescreen configurations whose bf16 dL/dz sits at 6e-2 / 0.998: through the exact mode they
+    meet the same 1e-4 gate as the headline, so that deviation is bf16 operand rounding on a noisy loss surface"""
+    r = step_ref.compare_one_iteration(precision="f32", **cfg)
+    print("[f32]", cfg["size"], r)
+    assert r["indices_equal"] and r["loss_abs_err"] < 1e-5
+    assert r["dz_rel_l2"] < F32_GATE, r
+
+
+def test_bf16_path_against_the_f32_mode_on_device():
+    """what bf16 operands cost, measured against the product's own exact mode (no oracle): the stated bf16 gate of
+    BASELINE.md §3 (2e-2 / 0.999) at the headline config"""
+    r = step_ref.compare_precisions()
+    print("[bf16 vs f32] headline:", r)
+    assert r["indices_equal"]
+    assert r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r
+    small = step_ref.compare_precisions(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0)
+    print("[bf16 vs f32] reduced:", small)
+    assert small["dz_rel_l2"] < 8e-2 and small["dz_cosine"] > 0.997, small

@@ -22,9 +22,9 @@ def stream():
 @pytest.fixture(params=[1, 0], ids=["glds_v2", "regstage_v1"])
 def gemm_variant(request):
     """both GEMM kernels: direct-to-LDS (default) and register-staged"""
-    _lib.load().prx_gemm_variant(request.param)
+    _lib.load().prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, request.param)
     yield request.param
-    _lib.load().prx_gemm_variant(1)
+    _lib.load().prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, 1)
 
 
 def bf(x):
@@ -120,8 +120,8 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
     lib = _lib.load()
     torch.manual_seed(7)
     try:
-        lib.prx_gemm_tile_override(tile[0], tile[1], splits)
-        lib.prx_gemm_tile_override(-2, 0, stages)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], splits)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, stages)
         for (M, N, K) in [(3200, 768, 768), (1000, 200, 1096), (257, 136, 64)]:
             A = bf(torch.randn(M, K, device=DEV))
             Bt = bf(torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K))
@@ -146,8 +146,8 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
             ref = F.conv2d(xr, bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
             assert rel_l2(out, ref) < 2e-5, (H, W, Cin, Cout, up, rel_l2(out, ref))
     finally:
-        lib.prx_gemm_tile_override(0, 0, 0)
-        lib.prx_gemm_tile_override(-2, 0, 0)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
 @pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [

@@ -26,7 +26,7 @@ def gemm_once(M, N, K, conv=None, stats=False, tile=(0, 0, 0), stages=0):
     bias = torch.randn(N, device=DEV)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
     outs = []
-    lib.prx_gemm_tile_override(*tile); lib.prx_gemm_tile_override(-2, 0, stages)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), *tile); lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, stages)
     for rep in range(2):
         out = torch.full((M, N), float("nan"), device=DEV)
         st = torch.zeros(64, dtype=torch.float64, device=DEV)
@@ -40,7 +40,7 @@ def gemm_once(M, N, K, conv=None, stats=False, tile=(0, 0, 0), stages=0):
         call("prx_k_gemm", g, ws, ws.numel(), s())
         torch.cuda.synchronize()
         outs.append((out, st))
-    lib.prx_gemm_tile_override(0, 0, 0); lib.prx_gemm_tile_override(-2, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0); lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
     return outs
 
 for (H, C, Co, up) in [(16, 512, 512, 0), (32, 512, 256, 1), (64, 256, 256, 0), (128, 128, 128, 0), (256, 128, 128, 1)]:

@@ -26,7 +26,7 @@ def bench(M, N, K, conv=None, iters=20):
     s = _lib.current_stream()
     res = []
     for variant in (0, 1):
-        _lib.load().prx_gemm_variant(variant)
+        _lib.load().prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, variant)
         for _ in range(3):
             call("prx_k_gemm", g, ws, ws.numel(), s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -21,6 +21,7 @@ dev = torch.device("cuda", 0)
 sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
                                     num_cuts=64, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev)
 lib = _lib.load()
+prof = api.GemmProfile(sess)
 it = [0]
 
 
@@ -34,11 +35,11 @@ def measure():
     """{(M,N,K,mode): (launches/iter, us per launch, (bm,bn,splits))}, total ms/iter"""
     if os.path.exists(path):
         os.remove(path)
-    lib.prx_profile_gemm_enable(1)
+    prof.enable(True)
     run(steps)
-    lib.prx_profile_gemm_enable(0)
-    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-    lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+    prof.enable(False)
+    _ms, _fl, _n = prof.collect()
+    ms = ctypes.c_double(_ms)
     agg = collections.OrderedDict()
     for line in open(path):
         M, N, K, mode, bm, bn, sp, us = line.strip().split(",")
@@ -72,14 +73,14 @@ for key in order:
         for sp in sorted(cands):
             if (bm, bn, sp) == cfg0:
                 continue
-            lib.prx_gemm_tile_rule(M, N, K, mode, bm, bn, sp)
+            prof.tile_rule(M, N, K, mode, bm, bn, sp)
             try:
                 r, _ = measure()
             except Exception as e:                      # a shape a tile cannot take (fused-stat constraints)
                 print("   skip", key, bm, bn, sp, str(e)[:80])
-                lib.prx_gemm_tile_rule(M, N, K, mode, 0, 0, 0)
+                prof.tile_rule(M, N, K, mode, 0, 0, 0)
                 continue
-            lib.prx_gemm_tile_rule(M, N, K, mode, 0, 0, 0)
+            prof.tile_rule(M, N, K, mode, 0, 0, 0)
             us = r[key][1]
             row += f" {bm}x{bn}s{sp}:{us:6.1f}"
             if us < best[0]:
@@ -92,7 +93,7 @@ for key, c0, c1, u0, u1, cnt in wins:
     print(f"  {key}: {c0} {u0:.1f} us -> {c1} {u1:.1f} us  (x{cnt:.0f}/iter = {(u0 - u1) * cnt / 1e3:.3f} ms)")
 # confirm the winners together
 for key, c0, c1, *_ in wins:
-    lib.prx_gemm_tile_rule(*key, *c1)
+    prof.tile_rule(*key, *c1)
 if wins:
     _, ms_all = measure()
     print(f"all winners applied: GEMM engine {ms_all:.3f} ms per iteration (baseline {base_ms:.3f} / {base_ms2:.3f})")

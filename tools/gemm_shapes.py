@@ -23,14 +23,14 @@ sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_1
 for i in range(3):
     sess.train(i)
 torch.cuda.synchronize()
-lib = _lib.load()
-lib.prx_profile_gemm_enable(1)
+prof = api.GemmProfile(sess)
+prof.enable(True)
 for i in range(steps):
     sess.train(3 + i)
 torch.cuda.synchronize()
-lib.prx_profile_gemm_enable(0)
-ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-lib.prx_profile_gemm_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+prof.enable(False)
+_ms, _fl, _n = prof.collect()
+ms, fl, n = ctypes.c_double(_ms), ctypes.c_double(_fl), ctypes.c_longlong(_n)
 agg = collections.OrderedDict()
 for line in open(path):
     M, N, K, mode, bm, bn, sp, us = line.strip().split(",")

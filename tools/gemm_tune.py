@@ -20,44 +20,44 @@ def run(M, N, K, conv, cfgs, iters=20):
     s = _lib.current_stream()
     res = []
     for (bm, bn, sp) in cfgs:
-        lib.prx_gemm_tile_override(bm, bn, sp)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), bm, bn, sp)
         for _ in range(3): call("prx_k_gemm", g, ws, ws.numel(), s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters): call("prx_k_gemm", g, ws, ws.numel(), s)
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / iters * 1e3)
-    lib.prx_gemm_tile_override(0, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
     best = min(range(len(res)), key=lambda i: res[i])
     print(f"M={M:6d} N={N:5d} K={K:5d} conv={str(conv):20s} " + "  ".join(f"{c}:{t:6.1f}" for c, t in zip(cfgs, res)) + f"   best {cfgs[best]} {2.0*M*N*K/res[best]/1e6:.0f} TF", flush=True)
 
 import sys as _s
 if len(_s.argv) > 1 and _s.argv[1] == "xcd":
     for sw in (0, 1):
-        lib.prx_gemm_tile_override(-1, 0, sw)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -1, 0, sw)
         print("== xcd swizzle", sw)
         for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
             run(M, N, K, None, [(0, 0, 0)])
         for (H, C, Co, up) in [(64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0), (256, 128, 128, 0), (256, 128, 128, 1)]:
             run(H * H, Co, 9 * C, (H, H, C, up), [(0, 0, 0)])
-    lib.prx_gemm_tile_override(-1, 0, 1)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -1, 0, 1)
     _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "dbg":
-    lib.prx_gemm_tile_override(-3, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, 0)
     for dbg in (0, 1, 2, 3):
-        lib.prx_gemm_tile_override(-4, 0, dbg)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -4, 0, dbg)
         print("== dbg", dbg, "(bit0: no DMA issue, bit1: no LDS-read/MFMA)")
         cf = [(128, 128, 1), (128, 64, 1), (64, 64, 1)]
         for (M, N, K) in [(3200, 768, 2304), (3200, 768, 3072), (3200, 3072, 768), (8192, 8192, 8192)]:
             run(M, N, K, None, cf)
         for (H, C, Co, up) in [(64, 256, 256, 0), (128, 256, 256, 1), (256, 128, 128, 0)]:
             run(H * H, Co, 9 * C, (H, H, C, up), cf)
-    lib.prx_gemm_tile_override(-4, 0, 0); lib.prx_gemm_tile_override(-3, 0, 1)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -4, 0, 0); lib.prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, 1)
     _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "wsplit":
     for wsp in (0, 1):
         for st in (2, 3):
-            lib.prx_gemm_tile_override(-3, 0, wsp); lib.prx_gemm_tile_override(-2, 0, st)
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, wsp); lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, st)
             print("== wsplit", wsp, "stages", st)
             cf = [(0, 0, 0), (64, 64, 1)]
             for (M, N, K) in [(3200, 768, 2304), (3200, 768, 768), (3200, 768, 3072), (3200, 2304, 768), (3200, 3072, 768)]:
@@ -66,32 +66,32 @@ if len(_s.argv) > 1 and _s.argv[1] == "wsplit":
                 run(H * H, Co, 9 * C, (H, H, C, up), cf + [(64, 64, 4)])
             for (M, N, K) in [(256, 1536, 512), (1024, 256, 512), (16384, 128, 256)]:
                 run(M, N, K, None, cf)
-    lib.prx_gemm_tile_override(-2, 0, 0); lib.prx_gemm_tile_override(-3, 0, 1)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0); lib.prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, 1)
     _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "c64":
     for c64 in (0, 1):
         for st in (2, 3):
-            lib.prx_gemm_tile_override(-5, 0, c64); lib.prx_gemm_tile_override(-2, 0, st)
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -5, 0, c64); lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, st)
             print("== conv scalar-tap gather", c64, "stages", st)
             cf = [(0, 0, 0), (128, 128, 1), (128, 64, 1), (64, 64, 1), (64, 64, 4), (128, 64, 4), (128, 128, 4)]
             for (H, C, Co, up) in [(16, 512, 512, 0), (32, 512, 512, 1), (32, 256, 256, 0), (64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0), (256, 128, 128, 0), (256, 128, 128, 1)]:
                 run(H * H, Co, 9 * C, (H, H, C, up), cf)
-    lib.prx_gemm_tile_override(-2, 0, 0); lib.prx_gemm_tile_override(-5, 0, 1)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0); lib.prx_gemm_tile_override(_lib.tool_ctx(), -5, 0, 1)
     _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "big":
     for st in (2, 3):
-        lib.prx_gemm_tile_override(-2, 0, st)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, st)
         print("== 256x128 tiles, stages", st)
         cf = [(0, 0, 0), (256, 128, 1), (256, 128, 2), (256, 128, 3), (256, 128, 4), (128, 128, 2), (128, 128, 1), (64, 64, 1)]
         for (M, N, K) in [(3200, 768, 3072), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 2304, 768), (4096, 4096, 4096), (8192, 8192, 8192)]:
             run(M, N, K, None, cf)
         for (H, C, Co, up) in [(64, 256, 256, 0), (128, 256, 256, 1), (128, 128, 128, 0), (256, 128, 128, 0), (256, 128, 128, 1)]:
             run(H * H, Co, 9 * C, (H, H, C, up), cf)
-    lib.prx_gemm_tile_override(-2, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
     _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "stages":
     for st in (2, 3, 4):
-        lib.prx_gemm_tile_override(-2, 0, st)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, st)
         print("== stages", st)
         cf = [(0, 0, 0), (128, 128, 1), (128, 64, 1), (64, 64, 1)]
         for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
@@ -100,7 +100,7 @@ if len(_s.argv) > 1 and _s.argv[1] == "stages":
             run(H * H, Co, 9 * C, (H, H, C, up), cf + [(64, 64, 4), (128, 64, 4)])
         for (M, N, K) in [(256, 1536, 512), (1024, 256, 512), (16384, 128, 256)]:
             run(M, N, K, None, cf)
-    lib.prx_gemm_tile_override(-2, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
     _s.exit(0)
 cfgs = [(0, 0, 0), (128, 128, 1), (128, 128, 2), (128, 64, 1), (128, 64, 2), (64, 64, 1)]
 for (M, N, K) in [(3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768), (3200, 3072, 768), (3200, 768, 3072), (3200, 3072, 768)]:
