@@ -1,18 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- optimisation iterations/sec of the pixray hot path on MI355X.
 
-One "step" = one body of the reference's train() (pixray.py:1448-1487, batches=1): VqganDrawer.synth ->
-MakeCutouts (host-drawn augmentation parameters, device noise) -> CLIP ViT encode_image -> Prompt loss ->
-backward to z -> (N>1: all-reduce of dL/d(image)) -> Adam -> clip_z, at BASELINE.json configs[1]:
-VQGAN imagenet_f16_16384 256x256 + ViT-B/32 + 64 cutouts, seeded random weights of the real architectures.
+One "step" = one body of the reference's train() (pixray.py:1448-1487, batches=1): drawer.synth -> MakeCutouts
+(host-drawn augmentation parameters, device noise) -> CLIP encode_image -> Prompt loss (+ custom losses) -> backward ->
+(N>1: all-reduce of dL/d(image)) -> Adam -> clip_z, with seeded random weights of the real architectures.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # BASELINE.json configs[1] (the metric): vqgan 256^2 + ViT-B/32 + 64 cutouts
+    python bench.py --config cfg2                    # configs[2]: vqgan 512^2 + ViT-B/16 + RN50x4, 128 cutouts per perceptor
+    python bench.py --config cfg2 --cutn 16          #   ... at the 16-cutout shard one of 8 GPUs holds
+    python bench.py --config cfg3                    # configs[3]: fft 512^2 + ViT-L/14 + 256 cutouts + StyleLoss + SaturationLoss
+    python bench.py --precision f32                  # the exact-f32 MFMA parity mode instead of the bf16 fast path
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is measured live with HIP events around every
-launch of the dominant kernel family (the bf16 MFMA GEMM / implicit-GEMM conv engine) on the launch stream;
-`cpu_baseline` times the CPU oracle (a port: the reference itself is not importable offline) on the host cores.
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every launch of the dominant kernel
+family (the MFMA GEMM / implicit-GEMM conv engine) on the launch stream; `cpu_baseline` times the CPU oracle (a port: the
+reference itself is not importable offline) on the host cores, on a stated, bounded sample.
 """
 import argparse
 import json
@@ -24,27 +27,119 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic work per iteration at the headline config
-GFLOP_DECODER = 506.0 + 2.1      # decoder fwd+bwd + VQ distance GEMM (replicated on every rank)
-GFLOP_CLIP_PER_CUT = 8.82 + 8.91  # ViT-B/32 fwd + bwd(dgrad) per cutout
-PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+# algorithmic work per iteration at the headline config; the other configurations report
+# the contraction flops the engine executed (sum of 2MNK over its launches, split-K counted once)
+GFLOP_DECODER_256 = 506.0 + 2.1
+GFLOP_CLIP_B32_PER_CUT = 8.82 + 8.91
+
+
+def make_saturation_loss(device):
+    """BASELINE.json configs[3]'s SaturationLoss: the reference plugin is plain torch (Losses/SaturationLoss.py:15-30) and
+    drops in unchanged where /root/reference exists (tests/test_host_logic.py); the GPU box has no reference tree, so the
+    benchmark carries the same arithmetic as a LossInterface plugin of its own."""
+    import torch
+    from pixray_amd.interfaces import LossInterface
+
+    class SaturationLoss(LossInterface):
+        needs_full_batch = True          # std over ALL cutout pixels: scored on the gathered batch when sharded
+
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            res = []
+            for _, cutouts in cur_cutouts.items():
+                px = cutouts.permute(0, 2, 3, 1).reshape(-1, 3)
+                rg, yb = px[:, 0] - px[:, 1], 0.5 * (px[:, 0] + px[:, 1]) - px[:, 2]
+                rg_std, rg_mean = torch.std_mean(rg)
+                yb_std, yb_mean = torch.std_mean(yb)
+                res.append(-(torch.sqrt(rg_std ** 2 + yb_std ** 2) + 0.3 * torch.sqrt(rg_mean ** 2 + yb_mean ** 2)) / 10.0)
+            return res
+    return SaturationLoss(device=device)
+
+
+def cfg3_custom_losses(device, precision, on_cpu=False):
+    """StyleLoss (VGG16 extractor on the HIP engine, STROTSS on top) + SaturationLoss, synthetic style image and VGG weights.
+    --styleloss_skip 0: the steady state after the reference's default 100 silent iterations."""
+    import argparse as ap
+    import torch
+    from pixray_amd import style_loss as sl
+    from pixray_amd import weights
+    args = sl.StyleLoss.add_settings(ap.ArgumentParser()).parse_args(["--styleloss_skip", "0"])
+    params = weights.synthetic_vgg16_params(0)
+    style_img = torch.rand(1, 3, 384, 448, generator=torch.Generator().manual_seed(4))
+    if on_cpu:
+        from oracle import workload_ref
+        style = sl.StyleLoss(extractor=workload_ref.OracleVggExtractor(params), style_image=style_img, device="cpu")
+        sat = workload_ref.SaturationLossRef()
+    else:
+        ext = sl.Vgg16Extractor(space=args.styleloss_ospace, params=params, device=device, max_hw=(512, 512), precision=precision)
+        style = sl.StyleLoss(extractor=ext, style_image=style_img, device=device)
+        sat = make_saturation_loss(device)
+    args = style.parse_settings(args)
+    return [{"loss": style, "weight": 1.0}, {"loss": sat, "weight": 1.0}], args
+
+
+class CollectiveTimer:
+    """per-collective device time of the N>1 path: wraps torch.distributed's all_reduce / all_gather with events"""
+
+    def __init__(self):
+        self.records = []
+        self._orig = {}
+
+    def __enter__(self):
+        import torch
+        import torch.distributed as dist
+        for name in ("all_reduce", "all_gather"):
+            orig = getattr(dist, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _orig=orig, _name=name, **k):
+                t = a[0] if _name == "all_reduce" else a[1]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _orig(*a, **k)
+                e1.record()
+                self.records.append((f"{_name}[{t.numel() * t.element_size()} B]", e0, e1))
+                return r
+            setattr(dist, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        for name, orig in self._orig.items():
+            setattr(dist, name, orig)
+
+    def summary(self, steps):
+        out = {}
+        for key, e0, e1 in self.records:
+            out[key] = out.get(key, 0.0) + e0.elapsed_time(e1)
+        return {k: round(v / steps, 4) for k, v in out.items()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cutn", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3"], default="cfg1")
+    ap.add_argument("--cutn", type=int, default=None, help="cutouts (default: the configuration's own count)")
+    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the iteration from a captured hipGraph (measured neutral on MI355X: the loop is GPU-bound)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-sample-cutn", type=int, default=None)
     ap.add_argument("--profile-steps", type=int, default=3)
     args = ap.parse_args()
 
     import torch
     from pixray_amd import _lib, api
+
+    wl = api.WORKLOADS[args.config]
+    cutn = args.cutn if args.cutn else wl["num_cuts"]
+    heavy = args.config != "cfg1" or args.precision == "f32"
+    steps = args.steps if args.steps is not None else (10 if heavy else 30)
+    warmup = args.warmup if args.warmup is not None else (2 if heavy else 5)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -54,7 +149,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    force_dist = os.environ.get("PRX_FORCE_DIST") == "1"      # exercise the RCCL code path on a single GPU (tests)
+    force_dist = os.environ.get("PRX_FORCE_DIST") == "1"      # exercise the RCCL code path on a single GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -63,9 +158,13 @@ def main():
         group = dist.group.WORLD
     torch.manual_seed(1234 + rank)          # per-rank device noise streams (host-side draws are seeded identically)
 
-    sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
-                                        num_cuts=args.cutn, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev,
-                                        group=group, rank=rank, world_size=world)
+    custom, largs = ((), None)
+    if args.config == "cfg3":
+        import numpy as np
+        np.random.seed(0)                    # STROTSS samples its hyper-column positions from numpy's global RNG
+        custom, largs = cfg3_custom_losses(dev, args.precision)
+    sess = api.build_workload(args.config, num_cuts=cutn, precision=args.precision, device=dev, group=group, rank=rank,
+                              world_size=world, custom_losses=custom, args=largs)
     if force_dist and world == 1:
         sess.world_size = 1
         for p_ in sess.perceptors.values():
@@ -81,13 +180,13 @@ def main():
     it = 0
     graphed = False
     if args.graph and world == 1:
-        graphed = sess.enable_graph(warmup=max(args.warmup - 1, 1))      # warm-up iterations run inside
+        graphed = sess.enable_graph(warmup=max(warmup - 1, 1))      # warm-up iterations run inside
         it = sess.cur_iteration
-    for _ in range(0 if graphed else args.warmup):
+    for _ in range(0 if graphed else warmup):
         sess.train(it); it += 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         sess.train(it); it += 1
     barrier()
     elapsed = time.perf_counter() - t0
@@ -96,25 +195,33 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / steps
+    value = steps / elapsed
     loss = float(sum(l.detach() for l in sess.last_losses))
+
+    # ---- per-collective device time (N > 1, or the forced 1-rank group) ------------------------------------------------
+    collectives = None
+    if world > 1 or force_dist:
+        with CollectiveTimer() as ct:
+            for _ in range(args.profile_steps):
+                sess.train(it); it += 1
+            torch.cuda.synchronize(dev)
+        collectives = ct.summary(args.profile_steps)
 
     # ---- roofline leg: per-launch HIP-event timing of the GEMM engine over a few extra steps ------------------
     # (eager launches: events cannot be recorded around the nodes of a replayed graph)
     roofline = None
     sess._drop_graph()
+    peak = PEAK_TFLOPS[args.precision]
+    gemm_gflop_step = None
     if rank == 0:
-        import ctypes
         prof = api.GemmProfile(sess)
         prof.enable(True)
         for _ in range(args.profile_steps):
             sess.train(it); it += 1
         torch.cuda.synchronize(dev)
         prof.enable(False)
-        _ms, _fl, _n = prof.collect()
-        ms, fl, n = ctypes.c_double(_ms), ctypes.c_double(_fl), ctypes.c_longlong(_n)
-        rc = 0
+        raw_ms, flop, n = prof.collect()
         # A bracket [event, kernel, event] also times the events' own timestamp packets.  An EMPTY bracket on this stream
         # measures ~5 us; around a kernel about half of that is hidden behind the kernel's own dispatch/drain, and taking
         # half of the empty-bracket time off every launch reproduces rocprofv3's kernel durations for the same command
@@ -125,54 +232,82 @@ def main():
             a_.record(); b_.record(); pairs.append((a_, b_))
         torch.cuda.synchronize(dev)
         ev_over_ms = 0.5 * sorted(x.elapsed_time(y) for x, y in pairs)[len(pairs) // 2]
-        raw_ms = ms.value
-        if rc == 0 and ms.value > 0:
-            ms.value = max(ms.value - ev_over_ms * n.value, 0.5 * ms.value)
-            achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_glds_kernel<BM,BN,AMODE,STAGES,..> (bf16 MFMA GEMM / implicit 3x3 conv, all launches)",
-                        "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                        # HBM-side bytes per GEMM launch from the PMC passes committed in profiles/r01_h_pmc_hbm_traffic.csv
-                        # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH doubled per the gfx950
-                        # correction of MI355X_MICROARCH.md); not re-measured live
-                        "traffic": 42.5e6, "traffic_source": "profiles/r01_h_pmc_hbm_traffic.csv",
-                        "launches_per_step": n.value // args.profile_steps,
-                        "gemm_gflop_per_step": round(fl.value / args.profile_steps / 1e9, 1),
-                        "gemm_ms_per_step": round(ms.value / args.profile_steps, 3),
-                        "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2),
+        if raw_ms > 0 and n > 0:
+            ms = max(raw_ms - ev_over_ms * n, 0.5 * raw_ms)
+            achieved = flop / (ms * 1e-3) / 1e12
+            gemm_gflop_step = flop / args.profile_steps / 1e9
+            kern = ("gemm_glds_kernel<BM,BN,AMODE,STAGES,..> (bf16 MFMA GEMM / implicit 3x3 conv, all launches)" if args.precision == "bf16"
+                    else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
+            # HBM-side bytes per launch come from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+            # command, gfx950 FETCH correction applied): not measurable from inside this process, so `traffic` is null here
+            # and the committed profile of the round is quoted next to it when there is one for this configuration
+            pmc = None
+            pmc_path = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
+            if args.precision == "bf16" and os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                pmc["source"] = os.path.relpath(pmc_path, ROOT)
+            roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": None, "traffic_pmc_profile": pmc,
+                        "launches_per_step": n // args.profile_steps,
+                        "gemm_gflop_per_step": round(gemm_gflop_step, 1),
+                        "gemm_ms_per_step": round(ms / args.profile_steps, 3),
+                        "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                         "event_overhead_us_removed_per_launch": round(1e3 * ev_over_ms, 2),
-                        "avg_launch_us_raw_events": round(1e3 * raw_ms / max(n.value, 1), 2)}
+                        "avg_launch_us_raw_events": round(1e3 * raw_ms / max(n, 1), 2)}
     elif world > 1:
         for _ in range(args.profile_steps):      # keep ranks in lock-step through the collectives
             sess.train(it); it += 1
 
-    per_gpu_gflop = GFLOP_DECODER + GFLOP_CLIP_PER_CUT * args.cutn / world
-    iter_frac = value * per_gpu_gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12)
+    if args.config == "cfg1":
+        per_gpu_gflop = GFLOP_DECODER_256 + GFLOP_CLIP_B32_PER_CUT * cutn / world
+    else:
+        per_gpu_gflop = gemm_gflop_step      # rank 0's executed contraction flops (identical on every rank)
+    iter_frac = value * per_gpu_gflop * 1e9 / (peak * 1e12) if per_gpu_gflop else None
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import step_ref
-        r = step_ref.time_oracle_iterations(n_iters=args.cpu_iters, warmup=1, cutn=args.cutn)
-        cpu_baseline = {"value": round(r["iters_per_sec"], 4), "unit": "iterations/s", "cores": r["threads"],
-                        "kind": "port",
-                        "sample": f"{args.cpu_iters} full iterations (same config, fp32 torch CPU oracle, "
-                                  f"{r['threads']} threads of {r['cores']} host cores) after 1 warm-up"}
+        from oracle import step_ref, workload_ref
+        if args.config == "cfg1":
+            r = step_ref.time_oracle_iterations(n_iters=args.cpu_iters, warmup=1, cutn=cutn)
+            cpu_baseline = {"value": round(r["iters_per_sec"], 4), "unit": "iterations/s", "cores": r["threads"],
+                            "kind": "port",
+                            "sample": f"{args.cpu_iters} full iterations (same config, fp32 torch CPU oracle, "
+                                      f"{r['threads']} threads of {r['cores']} host cores) after 1 warm-up"}
+        else:
+            sample = args.cpu_sample_cutn or (16 if args.config == "cfg2" else 8)
+            sample = min(sample, cutn)
+            ccustom, cargs = ((), None)
+            if args.config == "cfg3":
+                ccustom, cargs = cfg3_custom_losses("cpu", "f32", on_cpu=True)
+            r = workload_ref.time_workload(args.config, sample, n_iters=args.cpu_iters, warmup=1, custom=ccustom, args=cargs)
+            # the cutout-proportional part (cutouts + towers) scales linearly in the cutout count; the drawer part does not
+            t_full = r["drawer_seconds"] + (r["seconds_per_iter"] - r["drawer_seconds"]) * (cutn / sample)
+            cpu_baseline = {"value": round(1.0 / t_full, 5), "unit": "iterations/s", "cores": r["threads"], "kind": "port",
+                            "sample": f"{args.cpu_iters} oracle iterations at {sample} of {cutn} cutouts per perceptor "
+                                      f"({r['seconds_per_iter']:.1f} s each, drawer part {r['drawer_seconds']:.1f} s; fp32 torch, "
+                                      f"{r['threads']} threads of {r['cores']} host cores) after 1 warm-up, the cutout-proportional "
+                                      f"part extrapolated linearly to {cutn}"}
 
     if rank == 0:
+        metric = {"cfg1": "optimisation iters/sec, VQGAN 256^2 + ViT-B/32 + 64 cutouts",
+                  "cfg2": "optimisation iters/sec, VQGAN 512^2 + ViT-B/16 + RN50x4 + 128 cutouts",
+                  "cfg3": "optimisation iters/sec, fft 512^2 + ViT-L/14 + 256 cutouts + StyleLoss + SaturationLoss"}[args.config]
         out = {
-            "metric": "optimisation iters/sec, VQGAN 256^2 + ViT-B/32 + 64 cutouts",
-            "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "vqgan imagenet_f16_16384 256x256 + CLIP ViT-B/32 + %d cutouts, 1 prompt, Adam lr 0.2"
-                                   % args.cutn,
-                       "weights": "seeded random, real architectures", "cutouts_per_gpu": args.cutn // world,
+            "metric": metric,
+            "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": wl["text"] if cutn == wl["num_cuts"] else wl["text"] + f" [run at {cutn} cutouts per perceptor]",
+                       "weights": "seeded random, real architectures", "cutouts_per_gpu": cutn // world,
                        "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU",
-                       "launch": "hipGraph replay" if graphed else "eager"},
+                       "launch": "hipGraph replay" if graphed else "eager",
+                       "precision": "bf16 MFMA operands, fp32 accumulate / residual streams / norms" if args.precision == "bf16"
+                                    else "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)"},
             "final_loss": round(loss, 5),
-            "per_gpu_gflop_per_step": round(per_gpu_gflop, 1),
-            "iter_mfma_frac": round(iter_frac, 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "per_gpu_gflop_per_step": round(per_gpu_gflop, 1) if per_gpu_gflop else None,
+            "iter_mfma_frac": round(iter_frac, 4) if iter_frac else None,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "collectives_ms_per_step": collectives,
         }
     if world > 1 or force_dist:
         import torch.distributed as dist

@@ -24,6 +24,48 @@ Pipeline (pixray.py):
      MyRandomPerspectivePadded(0.2, p=.7, padding 'fill' gray)
      ColorJitter(hue=.1, saturation=.1, p=.8)
   batch + U(0, 0.1) * N(0,1)                                                       508-510
+
+kornia 0.6.2 defaults this restatement relies on (from the published 0.6.2 sources, `kornia/augmentation/augmentation.py`
+and `kornia/geometry/transform/{imgwarp,crop2d}.py`; NOT checkable offline -> **parity unpinned**).  pixray passes none of
+these flags itself (pixray.py:414-436), so each call runs on its constructor / function default:
+
+  call in pixray.py                               kornia 0.6.2 definition                                     align_corners  resample   padding
+  ----------------------------------------------  ----------------------------------------------------------  -------------  ---------  ---------------------------
+  MyRandomPerspective (326-337, ctor 414)          RandomPerspective(distortion_scale, resample=BILINEAR,      False          bilinear   global_padding_mode:
+                                                   align_corners=False, p) -> warp_perspective(input, T,                                'reflection' (even it) /
+                                                   (h,w), mode, align_corners=flags['align_corners'], ...)                              'border' (odd it), 1250-1253
+  K.RandomResizedCrop(cropping_mode='resample')    RandomResizedCrop(size, scale, ratio, resample=BILINEAR,    **True**       bilinear   'zeros' (hard-coded in
+    (415)                                          align_corners=True, p=1., cropping_mode) ->                                           crop_by_transform_mat call)
+                                                   crop_by_transform_mat(input, T, size, mode, 'zeros',
+                                                   align_corners=flags['align_corners']) -> warp_affine
+  K.ColorJitter(hue, saturation, p) (416, 436)     brightness / contrast factors sampled from [1,1] -> a       -              -          -
+                                                   clamp to [0,1] each (identity on [0,1] images); saturation
+                                                   U(.9,1.1), hue U(-.1,.1)*2pi in HSV, all four in a random
+                                                   order drawn once per call
+  MyRandomAffine (340-353, ctor 420-431)           RandomAffine(degrees, translate, scale, resample=BILINEAR,  False          bilinear   'fill', fill_value =
+                                                   align_corners=False, padding_mode=ZEROS, p) ->                                        global_fill_color
+                                                   warp_affine(input, T[:, :2], (h,w), mode, align_corners=
+                                                   flags['align_corners'], padding_mode='fill', fill_value)
+  K.CenterCrop(size, cropping_mode='resample')     CenterCrop(size, align_corners=True, resample=BILINEAR,     **True**       bilinear   'zeros'
+    (433)                                          p=1., cropping_mode) -> crop_by_transform_mat(...);
+                                                   center_crop_generator truncates the window origin to an
+                                                   integer, so with align_corners=True the resample is an
+                                                   exact copy of that window
+  MyRandomPerspectivePadded (355-366, ctor 434)    RandomPerspective(... align_corners=False ...)              False          bilinear   'fill', fill_value
+  kornia.geometry.transform.warp_perspective       warp_perspective(src, M, dsize, mode='bilinear',            **True**       bilinear   global_padding_mode /
+    on the cached transforms (482-485)             padding_mode='zeros', align_corners=True, fill_value)       (fn default)              'fill'
+  kornia.geometry.transform.rescale (469-472)      rescale(input, factor, interpolation='bilinear',            None (=False)  bilinear   -
+                                                   align_corners=None) -> F.interpolate
+
+Both warps normalise the 3x3 with `normalize_homography` ([0, W-1] -> [-1, 1], i.e. the align_corners=True geometry)
+whatever the flag, build the destination grid with `create_meshgrid(normalized_coordinates=True)` (warp_perspective: always
+linspace(-1, 1)) or `F.affine_grid(theta, size, align_corners=flag)` (warp_affine), and hand the flag to `F.grid_sample`.
+With the flag False the map is therefore NOT the exact pixel map of the matrix (a half-pixel-class scale/shift that the
+reference really has); with the flag True it is.  `CONVENTIONS` below carries the flags; `make_cutouts(..., conventions=)`
+and the product's descriptor builder (`pixray_amd.cutouts.build_descriptors(..., conventions=)`) take the same dict, so a
+test can flip one and watch the HIP kernel follow (tests/test_path_gpu.py::test_cutout_align_corners_convention_is_a_
+descriptor_field).  Round 1 of this repository had `crop_align_corners` False on both sides; that was a misreading of the
+RandomResizedCrop constructor default.
 """
 from __future__ import annotations
 
@@ -34,6 +76,10 @@ import torch
 import torch.nn.functional as F
 
 TWO_PI = 2.0 * math.pi
+
+# the align_corners flag each kornia 0.6.2 call passes to F.grid_sample (table in the module docstring)
+CONVENTIONS = {"perspective_align_corners": False, "affine_align_corners": False, "crop_align_corners": True,
+               "cached_align_corners": True}
 
 
 # ---------------------------------------------------------------- kornia geometry [UPSTREAM]
@@ -227,9 +273,12 @@ def _wide_affine(prm, nw, Hb, Wb):
     return Ma
 
 
-def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, spot_mask=None) -> torch.Tensor:
+def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, spot_mask=None, conventions=None) -> torch.Tensor:
     """MakeCutouts.forward(img[1,3,H,W]) -> [cutn,3,S,S] with explicit randomness `prm`
-    (see pixray_amd.cutouts.sample_cutout_params for the fields; prm["aspect"] = canvas width / height)."""
+    (see pixray_amd.cutouts.sample_cutout_params for the fields; prm["aspect"] = canvas width / height).
+    `conventions`: overrides of CONVENTIONS (which align_corners flag each kornia call passes)."""
+    cv = dict(CONVENTIONS, **(conventions or prm.get("conventions") or {}))
+    ac_p, ac_a, ac_c = cv["perspective_align_corners"], cv["affine_align_corners"], cv["crop_align_corners"]
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)                                   # pixray.py:407
     nw = cutn - nz
@@ -242,26 +291,26 @@ def make_cutouts(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, spot_m
     if nz > 0:
         x = base.expand(nz, -1, -1, -1)
         Mp = _persp_matrix(prm["z_persp_rand"], 0.4, Hb, Wb)
-        warped = warp_perspective(x, Mp, (Hb, Wb), pad_mode, align_corners=False)
+        warped = warp_perspective(x, Mp, (Hb, Wb), pad_mode, align_corners=ac_p)
         x = torch.where(prm["z_persp_apply"].view(-1, 1, 1, 1), warped, x)
         xs, ys, w, h = [prm["z_crop"][:, i].double() for i in range(4)]
         src = torch.stack([torch.stack([xs, ys], 1), torch.stack([xs + w - 1, ys], 1),
                            torch.stack([xs + w - 1, ys + h - 1], 1), torch.stack([xs, ys + h - 1], 1)], dim=1)
         dst = torch.tensor([[0.0, 0.0], [S - 1.0, 0.0], [S - 1.0, S - 1.0], [0.0, S - 1.0]], dtype=torch.float64)
         Mc = get_perspective_transform(src, dst[None].expand(nz, 4, 2))
-        x = warp_affine(x, Mc[:, :2, :], (S, S), "zeros", align_corners=False)
+        x = warp_affine(x, Mc[:, :2, :], (S, S), "zeros", align_corners=ac_c)     # crop_by_transform_mat, RandomResizedCrop's flag
         x = color_jitter(x, prm["z_jit_apply"], prm["z_sat"], prm["z_hue"], bool(prm["z_sat_first"]))
         outs.append(x)
     if nw > 0:
         x = base.expand(nw, -1, -1, -1)
         Ma = _wide_affine(prm, nw, Hb, Wb)
-        x = warp_affine(x, Ma[:, :2, :], (Hb, Wb), "fill", align_corners=False, fill_value=fill)
-        # CenterCrop(S) (pixray.py:433): the centred S x S window (an exact copy for integer offsets; kornia resamples at
-        # half pixels when (Wb - S) is odd, which this restatement floors)
+        x = warp_affine(x, Ma[:, :2, :], (Hb, Wb), "fill", align_corners=ac_a, fill_value=fill)
+        # CenterCrop(S) (pixray.py:433): center_crop_generator truncates the window origin to an integer and the crop is
+        # resampled with align_corners=True -> an exact copy of the centred S x S window
         oy, ox = (Hb - S) // 2, (Wb - S) // 2
         x = x[:, :, oy:oy + S, ox:ox + S]
         Mp = _persp_matrix(prm["w_persp_rand"], 0.2, S)
-        warped = warp_perspective(x, Mp, (S, S), "fill", align_corners=False, fill_value=fill)
+        warped = warp_perspective(x, Mp, (S, S), "fill", align_corners=ac_p, fill_value=fill)
         x = torch.where(prm["w_persp_apply"].view(-1, 1, 1, 1), warped, x)
         x = color_jitter(x, prm["w_jit_apply"], prm["w_sat"], prm["w_hue"], bool(prm["w_sat_first"]))
         outs.append(x)
@@ -303,11 +352,13 @@ def composed_transforms(prm: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
     return torch.cat(out, dim=0)
 
 
-def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None, spot_mask=None) -> torch.Tensor:
+def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int, noise_fac=None, noise=None, spot_mask=None,
+                        conventions=None) -> torch.Tensor:
     """MakeCutouts.forward when `.transforms` is cached (pixray.py:480-486; image prompts, pixray.py:1318-1333): ONE
     `kornia.warp_perspective(cutout, T, (S,S), padding_mode=...)` per set -- kornia 0.6.2's default align_corners=True
     [UPSTREAM, from knowledge: parity unpinned], zoom set with the iteration's reflection/border padding, wide set filled
     with the iteration's gray -- no ColorJitter, then fresh noise."""
+    ac = dict(CONVENTIONS, **(conventions or {}))["cached_align_corners"]
     cutn = int(prm["cutn"])
     nz = int(0.6 * cutn)
     aspect = float(prm["aspect"]) if "aspect" in prm else 1.0
@@ -317,9 +368,9 @@ def make_cutouts_cached(img: torch.Tensor, prm: Dict[str, torch.Tensor], S: int,
     fill = torch.full((3,), float(prm["fill"]), dtype=img.dtype)
     outs = []
     if nz > 0:
-        outs.append(warp_perspective(base.expand(nz, -1, -1, -1), T[:nz], (S, S), pad_mode, align_corners=True))
+        outs.append(warp_perspective(base.expand(nz, -1, -1, -1), T[:nz], (S, S), pad_mode, align_corners=ac))
     if cutn - nz > 0:
-        outs.append(warp_perspective(base.expand(cutn - nz, -1, -1, -1), T[nz:], (S, S), "fill", align_corners=True, fill_value=fill))
+        outs.append(warp_perspective(base.expand(cutn - nz, -1, -1, -1), T[nz:], (S, S), "fill", align_corners=ac, fill_value=fill))
     batch = torch.cat(outs, dim=0)
     if noise is not None:
         batch = batch + noise_fac.view(-1, 1, 1, 1).to(batch) * noise

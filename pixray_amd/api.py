@@ -98,6 +98,58 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                    overlay_until=overlay_until, overlay_alpha=overlay_alpha)
 
 
+def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=256, iterations=250, seed=0, device="cuda",
+                           group=None, rank=0, world_size=1, custom_losses=(), args=None, prompt_embeds=None,
+                           precision: str = "bf16", fft_lrate: float = 0.3, fft_decay: float = 1.5) -> Session:
+    """BASELINE.json configs[3]'s shape: the spectrum drawer plugin (`FftDrawer`, its own Adam, no z) + one CLIP perceptor +
+    MakeCutouts + a Prompt + a custom-loss stack handed in by the caller ([{"loss": LossInterface, "weight": w}], e.g.
+    StyleLoss + SaturationLoss; `args` is what their `parse_settings` returned)."""
+    from .fft_drawer import FftDrawer
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
+    dev = torch.device(device)
+    st = types.SimpleNamespace(size=tuple(size), fft_use="fft", fft_decay=fft_decay, fft_lrate=fft_lrate, weight_seed=seed)
+    drawer = FftDrawer(st)
+    drawer.load_model(st, dev)
+    drawer.init_from_tensor(None)
+    per_rank = num_cuts // world_size
+    perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group, precision=precision)
+    mk = MakeCutouts(perceptor.input_resolution, num_cuts, generator=torch.Generator().manual_seed(1000 + seed),
+                     aspect_width=size[0] / size[1])
+    pe = prompt_embeds if prompt_embeds is not None else seeded_unit_vectors(1, perceptor.output_dim, seed + 2)
+    pms = {clip_model: [Prompt(pe.to(dev), 1.0, float("-inf")).to(dev)]}
+    return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, pms, iterations=iterations,
+                   custom_losses=list(custom_losses), args=args, seed=seed, group=group, rank=rank, world_size=world_size)
+
+
+# BASELINE.json `configs` as (builder kwargs); configs[0] is the CPU plumbing case (tests/test_host_logic.py), configs[4]
+# (vdiff) has no source in the reference checkout
+WORKLOADS = {
+    "cfg1": dict(kind="vqgan", size=(256, 256), clip_model="ViT-B/32", num_cuts=64,
+                 text="vqgan imagenet_f16_16384 256x256 + CLIP ViT-B/32 + 64 cutouts, 1 prompt, Adam lr 0.2"),
+    "cfg2": dict(kind="vqgan", size=(512, 512), clip_model=["ViT-B/16", "RN50x4"], num_cuts=128,
+                 text="vqgan imagenet_f16_16384 512x512 + CLIP ViT-B/16 + RN50x4 ensemble, 128 cutouts per perceptor, Adam lr 0.2"),
+    "cfg3": dict(kind="fft", size=(512, 512), clip_model="ViT-L/14", num_cuts=256,
+                 text="fft spectrum drawer 512x512 + CLIP ViT-L/14 + 256 cutouts + StyleLoss (VGG16 STROTSS) + SaturationLoss, Adam lr 0.3"),
+}
+
+
+def build_workload(name: str, *, num_cuts=None, precision="bf16", device="cuda", group=None, rank=0, world_size=1, seed=0,
+                   custom_losses=(), args=None) -> Session:
+    """A BASELINE.json configuration by name ("cfg1" = configs[1], the headline; "cfg2"; "cfg3"), seeded random weights of
+    the real architectures.  `num_cuts` overrides the configuration's cutout count (per-GPU shard sizes)."""
+    w = WORKLOADS[name]
+    n = int(num_cuts) if num_cuts else w["num_cuts"]
+    if w["kind"] == "vqgan":
+        return build_vqgan_clip_session(size=w["size"], vqgan_model="imagenet_f16_16384", clip_model=w["clip_model"], num_cuts=n,
+                                        learning_rate=0.2, iterations=10 ** 9, seed=seed, device=device, group=group, rank=rank,
+                                        world_size=world_size, precision=precision, custom_losses=custom_losses)
+    return build_fft_clip_session(size=w["size"], clip_model=w["clip_model"], num_cuts=n, iterations=10 ** 9, seed=seed,
+                                  device=device, group=group, rank=rank, world_size=world_size, custom_losses=custom_losses,
+                                  args=args, precision=precision)
+
+
 def session_gemm_contexts(sess: Session):
     """The `prx_gemm_ctx` of every runner handle a session drives (drawer, perceptors, HIP-backed custom losses): bench.py
     and tools/gemm_*.py enable per-launch timing / tile rules on these (the library itself has no global switch)."""

@@ -12,8 +12,9 @@
 // Each geometric stage is described by a 3x3 matrix taking a destination pixel (x, y, 1) to the
 // source sampling position in F.grid_sample's unnormalised pixel coordinates; the host
 // (pixray_amd/cutouts.py) folds kornia's normalisation conventions into it.
-// Backward scatters with fp32 atomics (as the reference's grid_sampler_2d_backward does,
-// pixray.py:29); the ColorJitter Jacobian is obtained with forward-mode duals.
+// Backward is in GATHER form: every source pixel sums its own contributions in a fixed order (no atomics, bit-
+// reproducible -- the reference's grid_sampler_2d_backward is the non-determinism pixray.py:29 complains about); the
+// ColorJitter Jacobian is obtained with forward-mode duals.
 #include "cutouts.h"
 #include <algorithm>
 
@@ -25,7 +26,16 @@ constexpr int DESC_WORDS = 32;
 enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
        D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27,
        D_WOX = 28, D_WOY = 29, D_WW = 30, D_WH = 31 };   // stage-B source window inside the stage-A image (x, y, width, height)
-enum { GRID_MESH = 0, GRID_AFFINE = 1 };
+// grid flavour of a stage = which kornia 0.6.2 call built its sampling grid AND the align_corners flag that call passed to
+// F.grid_sample (the convention is part of the descriptor, not an assumption of the kernel):
+//   GRID_MESH       warp_perspective(align_corners=False): create_meshgrid + transform_points, sampled with (g+1)*W/2 - 0.5
+//                   (RandomPerspective's default flag, pixray.py:333-334,363)
+//   GRID_AFFINE     warp_affine(align_corners=False): F.affine_grid's pixel-centre base grid (RandomAffine's default, pixray.py:349)
+//   GRID_AFFINE_AC  warp_affine(align_corners=True): F.affine_grid's corner-aligned base grid linspace(-1,1), sampled with
+//                   (g+1)/2*(W-1) -- what crop_by_transform_mat passes for RandomResizedCrop / CenterCrop, whose flag
+//                   defaults to True (pixray.py:415,433 pass none)
+//   GRID_MESH_AC    warp_perspective(align_corners=True), the function default: the cached-transform path (pixray.py:482-485)
+enum { GRID_MESH = 0, GRID_AFFINE = 1, GRID_AFFINE_AC = 2, GRID_MESH_AC = 3 };
 enum { MODE_IDENT = 0, MODE_ZEROS = 1, MODE_BORDER = 2, MODE_REFLECT = 3, MODE_FILL = 4,
        MODE_REFLECT_AC = 5 };   // reflection as F.grid_sample does it with align_corners=True (the cached-transform path)
 
@@ -57,20 +67,33 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     }
 }
 
+// Backward of the pooling in GATHER form (one thread per image pixel, fixed summation order -> bit-reproducible; the
+// scatter form needed float atomics because adaptive windows overlap whenever H is not a multiple of S): the pooled cells
+// whose window [win_start, win_end) contains row yy are a run of at most a few consecutive y around yy*S/H.
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const int* __restrict__ argmax,
                                                        const unsigned char* __restrict__ mask, float* __restrict__ gimg, int C, int H,
                                                        int W, int S) {
-    const int total = C * S * S;
+    const int total = C * H * W;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int x = idx % S, y = (idx / S) % S, c = idx / (S * S);
-        const int y0 = win_start(y, H, S), y1 = win_end(y, H, S);
-        const int x0 = win_start(x, W, S), x1 = win_end(x, W, S);
-        if (mask && mask[idx]) continue;            // masked pooled pixels are constants
-        const float gv = 0.5f * g[idx];
-        const float ga = gv / (float)((y1 - y0) * (x1 - x0));
-        for (int yy = y0; yy < y1; ++yy)
-            for (int xx = x0; xx < x1; ++xx) atomicAdd(&gimg[((size_t)c * H + yy) * W + xx], ga);
-        atomicAdd(&gimg[(size_t)c * H * W + argmax[idx]], gv);
+        const int xx = idx % W, yy = (idx / W) % H, c = idx / (H * W);
+        int ya = (int)(((long long)yy * S) / H), xa = (int)(((long long)xx * S) / W);
+        while (ya > 0 && win_end(ya - 1, H, S) > yy) --ya;          // first cell whose window reaches down to yy
+        while (xa > 0 && win_end(xa - 1, W, S) > xx) --xa;
+        float acc = 0.f;
+        for (int y = ya; y < S && win_start(y, H, S) <= yy; ++y) {
+            const int y0 = win_start(y, H, S), y1 = win_end(y, H, S);
+            if (yy >= y1) continue;
+            for (int x = xa; x < S && win_start(x, W, S) <= xx; ++x) {
+                const int x0 = win_start(x, W, S), x1 = win_end(x, W, S);
+                if (xx >= x1) continue;
+                const int cell = (c * S + y) * S + x;
+                if (mask && mask[cell]) continue;                   // masked pooled pixels are constants
+                const float gv = 0.5f * g[cell];
+                acc += gv / (float)((y1 - y0) * (x1 - x0));
+                if (argmax[cell] == yy * W + xx) acc += gv;
+            }
+        }
+        gimg[idx] = acc;
     }
 }
 
@@ -136,14 +159,14 @@ __device__ __forceinline__ float linspace_pm1(int i, int n) {
     return (i < n / 2) ? (-1.f + step * (float)i) : (1.f - step * (float)(n - 1 - i));
 }
 
-// Source sampling position (F.grid_sample pixel coordinates, align_corners=False) of destination pixel
-// (x, y).  GRID_MESH: kornia create_meshgrid + transform_points (fp64) -> fp32 grid (warp_perspective);
-// GRID_AFFINE: F.affine_grid's fp32 base grid times the fp32 theta (warp_affine).  The fp32 grid value is
-// then unnormalised the way ATen does: (g + 1) * (size / 2) - 0.5.
+// Source sampling position (F.grid_sample pixel coordinates) of destination pixel (x, y).
+// GRID_MESH*: kornia create_meshgrid + transform_points (fp64) -> fp32 grid (warp_perspective);
+// GRID_AFFINE*: F.affine_grid's fp32 base grid times the fp32 theta (warp_affine).  The fp32 grid value is
+// then unnormalised the way ATen does for the stage's align_corners flag.
 __device__ __forceinline__ void project(const double* m, int gtype, int x, int y, int Wd, int Hd, int Ws, int Hs,
                                         float& u, float& v) {
     float gx, gy;
-    if (gtype == GRID_MESH) {
+    if (gtype == GRID_MESH || gtype == GRID_MESH_AC) {
         const double xn = ((double)x / (double)(Wd - 1) - 0.5) * 2.0;
         const double yn = ((double)y / (double)(Hd - 1) - 0.5) * 2.0;
         const double X = m[0] * xn + m[1] * yn + m[2];
@@ -152,13 +175,21 @@ __device__ __forceinline__ void project(const double* m, int gtype, int x, int y
         const double sc = (fabs(Z) > 1e-8) ? 1.0 / Z : 1.0;
         gx = (float)(X * sc); gy = (float)(Y * sc);
     } else {
-        const float xb = (linspace_pm1(x, Wd) * (float)(Wd - 1)) / (float)Wd;
-        const float yb = (linspace_pm1(y, Hd) * (float)(Hd - 1)) / (float)Hd;
+        float xb = linspace_pm1(x, Wd), yb = linspace_pm1(y, Hd);      // affine_grid(align_corners=True): corner-aligned
+        if (gtype == GRID_AFFINE) {                                      // align_corners=False: pixel centres
+            xb = (xb * (float)(Wd - 1)) / (float)Wd;
+            yb = (yb * (float)(Hd - 1)) / (float)Hd;
+        }
         gx = (float)((double)xb * m[0] + (double)yb * m[1] + m[2]);
         gy = (float)((double)xb * m[3] + (double)yb * m[4] + m[5]);
     }
-    u = (gx + 1.f) * ((float)Ws * 0.5f) - 0.5f;
-    v = (gy + 1.f) * ((float)Hs * 0.5f) - 0.5f;
+    if (gtype >= GRID_AFFINE_AC) {          // ATen grid_sampler_unnormalize, align_corners=True
+        u = ((gx + 1.f) / 2.f) * (float)(Ws - 1);
+        v = ((gy + 1.f) / 2.f) * (float)(Hs - 1);
+    } else {                                // align_corners=False
+        u = (gx + 1.f) * ((float)Ws * 0.5f) - 0.5f;
+        v = (gy + 1.f) * ((float)Hs * 0.5f) - 0.5f;
+    }
 }
 
 // sample one channel plane; returns value and the coverage (sum of in-bounds weights)
@@ -167,7 +198,12 @@ __device__ __forceinline__ float sample_plane(const float* __restrict__ p, int W
     float v01 = (t.vx1 && t.vy0) ? p[t.y0 * W + t.x0 + 1] : 0.f;
     float v10 = (t.vx0 && t.vy1) ? p[(t.y0 + 1) * W + t.x0] : 0.f;
     float v11 = (t.vx1 && t.vy1) ? p[(t.y0 + 1) * W + t.x0 + 1] : 0.f;
-    return v00 * (1.f - t.wx) * (1.f - t.wy) + v01 * t.wx * (1.f - t.wy) + v10 * (1.f - t.wx) * t.wy + v11 * t.wx * t.wy;
+    // ATen's operation order (GridSamplerKernel.cpp, bilinear): the four weights first (nw = s*e, ne = s*w, sw = n*e,
+    // se = n*w with e = 1-w, s = 1-n), then nw_val*nw + ne_val*ne + sw_val*sw + se_val*se left to right -- so that flat
+    // regions (the exact 0/1 plateaus ClampWithGrad leaves) round to the same fp32 value as the oracle's and ties
+    // between channels, which the HSV jitter's Jacobian is discontinuous at, break the same way
+    const float e = 1.f - t.wx, s_ = 1.f - t.wy;
+    return v00 * (s_ * e) + v01 * (s_ * t.wx) + v10 * (t.wy * e) + v11 * (t.wy * t.wx);
 }
 __device__ __forceinline__ float coverage(const Taps& t) {
     float c = 0.f;
@@ -184,13 +220,6 @@ __device__ __forceinline__ float fill_term(const Taps& t, int mode, const double
     const float fillv = (mode == MODE_FILL) ? (float)d[D_FILL] : 0.f;
     return (1.f - coverage(t)) * fillv;
 }
-__device__ __forceinline__ void scatter_plane(float* __restrict__ p, int W, const Taps& t, float g) {
-    if (t.vx0 && t.vy0) atomicAdd(&p[t.y0 * W + t.x0], g * (1.f - t.wx) * (1.f - t.wy));
-    if (t.vx1 && t.vy0) atomicAdd(&p[t.y0 * W + t.x0 + 1], g * t.wx * (1.f - t.wy));
-    if (t.vx0 && t.vy1) atomicAdd(&p[(t.y0 + 1) * W + t.x0], g * (1.f - t.wx) * t.wy);
-    if (t.vx1 && t.vy1) atomicAdd(&p[(t.y0 + 1) * W + t.x0 + 1], g * t.wx * t.wy);
-}
-
 // ------------------------------------------------------------------ ColorJitter (HSV) with duals
 template <int ND>
 struct Dual {
@@ -339,90 +368,273 @@ __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict
     }
 }
 
-// ---- backward scatter with LDS tile staging -----------------------------------------------------------------
-// A block owns a 16x16 tile of destination pixels of ONE cutout.  Its bilinear taps land in a compact window of
-// the source plane, so they are accumulated with ds_add_f32 into an LDS window (WIN x WIN x 3) anchored at the
-// block's minimum tap, and the window is flushed once to HBM (one atomic per touched source pixel instead of
-// four per destination pixel).  Taps that fall outside the window (reflection wrap-around, extreme
-// perspective) go straight to HBM atomics, so the result never depends on the window size.
-constexpr int TILE_W = 16;
-constexpr int WIN = 48;
-
-struct ScatterWin {
-    float acc[3][WIN][WIN];
-    int org[2];
+// ---- backward in GATHER form ----------------------------------------------------------------------------------------
+// The reference differentiates its warps with grid_sampler_2d_backward: float atomics, run-to-run different bits
+// (pixray.py:29 documents the non-determinism).  Here every SOURCE pixel collects its own contributions in a fixed order:
+// bit-reproducible, no atomics, no memsets.  For source pixel s the destination pixels whose bilinear footprint touches
+// it lie in the pre-image of a 2x2 source square -- under zero / fill padding one square, under border padding a half
+// strip for border pixels, under reflection one square per mirror image.  Each pre-image is a quadrilateral of the
+// destination plane (the stage map is a homography); its bounding box is enumerated, candidates are screened with an
+// fp32 evaluation of the map, and the survivors are re-projected EXACTLY as the forward does (same fp64 -> fp32 steps, same
+// taps and weights), so the gradient is the exact adjoint of the forward, only summed in a different order than ATen.
+// Uniqueness: the raw-coordinate rectangles of one source pixel are disjoint and a candidate is counted in the rectangle
+// that contains its raw coordinate; completeness: acceptance is by the exact taps, the rectangles only bound the search.
+struct StageMap {
+    float P[9];      // destination pixel (x, y, 1) -> raw source coordinate (u, v), approximate (fp32) -- screening only
+    float Pi[9];     // its inverse: raw source coordinate -> destination pixel, for bounding boxes
+    float ulo, uhi, vlo, vhi;   // raw-coordinate range of the destination image (+- 1)
 };
 
-__device__ __forceinline__ void win_begin(ScatterWin& w, bool has_taps, const Taps& t) {
-    if (threadIdx.x == 0) { w.org[0] = 0x7fffffff; w.org[1] = 0x7fffffff; }
-    for (int i = threadIdx.x; i < 3 * WIN * WIN; i += 256) (&w.acc[0][0][0])[i] = 0.f;
-    __syncthreads();
-    if (has_taps) {
-        atomicMin(&w.org[0], max(t.x0, 0));
-        atomicMin(&w.org[1], max(t.y0, 0));
+// pixel-space matrix of a stage: A_src(flavour) * M * A_dst(flavour), all fp64
+__device__ void stage_matrix(const double* m, int gtype, int Wd, int Hd, int Ws, int Hs, double* P) {
+    // destination pixel -> normalised destination coordinate
+    double ax, bx, ay, by;
+    if (gtype == GRID_AFFINE) { ax = 2.0 / Wd; bx = 1.0 / Wd - 1.0; ay = 2.0 / Hd; by = 1.0 / Hd - 1.0; }
+    else { ax = 2.0 / (Wd - 1); bx = -1.0; ay = 2.0 / (Hd - 1); by = -1.0; }
+    double T[9];
+    for (int r = 0; r < 3; ++r) {
+        T[r * 3 + 0] = m[r * 3 + 0] * ax;
+        T[r * 3 + 1] = m[r * 3 + 1] * ay;
+        T[r * 3 + 2] = m[r * 3 + 0] * bx + m[r * 3 + 1] * by + m[r * 3 + 2];
     }
-    __syncthreads();
-}
-__device__ __forceinline__ void win_add(ScatterWin& w, float* __restrict__ plane, int W, int c, int x, int y, float v) {
-    const int lx = x - w.org[0], ly = y - w.org[1];
-    if (lx >= 0 && lx < WIN && ly >= 0 && ly < WIN) atomicAdd(&w.acc[c][ly][lx], v);
-    else atomicAdd(&plane[y * W + x], v);
-}
-__device__ __forceinline__ void win_scatter(ScatterWin& w, float* __restrict__ plane, int W, int c, const Taps& t, float g) {
-    if (t.vx0 && t.vy0) win_add(w, plane, W, c, t.x0, t.y0, g * (1.f - t.wx) * (1.f - t.wy));
-    if (t.vx1 && t.vy0) win_add(w, plane, W, c, t.x0 + 1, t.y0, g * t.wx * (1.f - t.wy));
-    if (t.vx0 && t.vy1) win_add(w, plane, W, c, t.x0, t.y0 + 1, g * (1.f - t.wx) * t.wy);
-    if (t.vx1 && t.vy1) win_add(w, plane, W, c, t.x0 + 1, t.y0 + 1, g * t.wx * t.wy);
-}
-// flush the window into the 3 planes at `base` (a Hs x Ws image with row pitch `pitch` and plane stride `pstride`)
-__device__ __forceinline__ void win_flush(ScatterWin& w, float* __restrict__ base, int Hs, int Ws, int pitch, size_t pstride) {
-    __syncthreads();
-    const int ox = w.org[0], oy = w.org[1];
-    if (ox == 0x7fffffff) return;
-    for (int i = threadIdx.x; i < 3 * WIN * WIN; i += 256) {
-        const float v = (&w.acc[0][0][0])[i];
-        if (v == 0.f) continue;
-        const int c = i / (WIN * WIN), r = (i / WIN) % WIN, q = i % WIN;
-        const int x = ox + q, y = oy + r;
-        if (x < Ws && y < Hs) atomicAdd(&base[(size_t)c * pstride + (size_t)y * pitch + x], v);
+    if (gtype == GRID_AFFINE || gtype == GRID_AFFINE_AC) { T[6] = 0.0; T[7] = 0.0; T[8] = 1.0; }    // warp_affine drops the last row
+    // normalised source coordinate -> raw pixel coordinate
+    double sx, ox, sy, oy;
+    if (gtype >= GRID_AFFINE_AC) { sx = 0.5 * (Ws - 1); ox = sx; sy = 0.5 * (Hs - 1); oy = sy; }
+    else { sx = 0.5 * Ws; ox = sx - 0.5; sy = 0.5 * Hs; oy = sy - 0.5; }
+    for (int c = 0; c < 3; ++c) {
+        P[c] = sx * T[c] + ox * T[6 + c];
+        P[3 + c] = sy * T[3 + c] + oy * T[6 + c];
+        P[6 + c] = T[6 + c];
     }
+}
+__device__ void invert3(const double* a, double* o) {
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c0 + a[1] * c1 + a[2] * c2;
+    const double id = det != 0.0 ? 1.0 / det : 0.0;
+    o[0] = c0 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c1 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c2 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+// thread 0 of the block builds the stage map of its cutout in LDS
+__device__ void build_stage_map(StageMap& sm, const double* m, int gtype, int Wd, int Hd, int Ws, int Hs) {
+    double P[9], Pi[9];
+    stage_matrix(m, gtype, Wd, Hd, Ws, Hs, P);
+    invert3(P, Pi);
+    // normalise so that the projective denominators are O(1) and positive inside the image
+    const double zc = P[6] * (0.5 * Wd) + P[7] * (0.5 * Hd) + P[8];
+    const double sp = zc != 0.0 ? 1.0 / zc : 1.0;
+    float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY;
+    for (int k = 0; k < 4; ++k) {
+        const double x = (k & 1) ? (double)(Wd - 1) : 0.0, y = (k & 2) ? (double)(Hd - 1) : 0.0;
+        const double z = P[6] * x + P[7] * y + P[8];
+        const double u = (P[0] * x + P[1] * y + P[2]) / z, v = (P[3] * x + P[4] * y + P[5]) / z;
+        ulo = fminf(ulo, (float)u); uhi = fmaxf(uhi, (float)u); vlo = fminf(vlo, (float)v); vhi = fmaxf(vhi, (float)v);
+    }
+    const double zi = Pi[6] * (0.5 * (ulo + uhi)) + Pi[7] * (0.5 * (vlo + vhi)) + Pi[8];
+    const double si = zi != 0.0 ? 1.0 / zi : 1.0;
+    for (int k = 0; k < 9; ++k) { sm.P[k] = (float)(P[k] * sp); sm.Pi[k] = (float)(Pi[k] * si); }
+    sm.ulo = ulo - 1.5f; sm.uhi = uhi + 1.5f; sm.vlo = vlo - 1.5f; sm.vhi = vhi + 1.5f;
 }
 
-// Stage A backward: g[n][3][Ha][Wa] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws]
-// (summed over n afterwards by reduce_planes_kernel: no cross-cutout atomic contention on the shared image)
+// Raw-coordinate intervals [a, b) whose padded coordinate can produce a tap on source index s (size W), clipped to
+// [lo, hi].  Returns the count (<= MAXI); intervals come out sorted, merged and pairwise disjoint.
+constexpr int MAXI = 6;
+__device__ __forceinline__ int tap_intervals(int mode, int s, int W, float lo, float hi, float* ia, float* ib) {
+    const float eps = 2e-3f;       // slack against the fp32 rounding of the forward's own coordinate arithmetic
+    int n = 0;
+    auto push = [&](float a, float b) {
+        a = fmaxf(a - eps, lo); b = fminf(b + eps, hi);
+        if (!(b > a)) return;
+        if (n == MAXI) { ia[0] = lo; ib[0] = hi; n = -1; return; }       // overflow: fall back to the whole range
+        ia[n] = a; ib[n] = b; ++n;
+    };
+    const float fs = (float)s, fW = (float)W;
+    if (mode == MODE_BORDER) {
+        push(s == 0 ? -INFINITY : fs - 1.f, s == W - 1 ? INFINITY : fs + 1.f);
+    } else if (mode == MODE_REFLECT) {              // align_corners=False: mirrors about -0.5 and W-0.5, period 2W
+        const float per = 2.f * fW;
+        const int j0 = (int)floorf((lo + 0.5f) / per) - 1, j1 = (int)floorf((hi + 0.5f) / per) + 1;
+        for (int j = j0; j <= j1 && n >= 0; ++j) {
+            const float c = per * (float)j;
+            push(fmaxf(c + fs - 1.f, c - 0.5f), fminf(c + fs + 1.f, c + fW - 0.5f));                          // upright image
+            if (n < 0) break;
+            push(fmaxf(c + per - fs - 2.f, c + fW - 0.5f), fminf(c + per - fs, c + per - 0.5f));              // mirrored image
+        }
+    } else if (mode == MODE_REFLECT_AC) {           // align_corners=True: mirrors about 0 and W-1, period 2(W-1)
+        const float span = fW - 1.f, per = 2.f * span;
+        if (span <= 0.f) push(lo, hi);
+        else {
+            const int j0 = (int)floorf(lo / per) - 1, j1 = (int)floorf(hi / per) + 1;
+            for (int j = j0; j <= j1 && n >= 0; ++j) {
+                const float c = per * (float)j;
+                push(fmaxf(c + fs - 1.f, c), fminf(c + fs + 1.f, c + span));
+                if (n < 0) break;
+                push(fmaxf(c + per - fs - 1.f, c + span), fminf(c + per - fs + 1.f, c + per));
+            }
+        }
+    } else {                                        // zeros / fill: out-of-range taps simply drop out
+        push(fs - 1.f, fs + 1.f);
+    }
+    if (n < 0) return 1;
+    // insertion sort + merge (the slack can make neighbours of adjacent mirror images overlap)
+    for (int i = 1; i < n; ++i)
+        for (int k = i; k > 0 && ia[k] < ia[k - 1]; --k) {
+            float t = ia[k]; ia[k] = ia[k - 1]; ia[k - 1] = t;
+            t = ib[k]; ib[k] = ib[k - 1]; ib[k - 1] = t;
+        }
+    int m = 0;
+    for (int i = 1; i < n; ++i) {
+        if (ia[i] <= ib[m]) ib[m] = fmaxf(ib[m], ib[i]);
+        else { ++m; ia[m] = ia[i]; ib[m] = ib[i]; }
+    }
+    return n > 0 ? m + 1 : 0;
+}
+
+// bounding box (inclusive, clipped to the destination image) of the pre-image of the raw rectangle [ua,ub) x [va,vb)
+__device__ __forceinline__ bool preimage_box(const StageMap& sm, float ua, float ub, float va, float vb, int Wd, int Hd,
+                                             int& x0, int& x1, int& y0, int& y1) {
+    float xl = INFINITY, xh = -INFINITY, yl = INFINITY, yh = -INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float u = (k & 1) ? ub : ua, v = (k & 2) ? vb : va;
+        const float z = sm.Pi[6] * u + sm.Pi[7] * v + sm.Pi[8];
+        if (!(z > 0.05f)) { bad = true; continue; }
+        const float iz = 1.f / z;
+        const float x = (sm.Pi[0] * u + sm.Pi[1] * v + sm.Pi[2]) * iz, y = (sm.Pi[3] * u + sm.Pi[4] * v + sm.Pi[5]) * iz;
+        xl = fminf(xl, x); xh = fmaxf(xh, x); yl = fminf(yl, y); yh = fmaxf(yh, y);
+    }
+    if (bad) { x0 = 0; x1 = Wd - 1; y0 = 0; y1 = Hd - 1; return true; }        // near the horizon: search everything
+    x0 = max((int)floorf(xl) - 1, 0); x1 = min((int)ceilf(xh) + 1, Wd - 1);
+    y0 = max((int)floorf(yl) - 1, 0); y1 = min((int)ceilf(yh) + 1, Hd - 1);
+    return x0 <= x1 && y0 <= y1;
+}
+
+// what one stage's gather needs to know
+struct GatherStage {
+    const double* m; int gtype, mode;
+    int Wd, Hd;            // destination plane
+    int Ws, Hs;            // source image the taps index (the stage-B window, or the whole stage-A source)
+    const float* g;        // destination-side gradient planes of this cutout, [3][Hd][Wd]
+};
+
+// contribution of destination pixel (x, y) to source pixel (sx, sy), if its raw coordinate lies in [ua,ub) x [va,vb)
+__device__ __forceinline__ void gather_candidate(const GatherStage& st, const StageMap& sm, int x, int y, int sx, int sy,
+                                                 float ua, float ub, float va, float vb, float (&acc)[3]) {
+    const float fx = (float)x, fy = (float)y;
+    const float z = sm.P[6] * fx + sm.P[7] * fy + sm.P[8];
+    const float iz = 1.f / z;
+    const float uq = (sm.P[0] * fx + sm.P[1] * fy + sm.P[2]) * iz, vq = (sm.P[3] * fx + sm.P[4] * fy + sm.P[5]) * iz;
+    const float tol = 0.02f;       // the screening map is fp32 and ignores the forward's fp32 grid rounding (<< 0.02 px)
+    if (!(uq >= ua - tol && uq < ub + tol && vq >= va - tol && vq < vb + tol)) return;
+    float u, v;
+    project(st.m, st.gtype, x, y, st.Wd, st.Hd, st.Ws, st.Hs, u, v);
+    if (!(u >= ua && u < ub && v >= va && v < vb)) return;
+    const Taps t = make_taps(u, v, st.Ws, st.Hs, st.mode);
+    const float e = 1.f - t.wx, s_ = 1.f - t.wy;
+    float w = 0.f;
+    if (t.vx0 && t.vy0 && t.x0 == sx && t.y0 == sy) w += s_ * e;
+    if (t.vx1 && t.vy0 && t.x0 + 1 == sx && t.y0 == sy) w += s_ * t.wx;
+    if (t.vx0 && t.vy1 && t.x0 == sx && t.y0 + 1 == sy) w += t.wy * e;
+    if (t.vx1 && t.vy1 && t.x0 + 1 == sx && t.y0 + 1 == sy) w += t.wy * t.wx;
+    if (w == 0.f) return;
+    const size_t o = (size_t)y * st.Wd + x, plane = (size_t)st.Hd * st.Wd;
+    acc[0] += st.g[o] * w; acc[1] += st.g[plane + o] * w; acc[2] += st.g[2 * plane + o] * w;
+}
+
+// All contributions to source pixel (sx, sy).  `coop`: the 64 lanes of the wave share the enumeration of ONE pixel (every
+// lane passes the same sx, sy) and the partial sums are combined by a fixed butterfly; otherwise the lane works alone.
+constexpr int HEAVY = 160;       // candidates above which a pixel is handed to the whole wave (border strips, corners)
+template <bool COOP>
+__device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMap& sm, int sx, int sy, float (&acc)[3], int budget) {
+    float xa[MAXI], xb[MAXI], ya[MAXI], yb[MAXI];
+    const int nx = tap_intervals(st.mode, sx, st.Ws, sm.ulo, sm.uhi, xa, xb);
+    const int ny = tap_intervals(st.mode, sy, st.Hs, sm.vlo, sm.vhi, ya, yb);
+    const int lane = threadIdx.x & 63;
+    int total = 0;
+    if (!COOP) {       // first pass: how much work is it?
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                int x0, x1, y0, y1;
+                if (preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) total += (x1 - x0 + 1) * (y1 - y0 + 1);
+            }
+        if (total > budget) return total;          // too much for one lane: the caller schedules a cooperative pass
+    }
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            int x0, x1, y0, y1;
+            if (!preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) continue;
+            const int bw = x1 - x0 + 1, cnt = bw * (y1 - y0 + 1);
+            if (COOP) {
+                for (int k = lane; k < cnt; k += 64)
+                    gather_candidate(st, sm, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+            } else {
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) gather_candidate(st, sm, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+            }
+        }
+    if (COOP) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    }
+    return total;
+}
+
+// one block = a 16 x 16 tile of SOURCE pixels of one cutout; out-of-tile / out-of-window pixels idle
+__device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMap& sm, int sx, int sy, bool live, float (&out)[3]) {
+    float acc[3] = {0.f, 0.f, 0.f};
+    int work = 0;
+    if (live) work = gather_pixel<false>(st, sm, sx, sy, acc, HEAVY);
+    // pixels that were too heavy for one lane (work > HEAVY: nothing accumulated yet): the wave takes them one by one
+    unsigned long long heavy = __ballot(live && work > HEAVY);
+    while (heavy) {
+        const int src = __ffsll((long long)heavy) - 1;
+        heavy &= heavy - 1;
+        const int hx = __shfl(sx, src, 64), hy = __shfl(sy, src, 64);
+        float a2[3] = {0.f, 0.f, 0.f};
+        gather_pixel<true>(st, sm, hx, hy, a2, 0);
+        if ((int)(threadIdx.x & 63) == src) { acc[0] = a2[0]; acc[1] = a2[1]; acc[2] = a2[2]; }
+    }
+    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+}
+
+constexpr int TILE_W = 16;
+
+// Stage A backward: g[n][3][Ha][Wa] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws] (every element written;
+// summed over n afterwards by reduce_planes_kernel in a fixed order)
 __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
                                                          const double* __restrict__ desc, float* __restrict__ gsrc,
                                                          int n_cut, int Ha, int Wa) {
-    __shared__ ScatterWin w;
-    const int tiles = (Wa + TILE_W - 1) / TILE_W;
+    __shared__ StageMap sm;
+    const int tiles = (Ws + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
-    const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
-    const int y = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
-    const bool valid = x < Wa && y < Ha;
-    const size_t plane = (size_t)Ha * Wa;
+    const int sx = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
+    const int sy = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const bool live = sx < Ws && sy < Hs;
     const double* d = desc + (size_t)n * DESC_WORDS;
     const int mode = (int)d[D_MODE1];
-    float* gs = gsrc + (size_t)n * 3 * Hs * Ws;
-    const float* gi = g + ((size_t)n * 3) * plane + (size_t)y * Wa + x;
-    if (mode == MODE_IDENT) {      // 1:1 copy: each source pixel has exactly one writer
-        if (valid) {
+    const size_t plane = (size_t)Ha * Wa, splane = (size_t)Hs * Ws;
+    const float* gi = g + (size_t)n * 3 * plane;
+    float* gs = gsrc + (size_t)n * 3 * splane + (size_t)sy * Ws + sx;
+    if (mode == MODE_IDENT) {      // 1:1 copy (Ha x Wa == Hs x Ws)
+        if (live) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gs[(size_t)c * Hs * Ws + (size_t)y * Ws + x] = gi[(size_t)c * plane];
+            for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = gi[(size_t)c * plane + (size_t)sy * Wa + sx];
         }
         return;
     }
-    Taps t{};
-    if (valid) {
-        float u, v;
-        project(d + D_M1, (int)d[D_GRID1], x, y, Wa, Ha, Ws, Hs, u, v);
-        t = make_taps(u, v, Ws, Hs, mode);
-    }
-    win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
-    if (valid) {
+    if (threadIdx.x == 0) build_stage_map(sm, d + D_M1, (int)d[D_GRID1], Wa, Ha, Ws, Hs);
+    __syncthreads();
+    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi};
+    float o[3];
+    gather_tile(st, sm, sx, sy, live, o);
+    if (live) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) win_scatter(w, gs + (size_t)c * Hs * Ws, Ws, c, t, gi[(size_t)c * plane]);
+        for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = o[c];
     }
-    win_flush(w, gs, Hs, Ws, Ws, (size_t)Hs * Ws);
 }
 
 // out[i] = sum_n planes[n][i]
@@ -479,60 +691,75 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void warp_b_bwd_kernel(const float* __restrict__ a, int Ha, int Wa, const double* __restrict__ desc,
-                                                         const float* __restrict__ g, float* __restrict__ ga, int n_cut,
-                                                         int S) {
-    __shared__ ScatterWin w;
+// Stage B backward, pass 1 (destination-parallel): the gradient w.r.t. the SAMPLED rgb of every output pixel, i.e. the
+// incoming gradient pulled back through the ColorJitter (forward-mode duals of kornia's rgb -> hsv -> rgb round trips).
+// Cutouts without jitter are skipped (pass 2 reads their incoming gradient directly).
+__global__ __launch_bounds__(256) void warp_b_jac_kernel(const float* __restrict__ a, int Ha, int Wa, const double* __restrict__ desc,
+                                                         const float* __restrict__ g, float* __restrict__ grgb, int n_cut, int S) {
     const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
-    const int tiles = (S + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
-    const int x = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
-    const int y = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
-    const bool valid = x < S && y < S;
     const double* d = desc + (size_t)n * DESC_WORDS;
+    if (d[D_JIT] == 0.0) return;
     const int mode = (int)d[D_MODE2];
     const SrcWin q = src_window(d);
     const float* an = a + (size_t)n * 3 * aplane + (size_t)q.oy * Wa + q.ox;
-    float* gan = ga + (size_t)n * 3 * aplane + (size_t)q.oy * Wa + q.ox;
-    const size_t pix = (size_t)y * S + x;
-    Taps t = ident_taps(valid ? x : 0, valid ? y : 0);
-    float grgb[3] = {0.f, 0.f, 0.f};
-    if (valid) {
-        float gin[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gin[c] = g[(size_t)n * 3 * plane + c * plane + pix];
-        grgb[0] = gin[0]; grgb[1] = gin[1]; grgb[2] = gin[2];
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < plane; pix += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % S), y = (int)(pix / S);
+        Taps t = ident_taps(x, y);
         if (mode != MODE_IDENT) {
             float u, v;
             project(d + D_M2, (int)d[D_GRID2], x, y, S, S, q.ww, q.wh, u, v);
             t = make_taps(u, v, q.ww, q.wh, mode);
         }
-        if (d[D_JIT] != 0.0) {
-            Dual<3> rgb[3];
-            const float fillc = fill_term(t, mode, d);
+        const float fillc = fill_term(t, mode, d);
+        Dual<3> rgb[3];
+        float gin[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                rgb[c] = cst<3>(sample_plane(an + c * aplane, Wa, t) + fillc);
-                rgb[c].d[c] = 1.f;
-            }
-            jitter_d<3>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) grgb[i] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
+        for (int c = 0; c < 3; ++c) {
+            rgb[c] = cst<3>(sample_plane(an + c * aplane, Wa, t) + fillc);
+            rgb[c].d[c] = 1.f;
+            gin[c] = g[(size_t)n * 3 * plane + c * plane + pix];
         }
-    }
-    if (mode == MODE_IDENT) {      // 1:1: one writer per source pixel (the rest of the stage-A gradient stays zero)
-        if (valid) {
+        jitter_d<3>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gan[c * aplane + (size_t)y * Wa + x] = grgb[c];
+        for (int i = 0; i < 3; ++i)
+            grgb[(size_t)n * 3 * plane + i * plane + pix] = gin[0] * rgb[0].d[i] + gin[1] * rgb[1].d[i] + gin[2] * rgb[2].d[i];
+    }
+}
+
+// pass 2 (source-parallel gather): ga[n][3][Ha][Wa], every element written (zero outside the stage-B source window)
+__global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
+                                                         const float* __restrict__ grgb, float* __restrict__ ga, int n_cut, int S) {
+    __shared__ StageMap sm;
+    const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
+    const int tiles = (Wa + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int ax = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);      // stage-A image coordinates
+    const int ay = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const bool inimg = ax < Wa && ay < Ha;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE2];
+    const SrcWin q = src_window(d);
+    const int sx = ax - q.ox, sy = ay - q.oy;                                // coordinates inside the source window
+    const bool live = inimg && sx >= 0 && sx < q.ww && sy >= 0 && sy < q.wh;
+    const float* gi = (d[D_JIT] != 0.0 ? grgb : g) + (size_t)n * 3 * plane;
+    float* go = ga + (size_t)n * 3 * aplane + (size_t)ay * Wa + ax;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (mode == MODE_IDENT) {      // output pixel (x, y) copies window pixel (x, y)
+        if (live && sx < S && sy < S) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = gi[(size_t)c * plane + (size_t)sy * S + sx];
         }
-        return;
+    } else {
+        if (threadIdx.x == 0) build_stage_map(sm, d + D_M2, (int)d[D_GRID2], S, S, q.ww, q.wh);
+        __syncthreads();
+        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi};
+        gather_tile(st, sm, sx, sy, live, o);
     }
-    win_begin(w, valid && (t.vx0 || t.vx1) && (t.vy0 || t.vy1), t);
-    if (valid) {
+    if (inimg) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) win_scatter(w, gan + c * aplane, Wa, c, t, grgb[c]);
+        for (int c = 0; c < 3; ++c) go[(size_t)c * aplane] = o[c];
     }
-    win_flush(w, gan, q.wh, q.ww, Wa, aplane);
 }
 
 // F.interpolate(bilinear, align_corners=False) of the pooled image [C,S,S] to the canvas aspect [C,Hb,Wb]
@@ -554,16 +781,39 @@ __global__ __launch_bounds__(256) void rescale_fwd_kernel(const float* __restric
         out[idx] = (1.f - wy) * ((1.f - wx) * q[y0 * S + x0] + wx * q[y0 * S + x1]) + wy * ((1.f - wx) * q[y1 * S + x0] + wx * q[y1 * S + x1]);
     }
 }
+// gather form of the rescale backward (one thread per pooled pixel; fixed order -> bit-reproducible): destination columns
+// whose two taps include source column sx are those with source coordinate in (sx-1, sx+1), a contiguous run
+__device__ __forceinline__ void rescale_run(int s, int in, int outn, int& o0, int& o1) {
+    const float sc = (float)outn / (float)in;
+    o0 = max((int)floorf(((float)s - 1.f + 0.5f) * sc - 0.5f) - 1, 0);
+    o1 = min((int)ceilf(((float)s + 1.f + 0.5f) * sc - 0.5f) + 1, outn - 1);
+}
 __global__ __launch_bounds__(256) void rescale_bwd_kernel(const float* __restrict__ g, float* __restrict__ gp, int C, int S, int Hb, int Wb) {
-    const size_t total = (size_t)C * Hb * Wb;
+    const size_t total = (size_t)C * S * S;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % Wb), y = (int)((idx / Wb) % Hb), c = (int)(idx / ((size_t)Hb * Wb));
-        int x0, x1, y0, y1; float wx, wy;
-        resize_taps(x, S, Wb, x0, x1, wx); resize_taps(y, S, Hb, y0, y1, wy);
-        float* q = gp + (size_t)c * S * S;
-        const float v = g[idx];
-        atomicAdd(&q[y0 * S + x0], v * (1.f - wy) * (1.f - wx)); atomicAdd(&q[y0 * S + x1], v * (1.f - wy) * wx);
-        atomicAdd(&q[y1 * S + x0], v * wy * (1.f - wx)); atomicAdd(&q[y1 * S + x1], v * wy * wx);
+        const int sx = (int)(idx % S), sy = (int)((idx / S) % S), c = (int)(idx / ((size_t)S * S));
+        int xa, xb, ya, yb;
+        rescale_run(sx, S, Wb, xa, xb); rescale_run(sy, S, Hb, ya, yb);
+        const float* q = g + (size_t)c * Hb * Wb;
+        float acc = 0.f;
+        for (int y = ya; y <= yb; ++y) {
+            int y0, y1; float wy;
+            resize_taps(y, S, Hb, y0, y1, wy);
+            const float cy = (y0 == sy ? (1.f - wy) : 0.f) + (y1 == sy ? wy : 0.f);
+            if (cy == 0.f) continue;
+            for (int x = xa; x <= xb; ++x) {
+                int x0, x1; float wx;
+                resize_taps(x, S, Wb, x0, x1, wx);
+                // the forward's weights: (1-wy)(1-wx), (1-wy)wx, wy(1-wx), wy wx on (y0,x0), (y0,x1), (y1,x0), (y1,x1)
+                float w = 0.f;
+                if (y0 == sy && x0 == sx) w += (1.f - wy) * (1.f - wx);
+                if (y0 == sy && x1 == sx) w += (1.f - wy) * wx;
+                if (y1 == sy && x0 == sx) w += wy * (1.f - wx);
+                if (y1 == sy && x1 == sx) w += wy * wx;
+                if (w != 0.f) acc += q[(size_t)y * Wb + x] * w;
+            }
+        }
+        gp[idx] = acc;
     }
 }
 
@@ -724,8 +974,7 @@ int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned ch
     return 0;
 }
 int prx_pool_bwd(const float* g, const int* argmax, const unsigned char* mask, float* gimg, int C, int H, int W, int S, hipStream_t s) {
-    PRX_CHECK_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * C * H * W, s));
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, g, argmax, mask, gimg, C, H, W, S);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid((size_t)C * H * W)), dim3(256), 0, s, g, argmax, mask, gimg, C, H, W, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -737,9 +986,8 @@ int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* 
 }
 int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,
                    hipStream_t s) {
-    // gsrc_priv: [n_cut][3][Hs][Ws] per-cutout private planes (scratch); gsrc: [3][Hs][Ws] their sum
-    PRX_CHECK_HIP(hipMemsetAsync(gsrc_priv, 0, sizeof(float) * (size_t)n_cut * 3 * Hs * Ws, s));
-    const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
+    // gsrc_priv: [n_cut][3][Hs][Ws] per-cutout private planes (scratch, every element written); gsrc: [3][Hs][Ws] their sum
+    const int tx = (Ws + TILE_W - 1) / TILE_W, ty = (Hs + TILE_W - 1) / TILE_W;
     hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, gsrc_priv, n_cut, Ha, Wa);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
@@ -754,10 +1002,14 @@ int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const flo
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* ga, int n_cut, int S, hipStream_t s) {
-    PRX_CHECK_HIP(hipMemsetAsync(ga, 0, sizeof(float) * (size_t)n_cut * 3 * Ha * Wa, s));
-    const int tiles = (S + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tiles * tiles, n_cut), dim3(256), 0, s, a, Ha, Wa, desc, g, ga, n_cut, S);
+int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* ga, int n_cut, int S,
+                   hipStream_t s) {
+    // grgb: [n_cut][3][S][S] scratch (the gradient pulled back through the ColorJitter); ga: [n_cut][3][Ha][Wa], every element written
+    hipLaunchKernelGGL(warp_b_jac_kernel, dim3(std::min(ew_grid((size_t)S * S), 64), n_cut), dim3(256), 0, s, a, Ha, Wa, desc, g, grgb,
+                       n_cut, S);
+    PRX_LAUNCH_CHECK();
+    const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
+    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, ga, n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -767,8 +1019,7 @@ int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int 
     return 0;
 }
 int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s) {
-    PRX_CHECK_HIP(hipMemsetAsync(g_pooled, 0, sizeof(float) * (size_t)C * S * S, s));
-    hipLaunchKernelGGL(rescale_bwd_kernel, dim3(ew_grid((size_t)C * Hb * Wb)), dim3(256), 0, s, g_base, g_pooled, C, S, Hb, Wb);
+    hipLaunchKernelGGL(rescale_bwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, g_base, g_pooled, C, S, Hb, Wb);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,24 @@ from . import ops
 
 DESC_WORDS = 32
 MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL, MODE_REFLECT_AC = 0, 1, 2, 3, 4, 5
-GRID_MESH, GRID_AFFINE = 0, 1
+GRID_MESH, GRID_AFFINE, GRID_AFFINE_AC, GRID_MESH_AC = 0, 1, 2, 3
+
+# The align_corners flag each kornia 0.6.2 call of the reference's augmentation stack hands to F.grid_sample (kornia is not
+# vendored: from the published 0.6.2 sources, parity unpinned -- the table is restated in oracle/cutouts_ref.py with the
+# kornia definitions it follows).  The flag is DATA here: it selects the grid flavour written into the descriptor, and the
+# kernel follows whatever the descriptor says (tests/test_path_gpu.py::test_cutout_align_corners_convention_is_a_descriptor_field).
+KORNIA_062_CONVENTIONS = {
+    "perspective_align_corners": False,   # K.RandomPerspective(align_corners=False) -> pixray.py:333-334, 363 pass the flag on
+    "affine_align_corners": False,        # K.RandomAffine(align_corners=False)      -> pixray.py:349
+    "crop_align_corners": True,           # K.RandomResizedCrop / K.CenterCrop(align_corners=True): crop_by_transform_mat -> warp_affine
+    "cached_align_corners": True,         # kornia.geometry.transform.warp_perspective(..., align_corners=True) default, pixray.py:482-485
+}
+
+
+def _grid(kind: str, align_corners: bool) -> int:
+    if kind == "mesh":
+        return GRID_MESH_AC if align_corners else GRID_MESH
+    return GRID_AFFINE_AC if align_corners else GRID_AFFINE
 
 
 def _uniform(gen, shape, lo=0.0, hi=1.0):
@@ -144,16 +161,18 @@ def _np(t):
     return t.detach().cpu().numpy().astype(np.float64) if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)
 
 
-def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
+def build_descriptors(p: Dict[str, torch.Tensor], S: int, conventions: Optional[Dict[str, bool]] = None) -> torch.Tensor:
     """[cutn, 32] fp64 descriptor table for prx_cutouts_forward (layout: include/prx.h).
 
     Each stage carries kornia's `src_norm_trans_dst_norm` 3x3 (the inverse of normalize_homography(M) with
     the [0, W-1] -> [-1, 1] convention) plus the grid flavour that produced the sampling grid in kornia 0.6.2:
-      GRID_MESH   (warp_perspective): create_meshgrid(normalized) + transform_points, then F.grid_sample
-      GRID_AFFINE (warp_affine)     : F.affine_grid(theta = first two rows, rounded to fp32), then F.grid_sample
-    both sampled with align_corners=False (the augmentation flag the reference passes, pixray.py:333-334,349,363).
-    The kernel evaluates the grid with the same precision steps, so tap positions round like the oracle's.
-    (numpy float64 on the host: ~0.3 ms for 64 cutouts.)"""
+      GRID_MESH[_AC]   (warp_perspective): create_meshgrid(normalized) + transform_points, then F.grid_sample
+      GRID_AFFINE[_AC] (warp_affine)     : F.affine_grid(theta = first two rows, rounded to fp32), then F.grid_sample
+    where _AC = that call's align_corners flag was True (`conventions`, default KORNIA_062_CONVENTIONS: the perspective and
+    affine augmentations pass False, the resized / centre crops True).  The kernel evaluates the grid with the same
+    precision steps, so tap positions round like the oracle's.  (numpy float64 on the host: ~0.3 ms for 64 cutouts.)"""
+    cv = dict(KORNIA_062_CONVENTIONS, **(conventions or p.get("conventions") or {}))
+    ac_p, ac_a, ac_c = bool(cv["perspective_align_corners"]), bool(cv["affine_align_corners"]), bool(cv["crop_align_corners"])
     cutn = int(p["cutn"])
     nz = int(0.6 * cutn)
     nw = cutn - nz
@@ -180,9 +199,9 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         end = start + persp_offsets(p["z_persp_rand"], 0.4, Hb, Wb)
         app = _np(p["z_persp_apply"]) != 0
         desc[:nz, 0:9] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), (Hb, Wb)).reshape(nz, 9), eye[None])
-        pad = MODE_REFLECT if int(p["reflect"]) else MODE_BORDER
+        pad = (MODE_REFLECT_AC if ac_p else MODE_REFLECT) if int(p["reflect"]) else MODE_BORDER
         desc[:nz, 18] = np.where(app, float(pad), float(MODE_IDENT))
-        desc[:nz, 26] = GRID_MESH
+        desc[:nz, 26] = _grid("mesh", ac_p)
         crop = _np(p["z_crop"])
         xs, ys, w, h = crop[:, 0], crop[:, 1], crop[:, 2], crop[:, 3]
         src = np.stack([np.stack([xs, ys], 1), np.stack([xs + w - 1, ys], 1),
@@ -191,7 +210,7 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         Mc[:, 2, :] = (0.0, 0.0, 1.0)                                      # warp_affine drops the last row
         desc[:nz, 9:18] = affine_theta(Mc, (Hb, Wb), (S, S))
         desc[:nz, 19] = MODE_ZEROS
-        desc[:nz, 27] = GRID_AFFINE
+        desc[:nz, 27] = _grid("affine", ac_c)       # RandomResizedCrop(cropping_mode='resample') -> crop_by_transform_mat
         desc[:nz, 21] = _np(p["z_jit_apply"])
         desc[:nz, 22] = _np(p["z_sat"])
         desc[:nz, 23] = (p["z_hue"].float() * (2.0 * math.pi)).double().numpy()   # kornia: hue_factor * 2*pi in fp32
@@ -206,7 +225,7 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         Ma[:, 1, 2] = (1 - sc) * cy + tr[:, 1]
         desc[nz:, 0:9] = affine_theta(Ma, (Hb, Wb))
         desc[nz:, 18] = MODE_FILL
-        desc[nz:, 26] = GRID_AFFINE
+        desc[nz:, 26] = _grid("affine", ac_a)
         # ... except the wide set on a non-square canvas: CenterCrop(S) (pixray.py:433) = the centred S x S window
         desc[nz:, 28:32] = (float((Wb - S) // 2), float((Hb - S) // 2), float(S), float(S))
         start = _corners(S, nw)
@@ -214,7 +233,7 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
         app = _np(p["w_persp_apply"]) != 0
         desc[nz:, 9:18] = np.where(app[:, None], _src_norm_from_dst_norm(_dlt(start, end), S).reshape(nw, 9), eye[None])
         desc[nz:, 19] = np.where(app, float(MODE_FILL), float(MODE_IDENT))
-        desc[nz:, 27] = GRID_MESH
+        desc[nz:, 27] = _grid("mesh", ac_p)
         desc[nz:, 21] = _np(p["w_jit_apply"])
         desc[nz:, 22] = _np(p["w_sat"])
         desc[nz:, 23] = (p["w_hue"].float() * (2.0 * math.pi)).double().numpy()
@@ -224,17 +243,19 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int) -> torch.Tensor:
 
 
 def build_cached_descriptors(live: torch.Tensor, cutn: int, S: int, reflect: bool, fill: float, noise_fac: torch.Tensor,
-                             aspect: float = 1.0) -> torch.Tensor:
+                             aspect: float = 1.0, conventions: Optional[Dict[str, bool]] = None) -> torch.Tensor:
     """Descriptor table of the reference's CACHED-transform path (pixray.py:480-486): when `.transforms` is set (second
     and later calls inside one iteration: image prompts, pixray.py:1318-1333) the (aspect-rescaled) pooled image is
     warped ONCE with the composed 3x3 of the augmentation stages, `kornia.warp_perspective(x, T, (S,S),
-    padding_mode=...)` with kornia 0.6.2's default `align_corners=True` [UPSTREAM], zoom set padded by the iteration's
-    reflection/border mode, wide set filled with the iteration's gray; no ColorJitter; fresh noise.
+    padding_mode=...)` with kornia 0.6.2's function default `align_corners=True` [UPSTREAM] (`conventions[
+    "cached_align_corners"]`), zoom set padded by the iteration's reflection/border mode, wide set filled with the
+    iteration's gray; no ColorJitter; fresh noise.
 
     `live` = the live descriptor table of this iteration.  Stage A degenerates to a copy of the base image and stage B
     carries the composed map: M1 @ C @ M2 with C = the change of normalised coordinates between the stage-B source
-    window and the stage-A image.  Scaling its rows by (Wb-1)/Wb and (Hb-1)/Hb turns the kernel's align_corners=False
-    pixel mapping `(g+1)*W/2 - 0.5` into align_corners=True's `(g+1)*(W-1)/2`."""
+    window and the stage-A image, sampled with the GRID_MESH flavour of the cached call's align_corners flag."""
+    cv = dict(KORNIA_062_CONVENTIONS, **(conventions or {}))
+    ac = bool(cv["cached_align_corners"])
     t = live.double().numpy()
     Hb, Wb = base_size(S, aspect)
     M1 = t[:, 0:9].reshape(-1, 3, 3)
@@ -246,19 +267,17 @@ def build_cached_descriptors(live: torch.Tensor, cutn: int, S: int, reflect: boo
         shift = np.array([[1.0, 0.0, ox], [0.0, 1.0, oy], [0.0, 0.0, 1.0]])
         C[i] = _norm_pixel(Hb, Wb) @ shift @ np.linalg.inv(_norm_pixel(int(wh), int(ww)))
     M = M1 @ C @ M2
-    M[:, 0, :] *= (Wb - 1.0) / Wb
-    M[:, 1, :] *= (Hb - 1.0) / Hb
     nz = int(0.6 * cutn)
     desc = np.zeros((cutn, DESC_WORDS))
     desc[:, 0:9] = np.eye(3).reshape(9)
     desc[:, 18] = MODE_IDENT
     desc[:, 9:18] = M.reshape(-1, 9)
-    desc[:nz, 19] = MODE_REFLECT_AC if reflect else MODE_BORDER
+    desc[:nz, 19] = (MODE_REFLECT_AC if ac else MODE_REFLECT) if reflect else MODE_BORDER
     desc[nz:, 19] = MODE_FILL
     desc[:, 20] = float(fill)
     desc[:, 25] = _np(noise_fac)
     desc[:, 26] = GRID_MESH
-    desc[:, 27] = GRID_MESH
+    desc[:, 27] = _grid("mesh", ac)
     desc[:, 28:32] = (0.0, 0.0, float(Wb), float(Hb))
     return torch.from_numpy(desc)
 
@@ -315,6 +334,7 @@ class MakeCutouts(nn.Module):
         self.fill = None           # gray fill for this call (pixray.py:1255-1258); drawn if None
         self.last_params = None
         self.fixed_params = None   # tests / parity: use these draws instead of sampling
+        self.conventions = None    # overrides of KORNIA_062_CONVENTIONS (which align_corners flag each kornia call passes)
 
     # -- host part: draw this iteration's parameters and stage the descriptor table ---------------------------------
     def enable_static_buffers(self, device):
@@ -333,7 +353,7 @@ class MakeCutouts(nn.Module):
         prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
             self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill, aspect=self.aspect_width)
         self.last_params = prm
-        desc = build_descriptors(prm, S)
+        desc = build_descriptors(prm, S, self.conventions)
         self.transforms = desc          # this iteration's geometry (opaque, like the reference's composed 3x3 cache)
         lo, hi = (0, self.cutn) if self.shard is None else self.shard
         if getattr(self, "_static_desc", None) is not None:
@@ -360,7 +380,8 @@ class MakeCutouts(nn.Module):
             prm = self.last_params
             asp = float(prm["aspect"]) if "aspect" in prm else 1.0
             facs = _uniform(self.generator, (self.cutn,), 0.0, self.noise_fac).float()
-            desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp)
+            desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp,
+                                            self.conventions)
             noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32) if self.noise_fac else None
             return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S, base_size(S, asp), spot_mask)
         if not getattr(self, "_prepared", False):

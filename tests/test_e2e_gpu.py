@@ -395,6 +395,60 @@ def test_config2_vqgan512_vitb16_rn50x4_ensemble_runs():
     assert torch.isfinite(sess.drawer.get_z()).all()
 
 
+def test_config2_at_the_per_gpu_shard_size_vs_oracle():
+    """BASELINE.json configs[2] at the size one of its 8 GPUs runs: the 512x512 decoder (latent 32x32) + the full ViT-B/16
+    and RN50x4 towers on a 16-cutout shard each.  dL/dz of the exact-f32 mode against the CPU oracle meets the f32 gate;
+    the bf16 fast path is stated against both."""
+    from oracle import workload_ref
+    r = workload_ref.compare_workload("cfg2", 16, precisions=("f32", "bf16"))
+    print("cfg2 @16:", r)
+    assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
+    assert r["f32"]["grad_rel_l2"] < 1e-3 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
+    assert r["bf16"]["grad_rel_l2"] < 8e-2 and r["bf16"]["grad_cosine"] > 0.997, r["bf16"]
+
+
+def test_config3_at_the_per_gpu_shard_size_vs_oracle():
+    """BASELINE.json configs[3] at the size one of 8 GPUs runs: fft drawer 512x512 + the full-width ViT-L/14 (1024 x 24 layers,
+    257 tokens) on a 32-cutout shard + the batch-coupled SaturationLoss; gradient w.r.t. the drawer's spectrum.  (The
+    StyleLoss term is checked on its own below: 27 VGG16 passes on a 512x512 image are minutes on the CPU oracle.)"""
+    import bench
+    from oracle import workload_ref
+    r = workload_ref.compare_workload("cfg3", 32, precisions=("f32", "bf16"),
+                                      custom_factory=lambda prec: [{"loss": bench.make_saturation_loss(DEV), "weight": 1.0}],
+                                      custom_ref=[{"loss": workload_ref.SaturationLossRef(), "weight": 1.0}])
+    print("cfg3 @32:", r)
+    assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
+    assert r["f32"]["grad_rel_l2"] < 1e-3 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
+    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]
+
+
+def test_config3_styleloss_term_at_512_bf16_vs_f32_extractor():
+    """the StyleLoss term of configs[3] at its own size (512x512 image): the bf16 VGG16 extractor against the exact-f32 one on
+    the device, same numpy seed -> same sampled hyper-column positions"""
+    import warnings
+    from pixray_amd import style_loss as sl
+    params = weights.synthetic_vgg16_params(0)
+    g = torch.Generator().manual_seed(8)
+    low = torch.rand(1, 3, 64, 64, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(512, 512), mode="bilinear", align_corners=False).clamp(0, 1)
+    style = torch.rand(1, 3, 384, 448, generator=g)
+    vals, grads = {}, {}
+    for prec in ("f32", "bf16"):
+        x = img.clone().to(DEV).requires_grad_(True)
+        ex = sl.Vgg16Extractor(params=params, device=DEV, max_hw=(512, 512), precision=prec)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            np.random.seed(3)
+            l = sl.strotss_loss(x, style.to(DEV), 16.0, extractor=ex)
+        (gx,) = torch.autograd.grad(l, x)
+        vals[prec], grads[prec] = float(l.detach()), gx.detach().cpu()
+    a, b = grads["bf16"].flatten(), grads["f32"].flatten()
+    cs = float(a @ b / (a.norm() * b.norm()))
+    print("cfg3 style term @512: value f32", vals["f32"], "bf16", vals["bf16"], "grad cos", cs)
+    assert abs(vals["bf16"] - vals["f32"]) < 3e-2 * abs(vals["f32"])
+    assert cs > 0.9
+
+
 def test_fft_drawer_plugin_on_the_hip_path():
     """BASELINE.json configs[3] shape at small size: a spectrum drawer plugin (own optimiser, no z) + a custom loss stack
     feeding the HIP cutouts / tower / loss; its image gradient comes back through torch.fft"""

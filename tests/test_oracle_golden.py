@@ -159,3 +159,32 @@ def test_oracle_vs_hf_live():
         ref = m(pixel_values=x).image_embeds
         out = clip_vit_ref.vit_forward(p, x, patch=32, heads=12, layers=2)
     assert rel(out, ref) < 1e-5
+
+
+def test_cutout_oracle_crop_convention_is_the_exact_pixel_map():
+    """kornia 0.6.2 resamples RandomResizedCrop / CenterCrop with align_corners=True (oracle/cutouts_ref.py table): the crop
+    of box (xs, ys, w, h) to S x S is then the EXACT pixel map x_src = xs + i (w-1)/(S-1), so a full-size box is a bit-exact
+    copy and an integer-aligned half-size box reproduces the source pixels at every other output position.  With the flag
+    False (what round 1 of this repository assumed) neither holds."""
+    import torch
+    from oracle import cutouts_ref
+    from pixray_amd import cutouts as pc
+    S, cutn = 33, 5                      # nz = 3 zoom cutouts
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(1, 3, S, S, generator=g)            # pooling an S x S image to S x S is the identity
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=0)
+    prm["z_persp_apply"][:] = False
+    prm["z_jit_apply"][:] = False
+    prm["z_crop"] = torch.tensor([[0.0, 0.0, S, S], [4.0, 6.0, 17.0, 17.0], [0.0, 0.0, S, S]], dtype=torch.float64)
+    out = cutouts_ref.make_cutouts(img, prm, S)
+    assert torch.equal(out[0], img[0]) and torch.equal(out[2], img[0])
+    # box of 17 source pixels onto 33 output pixels: output 2k sits exactly on source pixel 4 + k / 6 + k
+    assert torch.allclose(out[1][:, ::2, ::2], img[0][:, 6:23, 4:21], atol=1e-6)
+    wrong = cutouts_ref.make_cutouts(img, prm, S, conventions={"crop_align_corners": False})
+    assert torch.allclose(wrong[0], img[0], atol=1e-4)       # an identity map stays an identity under either flag ...
+    assert not torch.allclose(wrong[1][:, ::2, ::2], img[0][:, 6:23, 4:21], atol=1e-3)      # ... a real crop is not
+    # the product's descriptor builder writes the same convention into the table (grid flavour words 26 / 27)
+    d = pc.build_descriptors(prm, S)
+    assert int(d[0, 27]) == pc.GRID_AFFINE_AC and int(d[0, 26]) == pc.GRID_MESH and int(d[4, 26]) == pc.GRID_AFFINE
+    d2 = pc.build_descriptors(prm, S, conventions={"crop_align_corners": False, "perspective_align_corners": True})
+    assert int(d2[0, 27]) == pc.GRID_AFFINE and int(d2[0, 26]) == pc.GRID_MESH_AC and int(d2[4, 27]) == pc.GRID_MESH_AC

@@ -83,6 +83,35 @@ def test_make_cutouts_vs_oracle(cutn, S, HW, it, kind):
         assert cosine(gd, gref) > 0.9998
 
 
+@pytest.mark.parametrize("flip", ["crop_align_corners", "perspective_align_corners", "affine_align_corners"])
+def test_cutout_align_corners_convention_is_a_descriptor_field(flip):
+    """which align_corners flag each kornia call passes (oracle/cutouts_ref.py table) is DATA in the descriptor, not an
+    assumption baked into the kernel: flip one convention on both sides and the HIP kernel follows the oracle again, forward
+    and backward, while the two conventions themselves give visibly different cutouts"""
+    cutn, S, HW = 10, 224, 256
+    g = torch.Generator().manual_seed(77)
+    img = _test_image("smooth", HW, g)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=0)
+    prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    gout = torch.randn(cutn, 3, S, S, generator=g)
+    outs = {}
+    for value in (pc.KORNIA_062_CONVENTIONS[flip], not pc.KORNIA_062_CONVENTIONS[flip]):
+        cv = {flip: value}
+        img_ref = img.clone().requires_grad_(True)
+        ref = cutouts_ref.make_cutouts(img_ref, prm, S, conventions=cv)
+        (gref,) = torch.autograd.grad(ref, img_ref, gout)
+        mk = pc.MakeCutouts(S, cutn)
+        mk.fixed_params = prm
+        mk.conventions = cv
+        img_d = img.to(DEV).requires_grad_(True)
+        out = mk(img_d)
+        (gd,) = torch.autograd.grad(out, img_d, gout.to(DEV))
+        assert rel_l2(out, ref) < 1e-5, (flip, value, rel_l2(out, ref))
+        assert rel_l2(gd, gref) < 3e-3, (flip, value, rel_l2(gd, gref))
+        outs[value] = out.detach().cpu()
+    assert rel_l2(outs[True], outs[False]) > 1e-3          # the convention matters: a half-pixel-class resampling difference
+
+
 def test_make_cutouts_shard_matches_full():
     """cutout sharding: slices of the batch equal the same rows of the full batch"""
     cutn, S = 16, 224
