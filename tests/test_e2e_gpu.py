@@ -204,6 +204,39 @@ def test_cutout_shards_reproduce_the_unsharded_gradient():
     assert rel(x2.grad, g_full) < 2e-3, rel(x2.grad, g_full)
 
 
+def test_rccl_code_path_with_a_one_rank_group():
+    """the product's N > 1 branches on the HIP tensors -- min/max all-reduce -> encode -> renorm-gradient all-reduce in
+    ops._ClipEncodeFn, the global `Prompt.denom`, the dL/d(image) all-reduce hook of the engine -- driven through RCCL with a
+    1-rank group inside this process (one GPU is what the test box has): same loss, bit-identical dL/dz as the plain path"""
+    import socket
+    import torch.distributed as dist
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        kw = dict(size=(64, 64), vqgan_model="tiny_f4", clip_model="tiny-B/32", num_cuts=8, seed=3)
+        a = api.build_vqgan_clip_session(**kw)
+        b = api.build_vqgan_clip_session(**kw, group=dist.group.WORLD, rank=0, world_size=1)
+        for p_ in b.perceptors.values():
+            p_.group = dist.group.WORLD
+        b._force_hook_group = dist.group.WORLD
+        for pms in b.pmsTable.values():
+            for pm in pms:
+                pm.denom = float(8 * pm.embed.shape[0])          # what Session._shard_cutouts sets when world_size > 1
+        for s2 in (a, b):
+            for mk in s2.cutoutsTable.values():
+                mk.noise_fac = 0.0
+        for it in range(2):
+            a.train(it); b.train(it)
+            assert torch.equal(sum(l.detach() for l in a.last_losses), sum(l.detach() for l in b.last_losses))
+            assert torch.equal(a.drawer.get_z().grad, b.drawer.get_z().grad)
+            assert torch.equal(a.drawer.get_z(), b.drawer.get_z())
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_hipgraph_replay_matches_eager_launches():
     """the captured-and-replayed iteration is the same computation as the eagerly launched one (teacher-forced:
     the loop is chaotic, so both sessions start every step from the same z and Adam moments)"""
