@@ -1,7 +1,10 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) into HBM bytes per
 kernel family, per iteration and per launch.
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <iterations> <out.csv>
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <iterations> <out.csv> [<out.json>]
+
+The optional JSON ({"bytes_per_launch", ...} of the GEMM engine) is what bench.py quotes as `roofline.traffic_pmc_profile`
+when it is committed as profiles/r02_<config>_hbm_traffic.json.
 
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): the counters are reported in KiB;
 FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so the corrected fetch doubles it."""
@@ -56,3 +59,14 @@ with open(dst, "w") as out:
         wmb = wk * 1024 / 1e6 / iters
         out.write(f"\"{fam}\",{n},{fk:.0f},{fmb:.1f},{wmb:.1f},{n / iters:.1f},{(fmb + wmb) / (n / iters):.2f}\n")
 print(open(dst).read())
+if len(sys.argv) > 5:
+    import json
+    fam = FAMILIES[0][0]
+    n, fk = f[fam]
+    _, wk = w[fam]
+    if n:
+        json.dump({"kernel_family": fam, "iterations_in_trace": iters, "launches_per_iter": n / iters,
+                   "fetch_bytes_per_iter_corrected": 2.0 * fk * 1024 / iters, "write_bytes_per_iter": wk * 1024 / iters,
+                   "bytes_per_launch": (2.0 * fk + wk) * 1024 / n,
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the bench.py command; KiB units; "
+                             "FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md"}, open(sys.argv[5], "w"), indent=1)
