@@ -213,10 +213,14 @@ int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const 
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
  *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination
  *          coords -> normalised source coords, [0,W-1]->[-1,1] convention),
- *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill),
+ *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill, 5 reflection under align_corners=True),
  *   [20] fill gray, [21] jitter on/off, [22] saturation factor, [23] hue shift (rad), [24] saturation-first,
- *   [25] noise factor, [26]/[27] stage-A/B grid flavour (0 = create_meshgrid + transform_points as in
- *   kornia warp_perspective, 1 = F.affine_grid as in kornia warp_affine),
+ *   [25] noise factor, [26]/[27] stage-A/B grid flavour = which kornia 0.6.2 call built the sampling grid AND the
+ *   align_corners flag that call hands to F.grid_sample (the convention is data, pixray_amd.cutouts.KORNIA_062_CONVENTIONS):
+ *   0 warp_perspective(align_corners=False): create_meshgrid + transform_points, sampled with (g+1)*W/2-0.5 (RandomPerspective);
+ *   1 warp_affine(align_corners=False): F.affine_grid pixel-centre grid (RandomAffine); 2 warp_affine(align_corners=True):
+ *   corner-aligned grid sampled with (g+1)/2*(W-1) (RandomResizedCrop / CenterCrop via crop_by_transform_mat);
+ *   3 warp_perspective(align_corners=True) (the cached-transform path, pixray.py:482-485),
  *   [28..31] stage-B source window (x, y, width, height) inside the stage-A image.
  * Geometry: the canvas is pooled to [3,S,S] (pixray.py:463); on a W != H canvas the reference rescales that to the
  * canvas aspect (pixray.py:468-472): the "base" image [3,Hb,Wb] with Hb == S or Wb == S (Hb = Wb = S on a square
@@ -227,10 +231,12 @@ int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const 
 int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, const unsigned char* spot_mask,
                         int n_cut, int S, int Hb, int Wb, float* pooled, int* argmax, float* base, float* stage_a, float* out,
                         prx_stream_t s);
-/* scratch: g_stage_a and g_base_priv are [n_cut,3,Hb,Wb] fp32 each, g_base is [3,Hb,Wb], g_pooled is [3,S,S] */
+/* scratch: g_stage_a and g_base_priv are [n_cut,3,Hb,Wb] fp32 each, uv_scratch is [n_cut,Hb*Wb,2] fp32 (the forward's sampling
+ * coordinates, recomputed per stage), g_base is [3,Hb,Wb], g_pooled is [3,S,S].  The backward is in
+ * gather form (every source pixel sums its contributions in a fixed order): no atomics, bit-reproducible (cf. pixray.py:29). */
 int prx_cutouts_backward(const float* g_out, const double* desc, const unsigned char* spot_mask, int n_cut, int S, int Hb, int Wb,
-                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base,
-                         float* g_pooled, float* g_img, prx_stream_t s);
+                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* uv_scratch,
+                         float* g_base, float* g_pooled, float* g_img, prx_stream_t s);
 
 /* --- CLIP_Base.encode_image (slip.py:62-66) for a ViT visual tower [UPSTREAM clip/model.py].
  * weights[]: fp32 device tensors in OpenAI state-dict order under `visual.`:

@@ -133,19 +133,33 @@ def _oracle_inputs(vqgan_model, clip_model, seed):
     return vq_cfg, clip_cfg, vq_params, clip_params
 
 
+JITTER = True     # tests switch the ColorJitter off to separate its (discontinuous) Jacobian from everything else
+
+
 def _draws(cutn, S, seed, iteration, with_noise=True, aspect=1.0):
     from pixray_amd import cutouts as pc
     g = torch.Generator().manual_seed(5000 + 17 * seed + iteration)
     prm = pc.sample_cutout_params(cutn, S, g, iteration=iteration, aspect=aspect)
     if with_noise:
         prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    if not JITTER:
+        prm["z_jit_apply"][:] = False
+        prm["w_jit_apply"][:] = False
     return prm
 
 
 def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                          device="cuda:0", precision="bf16") -> Dict[str, float]:
+                          device="cuda:0", precision="bf16", jitter=True) -> Dict[str, float]:
     """dL/dz (and the intermediate image / embeddings / loss) of the HIP path vs the oracle after ONE iteration.
-    `precision`: "bf16" (the fast path) or "f32" (the exact-f32 MFMA parity mode)."""
+    `precision`: "bf16" (the fast path) or "f32" (the exact-f32 MFMA parity mode); `jitter=False` draws the same
+    augmentations with the ColorJitter switched off."""
+    global JITTER
+    if not jitter:
+        JITTER = False
+        try:
+            return compare_one_iteration(vqgan_model, clip_model, size, cutn, seed, device, precision)
+        finally:
+            JITTER = True
     from pixray_amd import api
     sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, precision=precision)
     vq_cfg, clip_cfg, vq_params, clip_params = _oracle_inputs(vqgan_model, clip_model, seed)

@@ -93,15 +93,15 @@ int prx_cutouts_forward(const float* img, int H, int W, const double* desc, cons
     return prx_warp_b_fwd(stage_a, Hb, Wb, desc, noise, out, n_cut, S, S_(s));
 }
 int prx_cutouts_backward(const float* g_out, const double* desc, const unsigned char* spot_mask, int n_cut, int S, int Hb, int Wb,
-                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* g_base, float* g_pooled, float* g_img,
-                         prx_stream_t s) {
-    PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_base_priv && g_base && g_pooled && g_img,
+                         int H, int W, const float* stage_a, const int* argmax, float* g_stage_a, float* g_base_priv, float* uv_scratch,
+                         float* g_base, float* g_pooled, float* g_img, prx_stream_t s) {
+    PRX_REQUIRE(g_out && desc && stage_a && argmax && g_stage_a && g_base_priv && uv_scratch && g_base && g_pooled && g_img,
                 "prx_cutouts_backward: null argument");
     int r;
     // g_base_priv doubles as the [n_cut,3,S,S] scratch of the ColorJitter pull-back (S <= Hb, Wb) before stage A overwrites it
-    if ((r = prx_warp_b_bwd(stage_a, Hb, Wb, desc, g_out, g_base_priv, g_stage_a, n_cut, S, S_(s)))) return r;
+    if ((r = prx_warp_b_bwd(stage_a, Hb, Wb, desc, g_out, g_base_priv, uv_scratch, g_stage_a, n_cut, S, S_(s)))) return r;
     const bool rect = Hb != S || Wb != S;
-    if ((r = prx_warp_a_bwd(g_stage_a, Hb, Wb, desc, g_base_priv, rect ? g_base : g_pooled, n_cut, Hb, Wb, S_(s)))) return r;
+    if ((r = prx_warp_a_bwd(g_stage_a, Hb, Wb, desc, uv_scratch, g_base_priv, rect ? g_base : g_pooled, n_cut, Hb, Wb, S_(s)))) return r;
     if (rect && (r = prx_rescale_bwd(g_base, g_pooled, 3, S, Hb, Wb, S_(s)))) return r;
     return prx_pool_bwd(g_pooled, argmax, spot_mask, g_img, 3, H, W, S, S_(s));
 }

@@ -5,12 +5,12 @@ int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned ch
 int prx_pool_bwd(const float* g, const int* argmax, const unsigned char* mask, float* gimg, int C, int H, int W, int S, hipStream_t s);
 // stage A renders Ha x Wa images from the shared Hs x Ws source; stage B reads them through the descriptor's window
 int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* out, int n_cut, int Ha, int Wa, hipStream_t s);
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,
-                   hipStream_t s);
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv, float* gsrc_priv, float* gsrc, int n_cut, int Ha,
+                   int Wa, hipStream_t s);   // uv: [n_cut,Ha*Wa,2] scratch
 int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const float* noise, float* out, int n_cut, int S,
                    hipStream_t s);
-int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* ga, int n_cut, int S,
-                   hipStream_t s);   // grgb: [n_cut,3,S,S] scratch
+int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* uv, float* ga, int n_cut,
+                   int S, hipStream_t s);   // grgb: [n_cut,3,S,S], uv: [n_cut,S*S,2] scratch
 // bilinear resize of the pooled [C,S,S] image to the canvas aspect [C,Hb,Wb] (pixray.py:468-472) and its gradient
 int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int Wb, hipStream_t s);
 int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s);

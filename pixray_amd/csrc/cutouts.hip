@@ -374,14 +374,14 @@ __global__ __launch_bounds__(256) void warp_a_fwd_kernel(const float* __restrict
 // bit-reproducible, no atomics, no memsets.  For source pixel s the destination pixels whose bilinear footprint touches
 // it lie in the pre-image of a 2x2 source square -- under zero / fill padding one square, under border padding a half
 // strip for border pixels, under reflection one square per mirror image.  Each pre-image is a quadrilateral of the
-// destination plane (the stage map is a homography); its bounding box is enumerated, candidates are screened with an
-// fp32 evaluation of the map, and the survivors are re-projected EXACTLY as the forward does (same fp64 -> fp32 steps, same
-// taps and weights), so the gradient is the exact adjoint of the forward, only summed in a different order than ATen.
+// destination plane (the stage map is a homography); its bounding box is enumerated and every candidate is judged by the
+// forward's OWN raw sampling coordinate (the uv map a destination-parallel pre-pass writes with the same fp64 -> fp32
+// steps), so taps and weights are bit-for-bit the forward's and the gradient is its exact adjoint, only summed in a
+// different order than ATen does.
 // Uniqueness: the raw-coordinate rectangles of one source pixel are disjoint and a candidate is counted in the rectangle
 // that contains its raw coordinate; completeness: acceptance is by the exact taps, the rectangles only bound the search.
 struct StageMap {
-    float P[9];      // destination pixel (x, y, 1) -> raw source coordinate (u, v), approximate (fp32) -- screening only
-    float Pi[9];     // its inverse: raw source coordinate -> destination pixel, for bounding boxes
+    float Pi[9];     // raw source coordinate (u, v, 1) -> destination pixel, approximate (fp32): bounding boxes only
     float ulo, uhi, vlo, vhi;   // raw-coordinate range of the destination image (+- 1)
 };
 
@@ -421,9 +421,6 @@ __device__ void build_stage_map(StageMap& sm, const double* m, int gtype, int Wd
     double P[9], Pi[9];
     stage_matrix(m, gtype, Wd, Hd, Ws, Hs, P);
     invert3(P, Pi);
-    // normalise so that the projective denominators are O(1) and positive inside the image
-    const double zc = P[6] * (0.5 * Wd) + P[7] * (0.5 * Hd) + P[8];
-    const double sp = zc != 0.0 ? 1.0 / zc : 1.0;
     float ulo = INFINITY, uhi = -INFINITY, vlo = INFINITY, vhi = -INFINITY;
     for (int k = 0; k < 4; ++k) {
         const double x = (k & 1) ? (double)(Wd - 1) : 0.0, y = (k & 2) ? (double)(Hd - 1) : 0.0;
@@ -431,9 +428,10 @@ __device__ void build_stage_map(StageMap& sm, const double* m, int gtype, int Wd
         const double u = (P[0] * x + P[1] * y + P[2]) / z, v = (P[3] * x + P[4] * y + P[5]) / z;
         ulo = fminf(ulo, (float)u); uhi = fmaxf(uhi, (float)u); vlo = fminf(vlo, (float)v); vhi = fmaxf(vhi, (float)v);
     }
+    // normalise so that the projective denominator is O(1) and positive inside the image
     const double zi = Pi[6] * (0.5 * (ulo + uhi)) + Pi[7] * (0.5 * (vlo + vhi)) + Pi[8];
     const double si = zi != 0.0 ? 1.0 / zi : 1.0;
-    for (int k = 0; k < 9; ++k) { sm.P[k] = (float)(P[k] * sp); sm.Pi[k] = (float)(Pi[k] * si); }
+    for (int k = 0; k < 9; ++k) sm.Pi[k] = (float)(Pi[k] * si);
     sm.ulo = ulo - 1.5f; sm.uhi = uhi + 1.5f; sm.vlo = vlo - 1.5f; sm.vhi = vhi + 1.5f;
 }
 
@@ -506,8 +504,9 @@ __device__ __forceinline__ bool preimage_box(const StageMap& sm, float ua, float
         xl = fminf(xl, x); xh = fmaxf(xh, x); yl = fminf(yl, y); yh = fmaxf(yh, y);
     }
     if (bad) { x0 = 0; x1 = Wd - 1; y0 = 0; y1 = Hd - 1; return true; }        // near the horizon: search everything
-    x0 = max((int)floorf(xl) - 1, 0); x1 = min((int)ceilf(xh) + 1, Wd - 1);
-    y0 = max((int)floorf(yl) - 1, 0); y1 = min((int)ceilf(yh) + 1, Hd - 1);
+    // the fp32 inverse map is good to a small fraction of a pixel (it only ignores the forward's fp32 grid rounding)
+    x0 = max((int)floorf(xl - 0.25f), 0); x1 = min((int)ceilf(xh + 0.25f), Wd - 1);
+    y0 = max((int)floorf(yl - 0.25f), 0); y1 = min((int)ceilf(yh + 0.25f), Hd - 1);
     return x0 <= x1 && y0 <= y1;
 }
 
@@ -517,21 +516,18 @@ struct GatherStage {
     int Wd, Hd;            // destination plane
     int Ws, Hs;            // source image the taps index (the stage-B window, or the whole stage-A source)
     const float* g;        // destination-side gradient planes of this cutout, [3][Hd][Wd]
+    const float2* uv;      // the forward's raw source coordinate of every destination pixel of this cutout, [Hd][Wd] (uv_kernel)
 };
 
-// contribution of destination pixel (x, y) to source pixel (sx, sy), if its raw coordinate lies in [ua,ub) x [va,vb)
-__device__ __forceinline__ void gather_candidate(const GatherStage& st, const StageMap& sm, int x, int y, int sx, int sy,
+// contribution of destination pixel (x, y) to source pixel (sx, sy), if its raw coordinate lies in [ua,ub) x [va,vb).
+// The raw coordinate comes from the uv map a destination-parallel pre-pass wrote with the forward's own `project` (fp64
+// homography -> fp32 grid -> unnormalise), so the taps and weights below are bit-for-bit the forward's.
+__device__ __forceinline__ void gather_candidate(const GatherStage& st, int x, int y, int sx, int sy,
                                                  float ua, float ub, float va, float vb, float (&acc)[3]) {
-    const float fx = (float)x, fy = (float)y;
-    const float z = sm.P[6] * fx + sm.P[7] * fy + sm.P[8];
-    const float iz = 1.f / z;
-    const float uq = (sm.P[0] * fx + sm.P[1] * fy + sm.P[2]) * iz, vq = (sm.P[3] * fx + sm.P[4] * fy + sm.P[5]) * iz;
-    const float tol = 0.02f;       // the screening map is fp32 and ignores the forward's fp32 grid rounding (<< 0.02 px)
-    if (!(uq >= ua - tol && uq < ub + tol && vq >= va - tol && vq < vb + tol)) return;
-    float u, v;
-    project(st.m, st.gtype, x, y, st.Wd, st.Hd, st.Ws, st.Hs, u, v);
-    if (!(u >= ua && u < ub && v >= va && v < vb)) return;
-    const Taps t = make_taps(u, v, st.Ws, st.Hs, st.mode);
+    const size_t o = (size_t)y * st.Wd + x;
+    const float2 q = st.uv[o];
+    if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return;
+    const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);
     const float e = 1.f - t.wx, s_ = 1.f - t.wy;
     float w = 0.f;
     if (t.vx0 && t.vy0 && t.x0 == sx && t.y0 == sy) w += s_ * e;
@@ -539,7 +535,7 @@ __device__ __forceinline__ void gather_candidate(const GatherStage& st, const St
     if (t.vx0 && t.vy1 && t.x0 == sx && t.y0 + 1 == sy) w += t.wy * e;
     if (t.vx1 && t.vy1 && t.x0 + 1 == sx && t.y0 + 1 == sy) w += t.wy * t.wx;
     if (w == 0.f) return;
-    const size_t o = (size_t)y * st.Wd + x, plane = (size_t)st.Hd * st.Wd;
+    const size_t plane = (size_t)st.Hd * st.Wd;
     acc[0] += st.g[o] * w; acc[1] += st.g[plane + o] * w; acc[2] += st.g[2 * plane + o] * w;
 }
 
@@ -554,6 +550,15 @@ __device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMa
     const int lane = threadIdx.x & 63;
     int total = 0;
     if (!COOP) {       // first pass: how much work is it?
+        if (nx == 1 && ny == 1) {                  // the common case (interior pixel, or zero / fill padding): one box, used directly
+            int x0, x1, y0, y1;
+            if (!preimage_box(sm, xa[0], xb[0], ya[0], yb[0], st.Wd, st.Hd, x0, x1, y0, y1)) return 0;
+            total = (x1 - x0 + 1) * (y1 - y0 + 1);
+            if (total > budget) return total;
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) gather_candidate(st, x, y, sx, sy, xa[0], xb[0], ya[0], yb[0], acc);
+            return total;
+        }
         for (int j = 0; j < ny; ++j)
             for (int i = 0; i < nx; ++i) {
                 int x0, x1, y0, y1;
@@ -568,10 +573,10 @@ __device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMa
             const int bw = x1 - x0 + 1, cnt = bw * (y1 - y0 + 1);
             if (COOP) {
                 for (int k = lane; k < cnt; k += 64)
-                    gather_candidate(st, sm, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+                    gather_candidate(st, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
             } else {
                 for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) gather_candidate(st, sm, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+                    for (int x = x0; x <= x1; ++x) gather_candidate(st, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
             }
         }
     if (COOP) {
@@ -603,11 +608,29 @@ __device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMa
 
 constexpr int TILE_W = 16;
 
+// destination-parallel pre-pass of a gather stage: the raw source coordinate of every destination pixel, exactly as the
+// forward computed it (stage 1: D_M1 / D_GRID1 / D_MODE1 on the Ha x Wa stage-A plane; stage 2: the stage-B words on S x S)
+__global__ __launch_bounds__(256) void uv_kernel(const double* __restrict__ desc, int stage, float2* __restrict__ uv, int Wd, int Hd,
+                                                 int Ws, int Hs) {
+    const int n = blockIdx.y;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    if ((int)d[stage == 1 ? D_MODE1 : D_MODE2] == MODE_IDENT) return;
+    const double* m = d + (stage == 1 ? D_M1 : D_M2);
+    const int gtype = (int)d[stage == 1 ? D_GRID1 : D_GRID2];
+    if (stage == 2) { Ws = (int)d[D_WW]; Hs = (int)d[D_WH]; }
+    const size_t plane = (size_t)Hd * Wd;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < plane; pix += (size_t)gridDim.x * blockDim.x) {
+        float u, v;
+        project(m, gtype, (int)(pix % Wd), (int)(pix / Wd), Wd, Hd, Ws, Hs, u, v);
+        uv[(size_t)n * plane + pix] = make_float2(u, v);
+    }
+}
+
 // Stage A backward: g[n][3][Ha][Wa] -> per-cutout private source-gradient planes gsrc[n][3][Hs][Ws] (every element written;
 // summed over n afterwards by reduce_planes_kernel in a fixed order)
 __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict__ g, int Hs, int Ws,
-                                                         const double* __restrict__ desc, float* __restrict__ gsrc,
-                                                         int n_cut, int Ha, int Wa) {
+                                                         const double* __restrict__ desc, const float2* __restrict__ uv,
+                                                         float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
     __shared__ StageMap sm;
     const int tiles = (Ws + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
@@ -628,7 +651,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) build_stage_map(sm, d + D_M1, (int)d[D_GRID1], Wa, Ha, Ws, Hs);
     __syncthreads();
-    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi};
+    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
     float o[3];
     gather_tile(st, sm, sx, sy, live, o);
     if (live) {
@@ -729,7 +752,8 @@ __global__ __launch_bounds__(256) void warp_b_jac_kernel(const float* __restrict
 
 // pass 2 (source-parallel gather): ga[n][3][Ha][Wa], every element written (zero outside the stage-B source window)
 __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
-                                                         const float* __restrict__ grgb, float* __restrict__ ga, int n_cut, int S) {
+                                                         const float* __restrict__ grgb, const float2* __restrict__ uv,
+                                                         float* __restrict__ ga, int n_cut, int S) {
     __shared__ StageMap sm;
     const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     const int tiles = (Wa + TILE_W - 1) / TILE_W;
@@ -753,7 +777,7 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
     } else {
         if (threadIdx.x == 0) build_stage_map(sm, d + D_M2, (int)d[D_GRID2], S, S, q.ww, q.wh);
         __syncthreads();
-        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi};
+        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
         gather_tile(st, sm, sx, sy, live, o);
     }
     if (inimg) {
@@ -984,11 +1008,15 @@ int prx_warp_a_fwd(const float* src, int Hs, int Ws, const double* desc, float* 
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* gsrc_priv, float* gsrc, int n_cut, int Ha, int Wa,
-                   hipStream_t s) {
+int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv, float* gsrc_priv, float* gsrc, int n_cut, int Ha,
+                   int Wa, hipStream_t s) {
+    // uv: [n_cut][Ha*Wa][2] scratch
     // gsrc_priv: [n_cut][3][Hs][Ws] per-cutout private planes (scratch, every element written); gsrc: [3][Hs][Ws] their sum
     const int tx = (Ws + TILE_W - 1) / TILE_W, ty = (Hs + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, gsrc_priv, n_cut, Ha, Wa);
+    hipLaunchKernelGGL(uv_kernel, dim3(std::min(ew_grid((size_t)Ha * Wa), 64), n_cut), dim3(256), 0, s, desc, 1, (float2*)uv, Wa, Ha, Ws, Hs);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
+                       Ha, Wa);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
                        (size_t)3 * Hs * Ws);
@@ -1002,14 +1030,17 @@ int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const flo
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* ga, int n_cut, int S,
-                   hipStream_t s) {
-    // grgb: [n_cut][3][S][S] scratch (the gradient pulled back through the ColorJitter); ga: [n_cut][3][Ha][Wa], every element written
+int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* uv, float* ga, int n_cut,
+                   int S, hipStream_t s) {
+    // grgb: [n_cut][3][S][S] scratch (the gradient pulled back through the ColorJitter); uv: [n_cut][S*S][2] scratch;
+    // ga: [n_cut][3][Ha][Wa], every element written
+    hipLaunchKernelGGL(uv_kernel, dim3(std::min(ew_grid((size_t)S * S), 64), n_cut), dim3(256), 0, s, desc, 2, (float2*)uv, S, S, 0, 0);
+    PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(warp_b_jac_kernel, dim3(std::min(ew_grid((size_t)S * S), 64), n_cut), dim3(256), 0, s, a, Ha, Wa, desc, g, grgb,
                        n_cut, S);
     PRX_LAUNCH_CHECK();
     const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, ga, n_cut, S);
+    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -68,11 +68,12 @@ class _MakeCutoutsFn(torch.autograd.Function):
         dev = g.device
         g_a = torch.empty(n, 3, Hb, Wb, device=dev)
         g_priv = torch.empty(n, 3, Hb, Wb, device=dev)
+        uv = torch.empty(n, Hb * Wb, 2, device=dev)
         g_base = torch.empty(3, Hb, Wb, device=dev)
         g_pooled = torch.empty(3, S, S, device=dev)
         g_img = torch.empty(1, 3, H, W, device=dev)
-        call("prx_cutouts_backward", g, desc, ctx.spot_mask, n, S, Hb, Wb, H, W, stage_a, argmax, g_a, g_priv, g_base, g_pooled, g_img,
-             _stream())
+        call("prx_cutouts_backward", g, desc, ctx.spot_mask, n, S, Hb, Wb, H, W, stage_a, argmax, g_a, g_priv, uv, g_base, g_pooled,
+             g_img, _stream())
         return g_img, None, None, None, None, None
 
 

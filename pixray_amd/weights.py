@@ -412,7 +412,11 @@ def synthetic_clip_resnet_params(cfg: ClipResNetConfig, seed: int = 0) -> "Order
         elif ".bn" in name or name.startswith("bn") or "downsample.1" in name:
             t = (1.0 + 0.1 * torch.randn(shape, generator=g)) if name.endswith("weight") else 0.05 * torch.randn(shape, generator=g)
             if name.endswith("bn3.weight") and name.startswith("layer"):
-                t = t * 0.5                        # keep the residual stream O(1)
+                # residual-branch gain 0.2: with 26 bottlenecks the variance of the residual stream then grows 1.04^26 = 2.8x,
+                # as in a BatchNorm-trained tower.  (Round 1 used 0.5: 1.25^26 = 330x, which saturated the attention pool's
+                # softmax and made the random tower ill-conditioned -- rounding its WEIGHTS to bf16 alone moved the embedding by
+                # 1.7-3 % depending on the seed, against 0.4 % now.)
+                t = t * 0.2
         elif name == "attnpool.positional_embedding":
             t = torch.randn(shape, generator=g) * (shape[1] ** -0.5)
         elif name.endswith(".bias"):

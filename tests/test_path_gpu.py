@@ -93,6 +93,8 @@ def test_cutout_align_corners_convention_is_a_descriptor_field(flip):
     img = _test_image("smooth", HW, g)
     prm = pc.sample_cutout_params(cutn, S, g, iteration=0)
     prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    prm["z_jit_apply"][:] = False          # geometry only: the jitter's Jacobian has its own (tie-break) noise
+    prm["w_jit_apply"][:] = False
     gout = torch.randn(cutn, 3, S, S, generator=g)
     outs = {}
     for value in (pc.KORNIA_062_CONVENTIONS[flip], not pc.KORNIA_062_CONVENTIONS[flip]):
@@ -107,7 +109,7 @@ def test_cutout_align_corners_convention_is_a_descriptor_field(flip):
         out = mk(img_d)
         (gd,) = torch.autograd.grad(out, img_d, gout.to(DEV))
         assert rel_l2(out, ref) < 1e-5, (flip, value, rel_l2(out, ref))
-        assert rel_l2(gd, gref) < 3e-3, (flip, value, rel_l2(gd, gref))
+        assert rel_l2(gd, gref) < 1e-4, (flip, value, rel_l2(gd, gref))
         outs[value] = out.detach().cpu()
     assert rel_l2(outs[True], outs[False]) > 1e-3          # the convention matters: a half-pixel-class resampling difference
 
