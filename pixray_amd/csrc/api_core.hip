@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -13,6 +14,11 @@ void prx_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int prx_xcd_local() {
+    static const int v = getenv("PRX_XCD_LOCAL") ? atoi(getenv("PRX_XCD_LOCAL")) : 1;     // immutable after first use
+    return v;
 }
 
 extern "C" {

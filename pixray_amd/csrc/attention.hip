@@ -189,13 +189,17 @@ __device__ __forceinline__ void mma_acc_tr(const f32x16 (&a)[2], const bf16_t* T
 }
 
 __global__ __launch_bounds__(128) void mha_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T,
-                                                      int C, float scale) {
+                                                      int C, float scale, int xcd) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[3 * TILE];
     bf16_t* Qs = smem;
     bf16_t* Ks = smem + TILE;
     bf16_t* Vt = smem + 2 * TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int h = blockIdx.x, n = blockIdx.y;
+    // (image, head) from the flat workgroup id through the XCD map (common.h): an XCD works on a contiguous range of images,
+    // the same token rows whose qkv the projection GEMM of that XCD just wrote
+    const unsigned flat = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const unsigned lin = xcd ? xcd_linear(flat, nwg) : flat;
+    const int h = (int)(lin % gridDim.x), n = (int)(lin / gridDim.x);
     const long long ld = 3LL * C;
     const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
     load_tile(base, ld, T, Qs, nullptr, tid);
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(128) void mha_fwd_kernel(const bf16_t* __restrict__
 // LDS images built one after the other in the fifth tile.  Two waves per (image, head), as in the forward: wave w owns
 // queries 32w.. in orientation 1 (its rows of dQ) and keys 32w.. in orientation 2 (its rows of dK and dV).
 __global__ __launch_bounds__(128) void mha_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                      bf16_t* __restrict__ dqkv, int T, int C, float scale) {
+                                                      bf16_t* __restrict__ dqkv, int T, int C, float scale, int xcd) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[5 * TILE];
     __shared__ __attribute__((aligned(16))) float s_lse[64], s_D[64];
     bf16_t* Qs = smem;
@@ -257,7 +261,11 @@ __global__ __launch_bounds__(128) void mha_bwd_kernel(const bf16_t* __restrict__
     bf16_t* dOs = smem + 3 * TILE;
     bf16_t* Tt = smem + 4 * TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int h = blockIdx.x, n = blockIdx.y;
+    // (image, head) from the flat workgroup id through the XCD map (common.h): an XCD works on a contiguous range of images,
+    // the same token rows whose qkv the projection GEMM of that XCD just wrote
+    const unsigned flat = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const unsigned lin = xcd ? xcd_linear(flat, nwg) : flat;
+    const int h = (int)(lin % gridDim.x), n = (int)(lin / gridDim.x);
     const int hh = lane >> 5;
     const long long ld = 3LL * C;
     const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
@@ -577,14 +585,14 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_gen_kernel(const bf16_t* __res
 
 int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, out, T, C, 0.125f);
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, out, T, C, 0.125f, prx_xcd_local());
     PRX_LAUNCH_CHECK();
     return 0;
 }
 
 int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha bwd: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, dout, dqkv, T, C, 0.125f);
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(heads, N), dim3(128), 0, s, qkv, dout, dqkv, T, C, 0.125f, prx_xcd_local());
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -108,5 +108,18 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- XCD-aware work split of streaming kernels -------------------------------------------------------------------------
+// MI355X has 8 XCDs with a private 4 MB L2 each, and workgroup b is observed to run on XCD b % 8 (used for speed only:
+// nothing below depends on it for correctness).  The GEMM engine can give every XCD a contiguous eighth of the tile rows
+// (gemm.hip, xcd_swizzle); when the streaming kernels that produce its A operand and consume its output (GroupNorm /
+// LayerNorm apply passes) split their index space the same way, an activation row is written and re-read through the SAME
+// L2 instead of crossing the fabric on every kernel boundary.  xcd_linear() is the shared block -> slot map (bijective for
+// any grid size); PRX_XCD_LOCAL=0 switches the elementwise side off for A/B runs.
+__device__ __forceinline__ unsigned xcd_linear(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, local = bid >> 3, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+int prx_xcd_local();      // process-wide constant read once from the environment (api_core.hip)
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

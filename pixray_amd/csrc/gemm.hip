@@ -1100,6 +1100,9 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     // measured (tools/gemm_tune.py xcd + bench.py A/B): +10-19% on the row-major N=768 ViT GEMMs, neutral-to-negative
     // on the implicit-conv shapes -> mode 2 (default) applies it to narrow row-major problems only
     a.xcd_swizzle = tiles >= 16 && (cx.xcd_swizzle == 1 || (cx.xcd_swizzle == 2 && d.a_mode == PRX_A_ROWMAJOR && d.N <= 1024));
+    // with the streaming producers / consumers split the same way (common.h, PRX_XCD_LOCAL): every tiled launch keeps an
+    // XCD on a contiguous eighth of the tile rows, so activation rows stay in one L2 across kernel boundaries
+    if (cx.xcd_swizzle == 3) a.xcd_swizzle = tiles >= 16;
     if (d.gnb_x) {
         PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
                     "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");

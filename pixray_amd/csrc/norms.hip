@@ -110,12 +110,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs a) {
 }
 
 // y = gn(x); out = swish ? y*sigmoid(y) : y   -> bf16 (and optionally fp32)
-__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_t* out_bf16, float* out_f32, int NB) {
+// `xcd`: give workgroup b the xcd_linear(b)-th contiguous slice of the tensor (common.h) instead of a grid-stride comb
+__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_t* out_bf16, float* out_f32, int NB, int xcd) {
     const int C4 = a.C >> 2;
     const int gs = a.C / 32;
     const size_t total = (size_t)NB * a.P * C4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
+    size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = (size_t)gridDim.x * blockDim.x;
+    if (xcd) {
+        const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
+        i0 = lo + threadIdx.x; i1 = lo + per < total ? lo + per : total; step = blockDim.x;
+    }
+    for (size_t idx = i0; idx < i1; idx += step) {
         const int cq = (int)(idx % C4);
         const int b = (int)(idx / ((size_t)a.P * C4));
         const int grp = (cq * 4) / gs;
@@ -143,13 +148,17 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_
 
 // dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat)) (+ add)
 __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const double* bstats, const float* add,
-                                                           float* dx, bf16_t* dx_bf16, int NB) {
+                                                           float* dx, bf16_t* dx_bf16, int NB, int xcd) {
     const int C4 = a.C >> 2;
     const int gs = a.C / 32;
     const size_t total = (size_t)NB * a.P * C4;
     const double n = (double)a.P * gs;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
+    size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = (size_t)gridDim.x * blockDim.x;
+    if (xcd) {
+        const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
+        i0 = lo + threadIdx.x; i1 = lo + per < total ? lo + per : total; step = blockDim.x;
+    }
+    for (size_t idx = i0; idx < i1; idx += step) {
         const int cq = (int)(idx % C4);
         const int b = (int)(idx / ((size_t)a.P * C4));
         const int grp = (cq * 4) / gs;
@@ -193,9 +202,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16_t* __restrict__ out_bf16,
                                                      float* __restrict__ out_f32, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int rows, int C, long long ldx,
-                                                     float eps) {
+                                                     float eps, int xcd) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (xcd ? xcd_linear(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 8;  // float4 per lane
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
@@ -247,9 +256,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ add,
                                                      long long ldadd, float* __restrict__ dx, long long lddx,
-                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C) {
+                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C, int xcd) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = (xcd ? xcd_linear(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 8;
     const float mean = mean_in[row], rstd = rstd_in[row];
@@ -308,7 +317,7 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
     }
     if (out_bf16 || out_f32) {
         hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, out_bf16,
-                           out_f32, NB);
+                           out_f32, NB, prx_xcd_local());
         PRX_LAUNCH_CHECK();
     }
     return 0;
@@ -329,7 +338,7 @@ int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const 
         PRX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,
-                       dx_bf16, NB);
+                       dx_bf16, NB, prx_xcd_local());
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -340,10 +349,10 @@ int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const f
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, x, gamma, beta, out_bf16, out_f32, mean, rstd, rows,
-                           C, ldx, eps);
+                           C, ldx, eps, prx_xcd_local());
     else
         hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, x, gamma, beta, out_bf16, out_f32, mean, rstd, rows,
-                           C, ldx, eps);
+                           C, ldx, eps, prx_xcd_local());
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -355,10 +364,10 @@ int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long l
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C);
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local());
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C);
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local());
     PRX_LAUNCH_CHECK();
     return 0;
 }
