@@ -519,13 +519,28 @@ struct GatherStage {
     const float2* uv;      // the forward's raw source coordinate of every destination pixel of this cutout, [Hd][Wd] (uv_kernel)
 };
 
+// LDS staging of one block's candidates: neighbouring source pixels share almost all of their destination candidates, so
+// the block loads the bounding box of its whole source tile's (direct) pre-image ONCE, coalesced -- raw coordinates and the
+// three gradient planes -- and the per-pixel enumeration then reads LDS.  Candidates outside the staged box (mirror images,
+// border strips, boxes too large for the buffer) fall back to HBM / L2 reads.
+constexpr int TILE_W = 16;           // a block owns a TILE_W x TILE_W tile of source pixels
+constexpr int STAGE_CAP = 2304;       // destination pixels (48 x 48): 18 KB of coordinates + 27 KB of gradients
+struct TileStage {
+    int x0, y0, w, h;                 // staged destination box (w == 0: nothing staged)
+    float2 uv[STAGE_CAP];
+    float g[3][STAGE_CAP];
+};
+
 // contribution of destination pixel (x, y) to source pixel (sx, sy), if its raw coordinate lies in [ua,ub) x [va,vb).
 // The raw coordinate comes from the uv map a destination-parallel pre-pass wrote with the forward's own `project` (fp64
 // homography -> fp32 grid -> unnormalise), so the taps and weights below are bit-for-bit the forward's.
-__device__ __forceinline__ void gather_candidate(const GatherStage& st, int x, int y, int sx, int sy,
+__device__ __forceinline__ void gather_candidate(const GatherStage& st, const TileStage& ts, int x, int y, int sx, int sy,
                                                  float ua, float ub, float va, float vb, float (&acc)[3]) {
+    const int lx = x - ts.x0, ly = y - ts.y0;
+    const bool in_lds = lx >= 0 && lx < ts.w && ly >= 0 && ly < ts.h;
+    const int li = ly * ts.w + lx;
     const size_t o = (size_t)y * st.Wd + x;
-    const float2 q = st.uv[o];
+    const float2 q = in_lds ? ts.uv[li] : st.uv[o];
     if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return;
     const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);
     const float e = 1.f - t.wx, s_ = 1.f - t.wy;
@@ -535,15 +550,20 @@ __device__ __forceinline__ void gather_candidate(const GatherStage& st, int x, i
     if (t.vx0 && t.vy1 && t.x0 == sx && t.y0 + 1 == sy) w += t.wy * e;
     if (t.vx1 && t.vy1 && t.x0 + 1 == sx && t.y0 + 1 == sy) w += t.wy * t.wx;
     if (w == 0.f) return;
-    const size_t plane = (size_t)st.Hd * st.Wd;
-    acc[0] += st.g[o] * w; acc[1] += st.g[plane + o] * w; acc[2] += st.g[2 * plane + o] * w;
+    if (in_lds) {
+        acc[0] += ts.g[0][li] * w; acc[1] += ts.g[1][li] * w; acc[2] += ts.g[2][li] * w;
+    } else {
+        const size_t plane = (size_t)st.Hd * st.Wd;
+        acc[0] += st.g[o] * w; acc[1] += st.g[plane + o] * w; acc[2] += st.g[2 * plane + o] * w;
+    }
 }
 
 // All contributions to source pixel (sx, sy).  `coop`: the 64 lanes of the wave share the enumeration of ONE pixel (every
 // lane passes the same sx, sy) and the partial sums are combined by a fixed butterfly; otherwise the lane works alone.
 constexpr int HEAVY = 160;       // candidates above which a pixel is handed to the whole wave (border strips, corners)
 template <bool COOP>
-__device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMap& sm, int sx, int sy, float (&acc)[3], int budget) {
+__device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMap& sm, const TileStage& ts, int sx, int sy,
+                                            float (&acc)[3], int budget) {
     float xa[MAXI], xb[MAXI], ya[MAXI], yb[MAXI];
     const int nx = tap_intervals(st.mode, sx, st.Ws, sm.ulo, sm.uhi, xa, xb);
     const int ny = tap_intervals(st.mode, sy, st.Hs, sm.vlo, sm.vhi, ya, yb);
@@ -556,7 +576,7 @@ __device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMa
             total = (x1 - x0 + 1) * (y1 - y0 + 1);
             if (total > budget) return total;
             for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) gather_candidate(st, x, y, sx, sy, xa[0], xb[0], ya[0], yb[0], acc);
+                for (int x = x0; x <= x1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[0], xb[0], ya[0], yb[0], acc);
             return total;
         }
         for (int j = 0; j < ny; ++j)
@@ -573,10 +593,10 @@ __device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMa
             const int bw = x1 - x0 + 1, cnt = bw * (y1 - y0 + 1);
             if (COOP) {
                 for (int k = lane; k < cnt; k += 64)
-                    gather_candidate(st, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+                    gather_candidate(st, ts, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
             } else {
                 for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) gather_candidate(st, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+                    for (int x = x0; x <= x1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
             }
         }
     if (COOP) {
@@ -589,10 +609,34 @@ __device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMa
 }
 
 // one block = a 16 x 16 tile of SOURCE pixels of one cutout; out-of-tile / out-of-window pixels idle
-__device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMap& sm, int sx, int sy, bool live, float (&out)[3]) {
+// (tx0, ty0): source coordinates of the tile's first pixel (may be negative / beyond the image at the window edges)
+__device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMap& sm, TileStage& ts, int tx0, int ty0, int sx, int sy,
+                                            bool live, float (&out)[3]) {
+    // stage the pre-image of the whole tile (its direct image: source square [tx0-1, tx0+TILE_W+1) etc.)
+    if (threadIdx.x == 0) {
+        int x0, x1, y0, y1;
+        ts.w = 0; ts.h = 0; ts.x0 = 0; ts.y0 = 0;
+        const float ua = fmaxf((float)tx0 - 1.f, sm.ulo), ub = fminf((float)(tx0 + TILE_W) + 1.f, sm.uhi);
+        const float va = fmaxf((float)ty0 - 1.f, sm.vlo), vb = fminf((float)(ty0 + TILE_W) + 1.f, sm.vhi);
+        if (ub > ua && vb > va && preimage_box(sm, ua, ub, va, vb, st.Wd, st.Hd, x0, x1, y0, y1) &&
+            (x1 - x0 + 1) * (y1 - y0 + 1) <= STAGE_CAP) {
+            ts.x0 = x0; ts.y0 = y0; ts.w = x1 - x0 + 1; ts.h = y1 - y0 + 1;
+        }
+    }
+    __syncthreads();
+    {
+        const int cnt = ts.w * ts.h;
+        const size_t plane = (size_t)st.Hd * st.Wd;
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const size_t o = (size_t)(ts.y0 + k / ts.w) * st.Wd + (ts.x0 + k % ts.w);
+            ts.uv[k] = st.uv[o];
+            ts.g[0][k] = st.g[o]; ts.g[1][k] = st.g[plane + o]; ts.g[2][k] = st.g[2 * plane + o];
+        }
+    }
+    __syncthreads();
     float acc[3] = {0.f, 0.f, 0.f};
     int work = 0;
-    if (live) work = gather_pixel<false>(st, sm, sx, sy, acc, HEAVY);
+    if (live) work = gather_pixel<false>(st, sm, ts, sx, sy, acc, HEAVY);
     // pixels that were too heavy for one lane (work > HEAVY: nothing accumulated yet): the wave takes them one by one
     unsigned long long heavy = __ballot(live && work > HEAVY);
     while (heavy) {
@@ -600,13 +644,11 @@ __device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMa
         heavy &= heavy - 1;
         const int hx = __shfl(sx, src, 64), hy = __shfl(sy, src, 64);
         float a2[3] = {0.f, 0.f, 0.f};
-        gather_pixel<true>(st, sm, hx, hy, a2, 0);
+        gather_pixel<true>(st, sm, ts, hx, hy, a2, 0);
         if ((int)(threadIdx.x & 63) == src) { acc[0] = a2[0]; acc[1] = a2[1]; acc[2] = a2[2]; }
     }
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
 }
-
-constexpr int TILE_W = 16;
 
 // destination-parallel pre-pass of a gather stage: the raw source coordinate of every destination pixel, exactly as the
 // forward computed it (stage 1: D_M1 / D_GRID1 / D_MODE1 on the Ha x Wa stage-A plane; stage 2: the stage-B words on S x S)
@@ -632,10 +674,12 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
                                                          const double* __restrict__ desc, const float2* __restrict__ uv,
                                                          float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
     __shared__ StageMap sm;
+    __shared__ TileStage ts;
     const int tiles = (Ws + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
-    const int sx = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);
-    const int sy = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const int tx0 = (blockIdx.x % tiles) * TILE_W, ty0 = (blockIdx.x / tiles) * TILE_W;
+    const int sx = tx0 + (threadIdx.x & 15);
+    const int sy = ty0 + (threadIdx.x >> 4);
     const bool live = sx < Ws && sy < Hs;
     const double* d = desc + (size_t)n * DESC_WORDS;
     const int mode = (int)d[D_MODE1];
@@ -653,7 +697,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
     __syncthreads();
     GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
     float o[3];
-    gather_tile(st, sm, sx, sy, live, o);
+    gather_tile(st, sm, ts, tx0, ty0, sx, sy, live, o);
     if (live) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = o[c];
@@ -755,11 +799,13 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
                                                          const float* __restrict__ grgb, const float2* __restrict__ uv,
                                                          float* __restrict__ ga, int n_cut, int S) {
     __shared__ StageMap sm;
+    __shared__ TileStage ts;
     const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     const int tiles = (Wa + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
-    const int ax = (blockIdx.x % tiles) * TILE_W + (threadIdx.x & 15);      // stage-A image coordinates
-    const int ay = (blockIdx.x / tiles) * TILE_W + (threadIdx.x >> 4);
+    const int ax0 = (blockIdx.x % tiles) * TILE_W, ay0 = (blockIdx.x / tiles) * TILE_W;
+    const int ax = ax0 + (threadIdx.x & 15);      // stage-A image coordinates
+    const int ay = ay0 + (threadIdx.x >> 4);
     const bool inimg = ax < Wa && ay < Ha;
     const double* d = desc + (size_t)n * DESC_WORDS;
     const int mode = (int)d[D_MODE2];
@@ -778,7 +824,7 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
         if (threadIdx.x == 0) build_stage_map(sm, d + D_M2, (int)d[D_GRID2], S, S, q.ww, q.wh);
         __syncthreads();
         GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
-        gather_tile(st, sm, sx, sy, live, o);
+        gather_tile(st, sm, ts, ax0 - q.ox, ay0 - q.oy, sx, sy, live, o);
     }
     if (inimg) {
 #pragma unroll
