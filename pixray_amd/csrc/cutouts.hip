@@ -252,15 +252,17 @@ template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& 
 }
 template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND>& a, const Dual<ND>& b) {
     Dual<ND> r; r.v = a.v / b.v;   // true (correctly rounded) division: mirrors torch's op sequence
+    const float ib = 1.f / b.v;    // the derivative parts need no bit-parity with anything: one reciprocal, ND multiplies
 #pragma unroll
-    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
     return r;
 }
 template <int ND> __device__ __forceinline__ Dual<ND> addc(const Dual<ND>& a, float c) { Dual<ND> r = a; r.v += c; return r; }
 template <int ND> __device__ __forceinline__ Dual<ND> divc(const Dual<ND>& a, float c) {
     Dual<ND> r; r.v = a.v / c;
+    const float ic = 1.f / c;
 #pragma unroll
-    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] / c;
+    for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * ic;
     return r;
 }
 template <int ND> __device__ __forceinline__ Dual<ND> mulc(const Dual<ND>& a, float c) {
