@@ -69,7 +69,8 @@ def cfg3_custom_losses(device, precision, on_cpu=False):
     style_img = torch.rand(1, 3, 384, 448, generator=torch.Generator().manual_seed(4))
     if on_cpu:
         from oracle import workload_ref
-        style = sl.StyleLoss(extractor=workload_ref.OracleVggExtractor(params), style_image=style_img, device="cpu")
+        style = sl.StyleLoss(extractor=workload_ref.OracleVggExtractor(params), style_image=style_img, device="cpu",
+                             reference_schedule=True)
         sat = workload_ref.SaturationLossRef()
     else:
         ext = sl.Vgg16Extractor(space=args.styleloss_ospace, params=params, device=device, max_hw=(512, 512), precision=precision)
@@ -130,6 +131,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-sample-cutn", type=int, default=None)
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--phase-steps", type=int, default=2, help="iterations of the synchronised phase breakdown (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -259,6 +261,12 @@ def main():
         for _ in range(args.profile_steps):      # keep ranks in lock-step through the collectives
             sess.train(it); it += 1
 
+    # ---- phase breakdown (forward phases bracketed by synchronisations; after the timed region, rank 0 only) ----
+    phase_ms = None
+    if rank == 0 and world == 1 and args.phase_steps > 0:
+        phase_ms = api.phase_breakdown(sess, it, args.phase_steps)
+        it += args.phase_steps
+
     if args.config == "cfg1":
         per_gpu_gflop = GFLOP_DECODER_256 + GFLOP_CLIP_B32_PER_CUT * cutn / world
     else:
@@ -281,11 +289,12 @@ def main():
             if args.config == "cfg3":
                 ccustom, cargs = cfg3_custom_losses("cpu", "f32", on_cpu=True)
             r = workload_ref.time_workload(args.config, sample, n_iters=args.cpu_iters, warmup=1, custom=ccustom, args=cargs)
-            # the cutout-proportional part (cutouts + towers) scales linearly in the cutout count; the drawer part does not
-            t_full = r["drawer_seconds"] + (r["seconds_per_iter"] - r["drawer_seconds"]) * (cutn / sample)
+            # the cutout-proportional part (cutouts + towers) scales linearly in the cutout count; the drawer and the losses
+            # that read only the image (StyleLoss) do not
+            t_full = r["fixed_seconds"] + (r["seconds_per_iter"] - r["fixed_seconds"]) * (cutn / sample)
             cpu_baseline = {"value": round(1.0 / t_full, 5), "unit": "iterations/s", "cores": r["threads"], "kind": "port",
                             "sample": f"{args.cpu_iters} oracle iterations at {sample} of {cutn} cutouts per perceptor "
-                                      f"({r['seconds_per_iter']:.1f} s each, drawer part {r['drawer_seconds']:.1f} s; fp32 torch, "
+                                      f"({r['seconds_per_iter']:.1f} s each, of which drawer + image-only losses {r['fixed_seconds']:.1f} s; fp32 torch, "
                                       f"{r['threads']} threads of {r['cores']} host cores) after 1 warm-up, the cutout-proportional "
                                       f"part extrapolated linearly to {cutn}"}
 
@@ -307,7 +316,7 @@ def main():
             "final_loss": round(loss, 5),
             "per_gpu_gflop_per_step": round(per_gpu_gflop, 1) if per_gpu_gflop else None,
             "iter_mfma_frac": round(iter_frac, 4) if iter_frac else None,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "collectives_ms_per_step": collectives,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "collectives_ms_per_step": collectives, "phase_ms": phase_ms,
         }
     if world > 1 or force_dist:
         import torch.distributed as dist

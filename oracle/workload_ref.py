@@ -189,7 +189,7 @@ def compare_workload(workload: str, cutn: int, precisions=("bf16",), seed: int =
 def time_workload(workload: str, sample_cutn: int, n_iters: int = 3, warmup: int = 1, seed: int = 0, custom=(), args=None,
                   threads: Optional[int] = None) -> Dict[str, float]:
     """CPU-baseline leg of bench.py: `n_iters` full oracle iterations (forward + backward + the optimiser step is negligible)
-    at `sample_cutn` cutouts, plus the drawer-only time, so that the caller can state the sample and extrapolate the
+    at `sample_cutn` cutouts, plus the time of the part that does not depend on the cutout count, so that the caller can state the sample and extrapolate the
     cutout-proportional part to the configuration's own cutout count."""
     import os
     if threads:
@@ -200,14 +200,20 @@ def time_workload(workload: str, sample_cutn: int, n_iters: int = 3, warmup: int
         t0 = time.perf_counter()
         iteration(workload, sample_cutn, seed, prm, custom=custom, args=args, cur_iteration=it)
         dt = time.perf_counter() - t0
-        # drawer forward + backward alone (the part that does not scale with the cutout count)
+        # the part that does not scale with the cutout count: drawer forward + backward, plus the custom losses that read
+        # only the image (StyleLoss; a batch-coupled loss such as SaturationLoss reads the cutouts and scales with them)
         t1 = time.perf_counter()
         leaf, synth = image_of(workload, seed)
         img = synth(leaf)
-        torch.autograd.grad(img.sum(), leaf)
+        fixed = [img.sum()]
+        for t in custom:
+            if not getattr(t["loss"], "needs_full_batch", False):
+                r = t["loss"].get_loss({}, img, args, globals={"cur_iteration": it, "embeds": None}, lossGlobals={})
+                fixed += [t["weight"] * l for l in (r if isinstance(r, (list, tuple)) else [r])]
+        torch.autograd.grad(sum(fixed), leaf)
         di = time.perf_counter() - t1
         if it >= warmup:
             times.append(dt); t_img.append(di)
     mean, mean_img = sum(times) / len(times), sum(t_img) / len(t_img)
-    return dict(seconds_per_iter=mean, drawer_seconds=mean_img, sample_cutn=sample_cutn, iters=n_iters,
+    return dict(seconds_per_iter=mean, fixed_seconds=mean_img, sample_cutn=sample_cutn, iters=n_iters,
                 threads=torch.get_num_threads(), cores=os.cpu_count())

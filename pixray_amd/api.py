@@ -4,7 +4,7 @@ from __future__ import annotations
 import json
 import os
 import types
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -196,3 +196,53 @@ class GemmProfile:
     def tile_rule(self, M, N, K, mode, bm, bn, splits):
         for c in self.ctxs:
             self.lib.prx_gemm_tile_rule(c, M, N, K, mode, bm, bn, splits)
+
+
+def phase_breakdown(sess: Session, first_iteration: int, iters: int = 2) -> Dict[str, float]:
+    """Where an iteration's time goes, in ms per iteration: every phase of the forward pass bracketed by device
+    synchronisations (so the phases do not overlap and the sum is slower than the free-running loop), the rest of
+    `train()` reported as backward + optimiser.  Measurement aid for bench.py (`phase_ms`); the wrappers are removed
+    before it returns."""
+    import time
+    dev = sess.drawer.get_z().device if sess.drawer.get_z() is not None else sess.drawer.params[0].device
+    acc: Dict[str, float] = {}
+    undo = []
+
+    def wrap(obj, attr, key):
+        fn = getattr(obj, attr)
+
+        def timed(*a, **k):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize(dev)
+            acc[key] = acc.get(key, 0.0) + (time.perf_counter() - t0)
+            return r
+        setattr(obj, attr, timed)
+        undo.append((obj, attr, fn))
+
+    wrap(sess.drawer, "synth", "drawer_synth")
+    for size, mk in sess.cutoutsTable.items():
+        wrap(mk, "forward", f"cutouts_{size}")
+    for name, p in sess.perceptors.items():
+        wrap(p, "encode_image", f"encode_{name}")
+    for t in sess.custom_losses:
+        wrap(t["loss"], "get_loss", f"loss_{type(t['loss']).__name__}")
+    wrap(sess, "ascend_txt", "forward_total")
+    try:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(iters):
+            sess.train(first_iteration + i)
+        torch.cuda.synchronize(dev)
+        total = time.perf_counter() - t0
+    finally:
+        for obj, attr, fn in undo:
+            try:
+                delattr(obj, attr)            # instance attribute shadowing the class's method
+            except AttributeError:
+                setattr(obj, attr, fn)
+    out = {k: round(1e3 * v / iters, 3) for k, v in acc.items()}
+    out["backward_and_step"] = round(1e3 * (total - acc.get("forward_total", 0.0)) / iters, 3)
+    out["total_serialised"] = round(1e3 * total / iters, 3)
+    return out

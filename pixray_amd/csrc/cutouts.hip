@@ -439,56 +439,48 @@ __device__ void build_stage_map(StageMap& sm, const double* m, int gtype, int Wd
 
 // Raw-coordinate intervals [a, b) whose padded coordinate can produce a tap on source index s (size W), clipped to
 // [lo, hi].  Returns the count (<= MAXI); intervals come out sorted, merged and pairwise disjoint.
-constexpr int MAXI = 6;
+constexpr int MAXI = 3;
 __device__ __forceinline__ int tap_intervals(int mode, int s, int W, float lo, float hi, float* ia, float* ib) {
     const float eps = 2e-3f;       // slack against the fp32 rounding of the forward's own coordinate arithmetic
-    int n = 0;
-    auto push = [&](float a, float b) {
-        a = fmaxf(a - eps, lo); b = fminf(b + eps, hi);
-        if (!(b > a)) return;
-        if (n == MAXI) { ia[0] = lo; ib[0] = hi; n = -1; return; }       // overflow: fall back to the whole range
-        ia[n] = a; ib[n] = b; ++n;
-    };
     const float fs = (float)s, fW = (float)W;
-    if (mode == MODE_BORDER) {
-        push(s == 0 ? -INFINITY : fs - 1.f, s == W - 1 ? INFINITY : fs + 1.f);
-    } else if (mode == MODE_REFLECT) {              // align_corners=False: mirrors about -0.5 and W-0.5, period 2W
-        const float per = 2.f * fW;
-        const int j0 = (int)floorf((lo + 0.5f) / per) - 1, j1 = (int)floorf((hi + 0.5f) / per) + 1;
-        for (int j = j0; j <= j1 && n >= 0; ++j) {
-            const float c = per * (float)j;
-            push(fmaxf(c + fs - 1.f, c - 0.5f), fminf(c + fs + 1.f, c + fW - 0.5f));                          // upright image
-            if (n < 0) break;
-            push(fmaxf(c + per - fs - 2.f, c + fW - 0.5f), fminf(c + per - fs, c + per - 0.5f));              // mirrored image
-        }
-    } else if (mode == MODE_REFLECT_AC) {           // align_corners=True: mirrors about 0 and W-1, period 2(W-1)
-        const float span = fW - 1.f, per = 2.f * span;
-        if (span <= 0.f) push(lo, hi);
-        else {
-            const int j0 = (int)floorf(lo / per) - 1, j1 = (int)floorf(hi / per) + 1;
-            for (int j = j0; j <= j1 && n >= 0; ++j) {
-                const float c = per * (float)j;
-                push(fmaxf(c + fs - 1.f, c), fminf(c + fs + 1.f, c + span));
-                if (n < 0) break;
-                push(fmaxf(c + per - fs - 1.f, c + span), fminf(c + per - fs + 1.f, c + per));
-            }
-        }
-    } else {                                        // zeros / fill: out-of-range taps simply drop out
-        push(fs - 1.f, fs + 1.f);
+    // the direct image: every mode has it (the upright copy of the source inside its own domain)
+    float a = fs - 1.f - eps, b = fs + 1.f + eps;
+    if (mode == MODE_BORDER) {                      // clamping folds everything beyond the edge onto the edge pixel
+        if (s == 0) a = -INFINITY;
+        if (s == W - 1) b = INFINITY;
     }
-    if (n < 0) return 1;
-    // insertion sort + merge (the slack can make neighbours of adjacent mirror images overlap)
-    for (int i = 1; i < n; ++i)
-        for (int k = i; k > 0 && ia[k] < ia[k - 1]; --k) {
-            float t = ia[k]; ia[k] = ia[k - 1]; ia[k - 1] = t;
-            t = ib[k]; ib[k] = ib[k - 1]; ib[k - 1] = t;
-        }
-    int m = 0;
-    for (int i = 1; i < n; ++i) {
-        if (ia[i] <= ib[m]) ib[m] = fmaxf(ib[m], ib[i]);
-        else { ++m; ia[m] = ia[i]; ib[m] = ib[i]; }
+    a = fmaxf(a, lo); b = fminf(b, hi);
+    int n = 0;
+    if (b > a) { ia[0] = a; ib[0] = b; n = 1; }
+    if (mode != MODE_REFLECT && mode != MODE_REFLECT_AC) return n;
+    // first-order mirror images (reflection about the low and the high edge); a raw range that reaches past them
+    // (|excursion| > one image size: never with pixray's distortion scales) falls back to the whole range
+    float m0a, m0b, m1a, m1b, dlo, dhi;
+    if (mode == MODE_REFLECT) {                     // align_corners=False: mirrors about -0.5 and W-0.5
+        m0a = -fs - 2.f; m0b = -fs; m1a = 2.f * fW - fs - 2.f; m1b = 2.f * fW - fs;
+        dlo = -fW - 0.5f; dhi = 2.f * fW - 0.5f;
+    } else {                                        // align_corners=True: mirrors about 0 and W-1
+        const float span = fW - 1.f;
+        m0a = -fs - 1.f; m0b = -fs + 1.f; m1a = 2.f * span - fs - 1.f; m1b = 2.f * span - fs + 1.f;
+        dlo = -span; dhi = 2.f * span;
     }
-    return n > 0 ? m + 1 : 0;
+    if (lo < dlo || hi > dhi) { ia[0] = lo; ib[0] = hi; return 1; }
+    // the three images can touch (s near an edge: the slack makes neighbours overlap) -> merge while inserting, in order
+    m0a = fmaxf(m0a - eps, lo); m0b = fminf(m0b + eps, hi);
+    m1a = fmaxf(m1a - eps, lo); m1b = fminf(m1b + eps, hi);
+    int cnt = 0;
+    float ra[3], rb[3];
+    if (m0b > m0a) { ra[cnt] = m0a; rb[cnt] = m0b; ++cnt; }                     // lowest
+    if (n) {
+        if (cnt && ia[0] <= rb[cnt - 1]) rb[cnt - 1] = fmaxf(rb[cnt - 1], ib[0]);
+        else { ra[cnt] = ia[0]; rb[cnt] = ib[0]; ++cnt; }
+    }
+    if (m1b > m1a) {
+        if (cnt && m1a <= rb[cnt - 1]) rb[cnt - 1] = fmaxf(rb[cnt - 1], m1b);
+        else { ra[cnt] = m1a; rb[cnt] = m1b; ++cnt; }
+    }
+    for (int i = 0; i < cnt; ++i) { ia[i] = ra[i]; ib[i] = rb[i]; }
+    return cnt;
 }
 
 // bounding box (inclusive, clipped to the destination image) of the pre-image of the raw rectangle [ua,ub) x [va,vb)
@@ -533,9 +525,25 @@ struct TileStage {
     float g[3][STAGE_CAP];
 };
 
+// the forward's padded sampling coordinate along one axis (what make_taps does before it takes the floor)
+__device__ __forceinline__ float pad_coord(float u, int W, int mode) {
+    if (mode == MODE_BORDER) return fminf(fmaxf(u, 0.f), (float)(W - 1));
+    if (mode == MODE_REFLECT) return fminf(fmaxf(reflect_coord(u, (float)W), 0.f), (float)(W - 1));
+    if (mode == MODE_REFLECT_AC) return fminf(fmaxf(reflect_coord_ac(u, (float)W), 0.f), (float)(W - 1));
+    return u;
+}
+// bilinear weight of source index s for the padded coordinate t, with the forward's own roundings: the tap pair is
+// (floor t, floor t + 1) with weights (1 - (t - floor t), t - floor t)
+__device__ __forceinline__ float tap_weight(float t, int s) {
+    const float d = t - (float)s;
+    if (d >= 0.f) return d < 1.f ? 1.f - d : 0.f;                 // floor t == s      : weight 1 - (t - s)
+    return d > -1.f ? t - (float)(s - 1) : 0.f;                    // floor t == s - 1  : weight t - (s - 1)
+}
+
 // contribution of destination pixel (x, y) to source pixel (sx, sy), if its raw coordinate lies in [ua,ub) x [va,vb).
 // The raw coordinate comes from the uv map a destination-parallel pre-pass wrote with the forward's own `project` (fp64
-// homography -> fp32 grid -> unnormalise), so the taps and weights below are bit-for-bit the forward's.
+// homography -> fp32 grid -> unnormalise), so the weights below are bit-for-bit the forward's (y-weight * x-weight, as
+// sample_plane multiplies them).
 __device__ __forceinline__ void gather_candidate(const GatherStage& st, const TileStage& ts, int x, int y, int sx, int sy,
                                                  float ua, float ub, float va, float vb, float (&acc)[3]) {
     const int lx = x - ts.x0, ly = y - ts.y0;
@@ -544,13 +552,9 @@ __device__ __forceinline__ void gather_candidate(const GatherStage& st, const Ti
     const size_t o = (size_t)y * st.Wd + x;
     const float2 q = in_lds ? ts.uv[li] : st.uv[o];
     if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return;
-    const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);
-    const float e = 1.f - t.wx, s_ = 1.f - t.wy;
-    float w = 0.f;
-    if (t.vx0 && t.vy0 && t.x0 == sx && t.y0 == sy) w += s_ * e;
-    if (t.vx1 && t.vy0 && t.x0 + 1 == sx && t.y0 == sy) w += s_ * t.wx;
-    if (t.vx0 && t.vy1 && t.x0 == sx && t.y0 + 1 == sy) w += t.wy * e;
-    if (t.vx1 && t.vy1 && t.x0 + 1 == sx && t.y0 + 1 == sy) w += t.wy * t.wx;
+    const float wx = tap_weight(pad_coord(q.x, st.Ws, st.mode), sx);
+    const float wy = tap_weight(pad_coord(q.y, st.Hs, st.mode), sy);
+    const float w = wy * wx;
     if (w == 0.f) return;
     if (in_lds) {
         acc[0] += ts.g[0][li] * w; acc[1] += ts.g[1][li] * w; acc[2] += ts.g[2][li] * w;

@@ -30,6 +30,29 @@ VGG_STD = (0.229, 0.224, 0.225)
 N_FEATURE_CHANNELS = 3 + 2 * 64 + 128 * 2 + 256 * 3 + 512 * 2      # StyleLoss.py:298 (every captured channel, no coordinates)
 
 
+# ---------------------------------------------------------------------------------------------- host <-> device plumbing
+_CONST = {}
+
+
+def _const(key, values, device):
+    """small constant tables (VGG mean/std, the YUV matrix) uploaded once per device: a `torch.tensor(list, device=...)`
+    in the loss body is a blocking pageable H2D copy per call"""
+    k = (key, str(device))
+    t = _CONST.get(k)
+    if t is None:
+        t = _CONST[k] = torch.tensor(values, dtype=torch.float32, device=device)
+    return t
+
+
+def _upload(a: np.ndarray, device):
+    """one numpy table -> device through the pinned caching allocator, stream-ordered (no host/GPU sync: the sampling tables
+    are drawn by the host while the GPU is still busy with the previous kernels)"""
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 # ---------------------------------------------------------------------------------------------- extractor
 class Vgg16Extractor:
     """`Vgg16_Extractor` (StyleLoss.py:24-81): returns [input, relu1_1, relu1_2, relu2_1, relu2_2, relu3_1, relu3_2, relu3_3,
@@ -62,8 +85,8 @@ class Vgg16Extractor:
         """StyleLoss.py:41-45"""
         if self.space != "vgg":
             x = (x + 1.0) / 2.0
-            x = x - torch.tensor(VGG_MEAN, device=x.device, dtype=x.dtype).view(1, -1, 1, 1)
-            x = x / torch.tensor(VGG_STD, device=x.device, dtype=x.dtype).view(1, -1, 1, 1)
+            x = x - _const("vgg_mean", VGG_MEAN, x.device).to(x.dtype).view(1, -1, 1, 1)
+            x = x / _const("vgg_std", VGG_STD, x.device).to(x.dtype).view(1, -1, 1, 1)
         return x
 
     def __call__(self, x) -> List[torch.Tensor]:
@@ -83,21 +106,27 @@ def sample_hypercolumns(feat: Sequence[torch.Tensor], samps: int) -> torch.Tenso
     input, followed down the pyramid by halving (the reference halves whenever a map is smaller than the one before it),
     one column of all 2179 channels per position -> [1, 2179, samps], detached."""
     H, W = feat[0].shape[1], feat[0].shape[2]
-    xx, xy = np.meshgrid(np.arange(H), np.arange(W))
-    xc = np.concatenate([np.expand_dims(xx.flatten(), 1), np.expand_dims(xy.flatten(), 1)], 1)
-    samples = min(samps, xc.shape[0])
-    np.random.shuffle(xc)
-    xx = xc[:samples, 0]
-    yy = xc[:samples, 1]
-    cols = []
+    # The reference shuffles the [H*W, 2] coordinate table in place and keeps the first `samps` rows.  numpy's row shuffle
+    # of a 2-D array is an interpreted per-row swap (0.3 s at 512x512); shuffling a 1-D index array walks the same
+    # Fisher-Yates loop with the same `random_interval` draws in C (tests/test_host_logic.py pins both the permutation and
+    # the generator state afterwards), so the draws -- and np.random's stream for everything after -- are unchanged.
+    idx = np.arange(H * W)
+    np.random.shuffle(idx)
+    samples = min(samps, idx.shape[0])
+    idx = idx[:samples]
+    # meshgrid(arange(H), arange(W)) is [W, H]-shaped ('xy' indexing): flat position p holds (p % H, p // H)
+    xx = (idx % H).astype(np.int64)
+    yy = (idx // H).astype(np.int64)
+    rows = np.empty((len(feat), samples), np.int64)
     for i, layer in enumerate(feat):
         if i > 0 and layer.shape[1] < feat[i - 1].shape[1]:
             xx = xx / 2.0
             yy = yy / 2.0
         xx = np.clip(xx, 0, layer.shape[1] - 1).astype(np.int32)
         yy = np.clip(yy, 0, layer.shape[2] - 1).astype(np.int32)
-        rows = torch.from_numpy(xx.astype(np.int64) * layer.shape[2] + yy.astype(np.int64)).to(layer.device)
-        cols.append(layer.reshape(-1, layer.shape[3]).index_select(0, rows).detach())        # [samples, C]
+        rows[i] = xx.astype(np.int64) * layer.shape[2] + yy.astype(np.int64)
+    rows_d = _upload(rows, feat[0].device)
+    cols = [layer.reshape(-1, layer.shape[3]).index_select(0, rows_d[i]).detach() for i, layer in enumerate(feat)]   # [samples, C]
     return torch.cat(cols, 1).t().unsqueeze(0).contiguous()
 
 
@@ -149,9 +178,11 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
     positions (halved whenever the resolution drops), concatenated over channels, plus the two (finally halved) coordinate
     channels -> two [1, 2181, n, 1] tensors."""
     dev = feat_a[0].device
-    ca, cb = [], []
-    for i in range(len(feat_a)):
-        fa, fb = feat_a[i], feat_b[i]
+    L, n = len(feat_a), len(xx)
+    rows = np.empty((L, 4, n), np.int64)
+    wts = np.empty((L * 4 + 2, n), np.float32)        # per layer w00 w01 w10 w11, then the two coordinate channels
+    for i in range(L):
+        fa = feat_a[i]
         if i > 0 and feat_a[i - 1].shape[1] > fa.shape[1]:
             xx = xx / 2.0
             xy = xy / 2.0
@@ -159,25 +190,33 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
         xxr = xx - xxm
         xym = np.floor(xy).astype(np.float32)
         xyr = xy - xym
-        w00 = torch.from_numpy((1. - xxr) * (1. - xyr)).float().view(-1, 1).to(dev)
-        w01 = torch.from_numpy((1. - xxr) * xyr).float().view(-1, 1).to(dev)
-        w10 = torch.from_numpy(xxr * (1. - xyr)).float().view(-1, 1).to(dev)
-        w11 = torch.from_numpy(xxr * xyr).float().view(-1, 1).to(dev)
+        wts[4 * i + 0] = (1. - xxr) * (1. - xyr)
+        wts[4 * i + 1] = (1. - xxr) * xyr
+        wts[4 * i + 2] = xxr * (1. - xyr)
+        wts[4 * i + 3] = xxr * xyr
         hh, ww = fa.shape[1], fa.shape[2]
-        xi = np.clip(xxm.astype(np.int32), 0, hh - 1)
-        yi = np.clip(xym.astype(np.int32), 0, ww - 1)
-        rows = [xi * ww + yi, xi * ww + np.clip(yi + 1, 0, ww - 1),
-                np.clip(xi + 1, 0, hh - 1) * ww + yi, np.clip(xi + 1, 0, hh - 1) * ww + np.clip(yi + 1, 0, ww - 1)]
-        rows = [torch.from_numpy(r.astype(np.int64)).to(dev) for r in rows]
+        xi = np.clip(xxm.astype(np.int32), 0, hh - 1).astype(np.int64)
+        yi = np.clip(xym.astype(np.int32), 0, ww - 1).astype(np.int64)
+        xi1, yi1 = np.clip(xi + 1, 0, hh - 1), np.clip(yi + 1, 0, ww - 1)
+        rows[i, 0] = xi * ww + yi
+        rows[i, 1] = xi * ww + yi1
+        rows[i, 2] = xi1 * ww + yi
+        rows[i, 3] = xi1 * ww + yi1
+    wts[4 * L] = np.asarray(xx, dtype=np.float32)
+    wts[4 * L + 1] = np.asarray(xy, dtype=np.float32)
+    rows_d = _upload(rows, dev)                             # two stream-ordered uploads for the whole pyramid
+    wts_d = _upload(wts, dev).unsqueeze(2)                  # [4L+2, n, 1]
+    ca, cb = [], []
+    for i in range(L):
+        r, w = rows_d[i], wts_d[4 * i:4 * i + 4]
 
         def gather(f):
             m = f.reshape(-1, f.shape[3])                         # [h*w, C], rows contiguous
-            return (m.index_select(0, rows[0]) * w00 + m.index_select(0, rows[1]) * w01
-                    + m.index_select(0, rows[2]) * w10 + m.index_select(0, rows[3]) * w11)
-        ca.append(gather(fa))
-        cb.append(gather(fb))
-    cx = torch.from_numpy(np.asarray(xx, dtype=np.float32)).view(-1, 1).to(dev)
-    cy = torch.from_numpy(np.asarray(xy, dtype=np.float32)).view(-1, 1).to(dev)
+            return (m.index_select(0, r[0]) * w[0] + m.index_select(0, r[1]) * w[1]
+                    + m.index_select(0, r[2]) * w[2] + m.index_select(0, r[3]) * w[3])
+        ca.append(gather(feat_a[i]))
+        cb.append(gather(feat_b[i]))
+    cx, cy = wts_d[4 * L], wts_d[4 * L + 1]
     a = torch.cat(ca + [cx, cy], 1).t()[None, :, :, None]
     b = torch.cat(cb + [cx, cy], 1).t()[None, :, :, None]
     return a, b
@@ -218,7 +257,7 @@ def _remd(a, b):
     d = a.shape[1]
     X, Y = _columns(a), _columns(b)
     if d == 3:
-        C = torch.tensor(_YUV, dtype=X.dtype, device=X.device)
+        C = _const("yuv", _YUV, X.device).to(X.dtype)
         X, Y = torch.mm(C, X.t()).t(), torch.mm(C, Y.t()).t()
     M = _cos_dist(X, Y)
     if d == 3:
@@ -250,16 +289,22 @@ def _pair_loss(feat_result, feat_content, feat_style, xx, xy, content_weight, mo
     return (content_weight * loss_content + loss_style) / (content_weight + 1.0 + moment_weight)
 
 
-def _scale_loss(result, content, style, content_weight, lr, extractor):
+def _scale_loss(result, content, style, content_weight, lr, extractor, style_maps=None, recompute=False):
     """`scale_loss` (StyleLoss.py:349-389): 5 x 1000 style hyper-columns, one sampling grid, three evaluations of the
-    refolded image (the grid is reshuffled before the 2nd and 3rd)"""
+    refolded image (the grid is reshuffled before the 2nd and 3rd).  The reference runs VGG16 on the (frozen) style image
+    for each of the 5 draws; the maps are the same every time, so they are computed once (`style_maps`: the caller's copy
+    from an earlier iteration) and only the sampling is repeated.  `recompute=True` is the reference's schedule verbatim (one
+    VGG pass per draw): what bench.py's CPU-baseline leg times."""
     pyramid = _laplace_pyramid(result, 5)
     feat_content = extractor(content)
-    feat_style = None
-    for _ in range(5):
+    if recompute:
         with torch.no_grad():
-            cols = extractor.forward_samples_hypercolumn(style, samps=1000)
-        feat_style = cols if feat_style is None else torch.cat((feat_style, cols), dim=2)
+            feat_style = torch.cat([extractor.forward_samples_hypercolumn(style, samps=1000) for _ in range(5)], dim=2)
+    else:
+        if style_maps is None:
+            with torch.no_grad():
+                style_maps = [f.detach() for f in extractor(style)]
+        feat_style = torch.cat([sample_hypercolumns(style_maps, 1000) for _ in range(5)], dim=2)
     xx, xy = _sample_grid(feat_content[0].shape[1], feat_content[0].shape[2])
     total = 0.0
     for it in range(3):
@@ -271,7 +316,7 @@ def _scale_loss(result, content, style, content_weight, lr, extractor):
     return total
 
 
-def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None):
+def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None, style_cache=None, recompute=False):
     """`strotss_loss` (StyleLoss.py:392-431): coarse-to-fine over the scales whose short side is >= 33 px; the running
     `result` image is the upsampled previous result plus the Laplacian of the content at that scale; only the finest scale
     carries weight 1 (the others 2e-3), the content weight halves per scale"""
@@ -288,7 +333,13 @@ def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None):
             lr = 1
         else:
             result = _resample(result, [content.shape[2], content.shape[3]]) + _laplacian(content)
-        total = total + _scale_loss(result, content, style, content_weight, lr, extractor)
+        maps = None
+        if style_cache is not None and not recompute:          # the style image and the VGG are frozen: its feature maps per scale are too
+            maps = style_cache.get(scale)
+            if maps is None:
+                with torch.no_grad():
+                    maps = style_cache[scale] = [f.detach() for f in extractor(style)]
+        total = total + _scale_loss(result, content, style, content_weight, lr, extractor, maps, recompute)
         content_weight /= 2.0
     return total
 
@@ -296,10 +347,13 @@ def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None):
 # ---------------------------------------------------------------------------------------------- the plugin
 class StyleLoss(LossInterface):
     """`StyleLoss` (StyleLoss.py:458-500).  Extra constructor arguments (not in the reference): `extractor` (anything with the
-    `Vgg16Extractor` call surface), `vgg_params` (torchvision VGG16 state dict), `style_image` ([1,3,h,w] tensor in [0,1])."""
+    `Vgg16Extractor` call surface), `vgg_params` (torchvision VGG16 state dict), `style_image` ([1,3,h,w] tensor in [0,1]),
+    `reference_schedule` (recompute the frozen style maps per draw like the reference instead of caching them per scale)."""
 
-    def __init__(self, extractor=None, vgg_params=None, style_image=None, **kwargs):
+    def __init__(self, extractor=None, vgg_params=None, style_image=None, reference_schedule=False, **kwargs):
+        self.reference_schedule = reference_schedule   # True: one VGG pass per style draw, every iteration (StyleLoss.py:357-362)
         self.resized = None
+        self._style_cache = {}          # scale -> VGG16 maps of the resized style image (frozen inputs: computed once)
         self.extractor = extractor
         self.vgg_params = vgg_params
         self.style = style_image
@@ -336,8 +390,10 @@ class StyleLoss(LossInterface):
                 raise ValueError("StyleLoss: no style image (set --style_file or pass style_image=)")
             self.resized = F.interpolate(self.style.to(out.device, torch.float32), out.size()[2:4], mode="bicubic",
                                          align_corners=False)
+            self._style_cache = {}
         if globals["cur_iteration"] < args.styleloss_skip:
             return torch.tensor(0.0)
         if globals["cur_iteration"] % args.styleloss_every != 0:
             return torch.tensor(0.0)
-        return strotss_loss(out, self.resized, args.styleloss_content_weight, extractor=self.extractor)
+        return strotss_loss(out, self.resized, args.styleloss_content_weight, extractor=self.extractor,
+                            style_cache=self._style_cache, recompute=self.reference_schedule)

@@ -492,3 +492,23 @@ def test_drawer_and_filter_tables():
     with pytest.raises(ValueError, match="Requested filter not found"):
         plugins.setup_filters("sepia", _Settings())
     assert plugins.setup_filters(None, _Settings()) == []
+
+
+def test_hypercolumn_index_shuffle_is_the_reference_row_shuffle():
+    """style_loss.sample_hypercolumns shuffles a 1-D index array instead of the reference's [H*W, 2] coordinate table
+    (StyleLoss.py:52-57): same Fisher-Yates walk, same `random_interval` draws -> same rows kept AND the same np.random
+    state afterwards (everything drawn later in the iteration is unchanged)."""
+    import numpy as np
+    H, W, samps = 37, 52, 100
+    xx, xy = np.meshgrid(np.arange(H), np.arange(W))
+    xc = np.concatenate([np.expand_dims(xx.flatten(), 1), np.expand_dims(xy.flatten(), 1)], 1)
+    np.random.seed(11)
+    np.random.shuffle(xc)
+    state_ref = np.random.get_state()
+    np.random.seed(11)
+    idx = np.arange(H * W)
+    np.random.shuffle(idx)
+    state_new = np.random.get_state()
+    idx = idx[:samps]
+    assert np.array_equal(idx % H, xc[:samps, 0]) and np.array_equal(idx // H, xc[:samps, 1])
+    assert np.array_equal(state_ref[1], state_new[1]) and state_ref[2] == state_new[2]
