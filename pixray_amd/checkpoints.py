@@ -93,6 +93,55 @@ def vqgan_from_taming(state_dict: Dict[str, torch.Tensor], cfg: VqganConfig, wit
     return out
 
 
+TAMING_TARGETS = {"taming.models.vqgan.VQModel": ("", False), "taming.models.vqgan.GumbelVQ": ("", True),
+                  "taming.models.cond_transformer.Net2NetTransformer": ("first_stage_model.", False)}
+
+
+def vqgan_config_from_taming_yaml(path_or_dict):
+    """taming's model yaml (`model.target` + `model.params.{embed_dim, n_embed, ddconfig}`; what `OmegaConf.load` reads at
+    vqgan.py:121) -> (VqganConfig, key prefix of the first-stage model inside the checkpoint, gumbel flag).  For a
+    Net2NetTransformer config the first stage is `params.first_stage_config` (vqgan.py:131-135)."""
+    import yaml
+    doc = path_or_dict
+    if not isinstance(doc, dict):
+        with open(path_or_dict) as f:
+            doc = yaml.safe_load(f)
+    model = doc["model"]
+    target = model["target"]
+    if target not in TAMING_TARGETS:
+        raise ValueError(f"unknown model type: {target}")                     # vqgan.py:136-137
+    prefix, gumbel = TAMING_TARGETS[target]
+    prm = model["params"]
+    if prefix:                                                                # the transformer wraps a VQModel config
+        prm = prm["first_stage_config"]["params"]
+    dd = prm["ddconfig"]
+    if dd.get("double_z", False):
+        raise ValueError("ddconfig.double_z=True is a KL autoencoder, not a VQGAN")
+    cfg = VqganConfig(ch=int(dd["ch"]), ch_mult=tuple(int(m) for m in dd["ch_mult"]), num_res_blocks=int(dd["num_res_blocks"]),
+                      attn_resolutions=tuple(int(r) for r in dd["attn_resolutions"]), resolution=int(dd["resolution"]),
+                      z_channels=int(dd["z_channels"]), embed_dim=int(prm["embed_dim"]), n_embed=int(prm["n_embed"]),
+                      out_ch=int(dd.get("out_ch", 3)))
+    if int(dd.get("in_channels", 3)) != 3 or cfg.out_ch != 3:
+        raise ValueError("only RGB VQGANs are supported (ddconfig.in_channels / out_ch must be 3)")
+    return cfg, prefix, gumbel
+
+
+def load_taming(config_path: str, checkpoint_path: str, with_encoder: bool = None):
+    """The reference's `load_model` (vqgan.py:96-140) without the download and without taming: yaml ddconfig -> VqganConfig,
+    Lightning `.ckpt` (`{"state_dict": ...}` with `loss.*` discriminator entries that `del model.loss` drops) -> the ordered
+    parameter dict of the HIP runner.  GumbelVQ keeps its codebook under `quantize.embed.weight` (vqgan.py:193): renamed to
+    the runner's `quantize.embedding.weight`.  -> (cfg, params, gumbel)"""
+    cfg, prefix, gumbel = vqgan_config_from_taming_yaml(config_path)
+    blob = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    sd = blob.get("state_dict", blob)
+    if prefix:
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    sd = {k: v for k, v in sd.items() if not k.startswith("loss.")}
+    if gumbel and "quantize.embed.weight" in sd:
+        sd["quantize.embedding.weight"] = sd.pop("quantize.embed.weight")
+    return cfg, vqgan_from_taming(sd, cfg, with_encoder), gumbel
+
+
 def vgg16_from_torchvision(state_dict: Dict[str, torch.Tensor]):
     """torchvision VGG16 state dict (optionally wrapped as {"state_dict": ...} or prefixed `module.`) -> the 26 tensors the
     StyleLoss extractor needs (`pixray_amd.style_loss.Vgg16Extractor(params=...)`)"""

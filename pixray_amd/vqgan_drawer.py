@@ -36,9 +36,22 @@ class VqganDrawer(DrawingInterface):
         self._fused_clamp = False
 
     def load_model(self, settings, device):
-        if self.vqgan_model not in VQGAN_CONFIGS:
+        # vqgan.py:100-108: explicit --vqgan_config / --vqgan_checkpoint, else models/vqgan_<name>.{yaml,ckpt}; files that
+        # are not there are NOT downloaded (vqgan.py:110-113 would wget them) -- without them the seeded synthetic weights
+        # of the named architecture are used, or the caller's `settings.vqgan_state_dict`
+        import os
+        cfg_path = getattr(settings, "vqgan_config", None) or f"models/vqgan_{self.vqgan_model}.yaml"
+        ckpt_path = getattr(settings, "vqgan_checkpoint", None) or f"models/vqgan_{self.vqgan_model}.ckpt"
+        explicit = bool(getattr(settings, "vqgan_config", None) or getattr(settings, "vqgan_checkpoint", None))
+        if self.state_dict is None and os.path.exists(cfg_path) and os.path.exists(ckpt_path):
+            from .checkpoints import load_taming
+            self.cfg, self.state_dict, self.gumbel = load_taming(cfg_path, ckpt_path)
+        elif explicit and self.state_dict is None:
+            raise FileNotFoundError(f"VQGAN config / checkpoint not found: {cfg_path}, {ckpt_path} (nothing is downloaded)")
+        elif self.vqgan_model not in VQGAN_CONFIGS:
             raise ValueError(f"unknown model type: {self.vqgan_model}")
-        self.cfg = VQGAN_CONFIGS[self.vqgan_model]
+        else:
+            self.cfg = VQGAN_CONFIGS[self.vqgan_model]
         self.device = torch.device(device)
         params = self.state_dict if self.state_dict is not None else synthetic_vqgan_params(self.cfg, self.weight_seed)
         f = 2 ** (self.cfg.num_resolutions - 1)

@@ -11,6 +11,7 @@
   /root/reference when present) drop into the loop.
 """
 import argparse
+from collections import OrderedDict
 import ctypes
 import importlib.util
 import os
@@ -512,3 +513,77 @@ def test_hypercolumn_index_shuffle_is_the_reference_row_shuffle():
     idx = idx[:samps]
     assert np.array_equal(idx % H, xc[:samps, 0]) and np.array_equal(idx // H, xc[:samps, 1])
     assert np.array_equal(state_ref[1], state_new[1]) and state_ref[2] == state_new[2]
+
+
+def _taming_yaml(cfg, target="taming.models.vqgan.VQModel"):
+    """the layout of taming's model yamls (what vqgan.py:121 loads with OmegaConf)"""
+    dd = dict(double_z=False, z_channels=cfg.z_channels, resolution=cfg.resolution, in_channels=3, out_ch=3, ch=cfg.ch,
+              ch_mult=list(cfg.ch_mult), num_res_blocks=cfg.num_res_blocks, attn_resolutions=list(cfg.attn_resolutions), dropout=0.0)
+    params = dict(embed_dim=cfg.embed_dim, n_embed=cfg.n_embed, ddconfig=dd,
+                  lossconfig=dict(target="taming.modules.losses.vqperceptual.VQLPIPSWithDiscriminator", params=dict(disc_start=0)))
+    if target.endswith("Net2NetTransformer"):
+        params = dict(first_stage_config=dict(target="taming.models.vqgan.VQModel", params=params),
+                      transformer_config=dict(target="taming.modules.transformer.mingpt.GPT", params=dict(vocab_size=cfg.n_embed)))
+    return dict(model=dict(base_learning_rate=4.5e-6, target=target, params=params))
+
+
+@pytest.mark.parametrize("target", ["taming.models.vqgan.VQModel", "taming.models.vqgan.GumbelVQ",
+                                    "taming.models.cond_transformer.Net2NetTransformer"])
+def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
+    """vqgan.py:96-140 without taming and without the download: yaml ddconfig -> VqganConfig, Lightning-format .ckpt
+    ({"state_dict": ...} carrying discriminator weights, a GumbelVQ codebook name, or a transformer's first-stage prefix) ->
+    exactly the tensors the HIP runner is created from, in the C ABI's order; VqganDrawer.load_model picks the pair up."""
+    import argparse
+    import yaml
+    from pixray_amd import checkpoints, weights
+    from pixray_amd.vqgan_drawer import VqganDrawer
+    cfg = weights.VQGAN_CONFIGS["tiny_f4"]
+    dec = weights.synthetic_vqgan_params(cfg, seed=5)
+    enc = weights.synthetic_vqgan_encoder_params(cfg, seed=5, codebook=dec["quantize.embedding.weight"])
+    sd = OrderedDict(dec)
+    sd.update(enc)
+    prefix, gumbel = checkpoints.TAMING_TARGETS[target]
+    if gumbel:
+        sd["quantize.embed.weight"] = sd.pop("quantize.embedding.weight")
+    sd = OrderedDict((prefix + k, v) for k, v in sd.items())
+    sd[prefix + "loss.discriminator.main.0.weight"] = torch.zeros(8, 3, 4, 4)          # dropped by `del model.loss`
+    if prefix:
+        sd["transformer.tok_emb.weight"] = torch.zeros(4, 4)
+    ypath, cpath = tmp_path / "vqgan_custom.yaml", tmp_path / "vqgan_custom.ckpt"
+    ypath.write_text(yaml.safe_dump(_taming_yaml(cfg, target)))
+    torch.save({"state_dict": sd, "global_step": 7, "epoch": 0}, cpath)
+
+    got_cfg, params, got_gumbel = checkpoints.load_taming(str(ypath), str(cpath))
+    assert got_cfg == cfg and got_gumbel == gumbel
+    want = list(OrderedDict.fromkeys(list(weights.vqgan_param_shapes(cfg)) + list(weights.vqgan_encoder_param_shapes(cfg))))
+    assert list(params) == want            # decoder entries in the C ABI's order, then the encoder's (codebook shared)
+    for k in weights.vqgan_param_shapes(cfg):
+        assert torch.equal(params[k], dec[k]), k
+    for k in weights.vqgan_encoder_param_shapes(cfg):
+        assert torch.equal(params[k], enc[k]), k
+
+    class _Stop(Exception):
+        pass
+
+    # the drawer resolves the same pair from --vqgan_config / --vqgan_checkpoint (no GPU here: stop at handle creation)
+    args = VqganDrawer.add_settings(argparse.ArgumentParser()).parse_args(
+        ["--vqgan_model", "custom", "--vqgan_config", str(ypath), "--vqgan_checkpoint", str(cpath)])
+    args.size = (64, 64)
+    drawer = VqganDrawer(args)
+    from pixray_amd import ops
+    real = ops.VqganHandle
+    try:
+        def stop(cfg_, params_, *a, **k):
+            assert cfg_ == cfg and torch.equal(params_["decoder.conv_in.weight"], dec["decoder.conv_in.weight"])
+            raise _Stop()
+        ops.VqganHandle = stop
+        with pytest.raises(_Stop):
+            drawer.load_model(args, "cpu")
+    finally:
+        ops.VqganHandle = real
+    bad = VqganDrawer.add_settings(argparse.ArgumentParser()).parse_args(["--vqgan_config", str(tmp_path / "nope.yaml")])
+    bad.size = (64, 64)
+    with pytest.raises(FileNotFoundError):
+        VqganDrawer(bad).load_model(bad, "cpu")
+    with pytest.raises(ValueError, match="unknown model type"):
+        checkpoints.vqgan_config_from_taming_yaml(dict(model=dict(target="taming.models.other.Thing", params={})))
