@@ -581,7 +581,303 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_gen_kernel(const bf16_t* __res
     store_c_global(dv, ob2 + 2 * C, ld, T - k0, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64 < T <= 512 (ViT-B/16: 197, ViT-L/14: 257, RN50x4 attention pool: 82): one WORKGROUP per (image, head) with one
+// wave per 32 tokens, the register-resident scheme of the T <= 64 kernels above (scores with the owned tokens on the
+// lane columns, so that the probabilities are already the A operand of the second product) streamed over 128-token LDS
+// chunks of the other operand.  The tile kernels further below (one wave per 64-query tile, every wave re-staging and
+// re-transposing K / V for itself, 36-55 KB of LDS per wave) ran ViT-L/14 at 256 cutouts at 1.5 / 1.9 / 6.0 ms per
+// layer (forward / dQ / dK+dV: 2-3 waves per CU); they remain for T > 512 and for the causal text tower.
+//   forward : online softmax per owned query (running max / sum per lane); the rescale factors reach the O accumulators
+//             (queries on register rows) through a 32-float LDS line per wave
+//   backward: dQ kernel (owned queries, chunks of K / V / K^T) and dK+dV kernel (owned keys, chunks of Q / dO / Q^T /
+//             dO^T with the per-query LSE and D = rowsum(dO o O) staged beside them); both recompute P from the LSE
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CH = 128;             // tokens per LDS chunk (four 32-token MFMA blocks)
+constexpr int TRS = 132;            // row stride (bf16) of a transposed [64][CH] image: 66 dwords = 2 mod 64 banks, so the 32
+                                    // rows d .. d+31 of one 8-byte fragment read fall into 32 distinct bank pairs
+
+// rows t0 .. t0+CH-1 of a [T][64] matrix (zero beyond T) -> row-major image and / or transposed image
+__device__ __forceinline__ void stage_chunk(const bf16_t* src, long long ld, int t0, int T, bf16_t* rm, bf16_t* tr, int tid, int nthr) {
+    for (int c = tid; c < CH * 8; c += nthr) {
+        const int row = c >> 3, kc = c & 7;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + row < T) v = *reinterpret_cast<const bf16x8*>(src + (long long)(t0 + row) * ld + kc * 8);
+        if (rm) *reinterpret_cast<bf16x8*>(&rm[row * LD + kc * 8]) = v;
+        if (tr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tr[(kc * 8 + e) * TRS + row] = v[e];
+        }
+    }
+}
+// the four k16 fragments of token `t` (one token per lane column, zero beyond T): the B operand of "chunk rows x owned tokens"
+__device__ __forceinline__ void own_frags(const bf16_t* src, long long ld, int t, int T, bf16x8 (&f)[4], int lane) {
+    const int fk = 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < T) f[ks] = *reinterpret_cast<const bf16x8*>(src + (long long)t * ld + ks * 16 + fk);
+    }
+}
+// acc = rows 32sb.. of the row-major chunk image (A) x owned tokens (B): [chunk token][owned token]
+__device__ __forceinline__ void mma_chunk_own(const bf16_t* A, int sb, const bf16x8 (&b)[4], f32x16& acc, int lane) {
+    const int fr = lane & 31, fk = 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&A[(sb * 32 + fr) * LD + ks * 16 + fk]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 tr_frag_chunk(const bf16_t* Tt, int dj, int sb, int G, int lane) {
+    const int d = dj * 32 + (lane & 31), t0 = 32 * sb + 16 * G + 4 * (lane >> 5);
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Tt + d * TRS + t0);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Tt + d * TRS + t0 + 8);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// o[dj] += (accumulators a: rows = chunk tokens 32sb.., lane column = owned token) as A  x  transposed chunk image
+__device__ __forceinline__ void mma_acc_tr_chunk(const f32x16& a, const bf16_t* Tt, int sb, f32x16 (&o)[2], int lane) {
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+        const bf16x8 fa = acc_frag(a, G);
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, tr_frag_chunk(Tt, dj, sb, G, lane), o[dj], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+// multiply the register rows of o (row of register r: (r&3) + 8(r>>2) + 4(lane>>5)) by line[row]
+__device__ __forceinline__ void scale_rows(f32x16 (&o)[2], const float* line, int lane) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&line[8 * rg + 4 * hh]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[0][rg * 4 + q] *= av[q]; o[1][rg * 4 + q] *= av[q]; }
+    }
+}
+__device__ __forceinline__ void block_head(int xcd, int& h, int& n) {
+    const unsigned flat = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const unsigned lin = xcd ? xcd_linear(flat, nwg) : flat;
+    h = (int)(lin % gridDim.x); n = (int)(lin / gridDim.x);
+}
+
+constexpr int WPB = 5;               // waves per workgroup: a head with more 32-token blocks is split over gridDim.z workgroups
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mha_fwd_blk_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           float* __restrict__ lse, int T, int C, int heads, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[CH * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * TRS];
+    __shared__ __attribute__((aligned(16))) float s_line[WPB][32];
+    const int tid = threadIdx.x, lane = tid & 63, w = blockIdx.z * (blockDim.x >> 6) + (tid >> 6), hh = lane >> 5;
+    const bool active = 32 * w < T;                        // the last workgroup of a head may carry a wave without tokens
+    int h, n;
+    block_head(xcd, h, n);
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const int q = 32 * w + (lane & 31);                    // this lane's query
+    bf16x8 qf[4];
+    own_frags(base, ld, q, T, qf, lane);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2];
+    zero16(o[0]); zero16(o[1]);
+    float* line = s_line[tid >> 6];
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        __syncthreads();
+        stage_chunk(base + C, ld, c0, T, Ks, nullptr, tid, blockDim.x);
+        stage_chunk(base + 2 * C, ld, c0, T, nullptr, Vt, tid, blockDim.x);
+        __syncthreads();
+        const int nsb = active ? min(CH / 32, (T - c0 + 31) / 32) : 0;
+        for (int sb = 0; sb < nsb; ++sb) {
+            f32x16 st;                                      // [key 32sb..][query]
+            zero16(st);
+            mma_chunk_own(Ks, sb, qf, st, lane);
+            float bm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = (j < T) ? st[r] * scale : -INFINITY;
+                st[r] = v;
+                bm = fmaxf(bm, v);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float mn = fmaxf(m, bm);                  // finite: every 32-key block that is visited has a valid key
+            const float alpha = __expf(m - mn);             // 0 on the first block
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[r] - mn);
+                st[r] = e;
+                sum += e;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            l = l * alpha + sum;
+            m = mn;
+            if (__any(alpha != 1.f)) {                      // the running maximum of some query moved: rescale its O row
+                if (hh == 0) line[lane] = alpha;
+                __builtin_amdgcn_wave_barrier();
+                scale_rows(o, line, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            mma_acc_tr_chunk(st, Vt, sb, o, lane);          // O[query][d] += P[query][key] V[key][d]
+        }
+    }
+    if (!active) return;
+    if (hh == 0) {
+        line[lane] = 1.f / l;
+        if (q < T && lse) lse[((long long)n * heads + h) * T + q] = m + __logf(l);
+    }
+    __builtin_amdgcn_wave_barrier();
+    scale_rows(o, line, lane);
+    store_rows_global(o, w, out + (long long)n * T * C + h * 64, C, T, lane);
+}
+
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mha_bwd_dq_blk_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                              bf16_t* __restrict__ dqkv, int T, int C, int heads, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[CH * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[CH * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * TRS];
+    const int tid = threadIdx.x, lane = tid & 63, w = blockIdx.z * (blockDim.x >> 6) + (tid >> 6), hh = lane >> 5;
+    const bool active = 32 * w < T;
+    int h, n;
+    block_head(xcd, h, n);
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const bf16_t* dob = dout + (long long)n * T * C + h * 64;
+    const bf16_t* ob = o + (long long)n * T * C + h * 64;
+    const int q = 32 * w + (lane & 31);
+    bf16x8 qf[4], dof[4];
+    own_frags(base, ld, q, T, qf, lane);
+    own_frags(dob, C, q, T, dof, lane);
+    float lse_q = INFINITY, D_q = 0.f;                      // exp(x - inf) = 0 for padded queries
+    if (q < T) {
+        lse_q = lse[((long long)n * heads + h) * T + q];
+        float dsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                       // this half-wave's 32 of the 64 head-dim columns
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (long long)q * C + hh * 32 + i * 8);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ob + (long long)q * C + hh * 32 + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
+        }
+        D_q = dsum;
+    }
+    D_q += __shfl_xor(D_q, 32, 64);
+    f32x16 acc[2];
+    zero16(acc[0]); zero16(acc[1]);
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        __syncthreads();
+        stage_chunk(base + C, ld, c0, T, Ks, Kt, tid, blockDim.x);
+        stage_chunk(base + 2 * C, ld, c0, T, Vs, nullptr, tid, blockDim.x);
+        __syncthreads();
+        const int nsb = active ? min(CH / 32, (T - c0 + 31) / 32) : 0;
+        for (int sb = 0; sb < nsb; ++sb) {
+            f32x16 pt, dpt;                                 // [key][query]
+            zero16(pt); zero16(dpt);
+            mma_chunk_own(Ks, sb, qf, pt, lane);            // S^T  = K Q^T
+            mma_chunk_own(Vs, sb, dof, dpt, lane);          // dP^T = V dO^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float p = (j < T) ? __expf(pt[r] * scale - lse_q) : 0.f;
+                dpt[r] = scale * p * (dpt[r] - D_q);        // dS^T
+            }
+            mma_acc_tr_chunk(dpt, Kt, sb, acc, lane);       // dQ[query][d] += dS[query][key] K[key][d]
+        }
+    }
+    if (active) store_rows_global(acc, w, dqkv + (long long)n * T * ld + h * 64, ld, T, lane);
+}
+
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void mha_bwd_dkv_blk_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int T, int C, int heads, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[CH * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[CH * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[64 * TRS];
+    __shared__ __attribute__((aligned(16))) bf16_t dOt[64 * TRS];
+    __shared__ __attribute__((aligned(16))) float s_lse[CH], s_D[CH];
+    const int tid = threadIdx.x, lane = tid & 63, w = blockIdx.z * (blockDim.x >> 6) + (tid >> 6), hh = lane >> 5;
+    const bool active = 32 * w < T;
+    int h, n;
+    block_head(xcd, h, n);
+    const long long ld = 3LL * C;
+    const bf16_t* base = qkv + (long long)n * T * ld + h * 64;
+    const bf16_t* dob = dout + (long long)n * T * C + h * 64;
+    const bf16_t* ob = o + (long long)n * T * C + h * 64;
+    const float* lse_h = lse + ((long long)n * heads + h) * T;
+    const int key = 32 * w + (lane & 31);
+    const bool key_ok = key < T;
+    bf16x8 kf[4], vf[4];
+    own_frags(base + C, ld, key, T, kf, lane);
+    own_frags(base + 2 * C, ld, key, T, vf, lane);
+    f32x16 dk[2], dv[2];
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        __syncthreads();
+        stage_chunk(base, ld, c0, T, Qs, Qt, tid, blockDim.x);
+        // dO chunk, and beside it D_i = sum_d dO_id O_id (eight lanes share a row: one 8-column piece each)
+        for (int c = tid; c < CH * 8; c += blockDim.x) {
+            const int row = c >> 3, kc = c & 7;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            float part = 0.f;
+            if (c0 + row < T) {
+                v = *reinterpret_cast<const bf16x8*>(dob + (long long)(c0 + row) * C + kc * 8);
+                const bf16x8 ov = *reinterpret_cast<const bf16x8*>(ob + (long long)(c0 + row) * C + kc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (float)v[e] * (float)ov[e];
+            }
+            *reinterpret_cast<bf16x8*>(&dOs[row * LD + kc * 8]) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dOt[(kc * 8 + e) * TRS + row] = v[e];
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (kc == 0) {
+                s_D[row] = part;
+                s_lse[row] = (c0 + row < T) ? lse_h[c0 + row] : INFINITY;
+            }
+        }
+        __syncthreads();
+        const int nsb = active ? min(CH / 32, (T - c0 + 31) / 32) : 0;
+        for (int sb = 0; sb < nsb; ++sb) {
+            f32x16 p, dp;                                   // [query 32sb..][key]
+            zero16(p); zero16(dp);
+            mma_chunk_own(Qs, sb, kf, p, lane);             // S  = Q K^T
+            mma_chunk_own(dOs, sb, vf, dp, lane);           // dP = dO V^T
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int i0 = sb * 32 + 8 * rg + 4 * hh;
+                const float4 l4 = *reinterpret_cast<const float4*>(&s_lse[i0]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&s_D[i0]);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int r = rg * 4 + qq;
+                    const float pv = key_ok ? __expf(p[r] * scale - lv[qq]) : 0.f;
+                    p[r] = pv;
+                    dp[r] = scale * pv * (dp[r] - dvv[qq]);   // dS
+                }
+            }
+            mma_acc_tr_chunk(dp, Qt, sb, dk, lane);         // dK[key][d] += dS[query][key] Q[query][d]
+            mma_acc_tr_chunk(p, dOt, sb, dv, lane);         // dV[key][d] += P[query][key] dO[query][d]
+        }
+    }
+    if (!active) return;
+    bf16_t* obase = dqkv + (long long)n * T * ld + h * 64;
+    store_rows_global(dk, w, obase + C, ld, T, lane);
+    store_rows_global(dv, w, obase + 2 * C, ld, T, lane);
+}
+
 }  // namespace
+
+// PRX_MHA_TILES=1: route 64 < T <= 512 through the tile kernels as well (A/B measurements; keeps the T > 512 path tested)
+static bool prx_mha_force_tiles() {
+    static const bool v = [] { const char* e = getenv("PRX_MHA_TILES"); return e && e[0] == '1'; }();
+    return v;
+}
 
 int prx_mha_fwd(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(T <= 64 && C == heads * 64, "mha: needs T <= 64 and head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
@@ -599,6 +895,12 @@ int prx_mha_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int N, int 
 
 int prx_mha_fwd_gen(const bf16_t* qkv, bf16_t* out, float* lse, int N, int T, int C, int heads, hipStream_t s) {
     PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(gen): needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
+    if (T <= 512 && !prx_mha_force_tiles()) {       // workgroups of <= 5 waves per (image, head), one wave per 32 tokens
+        const int nw = ceil_div(T, 32), nsplit = ceil_div(nw, 5), wpb = ceil_div(nw, nsplit);
+        hipLaunchKernelGGL(mha_fwd_blk_kernel, dim3(heads, N, nsplit), dim3(64 * wpb), 0, s, qkv, out, lse, T, C, heads, 0.125f, prx_xcd_local());
+        PRX_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(mha_fwd_gen_kernel<false>, dim3(ceil_div(T, 64), heads, N), dim3(64), 0, s, qkv, out, lse, T, C, heads, 0.125f);
     PRX_LAUNCH_CHECK();
     return 0;
@@ -613,6 +915,16 @@ int prx_mha_fwd_causal(const bf16_t* qkv, bf16_t* out, int N, int T, int C, int 
 int prx_mha_bwd_gen(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int N, int T,
                     int C, int heads, hipStream_t s) {
     PRX_REQUIRE(C == heads * 64 && T >= 1, "mha(gen) bwd: needs head dim 64 (T=%d C=%d heads=%d)", T, C, heads);
+    if (T <= 512 && !prx_mha_force_tiles()) {
+        const int nw = ceil_div(T, 32), nsplit = ceil_div(nw, 5), wpb = ceil_div(nw, nsplit);
+        const dim3 g(heads, N, nsplit), b(64 * wpb);
+        const int xcd = prx_xcd_local();
+        hipLaunchKernelGGL(mha_bwd_dq_blk_kernel, g, b, 0, s, qkv, out, dout, lse, dqkv, T, C, heads, 0.125f, xcd);
+        PRX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mha_bwd_dkv_blk_kernel, g, b, 0, s, qkv, out, dout, lse, dqkv, T, C, heads, 0.125f, xcd);
+        PRX_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(ceil_div(T, 64), heads, N);
     hipLaunchKernelGGL(mha_bwd_dq_gen_kernel, grid, dim3(64), 0, s, qkv, out, dout, lse, dqkv, T, C, heads, 0.125f);
     PRX_LAUNCH_CHECK();

@@ -327,12 +327,17 @@ def test_mha_fwd_bwd(N, T):
         assert e < 1.2e-2, (nm, e)
 
 
-@pytest.mark.parametrize("N,T", [(2, 65), (3, 197), (2, 257), (4, 50)])
-def test_mha_general_fwd_bwd(N, T):
-    """flash-style attention for any sequence length (ViT-B/16: 197 tokens, ViT-L/14: 257)"""
+@pytest.mark.parametrize("N,T,qs", [(2, 65, 1.0), (3, 197, 1.0), (2, 257, 1.0), (4, 50, 1.0), (2, 82, 1.0), (1, 130, 1.0), (1, 300, 1.0),
+                                    (1, 512, 1.0), (1, 577, 1.0), (2, 257, 6.0), (1, 197, 6.0)])
+def test_mha_general_fwd_bwd(N, T, qs):
+    """flash-style attention for any sequence length (ViT-B/16: 197 tokens, ViT-L/14: 257, RN50x4 attention pool: 82):
+    workgroup-per-head kernels up to 512 tokens (one, two or four workgroups per head), tile kernels beyond (577 = ViT-L/14
+    at 336 px); `qs` scales the queries so that the running maximum of the online softmax moves between key blocks"""
     torch.manual_seed(N * T + 1)
     C, heads = 256, 4
-    qkv = bf(torch.randn(N * T, 3 * C, device=DEV))
+    qkv = torch.randn(N * T, 3 * C, device=DEV)
+    qkv[:, :C] *= qs
+    qkv = bf(qkv)
     out = torch.full((N * T, C), float("nan"), dtype=torch.bfloat16, device=DEV)
     lse = torch.full((N * heads * T,), float("nan"), device=DEV)
     call("prx_k_mha_fwd_gen", qkv, out, lse, N, T, C, heads, stream())
