@@ -436,8 +436,8 @@ def test_config2_at_the_per_gpu_shard_size_vs_oracle():
     r = workload_ref.compare_workload("cfg2", 16, precisions=("f32", "bf16"))
     print("cfg2 @16:", r)
     assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
-    assert r["f32"]["grad_rel_l2"] < 1e-3 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
-    assert r["bf16"]["grad_rel_l2"] < 8e-2 and r["bf16"]["grad_cosine"] > 0.997, r["bf16"]
+    assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]      # measured 1.2e-4
+    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]       # measured 2.4e-2 / 0.99978
 
 
 def test_config3_at_the_per_gpu_shard_size_vs_oracle():
@@ -451,8 +451,8 @@ def test_config3_at_the_per_gpu_shard_size_vs_oracle():
                                       custom_ref=[{"loss": workload_ref.SaturationLossRef(), "weight": 1.0}])
     print("cfg3 @32:", r)
     assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
-    assert r["f32"]["grad_rel_l2"] < 1e-3 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
-    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]
+    assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]      # measured 7.6e-5
+    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]       # measured 1.6e-2 / 0.99988
 
 
 def test_config3_styleloss_term_at_512_bf16_vs_f32_extractor():
