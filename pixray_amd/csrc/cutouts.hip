@@ -564,33 +564,58 @@ __device__ __forceinline__ void gather_candidate(const GatherStage& st, const Ti
     }
 }
 
-// Work scheduling inside a wave.  Most source pixels have ONE raw rectangle whose pre-image holds a few dozen destination
-// pixels (about (2 * magnification + 1)^2); edge pixels under border padding own a whole strip of the padded area and pixels
-// near an edge under reflection own up to nine rectangles.  A lane that walks 10x the candidates of its neighbours stalls
-// the other 63, so a pixel whose count exceeds `budget` (twice the wave's average, at least HEAVY_MIN) is handed to the whole
-// wave: 64 lanes stride through its candidates and a fixed butterfly combines the partial sums (the order of the additions
-// depends only on the geometry, never on timing).
-constexpr int HEAVY_MIN = 48;
-
-// all rectangles of (sx, sy), cooperatively: every lane passes the same pixel
-__device__ __forceinline__ void gather_pixel_coop(const GatherStage& st, const StageMap& sm, const TileStage& ts, int sx, int sy,
-                                                  float (&acc)[3]) {
+// All contributions to source pixel (sx, sy).  `coop`: the 64 lanes of the wave share the enumeration of ONE pixel (every
+// lane passes the same sx, sy) and the partial sums are combined by a fixed butterfly; otherwise the lane works alone.
+constexpr int HEAVY = 96;        // candidates above which a pixel is handed to the whole wave (border strips, corners)
+template <bool COOP>
+__device__ __forceinline__ int gather_pixel(const GatherStage& st, const StageMap& sm, const TileStage& ts, int sx, int sy,
+                                            float (&acc)[3], int budget) {
     float xa[MAXI], xb[MAXI], ya[MAXI], yb[MAXI];
     const int nx = tap_intervals(st.mode, sx, st.Ws, sm.ulo, sm.uhi, xa, xb);
     const int ny = tap_intervals(st.mode, sy, st.Hs, sm.vlo, sm.vhi, ya, yb);
     const int lane = threadIdx.x & 63;
+    int total = 0;
+    // Only border padding creates unbounded rectangles (an edge pixel owns the whole strip of padded area beside it); under
+    // reflection / zeros / fill every rectangle is a 2 x 2 source square, so the counting pass is skipped there.
+    const bool may_be_heavy = st.mode == MODE_BORDER;
+    if (!COOP && (may_be_heavy || (nx == 1 && ny == 1))) {       // first pass: how much work is it?
+        if (nx == 1 && ny == 1) {                  // the common case (interior pixel, or zero / fill padding): one box, used directly
+            int x0, x1, y0, y1;
+            if (!preimage_box(sm, xa[0], xb[0], ya[0], yb[0], st.Wd, st.Hd, x0, x1, y0, y1)) return 0;
+            total = (x1 - x0 + 1) * (y1 - y0 + 1);
+            if (total > budget && may_be_heavy) return total;
+            if (!may_be_heavy) total = 0;              // a large magnification is uniform over the wave: every lane works alone
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[0], xb[0], ya[0], yb[0], acc);
+            return total;
+        }
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                int x0, x1, y0, y1;
+                if (preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) total += (x1 - x0 + 1) * (y1 - y0 + 1);
+            }
+        if (total > budget) return total;          // too much for one lane: the caller schedules a cooperative pass
+    }
     for (int j = 0; j < ny; ++j)
         for (int i = 0; i < nx; ++i) {
             int x0, x1, y0, y1;
             if (!preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) continue;
             const int bw = x1 - x0 + 1, cnt = bw * (y1 - y0 + 1);
-            for (int k = lane; k < cnt; k += 64)
-                gather_candidate(st, ts, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+            if (COOP) {
+                for (int k = lane; k < cnt; k += 64)
+                    gather_candidate(st, ts, x0 + k % bw, y0 + k / bw, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+            } else {
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
+            }
         }
+    if (COOP) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+            for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+    }
+    return total;
 }
 
 // one block = a 16 x 16 tile of SOURCE pixels of one cutout; out-of-tile / out-of-window pixels idle
@@ -620,49 +645,16 @@ __device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMa
     }
     __syncthreads();
     float acc[3] = {0.f, 0.f, 0.f};
-    // ---- this lane's rectangles; a single rectangle (interior pixel, or zero / fill padding) keeps its box in registers
-    float xa[MAXI], xb[MAXI], ya[MAXI], yb[MAXI];
-    int nx = 0, ny = 0;
-    if (live) {
-        nx = tap_intervals(st.mode, sx, st.Ws, sm.ulo, sm.uhi, xa, xb);
-        ny = tap_intervals(st.mode, sy, st.Hs, sm.vlo, sm.vhi, ya, yb);
-    }
-    const bool single = nx == 1 && ny == 1;
-    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, total = 0;
-    if (single && preimage_box(sm, xa[0], xb[0], ya[0], yb[0], st.Wd, st.Hd, bx0, bx1, by0, by1)) total = (bx1 - bx0 + 1) * (by1 - by0 + 1);
-    // the wave's typical count (single-rectangle lanes) sets the budget of a lane working alone
-    int sum = total, cntl = (single && total > 0) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cntl += __shfl_xor(cntl, o, 64); }
-    const int budget = max(HEAVY_MIN, 2 * (sum / max(cntl, 1)));
-    bool heavy = false;
-    if (single) {
-        if (total > budget) heavy = true;
-        else
-            for (int y = by0; y <= by1; ++y)
-                for (int x = bx0; x <= bx1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[0], xb[0], ya[0], yb[0], acc);
-    } else if (nx > 0 && ny > 0) {
-        // several rectangles: walk them directly and give up (partial sums discarded) once the budget is exceeded
-        int done = 0;
-        for (int j = 0; j < ny && !heavy; ++j)
-            for (int i = 0; i < nx && !heavy; ++i) {
-                int x0, x1, y0, y1;
-                if (!preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) continue;
-                done += (x1 - x0 + 1) * (y1 - y0 + 1);
-                if (done > budget) { heavy = true; break; }
-                for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) gather_candidate(st, ts, x, y, sx, sy, xa[i], xb[i], ya[j], yb[j], acc);
-            }
-        if (heavy) { acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; }
-    }
-    // pixels that were too heavy for one lane (nothing kept from them yet): the wave takes them one by one, in lane order
-    unsigned long long hv = __ballot(heavy);
-    while (hv) {
-        const int src = __ffsll((long long)hv) - 1;
-        hv &= hv - 1;
+    int work = 0;
+    if (live) work = gather_pixel<false>(st, sm, ts, sx, sy, acc, HEAVY);
+    // pixels that were too heavy for one lane (work > HEAVY: nothing accumulated yet): the wave takes them one by one
+    unsigned long long heavy = __ballot(live && work > HEAVY);
+    while (heavy) {
+        const int src = __ffsll((long long)heavy) - 1;
+        heavy &= heavy - 1;
         const int hx = __shfl(sx, src, 64), hy = __shfl(sy, src, 64);
         float a2[3] = {0.f, 0.f, 0.f};
-        gather_pixel_coop(st, sm, ts, hx, hy, a2);
+        gather_pixel<true>(st, sm, ts, hx, hy, a2, 0);
         if ((int)(threadIdx.x & 63) == src) { acc[0] = a2[0]; acc[1] = a2[1]; acc[2] = a2[2]; }
     }
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
