@@ -52,6 +52,8 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
 #define PRX_ACT_MUL_DQUICKGELU 2 /* multiply by QuickGELU'(aux) (backward) */
 #define PRX_ACT_RELU 3           /* max(v, 0) after bias / residual (CLIP ModifiedResNet [UPSTREAM clip/model.py]) */
 #define PRX_ACT_MUL_RELUMASK 4   /* multiply by (aux > 0): ReLU backward, aux = the forward output */
+#define PRX_ACT_RELUMASK_POST 5  /* the same mask applied AFTER the residual add: (acc + resid) * (aux > 0) -- the gradient
+                                    arriving at a Bottleneck's output ReLU, formed in the epilogue of the GEMM that sums it */
 #define PRX_A_ROWMAJOR 0
 #define PRX_A_CONV3X3 1          /* implicit im2col of an NHWC tensor, 3x3 pad 1 */
 

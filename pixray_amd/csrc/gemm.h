@@ -14,7 +14,8 @@
 
 enum { PRX_ACT_NONE = 0, PRX_ACT_QUICKGELU = 1, PRX_ACT_MUL_DQUICKGELU = 2,
        PRX_ACT_RELU = 3,            // max(v, 0) after bias / residual (CLIP ModifiedResNet)
-       PRX_ACT_MUL_RELUMASK = 4 };  // v *= (aux > 0): ReLU backward with the forward OUTPUT as aux
+       PRX_ACT_MUL_RELUMASK = 4,    // v *= (aux > 0): ReLU backward with the forward OUTPUT as aux
+       PRX_ACT_RELUMASK_POST = 5 }; // the same mask after the residual add: (acc + resid) * (aux > 0)
 enum { PRX_A_ROWMAJOR = 0, PRX_A_CONV3X3 = 1 };
 
 struct GemmDesc {

@@ -76,6 +76,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     if (d.act == PRX_ACT_MUL_DQUICKGELU) v *= dquickgelu_f(op_ld(aux, (size_t)row * d.ldaux + col));
     if (d.act == PRX_ACT_MUL_RELUMASK && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f)) v = 0.f;
     if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
+    if (d.act == PRX_ACT_RELUMASK_POST && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f)) v = 0.f;
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
         const TOp pre = (TOp)v;     // the saved pre-activation is what the backward differentiates: activate its rounded value
@@ -112,6 +113,14 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     if (d.resid) {
         const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (d.act == PRX_ACT_RELUMASK_POST) {
+        float t[4];
+        op_ld4(aux, (size_t)row * d.ldaux + col, t);
+        if (!(t[0] > 0.f)) v.x = 0.f;
+        if (!(t[1] > 0.f)) v.y = 0.f;
+        if (!(t[2] > 0.f)) v.z = 0.f;
+        if (!(t[3] > 0.f)) v.w = 0.f;
     }
     if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (d.act == PRX_ACT_QUICKGELU) {
@@ -1041,7 +1050,8 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         PRX_REQUIRE(d.up != 2 || d.f32 || (c64 && !d.a_is_f32 && cx.use_glds),
                     "gemm/conv: the stride-2 gather needs a bf16 operand with Cin %% 64 == 0 (Cin=%d)", d.Cin);
     }
-    PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK) || d.aux, "gemm: MUL_DQUICKGELU / MUL_RELUMASK need aux");
+    PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK && d.act != PRX_ACT_RELUMASK_POST) || d.aux,
+                "gemm: MUL_DQUICKGELU / MUL_RELUMASK / RELUMASK_POST need aux");
     PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------

@@ -43,53 +43,78 @@ __global__ __launch_bounds__(256) void rn_pack_conv3x3_kernel(const float* __res
 }
 
 // stem conv1: y = relu(conv3x3 stride 2 pad 1 (normalise(cutouts)) + b) -> NHWC bf16 [n, Ho*Wo, Co]
-// normalise = slip.py:21-42: (x - min) / (max - min) with the batch-global min / max, then CLIP mean / std
-template <typename TOp>
+// normalise = slip.py:21-42: (x - min) / (max - min) with the batch-global min / max, then CLIP mean / std.
+// One thread per OUTPUT PIXEL: its 27 normalised inputs are loaded once and all CO channels are produced from the weights
+// in LDS ([tap][co], read as wave-wide broadcasts), the CO results leave as 16-byte stores.  (One thread per output
+// element -- 27 scattered loads and 27 weight loads each, 40 threads re-reading the same inputs -- took 3.0 ms for
+// RN50x4 at 128 cutouts; the accumulation order per channel, (c, ky, kx) after the bias, is unchanged.)
+template <typename TOp, int CO>
 __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        void* __restrict__ out_, int N, int S, int Co) {
+                                                        void* __restrict__ out_, int N, int S) {
+    __shared__ float ws[27 * CO], bs[CO];
+    for (int i = threadIdx.x; i < 27 * CO; i += 256) {
+        const int co = i % CO, t = i / CO;               // t = (c*3 + ky)*3 + kx
+        ws[i] = w[co * 27 + t];
+    }
+    for (int i = threadIdx.x; i < CO; i += 256) bs[i] = b[i];
+    __syncthreads();
     TOp* out = reinterpret_cast<TOp*>(out_);
     const int So = S / 2;
     const float mn = mm[0], range = mm[1] - mm[0];
     const float inv = range != 0.f ? 1.f / range : 1.f;
-    const size_t total = (size_t)N * So * So * Co;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % Co);
-        const size_t pix = idx / Co;
+    const size_t total = (size_t)N * So * So;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
         const int xo = (int)(pix % So), yo = (int)((pix / So) % So), n = (int)(pix / ((size_t)So * So));
-        float acc = b[co];
+        float v[27];
+        bool ok[27];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float im = r_clip_mean[c], is = 1.f / r_clip_std[c];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int y = 2 * yo + ky - 1;
-                if (y < 0 || y >= S) continue;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int x = 2 * xo + kx - 1;
-                    if (x < 0 || x >= S) continue;
-                    const float v = ((cut[(((size_t)n * 3 + c) * S + y) * S + x] - mn) * inv - im) * is;
-                    acc += v * w[((co * 3 + c) * 3 + ky) * 3 + kx];
+                    const int y = 2 * yo + ky - 1, x = 2 * xo + kx - 1, t = (c * 3 + ky) * 3 + kx;
+                    ok[t] = y >= 0 && y < S && x >= 0 && x < S;
+                    v[t] = ok[t] ? ((cut[(((size_t)n * 3 + c) * S + y) * S + x] - mn) * inv - im) * is : 0.f;
                 }
-            }
         }
-        out[idx] = (TOp)fmaxf(acc, 0.f);
+        TOp* o = out + pix * CO;
+#pragma unroll
+        for (int c0 = 0; c0 < CO; c0 += 4) {
+            float a[4] = {bs[c0], bs[c0 + 1], bs[c0 + 2], bs[c0 + 3]};
+#pragma unroll
+            for (int t = 0; t < 27; ++t)
+                if (ok[t]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] += v[t] * ws[t * CO + c0 + q];
+                }
+            op_st4(o, (size_t)c0, fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
     }
 }
 
 // dY[n][c][y][x] = sum over (co, ky, kx) with y = 2*yo + ky - 1, x = 2*xo + kx - 1 of g[n][yo][xo][co] * w[co][c][ky][kx]
-// (g already masked by the ReLU of the stem conv1 output)
-template <typename TOp>
+// (g already masked by the ReLU of the stem conv1 output).  One thread per input PIXEL (its three channels): each of the
+// (at most four) taps that reach it reads the CO gradients of one output pixel as contiguous vectors, the weights come
+// from LDS ([ky][kx][c][co]); the order of the additions per channel, (ky, kx, co), is the one-thread-per-element kernel's
+// (which took 7.4 ms for RN50x4 at 128 cutouts: 2-byte loads of 40 values per tap, three threads per pixel re-reading them).
+template <typename TOp, int CO>
 __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__ g_, const float* __restrict__ w, float* __restrict__ dY,
-                                                        int N, int S, int Co) {
+                                                        int N, int S) {
+    __shared__ float ws[27 * CO];
+    for (int i = threadIdx.x; i < 27 * CO; i += 256) {
+        const int co = i % CO, c = (i / CO) % 3, kx = (i / (3 * CO)) % 3, ky = i / (9 * CO);
+        ws[i] = w[((co * 3 + c) * 3 + ky) * 3 + kx];
+    }
+    __syncthreads();
     const TOp* g = reinterpret_cast<const TOp*>(g_);
     const int So = S / 2;
-    const size_t total = (size_t)N * 3 * S * S;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % S), y = (int)((idx / S) % S), c = (int)((idx / ((size_t)S * S)) % 3);
-        const int n = (int)(idx / ((size_t)3 * S * S));
-        float acc = 0.f;
+    const size_t plane = (size_t)S * S, total = (size_t)N * plane;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % S), y = (int)((pix / S) % S), n = (int)(pix / plane);
+        float acc[3] = {0.f, 0.f, 0.f};
         for (int ky = 0; ky < 3; ++ky) {
             const int t = y + 1 - ky;
             if (t < 0 || (t & 1)) continue;
@@ -100,11 +125,23 @@ __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__
                 if (u < 0 || (u & 1)) continue;
                 const int xo = u >> 1;
                 if (xo >= So) continue;
-                const TOp* gp = g + (((size_t)n * So + yo) * So + xo) * Co;
-                for (int co = 0; co < Co; ++co) acc += (float)gp[co] * w[((co * 3 + c) * 3 + ky) * 3 + kx];
+                const TOp* gp = g + (((size_t)n * So + yo) * So + xo) * CO;
+                const float* wp = ws + (ky * 3 + kx) * 3 * CO;
+#pragma unroll
+                for (int c0 = 0; c0 < CO; c0 += 4) {
+                    float gv[4];
+                    op_ld4(gp, (size_t)c0, gv);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[0] += gv[q] * wp[c0 + q];
+                        acc[1] += gv[q] * wp[CO + c0 + q];
+                        acc[2] += gv[q] * wp[2 * CO + c0 + q];
+                    }
+                }
             }
         }
-        dY[idx] = acc;
+        float* o = dY + (size_t)n * 3 * plane + (size_t)y * S + x;
+        o[0] = acc[0]; o[plane] = acc[1]; o[2 * plane] = acc[2];
     }
 }
 
@@ -262,6 +299,23 @@ int ralloc_op(PrxResNet* r, void** p, size_t count) {   // `count` operand eleme
         else        hipLaunchKernelGGL(kernel<bf16_t>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);                \
         PRX_LAUNCH_CHECK();                                                                                              \
     } while (0)
+// the stem kernels keep all CO = width/2 output channels of a pixel in one thread: CO is a template parameter
+// (RN50: 32, RN50x4: 40, RN50x16: 48, RN50x64: 64)
+#define STEM_CASE(kernel, CO_, total, ...)                                                                               \
+    case CO_:                                                                                                            \
+        if (r->f32) hipLaunchKernelGGL((kernel<float, CO_>), dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);          \
+        else        hipLaunchKernelGGL((kernel<bf16_t, CO_>), dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);         \
+        break;
+#define STEM_LAUNCH(kernel, total, co, ...)                                                                              \
+    do {                                                                                                                 \
+        switch (co) {                                                                                                    \
+            STEM_CASE(kernel, 8, total, __VA_ARGS__) STEM_CASE(kernel, 16, total, __VA_ARGS__)                           \
+            STEM_CASE(kernel, 32, total, __VA_ARGS__) STEM_CASE(kernel, 40, total, __VA_ARGS__)                          \
+            STEM_CASE(kernel, 48, total, __VA_ARGS__) STEM_CASE(kernel, 64, total, __VA_ARGS__)                          \
+            default: PRX_REQUIRE(false, "resnet stem: width/2 = %d is not one of 8, 16, 32, 40, 48, 64", co);            \
+        }                                                                                                                \
+        PRX_LAUNCH_CHECK();                                                                                              \
+    } while (0)
 struct RCur { const float* const* w; int n, pos; };
 #define RNEXT(cur, dst) do { PRX_REQUIRE((cur).pos < (cur).n, "resnet_create: weight list too short"); (dst) = (cur).w[(cur).pos++]; } while (0)
 
@@ -397,7 +451,7 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     const int S = r->res, S2 = S / 2, S4 = S / 4, w = r->width, wh = w / 2;
     int e;
     r->cur_n = n;
-    RLAUNCH(stem1_fwd_kernel, (size_t)n * S2 * S2 * wh, cutouts, mm, r->w1, r->b1, r->s1, n, S, wh);
+    STEM_LAUNCH(stem1_fwd_kernel, (size_t)n * S2 * S2, wh, cutouts, mm, r->w1, r->b1, r->s1, n, S);
     if ((e = conv3(r, r->s1, n, S2, wh, r->s2.Wf, wh, r->s2.b, PRX_ACT_RELU, nullptr, nullptr, r->s2a, s))) return e;
     if ((e = conv3(r, r->s2a, n, S2, wh, r->s3.Wf, w, r->s3.b, PRX_ACT_RELU, nullptr, nullptr, r->s3a, s))) return e;
     RLAUNCH(avgpool2_fwd_kernel, (size_t)n * S4 * S4 * w, r->s3a, r->s0_bf, n, S2, S2, w);
@@ -458,8 +512,12 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     for (int bi = (int)r->blocks.size() - 1; bi >= 0; --bi) {
         RBlock& k = r->blocks[bi];
         const int H = k.Hin, Ho = H / k.stride, Min = n * H * H, Mout = n * Ho * Ho, p = k.planes;
-        // through the final ReLU: g (fp32, in place) and its bf16 twin
-        RLAUNCH(relu_mask_kernel, (size_t)Mout * 4 * p, g, k.out_bf, r->gbf, (size_t)Mout * 4 * p);
+        // through the final ReLU: g (fp32, in place) and its operand-precision twin.  Only the last block needs a pass of its
+        // own; for every other block the GEMM that formed g (conv1 dgrad + identity gradient of the block after it) applied
+        // this block's mask in its epilogue and wrote both copies (PRX_ACT_RELUMASK_POST below): 25 of RN50x4's 26 passes
+        // over the residual-stream gradient (12 bytes per element each) are gone.
+        if (bi == (int)r->blocks.size() - 1)
+            RLAUNCH(relu_mask_kernel, (size_t)Mout * 4 * p, g, k.out_bf, r->gbf, (size_t)Mout * 4 * p);
         // main branch: conv3 (1x1) dgrad [-> avgpool bwd] -> ReLU mask of a2
         if (k.stride > 1) {
             if ((e = lin(r, r->gbf, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
@@ -485,7 +543,10 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
         // conv1 (1x1) dgrad + identity gradient -> gradient w.r.t. the block input
         float* dst = (gid == g2) ? g : g2;        // never write over the residual being added
         if (gid == r->tf) dst = g2;
-        if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_NONE, nullptr, dst, nullptr, s))) return e;
+        // ... masked by the output ReLU of the block below (its out_bf is this block's input), fp32 + operand twin
+        if (bi > 0) {
+            if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_RELUMASK_POST, r->blocks[bi - 1].out_bf, dst, r->gbf, s))) return e;
+        } else if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_NONE, nullptr, dst, nullptr, s))) return e;
         if (dst != g) std::swap(g, g2);
     }
     // stem: avgpool -> relu3 mask -> conv3 dgrad -> relu2 mask -> conv2 dgrad -> relu1 mask -> conv1 input gradient
@@ -493,7 +554,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
     if ((e = conv3(r, r->tb1, n, S2, w, r->s3.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s2a, nullptr, r->tb2, s))) return e;
     if ((e = conv3(r, r->tb2, n, S2, wh, r->s2.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s1, nullptr, r->tb1, s))) return e;
-    RLAUNCH(stem1_bwd_kernel, (size_t)n * 3 * S * S, r->tb1, r->w1, r->dY, n, S, wh);
+    STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S);
     return prx_preproc_bwd_reduce(cutouts, mm, r->dY, acc, n, S, s);
 }
 

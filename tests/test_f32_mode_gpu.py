@@ -130,6 +130,13 @@ def test_gemm_f32_activation_epilogues():
     assert rel_l2(out3, t.clamp_min(0)) < 2e-6
     out4, _, _ = gemm_f32(A, Bt, M, N, K, act=4, aux=out3)                                   # * [aux > 0]
     assert rel_l2(out4, t * (t > 0)) < 2e-6
+    # the mask after the residual add (PRX_ACT_RELUMASK_POST): the gradient arriving at a Bottleneck's output ReLU
+    resid = torch.randn(M, N, device=DEV)
+    mask_src = torch.randn(M, N, device=DEV)
+    out5, op5, _ = gemm_f32(A, Bt, M, N, K, act=5, aux=mask_src, resid=resid, want_op=True)
+    assert rel_l2(out5, (t + resid.double()) * (mask_src > 0)) < 2e-6 and torch.equal(out5, op5)
+    out6, _, _ = gemm_f32(A, Bt, M, N, K, act=4, aux=mask_src, resid=resid)                  # mask BEFORE the add (unchanged)
+    assert rel_l2(out6, t * (mask_src > 0) + resid.double()) < 2e-6
 
 
 @pytest.mark.parametrize("N,T,heads", [(3, 50, 4), (2, 197, 2), (2, 257, 3), (1, 64, 1)])
