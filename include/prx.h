@@ -211,6 +211,18 @@ int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c);
 int prx_vgg16_forward(prx_vgg16* h, const float* x, int H, int W, void* workspace, float* const* feats, prx_stream_t s);
 int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, prx_stream_t s);
 
+/* --- STROTSS hyper-column sampling of the StyleLoss plugin (`spatial_feature_extract`, Losses/StyleLoss.py:169-223): n
+ * positions, one bilinear sample of each of n_layers NHWC fp32 feature maps per position, concatenated over channels, plus
+ * the two coordinate channels -> out [n, ldo] (ldo >= sum(channels) + 2).
+ * feats / g_feats / channels: HOST arrays of n_layers device pointers / channel counts.  rows: device int64 [n_layers][4][n],
+ * flat row (pixel) index of the four taps; weights: device fp32 [4*n_layers + 2][n], the tap weights, then the x and y
+ * coordinate channels.  Same roundings as the composed torch expression (products added left to right).
+ * backward: g_feats[l] (or NULL) must be zero-initialised [h_l*w_l, C_l]; adds weight * g_out to the four taps. */
+int prx_hypercolumns_fwd(const float* const* feats, const int* channels, int n_layers, const long long* rows, const float* weights,
+                         int n, float* out, int ldo, prx_stream_t s);
+int prx_hypercolumns_bwd(float* const* g_feats, const int* channels, int n_layers, const long long* rows, const float* weights,
+                         int n, const float* g_out, int ldo, prx_stream_t s);
+
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
  *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination

@@ -74,9 +74,10 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     if (d.bias_n) v += d.bias_n[col];
     if (d.bias_m) v += d.bias_m[row];
     if (d.act == PRX_ACT_MUL_DQUICKGELU) v *= dquickgelu_f(op_ld(aux, (size_t)row * d.ldaux + col));
-    if (d.act == PRX_ACT_MUL_RELUMASK && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f)) v = 0.f;
+    const bool masked = (d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST) && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f);
+    if (masked && d.act == PRX_ACT_MUL_RELUMASK) v = 0.f;
     if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
-    if (d.act == PRX_ACT_RELUMASK_POST && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f)) v = 0.f;
+    if (masked && d.act == PRX_ACT_RELUMASK_POST) v = 0.f;          // the mask after the residual add
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
         const TOp pre = (TOp)v;     // the saved pre-activation is what the backward differentiates: activate its rounded value
@@ -102,25 +103,28 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
         op_ld4(aux, (size_t)row * d.ldaux + col, t);
         v.x *= dquickgelu_f(t[0]); v.y *= dquickgelu_f(t[1]); v.z *= dquickgelu_f(t[2]); v.w *= dquickgelu_f(t[3]);
     }
-    if (d.act == PRX_ACT_MUL_RELUMASK) {
+    // ReLU backward: the mask (aux > 0) multiplies the product (MUL_RELUMASK) or the product + residual (RELUMASK_POST)
+    float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST) {
         float t[4];
         op_ld4(aux, (size_t)row * d.ldaux + col, t);
-        if (!(t[0] > 0.f)) v.x = 0.f;
-        if (!(t[1] > 0.f)) v.y = 0.f;
-        if (!(t[2] > 0.f)) v.z = 0.f;
-        if (!(t[3] > 0.f)) v.w = 0.f;
+        keep = make_float4(t[0] > 0.f ? 1.f : 0.f, t[1] > 0.f ? 1.f : 0.f, t[2] > 0.f ? 1.f : 0.f, t[3] > 0.f ? 1.f : 0.f);
+    }
+    if (d.act == PRX_ACT_MUL_RELUMASK) {
+        if (keep.x == 0.f) v.x = 0.f;
+        if (keep.y == 0.f) v.y = 0.f;
+        if (keep.z == 0.f) v.z = 0.f;
+        if (keep.w == 0.f) v.w = 0.f;
     }
     if (d.resid) {
         const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    if (d.act == PRX_ACT_RELUMASK_POST) {
-        float t[4];
-        op_ld4(aux, (size_t)row * d.ldaux + col, t);
-        if (!(t[0] > 0.f)) v.x = 0.f;
-        if (!(t[1] > 0.f)) v.y = 0.f;
-        if (!(t[2] > 0.f)) v.z = 0.f;
-        if (!(t[3] > 0.f)) v.w = 0.f;
+        if (d.act == PRX_ACT_RELUMASK_POST) {
+            if (keep.x == 0.f) v.x = 0.f;
+            if (keep.y == 0.f) v.y = 0.f;
+            if (keep.z == 0.f) v.z = 0.f;
+            if (keep.w == 0.f) v.w = 0.f;
+        }
     }
     if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (d.act == PRX_ACT_QUICKGELU) {
@@ -1052,6 +1056,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     }
     PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK && d.act != PRX_ACT_RELUMASK_POST) || d.aux,
                 "gemm: MUL_DQUICKGELU / MUL_RELUMASK / RELUMASK_POST need aux");
+    PRX_REQUIRE(d.act != PRX_ACT_RELUMASK_POST || d.resid, "gemm: RELUMASK_POST masks product + residual: it needs resid");
     PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------

@@ -558,6 +558,48 @@ class _Vgg16Fn(torch.autograd.Function):
         return gx, None
 
 
+class _HypercolumnsFn(torch.autograd.Function):
+    """`spatial_feature_extract` (Losses/StyleLoss.py:169-223) over all feature maps in one gather launch (and one scatter
+    launch backward); rows int64 [L,4,n], wts fp32 [4L+2,n] (tap weights, then the two coordinate channels)"""
+
+    @staticmethod
+    def forward(ctx, rows, wts, *feats):
+        L, n = len(feats), int(rows.shape[2])
+        for f in feats:
+            _need_cuda(f)
+            if f.dtype != torch.float32 or not f.is_contiguous() or f.dim() != 4 or f.shape[0] != 1:
+                raise PrxError("hypercolumns: feature maps must be contiguous fp32 [1,h,w,C] device tensors")
+        if rows.dtype != torch.int64 or not rows.is_contiguous() or tuple(rows.shape) != (L, 4, n):
+            raise PrxError("hypercolumns: rows must be a contiguous int64 [L,4,n] tensor")
+        if wts.dtype != torch.float32 or not wts.is_contiguous() or tuple(wts.shape) != (4 * L + 2, n):
+            raise PrxError("hypercolumns: weights must be a contiguous fp32 [4L+2,n] tensor")
+        chans = (ctypes.c_int * L)(*[int(f.shape[3]) for f in feats])
+        ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+        ctot = sum(chans)
+        out = torch.empty(n, ctot + 2, dtype=torch.float32, device=feats[0].device)
+        call("prx_hypercolumns_fwd", ctypes.addressof(ptrs), ctypes.addressof(chans), L, rows, wts, n, out, ctot + 2, _stream())
+        ctx.save_for_backward(rows, wts)
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        rows, wts = ctx.saved_tensors
+        L, n = len(ctx.shapes), int(rows.shape[2])
+        gout = gout.to(torch.float32).contiguous()
+        grads = [torch.zeros(sh, dtype=torch.float32, device=gout.device) if ctx.needs_input_grad[2 + l] else None
+                 for l, sh in enumerate(ctx.shapes)]
+        chans = (ctypes.c_int * L)(*[int(sh[3]) for sh in ctx.shapes])
+        ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() if g is not None else None for g in grads])
+        call("prx_hypercolumns_bwd", ctypes.addressof(ptrs), ctypes.addressof(chans), L, rows, wts, n, gout, int(gout.shape[1]), _stream())
+        return (None, None) + tuple(grads)
+
+
+def hypercolumns(feats, rows, wts):
+    """feats: list of [1,h,w,C] fp32 NHWC maps -> [n, sum(C)+2] sampled columns (+ the two coordinate channels)"""
+    return _HypercolumnsFn.apply(rows, wts, *[f.contiguous() for f in feats])
+
+
 def vgg16_features(x, handle: Vgg16Handle):
     """x [1,3,H,W] (already normalised for VGG) -> the nine captured feature maps as NHWC fp32 tensors [1,h,w,C]
     (channels-last is the engine's layout; `f.permute(0,3,1,2)` is the reference's NCHW view)."""

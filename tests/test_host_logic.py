@@ -587,3 +587,24 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
         VqganDrawer(bad).load_model(bad, "cpu")
     with pytest.raises(ValueError, match="unknown model type"):
         checkpoints.vqgan_config_from_taming_yaml(dict(model=dict(target="taming.models.other.Thing", params={})))
+
+
+def test_gemm_engine_kernels_have_no_scratch():
+    """The GEMM kernels take their descriptor by value; one epilogue variant written the wrong way made hipcc keep that struct
+    on the stack (320 bytes of scratch per lane in EVERY kernel of the file) and the engine ran 3x slower with all parity
+    tests green.  The resource report of the compiler is the guard: no kernel of gemm.hip may use scratch."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc", "gemm.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) and len(names) > 20
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, bad

@@ -359,3 +359,31 @@ def test_mha_general_fwd_bwd(N, T, qs):
     for i, nm in enumerate("qkv"):
         e = rel_l2(dqkv[:, i * C:(i + 1) * C], refd[:, i * C:(i + 1) * C])
         assert e < 1.5e-2, (nm, e)
+
+
+def test_hypercolumns_match_the_composed_torch_expression():
+    """StyleLoss `spatial_feature_extract` (Losses/StyleLoss.py:169-223) in one gather launch: the CUDA branch of
+    style_loss._bilinear_columns against its own composed torch branch (what runs on CPU tensors and is pinned to the
+    reference's goldens) -- forward bit-identical, gradients to fp32 atomics' reordering"""
+    import numpy as np
+    from pixray_amd import ops, style_loss as sl
+    g = torch.Generator().manual_seed(5)
+    shapes = [(40, 56, 3), (40, 56, 64), (40, 56, 64), (20, 28, 128), (20, 28, 128), (10, 14, 256), (10, 14, 256), (10, 14, 256),
+              (5, 7, 512), (2, 3, 512)]
+    fa = [torch.randn(1, h, w, c, generator=g).to(DEV).requires_grad_(True) for h, w, c in shapes]
+    fb = [torch.randn(1, h, w, c, generator=g).to(DEV).requires_grad_(True) for h, w, c in shapes]
+    np.random.seed(2)
+    xx, xy = sl._sample_grid(40, 56)
+    xx, xy = xx[:300].astype(np.float64) + 0.37, xy[:300].astype(np.float64) + 0.61      # off-grid: all four taps weigh in
+    a, b = sl._bilinear_columns(fa, fb, xx, xy)
+    go = torch.randn(a.shape, generator=g).to(DEV)
+    ga = torch.autograd.grad((a * go).sum() + (b * go).sum() * 0.5, fa + fb)
+    # the composed form: the same function on CPU copies
+    fa_c = [f.detach().cpu().requires_grad_(True) for f in fa]
+    fb_c = [f.detach().cpu().requires_grad_(True) for f in fb]
+    a_c, b_c = sl._bilinear_columns(fa_c, fb_c, xx, xy)
+    gc = torch.autograd.grad((a_c * go.cpu()).sum() + (b_c * go.cpu()).sum() * 0.5, fa_c + fb_c)
+    assert tuple(a.shape) == tuple(a_c.shape) == (1, sum(c for _, _, c in shapes) + 2, 300, 1)
+    assert torch.equal(a.cpu(), a_c) and torch.equal(b.cpu(), b_c)
+    for x, y in zip(ga, gc):
+        assert rel_l2(x.cpu(), y) < 1e-6
