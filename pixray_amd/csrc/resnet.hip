@@ -52,7 +52,8 @@ template <typename TOp, int CO>
 __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict__ cut, const float* __restrict__ mm,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         void* __restrict__ out_, int N, int S) {
-    __shared__ float ws[27 * CO], bs[CO];
+    __shared__ __attribute__((aligned(16))) float ws[27 * CO];
+    __shared__ float bs[CO];
     for (int i = threadIdx.x; i < 27 * CO; i += 256) {
         const int co = i % CO, t = i / CO;               // t = (c*3 + ky)*3 + kx
         ws[i] = w[co * 27 + t];
@@ -66,8 +67,7 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
     const size_t total = (size_t)N * So * So;
     for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
         const int xo = (int)(pix % So), yo = (int)((pix / So) % So), n = (int)(pix / ((size_t)So * So));
-        float v[27];
-        bool ok[27];
+        float v[27];                       // taps outside the image stay 0: adding 0 * w leaves the sum as the skipped tap did
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float im = r_clip_mean[c], is = 1.f / r_clip_std[c];
@@ -76,20 +76,19 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int y = 2 * yo + ky - 1, x = 2 * xo + kx - 1, t = (c * 3 + ky) * 3 + kx;
-                    ok[t] = y >= 0 && y < S && x >= 0 && x < S;
-                    v[t] = ok[t] ? ((cut[(((size_t)n * 3 + c) * S + y) * S + x] - mn) * inv - im) * is : 0.f;
+                    const bool ok = y >= 0 && y < S && x >= 0 && x < S;
+                    v[t] = ok ? ((cut[(((size_t)n * 3 + c) * S + y) * S + x] - mn) * inv - im) * is : 0.f;
                 }
         }
         TOp* o = out + pix * CO;
-#pragma unroll
+#pragma unroll 1
         for (int c0 = 0; c0 < CO; c0 += 4) {
             float a[4] = {bs[c0], bs[c0 + 1], bs[c0 + 2], bs[c0 + 3]};
 #pragma unroll
-            for (int t = 0; t < 27; ++t)
-                if (ok[t]) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] += v[t] * ws[t * CO + c0 + q];
-                }
+            for (int t = 0; t < 27; ++t) {
+                const float4 w4 = *reinterpret_cast<const float4*>(&ws[t * CO + c0]);
+                a[0] += v[t] * w4.x; a[1] += v[t] * w4.y; a[2] += v[t] * w4.z; a[3] += v[t] * w4.w;
+            }
             op_st4(o, (size_t)c0, fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
         }
     }
