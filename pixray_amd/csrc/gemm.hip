@@ -983,6 +983,7 @@ GemmCtx::GemmCtx() {
     xcd_swizzle = env_int("PRX_XCD_SWIZZLE", 2);
     conv_c64 = env_int("PRX_CONV_C64", 1);
     wide_tile = env_int("PRX_WIDE_TILE", 128);
+    big_tile = env_int("PRX_BIG_TILE", 0);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
@@ -1081,6 +1082,9 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         // sweeps give 128x64 28 us vs 64x64 31 us vs 128x128 31.5 us
         if (cx.wide_tile == 128 && d.a_mode == PRX_A_ROWMAJOR && d.N >= 2048 && BM == 64 && ntiles(128, 128) > 2 * n_cu) { BM = 128; BN = 64; }
     }
+    // very large problems (ViT-L/14 at 256 cutouts: M = 65 792): the 8-wave 256 x 128 tile, when it still fills the chip
+    // several times over (A/B switch, off by default: see DESIGN.md section 6)
+    if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; }
     int rule_splits = 0;
     if (!cx.rules.empty()) {

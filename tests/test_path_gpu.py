@@ -471,11 +471,23 @@ def test_clip_resnet_vs_oracle(name, n):
     for i in range(n):
         assert cosine(emb[i], ref[i]) > 0.999
     # gradient: bf16 roundings through up to 80 layers, and every pre-activation that bf16 moves across zero flips a
-    # ReLU mask (a discrete change of the gradient path; the reference's own fp16 CUDA tower behaves the same way)
-    print(name, "emb rel", rel_l2(emb, ref), "grad rel", rel_l2(gd, gref), "grad cos", cosine(gd, gref))
-    tol_rel, tol_cos = (6e-2, 0.997) if name == "tiny-RN" else (1.6e-1, 0.985)
-    assert rel_l2(gd, gref) < tol_rel, rel_l2(gd, gref)
-    assert cosine(gd, gref) > tol_cos, cosine(gd, gref)
+    # ReLU mask (a discrete change of the gradient path; the reference's own fp16 CUDA tower behaves the same way).
+    # The two elements that hold the batch-global min and max of the cutouts (slip.py:21-36) receive the SUMS of the whole
+    # batch's gradient through the renormalisation -- two entries that can be a fifth of one cutout's gradient norm and carry
+    # the few-% error of a bf16 sum over 5e5 terms; they are checked on their own, the other entries as the bulk
+    # (tools/f32_error_budget.py; the exact-f32 mode agrees on all of them to 4e-5, tests/test_f32_mode_gpu.py).
+    flat = cut.flatten()
+    ext = torch.stack([flat.argmin(), flat.argmax()])
+    bulk_d, bulk_r = gd.detach().cpu().flatten().clone(), gref.flatten().clone()
+    ext_d, ext_r = bulk_d[ext].clone(), bulk_r[ext].clone()
+    bulk_d[ext] = 0.0; bulk_r[ext] = 0.0
+    print(name, "emb rel", rel_l2(emb, ref), "grad rel", rel_l2(gd, gref), "grad cos", cosine(gd, gref),
+          "| bulk rel", rel_l2(bulk_d, bulk_r), "bulk cos", cosine(bulk_d, bulk_r), "| min/max entries", ext_d.tolist(), ext_r.tolist())
+    tol_rel, tol_cos = (6e-2, 0.997) if name == "tiny-RN" else (6e-2, 0.997)
+    assert rel_l2(bulk_d, bulk_r) < tol_rel, rel_l2(bulk_d, bulk_r)
+    assert cosine(bulk_d, bulk_r) > tol_cos, cosine(bulk_d, bulk_r)
+    # heavily cancelling sums: a quarter of their value is the bf16 noise of the terms (f32 mode: 1e-4)
+    assert ((ext_d - ext_r).abs() <= 0.3 * ext_r.abs() + 1e-3 * gref.abs().max()).all(), (ext_d, ext_r)
 
 
 # ------------------------------------------------------------------------------------------ non-square canvases (a6)
