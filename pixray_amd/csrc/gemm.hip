@@ -1034,6 +1034,18 @@ void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* 
     else
         hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
 }
+// 128x128 tile with EIGHT waves (wave tile 32x64) and a 3- or 4-deep ring: one workgroup per CU holds the waves of two
+// 4-wave workgroups, and the LDS they would have spent on two 2-deep rings buys 2-3 K tiles of DMA in flight (A/B switch
+// PRX_GEMM_W8=3|4)
+template <int STAGES>
+void launch_glds_w8(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR)
+        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_ROWMAJOR, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
+    else if (c64)
+        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_CONV3X3, STAGES, true, 4>), grid, dim3(512), 0, s, a, zero_page);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
+}
 template <int BM, int BN>
 void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages, bool c64) {
     if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page, c64);
@@ -1071,6 +1083,7 @@ GemmCtx::GemmCtx() {
     conv_c64 = env_int("PRX_CONV_C64", 1);
     wide_tile = env_int("PRX_WIDE_TILE", 128);
     interleave = env_int("PRX_GEMM_INTERLEAVE", 0);
+    w8 = env_int("PRX_GEMM_W8", 0);
     big_tile = env_int("PRX_BIG_TILE", 0);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
@@ -1256,6 +1269,8 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         int stages = (BM == 64 && BN == 64) ? 3 : 2;
         if (cx.force_stages) stages = cx.force_stages;
         if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp, c64); else launch_glds_256<2>(a, grid, stream, zp, c64); }
+        else if (BM == 128 && BN == 128 && cx.w8 == 3) launch_glds_w8<3>(a, grid, stream, zp, c64);
+        else if (BM == 128 && BN == 128 && cx.w8 == 4) launch_glds_w8<4>(a, grid, stream, zp, c64);
         else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
         else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages, c64);
         else launch_glds<64, 64>(a, grid, stream, zp, stages, c64);
