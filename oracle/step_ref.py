@@ -112,9 +112,10 @@ def oracle_iteration(vq_params, vq_cfg, clip_params, clip_cfg, z0, prm, prompts,
 
 
 def _metrics(a: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
-    a, b = a.detach().float().cpu().flatten(), b.detach().float().cpu().flatten()
-    rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
-    cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+    # fp64: a cosine accumulated in fp32 over 65k terms is only good to ~1e-6 (it came out as 1.000002 and 0.9999998)
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    rel = ((a - b).norm() / (b.norm() + 1e-300)).item()
+    cos = (a @ b / (a.norm() * b.norm() + 1e-300)).item()
     return rel, cos
 
 
