@@ -145,9 +145,13 @@ def build_workload(name: str, *, num_cuts=None, precision="bf16", device="cuda",
         return build_vqgan_clip_session(size=w["size"], vqgan_model="imagenet_f16_16384", clip_model=w["clip_model"], num_cuts=n,
                                         learning_rate=0.2, iterations=10 ** 9, seed=seed, device=device, group=group, rank=rank,
                                         world_size=world_size, precision=precision, custom_losses=custom_losses)
-    return build_fft_clip_session(size=w["size"], clip_model=w["clip_model"], num_cuts=n, iterations=10 ** 9, seed=seed,
+    sess = build_fft_clip_session(size=w["size"], clip_model=w["clip_model"], num_cuts=n, iterations=10 ** 9, seed=seed,
                                   device=device, group=group, rank=rank, world_size=world_size, custom_losses=custom_losses,
                                   args=args, precision=precision)
+    # the spectrum drawer's backward is one inverse FFT: let the perceptor's backward reach the GPU before the host works
+    # through the plugins' backward (engine.Session.custom_backward_last); PRX_CUSTOM_BACKWARD_LAST=0 for the A/B
+    sess.custom_backward_last = os.environ.get("PRX_CUSTOM_BACKWARD_LAST", "1") != "0"
+    return sess
 
 
 def session_gemm_contexts(sess: Session):

@@ -153,6 +153,13 @@ class Session:
         self.batches = batches
         self.learning_rate_drops = list(learning_rate_drops)
         self.custom_losses = list(custom_losses)     # [{"loss": LossInterface, "weight": float}] (pixray.py:961-995)
+        # Scheduling, not arithmetic: differentiate the perceptor terms first and the custom-loss terms in a second
+        # backward() (gradients accumulate in the leaves exactly as in one pass; the shared drawer graph is walked twice).
+        # autograd runs the most recently created nodes first, i.e. a host-heavy plugin (StyleLoss: thousands of small
+        # launches) BEFORE the perceptor's backward, so the GPU idles while the host works through the plugin and the host
+        # idles while the GPU runs the tower.  Worth it when the drawer's backward is cheap (FftDrawer); off by default.
+        self.custom_backward_last = False
+        self._n_path_terms = None                    # how many entries of ascend_txt()'s list precede the custom-loss terms
         self.filters = list(filters)                 # [{"filter": FilterInterface, "weight": float}] (650-669)
         self.args = args if args is not None else types.SimpleNamespace()
         self.init_weight = init_weight
@@ -355,6 +362,7 @@ class Session:
             # through the all-reduce hook on `out` -- every rank holds the whole term, like the z regularisers above
             result.append(t_w * torch.mean(img_alpha))
         full_cutouts = full_globals = None
+        self._n_path_terms = len(result)
         for t in self.custom_losses:
             w = t["weight"] / self.world_size if self.world_size > 1 else t["weight"]
             cuts, glb = cur_cutouts, needed_globals
@@ -394,8 +402,15 @@ class Session:
             opt.zero_grad(set_to_none=True)
         for i in range(self.batches):
             lossAll = self.ascend_txt()
-            loss = sum(lossAll)
-            loss.backward()
+            n_path = self._n_path_terms
+            if self.custom_backward_last and self.custom_losses and n_path and 0 < n_path < len(lossAll):
+                custom = [l for l in lossAll[n_path:] if isinstance(l, torch.Tensor) and l.requires_grad]
+                sum(lossAll[:n_path]).backward(retain_graph=bool(custom))
+                if custom:
+                    sum(custom).backward()
+            else:
+                loss = sum(lossAll)
+                loss.backward()
             self.last_losses = lossAll
         for opt in self.opts:
             opt.step()

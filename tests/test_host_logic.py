@@ -608,3 +608,28 @@ def test_gemm_engine_kernels_have_no_scratch():
     assert len(names) == len(scratch) and len(names) > 20
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, bad
+
+
+def test_custom_backward_last_is_the_same_gradient():
+    """Session.custom_backward_last differentiates the perceptor terms and the custom-loss terms in two backward() calls (a
+    launch-ordering choice for host-heavy plugins): the accumulated gradient is the one-pass gradient"""
+    class ImgLoss(LossInterface):
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            return [(out ** 2).mean(), 0.3 * sum(c.std() for c in cur_cutouts.values())]
+
+    grads = []
+    for flag in (False, True):
+        sess = _cpu_session(cutn=2, custom_losses=[{"loss": ImgLoss(device="cpu"), "weight": 0.7}])
+        sess.custom_backward_last = flag
+        z = sess.drawer.get_z()
+        for opt in sess.opts:
+            opt.zero_grad(set_to_none=True)
+        captured = {}
+        real_step = sess.opts[0].step
+        sess.opts[0].step = lambda *a, **k: captured.setdefault("g", z.grad.detach().clone())    # look, do not move z
+        sess._device_step()
+        sess.opts[0].step = real_step
+        assert len(sess.last_losses) == 3 and sess._n_path_terms == 1
+        grads.append(captured["g"])
+    assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-8)
+    assert (grads[0] - grads[1]).abs().max() <= 1e-6 * grads[0].abs().max()
