@@ -148,9 +148,9 @@ def build_workload(name: str, *, num_cuts=None, precision="bf16", device="cuda",
     sess = build_fft_clip_session(size=w["size"], clip_model=w["clip_model"], num_cuts=n, iterations=10 ** 9, seed=seed,
                                   device=device, group=group, rank=rank, world_size=world_size, custom_losses=custom_losses,
                                   args=args, precision=precision)
-    # the spectrum drawer's backward is one inverse FFT: let the perceptor's backward reach the GPU before the host works
-    # through the plugins' backward (engine.Session.custom_backward_last); PRX_CUSTOM_BACKWARD_LAST=0 for the A/B
-    sess.custom_backward_last = os.environ.get("PRX_CUSTOM_BACKWARD_LAST", "1") != "0"
+    # engine.Session.custom_backward_last (perceptor backward enqueued before the plugins' backward) measured neutral on
+    # configs[3]: 366.6 vs 358.0 ms per step; PRX_CUSTOM_BACKWARD_LAST=1 switches it on for an A/B
+    sess.custom_backward_last = os.environ.get("PRX_CUSTOM_BACKWARD_LAST", "0") == "1"
     return sess
 
 

@@ -157,7 +157,7 @@ class Session:
         # backward() (gradients accumulate in the leaves exactly as in one pass; the shared drawer graph is walked twice).
         # autograd runs the most recently created nodes first, i.e. a host-heavy plugin (StyleLoss: thousands of small
         # launches) BEFORE the perceptor's backward, so the GPU idles while the host works through the plugin and the host
-        # idles while the GPU runs the tower.  Worth it when the drawer's backward is cheap (FftDrawer); off by default.
+        # idles while the GPU runs the tower.  Measured neutral on configs[3] (the two already overlap across iterations); off.
         self.custom_backward_last = False
         self._n_path_terms = None                    # how many entries of ascend_txt()'s list precede the custom-loss terms
         self.filters = list(filters)                 # [{"filter": FilterInterface, "weight": float}] (650-669)
