@@ -69,8 +69,6 @@ struct GemmCtx {
     int xcd_swizzle = 2;              // 0 off, 1 on, 2 narrow row-major problems only
     int conv_c64 = 1;                 // scalar-tap conv gather when Cin % 64 == 0
     int wide_tile = 128;
-    int w8 = 0;                  // 3 | 4: 8-wave 128x128 kernel with a 3- / 4-deep ring (PRX_GEMM_W8)
-    int interleave = 0;          // 1: interleaved DMA / MFMA schedule of the 2-stage kernels (PRX_GEMM_INTERLEAVE)
     int big_tile = 0;            // > 0: use the 8-wave 256 x 128 tile when it gives >= big_tile * 256 tiles (PRX_BIG_TILE)
     std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic
     bool prof_on = false;

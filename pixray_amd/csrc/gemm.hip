@@ -23,7 +23,6 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     int xcd_swizzle;
-    int interleave;   // 1: 2-stage kernels issue the next K tile's DMA in four pieces between the MFMA groups of the current one
     float* ws;
 };
 
@@ -672,62 +671,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         }
     };
 
-    // the same DMA instructions as issue(), a quarter of them per call (part = 0..3, in order): interleaved with the MFMA
-    // groups of the tile being computed, so that the issue time of the DMA (tens of cycles each) runs under the matrix
-    // pipe instead of in front of it
-    auto issue_part = [&](int kt, int buf, int part) {
-        bf16_t* As = lds + buf * TILE;
-        bf16_t* Bs = As + BM * BK;
-        constexpr int A_PP = (A_IN + 3) / 4, B_PP = (B_IN + 3) / 4;
-        if constexpr (C64) {
-            const int ky = c_tap >= 6 ? 2 : (c_tap >= 3 ? 1 : 0);
-            const int kx = c_tap - 3 * ky;
-            const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
-#pragma unroll
-            for (int i = 0; i < A_IN; ++i) {
-                if (i / A_PP != part) continue;
-                const int ro = c_r1[i] + (my0 & c_rd0[i]) + (my2 & c_rd2[i]);
-                const int co = c_c1[i] + (mx0 & c_cd0[i]) + (mx2 & c_cd2[i]);
-                const bool ok = ((c_ok[i] >> ky) & (c_ok[i] >> (3 + kx)) & 1) != 0;
-                const bf16_t* src = ok ? Ap + (long long)(ro + co) * d.lda + (c_c0 + a_sw[i] * 8) : zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * A_IN + i) * 8 * BK), 16, 0, 0);
-            }
-            if (part == 3) {
-                c_c0 += BK;
-                if (c_c0 >= d.Cin) { c_c0 = 0; ++c_tap; }
-            }
-        } else
-#pragma unroll
-        for (int i = 0; i < A_IN; ++i) {
-            if (i / A_PP != part) continue;
-            const int k = kt * BK + a_sw[i] * 8;
-            const bf16_t* src = zero_page;
-            if (AMODE == PRX_A_ROWMAJOR) {
-                if (a_ok[i] && k < d.K) src = Ap + a_base[i] + k;
-            } else {
-                const int tap = k / d.Cin;
-                const int c = k - tap * d.Cin;
-                const int ky = tap / 3;
-                const int kx = tap - 3 * ky;
-                const int yy = a_y[i] + ky - 1, xx = a_x[i] + kx - 1;
-                if (a_ok[i] && k < d.K && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) {
-                    long long pix;
-                    if (d.up) pix = ((long long)a_b[i] * (d.H >> 1) + (yy >> 1)) * (d.W >> 1) + (xx >> 1);
-                    else      pix = ((long long)a_b[i] * d.H + yy) * d.W + xx;
-                    src = Ap + pix * d.lda + c;
-                }
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * A_IN + i) * 8 * BK), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_IN; ++i) {
-            if (i / B_PP != part) continue;
-            const int k = kt * BK + b_sw[i] * 8;
-            const bf16_t* src = (b_ok[i] && k < d.K) ? (Bp + b_base[i] + k) : zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (wave * B_IN + i) * 8 * BK), 16, 0, 0);
-        }
-    };
-
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -770,40 +713,10 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         }
     };
 
-    // one k16 step of compute(): fragments of step ks, then its MT x NT MFMAs
-    auto compute_step = [&](int buf, int ks) {
-        const bf16_t* As = lds + buf * TILE;
-        const bf16_t* Bs = As + BM * BK;
-        const int kc = ks * 2 + khalf;
-        bf16x8 af[MT], bfr[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + a_off[i] + ((kc ^ a_key[i]) << 3));
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[j] + ((kc ^ b_key[j]) << 3));
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    };
-
     if constexpr (STAGES == 2) {
         // double buffer, one barrier per K tile (hipcc drains the DMA queue -- vmcnt(0) -- in front of the barrier)
         if (kt0 < kt1) issue(kt0, 0);
         __syncthreads();
-        if (p.interleave) {
-            static_assert(BK / 16 == 4, "the interleaved schedule splits the DMA of a tile over four k16 steps");
-            for (int kt = kt0; kt < kt1; ++kt) {
-                const int cur = (kt - kt0) & 1;
-                const bool more = kt + 1 < kt1;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    compute_step(cur, ks);
-                    if (more) issue_part(kt + 1, cur ^ 1, ks);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __syncthreads();
-            }
-        } else
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
             if (kt + 1 < kt1) issue(kt + 1, cur ^ 1);
@@ -1034,18 +947,6 @@ void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* 
     else
         hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
 }
-// 128x128 tile with EIGHT waves (wave tile 32x64) and a 3- or 4-deep ring: one workgroup per CU holds the waves of two
-// 4-wave workgroups, and the LDS they would have spent on two 2-deep rings buys 2-3 K tiles of DMA in flight (A/B switch
-// PRX_GEMM_W8=3|4)
-template <int STAGES>
-void launch_glds_w8(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
-    if (a.d.a_mode == PRX_A_ROWMAJOR)
-        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_ROWMAJOR, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
-    else if (c64)
-        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_CONV3X3, STAGES, true, 4>), grid, dim3(512), 0, s, a, zero_page);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<128, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
-}
 template <int BM, int BN>
 void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages, bool c64) {
     if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page, c64);
@@ -1082,8 +983,6 @@ GemmCtx::GemmCtx() {
     xcd_swizzle = env_int("PRX_XCD_SWIZZLE", 2);
     conv_c64 = env_int("PRX_CONV_C64", 1);
     wide_tile = env_int("PRX_WIDE_TILE", 128);
-    interleave = env_int("PRX_GEMM_INTERLEAVE", 0);
-    w8 = env_int("PRX_GEMM_W8", 0);
     big_tile = env_int("PRX_BIG_TILE", 0);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
@@ -1233,7 +1132,6 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && cx.use_glds,
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
-    a.interleave = cx.interleave;
     a.kt_per_split = ceil_div(a.kt_total, splits);
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;
@@ -1269,8 +1167,6 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         int stages = (BM == 64 && BN == 64) ? 3 : 2;
         if (cx.force_stages) stages = cx.force_stages;
         if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp, c64); else launch_glds_256<2>(a, grid, stream, zp, c64); }
-        else if (BM == 128 && BN == 128 && cx.w8 == 3) launch_glds_w8<3>(a, grid, stream, zp, c64);
-        else if (BM == 128 && BN == 128 && cx.w8 == 4) launch_glds_w8<4>(a, grid, stream, zp, c64);
         else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
         else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages, c64);
         else launch_glds<64, 64>(a, grid, stream, zp, stages, c64);
