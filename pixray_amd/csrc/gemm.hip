@@ -623,6 +623,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         b_base[i] = (long long)gn * d.ldb;
     }
 
+    const long long zoff = zero_page - Ap;
     auto issue = [&](int kt, int buf) {
         bf16_t* As = lds + buf * TILE;
         bf16_t* Bs = As + BM * BK;
@@ -647,7 +648,10 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
             const int k = kt * BK + a_sw[i] * 8;
             const bf16_t* src = zero_page;
             if (AMODE == PRX_A_ROWMAJOR) {
-                if (a_ok[i] && k < d.K) src = Ap + a_base[i] + k;
+                // a select, not a branch: written as nested ifs hipcc guarded each of these loads with its own saveexec /
+                // execz block in the K loop (the B loads below, written as a select, got two v_cndmask each)
+                const long long off = (a_ok[i] && k < d.K) ? a_base[i] + k : zoff;     // zoff: the zero page, relative to A
+                src = Ap + off;
             } else {
                 const int tap = k / d.Cin;
                 const int c = k - tap * d.Cin;
