@@ -680,7 +680,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int q = 32 * w + (lane & 31);                    // this lane's query
     bf16x8 qf[4];
     own_frags(base, ld, q, T, qf, lane);
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                           // running max (base-2 domain) and sum of this lane's query
+    const float sl2 = scale * 1.4426950408889634f;
     f32x16 o[2];
     zero16(o[0]); zero16(o[1]);
     float* line = s_line[tid >> 6];
@@ -694,21 +695,27 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             f32x16 st;                                      // [key 32sb..][query]
             zero16(st);
             mma_chunk_own(Ks, sb, qf, st, lane);
+            // scores in the base-2 domain (one multiply by scale * log2(e), then v_exp_f32 directly); only the last 32-key
+            // block of a head can hold keys beyond T (wave-uniform test)
             float bm = -INFINITY;
+            const bool partial = c0 + sb * 32 + 32 > T;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float v = (j < T) ? st[r] * scale : -INFINITY;
+                float v = st[r] * sl2;
+                if (partial) {
+                    const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    v = (j < T) ? v : -INFINITY;
+                }
                 st[r] = v;
                 bm = fmaxf(bm, v);
             }
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
             const float mn = fmaxf(m, bm);                  // finite: every 32-key block that is visited has a valid key
-            const float alpha = __expf(m - mn);             // 0 on the first block
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);     // 0 on the first block
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[r] - mn);
+                const float e = __builtin_amdgcn_exp2f(st[r] - mn);
                 st[r] = e;
                 sum += e;
             }
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (!active) return;
     if (hh == 0) {
         line[lane] = 1.f / l;
-        if (q < T && lse) lse[((long long)n * heads + h) * T + q] = m + __logf(l);
+        if (q < T && lse) lse[((long long)n * heads + h) * T + q] = (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
     }
     __builtin_amdgcn_wave_barrier();
     scale_rows(o, line, lane);
@@ -766,6 +773,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         D_q = dsum;
     }
     D_q += __shfl_xor(D_q, 32, 64);
+    const float sl2 = scale * 1.4426950408889634f, lse2 = lse_q * 1.4426950408889634f;     // base-2 domain
     f32x16 acc[2];
     zero16(acc[0]); zero16(acc[1]);
     for (int c0 = 0; c0 < T; c0 += CH) {
@@ -779,10 +787,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
             zero16(pt); zero16(dpt);
             mma_chunk_own(Ks, sb, qf, pt, lane);            // S^T  = K Q^T
             mma_chunk_own(Vs, sb, dof, dpt, lane);          // dP^T = V dO^T
+            const bool partial = c0 + sb * 32 + 32 > T;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float p = (j < T) ? __expf(pt[r] * scale - lse_q) : 0.f;
+                float p = __builtin_amdgcn_exp2f(pt[r] * sl2 - lse2);
+                if (partial) {
+                    const int j = c0 + sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    p = (j < T) ? p : 0.f;
+                }
                 dpt[r] = scale * p * (dpt[r] - D_q);        // dS^T
             }
             mma_acc_tr_chunk(dpt, Kt, sb, acc, lane);       // dQ[query][d] += dS[query][key] K[key][d]
@@ -810,6 +822,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
     const float* lse_h = lse + ((long long)n * heads + h) * T;
     const int key = 32 * w + (lane & 31);
     const bool key_ok = key < T;
+    const float sl2 = scale * 1.4426950408889634f;
     bf16x8 kf[4], vf[4];
     own_frags(base + C, ld, key, T, kf, lane);
     own_frags(base + 2 * C, ld, key, T, vf, lane);
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
             part += __shfl_xor(part, 4, 64);
             if (kc == 0) {
                 s_D[row] = part;
-                s_lse[row] = (c0 + row < T) ? lse_h[c0 + row] : INFINITY;
+                s_lse[row] = (c0 + row < T) ? lse_h[c0 + row] * 1.4426950408889634f : INFINITY;      // base-2 domain
             }
         }
         __syncthreads();
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int r = rg * 4 + qq;
-                    const float pv = key_ok ? __expf(p[r] * scale - lv[qq]) : 0.f;
+                    const float pv = key_ok ? __builtin_amdgcn_exp2f(p[r] * sl2 - lv[qq]) : 0.f;
                     p[r] = pv;
                     dp[r] = scale * pv * (dp[r] - dvv[qq]);   // dS
                 }
