@@ -187,6 +187,25 @@ def test_world2_gloo_matches_single_process():
     assert abs((l0 + l1) - float(sum(l.detach() for l in ref.last_losses))) < 1e-5
 
 
+def test_world4_gloo_matches_single_process():
+    """the same with four ranks and one cutout each (the zoom / wide split and the per-rank descriptor slices are by global
+    index, so every rank count that divides the cutout count must give the single-process iteration)"""
+    cutn, world = 4, 4
+    res = _run_world(world, cutn)
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None)
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    zs = [torch.from_numpy(r[1]) for r in res]
+    gs = [torch.from_numpy(r[2]) for r in res]
+    for z, g in zip(zs[1:], gs[1:]):
+        assert torch.equal(z, zs[0]) and torch.equal(g, gs[0]), "ranks diverged"
+    assert (gs[0] - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (zs[0] - z_ref).abs().max().item() < 1e-5
+    assert abs(sum(r[3] for r in res) - float(sum(l.detach() for l in ref.last_losses))) < 1e-5
+
+
 def test_world2_batch_coupled_custom_loss_is_scored_on_the_gathered_batch():
     """a SaturationLoss-style plugin (std over all cutout pixels) on 2 ranks: the loop gathers the cutout shards for it,
     so z, its gradient and the loss value equal the single-process run (the per-shard std would not)"""
