@@ -230,7 +230,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     opt = torch.optim.Adam([z_ref], lr=lr)
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
     emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
-    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free = [], [], [], [], [], []
+    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok = [], [], [], [], [], [], []
     for it in range(k):
         prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
         mk.fixed_params = prm
@@ -264,8 +264,15 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         loss_ref.append(float(sum(l.detach() for l in losses)))
         free.train(it)
         loss_free.append(float(sum(l.detach() for l in free.last_losses)))
+        free_idx_ok.append(float((free.drawer.handle.last_indices.cpu().long() == idx_ref).float().mean()))
+    z_free = free.drawer.get_z().detach().cpu()
     return dict(steps=k, dz_rel_l2_max=max(dz_rel), dz_cosine_min=min(dz_cos), vq_index_agreement_min=min(idx_ok),
-                z_after_step_max_abs_err=max(z_err), loss_oracle=loss_ref, loss_hip_free_running=loss_free)
+                z_after_step_max_abs_err=max(z_err), loss_oracle=loss_ref, loss_hip_free_running=loss_free,
+                # the FREE-RUNNING copy against the oracle's trajectory ("z after 10 Adam steps"): only
+                # meaningful while both sides still select the same codes at every step
+                free_running_index_agreement_min=min(free_idx_ok),
+                z_free_running_rel_l2=float((z_free - z_ref.detach()).norm() / z_ref.detach().norm()),
+                z_free_running_max_abs_err=float((z_free - z_ref.detach()).abs().max()))
 
 
 def time_oracle_iterations(n_iters=3, warmup=1, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",

@@ -321,3 +321,17 @@ def test_bf16_path_against_the_f32_mode_on_device():
     small = step_ref.compare_precisions(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0)
     print("[bf16 vs f32] reduced:", small)
     assert small["dz_rel_l2"] < 8e-2 and small["dz_cosine"] > 0.997, small
+
+
+def test_ten_adam_steps_f32_mode_follows_the_oracle_trajectory():
+    """SURVEY.md section 8(d)'s second parity item: z after 10 Adam steps.  The exact-f32 mode on the reduced graph,
+    FREE-RUNNING (no teacher forcing): as long as both sides pick the same VQ codes at every step the trajectories stay
+    together, because an Adam step from near-identical gradients is near-identical; the teacher-forced per-step figures are
+    asserted as well.  (In bf16 mode a 1 % gradient difference selects another code within a few steps: DESIGN.md section 4.)"""
+    r = step_ref.compare_k_steps(10, vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, precision="f32")
+    print("[f32] 10 steps:", {k: v for k, v in r.items() if not k.startswith("loss")})
+    assert r["vq_index_agreement_min"] == 1.0
+    assert r["dz_rel_l2_max"] < 1e-3 and r["dz_cosine_min"] > 0.999999, r      # ColorJitter on: the 1e-3 gate (see above)
+    # measured: same codes at all 10 steps, z rel-L2 1.2e-4 (max |dz| 5.7e-3), per-step dL/dz <= 3.9e-4
+    assert r["free_running_index_agreement_min"] == 1.0, r
+    assert r["z_free_running_rel_l2"] < 1e-3, r
