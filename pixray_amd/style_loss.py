@@ -208,7 +208,10 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
     wts_d = _upload(wts, dev)                               # [4L+2, n]
     if dev.type == "cuda":
         # one gather launch per feature list (and one scatter launch in its backward) instead of ~11 torch ops per map:
-        # the host-side launch cost of the composed form bounded the whole configs[3] iteration
+        # the host-side launch cost of the composed form bounded the whole configs[3] iteration.  Device tensors ALWAYS take
+        # this route (ops raises if the library lacks the entry point); the composed form below is the reference's own
+        # arithmetic, kept for CPU tensors only -- it is what tests/test_style_loss.py pins to the reference's goldens and
+        # what tests/test_kernels_gpu.py compares the kernel with, bit for bit.
         from . import ops
         a = ops.hypercolumns(feat_a, rows_d, wts_d)
         b = ops.hypercolumns(feat_b, rows_d, wts_d)
