@@ -120,6 +120,8 @@ def test_ops_fail_loudly_without_a_gpu():
         ops.prompt_loss(torch.randn(4, 64), torch.randn(1, 64))
     with pytest.raises(_lib.PrxError):
         ops.make_cutouts(torch.rand(1, 3, 32, 32), torch.zeros(2, 32, dtype=torch.float64), None, 16)
+    with pytest.raises(_lib.PrxError):          # the StyleLoss hyper-column op has no CPU route either
+        ops.hypercolumns([torch.randn(1, 4, 4, 3)], torch.zeros(1, 4, 2, dtype=torch.int64), torch.zeros(6, 2))
     from pixray_amd import api
     with pytest.raises(_lib.PrxError):
         api.build_vqgan_clip_session()
