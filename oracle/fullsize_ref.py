@@ -1,0 +1,97 @@
+"""ORACLE (test infrastructure only -- never imported by the product package).
+
+One iteration of a BASELINE.json configuration at its FULL cutout count on a machine whose RAM cannot hold the autograd
+graph of `workload_ref.iteration` (ViT-L/14 at 256 cutouts keeps ~130 GB of fp32 activations).  The computation is the one
+`workload_ref.iteration` does -- same restated operators, same seeds, same explicit augmentation draws -- cut at three
+tensors whose gradients are carried by hand:
+
+    leaf --synth--> img ==| img_d --make_cutouts--> cuts ==| cuts_d --min/max renorm + Normalize--> x ==| x chunks --tower,
+    Prompt--> partial losses
+
+* the tower runs on chunks of `chunk` cutouts; the prompt loss is a mean over cutouts (pixray.py:280), so chunk c contributes
+  Prompt(emb_c) * len(c) / cutn and the chunk gradients land in disjoint rows of dL/dx;
+* the batch-global min / max renormalisation (slip.py:21-36) couples every cutout: it is differentiated ONCE over the whole
+  batch (x -> cuts_d), with the accumulated dL/dx as the incoming gradient -- exactly autograd's chain rule;
+* every perceptor's dL/dcuts (+ the custom losses', which read the whole cutout batch) goes back through make_cutouts to
+  img_d, the contributions are summed, and the sum goes through the drawer once.
+
+Only the order of a few fp32 additions differs from the one-graph evaluation (checked in tests/test_oracle_golden.py:
+chunked == unchunked to 1e-6 at a small cutout count).  `tools/fullsize_oracle.py` runs this at 128 / 256 cutouts and
+commits the result as tests/golden/fullsize_<cfg>.npz.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Optional
+
+import torch
+
+from . import clip_resnet_ref, clip_vit_ref, cutouts_ref, prompt_ref, workload_ref
+
+
+def _tower(kind, cfg, params, x):
+    if kind == "resnet":
+        return clip_resnet_ref.encode_image(params, x, layers=cfg.layers, heads=cfg.heads, apply_preprocess=False)
+    return clip_vit_ref.encode_image(params, x, patch=cfg.patch_size, heads=cfg.heads, layers=cfg.layers, apply_preprocess=False)
+
+
+def iteration_chunked(workload: str, cutn: int, seed: int = 0, prm: Optional[Dict[int, dict]] = None, state=None, custom=(),
+                      args=None, cur_iteration: int = 0, chunk: int = 16, log=None):
+    """same contract as workload_ref.iteration -> dict(losses, grad, img, embeds, start)"""
+    from pixray_amd import api
+    say = log or (lambda *_: None)
+    prm = prm if prm is not None else workload_ref.draws_for(workload, cutn, seed)
+    leaf, synth = workload_ref.image_of(workload, seed, state)
+    t0 = time.perf_counter()
+    img = synth(leaf)
+    say(f"synth {time.perf_counter() - t0:.1f}s")
+    img_d = img.detach().requires_grad_(True)
+    kind = api.WORKLOADS[workload]["kind"]
+    losses, cuts, cuts_d, g_cuts, emb = [], {}, {}, {}, None
+    for mi, (name, tkind, cfg, params) in enumerate(workload_ref.towers_of(workload, seed)):
+        S = cfg.input_resolution
+        if S not in cuts:
+            cuts[S] = cutouts_ref.make_cutouts(img_d, prm[S], S)
+            cuts_d[S] = cuts[S].detach().requires_grad_(True)
+            g_cuts[S] = torch.zeros_like(cuts_d[S])
+        x = clip_vit_ref.preprocess(cuts_d[S])
+        x_val = x.detach()
+        gx = torch.zeros_like(x_val)
+        e_t = api.seeded_unit_vectors(1, cfg.output_dim, seed + 2 + (mi if kind == "vqgan" else 0))
+        prompt = prompt_ref.Prompt(e_t, 1.0, float("-inf"))
+        loss_t, embs = 0.0, []
+        for c0 in range(0, cutn, chunk):
+            t1 = time.perf_counter()
+            xc = x_val[c0:c0 + chunk].clone().requires_grad_(True)
+            e = _tower(tkind, cfg, params, xc)
+            l = prompt(e) * (e.shape[0] / cutn)
+            (g,) = torch.autograd.grad(l, xc)
+            gx[c0:c0 + chunk] = g
+            loss_t += float(l.detach())
+            embs.append(e.detach())
+            say(f"{name}: cutouts {c0}..{c0 + e.shape[0] - 1} {time.perf_counter() - t1:.1f}s")
+        (g,) = torch.autograd.grad(x, cuts_d[S], gx)
+        g_cuts[S] += g
+        losses.append(loss_t)
+        emb = torch.cat(embs)
+    if custom:
+        terms = []
+        for t in custom:
+            r = t["loss"].get_loss(cuts_d, img_d, args, globals={"cur_iteration": cur_iteration, "embeds": emb}, lossGlobals={})
+            terms += [t["weight"] * l for l in (r if isinstance(r, (list, tuple)) else [r])]
+        leaves = [cuts_d[S] for S in cuts_d] + [img_d]
+        gs = torch.autograd.grad(sum(terms), leaves, allow_unused=True)
+        for S, g in zip(cuts_d, gs[:-1]):
+            if g is not None:
+                g_cuts[S] += g
+        g_img = gs[-1] if gs[-1] is not None else torch.zeros_like(img_d)
+        losses += [float(l.detach()) for l in terms]
+    else:
+        g_img = torch.zeros_like(img_d)
+    for S in cuts:
+        (g,) = torch.autograd.grad(cuts[S], img_d, g_cuts[S])
+        g_img = g_img + g
+    t2 = time.perf_counter()
+    (grad,) = torch.autograd.grad(img, leaf, g_img)
+    say(f"drawer backward {time.perf_counter() - t2:.1f}s")
+    return dict(losses=losses, grad=grad.detach(), img=img.detach(), embeds=emb.detach(), start=leaf.detach().clone())
