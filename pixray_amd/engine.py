@@ -57,9 +57,20 @@ def needs_full_batch(loss) -> bool:
     such a loss is scored on the all-gathered batch; every other loss is scored on the local shard with weight / world.
     The reference's own batch-coupled plugins (`SaturationLoss`: std over all cutout pixels, Losses/SaturationLoss.py:19-28;
     `AestheticLoss`: target sized by num_cuts, Losses/AestheticLoss.py:26; `ResmemLoss`) predate the attribute, so
-    `plugins.register_reference_loss` / `mark_full_batch` set it on those classes when they are loaded -- there is no
-    matching by class name at scoring time."""
+    `plugins.add_custom_loss` / `mark_full_batch` set it on those classes when they are registered, and `Session.__init__`
+    resolves it ONCE for instances handed over directly (`resolve_full_batch`) -- there is no matching by class name at
+    scoring time."""
     return bool(getattr(loss, "needs_full_batch", False))
+
+
+def resolve_full_batch(loss):
+    """Decide the batch-coupling flag of a custom-loss instance once, when a Session takes it: an explicit
+    `needs_full_batch` attribute (class or instance, True or False) wins; otherwise an instance of one of the reference's
+    own batch-coupled classes (by class name anywhere in its MRO) is marked, so that an unregistered
+    `SaturationLoss()` passed straight to `Session(custom_losses=...)` is not silently scored per shard."""
+    if not hasattr(loss, "needs_full_batch") and any(c.__name__ in REFERENCE_FULL_BATCH_LOSSES for c in type(loss).__mro__):
+        loss.needs_full_batch = True
+    return loss
 
 
 # reference plugin classes that are batch-coupled but cannot declare it themselves (see needs_full_batch)
@@ -152,6 +163,8 @@ class Session:
         self.iterations = iterations
         self.batches = batches
         self.learning_rate_drops = list(learning_rate_drops)
+        for _t in custom_losses:
+            resolve_full_batch(_t["loss"])
         self.custom_losses = list(custom_losses)     # [{"loss": LossInterface, "weight": float}] (pixray.py:961-995)
         # Scheduling, not arithmetic: differentiate the perceptor terms first and the custom-loss terms in a second
         # backward() (gradients accumulate in the leaves exactly as in one pass; the shared drawer graph is walked twice).

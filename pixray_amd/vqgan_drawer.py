@@ -33,6 +33,7 @@ class VqganDrawer(DrawingInterface):
         self.weight_seed = getattr(settings, "weight_seed", 0)
         self.precision = getattr(settings, "precision", "bf16")           # "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.z = None
+        self.gumbel = False          # set by load_taming for GumbelVQ checkpoints (vqgan.py:149-153)
         self._fused_clamp = False
 
     def load_model(self, settings, device):
@@ -94,6 +95,12 @@ class VqganDrawer(DrawingInterface):
     def _encode(self, t):
         if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
             raise ValueError(f"expected an image tensor [1,3,H,W] in [-1,1], got {tuple(t.shape)}")
+        if self.gumbel:
+            # taming's GumbelQuantize encodes through `quantize.proj` logits + gumbel_softmax (vqgan.py:175-185 via
+            # GumbelVQ.encode), not through nearest-codebook lookup; those weights are not on the decode path and are
+            # dropped on load, so producing a z here would silently be a different z
+            raise NotImplementedError("init_image / overlay / z-label encoding is not implemented for GumbelVQ checkpoints "
+                                      "(decode / synth is); use a VQModel checkpoint for image-initialised runs")
         z, idx = ops.vqgan_encode(t.to(self.device), self._encoder())
         self.last_encode_indices = idx
         return z

@@ -113,6 +113,12 @@ def _build(cutn, world, rank, group, coupled_loss=False, extras=False):
     pm.denom = None
 
     custom = [{"loss": SaturationLoss(), "weight": 3.0}] if coupled_loss else []
+    if coupled_loss == "unregistered":
+        # the reference's own class arrives WITHOUT the attribute and without going through plugins.add_custom_loss: only
+        # its name says what it is (Session.__init__ -> engine.resolve_full_batch)
+        bare = type("SaturationLoss", (), {"get_loss": SaturationLoss.get_loss})
+        assert not hasattr(bare, "needs_full_batch")
+        custom = [{"loss": bare(), "weight": 3.0}]
     kw = {}
     if extras == "spot_rgba":
         # spot / spot-off prompts (pixray.py:1270-1292) on an RGBA drawer with the transparency term (1383-1386): the spot
@@ -224,6 +230,31 @@ def test_world2_batch_coupled_custom_loss_is_scored_on_the_gathered_batch():
     # the prompt shares add up; the coupled loss is the same full-batch value on both ranks (counted once)
     sat_ref = float(ref.last_losses[-1].detach())
     assert abs((l0 + l1) - (float(sum(l.detach() for l in ref.last_losses)) + sat_ref)) < 1e-5
+
+
+def test_world2_unregistered_reference_named_loss_is_still_gathered():
+    """a reference `SaturationLoss` instance handed straight to Session(custom_losses=...) -- never registered,
+    no `needs_full_batch` attribute -- must not be scored per shard: the Session resolves the flag once from the class name"""
+    cutn, world = 4, 2
+    res = _run_world(world, cutn, "unregistered")
+    torch.set_num_threads(4)
+    ref = _build(cutn, 1, 0, None, "unregistered")
+    for it in range(2):
+        ref.train(it)
+    z_ref, g_ref = ref.drawer.get_z().detach(), ref.drawer.get_z().grad.detach()
+    (_, z0, g0, l0), (_, z1, g1, l1) = res
+    z0, g0, z1, g1 = [torch.from_numpy(t) for t in (z0, g0, z1, g1)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    assert (g0 - g_ref).abs().max().item() < 1e-5 * max(1.0, g_ref.abs().max().item())
+    assert (z0 - z_ref).abs().max().item() < 1e-5
+
+
+def test_explicit_needs_full_batch_false_is_respected():
+    from pixray_amd.engine import needs_full_batch, resolve_full_batch
+    per_shard = type("SaturationLoss", (), {"needs_full_batch": False})()
+    assert not needs_full_batch(resolve_full_batch(per_shard))
+    assert needs_full_batch(resolve_full_batch(type("AestheticLoss", (), {})()))
+    assert not needs_full_batch(resolve_full_batch(type("MyLoss", (), {})()))
 
 
 def test_world2_image_prompts_and_regularisers_match_single_process():

@@ -583,6 +583,12 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
             drawer.load_model(args, "cpu")
     finally:
         ops.VqganHandle = real
+    # the flag is consulted -- a GumbelVQ checkpoint decodes, but its encoder side (quantize.proj logits +
+    # gumbel_softmax, vqgan.py:175-185) is not the nearest-code lookup the HIP encoder does, so it must refuse loudly
+    assert drawer.gumbel == gumbel and VqganDrawer(args).gumbel is False
+    if gumbel:
+        with pytest.raises(NotImplementedError, match="GumbelVQ"):
+            drawer.init_from_tensor(torch.zeros(1, 3, 64, 64))
     bad = VqganDrawer.add_settings(argparse.ArgumentParser()).parse_args(["--vqgan_config", str(tmp_path / "nope.yaml")])
     bad.size = (64, 64)
     with pytest.raises(FileNotFoundError):
