@@ -9,7 +9,7 @@ One "step" = one body of the reference's train() (pixray.py:1448-1487, batches=1
     python bench.py --config cfg2                    # configs[2]: vqgan 512^2 + ViT-B/16 + RN50x4, 128 cutouts per perceptor
     python bench.py --config cfg2 --cutn 16          #   ... at the 16-cutout shard one of 8 GPUs holds
     python bench.py --config cfg3                    # configs[3]: fft 512^2 + ViT-L/14 + 256 cutouts + StyleLoss + SaturationLoss
-    python bench.py --precision f32                  # the exact-f32 MFMA parity mode instead of the bf16 fast path
+    python bench.py --precision bf16|f32             # bf16 operands / the exact-f32 MFMA parity mode instead of the fp16 default
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -28,7 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "f32": 157.3}
 # algorithmic work per iteration at the headline config; the other configurations report
 # the contraction flops the engine executed (sum of 2MNK over its launches, split-K counted once)
 GFLOP_DECODER_256 = 506.0 + 2.1
@@ -124,7 +124,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3"], default="cfg1")
     ap.add_argument("--cutn", type=int, default=None, help="cutouts (default: the configuration's own count)")
-    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--precision", choices=["fp16", "bf16", "f32"], default="fp16",
+                    help="operand precision of the timed run: fp16 (default; the reference's own GPU arithmetic for CLIP, slip.py:175), "
+                         "bf16, or f32 (exact-f32 MFMA parity mode)")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the extra legs (headline config, 1 GPU): it/s of the other precisions and dL/dz parity of every mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the iteration from a captured hipGraph (measured neutral on MI355X: the loop is GPU-bound)")
@@ -238,14 +242,16 @@ def main():
             ms = max(raw_ms - ev_over_ms * n, 0.5 * raw_ms)
             achieved = flop / (ms * 1e-3) / 1e12
             gemm_gflop_step = flop / args.profile_steps / 1e9
-            kern = ("gemm_glds_kernel<BM,BN,AMODE,STAGES,..> (bf16 MFMA GEMM / implicit 3x3 conv, all launches)" if args.precision == "bf16"
+            kern = (f"gemm_glds_kernel<BM,BN,AMODE,STAGES,..> ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
+                    if args.precision != "f32"
                     else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
             # HBM-side bytes per launch come from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
             # command, gfx950 FETCH correction applied): not measurable from inside this process, so `traffic` is null here
             # and the committed profile of the round is quoted next to it when there is one for this configuration
             pmc = None
-            pmc_path = os.path.join(ROOT, "profiles", f"r02_{args.config}_hbm_traffic.json")
-            if args.precision == "bf16" and os.path.exists(pmc_path):
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (3, 2))
+                             if os.path.exists(q)), "")
+            if args.precision != "f32" and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 pmc["source"] = os.path.relpath(pmc_path, ROOT)
@@ -272,6 +278,45 @@ def main():
     else:
         per_gpu_gflop = gemm_gflop_step      # rank 0's executed contraction flops (identical on every rank)
     iter_frac = value * per_gpu_gflop * 1e9 / (peak * 1e12) if per_gpu_gflop else None
+
+    # ---- the other operand precisions at the same configuration, and dL/dz parity of every mode against the CPU oracle ----
+    # (headline configuration, one GPU, after the timed region; the oracle iteration is ONE extra evaluation on the host)
+    other_modes = parity = None
+    if rank == 0 and world == 1 and args.config == "cfg1" and cutn == wl["num_cuts"] and not args.no_other_modes and not force_dist:
+        del prof
+        sess = None
+        torch.cuda.empty_cache()
+        other_modes = {}
+        for prec in ("fp16", "bf16", "f32"):
+            if prec == args.precision:
+                continue
+            s2 = api.build_workload(args.config, num_cuts=cutn, precision=prec, device=dev)
+            n2, w2 = (10, 2) if prec == "f32" else (steps, warmup)
+            for i in range(w2):
+                s2.train(i)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(n2):
+                s2.train(w2 + i)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            other_modes[prec] = {"value": round(n2 / dt, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt / n2, 3), "steps": n2,
+                                 "warmup": w2, "frac_of_mfma_peak": round((n2 / dt) * per_gpu_gflop * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4)}
+            del s2
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            from oracle import workload_ref
+            prm = workload_ref.draws_for(args.config, cutn, 0)
+            ref = None
+            parity = {"what": "dL/dz after ONE iteration vs the fp32 CPU oracle, same seeds and explicit augmentation draws "
+                              "(SURVEY.md 8d gates: f32 rel-L2 <= 1e-4 jitter off / 1e-3 on; fp16, bf16 rel-L2 <= 2e-2 and cosine >= 0.999)"}
+            for prec in ("fp16", "bf16", "f32"):
+                hip = workload_ref.hip_gradient(args.config, cutn, prec, prm, 0, str(dev))
+                if ref is None:
+                    ref = workload_ref.iteration(args.config, cutn, 0, prm, state=hip["start"])
+                c = workload_ref.compare_with(ref, hip)
+                parity[prec] = {"dz_rel_l2": float(f"{c['grad_rel_l2']:.3e}"), "dz_cosine": round(c["grad_cosine"], 7),
+                                "loss_abs_err": float(f"{c['loss_abs_err']:.2e}")}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -311,12 +356,15 @@ def main():
                        "weights": "seeded random, real architectures", "cutouts_per_gpu": cutn // world,
                        "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU",
                        "launch": "hipGraph replay" if graphed else "eager",
-                       "precision": "bf16 MFMA operands, fp32 accumulate / residual streams / norms" if args.precision == "bf16"
-                                    else "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)"},
+                       "precision": {"fp16": "IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16: the reference's CLIP arithmetic on a GPU), "
+                                             "fp32 accumulate / residual streams / norms, power-of-two gradient scale in the backward",
+                                     "bf16": "bf16 MFMA operands, fp32 accumulate / residual streams / norms",
+                                     "f32": "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)"}[args.precision]},
             "final_loss": round(loss, 5),
             "per_gpu_gflop_per_step": round(per_gpu_gflop, 1) if per_gpu_gflop else None,
             "iter_mfma_frac": round(iter_frac, 4) if iter_frac else None,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "collectives_ms_per_step": collectives, "phase_ms": phase_ms,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precisions": other_modes, "parity_vs_oracle": parity,
+            "collectives_ms_per_step": collectives, "phase_ms": phase_ms,
         }
     if world > 1 or force_dist:
         import torch.distributed as dist

@@ -61,9 +61,17 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
  *   PRX_PREC_BF16  GEMM operands (inter-kernel activations, weight packs) bf16, fp32 accumulate on
  *                  v_mfma_f32_32x32x16_bf16; residual streams, norms, softmax statistics, loss, optimiser fp32.
  *   PRX_PREC_F32   every operand fp32 end to end on v_mfma_f32_32x32x2_f32 (exact f32 = what the reference's CPU
- *                  path computes, pixray.py:275-280, vqgan.py:60-79, slip.py:21-66): the parity mode, 1/16 of the rate. */
+ *                  path computes, pixray.py:275-280, vqgan.py:60-79, slip.py:21-66): the parity mode, 1/16 of the rate.
+ *   PRX_PREC_F16   the same data flow as PRX_PREC_BF16 with IEEE half operands on v_mfma_f32_32x32x16_f16 (same MFMA rate):
+ *                  the arithmetic the reference's CLIP towers run in on a GPU -- `clip.load` keeps fp16 weights and
+ *                  activations with fp32 LayerNorm (slip.py:175) -- with 11 significand bits instead
+ *                  of bf16's 8.  Conversions saturate at +-65504, and every runner backward runs under a power-of-two
+ *                  gradient scale (2^PRX_GRAD_SCALE_LOG2, default 2^14; exact, because each backward op is linear in the
+ *                  incoming gradient and ClampWithGrad / ReLU masks only read signs) that is removed before anything
+ *                  leaves the handle.  The VQGAN encoder, the CLIP text tower and the VGG16 extractor stay bf16 / fp32. */
 #define PRX_PREC_BF16 0
 #define PRX_PREC_F32 1
+#define PRX_PREC_F16 2
 
 /* Engine state of ONE handle: tile / split-K overrides and the optional per-launch timing log.  Each runner handle owns
  * one (prx_*_gemm_ctx below); the library has no process-global mutable state. */
@@ -92,7 +100,8 @@ typedef struct prx_gemm_args {
     int act;
     float* out_f32; int ldc_f32;
     void* out_bf16; void* out_bf16_pre; int ldc_bf16;
-    int f32;            /* PRX_PREC_F32: A, B, aux, out_bf16, out_bf16_pre are all fp32 and the product is exact f32 */
+    int f32;            /* operand precision, PRX_PREC_*: _F32 = A, B, aux, out_bf16, out_bf16_pre are all fp32 and the product is
+                         * exact f32; _F16 = the 16-bit operands are IEEE half; _BF16 (0) = bf16 */
     prx_gemm_ctx* ctx;  /* tuning / timing context or NULL (built-in heuristics) */
 } prx_gemm_args;
 int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream);
@@ -160,7 +169,7 @@ typedef struct prx_vqgan_config {
     int n_embed;           /* 16384 */
     int out_ch;            /* 3 */
     int latent_h, latent_w;/* z is [1, z_channels, latent_h, latent_w] */
-    int precision;         /* PRX_PREC_BF16 (fast path) | PRX_PREC_F32 (exact-f32 MFMA parity mode); the encoder ignores it */
+    int precision;         /* PRX_PREC_F16 | PRX_PREC_BF16 (fast paths) | PRX_PREC_F32 (exact-f32 MFMA parity mode); the encoder ignores it */
 } prx_vqgan_config;
 int prx_vqgan_create(prx_vqgan** out, const prx_vqgan_config* cfg, const float* const* weights, int n_weights,
                      prx_stream_t s);
@@ -273,7 +282,7 @@ typedef struct prx_clip_vit_config {
     int heads;             /* 12 */
     int output_dim;        /* 512 */
     int max_batch;         /* capacity in cutouts */
-    int precision;         /* PRX_PREC_BF16 | PRX_PREC_F32 */
+    int precision;         /* PRX_PREC_F16 | PRX_PREC_BF16 | PRX_PREC_F32 */
 } prx_clip_vit_config;
 int prx_clip_vit_create(prx_clip_vit** out, const prx_clip_vit_config* cfg, const float* const* weights, int n_weights,
                         prx_stream_t s);
@@ -301,7 +310,7 @@ typedef struct prx_clip_resnet_config {
     int heads;             /* 40 = width * 32 / 64 */
     int output_dim;        /* 640 */
     int max_batch;
-    int precision;         /* PRX_PREC_BF16 | PRX_PREC_F32 */
+    int precision;         /* PRX_PREC_F16 | PRX_PREC_BF16 | PRX_PREC_F32 */
 } prx_clip_resnet_config;
 int prx_clip_resnet_create(prx_clip_resnet** out, const prx_clip_resnet_config* cfg, const float* const* weights, int n_weights,
                            prx_stream_t s);

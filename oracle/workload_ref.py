@@ -151,38 +151,50 @@ def _metrics(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item(), (a @ b / (a.norm() * b.norm() + 1e-300)).item()
 
 
-def compare_workload(workload: str, cutn: int, precisions=("bf16",), seed: int = 0, device: str = "cuda:0", custom_factory=None,
-                     custom_ref=(), args=None) -> Dict[str, Dict[str, float]]:
-    """gradient w.r.t. the optimised tensor (z, or the fft drawer's spectrum) after ONE iteration: HIP path (one session per
-    entry of `precisions`) vs this oracle (evaluated once), same weights, same start, same explicit augmentation draws and
-    noise.  `custom_factory(precision) -> [{"loss", "weight"}]` builds the HIP-side custom losses."""
+def hip_gradient(workload: str, cutn: int, prec: str, prm, seed: int = 0, device: str = "cuda:0", custom_hip=(), args=None):
+    """one iteration of the HIP path (product session, `prec` operand precision) on the explicit draws `prm`
+    -> dict(grad, losses, embeds, start), everything on the CPU"""
     from pixray_amd import api
+    sess = api.build_workload(workload, num_cuts=cutn, precision=prec, device=device, seed=seed, custom_losses=custom_hip, args=args)
+    for S, mk in sess.cutoutsTable.items():
+        mk.fixed_params = prm[S]
+    leaf = sess.drawer.get_z() if sess.drawer.get_z() is not None else sess.drawer.params[0]
+    start = leaf.detach().cpu().clone()
+    losses = sess.ascend_txt()
+    sum(losses).backward()
+    out = dict(grad=leaf.grad.detach().cpu(), losses=[float(l.detach()) for l in losses], embeds=sess.last_embeds.detach().cpu(),
+               start=start)
+    del sess
+    return out
+
+
+def compare_with(ref: dict, hip: dict) -> Dict[str, float]:
+    """the parity figures of one HIP iteration against an oracle iteration (`iteration(...)`'s dict, or a golden fixture)"""
+    rel, cos = _metrics(hip["grad"], ref["grad"])
+    return dict(grad_rel_l2=rel, grad_cosine=cos, losses_hip=hip["losses"], losses_ref=list(ref["losses"]),
+                loss_abs_err=max(abs(a - b) for a, b in zip(hip["losses"], ref["losses"])),
+                embeds_rel_l2=_metrics(hip["embeds"], ref["embeds"])[0])
+
+
+def compare_workload(workload: str, cutn: int, precisions=("bf16",), seed: int = 0, device: str = "cuda:0", custom_factory=None,
+                     custom_ref=(), args=None, ref: Optional[dict] = None) -> Dict[str, Dict[str, float]]:
+    """gradient w.r.t. the optimised tensor (z, or the fft drawer's spectrum) after ONE iteration: HIP path (one session per
+    entry of `precisions`) vs this oracle (evaluated once, or handed in as `ref` -- e.g. a committed full-size fixture of
+    tools/fullsize_oracle.py), same weights, same start, same explicit augmentation draws and noise.
+    `custom_factory(precision) -> [{"loss", "weight"}]` builds the HIP-side custom losses."""
     prm = draws_for(workload, cutn, seed)
-    ref, out = None, {}
+    out, grads = {}, {}
     for prec in precisions:
         custom_hip = custom_factory(prec) if custom_factory is not None else ()
-        sess = api.build_workload(workload, num_cuts=cutn, precision=prec, device=device, seed=seed, custom_losses=custom_hip,
-                                  args=args)
-        for S, mk in sess.cutoutsTable.items():
-            mk.fixed_params = prm[S]
-        leaf = sess.drawer.get_z() if sess.drawer.get_z() is not None else sess.drawer.params[0]
-        start = leaf.detach().cpu().clone()
-        losses = sess.ascend_txt()
-        sum(losses).backward()
-        g_hip = leaf.grad.detach().cpu()
+        hip = hip_gradient(workload, cutn, prec, prm, seed, device, custom_hip, args)
         if ref is None:
-            ref = iteration(workload, cutn, seed, prm, state=start, custom=custom_ref, args=args)
-        rel, cos = _metrics(g_hip, ref["grad"])
-        lh = [float(l.detach()) for l in losses]
-        out[prec] = dict(grad_rel_l2=rel, grad_cosine=cos, losses_hip=lh, losses_ref=ref["losses"],
-                         loss_abs_err=max(abs(a - b) for a, b in zip(lh, ref["losses"])),
-                         embeds_rel_l2=_metrics(sess.last_embeds, ref["embeds"])[0], grad=g_hip)
-        del sess
-    if "bf16" in out and "f32" in out:
-        r, c = _metrics(out["bf16"]["grad"], out["f32"]["grad"])
-        out["bf16_vs_f32"] = dict(grad_rel_l2=r, grad_cosine=c)
-    for k in precisions:
-        out[k].pop("grad")
+            ref = iteration(workload, cutn, seed, prm, state=hip["start"], custom=custom_ref, args=args)
+        out[prec] = compare_with(ref, hip)
+        grads[prec] = hip["grad"]
+    for fast in precisions:
+        if fast != "f32" and "f32" in grads:
+            r, c = _metrics(grads[fast], grads["f32"])
+            out[f"{fast}_vs_f32"] = dict(grad_rel_l2=r, grad_cosine=c)
     return out
 
 

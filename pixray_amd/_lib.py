@@ -48,16 +48,29 @@ class GemmArgs(ctypes.Structure):
                 pass
 
 
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16 = 0, 1, 2
+# the product default: IEEE-half operands -- the reference's own GPU arithmetic for the CLIP towers (slip.py:175), at the
+# bf16 MFMA rate with 8x finer operand rounding (include/prx.h PRX_PREC_F16)
+DEFAULT_PRECISION = "fp16"
 
 
 def precision_code(precision) -> int:
-    """'bf16' | 'f32' (or the PRX_PREC_* integers) -> PRX_PREC_*"""
-    if precision in (PREC_BF16, "bf16", None):
+    """'fp16' | 'bf16' | 'f32' (or the PRX_PREC_* integers) -> PRX_PREC_*; None -> the product default"""
+    if precision is None:
+        precision = DEFAULT_PRECISION
+    if isinstance(precision, str):
+        precision = precision.lower()
+    if precision in (PREC_F16, "fp16", "f16", "half", "float16"):
+        return PREC_F16
+    if precision in (PREC_BF16, "bf16", "bfloat16"):
         return PREC_BF16
     if precision in (PREC_F32, "f32", "fp32", "float32"):
         return PREC_F32
-    raise ValueError(f"unknown precision {precision!r} (want 'bf16' or 'f32')")
+    raise ValueError(f"unknown precision {precision!r} (want 'fp16', 'bf16' or 'f32')")
+
+
+def precision_name(precision) -> str:
+    return {PREC_F16: "fp16", PREC_BF16: "bf16", PREC_F32: "f32"}[precision_code(precision)]
 
 
 _SCALARS = {

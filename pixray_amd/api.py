@@ -33,7 +33,7 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                              image_prompt_shuffle: bool = False, init_weight: float = 0.0, init_weight_dist: float = 0.0,
                              init_weight_pix: float = 0.0, init_weight_cos: float = 0.0, overlay_image=None,
                              overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
-                             overlay_alpha: Optional[int] = None, precision: str = "bf16") -> Session:
+                             overlay_alpha: Optional[int] = None, precision: Optional[str] = None) -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
     a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
 
@@ -44,7 +44,8 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     images [1,3,H,W] in [0,1] turned into per-iteration throwaway Prompts through the cached cutout transforms
     (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`);
     `overlay_*`: a PIL image (or path) pasted over the current image every `overlay_every` iterations and re-encoded by the HIP
-    VQGAN encoder (pixray.py:731-747, 1408-1420); `precision`: "bf16" (bf16 MFMA operands, the fast path) or "f32" (every
+    VQGAN encoder (pixray.py:731-747, 1408-1420); `precision`: "fp16" (the default: IEEE-half MFMA operands, the reference's own GPU arithmetic for CLIP,
+    slip.py:175), "bf16" (the same rate, 8 significand bits) or "f32" (every
     contraction on the exact-f32 MFMA: the parity mode the bf16 numbers are measured against)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
@@ -100,7 +101,7 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
 
 def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=256, iterations=250, seed=0, device="cuda",
                            group=None, rank=0, world_size=1, custom_losses=(), args=None, prompt_embeds=None,
-                           precision: str = "bf16", fft_lrate: float = 0.3, fft_decay: float = 1.5) -> Session:
+                           precision: Optional[str] = None, fft_lrate: float = 0.3, fft_decay: float = 1.5) -> Session:
     """BASELINE.json configs[3]'s shape: the spectrum drawer plugin (`FftDrawer`, its own Adam, no z) + one CLIP perceptor +
     MakeCutouts + a Prompt + a custom-loss stack handed in by the caller ([{"loss": LossInterface, "weight": w}], e.g.
     StyleLoss + SaturationLoss; `args` is what their `parse_settings` returned)."""
@@ -135,7 +136,7 @@ WORKLOADS = {
 }
 
 
-def build_workload(name: str, *, num_cuts=None, precision="bf16", device="cuda", group=None, rank=0, world_size=1, seed=0,
+def build_workload(name: str, *, num_cuts=None, precision=None, device="cuda", group=None, rank=0, world_size=1, seed=0,
                    custom_losses=(), args=None) -> Session:
     """A BASELINE.json configuration by name ("cfg1" = configs[1], the headline; "cfg2"; "cfg3"), seeded random weights of
     the real architectures.  `num_cuts` overrides the configuration's cutout count (per-GPU shard sizes)."""

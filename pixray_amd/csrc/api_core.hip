@@ -21,6 +21,17 @@ int prx_xcd_local() {
     return v;
 }
 
+float prx_default_grad_scale() {
+    static const float v = [] {
+        const char* e = getenv("PRX_GRAD_SCALE_LOG2");
+        int k = e ? atoi(e) : 14;
+        if (k < 0) k = 0;
+        if (k > 30) k = 30;
+        return (float)(1u << k);
+    }();
+    return v;
+}
+
 extern "C" {
 
 const char* prx_last_error(void) { return g_err; }
@@ -44,7 +55,8 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
     hipStream_t stream = (hipStream_t)stream_;
     PRX_REQUIRE(g != nullptr, "prx_k_gemm: null args");
     GemmDesc d;
-    d.f32 = g->f32;
+    PRX_REQUIRE(prec_valid(g->f32), "prx_k_gemm: unknown operand precision %d", g->f32);
+    d.f32 = prec_is_f32(g->f32); d.h16 = prec_is_h16(g->f32);
     d.A = g->A; d.a_is_f32 = g->a_is_f32; d.a_mode = g->a_mode; d.lda = g->lda;
     d.B = g->B; d.ldb = g->ldb;
     d.M = g->M; d.N = g->N; d.K = g->K;

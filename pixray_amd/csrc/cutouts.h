@@ -15,7 +15,7 @@ int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const flo
 int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int Wb, hipStream_t s);
 int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s);
 int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hipStream_t s);
-int prx_patchify_fwd(const float* cut, const float* mm, void* A, int f32, int N, int S, int P, int T, hipStream_t s);   // A at operand precision
+int prx_patchify_fwd(const float* cut, const float* mm, void* A, int prec, int N, int S, int P, int T, hipStream_t s);   // A at operand precision (PRX_PREC_*)
 int prx_patchify_bwd_reduce(const float* cut, const float* mm, const float* dA, double* acc, int N, int S, int P, int T,
                             hipStream_t s);
 int prx_patchify_bwd_apply(const float* cut, const float* mm, const float* dA, const double* acc, float* gcut, int N,

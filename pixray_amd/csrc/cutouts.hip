@@ -1119,12 +1119,12 @@ int prx_minmax(const float* x, size_t n, float* part, int nparts, float* mm, hip
 }
 static inline int patch_kp(int P) { return (3 * P * P + 7) / 8 * 8; }
 
-int prx_patchify_fwd(const float* cut, const float* mm, void* A, int f32, int N, int S, int P, int T, hipStream_t s) {
+int prx_patchify_fwd(const float* cut, const float* mm, void* A, int prec, int N, int S, int P, int T, hipStream_t s) {
     PRX_REQUIRE(S % P == 0 && T == (S / P) * (S / P) + 1, "patchify: bad geometry S=%d P=%d T=%d", S, P, T);
     const int Kp = patch_kp(P);
     const dim3 grid(ew_grid((size_t)N * T * Kp / 8));
-    if (f32) hipLaunchKernelGGL(patchify_fwd_kernel<float>, grid, dim3(256), 0, s, cut, mm, (float*)A, N, S, P, T, Kp);
-    else     hipLaunchKernelGGL(patchify_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, cut, mm, (bf16_t*)A, N, S, P, T, Kp);
+    PRX_OP_DISPATCH(prec_is_f32(prec), prec_is_h16(prec), TO,
+                    hipLaunchKernelGGL(patchify_fwd_kernel<TO>, grid, dim3(256), 0, s, cut, mm, (TO*)A, N, S, P, T, Kp));
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -1,20 +1,22 @@
 #pragma once
 #include "common.h"
-// `f32`: operand precision of the untyped buffers (PRX_PREC_*)
+// `f32`: the untyped buffers hold fp32 (else 16-bit); `prec`: PRX_PREC_* where the 16-bit FORMAT matters; `bf16_t*` + `h16`:
+// a 16-bit operand buffer holding bf16 (h16 == 0) or IEEE half
 int prx_transpose_op(const void* in, int ldin, void* out, int ldout, int R, int C, int f32, hipStream_t s);
 int prx_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, void* PT, int ldpt, int rows,
-                     int cols, int f32, hipStream_t s);
+                     int cols, int prec, hipStream_t s);
 int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
-                         void* dST, int lddst, int rows, int cols, int f32, hipStream_t s);
-int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s);
-int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s);
+                         void* dST, int lddst, int rows, int cols, int prec, hipStream_t s);
+int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16 = 0);
+int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s, int h16 = 0);
 int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);
 int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s);
+// gscale: multiplies the outgoing gradient (the runner's power-of-two gradient scale in the half mode; sign tests unaffected)
 int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
-                       int HW, hipStream_t s);
+                       int HW, hipStream_t s, int h16 = 0, float gscale = 1.f);
 int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
                    size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t s);
 int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
                        size_t n, const float* hyper, float b1, float b2, float eps, hipStream_t s);
-int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s, int h16 = 0);
 int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);

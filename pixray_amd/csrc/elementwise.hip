@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int c = lane; c < cols; c += 64) {
-        T p = (T)(__expf(s[c] * scale - mx) * inv);
+        T p = op_cvt<T>(__expf(s[c] * scale - mx) * inv);
         P[(size_t)row * ldp + c] = p;
         if (PT) PT[(size_t)c * ldpt + row] = p;
     }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
     dot = wave_sum(dot);
     for (int c = lane; c < cols; c += 64) {
         float p = (float)P[(size_t)row * ldp + c];
-        T v = (T)(scale * p * (dP[(size_t)row * lddp + c] - dot));
+        T v = op_cvt<T>(scale * p * (dP[(size_t)row * lddp + c] - dot));
         dS[(size_t)row * ldds + c] = v;
         if (dST) dST[(size_t)c * lddst + row] = v;
     }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
 // low[b][y][x][c] = sum over the 2x2 children of hi (NHWC fp32) -- backward of nearest-2x upsample
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ hi, float* __restrict__ low,
                                                              bf16_t* __restrict__ low_bf16, int NB, int Hl, int Wl,
-                                                             int C) {
+                                                             int C, int h16) {
     const int C4 = C >> 2;
     const size_t total = (size_t)NB * Hl * Wl * C4;
     const int Wh = Wl * 2;
@@ -95,9 +95,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
                                (a.w + bb.w) + (c.w + d.w));
         reinterpret_cast<float4*>(low)[idx] = o;
         if (low_bf16) {
-            bf16x4 r;
-            r[0] = (bf16_t)o.x; r[1] = (bf16_t)o.y; r[2] = (bf16_t)o.z; r[3] = (bf16_t)o.w;
-            reinterpret_cast<bf16x4*>(low_bf16)[idx] = r;
+            reinterpret_cast<bf16x4*>(low_bf16)[idx] = to_op16x4(o.x, o.y, o.z, o.w, h16);
         }
     }
 }
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 // NCHW fp32 -> NHWC (fp32 and/or bf16), channels padded with zeros up to Cpad
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
                                                            bf16_t* __restrict__ out_bf16, int NB, int C, int HW,
-                                                           int Cpad) {
+                                                           int Cpad, int h16) {
     const size_t total = (size_t)NB * HW * Cpad;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         int b = (int)(t / HW);
         float v = c < C ? in[((size_t)b * C + c) * HW + p] : 0.f;
         if (out_f32) out_f32[idx] = v;
-        if (out_bf16) out_bf16[idx] = (bf16_t)v;
+        if (out_bf16) out_bf16[idx] = to_op16(v, h16);
     }
 }
 
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(256) void image_head_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void image_head_bwd_kernel(const float* __restrict__ x, int ldc,
                                                              const float* __restrict__ gimg, float* __restrict__ dx,
                                                              bf16_t* __restrict__ dx_bf16, int ldo, int NB, int C,
-                                                             int HW) {
+                                                             int HW, int h16, float gscale) {
     const size_t total = (size_t)NB * HW * ldo;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -166,10 +164,10 @@ __global__ __launch_bounds__(256) void image_head_bwd_kernel(const float* __rest
             float u = (x[((size_t)b * HW + p) * ldc + c] + 1.f) * 0.5f;
             float g = gimg[((size_t)b * C + c) * HW + p];
             float uc = fminf(fmaxf(u, 0.f), 1.f);
-            o = (g * (u - uc) >= 0.f) ? 0.5f * g : 0.f;
+            o = (g * (u - uc) >= 0.f) ? (0.5f * gscale) * g : 0.f;      // gscale: power-of-two gradient scale of the half mode
         }
         if (dx) dx[idx] = o;
-        if (dx_bf16) dx_bf16[idx] = (bf16_t)o;
+        if (dx_bf16) dx_bf16[idx] = to_op16(o, h16);
     }
 }
 
@@ -199,9 +197,9 @@ __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ z, 
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
-                                                          size_t n) {
+                                                          size_t n, int h16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (bf16_t)in[i];
+        out[i] = to_op16(in[i], h16);
 }
 
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -220,34 +218,32 @@ int prx_transpose_op(const void* in, int ldin, void* out, int ldout, int R, int 
     return 0;
 }
 int prx_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, void* PT, int ldpt, int rows,
-                     int cols, int f32, hipStream_t s) {
-    if (f32) hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, (float*)P, ldp,
-                                (float*)PT, ldpt, rows, cols);
-    else     hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, (bf16_t*)P, ldp,
-                                (bf16_t*)PT, ldpt, rows, cols);
+                     int cols, int prec, hipStream_t s) {
+    PRX_OP_DISPATCH(prec_is_f32(prec), prec_is_h16(prec), T,
+                    hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, lds_, scale, (T*)P, ldp,
+                                       (T*)PT, ldpt, rows, cols));
     PRX_LAUNCH_CHECK();
     return 0;
 }
 int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
-                         void* dST, int lddst, int rows, int cols, int f32, hipStream_t s) {
-    if (f32) hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, (const float*)P, ldp, dP, lddp,
-                                scale, (float*)dS, ldds, (float*)dST, lddst, rows, cols);
-    else     hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16_t>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, (const bf16_t*)P, ldp, dP,
-                                lddp, scale, (bf16_t*)dS, ldds, (bf16_t*)dST, lddst, rows, cols);
+                         void* dST, int lddst, int rows, int cols, int prec, hipStream_t s) {
+    PRX_OP_DISPATCH(prec_is_f32(prec), prec_is_h16(prec), T,
+                    hipLaunchKernelGGL(softmax_rows_bwd_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, (const T*)P, ldp, dP, lddp,
+                                       scale, (T*)dS, ldds, (T*)dST, lddst, rows, cols));
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s) {
+int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16) {
     PRX_REQUIRE(C % 4 == 0, "upsample2x_bwd: C %% 4 != 0");
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, low_bf16,
-                       NB, Hl, Wl, C);
+                       NB, Hl, Wl, C, h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }
 int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad,
-                     hipStream_t s) {
+                     hipStream_t s, int h16) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((size_t)NB * HW * Cpad)), dim3(256), 0, s, in, out_f32,
-                       out_bf16, NB, C, HW, Cpad);
+                       out_bf16, NB, C, HW, Cpad, h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -264,9 +260,9 @@ int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int H
     return 0;
 }
 int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
-                       int HW, hipStream_t s) {
+                       int HW, hipStream_t s, int h16, float gscale) {
     hipLaunchKernelGGL(image_head_bwd_kernel, dim3(ew_grid((size_t)NB * HW * ldo)), dim3(256), 0, s, x, ldc, gimg, dx,
-                       dx_bf16, ldo, NB, C, HW);
+                       dx_bf16, ldo, NB, C, HW, h16, gscale);
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -288,8 +284,8 @@ int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, n);
+int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s, int h16) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, n, h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }

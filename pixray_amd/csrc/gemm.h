@@ -4,7 +4,8 @@
 // activation for a 3x3/pad-1 convolution (optionally reading through a fused
 // nearest-2x upsample or a stride-2 window).  Bt is the weight pack, K contiguous.
 // Two operand precisions (GemmDesc::f32):
-//   0  bf16 operands (A may be f32, converted on load), fp32 accumulate on v_mfma_f32_32x32x16_bf16 -- the fast path;
+//   0  16-bit operands -- bf16, or IEEE half with GemmDesc::h16 (A may be f32, converted on load) -- fp32 accumulate on
+//      v_mfma_f32_32x32x16_{bf16,f16} (same rate) -- the fast path;
 //   1  fp32 operands end to end on v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain, the f32 vector rate = 1/16 of
 //      the bf16 MFMA rate) -- the exact parity mode.  Every "bf16" pointer below then addresses fp32 data.
 #pragma once
@@ -20,7 +21,8 @@ enum { PRX_A_ROWMAJOR = 0, PRX_A_CONV3X3 = 1 };
 
 struct GemmDesc {
     // operands
-    int f32 = 0;               // operand precision (PRX_PREC_*): 1 = A, B, aux, out_bf16, out_bf16_pre are all fp32
+    int f32 = 0;               // 1 = A, B, aux, out_bf16, out_bf16_pre are all fp32 (exact mode)
+    int h16 = 0;               // 16-bit operand format when f32 == 0: 0 = bf16, 1 = IEEE half (v_mfma_f32_32x32x16_f16)
     const void* A = nullptr;   // bf16 or f32 (a_is_f32)
     int a_is_f32 = 0;
     int a_mode = PRX_A_ROWMAJOR;

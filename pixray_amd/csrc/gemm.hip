@@ -12,6 +12,7 @@
 #include <vector>
 #include <mutex>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -80,7 +81,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     if (masked && d.act == PRX_ACT_RELUMASK_POST) v = 0.f;          // the mask after the residual add
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
-        const TOp pre = (TOp)v;     // the saved pre-activation is what the backward differentiates: activate its rounded value
+        const TOp pre = op_cvt<TOp>(v);     // the saved pre-activation is what the backward differentiates: activate its rounded value
         if (d.out_bf16_pre) reinterpret_cast<TOp*>(d.out_bf16_pre)[(size_t)row * d.ldc_bf16 + col] = pre;
         v = quickgelu_f((float)pre);
     }
@@ -128,7 +129,7 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     }
     if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (d.act == PRX_ACT_QUICKGELU) {
-        const TOp p0 = (TOp)v.x, p1 = (TOp)v.y, p2 = (TOp)v.z, p3 = (TOp)v.w;
+        const TOp p0 = op_cvt<TOp>(v.x), p1 = op_cvt<TOp>(v.y), p2 = op_cvt<TOp>(v.z), p3 = op_cvt<TOp>(v.w);
         if (d.out_bf16_pre)
             op_st4(reinterpret_cast<TOp*>(d.out_bf16_pre), (size_t)row * d.ldc_bf16 + col, (float)p0, (float)p1, (float)p2, (float)p3);
         v.x = quickgelu_f((float)p0); v.y = quickgelu_f((float)p1); v.z = quickgelu_f((float)p2); v.w = quickgelu_f((float)p3);
@@ -138,23 +139,30 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     return v;
 }
 
-template <typename TA>
-__device__ __forceinline__ bf16x8 load8(const TA* p);
-template <>
-__device__ __forceinline__ bf16x8 load8<bf16_t>(const bf16_t* p) {
-    return *reinterpret_cast<const bf16x8*>(p);
+// 16-bit fragments travel as raw `bf16x8` whatever the format; T16 (bf16_t | half_t) picks the conversion and the opcode
+template <typename T16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (std::is_same<T16, half_t>::value)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-template <>
-__device__ __forceinline__ bf16x8 load8<float>(const float* p) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-    bf16x8 r;
-    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
-    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
-    return r;
+template <typename T16, typename TA>
+__device__ __forceinline__ bf16x8 load8(const TA* p) {
+    if constexpr (std::is_same<TA, float>::value) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+        typedef __attribute__((ext_vector_type(8))) T16 t16x8;
+        t16x8 r;
+        r[0] = op_cvt<T16>(a[0]); r[1] = op_cvt<T16>(a[1]); r[2] = op_cvt<T16>(a[2]); r[3] = op_cvt<T16>(a[3]);
+        r[4] = op_cvt<T16>(b[0]); r[5] = op_cvt<T16>(b[1]); r[6] = op_cvt<T16>(b[2]); r[7] = op_cvt<T16>(b[3]);
+        return __builtin_bit_cast(bf16x8, r);
+    } else {
+        return *reinterpret_cast<const bf16x8*>(p);
+    }
 }
 
-template <int BM, int BN, typename TA, int AMODE>
+template <int BM, int BN, typename TA, int AMODE, typename T16 = bf16_t>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int A_CH = BM * 8 / 256;  // 16-byte chunks per thread per K tile
     constexpr int B_CH = BN * 8 / 256;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (AMODE == PRX_A_ROWMAJOR) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
-                a_reg[i] = (a_ok[i] && k_ok) ? load8<TA>(Ap + a_base[i] + k) : zero8;
+                a_reg[i] = (a_ok[i] && k_ok) ? load8<T16, TA>(Ap + a_base[i] + k) : zero8;
         } else {
             int tap = k / d.Cin;
             int c = k - tap * d.Cin;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 long long pix;
                 if (d.up) pix = ((long long)a_b[i] * (d.H >> 1) + (yy >> 1)) * (d.W >> 1) + (xx >> 1);
                 else      pix = ((long long)a_b[i] * d.H + yy) * d.W + xx;
-                a_reg[i] = ok ? load8<TA>(Ap + pix * d.lda + c) : zero8;
+                a_reg[i] = ok ? load8<T16, TA>(Ap + pix * d.lda + c) : zero8;
             }
         }
 #pragma unroll
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<T16>(af[i], bfr[j], acc[i][j]);
         }
         __syncthreads();
         if (more) {
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 if (p.splits > 1)
                     p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
                 else
-                    epilogue_store<bf16_t>(d, row, col, acc[i][j][r]);
+                    epilogue_store<T16>(d, row, col, acc[i][j][r]);
             }
         }
 }
@@ -512,7 +520,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // NWM = waves along M (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads for the 256-row tiles); two waves along N.
-template <int BM, int BN, int AMODE, int STAGES, bool C64 = false, int NWM = 2>
+template <int BM, int BN, int AMODE, int STAGES, bool C64 = false, int NWM = 2, typename T16 = bf16_t>
 __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
     constexpr int NW = NWM * 2;
     constexpr int A_IN = BM / (8 * NW);   // DMA instructions (8 rows x 128 B each) per wave per K tile
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<T16>(af[i], bfr[j], acc[i][j]);
         }
     };
 
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                     if (p.splits > 1)
                         *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
                     else {
-                        const float4 o = epilogue_store4<bf16_t>(d, row, col, v);
+                        const float4 o = epilogue_store4<T16>(d, row, col, v);
                         if (gnb) gnb_accum(d, gc, row, col, o, gs0, gs1);
                         else {
                             gs0 += (o.x + o.y) + (o.z + o.w);
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                 if (p.splits > 1)
                     p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
                 else
-                    epilogue_store<bf16_t>(d, row, col, acc[i][j][r]);
+                    epilogue_store<T16>(d, row, col, acc[i][j][r]);
             }
         }
 }
@@ -915,16 +923,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN>
-void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
+template <int BM, int BN, typename T16>
+void launch_cfg_t(const GemmArgs& a, dim3 grid, hipStream_t s) {
     const GemmDesc& d = a.d;
     if (d.a_mode == PRX_A_ROWMAJOR) {
-        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a);
-        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_ROWMAJOR>), grid, dim3(256), 0, s, a);
+        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_ROWMAJOR, T16>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_ROWMAJOR, T16>), grid, dim3(256), 0, s, a);
     } else {
-        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
-        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
+        if (d.a_is_f32) hipLaunchKernelGGL((gemm_kernel<BM, BN, float, PRX_A_CONV3X3, T16>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((gemm_kernel<BM, BN, bf16_t, PRX_A_CONV3X3, T16>), grid, dim3(256), 0, s, a);
     }
+}
+template <int BM, int BN>
+void launch_cfg(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (a.d.h16) launch_cfg_t<BM, BN, half_t>(a, grid, s);
+    else         launch_cfg_t<BM, BN, bf16_t>(a, grid, s);
 }
 template <int BM, int BN>
 void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -932,24 +945,34 @@ void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t s) {
     else                              hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRX_A_CONV3X3>), grid, dim3(256), 0, s, a);
 }
 
+template <int BM, int BN, int STAGES, typename T16>
+void launch_glds_t(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR)
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR, STAGES, false, 2, T16>), grid, dim3(256), 0, s, a, zero_page);
+    else if (c64)
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES, true, 2, T16>), grid, dim3(256), 0, s, a, zero_page);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES, false, 2, T16>), grid, dim3(256), 0, s, a, zero_page);
+}
 template <int BM, int BN, int STAGES>
 void launch_glds_s(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
-    if (a.d.a_mode == PRX_A_ROWMAJOR)
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_ROWMAJOR, STAGES>), grid, dim3(256), 0, s, a, zero_page);
-    else if (c64)
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES, true>), grid, dim3(256), 0, s, a, zero_page);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, PRX_A_CONV3X3, STAGES>), grid, dim3(256), 0, s, a, zero_page);
+    if (a.d.h16) launch_glds_t<BM, BN, STAGES, half_t>(a, grid, s, zero_page, c64);
+    else         launch_glds_t<BM, BN, STAGES, bf16_t>(a, grid, s, zero_page, c64);
 }
 // 256x128 tile, 8 waves (wave tile 64x64 like the 128x128 kernel): 1.5 MFMA-flops per L2->LDS byte more than 128x128
+template <int STAGES, typename T16>
+void launch_glds_256_t(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
+    if (a.d.a_mode == PRX_A_ROWMAJOR)
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_ROWMAJOR, STAGES, false, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
+    else if (c64)
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, true, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
+}
 template <int STAGES>
 void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
-    if (a.d.a_mode == PRX_A_ROWMAJOR)
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_ROWMAJOR, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
-    else if (c64)
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, true, 4>), grid, dim3(512), 0, s, a, zero_page);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4>), grid, dim3(512), 0, s, a, zero_page);
+    if (a.d.h16) launch_glds_256_t<STAGES, half_t>(a, grid, s, zero_page, c64);
+    else         launch_glds_256_t<STAGES, bf16_t>(a, grid, s, zero_page, c64);
 }
 template <int BM, int BN>
 void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages, bool c64) {
@@ -1046,6 +1069,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     static const GemmCtx k_default;      // immutable: heuristics only
     const GemmCtx& cx = ctx ? *ctx : k_default;
     PRX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    PRX_REQUIRE(!(d.f32 && d.h16), "gemm: f32 and h16 are exclusive operand formats");
     const int kq = d.f32 ? 4 : 8;        // elements per 16-byte operand chunk
     PRX_REQUIRE(d.K % kq == 0 && d.ldb % kq == 0, "gemm: K (%d) and ldb (%d) must be multiples of %d", d.K, d.ldb, kq);
     PRX_REQUIRE(d.lda % kq == 0, "gemm: lda (%d) must be a multiple of %d", d.lda, kq);
@@ -1181,8 +1205,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     if (splits > 1) {
         size_t total = (size_t)d.M * d.N;
         int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
-        if (d.f32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, a);
-        else       hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, a);
+        PRX_OP_DISPATCH(d.f32, d.h16, T, hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a));
         PRX_LAUNCH_CHECK();
     }
     if (prof) {

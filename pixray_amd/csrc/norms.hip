@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs a) {
 
 // y = gn(x); out = swish ? y*sigmoid(y) : y   -> bf16 (and optionally fp32)
 // `xcd`: give workgroup b the xcd_linear(b)-th contiguous slice of the tensor (common.h) instead of a grid-stride comb
-__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_t* out_bf16, float* out_f32, int NB, int xcd) {
+__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_t* out_bf16, float* out_f32, int NB, int xcd, int h16) {
     const int C4 = a.C >> 2;
     const int gs = a.C / 32;
     const size_t total = (size_t)NB * a.P * C4;
@@ -138,9 +138,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_
             o[i] = a.swish ? y * sigmoidf_(y) : y;
         }
         if (out_bf16) {
-            bf16x4 r;
-            r[0] = (bf16_t)o[0]; r[1] = (bf16_t)o[1]; r[2] = (bf16_t)o[2]; r[3] = (bf16_t)o[3];
-            reinterpret_cast<bf16x4*>(out_bf16)[idx] = r;
+            reinterpret_cast<bf16x4*>(out_bf16)[idx] = to_op16x4(o[0], o[1], o[2], o[3], h16);
         }
         if (out_f32) reinterpret_cast<float4*>(out_f32)[idx] = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_
 
 // dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat)) (+ add)
 __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const double* bstats, const float* add,
-                                                           float* dx, bf16_t* dx_bf16, int NB, int xcd) {
+                                                           float* dx, bf16_t* dx_bf16, int NB, int xcd, int h16) {
     const int C4 = a.C >> 2;
     const int gs = a.C / 32;
     const size_t total = (size_t)NB * a.P * C4;
@@ -187,9 +185,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const
         }
         reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
         if (dx_bf16) {
-            bf16x4 r;
-            r[0] = (bf16_t)o[0]; r[1] = (bf16_t)o[1]; r[2] = (bf16_t)o[2]; r[3] = (bf16_t)o[3];
-            reinterpret_cast<bf16x4*>(dx_bf16)[idx] = r;
+            reinterpret_cast<bf16x4*>(dx_bf16)[idx] = to_op16x4(o[0], o[1], o[2], o[3], h16);
         }
     }
 }
@@ -202,7 +198,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16_t* __restrict__ out_bf16,
                                                      float* __restrict__ out_f32, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int rows, int C, long long ldx,
-                                                     float eps, int xcd) {
+                                                     float eps, int xcd, int h16) {
     const int lane = threadIdx.x & 63;
     const int row = (xcd ? xcd_linear(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -241,9 +237,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             float o2 = (v[i].z - mean) * rstd * ga.z + be.z;
             float o3 = (v[i].w - mean) * rstd * ga.w + be.w;
             if (out_bf16) {
-                bf16x4 r;
-                r[0] = (bf16_t)o0; r[1] = (bf16_t)o1; r[2] = (bf16_t)o2; r[3] = (bf16_t)o3;
-                reinterpret_cast<bf16x4*>(out_bf16 + (size_t)row * C)[c4] = r;
+                reinterpret_cast<bf16x4*>(out_bf16 + (size_t)row * C)[c4] = to_op16x4(o0, o1, o2, o3, h16);
             }
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * C)[c4] = make_float4(o0, o1, o2, o3);
         }
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ add,
                                                      long long ldadd, float* __restrict__ dx, long long lddx,
-                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C, int xcd) {
+                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C, int xcd, int h16) {
     const int lane = threadIdx.x & 63;
     const int row = (xcd ? xcd_linear(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -291,9 +285,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
             }
             reinterpret_cast<float4*>(dx + (size_t)row * lddx)[c4] = o;
             if (dx_bf16) {
-                bf16x4 r;
-                r[0] = (bf16_t)o.x; r[1] = (bf16_t)o.y; r[2] = (bf16_t)o.z; r[3] = (bf16_t)o.w;
-                reinterpret_cast<bf16x4*>(dx_bf16 + (size_t)row * lddxb)[c4] = r;
+                reinterpret_cast<bf16x4*>(dx_bf16 + (size_t)row * lddxb)[c4] = to_op16x4(o.x, o.y, o.z, o.w, h16);
             }
         }
 }
@@ -304,7 +296,7 @@ int gn_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 40
 
 int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, double* stats, bf16_t* out_bf16,
                       float* out_f32, int NB, int P, int C, int swish, float eps, hipStream_t s, int zero_stats,
-                      int stats_ready) {
+                      int stats_ready, int h16) {
     PRX_REQUIRE(C % 32 == 0 && (C / 32) % 4 == 0 && 256 % (C / 4) == 0, "groupnorm: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.gamma = gamma; a.beta = beta; a.stats = stats; a.P = P; a.C = C; a.swish = swish; a.eps = eps;
@@ -317,7 +309,7 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
     }
     if (out_bf16 || out_f32) {
         hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, out_bf16,
-                           out_f32, NB, prx_xcd_local());
+                           out_f32, NB, prx_xcd_local(), h16);
         PRX_LAUNCH_CHECK();
     }
     return 0;
@@ -325,7 +317,7 @@ int prx_groupnorm_fwd(const float* x, const float* gamma, const float* beta, dou
 
 int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const float* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
-                      float eps, hipStream_t s, int zero_stats, int stats_ready) {
+                      float eps, hipStream_t s, int zero_stats, int stats_ready, int h16) {
     PRX_REQUIRE(256 % (C / 4) == 0 && (C / 32) % 4 == 0, "groupnorm bwd: unsupported C=%d", C);
     GNArgs a{};
     a.x = x; a.g = g; a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.stats = bstats;
@@ -338,36 +330,36 @@ int prx_groupnorm_bwd(const float* g, const float* x, const float* gamma, const 
         PRX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,
-                       dx_bf16, NB, prx_xcd_local());
+                       dx_bf16, NB, prx_xcd_local(), h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }
 
 int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, bf16_t* out_bf16,
-                      float* out_f32, float* mean, float* rstd, int rows, int C, float eps, hipStream_t s) {
+                      float* out_f32, float* mean, float* rstd, int rows, int C, float eps, hipStream_t s, int h16) {
     PRX_REQUIRE(C % 256 == 0 && C <= 2048, "layernorm: C must be a multiple of 256 and <= 2048 (C=%d)", C);
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, x, gamma, beta, out_bf16, out_f32, mean, rstd, rows,
-                           C, ldx, eps, prx_xcd_local());
+                           C, ldx, eps, prx_xcd_local(), h16);
     else
         hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, x, gamma, beta, out_bf16, out_f32, mean, rstd, rows,
-                           C, ldx, eps, prx_xcd_local());
+                           C, ldx, eps, prx_xcd_local(), h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }
 
 int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
-                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s) {
+                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s, int h16) {
     PRX_REQUIRE(C % 256 == 0 && C <= 2048, "layernorm bwd: C must be a multiple of 256 and <= 2048 (C=%d)", C);
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local());
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local());
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -33,11 +33,11 @@ __global__ __launch_bounds__(256) void rn_pack_conv3x3_kernel(const float* __res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < total) {
             const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / ((size_t)9 * Cin));
-            Wf[i] = (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+            Wf[i] = op_cvt<TOp>(w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3]);
         } else {
             const size_t j = i - total;
             const int co = (int)(j % Cout), tap = (int)((j / Cout) % 9), ci = (int)(j / ((size_t)9 * Cout));
-            Wd[j] = (TOp)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)];
+            Wd[j] = op_cvt<TOp>(w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)]);
         }
     }
 }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
 // (which took 7.4 ms for RN50x4 at 128 cutouts: 2-byte loads of 40 values per tap, three threads per pixel re-reading them).
 template <typename TOp, int CO>
 __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__ g_, const float* __restrict__ w, float* __restrict__ dY,
-                                                        int N, int S) {
+                                                        int N, int S, float oscale) {
     __shared__ float ws[27 * CO];
     for (int i = threadIdx.x; i < 27 * CO; i += 256) {
         const int co = i % CO, c = (i / CO) % 3, kx = (i / (3 * CO)) % 3, ky = i / (9 * CO);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__
             }
         }
         float* o = dY + (size_t)n * 3 * plane + (size_t)y * S + x;
-        o[0] = acc[0]; o[plane] = acc[1]; o[2 * plane] = acc[2];
+        o[0] = acc[0] * oscale; o[plane] = acc[1] * oscale; o[2 * plane] = acc[2] * oscale;    // oscale: 1 / gradient scale
     }
 }
 
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const void* __restric
         const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Ho * Wo));
         const TOp* p = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
         const float v = ((float)p[0] + (float)p[C]) + ((float)p[(size_t)W * C] + (float)p[(size_t)W * C + C]);
-        out[idx] = (TOp)(0.25f * v);
+        out[idx] = op_cvt<TOp>(0.25f * v);
     }
 }
 // backward: dx[n][y][x][c] = 0.25 * g[n][y/2][x/2][c]  (* [mask > 0] when `mask` is given); fp32 and/or bf16 outputs
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         float v = 0.25f * g[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
         if (mask && !((float)mask[idx] > 0.f)) v = 0.f;
         if (dx_f32) dx_f32[idx] = v;
-        if (dx_bf) dx_bf[idx] = (TOp)v;
+        if (dx_bf) dx_bf[idx] = op_cvt<TOp>(v);
     }
 }
 // g <- g * [out > 0] in place (fp32) and as bf16
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, c
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = ((float)out[i] > 0.f) ? g[i] : 0.f;
         g[i] = v;
-        g_bf[i] = (TOp)v;
+        g_bf[i] = op_cvt<TOp>(v);
     }
 }
 // AttentionPool2d tokens: t[n][0] = mean_p x[n][p] + pos[0]; t[n][1+p] = x[n][p] + pos[1+p]   (x fp32 [n, P, C]) -> bf16
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict
         for (int p = 0; p < P; ++p) {
             const float v = xp[(size_t)p * C];
             sum += v;
-            tp[(size_t)(p + 1) * C] = (TOp)(v + pos[(size_t)(p + 1) * C + c]);
+            tp[(size_t)(p + 1) * C] = op_cvt<TOp>(v + pos[(size_t)(p + 1) * C + c]);
         }
-        tp[0] = (TOp)(sum / (float)P + pos[c]);
+        tp[0] = op_cvt<TOp>(sum / (float)P + pos[c]);
     }
 }
 // dx[n][p] = dt[n][1+p] + dt[n][0] / P   (fp32 + bf16 twin)
@@ -259,7 +259,9 @@ struct RBlock {
 
 struct PrxResNet {
     int res, width, heads, out_dim, max_n, C, G, T, cur_n;
-    int f32;          // PRX_PREC_*
+    int prec;         // PRX_PREC_*
+    int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *w1, *b1;                      // stem conv1 (fp32, BN folded)
@@ -294,16 +296,14 @@ int ralloc_op(PrxResNet* r, void** p, size_t count) {   // `count` operand eleme
 // launch an operand-typed kernel template for this handle's precision
 #define RLAUNCH(kernel, total, ...)                                                                                      \
     do {                                                                                                                 \
-        if (r->f32) hipLaunchKernelGGL(kernel<float>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);                 \
-        else        hipLaunchKernelGGL(kernel<bf16_t>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);                \
+        PRX_OP_DISPATCH(r->f32, r->h16, TO_, hipLaunchKernelGGL(kernel<TO_>, dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__)); \
         PRX_LAUNCH_CHECK();                                                                                              \
     } while (0)
 // the stem kernels keep all CO = width/2 output channels of a pixel in one thread: CO is a template parameter
 // (RN50: 32, RN50x4: 40, RN50x16: 48, RN50x64: 64)
 #define STEM_CASE(kernel, CO_, total, ...)                                                                               \
     case CO_:                                                                                                            \
-        if (r->f32) hipLaunchKernelGGL((kernel<float, CO_>), dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);          \
-        else        hipLaunchKernelGGL((kernel<bf16_t, CO_>), dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__);         \
+        PRX_OP_DISPATCH(r->f32, r->h16, TO_, hipLaunchKernelGGL((kernel<TO_, CO_>), dim3(rgrid(total)), dim3(256), 0, s, __VA_ARGS__)); \
         break;
 #define STEM_LAUNCH(kernel, total, co, ...)                                                                              \
     do {                                                                                                                 \
@@ -328,8 +328,8 @@ int mk1(PrxResNet* r, RConv1& c, int Cin, int Cout, RCur& cur, hipStream_t s) {
     c.Cin = Cin; c.Cout = Cout;
     RALLOC_OP(c.W, (size_t)Cout * Cin); RALLOC_OP(c.WT, (size_t)Cout * Cin);
     int e;
-    if ((e = prx_pack_op(w, c.W, (size_t)Cout * Cin, r->f32, s))) return e;
-    if ((e = prx_pack_transpose_op(w, c.WT, Cout, Cin, r->f32, s))) return e;
+    if ((e = prx_pack_op(w, c.W, (size_t)Cout * Cin, r->prec, s))) return e;
+    if ((e = prx_pack_transpose_op(w, c.WT, Cout, Cin, r->prec, s))) return e;
     return rcopy(r, &c.b, b, Cout, s);
 }
 int mk3(PrxResNet* r, RConv3& c, int Cin, int Cout, RCur& cur, hipStream_t s) {
@@ -341,6 +341,7 @@ int mk3(PrxResNet* r, RConv3& c, int Cin, int Cout, RCur& cur, hipStream_t s) {
 }
 int rg(PrxResNet* r, GemmDesc& d, hipStream_t s) {
     if (r->f32) { d.f32 = 1; d.a_is_f32 = 0; }
+    d.h16 = r->h16;
     return prx_gemm_launch(d, r->ws, r->ws_bytes, s, &r->gctx);
 }
 
@@ -367,12 +368,13 @@ GemmCtx* prx_resnet_gemm_ctx_impl(PrxResNet* r) { return r ? &r->gctx : nullptr;
 
 int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layers, int heads, int out_dim, int max_n,
                            int precision, const float* const* w, int n_w, hipStream_t s) {
-    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "resnet_create: unknown precision %d", precision);
+    PRX_REQUIRE(prec_valid(precision), "resnet_create: unknown precision %d", precision);
     PRX_REQUIRE(res % 32 == 0 && width % 16 == 0 && max_n >= 1, "resnet_create: unsupported geometry (res %d width %d)", res, width);
     PRX_REQUIRE(width * 32 == heads * 64, "resnet_create: the attention pool needs head dim 64 (width %d heads %d)", width, heads);
     PrxResNet* r = new PrxResNet();
     std::unique_ptr<PrxResNet> guard(r);
-    r->f32 = precision;
+    r->prec = precision; r->f32 = prec_is_f32(precision); r->h16 = prec_is_h16(precision);
+    r->gscale = r->h16 ? prx_default_grad_scale() : 1.f;
     r->res = res; r->width = width; r->heads = heads; r->out_dim = out_dim; r->max_n = max_n; r->cur_n = 0;
     r->C = width * 32; r->G = res / 32; r->T = r->G * r->G + 1;
     RCur cur{w, n_w, 0};
@@ -412,12 +414,12 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     const int C = r->C, T = r->T;
     if ((e = rcopy(r, &r->pos, pos, (size_t)T * C, s))) return e;
     RALLOC_OP(r->Win, (size_t)3 * C * C); RALLOC_OP(r->WinT, (size_t)3 * C * C);
-    if ((e = prx_pack_op(win, r->Win, (size_t)3 * C * C, r->f32, s))) return e;
-    if ((e = prx_pack_transpose_op(win, r->WinT, 3 * C, C, r->f32, s))) return e;
+    if ((e = prx_pack_op(win, r->Win, (size_t)3 * C * C, r->prec, s))) return e;
+    if ((e = prx_pack_transpose_op(win, r->WinT, 3 * C, C, r->prec, s))) return e;
     if ((e = rcopy(r, &r->bin, bin, 3 * C, s))) return e;
     RALLOC_OP(r->Wc, (size_t)out_dim * C); RALLOC_OP(r->WcT, (size_t)out_dim * C);
-    if ((e = prx_pack_op(wc, r->Wc, (size_t)out_dim * C, r->f32, s))) return e;
-    if ((e = prx_pack_transpose_op(wc, r->WcT, out_dim, C, r->f32, s))) return e;
+    if ((e = prx_pack_op(wc, r->Wc, (size_t)out_dim * C, r->prec, s))) return e;
+    if ((e = prx_pack_transpose_op(wc, r->WcT, out_dim, C, r->prec, s))) return e;
     if ((e = rcopy(r, &r->bc, bc, out_dim, s))) return e;
     const size_t S2 = (size_t)(res / 2) * (res / 2), S4 = (size_t)(res / 4) * (res / 4);
     RALLOC_OP(r->s1, N * S2 * (width / 2)); RALLOC_OP(r->s2a, N * S2 * (width / 2)); RALLOC_OP(r->s3a, N * S2 * width);
@@ -483,7 +485,7 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     RLAUNCH(tokens_fwd_kernel, (size_t)n * C, x_f32, r->pos, r->tok, n, P, C);
     if ((e = lin(r, r->tok, n * T, C, r->Win, 3 * C, r->bin, nullptr, PRX_ACT_NONE, nullptr, nullptr, r->qkv, s))) return e;
     if (r->f32) { if ((e = prx_mha_fwd_f32((const float*)r->qkv, (float*)r->att, r->lse, n, T, C, r->heads, s))) return e; }
-    else if ((e = prx_mha_fwd_gen((const bf16_t*)r->qkv, (bf16_t*)r->att, r->lse, n, T, C, r->heads, s))) return e;
+    else if ((e = prx_mha_fwd_gen((const bf16_t*)r->qkv, (bf16_t*)r->att, r->lse, n, T, C, r->heads, s, r->h16))) return e;
     RLAUNCH(tok0_gather_kernel, (size_t)n * C, r->att, r->o0, n, T, C);
     if ((e = lin(r, r->o0, n, C, r->Wc, r->out_dim, r->bc, nullptr, PRX_ACT_NONE, nullptr, r->e, nullptr, s))) return e;
     return prx_l2norm_fwd(r->e, embeds, n, r->out_dim, s);
@@ -501,10 +503,11 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     // c_proj dgrad: A fp32 -> the register-staged GEMM converts on load
     {   GemmDesc d; d.A = r->de; d.a_is_f32 = 1; d.lda = r->out_dim; d.B = r->WcT; d.ldb = r->out_dim; d.M = n; d.N = C; d.K = r->out_dim;
         d.out_bf16 = r->do0; d.ldc_bf16 = C;
+        d.alpha = r->gscale;      // half mode: the whole backward runs scaled by a power of two; stem1_bwd unscales
         if ((e = rg(r, d, s))) return e; }
     RLAUNCH(tok0_scatter_kernel, (size_t)n * T * C, r->do0, r->dtok, n, T, C);
     if (r->f32) { if ((e = prx_mha_bwd_f32((const float*)r->qkv, (const float*)r->att, (const float*)r->dtok, r->lse, (float*)r->dqkv, n, T, C, r->heads, s))) return e; }
-    else if ((e = prx_mha_bwd_gen((const bf16_t*)r->qkv, (const bf16_t*)r->att, (const bf16_t*)r->dtok, r->lse, (bf16_t*)r->dqkv, n, T, C, r->heads, s))) return e;
+    else if ((e = prx_mha_bwd_gen((const bf16_t*)r->qkv, (const bf16_t*)r->att, (const bf16_t*)r->dtok, r->lse, (bf16_t*)r->dqkv, n, T, C, r->heads, s, r->h16))) return e;
     if ((e = lin(r, r->dqkv, n * T, 3 * C, r->WinT, C, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->dtokf, nullptr, s))) return e;
     float* g = r->gA; float* g2 = r->gB;
     RLAUNCH(tokens_bwd_kernel, (size_t)n * P * C, r->dtokf, g, n, P, C);
@@ -553,7 +556,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
     if ((e = conv3(r, r->tb1, n, S2, w, r->s3.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s2a, nullptr, r->tb2, s))) return e;
     if ((e = conv3(r, r->tb2, n, S2, wh, r->s2.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s1, nullptr, r->tb1, s))) return e;
-    STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S);
+    STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S, 1.f / r->gscale);
     return prx_preproc_bwd_reduce(cutouts, mm, r->dY, acc, n, S, s);
 }
 

@@ -4,9 +4,9 @@ struct PrxVit;
 struct GemmCtx;
 int prx_pack_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStream_t s);
-// weight packs at operand precision (f32: plain copy / fp32 transpose)
-int prx_pack_op(const float* in, void* out, size_t n, int f32, hipStream_t s);
-int prx_pack_transpose_op(const float* in, void* out, int R, int C, int f32, hipStream_t s);
+// weight packs at operand precision `prec` (PRX_PREC_*; f32: plain copy / fp32 transpose)
+int prx_pack_op(const float* in, void* out, size_t n, int prec, hipStream_t s);
+int prx_pack_transpose_op(const float* in, void* out, int R, int C, int prec, hipStream_t s);
 int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers, int heads, int out_dim, int max_n,
                         int precision, const float* const* w, int n_w, hipStream_t s);
 GemmCtx* prx_vit_gemm_ctx_impl(PrxVit* v);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < C && r < R) out[(size_t)c * R + r] = (TOp)tile[tx][ty + 8 * i];
+        if (c < C && r < R) out[(size_t)c * R + r] = op_cvt<TOp>(tile[tx][ty + 8 * i]);
     }
 }
 
@@ -50,15 +50,15 @@ __global__ __launch_bounds__(256) void add_cls_pos_kernel(float* __restrict__ x,
 
 }  // namespace
 
-int prx_pack_op(const float* in, void* out, size_t n, int f32, hipStream_t s) {
-    if (!f32) return prx_f32_to_bf16(in, (bf16_t*)out, n, s);
+int prx_pack_op(const float* in, void* out, size_t n, int prec, hipStream_t s) {
+    if (!prec_is_f32(prec)) return prx_f32_to_bf16(in, (bf16_t*)out, n, s, prec_is_h16(prec));
     PRX_CHECK_HIP(hipMemcpyAsync(out, in, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
-int prx_pack_transpose_op(const float* in, void* out, int R, int C, int f32, hipStream_t s) {
+int prx_pack_transpose_op(const float* in, void* out, int R, int C, int prec, hipStream_t s) {
     const dim3 grid(ceil_div(C, 32), ceil_div(R, 32));
-    if (f32) hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, R, C);
-    else     hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, R, C);
+    PRX_OP_DISPATCH(prec_is_f32(prec), prec_is_h16(prec), TO,
+                    hipLaunchKernelGGL(pack_transpose_kernel<TO>, grid, dim3(256), 0, s, in, (TO*)out, R, C));
     PRX_LAUNCH_CHECK();
     return 0;
 }
@@ -77,7 +77,9 @@ struct VitLayer {
 
 struct PrxVit {
     int res, patch, width, layers, heads, out_dim, T, max_n, KP;
-    int f32;          // PRX_PREC_*: element type of every operand buffer below (void*)
+    int prec;         // PRX_PREC_*: element type of every operand buffer below (void*)
+    int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
     GemmCtx gctx;     // this handle's engine state (tile overrides, timing log)
     std::vector<void*> allocs;
     void *Wp, *WpT, *projT, *proj;
@@ -117,22 +119,23 @@ int copy_f32(PrxVit* v, float** dst, const float* src, size_t n, hipStream_t s) 
 int pack_both(PrxVit* v, void** W, void** WT, const float* src, int out, int in, hipStream_t s) {
     ALLOC_OP(*W, (size_t)out * in);
     ALLOC_OP(*WT, (size_t)out * in);
-    int r = prx_pack_op(src, *W, (size_t)out * in, v->f32, s);
+    int r = prx_pack_op(src, *W, (size_t)out * in, v->prec, s);
     if (r) return r;
-    return prx_pack_transpose_op(src, *WT, out, in, v->f32, s);
+    return prx_pack_transpose_op(src, *WT, out, in, v->prec, s);
 }
 }  // namespace
 
 int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers, int heads, int out_dim, int max_n,
                         int precision, const float* const* w, int n_w, hipStream_t s) {
-    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vit_create: unknown precision %d", precision);
+    PRX_REQUIRE(prec_valid(precision), "vit_create: unknown precision %d", precision);
     PRX_REQUIRE(n_w == 5 + 12 * layers + 3, "vit_create: expected %d weight tensors, got %d", 5 + 12 * layers + 3, n_w);
     PRX_REQUIRE(res % patch == 0 && width == heads * 64 && width % 256 == 0, "vit_create: unsupported geometry");
     const int G = res / patch;
     const int T = G * G + 1;
     PrxVit* v = new PrxVit();
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
-    v->f32 = precision;
+    v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
+    v->gscale = v->h16 ? prx_default_grad_scale() : 1.f;
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -200,6 +203,7 @@ void prx_vit_destroy_impl(PrxVit* v) {
 
 static int vit_gemm(PrxVit* v, GemmDesc& d, hipStream_t s) {
     if (v->f32) { d.f32 = 1; d.a_is_f32 = 0; }
+    d.h16 = v->h16;
     return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
 }
 GemmCtx* prx_vit_gemm_ctx_impl(PrxVit* v) { return v ? &v->gctx : nullptr; }
@@ -208,14 +212,14 @@ GemmCtx* prx_vit_gemm_ctx_impl(PrxVit* v) { return v ? &v->gctx : nullptr; }
 static int ln_op(PrxVit* v, const float* x, long long ldx, const float* g, const float* b, void* out, float* mean, float* rstd,
                  int rows, hipStream_t s) {
     return prx_layernorm_fwd(x, ldx, g, b, v->f32 ? nullptr : (bf16_t*)out, v->f32 ? (float*)out : nullptr, mean, rstd, rows,
-                             v->width, 1e-5f, s);
+                             v->width, 1e-5f, s, v->h16);
 }
 // LayerNorm backward producing the fp32 gradient stream + its operand twin (the same buffer in the exact mode)
 static int ln_bwd_op(PrxVit* v, const float* g, long long ldg, const float* x, long long ldx, const float* gamma, const float* mean,
                      const float* rstd, const float* add, long long ldadd, float* dx, long long lddx, void* dx_op, int rows,
                      hipStream_t s) {
     return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, v->f32 ? nullptr : (bf16_t*)dx_op, lddx, rows,
-                             v->width, s);
+                             v->width, s, v->h16);
 }
 
 int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
@@ -228,7 +232,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
     const int W = v->width, T = v->T, R = n * T, KP = v->KP;
     int r;
     v->cur_n = n;
-    if ((r = prx_patchify_fwd(cutouts, mm, v->A0, v->f32, n, v->res, v->patch, T, s))) return r;
+    if ((r = prx_patchify_fwd(cutouts, mm, v->A0, v->prec, n, v->res, v->patch, T, s))) return r;
     {   // conv1 (patch embed) as GEMM
         GemmDesc d; d.A = v->A0; d.lda = KP; d.B = v->Wp; d.ldb = KP; d.M = R; d.N = W; d.K = KP;
         d.out_f32 = v->xpre; d.ldc_f32 = W;
@@ -247,8 +251,8 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
             if ((r = vit_gemm(v, d, s))) return r; }
         const void* att = v->att_o;
         if (v->f32) { if ((r = prx_mha_fwd_f32((const float*)y.qkv, (float*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
-        else if (T <= 64) { if ((r = prx_mha_fwd((const bf16_t*)y.qkv, (bf16_t*)v->att_o, n, T, W, v->heads, s))) return r; }
-        else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
+        else if (T <= 64) { if ((r = prx_mha_fwd((const bf16_t*)y.qkv, (bf16_t*)v->att_o, n, T, W, v->heads, s, v->h16))) return r; }
+        else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s, v->h16))) return r; att = y.o_save; }
         {   GemmDesc d; d.A = att; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
             d.bias_n = y.bo; d.resid = y.x_in; d.ldr = W; d.out_f32 = y.x_mid; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
@@ -280,6 +284,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     if ((r = prx_l2norm_bwd(v->e, d_embeds, v->de, n, v->out_dim, s))) return r;
     {   GemmDesc d; d.A = v->de; d.a_is_f32 = 1; d.lda = v->out_dim; d.B = v->proj; d.ldb = v->out_dim;
         d.M = n; d.N = W; d.K = v->out_dim; d.out_f32 = v->dhpost; d.ldc_f32 = W;
+        d.alpha = v->gscale;      // half mode: everything below runs scaled by a power of two (exact: the backward is linear in g)
         if ((r = vit_gemm(v, d, s))) return r; }
     // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
     PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
@@ -301,8 +306,8 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
             d.out_bf16 = v->do_; d.ldc_bf16 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
         if (v->f32) { if ((r = prx_mha_bwd_f32((const float*)y.qkv, (const float*)y.o_save, (const float*)v->do_, y.lse, (float*)v->dqkv, n, T, W, v->heads, s))) return r; }
-        else if (T <= 64) { if ((r = prx_mha_bwd((const bf16_t*)y.qkv, (const bf16_t*)v->do_, (bf16_t*)v->dqkv, n, T, W, v->heads, s))) return r; }
-        else { if ((r = prx_mha_bwd_gen((const bf16_t*)y.qkv, (const bf16_t*)y.o_save, (const bf16_t*)v->do_, y.lse, (bf16_t*)v->dqkv, n, T, W, v->heads, s))) return r; }
+        else if (T <= 64) { if ((r = prx_mha_bwd((const bf16_t*)y.qkv, (const bf16_t*)v->do_, (bf16_t*)v->dqkv, n, T, W, v->heads, s, v->h16))) return r; }
+        else { if ((r = prx_mha_bwd_gen((const bf16_t*)y.qkv, (const bf16_t*)y.o_save, (const bf16_t*)v->do_, y.lse, (bf16_t*)v->dqkv, n, T, W, v->heads, s, v->h16))) return r; }
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
@@ -312,6 +317,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     if ((r = ln_bwd_op(v, v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s))) return r;
     {   GemmDesc d; d.A = v->dh_bf; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
         d.out_f32 = v->dA0; d.ldc_f32 = KP;
+        d.alpha = 1.f / v->gscale;      // ... and is unscaled here, before the (rank-summed) renormalisation sums
         if ((r = vit_gemm(v, d, s))) return r; }
     return prx_patchify_bwd_reduce(cutouts, mm, v->dA0, acc, n, v->res, v->patch, T, s);
 }

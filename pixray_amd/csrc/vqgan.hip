@@ -32,14 +32,14 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
             int ci = (int)(i % Cin);
             int tap = (int)((i / Cin) % 9);
             int co = (int)(i / ((size_t)9 * Cin));
-            Wf[i] = (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+            Wf[i] = op_cvt<TOp>(w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3]);
         } else {
             size_t j = i - total_f;
             int co = (int)(j % CoP);
             int tap = (int)((j / CoP) % 9);
             int ci = (int)(j / ((size_t)9 * CoP));
             int ky = 2 - tap / 3, kx = 2 - tap % 3;
-            Wd[j] = (co < Cout) ? (TOp)w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : (TOp)0.f;
+            Wd[j] = op_cvt<TOp>((co < Cout) ? w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx] : 0.f);
         }
     }
 }
@@ -79,7 +79,9 @@ struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
 
 struct PrxVqgan {
     int zc, D, NC, ch, out_ch, h0, w0, H, W, nstage;
-    int f32;          // PRX_PREC_*
+    int prec;         // PRX_PREC_*
+    int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *codebook, *cnorm, *zmin, *zmax;
@@ -139,8 +141,8 @@ int make_conv3(PrxVqgan* v, Conv3& c, int Cin, int Cout, WCursor& cur, hipStream
     c.Cin = Cin; c.Cout = Cout; c.CoP = (Cout + 7) / 8 * 8;
     VALLOC_OP(c.Wf, (size_t)Cout * 9 * Cin);
     VALLOC_OP(c.Wd, (size_t)Cin * 9 * c.CoP);
-    if (v->f32) hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(1024), dim3(256), 0, s, w, (float*)c.Wf, (float*)c.Wd, Cout, Cin, c.CoP);
-    else        hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(1024), dim3(256), 0, s, w, (bf16_t*)c.Wf, (bf16_t*)c.Wd, Cout, Cin, c.CoP);
+    PRX_OP_DISPATCH(v->f32, v->h16, TO,
+                    hipLaunchKernelGGL(pack_conv3x3_kernel<TO>, dim3(1024), dim3(256), 0, s, w, (TO*)c.Wf, (TO*)c.Wd, Cout, Cin, c.CoP));
     PRX_LAUNCH_CHECK();
     return copyf(v, &c.b, b, Cout, s);
 }
@@ -149,8 +151,8 @@ int make_conv1(PrxVqgan* v, Conv1& c, int Cin, int Cout, WCursor& cur, hipStream
     c.Cin = Cin; c.Cout = Cout;
     VALLOC_OP(c.W, (size_t)Cout * Cin); VALLOC_OP(c.WT, (size_t)Cout * Cin);
     int r;
-    if ((r = prx_pack_op(w, c.W, (size_t)Cout * Cin, v->f32, s))) return r;
-    if ((r = prx_pack_transpose_op(w, c.WT, Cout, Cin, v->f32, s))) return r;
+    if ((r = prx_pack_op(w, c.W, (size_t)Cout * Cin, v->prec, s))) return r;
+    if ((r = prx_pack_transpose_op(w, c.WT, Cout, Cin, v->prec, s))) return r;
     return copyf(v, &c.b, b, Cout, s);
 }
 int make_res(PrxVqgan* v, int Cin, int Cout, int rh, int rw, WCursor& cur, hipStream_t s) {
@@ -188,8 +190,8 @@ int make_attn(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
     }
     ab.qkv.Cin = C; ab.qkv.Cout = 3 * C; ab.qkv.b = bcat;
     VALLOC_OP(ab.qkv.W, (size_t)3 * C * C); VALLOC_OP(ab.qkv.WT, (size_t)3 * C * C);
-    if ((r = prx_pack_op(wcat, ab.qkv.W, (size_t)3 * C * C, v->f32, s))) return r;
-    if ((r = prx_pack_transpose_op(wcat, ab.qkv.WT, 3 * C, C, v->f32, s))) return r;
+    if ((r = prx_pack_op(wcat, ab.qkv.W, (size_t)3 * C * C, v->prec, s))) return r;
+    if ((r = prx_pack_transpose_op(wcat, ab.qkv.WT, 3 * C, C, v->prec, s))) return r;
     if ((r = make_conv1(v, ab.proj, C, C, cur, s))) return r;
     const size_t P = (size_t)rh * rw;
     const size_t P8 = (size_t)pad8((int)P);
@@ -216,11 +218,12 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
                           int resolution, int z_channels, int embed_dim, int n_embed, int out_ch, int h0, int w0,
                           int precision, const float* const* w, int n_w, hipStream_t s) {
     PRX_REQUIRE(h0 >= 1 && w0 >= 1, "vqgan_create: bad latent size %dx%d", h0, w0);
-    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vqgan_create: unknown precision %d", precision);
+    PRX_REQUIRE(prec_valid(precision), "vqgan_create: unknown precision %d", precision);
     PRX_REQUIRE(embed_dim == z_channels, "vqgan_create: embed_dim must equal z_channels");
     PrxVqgan* v = new PrxVqgan();
     std::unique_ptr<PrxVqgan> guard(v);
-    v->f32 = precision;
+    v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
+    v->gscale = v->h16 ? prx_default_grad_scale() : 1.f;
     v->n_gn = 0; v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
     WCursor cur{w, n_w, 0};
     int r;
@@ -327,6 +330,7 @@ static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) {
         d.f32 = 1; d.a_is_f32 = 0;
         if (d.out_bf16 == (void*)d.out_f32) d.out_bf16 = nullptr;   // the "twin" is the fp32 output itself
     }
+    d.h16 = v->h16;
     return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
 }
 GemmCtx* prx_vqgan_gemm_ctx_impl(PrxVqgan* v) { return v ? &v->gctx : nullptr; }
@@ -367,12 +371,12 @@ static const GN* first_norm(const PrxVqgan* v, int si) {
 }
 static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s, bool stats_ready = false) {
     return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->f32 ? nullptr : (bf16_t*)v->a, v->f32 ? (float*)v->a : nullptr, 1, P, g.C, swish,
-                             1e-6f, s, /*zero_stats=*/0, stats_ready ? 1 : 0);
+                             1e-6f, s, /*zero_stats=*/0, stats_ready ? 1 : 0, v->h16);
 }
 static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
                   void* dx_bf, int P, int swish, hipStream_t s, bool stats_ready = false) {
     return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, v->f32 ? nullptr : (bf16_t*)dx_bf, 1, P, g.C, swish, 1e-6f, s,
-                             /*zero_stats=*/0, stats_ready && fusable(v, g.C) ? 1 : 0);
+                             /*zero_stats=*/0, stats_ready && fusable(v, g.C) ? 1 : 0, v->h16);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -436,7 +440,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = op_off(b.qkvb, C, v->f32); d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;
                 if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, v->f32, s))) return r;
+            if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, v->prec, s))) return r;
             {   GemmDesc d; d.A = b.Pm; d.lda = P8; d.B = v->tA; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->tB; d.ldc_bf16 = C;
                 if ((r = vg(v, d, s))) return r; }
@@ -490,7 +494,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
     PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
     if ((r = prx_image_head_bwd(v->y, 4, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
-                                v->out_ch, PH, s))) return r;
+                                v->out_ch, PH, s, v->h16, v->gscale))) return r;      // half mode: the whole backward runs scaled
     struct GB { float* f; void* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
     if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
@@ -526,7 +530,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             const int P8 = pad8(P);
             if ((r = zero_if_padded(v, v->tB, P, P, s))) return r;
             if ((r = zero_if_padded(v, v->tC, P, P, s))) return r;
-            if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, v->f32, s))) return r;  // tB = dS, tC = dS^T
+            if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, v->prec, s))) return r;  // tB = dS, tC = dS^T
             if ((r = zero_if_padded(v, v->tD, C, P, s))) return r;
             if ((r = prx_transpose_op(op_off(b.qkvb, C, v->f32), 3 * C, v->tD, P8, P, C, v->f32, s))) return r;       // tD = k^T [C, P8]
             {   GemmDesc d; d.A = v->tB; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
@@ -549,7 +553,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
         } else {
             UpBlock& b = v->ups[st.idx];
             if ((r = conv3_bwd(v, b.c, g.b, false, b.rh, b.rw, t1.f, s))) return r;       // d up(x) at high res
-            if ((r = prx_upsample2x_bwd(t1.f, t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s))) return r;
+            if ((r = prx_upsample2x_bwd(t1.f, t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s, v->h16))) return r;
             std::swap(g, t2);
         }
     }
@@ -558,6 +562,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     const int P0 = v->h0 * v->w0;
     {   GemmDesc d; d.A = v->dpq_bf; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
         d.out_f32 = t2.f; d.ldc_f32 = v->D;
+        d.alpha = 1.f / v->gscale;         // unscale (exact: power of two)
         if ((r = vg(v, d, s))) return r; }
     return prx_nhwc_to_nchw(t2.f, v->D, dz, 1, v->D, P0, s);
 }

@@ -86,10 +86,10 @@ def make_cutouts(img, desc, noise, S, base_hw=None, spot_mask=None):
 # --------------------------------------------------------------------------------------- CLIP ViT
 class ClipVitHandle:
     """Owns a `prx_clip_vit` (packed weights + activation workspace for `max_batch` cutouts).
-    `precision`: "bf16" (fast path) or "f32" (exact-f32 MFMA parity mode, include/prx.h PRX_PREC_*)."""
+    `precision`: "fp16" (default) / "bf16" (fast paths) or "f32" (exact-f32 MFMA parity mode, include/prx.h PRX_PREC_*)."""
     abi = "prx_clip_vit"
 
-    def __init__(self, cfg, params, max_batch: int, device, precision="bf16"):
+    def __init__(self, cfg, params, max_batch: int, device, precision=None):
         from .weights import clip_vit_param_shapes
         names = list(clip_vit_param_shapes(cfg).keys())
         ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
@@ -133,7 +133,7 @@ class ClipResNetHandle:
     the OpenAI `visual.*` state dict (BatchNorm un-folded); the fold happens here."""
     abi = "prx_clip_resnet"
 
-    def __init__(self, cfg, params, max_batch: int, device, precision="bf16"):
+    def __init__(self, cfg, params, max_batch: int, device, precision=None):
         from .weights import fold_clip_resnet_params
         folded = fold_clip_resnet_params(cfg, params)
         ws = [t.to(device=device, dtype=torch.float32).contiguous() for t in folded.values()]
@@ -288,9 +288,9 @@ def clip_encode_text_tokens(tokens, handle: ClipTextHandle):
 
 # --------------------------------------------------------------------------------------- VQGAN
 class VqganHandle:
-    """Owns a `prx_vqgan` (codebook, weight packs, activations of one forward).  `precision`: "bf16" | "f32"."""
+    """Owns a `prx_vqgan` (codebook, weight packs, activations of one forward).  `precision`: "fp16" (default) | "bf16" | "f32"."""
 
-    def __init__(self, cfg, params, latent_hw, device, precision="bf16"):
+    def __init__(self, cfg, params, latent_hw, device, precision=None):
         from .weights import vqgan_param_shapes
         names = list(vqgan_param_shapes(cfg).keys())
         ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
@@ -495,8 +495,10 @@ class Vgg16Handle:
     """Owns a `prx_vgg16` (torchvision VGG16 `features` up to relu5_3, frozen) for inputs up to `max_hw`.
     `params`: {"features.N.weight", "features.N.bias"} (torchvision state-dict names)."""
 
-    def __init__(self, params, max_hw, device, precision="bf16"):
+    def __init__(self, params, max_hw, device, precision=None):
         self.precision = precision_code(precision)
+        if self.precision == 2:        # PRX_PREC_F16: the extractor has no half instantiation (include/prx.h) -- bf16 operands
+            self.precision = 0
         ws = []
         for i in VGG16_CONV_INDICES:
             ws.append(params[f"features.{i}.weight"].to(device=device, dtype=torch.float32).contiguous())

@@ -11,7 +11,7 @@ from .weights import (CLIP_CONFIGS, CLIP_RESNET_CONFIGS, CLIP_TEXT_CONFIGS, Clip
 
 class ClipVitPerceptor:
     def __init__(self, cfg: ClipVitConfig, params, device, max_batch: int = 64, group=None, text_cfg: ClipTextConfig = None,
-                 text_params=None, tokenizer=None, seed: int = 0, precision="bf16"):
+                 text_params=None, tokenizer=None, seed: int = 0, precision=None):
         self.cfg = cfg
         self.text_cfg = text_cfg
         self.text_params = text_params      # OpenAI state-dict entries of the text side (token_embedding.weight, ...)
@@ -76,10 +76,10 @@ class ClipVitPerceptor:
 
 
 def get_clip_perceptor(clip_model_name, device, params=None, max_batch=64, seed=0, group=None, text_params=None,
-                       tokenizer=None, precision="bf16"):
+                       tokenizer=None, precision=None):
     """slip.py:173-186 equivalent for the ViT family; `params` is an OpenAI `visual.*` state dict and `text_params` the
     text-side entries of the same checkpoint (random-init weights of the real architectures are synthesised when none
-    are given: no checkpoints exist offline).  `precision`: "bf16" (fast path) | "f32" (exact-f32 MFMA parity mode)."""
+    are given: no checkpoints exist offline).  `precision`: "fp16" (default) | "bf16" (fast paths) | "f32" (exact-f32 MFMA parity mode)."""
     if clip_model_name in CLIP_RESNET_CONFIGS:
         cfg = CLIP_RESNET_CONFIGS[clip_model_name]
         if params is None:

@@ -58,9 +58,9 @@ class Vgg16Extractor:
     """`Vgg16_Extractor` (StyleLoss.py:24-81): returns [input, relu1_1, relu1_2, relu2_1, relu2_2, relu3_1, relu3_2, relu3_3,
     relu4_3, relu5_3] as channels-last maps [1,h,w,C]."""
 
-    def __init__(self, space: str = "uniform", params=None, device=None, max_hw=(64, 64), precision="bf16"):
+    def __init__(self, space: str = "uniform", params=None, device=None, max_hw=(64, 64), precision=None):
         self.space = space
-        self.precision = precision      # "bf16" | "f32" (exact-f32 MFMA parity mode)
+        self.precision = precision      # None / "fp16" / "bf16" -> bf16 extractor | "f32" (exact-f32 MFMA parity mode)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         if params is None:
             path = os.environ.get("PIXRAY_VGG16_CKPT")

@@ -31,7 +31,7 @@ class VqganDrawer(DrawingInterface):
         self.size = tuple(getattr(settings, "size", (256, 256)))          # (width, height) as in the reference
         self.state_dict = getattr(settings, "vqgan_state_dict", None)     # taming state dict, if the caller has one
         self.weight_seed = getattr(settings, "weight_seed", 0)
-        self.precision = getattr(settings, "precision", "bf16")           # "bf16" | "f32" (exact-f32 MFMA parity mode)
+        self.precision = getattr(settings, "precision", None)             # None = "fp16" | "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.z = None
         self.gumbel = False          # set by load_taming for GumbelVQ checkpoints (vqgan.py:149-153)
         self._fused_clamp = False
