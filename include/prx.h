@@ -66,9 +66,9 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
  *                  the arithmetic the reference's CLIP towers run in on a GPU -- `clip.load` keeps fp16 weights and
  *                  activations with fp32 LayerNorm (slip.py:175) -- with 11 significand bits instead
  *                  of bf16's 8.  Conversions saturate at +-65504, and every runner backward runs under a power-of-two
- *                  gradient scale (2^PRX_GRAD_SCALE_LOG2, default 2^14; exact, because each backward op is linear in the
- *                  incoming gradient and ClampWithGrad / ReLU masks only read signs) that is removed before anything
- *                  leaves the handle.  The VQGAN encoder, the CLIP text tower and the VGG16 extractor stay bf16 / fp32. */
+ *                  gradient scale S chosen ON THE DEVICE from the gradient entering it (S * max|g| in [8, 16); no host
+ *                  synchronisation; exact, because each backward op is linear in the incoming gradient and ClampWithGrad /
+ *                  ReLU masks only read signs) that is removed before anything leaves the handle.  The VQGAN encoder, the CLIP text tower and the VGG16 extractor stay bf16 / fp32. */
 #define PRX_PREC_BF16 0
 #define PRX_PREC_F32 1
 #define PRX_PREC_F16 2

@@ -119,7 +119,7 @@ def _metrics(a: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
     return rel, cos
 
 
-def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2, precision="bf16"):
+def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2, precision=None):
     from pixray_amd import api
     return api.build_vqgan_clip_session(size=size, vqgan_model=vqgan_model, clip_model=clip_model, num_cuts=cutn,
                                         seed=seed, device=device, learning_rate=lr, precision=precision)
@@ -150,9 +150,9 @@ def _draws(cutn, S, seed, iteration, with_noise=True, aspect=1.0):
 
 
 def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                          device="cuda:0", precision="bf16", jitter=True) -> Dict[str, float]:
+                          device="cuda:0", precision=None, jitter=True) -> Dict[str, float]:
     """dL/dz (and the intermediate image / embeddings / loss) of the HIP path vs the oracle after ONE iteration.
-    `precision`: "bf16" (the fast path) or "f32" (the exact-f32 MFMA parity mode); `jitter=False` draws the same
+    `precision`: None / "fp16" (the product default), "bf16", or "f32" (the exact-f32 MFMA parity mode); `jitter=False` draws the same
     augmentations with the ColorJitter switched off."""
     global JITTER
     if not jitter:
@@ -187,12 +187,12 @@ def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
 
 
 def compare_precisions(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                       device="cuda:0") -> Dict[str, float]:
-    """The bf16 fast path against the exact-f32 MFMA mode ON THE DEVICE, same weights / z / augmentation draws / noise:
-    what the bf16 operand rounding alone costs (no oracle involved; both sides are the product's kernels)."""
+                       device="cuda:0", fast="bf16") -> Dict[str, float]:
+    """A fast path (`fast`: "fp16" | "bf16") against the exact-f32 MFMA mode ON THE DEVICE, same weights / z / augmentation
+    draws / noise: what the 16-bit operand rounding alone costs (no oracle involved; both sides are the product's kernels)."""
     out = {}
     res = {}
-    for prec in ("f32", "bf16"):
+    for prec in ("f32", fast):
         sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, precision=prec)
         S = next(iter(sess.cutoutsTable))
         sess.cutoutsTable[S].fixed_params = _draws(cutn, S, seed, 0, aspect=size[0] / size[1])
@@ -202,16 +202,16 @@ def compare_precisions(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", 
                          img=sess.drawer.synth(0).detach().cpu(), loss=float(loss.detach()),
                          idx=sess.drawer.handle.last_indices.cpu().long())
         del sess
-    out["dz_rel_l2"], out["dz_cosine"] = _metrics(res["bf16"]["dz"], res["f32"]["dz"])
-    out["embeds_rel_l2"], _ = _metrics(res["bf16"]["emb"], res["f32"]["emb"])
-    out["image_rel_l2"], _ = _metrics(res["bf16"]["img"], res["f32"]["img"])
-    out["loss_abs_err"] = abs(res["bf16"]["loss"] - res["f32"]["loss"])
-    out["indices_equal"] = bool(torch.equal(res["bf16"]["idx"], res["f32"]["idx"]))
+    out["dz_rel_l2"], out["dz_cosine"] = _metrics(res[fast]["dz"], res["f32"]["dz"])
+    out["embeds_rel_l2"], _ = _metrics(res[fast]["emb"], res["f32"]["emb"])
+    out["image_rel_l2"], _ = _metrics(res[fast]["img"], res["f32"]["img"])
+    out["loss_abs_err"] = abs(res[fast]["loss"] - res["f32"]["loss"])
+    out["indices_equal"] = bool(torch.equal(res[fast]["idx"], res["f32"]["idx"]))
     return out
 
 
 def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32", size=(256, 256), cutn=64, seed=0,
-                    device="cuda:0", lr=0.2, precision="bf16") -> Dict[str, float]:
+                    device="cuda:0", lr=0.2, precision=None) -> Dict[str, float]:
     """k optimiser steps (train(): synth .. Adam .. clip_z) of the HIP path vs the oracle.
 
     The loop is chaotic in the dynamical-systems sense: Adam with lr 0.2 moves every component of z by ~0.2 per step

@@ -21,13 +21,11 @@ int prx_xcd_local() {
     return v;
 }
 
-float prx_default_grad_scale() {
-    static const float v = [] {
-        const char* e = getenv("PRX_GRAD_SCALE_LOG2");
-        int k = e ? atoi(e) : 14;
-        if (k < 0) k = 0;
-        if (k > 30) k = 30;
-        return (float)(1u << k);
+int prx_grad_target_log2() {
+    static const int v = [] {
+        const char* e = getenv("PRX_GRAD_TARGET_LOG2");
+        int k = e ? atoi(e) : 4;
+        return k < -8 ? -8 : (k > 14 ? 14 : k);
     }();
     return v;
 }

@@ -175,9 +175,11 @@ __device__ __forceinline__ unsigned xcd_linear(unsigned bid, unsigned nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 int prx_xcd_local();      // process-wide constant read once from the environment (api_core.hip)
-// Power-of-two scale the runner backwards of the half (PRX_PREC_F16) mode run under: 2^PRX_GRAD_SCALE_LOG2, default 2^14
-// (unscaled gradient entries from 4e-9 up to 4 keep full half precision; api_core.hip).
-float prx_default_grad_scale();
+// The runner backwards of the half (PRX_PREC_F16) mode run under a power-of-two scale S chosen on the device per backward
+// (elementwise.h prx_grad_scale) such that S * max|incoming gradient| lies in [2^(T-1), 2^T); T = PRX_GRAD_TARGET_LOG2,
+// default 4: 2^12 of headroom below the half maximum for growth inside the backward, full half precision down to
+// entries 2^-18 of the largest one, subnormal tails below that (api_core.hip).
+int prx_grad_target_log2();
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -11,9 +11,14 @@ int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, in
 int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s, int h16 = 0);
 int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);
 int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s);
-// gscale: multiplies the outgoing gradient (the runner's power-of-two gradient scale in the half mode; sign tests unaffected)
+// gscale (device scalar or null): multiplies the outgoing gradient -- the runner's power-of-two gradient scale in the half
+// mode; the ClampWithGrad sign test is unaffected
 int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
-                       int HW, hipStream_t s, int h16 = 0, float gscale = 1.f);
+                       int HW, hipStream_t s, int h16 = 0, const float* gscale = nullptr);
+// Power-of-two gradient scale of the half (PRX_PREC_F16) mode, chosen on the device from the gradient that enters a runner's
+// backward: scale2 = {S, 1/S} with S * max|g| in [2^(T-1), 2^T), T = target_log2 (S = 1 for all-zero / non-finite g).
+// part: nparts floats of scratch.  Two tiny launches, no host synchronisation.
+int prx_grad_scale(const float* g, size_t n, float* part, int nparts, int target_log2, float* scale2, hipStream_t s);
 int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
                    size_t n, float lr, float b1, float b2, float eps, int step, hipStream_t s);
 int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void image_head_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void image_head_bwd_kernel(const float* __restrict__ x, int ldc,
                                                              const float* __restrict__ gimg, float* __restrict__ dx,
                                                              bf16_t* __restrict__ dx_bf16, int ldo, int NB, int C,
-                                                             int HW, int h16, float gscale) {
+                                                             int HW, int h16, const float* __restrict__ gscale_dev) {
+    const float gscale = gscale_dev ? *gscale_dev : 1.f;
     const size_t total = (size_t)NB * HW * ldo;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -200,6 +201,39 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
                                                           size_t n, int h16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = to_op16(in[i], h16);
+}
+
+// ---- power-of-two gradient scale of the half (PRX_PREC_F16) mode: scale2 = {S, 1/S} with S * max|g| in [2^(T-1), 2^T) --------
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(g[i]));
+    m = wave_max(m);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+__global__ __launch_bounds__(256) void grad_scale_final_kernel(const float* __restrict__ part, int nparts, int target_log2,
+                                                               float* __restrict__ scale2) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        float S = 1.f;
+        if (m > 0.f && m < INFINITY) {            // NaN / inf / all-zero gradients: leave them unscaled
+            int e;
+            (void)frexpf(m, &e);                   // m = f * 2^e, f in [0.5, 1)
+            int k = target_log2 - e;
+            k = k < -40 ? -40 : (k > 60 ? 60 : k);
+            S = ldexpf(1.f, k);
+        }
+        scale2[0] = S;
+        scale2[1] = 1.f / S;                       // exact: a power of two
+    }
 }
 
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -259,8 +293,17 @@ int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int H
     PRX_LAUNCH_CHECK();
     return 0;
 }
+int prx_grad_scale(const float* g, size_t n, float* part, int nparts, int target_log2, float* scale2, hipStream_t s) {
+    PRX_REQUIRE(nparts >= 1 && nparts <= 1024, "grad_scale: 1..1024 partials");
+    const int blocks = (int)std::min<size_t>((n + 1023) / 1024 + 1, (size_t)nparts);
+    hipLaunchKernelGGL(amax_partial_kernel, dim3(blocks), dim3(256), 0, s, g, n, part);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(256), 0, s, part, blocks, target_log2, scale2);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
 int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
-                       int HW, hipStream_t s, int h16, float gscale) {
+                       int HW, hipStream_t s, int h16, const float* gscale) {
     hipLaunchKernelGGL(image_head_bwd_kernel, dim3(ew_grid((size_t)NB * HW * ldo)), dim3(256), 0, s, x, ldc, gimg, dx,
                        dx_bf16, ldo, NB, C, HW, h16, gscale);
     PRX_LAUNCH_CHECK();

@@ -34,6 +34,7 @@ struct GemmDesc {
     int H = 0, W = 0, Cin = 0, up = 0;
     // epilogue:  v = alpha*acc + bias_n[n] + bias_m[m];  v *= dquickgelu(aux) ; v += resid
     float alpha = 1.f;
+    const float* alpha_dev = nullptr;   // optional device scalar multiplied into alpha (the half mode's gradient scale, common.h)
     const float* bias_n = nullptr;
     const float* bias_m = nullptr;
     const void* aux = nullptr; int ldaux = 0;   // operand precision
@@ -72,6 +73,7 @@ struct GemmCtx {
     int conv_c64 = 1;                 // scalar-tap conv gather when Cin % 64 == 0
     int wide_tile = 128;
     int big_tile = 0;            // > 0: use the 8-wave 256 x 128 tile when it gives >= big_tile * 256 tiles (PRX_BIG_TILE)
+    int tile8p = 0;              // > 0: 256 x 256 tiles on the 8-phase kernel (gemm8p.hip) when there are >= tile8p of them (PRX_GEMM_8P)
     std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic
     bool prof_on = false;
     std::vector<GemmProfRec> prof;

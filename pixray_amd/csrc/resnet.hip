@@ -9,6 +9,7 @@
 #include "resnet.h"
 #include "gemm.h"
 #include "attention.h"
+#include "elementwise.h"
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "vit.h"  // prx_pack_* helpers
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
 // (which took 7.4 ms for RN50x4 at 128 cutouts: 2-byte loads of 40 values per tap, three threads per pixel re-reading them).
 template <typename TOp, int CO>
 __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__ g_, const float* __restrict__ w, float* __restrict__ dY,
-                                                        int N, int S, float oscale) {
+                                                        int N, int S, const float* __restrict__ oscale_dev) {
+    const float oscale = oscale_dev ? *oscale_dev : 1.f;
     __shared__ float ws[27 * CO];
     for (int i = threadIdx.x; i < 27 * CO; i += 256) {
         const int co = i % CO, c = (i / CO) % 3, kx = (i / (3 * CO)) % 3, ky = i / (9 * CO);
@@ -261,7 +263,7 @@ struct PrxResNet {
     int res, width, heads, out_dim, max_n, C, G, T, cur_n;
     int prec;         // PRX_PREC_*
     int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
-    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
+    float* gs;        // half mode: device {S, 1/S} = the power-of-two scale of the backward in flight (common.h) + 64 partials; else null
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *w1, *b1;                      // stem conv1 (fp32, BN folded)
@@ -374,7 +376,7 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     PrxResNet* r = new PrxResNet();
     std::unique_ptr<PrxResNet> guard(r);
     r->prec = precision; r->f32 = prec_is_f32(precision); r->h16 = prec_is_h16(precision);
-    r->gscale = r->h16 ? prx_default_grad_scale() : 1.f;
+    r->gs = nullptr;
     r->res = res; r->width = width; r->heads = heads; r->out_dim = out_dim; r->max_n = max_n; r->cur_n = 0;
     r->C = width * 32; r->G = res / 32; r->T = r->G * r->G + 1;
     RCur cur{w, n_w, 0};
@@ -430,6 +432,7 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     RALLOC(r->gA, maxMC); RALLOC(r->gB, maxMC); RALLOC(r->tf, maxMC);
     RALLOC_OP(r->tb1, maxMC); RALLOC_OP(r->tb2, maxMC); RALLOC_OP(r->gbf, maxMC);
     RALLOC(r->dY, N * 3 * (size_t)res * res); RALLOC(r->mm_part, 2 * 1024);
+    if (r->h16) RALLOC(r->gs, 2 + 64);
     r->ws_bytes = (size_t)64 << 20;
     RALLOC(r->ws, r->ws_bytes / sizeof(float));
     *out = guard.release();
@@ -503,7 +506,8 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     // c_proj dgrad: A fp32 -> the register-staged GEMM converts on load
     {   GemmDesc d; d.A = r->de; d.a_is_f32 = 1; d.lda = r->out_dim; d.B = r->WcT; d.ldb = r->out_dim; d.M = n; d.N = C; d.K = r->out_dim;
         d.out_bf16 = r->do0; d.ldc_bf16 = C;
-        d.alpha = r->gscale;      // half mode: the whole backward runs scaled by a power of two; stem1_bwd unscales
+        // half mode: the whole backward runs scaled by a power of two S chosen from max|d e|; stem1_bwd unscales
+        if (r->h16) { if ((e = prx_grad_scale(r->de, (size_t)n * r->out_dim, r->gs + 2, 64, prx_grad_target_log2(), r->gs, s))) return e; d.alpha_dev = r->gs; }
         if ((e = rg(r, d, s))) return e; }
     RLAUNCH(tok0_scatter_kernel, (size_t)n * T * C, r->do0, r->dtok, n, T, C);
     if (r->f32) { if ((e = prx_mha_bwd_f32((const float*)r->qkv, (const float*)r->att, (const float*)r->dtok, r->lse, (float*)r->dqkv, n, T, C, r->heads, s))) return e; }
@@ -556,7 +560,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
     if ((e = conv3(r, r->tb1, n, S2, w, r->s3.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s2a, nullptr, r->tb2, s))) return e;
     if ((e = conv3(r, r->tb2, n, S2, wh, r->s2.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s1, nullptr, r->tb1, s))) return e;
-    STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S, 1.f / r->gscale);
+    STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S, (const float*)(r->h16 ? r->gs + 1 : nullptr));
     return prx_preproc_bwd_reduce(cutouts, mm, r->dY, acc, n, S, s);
 }
 

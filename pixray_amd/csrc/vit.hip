@@ -79,7 +79,7 @@ struct PrxVit {
     int res, patch, width, layers, heads, out_dim, T, max_n, KP;
     int prec;         // PRX_PREC_*: element type of every operand buffer below (void*)
     int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
-    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
+    float* gs;        // half mode: device {S, 1/S} = the power-of-two scale of the backward in flight (common.h) + 64 partials; else null
     GemmCtx gctx;     // this handle's engine state (tile overrides, timing log)
     std::vector<void*> allocs;
     void *Wp, *WpT, *projT, *proj;
@@ -135,7 +135,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     PrxVit* v = new PrxVit();
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
-    v->gscale = v->h16 ? prx_default_grad_scale() : 1.f;
+    v->gs = nullptr;
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -189,6 +189,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     if (v->f32) { v->dx_bf = v->dx; v->dh_bf = v->dh; }
     else { ALLOC_OP(v->dx_bf, R * W); ALLOC_OP(v->dh_bf, R * W); }
     ALLOC(v->dhpost, (size_t)max_n * W); ALLOC(v->mm_part, 2 * 1024);
+    if (v->h16) ALLOC(v->gs, 2 + 64);
     v->ws_bytes = (size_t)64 << 20;
     ALLOC(v->ws, v->ws_bytes / sizeof(float));
     *out = v;
@@ -284,7 +285,8 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     if ((r = prx_l2norm_bwd(v->e, d_embeds, v->de, n, v->out_dim, s))) return r;
     {   GemmDesc d; d.A = v->de; d.a_is_f32 = 1; d.lda = v->out_dim; d.B = v->proj; d.ldb = v->out_dim;
         d.M = n; d.N = W; d.K = v->out_dim; d.out_f32 = v->dhpost; d.ldc_f32 = W;
-        d.alpha = v->gscale;      // half mode: everything below runs scaled by a power of two (exact: the backward is linear in g)
+        // half mode: everything below runs scaled by a power of two S chosen from max|d e| (exact: the backward is linear in g)
+        if (v->h16) { if ((r = prx_grad_scale(v->de, (size_t)n * v->out_dim, v->gs + 2, 64, prx_grad_target_log2(), v->gs, s))) return r; d.alpha_dev = v->gs; }
         if ((r = vit_gemm(v, d, s))) return r; }
     // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
     PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
@@ -317,7 +319,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     if ((r = ln_bwd_op(v, v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s))) return r;
     {   GemmDesc d; d.A = v->dh_bf; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
         d.out_f32 = v->dA0; d.ldc_f32 = KP;
-        d.alpha = 1.f / v->gscale;      // ... and is unscaled here, before the (rank-summed) renormalisation sums
+        if (v->h16) d.alpha_dev = v->gs + 1;      // ... and is unscaled (1/S) here, before the (rank-summed) renormalisation sums
         if ((r = vit_gemm(v, d, s))) return r; }
     return prx_patchify_bwd_reduce(cutouts, mm, v->dA0, acc, n, v->res, v->patch, T, s);
 }

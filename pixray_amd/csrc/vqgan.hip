@@ -81,7 +81,7 @@ struct PrxVqgan {
     int zc, D, NC, ch, out_ch, h0, w0, H, W, nstage;
     int prec;         // PRX_PREC_*
     int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
-    float gscale;     // half mode: power-of-two scale the backward runs under (common.h), 1 otherwise
+    float* gs;        // half mode: device {S, 1/S} = the power-of-two scale of the backward in flight (common.h) + 256 partials; else null
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     float *codebook, *cnorm, *zmin, *zmax;
@@ -223,7 +223,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     PrxVqgan* v = new PrxVqgan();
     std::unique_ptr<PrxVqgan> guard(v);
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
-    v->gscale = v->h16 ? prx_default_grad_scale() : 1.f;
+    v->gs = nullptr;
     v->n_gn = 0; v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
     WCursor cur{w, n_w, 0};
     int r;
@@ -303,6 +303,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     }
     v->ws_bytes = (size_t)64 << 20;
     VALLOC(v->ws, v->ws_bytes / sizeof(float));
+    if (v->h16) VALLOC(v->gs, 2 + 256);
     *out = guard.release();
     return 0;
 }
@@ -493,8 +494,10 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     int r;
     PRX_REQUIRE(v->x_last != nullptr, "vqgan backward: no forward in flight on this handle");
     PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
+    // half mode: the whole backward runs under a power-of-two scale S chosen from max|dL/d(image)|; ClampWithGrad only reads signs
+    if (v->h16 && (r = prx_grad_scale(g_img, (size_t)v->out_ch * PH, v->gs + 2, 256, prx_grad_target_log2(), v->gs, s))) return r;
     if ((r = prx_image_head_bwd(v->y, 4, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
-                                v->out_ch, PH, s, v->h16, v->gscale))) return r;      // half mode: the whole backward runs scaled
+                                v->out_ch, PH, s, v->h16, v->gs))) return r;
     struct GB { float* f; void* b; };
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
     if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
@@ -562,7 +565,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     const int P0 = v->h0 * v->w0;
     {   GemmDesc d; d.A = v->dpq_bf; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
         d.out_f32 = t2.f; d.ldc_f32 = v->D;
-        d.alpha = 1.f / v->gscale;         // unscale (exact: power of two)
+        if (v->h16) d.alpha_dev = v->gs + 1;         // unscale: 1/S (exact, a power of two)
         if ((r = vg(v, d, s))) return r; }
     return prx_nhwc_to_nchw(t2.f, v->D, dz, 1, v->D, P0, s);
 }

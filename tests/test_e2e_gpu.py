@@ -33,13 +33,23 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def test_headline_config_one_iteration_vs_oracle():
-    r = step_ref.compare_one_iteration()            # vqgan 256^2 + ViT-B/32 + 64 cutouts
-    print(r)
+# Fast-mode gate of SURVEY.md section 8(d), at its stated value for EVERY configuration: rel-L2 <= 2e-2 and cosine >= 0.999.  It is met by
+# the product default (fp16 operands, the reference's own CLIP arithmetic on a GPU).  The bf16 mode (8 significand bits) meets
+# it at BASELINE sizes (cfg1 1.3e-2, cfg2 at 128 cutouts 1.2e-2, cfg3 at 256 cutouts 1.1e-2: tests/test_fullsize_gpu.py) but
+# not on few-cutout / reduced graphs, where its operand noise does not average out: those cases state the measured bf16
+# noise as a SEPARATE, labelled gate (BF16_SMALL) instead of relaxing the product gate.
+FAST_REL, FAST_COS = 2e-2, 0.999
+BF16_SMALL_REL, BF16_SMALL_COS = 8e-2, 0.997
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_headline_config_one_iteration_vs_oracle(precision):
+    r = step_ref.compare_one_iteration(precision=precision)            # vqgan 256^2 + ViT-B/32 + 64 cutouts
+    print(precision, r)
     assert r["indices_equal"]                        # integer work: exact
     assert r["loss_abs_err"] < 1e-3
     assert r["image_rel_l2"] < 1e-2 and r["embeds_rel_l2"] < 1e-2
-    assert r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r     # measured 1.3e-2 / 0.99994
+    assert r["dz_rel_l2"] < FAST_REL and r["dz_cosine"] > FAST_COS, r     # measured fp16 2.7e-3 / 0.999997, bf16 1.3e-2 / 0.99992
 
 
 def test_headline_config_steps_teacher_forced_vs_oracle():
@@ -48,7 +58,7 @@ def test_headline_config_steps_teacher_forced_vs_oracle():
     r = step_ref.compare_k_steps(5)
     print(r)
     assert r["vq_index_agreement_min"] == 1.0
-    assert r["dz_rel_l2_max"] < 2.5e-2 and r["dz_cosine_min"] > 0.999, r
+    assert r["dz_rel_l2_max"] < FAST_REL and r["dz_cosine_min"] > FAST_COS, r
     # one Adam(+clip_z) step from identical state: |dz| ~ lr, components whose gradient is ~0 can flip sign
     assert r["z_after_step_max_abs_err"] <= 2 * 0.2 + 1e-6
     # the free-running HIP loop optimises like the oracle does (loss goes down by a similar amount)
@@ -56,20 +66,26 @@ def test_headline_config_steps_teacher_forced_vs_oracle():
     assert lh[-1] < lh[0] and abs((lh[0] - lh[-1]) - (lo[0] - lo[-1])) < 0.5 * abs(lo[0] - lo[-1]) + 0.02
 
 
-def test_reduced_config_one_iteration_vs_oracle():
-    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0)
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_reduced_config_one_iteration_vs_oracle(precision):
+    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0, precision=precision)
+    print(precision, r)
     assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
     # a 2-layer random tower on 8 cutouts of a 64x64 image has a much noisier loss surface than the headline config
-    assert r["dz_rel_l2"] < 8e-2 and r["dz_cosine"] > 0.997, r
+    rel_gate, cos_gate = (FAST_REL, FAST_COS) if precision == "fp16" else (BF16_SMALL_REL, BF16_SMALL_COS)
+    assert r["dz_rel_l2"] < rel_gate and r["dz_cosine"] > cos_gate, r
 
 
-def test_widescreen_one_iteration_vs_oracle():
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_widescreen_one_iteration_vs_oracle(precision):
     """pixray's default aspect is widescreen: a non-square canvas through every stage (rectangular latent, decoder,
     adaptive pooling of a W != H image into square cutouts)"""
-    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(112, 64), cutn=8, seed=3)
+    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(112, 64), cutn=8, seed=3, precision=precision)
+    print(precision, r)
     assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
     assert r["image_rel_l2"] < 1e-2
-    assert r["dz_rel_l2"] < 8e-2 and r["dz_cosine"] > 0.997, r
+    rel_gate, cos_gate = (FAST_REL, FAST_COS) if precision == "fp16" else (BF16_SMALL_REL, BF16_SMALL_COS)
+    assert r["dz_rel_l2"] < rel_gate and r["dz_cosine"] > cos_gate, r
 
 
 # ------------------------------------------------------------------------------------------- golden fixtures
@@ -433,11 +449,14 @@ def test_config2_at_the_per_gpu_shard_size_vs_oracle():
     and RN50x4 towers on a 16-cutout shard each.  dL/dz of the exact-f32 mode against the CPU oracle meets the f32 gate;
     the bf16 fast path is stated against both."""
     from oracle import workload_ref
-    r = workload_ref.compare_workload("cfg2", 16, precisions=("f32", "bf16"))
+    r = workload_ref.compare_workload("cfg2", 16, precisions=("f32", "fp16", "bf16"))
     print("cfg2 @16:", r)
     assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
     assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]      # measured 1.2e-4
-    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]       # measured 2.4e-2 / 0.99978
+    assert r["fp16"]["grad_rel_l2"] < FAST_REL and r["fp16"]["grad_cosine"] > FAST_COS, r["fp16"]   # measured 5.9e-3 / 0.99998
+    # bf16 at this 16-cutout shard: 2.5e-2 / 0.99978 (operand noise over few cutouts); at the configuration's own 128 cutouts
+    # it is 1.2e-2 / 0.99992, inside the stated gate (tests/test_fullsize_gpu.py)
+    assert r["bf16"]["grad_rel_l2"] < BF16_SMALL_REL and r["bf16"]["grad_cosine"] > BF16_SMALL_COS, r["bf16"]
 
 
 def test_config3_at_the_per_gpu_shard_size_vs_oracle():
@@ -446,13 +465,14 @@ def test_config3_at_the_per_gpu_shard_size_vs_oracle():
     StyleLoss term is checked on its own below: 27 VGG16 passes on a 512x512 image are minutes on the CPU oracle.)"""
     import bench
     from oracle import workload_ref
-    r = workload_ref.compare_workload("cfg3", 32, precisions=("f32", "bf16"),
+    r = workload_ref.compare_workload("cfg3", 32, precisions=("f32", "fp16", "bf16"),
                                       custom_factory=lambda prec: [{"loss": bench.make_saturation_loss(DEV), "weight": 1.0}],
                                       custom_ref=[{"loss": workload_ref.SaturationLossRef(), "weight": 1.0}])
     print("cfg3 @32:", r)
     assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
     assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]      # measured 7.6e-5
-    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]       # measured 1.6e-2 / 0.99988
+    assert r["fp16"]["grad_rel_l2"] < FAST_REL and r["fp16"]["grad_cosine"] > FAST_COS, r["fp16"]
+    assert r["bf16"]["grad_rel_l2"] < FAST_REL and r["bf16"]["grad_cosine"] > FAST_COS, r["bf16"]       # measured 1.6e-2 / 0.99988
 
 
 def test_config3_styleloss_term_at_512_bf16_vs_f32_extractor():

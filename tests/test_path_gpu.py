@@ -445,15 +445,16 @@ def test_make_cutouts_cached_transform_path_vs_oracle(it):
 
 
 # ------------------------------------------------------------------------------------------ CLIP ModifiedResNet
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("name,n", [("tiny-RN", 3), ("RN50x4", 2)])
-def test_clip_resnet_vs_oracle(name, n):
+def test_clip_resnet_vs_oracle(name, n, precision):
     """CLIP_Base.encode_image with a ModifiedResNet tower (RN50x4 = BASELINE.json configs[2]): preprocessing, stem,
     bottlenecks with folded BatchNorm, attention pool, forward and the gradient w.r.t. the cutouts.  bf16 operands vs
     the fp32 oracle (which is restated from the published architecture: parity unpinned)."""
     from oracle import clip_resnet_ref
     cfg = weights.CLIP_RESNET_CONFIGS[name]
     p = weights.synthetic_clip_resnet_params(cfg, seed=3)
-    h = ops.ClipResNetHandle(cfg, p, max_batch=4, device=DEV)
+    h = ops.ClipResNetHandle(cfg, p, max_batch=4, device=DEV, precision=precision)
     g = torch.Generator().manual_seed(17)
     R = cfg.input_resolution
     low = torch.rand(n, 3, R // 8, R // 8, generator=g)
@@ -481,13 +482,15 @@ def test_clip_resnet_vs_oracle(name, n):
     bulk_d, bulk_r = gd.detach().cpu().flatten().clone(), gref.flatten().clone()
     ext_d, ext_r = bulk_d[ext].clone(), bulk_r[ext].clone()
     bulk_d[ext] = 0.0; bulk_r[ext] = 0.0
-    print(name, "emb rel", rel_l2(emb, ref), "grad rel", rel_l2(gd, gref), "grad cos", cosine(gd, gref),
+    print(name, precision, "emb rel", rel_l2(emb, ref), "grad rel", rel_l2(gd, gref), "grad cos", cosine(gd, gref),
           "| bulk rel", rel_l2(bulk_d, bulk_r), "bulk cos", cosine(bulk_d, bulk_r), "| min/max entries", ext_d.tolist(), ext_r.tolist())
     # gates = measured values + margin (tiny-RN: few channels, the bf16 noise of a product does not average out; RN50x4:
     # wide layers).  They are bf16-operand noise, not a modelling difference: the exact-f32 mode of the same code meets 1e-4
     # on every entry (tests/test_f32_mode_gpu.py::test_clip_resnet_f32_mode_vs_float64_oracle).
     # measured: tiny-RN bulk 0.119 / 0.9929, RN50x4 bulk 0.155 / 0.9880 (total incl. the min/max entries 0.014 / 0.177)
-    tol_rel, tol_cos = (2e-1, 0.98)
+    # fp16 (the product default, the reference's own arithmetic for this tower on a GPU): the stated 0.999 cosine holds for the
+    # tower on its own; the bf16 mode keeps its measured operand-noise gate
+    tol_rel, tol_cos = (5e-2, 0.999) if precision == "fp16" else (2e-1, 0.98)
     assert rel_l2(gd, gref) < 2e-1 and cosine(gd, gref) > 0.999, (rel_l2(gd, gref), cosine(gd, gref))
     assert rel_l2(bulk_d, bulk_r) < tol_rel, rel_l2(bulk_d, bulk_r)
     assert cosine(bulk_d, bulk_r) > tol_cos, cosine(bulk_d, bulk_r)

@@ -37,9 +37,24 @@ for M, N, K, tag in shapes:
     g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
     g.alpha = 1.0; g.out_bf16 = out_b.data_ptr(); g.ldc_bf16 = N
     s = _lib.current_stream()
+    lib = _lib.load()
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
     t_prx = timeit(lambda: call("prx_k_gemm", g, ws, ws.numel(), s))
+    ref_b = out_b.clone()
+    # the 256 x 256 8-phase kernel (gemm8p.hip) forced on, with the XCD-aware tile order on and off; result checked against
+    # the 4-wave kernels' (same operands, same fp32 accumulation order per K tile up to the MFMA's own)
+    t8 = {}
+    for xcd in (1, 0):
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 256, 256, 1)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -1, 0, xcd)
+        out_b.zero_()
+        t8[xcd] = timeit(lambda: call("prx_k_gemm", g, ws, ws.numel(), s))
+        err = (out_b.float() - ref_b.float()).abs().max().item() / max(ref_b.float().abs().max().item(), 1e-30)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -1, 0, 2)
     Btt = Bt.t()
     t_lib = timeit(lambda: torch.matmul(A, Btt))
     fl = 2.0 * M * N * K
-    print(f"{tag:18s} M={M:6d} N={N:5d} K={K:5d}: engine {1e3 * t_prx:7.1f} us {fl / t_prx / 1e9:7.0f} TF | "
+    print(f"{tag:18s} M={M:6d} N={N:5d} K={K:5d}: engine {1e3 * t_prx:7.1f} us {fl / t_prx / 1e9:7.0f} TF | 8-phase 256^2 "
+          f"{1e3 * t8[1]:7.1f} us {fl / t8[1] / 1e9:7.0f} TF (no XCD order {1e3 * t8[0]:7.1f} us; max rel diff vs engine {err:.1e}) | "
           f"torch.matmul (vendor library) {1e3 * t_lib:7.1f} us {fl / t_lib / 1e9:7.0f} TF", flush=True)
