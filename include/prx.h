@@ -397,6 +397,26 @@ prx_gemm_ctx* prx_clip_vit_gemm_ctx(prx_clip_vit* h);
 prx_gemm_ctx* prx_clip_resnet_gemm_ctx(prx_clip_resnet* h);
 prx_gemm_ctx* prx_vgg16_gemm_ctx(prx_vgg16* h);
 
+/* ---- the exchange step of the cutout-sharded iteration ------------------------------------------------
+ * The reference has no distributed code; what this replaces is the seam in `train()` between
+ * `loss.backward()` and `opt.step()` (pixray.py:1482-1485) where a data-parallel port would all-reduce the gradient.
+ * prx_allreduce_grad is a ONE-SHOT DIRECT-WRITE all-reduce (SUM, fp32, in place) over IPC-mapped peer windows: every rank
+ * writes its vector straight into each peer's window over xGMI, raises a flag, waits for the peers' flags in its own window
+ * and sums the slots in rank order -- bit-identical on every rank, one kernel, no ring (csrc/comm.hip).
+ *   prx_comm_create    allocates this rank's window (slots of max_bytes for 2 calls in flight x world ranks)
+ *   prx_comm_export    the window's IPC handle, prx_comm_handle_bytes() bytes, to be exchanged by the host side
+ *   prx_comm_connect   maps the peers' windows from `world` handles in rank order (own entry ignored)
+ *   prx_allreduce_grad n floats, n % 4 == 0, 16-byte aligned, n * 4 <= max_bytes; asynchronous on `stream`
+ *   prx_comm_status    0, or 1 + r when a wait for rank r's data timed out (synchronises) */
+typedef struct prx_comm prx_comm;
+int prx_comm_handle_bytes(void);
+int prx_comm_create(prx_comm** out, int rank, int world, size_t max_bytes);
+int prx_comm_export(prx_comm* c, void* handle_out);
+int prx_comm_connect(prx_comm* c, const void* handles);
+int prx_allreduce_grad(prx_comm* c, float* grad, size_t n, prx_stream_t stream);
+int prx_comm_status(prx_comm* c);
+void prx_comm_destroy(prx_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

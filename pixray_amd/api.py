@@ -24,6 +24,17 @@ def seeded_unit_vectors(n: int, dim: int, seed: int) -> torch.Tensor:
     return e / e.norm(dim=-1, keepdim=True)
 
 
+def _maybe_oneshot_comm(group, rank, world_size, size):
+    """PRX_ONESHOT_ALLREDUCE=1: carry the per-step all-reduce of dL/d(image) on the C-ABI one-shot direct-write collective
+    (`prx_allreduce_grad`, csrc/comm.hip) instead of torch.distributed / RCCL.  Off by default: only one GPU is reachable from
+    the build container, so the protocol is tested with two processes on one device and the RCCL path stays the default
+    until a node has confirmed it (bench.py prints collectives_ms_per_step for either)."""
+    if world_size <= 1 or group is None or os.environ.get("PRX_ONESHOT_ALLREDUCE", "0") != "1":
+        return None
+    from .comm import OneShotComm
+    return OneShotComm(group, rank, world_size, max_bytes=4 * 4 * int(size[0]) * int(size[1]))
+
+
 def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
                              num_cuts=64, learning_rate=0.2, iterations=250, prompt_embeds: Optional[torch.Tensor] = None,
                              prompt_weight=1.0, extra_prompts: Sequence = (), seed=0, device="cuda", group=None, rank=0,
@@ -96,7 +107,8 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                    init_weight_cos=init_weight_cos, z_orig=drawer.get_z_copy().detach() if init_image is not None else None,
                    init_image_tensor=None if init_image is None else init_image.to(dev).float(),
                    overlay_image=overlay_image, overlay_every=overlay_every, overlay_offset=overlay_offset,
-                   overlay_until=overlay_until, overlay_alpha=overlay_alpha)
+                   overlay_until=overlay_until, overlay_alpha=overlay_alpha,
+                   comm=_maybe_oneshot_comm(group, rank, world_size, size))
 
 
 def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=256, iterations=250, seed=0, device="cuda",
@@ -121,7 +133,8 @@ def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=2
     pe = prompt_embeds if prompt_embeds is not None else seeded_unit_vectors(1, perceptor.output_dim, seed + 2)
     pms = {clip_model: [Prompt(pe.to(dev), 1.0, float("-inf")).to(dev)]}
     return Session(drawer, {clip_model: perceptor}, {perceptor.input_resolution: mk}, pms, iterations=iterations,
-                   custom_losses=list(custom_losses), args=args, seed=seed, group=group, rank=rank, world_size=world_size)
+                   custom_losses=list(custom_losses), args=args, seed=seed, group=group, rank=rank, world_size=world_size,
+                   comm=_maybe_oneshot_comm(group, rank, world_size, size))
 
 
 # BASELINE.json `configs` as (builder kwargs); configs[0] is the CPU plumbing case (tests/test_host_logic.py), configs[4]

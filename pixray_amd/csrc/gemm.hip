@@ -949,7 +949,68 @@ int prx_gemm_ctx_profile_collect(GemmCtx* c, double* total_ms, double* total_flo
     return 0;
 }
 
+// ---- 256 x 256 8-phase tiles: when, and on how much of M ---------------------------------------------------------------
+// One workgroup per CU (128 KB of LDS), so tiles run in ROUNDS of 256: a problem of R full rounds + a few tiles pays a whole
+// extra round for the remainder (ViT-L/14 at 256 cutouts: M = 65 792 = 257 row tiles -> 1 028 tiles = 4.02 rounds).  The plan
+// gives the full rounds to the 8-phase kernel and hands the last few row tiles to the 4-wave kernels as a second launch
+// (rows are independent; every row-indexed pointer of the descriptor is offset).  Costs from tools/micro/gemm8p.hip and
+// tools/lib_gemm_compare.py on MI355X: a round costs ~1.5 us per K tile + ~8 us; the 4-wave kernels run ~500 TFLOP/s + ~8 us.
+struct Plan8p { int main_rows; };     // rows [0, main_rows) on the 8-phase kernel (0: not at all), the rest on the 4-wave kernels
+static Plan8p plan_8phase(const GemmDesc& d, const GemmCtx& cx) {
+    Plan8p p{0};
+    if (cx.tile8p <= 0 || !prx_gemm8p_eligible(d)) return p;
+    const int tm = ceil_div(d.M, 256), tn = ceil_div(d.N, 256), tiles = tm * tn;
+    if (tiles < cx.tile8p) return p;
+    const int n_cu = 256;
+    const double t_round = 1.5 * (d.K / 64) + 8.0;                                     // us
+    auto t_4wave = [&](int rows) { return rows <= 0 ? 0.0 : 2.0 * rows * (double)d.N * d.K / 500e6 + 8.0; };   // us
+    const int rounds_all = ceil_div(tiles, n_cu);
+    double best = rounds_all * t_round;
+    p.main_rows = d.M;
+    const int full = tiles / n_cu;                                                      // whole rounds available
+    if (full >= 1 && tiles % n_cu != 0) {
+        const int rows8 = std::min(tm, (full * n_cu) / tn);                             // row tiles that fit `full` rounds
+        const int m_main = std::min(d.M, rows8 * 256);
+        const double t = full * t_round + t_4wave(d.M - m_main);
+        if (m_main > 0 && m_main < d.M && t < 0.9 * best) { best = t; p.main_rows = m_main; }
+    }
+    if (t_4wave(d.M) < best) p.main_rows = 0;                                           // the 4-wave kernels win outright
+    return p;
+}
+// the same descriptor restricted to rows [r0, r0 + rows) (row-major A only)
+static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
+    GemmDesc s = d;
+    const size_t esz = d.f32 ? 4 : 2;
+    s.M = rows;
+    s.A = (const char*)d.A + (size_t)r0 * d.lda * (d.a_is_f32 ? 4 : esz);
+    if (d.bias_m) s.bias_m = d.bias_m + r0;
+    if (d.aux) s.aux = (const char*)d.aux + (size_t)r0 * d.ldaux * esz;
+    if (d.resid) s.resid = d.resid + (size_t)r0 * d.ldr;
+    if (d.out_f32) s.out_f32 = d.out_f32 + (size_t)r0 * d.ldc_f32;
+    if (d.out_bf16) s.out_bf16 = (char*)d.out_bf16 + (size_t)r0 * d.ldc_bf16 * esz;
+    if (d.out_bf16_pre) s.out_bf16_pre = (char*)d.out_bf16_pre + (size_t)r0 * d.ldc_bf16 * esz;
+    return s;
+}
+
+static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx, int use8p);
+
 int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
+    static const GemmCtx k_default;      // immutable: heuristics only
+    const GemmCtx& cx = ctx ? *ctx : k_default;
+    const bool forced = cx.force_bm != 0 || !cx.rules.empty();
+    if (!forced && d.M > 0 && d.N > 0 && d.K > 0) {
+        const Plan8p p = plan_8phase(d, cx);
+        if (p.main_rows >= d.M) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 1);
+        if (p.main_rows > 0) {
+            int r = gemm_launch_one(rows_of(d, 0, p.main_rows), ws, ws_bytes, stream, ctx, 1);
+            if (r) return r;
+            return gemm_launch_one(rows_of(d, p.main_rows, d.M - p.main_rows), ws, ws_bytes, stream, ctx, 0);
+        }
+    }
+    return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 0);
+}
+
+static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx, int use8p) {
     static const GemmCtx k_default;      // immutable: heuristics only
     const GemmCtx& cx = ctx ? *ctx : k_default;
     PRX_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
@@ -997,8 +1058,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     // very large problems (ViT-L/14 at 256 cutouts: M = 65 792): the 8-wave 256 x 128 tile, when it still fills the chip
     // several times over (A/B switch, off by default: see DESIGN.md section 6)
     if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
-    // 256 x 256 tiles on the 8-phase kernel (gemm8p.hip) when the problem fills the chip with them: tile8p = minimum tile count
-    if (cx.tile8p > 0 && prx_gemm8p_eligible(d) && ntiles(256, 256) >= cx.tile8p) { BM = 256; BN = 256; }
+    if (use8p) { BM = 256; BN = 256; }          // planned by plan_8phase (prx_gemm_launch)
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; }
     int rule_splits = 0;
     if (!cx.rules.empty()) {
@@ -1016,7 +1076,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     a.kt_total = ceil_div(d.K, bk);
     int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16) {
+    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16 && !(BM == 256 && BN == 256)) {
         // few tiles, long K (the 16x16 / 32x32 decoder convs): aim at ~320 blocks, >= 4 K tiles per split
         splits = std::max(1, std::min(std::min((320 + tiles / 2) / tiles, a.kt_total / 4), 32));
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;

@@ -153,8 +153,11 @@ class Session:
                  spot_prompts: Optional[Dict[str, Sequence[object]]] = None,
                  spot_prompts_off: Optional[Dict[str, Sequence[object]]] = None,
                  overlay_image=None, overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
-                 overlay_alpha: Optional[int] = None, prompt_factory=None, loss_globals: Optional[dict] = None):
+                 overlay_alpha: Optional[int] = None, prompt_factory=None, loss_globals: Optional[dict] = None, comm=None):
         self.drawer = drawer
+        # optional C-ABI exchange (pixray_amd.comm.OneShotComm over `prx_allreduce_grad`): carries the per-step all-reduce of
+        # dL/d(image) instead of torch.distributed; None = RCCL through torch.distributed
+        self.comm = comm
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
         self.cutoutSizeTable = {name: p.input_resolution for name, p in perceptors.items()}
@@ -300,7 +303,12 @@ class Session:
 
             def _allreduce(g):
                 g = g.contiguous()
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group if self.group is not None else self._force_hook_group)
+                if self.comm is not None and g.is_cuda:
+                    if g.data_ptr() % 16 or g.numel() % 4:
+                        g = g.clone()
+                    self.comm.all_reduce_sum_(g)          # one-shot direct-write over the peers' IPC windows (csrc/comm.hip)
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group if self.group is not None else self._force_hook_group)
                 return g
             out.register_hook(_allreduce)
         cur_cutouts = {}
