@@ -17,6 +17,7 @@
 // ColorJitter Jacobian is obtained with forward-mode duals.
 #include "cutouts.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -660,6 +661,128 @@ __device__ __forceinline__ void gather_tile(const GatherStage& st, const StageMa
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
 }
 
+// ---- backward, tile-owned scatter form (round 3) ----------------------------------------------------------------------
+// The per-PIXEL gather above spends ~1-2 k instructions of pre-image geometry per source pixel before it touches a candidate
+// (0.54 ms per iteration at the headline: 10x its HBM bound).  Same ownership, coarser granularity: a workgroup owns a
+// 16 x 16 tile of SOURCE pixels, works out the raw-coordinate rectangles / destination boxes ONCE for the tile, and then runs
+// DESTINATION-parallel over the candidates -- each lane takes one destination pixel, rebuilds the forward's own four taps
+// (make_taps on the stored raw coordinate: same roundings, exact adjoint) and adds the taps that fall inside the tile into an
+// LDS accumulator.  No global atomics, no memsets, every gradient element written exactly once, and still bit-reproducible:
+//   * candidates are visited in a fixed order (rectangle by rectangle, k = thread id + 256 j);
+//   * each of the block's 4 waves has its OWN accumulator plane, so no two waves ever add to the same word; within a wave the
+//     additions of one ds_add_f32 instruction are serialised by the LDS in a fixed lane order, and instructions retire in
+//     program order;
+//   * the four planes are summed in wave order at the end.
+// Uniqueness / completeness as in the gather: the tile's raw rectangles are pairwise disjoint and a candidate is counted in
+// the rectangle that contains its raw coordinate; acceptance is by the exact taps, the boxes only bound the search.
+constexpr int MAXR = 3;
+// raw-coordinate intervals whose padded coordinate can produce a tap on a source index in [s0, s1] (tile range, clipped to
+// the image), clipped to [lo, hi]: the tile-level version of tap_intervals
+__device__ __forceinline__ int tile_intervals(int mode, int s0, int s1, int W, float lo, float hi, float* ia, float* ib) {
+    const float eps = 2e-3f;
+    const float f0 = (float)s0, f1 = (float)s1, fW = (float)W;
+    float a = f0 - 1.f - eps, b = f1 + 1.f + eps;
+    if (mode == MODE_BORDER) {
+        if (s0 == 0) a = -INFINITY;
+        if (s1 == W - 1) b = INFINITY;
+    }
+    a = fmaxf(a, lo); b = fminf(b, hi);
+    int n = 0;
+    if (b > a) { ia[0] = a; ib[0] = b; n = 1; }
+    if (mode != MODE_REFLECT && mode != MODE_REFLECT_AC) return n;
+    float m0a, m0b, m1a, m1b, dlo, dhi;
+    if (mode == MODE_REFLECT) {                     // mirrors about -0.5 and W - 0.5: t -> -1 - t, t -> 2W - 1 - t
+        m0a = -f1 - 2.f; m0b = -f0; m1a = 2.f * fW - f1 - 2.f; m1b = 2.f * fW - f0;
+        dlo = -fW - 0.5f; dhi = 2.f * fW - 0.5f;
+    } else {                                        // mirrors about 0 and W - 1
+        const float span = fW - 1.f;
+        m0a = -f1 - 1.f; m0b = -f0 + 1.f; m1a = 2.f * span - f1 - 1.f; m1b = 2.f * span - f0 + 1.f;
+        dlo = -span; dhi = 2.f * span;
+    }
+    if (lo < dlo || hi > dhi) { ia[0] = lo; ib[0] = hi; return 1; }       // beyond the first-order mirrors: search the whole range
+    m0a = fmaxf(m0a - eps, lo); m0b = fminf(m0b + eps, hi);
+    m1a = fmaxf(m1a - eps, lo); m1b = fminf(m1b + eps, hi);
+    int cnt = 0;
+    float ra[3], rb[3];
+    if (m0b > m0a) { ra[cnt] = m0a; rb[cnt] = m0b; ++cnt; }
+    if (n) {
+        if (cnt && ia[0] <= rb[cnt - 1]) rb[cnt - 1] = fmaxf(rb[cnt - 1], ib[0]);
+        else { ra[cnt] = ia[0]; rb[cnt] = ib[0]; ++cnt; }
+    }
+    if (m1b > m1a) {
+        if (cnt && m1a <= rb[cnt - 1]) rb[cnt - 1] = fmaxf(rb[cnt - 1], m1b);
+        else { ra[cnt] = m1a; rb[cnt] = m1b; ++cnt; }
+    }
+    for (int i = 0; i < cnt; ++i) { ia[i] = ra[i]; ib[i] = rb[i]; }
+    return cnt;
+}
+
+struct TileScatter {
+    int nrect;
+    float ua[MAXR * MAXR], ub[MAXR * MAXR], va[MAXR * MAXR], vb[MAXR * MAXR];     // disjoint raw rectangles of the tile
+    int x0[MAXR * MAXR], y0[MAXR * MAXR], bw[MAXR * MAXR], cnt[MAXR * MAXR];      // their destination boxes
+    float acc[4][3][TILE_W * TILE_W];                                                 // one accumulator plane set per wave
+};
+
+// all contributions to the 16 x 16 source tile at (tx0, ty0) (source-window coordinates); thread t returns the sums of its own
+// source pixel (tx0 + (t & 15), ty0 + (t >> 4)).  Must be called by all 256 threads of the block.
+__device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageMap& sm, TileScatter& ts, int tx0, int ty0, float (&out)[3]) {
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) {
+        int n = 0;
+        const int sx0 = max(tx0, 0), sx1 = min(tx0 + TILE_W - 1, st.Ws - 1);
+        const int sy0 = max(ty0, 0), sy1 = min(ty0 + TILE_W - 1, st.Hs - 1);
+        if (sx0 <= sx1 && sy0 <= sy1) {
+            float xa[MAXR], xb[MAXR], ya[MAXR], yb[MAXR];
+            const int nx = tile_intervals(st.mode, sx0, sx1, st.Ws, sm.ulo, sm.uhi, xa, xb);
+            const int ny = tile_intervals(st.mode, sy0, sy1, st.Hs, sm.vlo, sm.vhi, ya, yb);
+            for (int j = 0; j < ny; ++j)
+                for (int i = 0; i < nx; ++i) {
+                    int x0, x1, y0, y1;
+                    if (!preimage_box(sm, xa[i], xb[i], ya[j], yb[j], st.Wd, st.Hd, x0, x1, y0, y1)) continue;
+                    ts.ua[n] = xa[i]; ts.ub[n] = xb[i]; ts.va[n] = ya[j]; ts.vb[n] = yb[j];
+                    ts.x0[n] = x0; ts.y0[n] = y0; ts.bw[n] = x1 - x0 + 1; ts.cnt[n] = (x1 - x0 + 1) * (y1 - y0 + 1);
+                    ++n;
+                }
+        }
+        ts.nrect = n;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) ts.acc[w][c][tid] = 0.f;
+    __syncthreads();
+    const size_t plane = (size_t)st.Hd * st.Wd;
+    const int nrect = ts.nrect;
+    for (int r = 0; r < nrect; ++r) {
+        const float ua = ts.ua[r], ub = ts.ub[r], va = ts.va[r], vb = ts.vb[r];
+        const int bx0 = ts.x0[r], by0 = ts.y0[r], bw = ts.bw[r], cnt = ts.cnt[r];
+        for (int k = tid; k < cnt; k += 256) {
+            const int ky = k / bw;
+            const size_t o = (size_t)(by0 + ky) * st.Wd + (bx0 + (k - ky * bw));
+            const float2 q = st.uv[o];
+            if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) continue;
+            const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);          // the forward's own taps
+            const int lx = t.x0 - tx0, ly = t.y0 - ty0;                          // north-west tap inside the tile?
+            const bool cx0 = t.vx0 && lx >= 0 && lx < TILE_W, cx1 = t.vx1 && lx + 1 >= 0 && lx + 1 < TILE_W;
+            const bool cy0 = t.vy0 && ly >= 0 && ly < TILE_W, cy1 = t.vy1 && ly + 1 >= 0 && ly + 1 < TILE_W;
+            if (!((cx0 || cx1) && (cy0 || cy1))) continue;
+            const float e = 1.f - t.wx, s_ = 1.f - t.wy;                        // sample_plane's weights, same products
+            const float w00 = s_ * e, w01 = s_ * t.wx, w10 = t.wy * e, w11 = t.wy * t.wx;
+            const float g0 = st.g[o], g1 = st.g[plane + o], g2 = st.g[2 * plane + o];
+            float* a0 = ts.acc[wave][0]; float* a1 = ts.acc[wave][1]; float* a2 = ts.acc[wave][2];
+            const int p00 = ly * TILE_W + lx;
+            if (cx0 && cy0) { atomicAdd(&a0[p00], g0 * w00); atomicAdd(&a1[p00], g1 * w00); atomicAdd(&a2[p00], g2 * w00); }
+            if (cx1 && cy0) { atomicAdd(&a0[p00 + 1], g0 * w01); atomicAdd(&a1[p00 + 1], g1 * w01); atomicAdd(&a2[p00 + 1], g2 * w01); }
+            if (cx0 && cy1) { atomicAdd(&a0[p00 + TILE_W], g0 * w10); atomicAdd(&a1[p00 + TILE_W], g1 * w10); atomicAdd(&a2[p00 + TILE_W], g2 * w10); }
+            if (cx1 && cy1) { atomicAdd(&a0[p00 + TILE_W + 1], g0 * w11); atomicAdd(&a1[p00 + TILE_W + 1], g1 * w11); atomicAdd(&a2[p00 + TILE_W + 1], g2 * w11); }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = ((ts.acc[0][c][tid] + ts.acc[1][c][tid]) + ts.acc[2][c][tid]) + ts.acc[3][c][tid];
+}
+
 // destination-parallel pre-pass of a gather stage: the raw source coordinate of every destination pixel, exactly as the
 // forward computed it (stage 1: D_M1 / D_GRID1 / D_MODE1 on the Ha x Wa stage-A plane; stage 2: the stage-B words on S x S)
 __global__ __launch_bounds__(256) void uv_kernel(const double* __restrict__ desc, int stage, float2* __restrict__ uv, int Wd, int Hd,
@@ -708,6 +831,41 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
     GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
     float o[3];
     gather_tile(st, sm, ts, tx0, ty0, sx, sy, live, o);
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = o[c];
+    }
+}
+
+// the same in the tile-owned scatter form (scatter_tile)
+__global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restrict__ g, int Hs, int Ws,
+                                                          const double* __restrict__ desc, const float2* __restrict__ uv,
+                                                          float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
+    __shared__ StageMap sm;
+    __shared__ TileScatter ts;
+    const int tiles = (Ws + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int tx0 = (blockIdx.x % tiles) * TILE_W, ty0 = (blockIdx.x / tiles) * TILE_W;
+    const int sx = tx0 + (threadIdx.x & 15);
+    const int sy = ty0 + (threadIdx.x >> 4);
+    const bool live = sx < Ws && sy < Hs;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE1];
+    const size_t plane = (size_t)Ha * Wa, splane = (size_t)Hs * Ws;
+    const float* gi = g + (size_t)n * 3 * plane;
+    float* gs = gsrc + (size_t)n * 3 * splane + (size_t)sy * Ws + sx;
+    if (mode == MODE_IDENT) {
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = gi[(size_t)c * plane + (size_t)sy * Wa + sx];
+        }
+        return;
+    }
+    if (threadIdx.x == 0) build_stage_map(sm, d + D_M1, (int)d[D_GRID1], Wa, Ha, Ws, Hs);
+    __syncthreads();
+    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
+    float o[3];
+    scatter_tile(st, sm, ts, tx0, ty0, o);
     if (live) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = o[c];
@@ -835,6 +993,45 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
         __syncthreads();
         GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
         gather_tile(st, sm, ts, ax0 - q.ox, ay0 - q.oy, sx, sy, live, o);
+    }
+    if (inimg) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[(size_t)c * aplane] = o[c];
+    }
+}
+
+// pass 2 in the tile-owned scatter form (scatter_tile)
+__global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
+                                                          const float* __restrict__ grgb, const float2* __restrict__ uv,
+                                                          float* __restrict__ ga, int n_cut, int S) {
+    __shared__ StageMap sm;
+    __shared__ TileScatter ts;
+    const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
+    const int tiles = (Wa + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int ax0 = (blockIdx.x % tiles) * TILE_W, ay0 = (blockIdx.x / tiles) * TILE_W;
+    const int ax = ax0 + (threadIdx.x & 15);
+    const int ay = ay0 + (threadIdx.x >> 4);
+    const bool inimg = ax < Wa && ay < Ha;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE2];
+    const SrcWin q = src_window(d);
+    const int sx = ax - q.ox, sy = ay - q.oy;
+    const bool live = inimg && sx >= 0 && sx < q.ww && sy >= 0 && sy < q.wh;
+    const float* gi = (d[D_JIT] != 0.0 ? grgb : g) + (size_t)n * 3 * plane;
+    float* go = ga + (size_t)n * 3 * aplane + (size_t)ay * Wa + ax;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (mode == MODE_IDENT) {
+        if (live && sx < S && sy < S) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = gi[(size_t)c * plane + (size_t)sy * S + sx];
+        }
+    } else {
+        if (threadIdx.x == 0) build_stage_map(sm, d + D_M2, (int)d[D_GRID2], S, S, q.ww, q.wh);
+        __syncthreads();
+        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
+        scatter_tile(st, sm, ts, ax0 - q.ox, ay0 - q.oy, o);
+        if (!live) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
     }
     if (inimg) {
 #pragma unroll
@@ -1048,6 +1245,12 @@ __global__ __launch_bounds__(256) void patchify_bwd_apply_kernel(const float* __
 
 }  // namespace
 
+// PRX_CUTOUT_BWD=gather: the round-2 per-pixel gather kernels instead of the tile-owned scatter (A/B measurements)
+static bool cutout_bwd_gather() {
+    static const bool v = [] { const char* e = getenv("PRX_CUTOUT_BWD"); return e && e[0] == 'g'; }();
+    return v;
+}
+
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned char* mask, int C, int H, int W, int S, hipStream_t s) {
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, img, pooled, argmax, mask, C, H, W, S);
     PRX_LAUNCH_CHECK();
@@ -1071,8 +1274,12 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv
     const int tx = (Ws + TILE_W - 1) / TILE_W, ty = (Hs + TILE_W - 1) / TILE_W;
     hipLaunchKernelGGL(uv_kernel, dim3(std::min(ew_grid((size_t)Ha * Wa), 64), n_cut), dim3(256), 0, s, desc, 1, (float2*)uv, Wa, Ha, Ws, Hs);
     PRX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
-                       Ha, Wa);
+    if (cutout_bwd_gather())
+        hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
+                           Ha, Wa);
+    else
+        hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
+                           Ha, Wa);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
                        (size_t)3 * Hs * Ws);
@@ -1096,7 +1303,10 @@ int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const flo
                        n_cut, S);
     PRX_LAUNCH_CHECK();
     const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
-    hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
+    if (cutout_bwd_gather())
+        hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
+    else
+        hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -10,13 +10,13 @@ export TMPDIR=/tmp
 cd /tmp
 todb() { find "$1" -name "*.db" | head -1; }
 if [ "$what" = stats ] || [ "$what" = both ]; then
-    rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_k -- python $R/bench.py "$@" --no-cpu-baseline --profile-steps 0 --phase-steps 0 > $R/gpurun_out/${tag}_rocprof_stats.log 2>&1
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_k -- python $R/bench.py "$@" --no-cpu-baseline --no-other-modes --profile-steps 0 --phase-steps 0 > $R/gpurun_out/${tag}_rocprof_stats.log 2>&1
     db=$(todb /tmp/prof_${tag}_k)
     [ -n "$db" ] && python $R/tools/rocpd_to_csv.py stats "$db" /tmp/${tag}_raw_stats.csv && python $R/tools/kernel_stats_summary.py /tmp/${tag}_raw_stats.csv $iters $R/gpurun_out/${tag}_kernel_stats.csv
 fi
 if [ "$what" = pmc ] || [ "$what" = both ]; then
     for c in FETCH_SIZE WRITE_SIZE; do
-        rocprofv3 --pmc $c -d /tmp/prof_${tag}_$c -- python $R/bench.py "$@" --no-cpu-baseline --profile-steps 0 --phase-steps 0 > $R/gpurun_out/${tag}_rocprof_$c.log 2>&1
+        rocprofv3 --pmc $c -d /tmp/prof_${tag}_$c -- python $R/bench.py "$@" --no-cpu-baseline --no-other-modes --profile-steps 0 --phase-steps 0 > $R/gpurun_out/${tag}_rocprof_$c.log 2>&1
         db=$(todb /tmp/prof_${tag}_$c)
         [ -n "$db" ] && python $R/tools/rocpd_to_csv.py counters "$db" /tmp/${tag}_$c.csv
     done
