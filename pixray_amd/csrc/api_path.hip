@@ -99,7 +99,9 @@ int prx_cutouts_backward(const float* g_out, const double* desc, const unsigned 
                 "prx_cutouts_backward: null argument");
     int r;
     // g_base_priv doubles as the [n_cut,3,S,S] scratch of the ColorJitter pull-back (S <= Hb, Wb) before stage A overwrites it
-    if ((r = prx_warp_b_bwd(stage_a, Hb, Wb, desc, g_out, g_base_priv, uv_scratch, g_stage_a, n_cut, S, S_(s)))) return r;
+    // g_pooled is written only at the very end of this call: until then it holds the per-cutout stage maps of stage B
+    if ((r = prx_warp_b_bwd(stage_a, Hb, Wb, desc, g_out, g_base_priv, uv_scratch, g_stage_a, n_cut, S, S_(s), g_pooled,
+                            sizeof(float) * 3 * (size_t)S * S))) return r;
     const bool rect = Hb != S || Wb != S;
     if ((r = prx_warp_a_bwd(g_stage_a, Hb, Wb, desc, uv_scratch, g_base_priv, rect ? g_base : g_pooled, n_cut, Hb, Wb, S_(s)))) return r;
     if (rect && (r = prx_rescale_bwd(g_base, g_pooled, 3, S, Hb, Wb, S_(s)))) return r;

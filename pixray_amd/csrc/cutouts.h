@@ -10,7 +10,9 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv
 int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const float* noise, float* out, int n_cut, int S,
                    hipStream_t s);
 int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* uv, float* ga, int n_cut,
-                   int S, hipStream_t s);   // grgb: [n_cut,3,S,S], uv: [n_cut,S*S,2] scratch
+                   int S, hipStream_t s, float* maps_scratch, size_t maps_scratch_bytes);
+// grgb: [n_cut,3,S,S], uv: [n_cut,S*S,2] scratch; maps_scratch: >= 64 bytes per cutout, untouched by anything else until the
+// launch has finished (the per-cutout inverse stage maps of the tile-owned scatter)
 // bilinear resize of the pooled [C,S,S] image to the canvas aspect [C,Hb,Wb] (pixray.py:468-472) and its gradient
 int prx_rescale_fwd(const float* pooled, float* base, int C, int S, int Hb, int Wb, hipStream_t s);
 int prx_rescale_bwd(const float* g_base, float* g_pooled, int C, int S, int Hb, int Wb, hipStream_t s);

@@ -724,6 +724,24 @@ struct TileScatter {
     float acc[4][3][TILE_W * TILE_W];                                                 // one accumulator plane set per wave
 };
 
+// one candidate: destination pixel with raw coordinate q and gradient (g0, g1, g2) -> LDS accumulator of the tile
+__device__ __forceinline__ void scatter_candidate(const GatherStage& st, float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
+                                                  int tx0, int ty0, float ua, float ub, float va, float vb, float2 q, float g0, float g1, float g2) {
+    if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return;
+    const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);          // the forward's own taps
+    const int lx = t.x0 - tx0, ly = t.y0 - ty0;                          // north-west tap inside the tile?
+    const bool cx0 = t.vx0 && lx >= 0 && lx < TILE_W, cx1 = t.vx1 && lx + 1 >= 0 && lx + 1 < TILE_W;
+    const bool cy0 = t.vy0 && ly >= 0 && ly < TILE_W, cy1 = t.vy1 && ly + 1 >= 0 && ly + 1 < TILE_W;
+    if (!((cx0 || cx1) && (cy0 || cy1))) return;
+    const float e = 1.f - t.wx, s_ = 1.f - t.wy;                        // sample_plane's weights, same products
+    const float w00 = s_ * e, w01 = s_ * t.wx, w10 = t.wy * e, w11 = t.wy * t.wx;
+    const int p00 = ly * TILE_W + lx;
+    if (cx0 && cy0) { atomicAdd(&a0[p00], g0 * w00); atomicAdd(&a1[p00], g1 * w00); atomicAdd(&a2[p00], g2 * w00); }
+    if (cx1 && cy0) { atomicAdd(&a0[p00 + 1], g0 * w01); atomicAdd(&a1[p00 + 1], g1 * w01); atomicAdd(&a2[p00 + 1], g2 * w01); }
+    if (cx0 && cy1) { atomicAdd(&a0[p00 + TILE_W], g0 * w10); atomicAdd(&a1[p00 + TILE_W], g1 * w10); atomicAdd(&a2[p00 + TILE_W], g2 * w10); }
+    if (cx1 && cy1) { atomicAdd(&a0[p00 + TILE_W + 1], g0 * w11); atomicAdd(&a1[p00 + TILE_W + 1], g1 * w11); atomicAdd(&a2[p00 + TILE_W + 1], g2 * w11); }
+}
+
 // all contributions to the 16 x 16 source tile at (tx0, ty0) (source-window coordinates); thread t returns the sums of its own
 // source pixel (tx0 + (t & 15), ty0 + (t >> 4)).  Must be called by all 256 threads of the block.
 __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageMap& sm, TileScatter& ts, int tx0, int ty0, float (&out)[3]) {
@@ -754,33 +772,49 @@ __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageM
     __syncthreads();
     const size_t plane = (size_t)st.Hd * st.Wd;
     const int nrect = ts.nrect;
+    float* a0 = ts.acc[wave][0]; float* a1 = ts.acc[wave][1]; float* a2 = ts.acc[wave][2];
+    constexpr int U = 4;                 // candidates per thread per trip: their 16 loads are in flight together
     for (int r = 0; r < nrect; ++r) {
         const float ua = ts.ua[r], ub = ts.ub[r], va = ts.va[r], vb = ts.vb[r];
         const int bx0 = ts.x0[r], by0 = ts.y0[r], bw = ts.bw[r], cnt = ts.cnt[r];
-        for (int k = tid; k < cnt; k += 256) {
-            const int ky = k / bw;
-            const size_t o = (size_t)(by0 + ky) * st.Wd + (bx0 + (k - ky * bw));
-            const float2 q = st.uv[o];
-            if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) continue;
-            const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);          // the forward's own taps
-            const int lx = t.x0 - tx0, ly = t.y0 - ty0;                          // north-west tap inside the tile?
-            const bool cx0 = t.vx0 && lx >= 0 && lx < TILE_W, cx1 = t.vx1 && lx + 1 >= 0 && lx + 1 < TILE_W;
-            const bool cy0 = t.vy0 && ly >= 0 && ly < TILE_W, cy1 = t.vy1 && ly + 1 >= 0 && ly + 1 < TILE_W;
-            if (!((cx0 || cx1) && (cy0 || cy1))) continue;
-            const float e = 1.f - t.wx, s_ = 1.f - t.wy;                        // sample_plane's weights, same products
-            const float w00 = s_ * e, w01 = s_ * t.wx, w10 = t.wy * e, w11 = t.wy * t.wx;
-            const float g0 = st.g[o], g1 = st.g[plane + o], g2 = st.g[2 * plane + o];
-            float* a0 = ts.acc[wave][0]; float* a1 = ts.acc[wave][1]; float* a2 = ts.acc[wave][2];
-            const int p00 = ly * TILE_W + lx;
-            if (cx0 && cy0) { atomicAdd(&a0[p00], g0 * w00); atomicAdd(&a1[p00], g1 * w00); atomicAdd(&a2[p00], g2 * w00); }
-            if (cx1 && cy0) { atomicAdd(&a0[p00 + 1], g0 * w01); atomicAdd(&a1[p00 + 1], g1 * w01); atomicAdd(&a2[p00 + 1], g2 * w01); }
-            if (cx0 && cy1) { atomicAdd(&a0[p00 + TILE_W], g0 * w10); atomicAdd(&a1[p00 + TILE_W], g1 * w10); atomicAdd(&a2[p00 + TILE_W], g2 * w10); }
-            if (cx1 && cy1) { atomicAdd(&a0[p00 + TILE_W + 1], g0 * w11); atomicAdd(&a1[p00 + TILE_W + 1], g1 * w11); atomicAdd(&a2[p00 + TILE_W + 1], g2 * w11); }
+        const float ibw = 1.f / (float)bw;
+        for (int k0 = tid; k0 < cnt; k0 += 256 * U) {
+            float2 q[U]; float g0[U], g1[U], g2[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int k = k0 + 256 * j;
+                q[j] = make_float2(-INFINITY, -INFINITY);         // fails every rectangle test
+                g0[j] = g1[j] = g2[j] = 0.f;
+                if (k < cnt) {
+                    int ky = (int)((float)k * ibw);                // k / bw without the integer division (cnt < 2^23; corrected below)
+                    int kx = k - ky * bw;
+                    if (kx < 0) { --ky; kx += bw; } else if (kx >= bw) { ++ky; kx -= bw; }
+                    const size_t o = (size_t)(by0 + ky) * st.Wd + (bx0 + kx);
+                    q[j] = st.uv[o];
+                    g0[j] = st.g[o]; g1[j] = st.g[plane + o]; g2[j] = st.g[2 * plane + o];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) scatter_candidate(st, a0, a1, a2, tx0, ty0, ua, ub, va, vb, q[j], g0[j], g1[j], g2[j]);
         }
     }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = ((ts.acc[0][c][tid] + ts.acc[1][c][tid]) + ts.acc[2][c][tid]) + ts.acc[3][c][tid];
+}
+
+// the stage map of every cutout, once per stage (it is the same for all tiles of a cutout; built from fp64 it costs a single
+// lane ~3 us, which every one of the 196 tile blocks of a cutout used to spend on its own): maps[n] for stage 1 / 2
+__global__ void stage_map_kernel(const double* __restrict__ desc, int stage, StageMap* __restrict__ maps, int n_cut, int Wd, int Hd, int Ws, int Hs) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_cut) return;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    StageMap sm{};
+    if ((int)d[stage == 1 ? D_MODE1 : D_MODE2] != MODE_IDENT) {
+        if (stage == 2) { Ws = (int)d[D_WW]; Hs = (int)d[D_WH]; }
+        build_stage_map(sm, d + (stage == 1 ? D_M1 : D_M2), (int)d[stage == 1 ? D_GRID1 : D_GRID2], Wd, Hd, Ws, Hs);
+    }
+    maps[n] = sm;
 }
 
 // destination-parallel pre-pass of a gather stage: the raw source coordinate of every destination pixel, exactly as the
@@ -840,8 +874,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
 // the same in the tile-owned scatter form (scatter_tile)
 __global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restrict__ g, int Hs, int Ws,
                                                           const double* __restrict__ desc, const float2* __restrict__ uv,
-                                                          float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
-    __shared__ StageMap sm;
+                                                          const StageMap* __restrict__ maps, float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
     __shared__ TileScatter ts;
     const int tiles = (Ws + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
@@ -861,8 +894,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restric
         }
         return;
     }
-    if (threadIdx.x == 0) build_stage_map(sm, d + D_M1, (int)d[D_GRID1], Wa, Ha, Ws, Hs);
-    __syncthreads();
+    const StageMap sm = maps[n];          // uniform address: scalar loads
     GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
     float o[3];
     scatter_tile(st, sm, ts, tx0, ty0, o);
@@ -1003,8 +1035,7 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
 // pass 2 in the tile-owned scatter form (scatter_tile)
 __global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
                                                           const float* __restrict__ grgb, const float2* __restrict__ uv,
-                                                          float* __restrict__ ga, int n_cut, int S) {
-    __shared__ StageMap sm;
+                                                          const StageMap* __restrict__ maps, float* __restrict__ ga, int n_cut, int S) {
     __shared__ TileScatter ts;
     const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     const int tiles = (Wa + TILE_W - 1) / TILE_W;
@@ -1027,8 +1058,7 @@ __global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const 
             for (int c = 0; c < 3; ++c) o[c] = gi[(size_t)c * plane + (size_t)sy * S + sx];
         }
     } else {
-        if (threadIdx.x == 0) build_stage_map(sm, d + D_M2, (int)d[D_GRID2], S, S, q.ww, q.wh);
-        __syncthreads();
+        const StageMap sm = maps[n];
         GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
         scatter_tile(st, sm, ts, ax0 - q.ox, ay0 - q.oy, o);
         if (!live) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
@@ -1277,9 +1307,14 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv
     if (cutout_bwd_gather())
         hipLaunchKernelGGL(warp_a_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
                            Ha, Wa);
-    else
-        hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, gsrc_priv, n_cut,
-                           Ha, Wa);
+    else {
+        // the per-cutout stage maps (16 floats each) live in `gsrc` until reduce_planes_kernel overwrites it with the result
+        PRX_REQUIRE((size_t)n_cut * sizeof(StageMap) <= (size_t)3 * Hs * Ws * sizeof(float), "warp_a_bwd: too many cutouts for the stage-map scratch");
+        hipLaunchKernelGGL(stage_map_kernel, dim3(ceil_div(n_cut, 64)), dim3(64), 0, s, desc, 1, (StageMap*)gsrc, n_cut, Wa, Ha, Ws, Hs);
+        PRX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
+                           gsrc_priv, n_cut, Ha, Wa);
+    }
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
                        (size_t)3 * Hs * Ws);
@@ -1294,7 +1329,7 @@ int prx_warp_b_fwd(const float* a, int Ha, int Wa, const double* desc, const flo
     return 0;
 }
 int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const float* g, float* grgb, float* uv, float* ga, int n_cut,
-                   int S, hipStream_t s) {
+                   int S, hipStream_t s, float* maps_scratch, size_t maps_scratch_bytes) {
     // grgb: [n_cut][3][S][S] scratch (the gradient pulled back through the ColorJitter); uv: [n_cut][S*S][2] scratch;
     // ga: [n_cut][3][Ha][Wa], every element written
     hipLaunchKernelGGL(uv_kernel, dim3(std::min(ew_grid((size_t)S * S), 64), n_cut), dim3(256), 0, s, desc, 2, (float2*)uv, S, S, 0, 0);
@@ -1305,8 +1340,14 @@ int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const flo
     const int tx = (Wa + TILE_W - 1) / TILE_W, ty = (Ha + TILE_W - 1) / TILE_W;
     if (cutout_bwd_gather())
         hipLaunchKernelGGL(warp_b_bwd_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
-    else
-        hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv, ga, n_cut, S);
+    else {
+        // maps_scratch: any buffer of >= n_cut stage maps that nothing else touches until this launch has finished
+        PRX_REQUIRE(maps_scratch != nullptr && (size_t)n_cut * sizeof(StageMap) <= maps_scratch_bytes, "warp_b_bwd: stage-map scratch too small");
+        hipLaunchKernelGGL(stage_map_kernel, dim3(ceil_div(n_cut, 64)), dim3(64), 0, s, desc, 2, (StageMap*)maps_scratch, n_cut, S, S, 0, 0);
+        PRX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
+                           (const StageMap*)maps_scratch, ga, n_cut, S);
+    }
     PRX_LAUNCH_CHECK();
     return 0;
 }
