@@ -803,6 +803,85 @@ __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageM
     for (int c = 0; c < 3; ++c) out[c] = ((ts.acc[0][c][tid] + ts.acc[1][c][tid]) + ts.acc[2][c][tid]) + ts.acc[3][c][tid];
 }
 
+// ---- the same, ONE WAVE per tile ---------------------------------------------------------------------------------------
+// Measured (profiles/r03_cfg1_kernel_stats.csv): with 256-thread blocks the two scatter kernels still took 170-190 us, the
+// same with and without precomputed stage maps and unrolled loads -- a tile has only ~350 candidates (1.4 trips of 256
+// lanes), so a block's life is its serial chain: descriptor words -> rectangles by one lane -> barrier -> loads -> LDS adds ->
+// barrier -> store, ~10 us, with 6 blocks resident per CU.  One wave per tile quadruples the tiles in flight per CU, needs
+// no workgroup barrier at all (the wave's own LDS traffic is ordered), computes the <= 9 rectangle boxes on 9 lanes in
+// parallel, and is reproducible by construction: one accumulator, fixed candidate order, in-order LDS.
+struct WaveScatter {
+    float ua[MAXR * MAXR], ub[MAXR * MAXR], va[MAXR * MAXR], vb[MAXR * MAXR];
+    int x0[MAXR * MAXR], y0[MAXR * MAXR], bw[MAXR * MAXR], cnt[MAXR * MAXR];
+    float acc[3][TILE_W * TILE_W];
+};
+
+// lane l returns the sums of source pixels l, l + 64, l + 128, l + 192 of the tile (row-major 16 x 16)
+__device__ __forceinline__ void scatter_tile_wave(const GatherStage& st, const StageMap& sm, WaveScatter& ts, int tx0, int ty0, float (&out)[4][3]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ts.acc[c][lane + 64 * j] = 0.f;
+    if (lane < MAXR * MAXR) {                    // rectangle (i, j) = (lane % 3, lane / 3) on its own lane
+        int cnt = 0;
+        const int sx0 = max(tx0, 0), sx1 = min(tx0 + TILE_W - 1, st.Ws - 1);
+        const int sy0 = max(ty0, 0), sy1 = min(ty0 + TILE_W - 1, st.Hs - 1);
+        if (sx0 <= sx1 && sy0 <= sy1) {
+            float xa[MAXR], xb[MAXR], ya[MAXR], yb[MAXR];
+            const int nx = tile_intervals(st.mode, sx0, sx1, st.Ws, sm.ulo, sm.uhi, xa, xb);
+            const int ny = tile_intervals(st.mode, sy0, sy1, st.Hs, sm.vlo, sm.vhi, ya, yb);
+            const int i = lane % MAXR, j = lane / MAXR;
+            if (i < nx && j < ny) {
+                // static selection (no dynamically indexed register arrays)
+                const float ua = i == 0 ? xa[0] : (i == 1 ? xa[1] : xa[2]), ub = i == 0 ? xb[0] : (i == 1 ? xb[1] : xb[2]);
+                const float va = j == 0 ? ya[0] : (j == 1 ? ya[1] : ya[2]), vb = j == 0 ? yb[0] : (j == 1 ? yb[1] : yb[2]);
+                int x0, x1, y0, y1;
+                if (preimage_box(sm, ua, ub, va, vb, st.Wd, st.Hd, x0, x1, y0, y1)) {
+                    ts.ua[lane] = ua; ts.ub[lane] = ub; ts.va[lane] = va; ts.vb[lane] = vb;
+                    ts.x0[lane] = x0; ts.y0[lane] = y0; ts.bw[lane] = x1 - x0 + 1;
+                    cnt = (x1 - x0 + 1) * (y1 - y0 + 1);
+                }
+            }
+        }
+        ts.cnt[lane] = cnt;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's LDS writes above are visible to its reads below
+    const size_t plane = (size_t)st.Hd * st.Wd;
+    constexpr int U = 4;
+    for (int r = 0; r < MAXR * MAXR; ++r) {
+        const int cnt = ts.cnt[r];
+        if (cnt == 0) continue;
+        const float ua = ts.ua[r], ub = ts.ub[r], va = ts.va[r], vb = ts.vb[r];
+        const int bx0 = ts.x0[r], by0 = ts.y0[r], bw = ts.bw[r];
+        const float ibw = 1.f / (float)bw;
+        for (int k0 = lane; k0 < cnt; k0 += 64 * U) {
+            float2 q[U]; float g0[U], g1[U], g2[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int k = k0 + 64 * j;
+                q[j] = make_float2(-INFINITY, -INFINITY);
+                g0[j] = g1[j] = g2[j] = 0.f;
+                if (k < cnt) {
+                    int ky = (int)((float)k * ibw);
+                    int kx = k - ky * bw;
+                    if (kx < 0) { --ky; kx += bw; } else if (kx >= bw) { ++ky; kx -= bw; }
+                    const size_t o = (size_t)(by0 + ky) * st.Wd + (bx0 + kx);
+                    q[j] = st.uv[o];
+                    g0[j] = st.g[o]; g1[j] = st.g[plane + o]; g2[j] = st.g[2 * plane + o];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) scatter_candidate(st, ts.acc[0], ts.acc[1], ts.acc[2], tx0, ty0, ua, ub, va, vb, q[j], g0[j], g1[j], g2[j]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[j][c] = ts.acc[c][lane + 64 * j];
+}
+
 // the stage map of every cutout, once per stage (it is the same for all tiles of a cutout; built from fp64 it costs a single
 // lane ~3 us, which every one of the 196 tile blocks of a cutout used to spend on its own): maps[n] for stage 1 / 2
 __global__ void stage_map_kernel(const double* __restrict__ desc, int stage, StageMap* __restrict__ maps, int n_cut, int Wd, int Hd, int Ws, int Hs) {
@@ -901,6 +980,43 @@ __global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restric
     if (live) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) gs[(size_t)c * splane] = o[c];
+    }
+}
+
+// one wave per tile (scatter_tile_wave)
+__global__ __launch_bounds__(64) void warp_a_bwd3_kernel(const float* __restrict__ g, int Hs, int Ws,
+                                                         const double* __restrict__ desc, const float2* __restrict__ uv,
+                                                         const StageMap* __restrict__ maps, float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
+    __shared__ WaveScatter ts;
+    const int tiles = (Ws + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int tx0 = (blockIdx.x % tiles) * TILE_W, ty0 = (blockIdx.x / tiles) * TILE_W;
+    const int lane = threadIdx.x;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE1];
+    const size_t plane = (size_t)Ha * Wa, splane = (size_t)Hs * Ws;
+    const float* gi = g + (size_t)n * 3 * plane;
+    float* gs = gsrc + (size_t)n * 3 * splane;
+    if (mode == MODE_IDENT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = lane + 64 * j, sx = tx0 + (p & 15), sy = ty0 + (p >> 4);
+            if (sx < Ws && sy < Hs)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gs[(size_t)c * splane + (size_t)sy * Ws + sx] = gi[(size_t)c * plane + (size_t)sy * Wa + sx];
+        }
+        return;
+    }
+    const StageMap sm = maps[n];
+    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
+    float o[4][3];
+    scatter_tile_wave(st, sm, ts, tx0, ty0, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = lane + 64 * j, sx = tx0 + (p & 15), sy = ty0 + (p >> 4);
+        if (sx < Ws && sy < Hs)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gs[(size_t)c * splane + (size_t)sy * Ws + sx] = o[j][c];
     }
 }
 
@@ -1066,6 +1182,45 @@ __global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const 
     if (inimg) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) go[(size_t)c * aplane] = o[c];
+    }
+}
+
+// one wave per tile (scatter_tile_wave)
+__global__ __launch_bounds__(64) void warp_b_bwd3_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
+                                                         const float* __restrict__ grgb, const float2* __restrict__ uv,
+                                                         const StageMap* __restrict__ maps, float* __restrict__ ga, int n_cut, int S) {
+    __shared__ WaveScatter ts;
+    const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
+    const int tiles = (Wa + TILE_W - 1) / TILE_W;
+    const int n = blockIdx.y;
+    const int ax0 = (blockIdx.x % tiles) * TILE_W, ay0 = (blockIdx.x / tiles) * TILE_W;
+    const int lane = threadIdx.x;
+    const double* d = desc + (size_t)n * DESC_WORDS;
+    const int mode = (int)d[D_MODE2];
+    const SrcWin q = src_window(d);
+    const float* gi = (d[D_JIT] != 0.0 ? grgb : g) + (size_t)n * 3 * plane;
+    float* go = ga + (size_t)n * 3 * aplane;
+    float o[4][3];
+    if (mode == MODE_IDENT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = lane + 64 * j, ax = ax0 + (p & 15), ay = ay0 + (p >> 4), sx = ax - q.ox, sy = ay - q.oy;
+            const bool live = ax < Wa && ay < Ha && sx >= 0 && sx < q.ww && sy >= 0 && sy < q.wh && sx < S && sy < S;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[j][c] = live ? gi[(size_t)c * plane + (size_t)sy * S + sx] : 0.f;
+        }
+    } else {
+        const StageMap sm = maps[n];
+        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
+        scatter_tile_wave(st, sm, ts, ax0 - q.ox, ay0 - q.oy, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = lane + 64 * j, ax = ax0 + (p & 15), ay = ay0 + (p >> 4), sx = ax - q.ox, sy = ay - q.oy;
+        if (!(ax < Wa && ay < Ha)) continue;
+        const bool live = sx >= 0 && sx < q.ww && sy >= 0 && sy < q.wh;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[(size_t)c * aplane + (size_t)ay * Wa + ax] = live ? o[j][c] : 0.f;
     }
 }
 
@@ -1281,6 +1436,12 @@ static bool cutout_bwd_gather() {
     return v;
 }
 
+// PRX_CUTOUT_BWD=block: the 256-thread form of the scatter (one tile per workgroup, per-wave accumulator planes) for A/B
+static bool cutout_bwd_block() {
+    static const bool v = [] { const char* e = getenv("PRX_CUTOUT_BWD"); return e && e[0] == 'b'; }();
+    return v;
+}
+
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned char* mask, int C, int H, int W, int S, hipStream_t s) {
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((size_t)C * S * S)), dim3(256), 0, s, img, pooled, argmax, mask, C, H, W, S);
     PRX_LAUNCH_CHECK();
@@ -1312,8 +1473,12 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv
         PRX_REQUIRE((size_t)n_cut * sizeof(StageMap) <= (size_t)3 * Hs * Ws * sizeof(float), "warp_a_bwd: too many cutouts for the stage-map scratch");
         hipLaunchKernelGGL(stage_map_kernel, dim3(ceil_div(n_cut, 64)), dim3(64), 0, s, desc, 1, (StageMap*)gsrc, n_cut, Wa, Ha, Ws, Hs);
         PRX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
-                           gsrc_priv, n_cut, Ha, Wa);
+        if (cutout_bwd_block())
+            hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
+                               gsrc_priv, n_cut, Ha, Wa);
+        else
+            hipLaunchKernelGGL(warp_a_bwd3_kernel, dim3(tx * ty, n_cut), dim3(64), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
+                               gsrc_priv, n_cut, Ha, Wa);
     }
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(ew_grid((size_t)3 * Hs * Ws)), dim3(256), 0, s, gsrc_priv, gsrc, n_cut,
@@ -1345,8 +1510,12 @@ int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const flo
         PRX_REQUIRE(maps_scratch != nullptr && (size_t)n_cut * sizeof(StageMap) <= maps_scratch_bytes, "warp_b_bwd: stage-map scratch too small");
         hipLaunchKernelGGL(stage_map_kernel, dim3(ceil_div(n_cut, 64)), dim3(64), 0, s, desc, 2, (StageMap*)maps_scratch, n_cut, S, S, 0, 0);
         PRX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
-                           (const StageMap*)maps_scratch, ga, n_cut, S);
+        if (cutout_bwd_block())
+            hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
+                               (const StageMap*)maps_scratch, ga, n_cut, S);
+        else
+            hipLaunchKernelGGL(warp_b_bwd3_kernel, dim3(tx * ty, n_cut), dim3(64), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
+                               (const StageMap*)maps_scratch, ga, n_cut, S);
     }
     PRX_LAUNCH_CHECK();
     return 0;

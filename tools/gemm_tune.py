@@ -42,6 +42,17 @@ if len(_s.argv) > 1 and _s.argv[1] == "xcd":
             run(H * H, Co, 9 * C, (H, H, C, up), [(0, 0, 0)])
     lib.prx_gemm_tile_override(_lib.tool_ctx(), -1, 0, 1)
     _s.exit(0)
+if len(_s.argv) > 1 and _s.argv[1] == "deep":
+    # LDS ring depth x tile on the M = 3200 products of the headline's ViT: with <= 256 tiles a launch is one workgroup per CU
+    # whatever the LDS footprint, so the "3 stages halve the occupancy" argument against deep rings on 128-wide tiles is void
+    for st in (0, 2, 3, 4):
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, st)
+        print("== stages", st, "(0 = heuristic)")
+        cf = [(0, 0, 0), (128, 128, 1), (128, 64, 1), (64, 64, 1), (256, 128, 1)]
+        for (M, N, K) in [(3200, 3072, 768), (3200, 768, 3072), (3200, 2304, 768), (3200, 768, 2304), (3200, 768, 768)]:
+            run(M, N, K, None, cf)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
+    _s.exit(0)
 if len(_s.argv) > 1 and _s.argv[1] == "dbg":
     lib.prx_gemm_tile_override(_lib.tool_ctx(), -3, 0, 0)
     for dbg in (0, 1, 2, 3):
