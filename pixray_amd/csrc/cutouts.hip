@@ -1436,9 +1436,13 @@ static bool cutout_bwd_gather() {
     return v;
 }
 
-// PRX_CUTOUT_BWD=block: the 256-thread form of the scatter (one tile per workgroup, per-wave accumulator planes) for A/B
+// The scatter runs one tile per 256-thread workgroup (per-wave accumulator planes) by default; PRX_CUTOUT_BWD=wave selects the
+// one-wave-per-tile form.  Measured at the headline (profiles/r03_cfg1_kernel_stats.csv, r03b): stage B / stage A
+// 187 / 170 us (workgroup), 209 / 184 us (wave), 150 / 255 us (round-2 gather): neither more tiles in flight nor the removed
+// barriers and serial set-up moved it -- what is left is the ~12 conflicting ds_add_f32 per candidate (4 taps x 3 channels,
+// neighbouring destination pixels share taps), i.e. the LDS atomic rate.
 static bool cutout_bwd_block() {
-    static const bool v = [] { const char* e = getenv("PRX_CUTOUT_BWD"); return e && e[0] == 'b'; }();
+    static const bool v = [] { const char* e = getenv("PRX_CUTOUT_BWD"); return !(e && e[0] == 'w'); }();
     return v;
 }
 
