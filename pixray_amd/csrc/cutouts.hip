@@ -18,6 +18,7 @@
 #include "cutouts.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -512,6 +513,7 @@ struct GatherStage {
     int Ws, Hs;            // source image the taps index (the stage-B window, or the whole stage-A source)
     const float* g;        // destination-side gradient planes of this cutout, [3][Hd][Wd]
     const float2* uv;      // the forward's raw source coordinate of every destination pixel of this cutout, [Hd][Wd] (uv_kernel)
+    unsigned long long* dbg = nullptr;   // PRX_CUTOUT_DBG=1: {candidates visited, rectangles, candidates inside their rectangle, with a tap in the tile}
 };
 
 // LDS staging of one block's candidates: neighbouring source pixels share almost all of their destination candidates, so
@@ -725,14 +727,14 @@ struct TileScatter {
 };
 
 // one candidate: destination pixel with raw coordinate q and gradient (g0, g1, g2) -> LDS accumulator of the tile
-__device__ __forceinline__ void scatter_candidate(const GatherStage& st, float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
-                                                  int tx0, int ty0, float ua, float ub, float va, float vb, float2 q, float g0, float g1, float g2) {
-    if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return;
+__device__ __forceinline__ int scatter_candidate(const GatherStage& st, float* __restrict__ a0, float* __restrict__ a1, float* __restrict__ a2,
+                                                 int tx0, int ty0, float ua, float ub, float va, float vb, float2 q, float g0, float g1, float g2) {
+    if (!(q.x >= ua && q.x < ub && q.y >= va && q.y < vb)) return 0;
     const Taps t = make_taps(q.x, q.y, st.Ws, st.Hs, st.mode);          // the forward's own taps
     const int lx = t.x0 - tx0, ly = t.y0 - ty0;                          // north-west tap inside the tile?
     const bool cx0 = t.vx0 && lx >= 0 && lx < TILE_W, cx1 = t.vx1 && lx + 1 >= 0 && lx + 1 < TILE_W;
     const bool cy0 = t.vy0 && ly >= 0 && ly < TILE_W, cy1 = t.vy1 && ly + 1 >= 0 && ly + 1 < TILE_W;
-    if (!((cx0 || cx1) && (cy0 || cy1))) return;
+    if (!((cx0 || cx1) && (cy0 || cy1))) return 1;
     const float e = 1.f - t.wx, s_ = 1.f - t.wy;                        // sample_plane's weights, same products
     const float w00 = s_ * e, w01 = s_ * t.wx, w10 = t.wy * e, w11 = t.wy * t.wx;
     const int p00 = ly * TILE_W + lx;
@@ -740,6 +742,7 @@ __device__ __forceinline__ void scatter_candidate(const GatherStage& st, float* 
     if (cx1 && cy0) { atomicAdd(&a0[p00 + 1], g0 * w01); atomicAdd(&a1[p00 + 1], g1 * w01); atomicAdd(&a2[p00 + 1], g2 * w01); }
     if (cx0 && cy1) { atomicAdd(&a0[p00 + TILE_W], g0 * w10); atomicAdd(&a1[p00 + TILE_W], g1 * w10); atomicAdd(&a2[p00 + TILE_W], g2 * w10); }
     if (cx1 && cy1) { atomicAdd(&a0[p00 + TILE_W + 1], g0 * w11); atomicAdd(&a1[p00 + TILE_W + 1], g1 * w11); atomicAdd(&a2[p00 + TILE_W + 1], g2 * w11); }
+    return 2;
 }
 
 // all contributions to the 16 x 16 source tile at (tx0, ty0) (source-window coordinates); thread t returns the sums of its own
@@ -764,6 +767,12 @@ __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageM
                 }
         }
         ts.nrect = n;
+        if (st.dbg) {
+            unsigned long long tot = 0;
+            for (int r = 0; r < n; ++r) tot += (unsigned long long)ts.cnt[r];
+            atomicAdd(&st.dbg[0], tot);
+            atomicAdd(&st.dbg[1], (unsigned long long)n);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -774,6 +783,7 @@ __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageM
     const int nrect = ts.nrect;
     float* a0 = ts.acc[wave][0]; float* a1 = ts.acc[wave][1]; float* a2 = ts.acc[wave][2];
     constexpr int U = 4;                 // candidates per thread per trip: their 16 loads are in flight together
+    int n_in = 0, n_tap = 0;
     for (int r = 0; r < nrect; ++r) {
         const float ua = ts.ua[r], ub = ts.ub[r], va = ts.va[r], vb = ts.vb[r];
         const int bx0 = ts.x0[r], by0 = ts.y0[r], bw = ts.bw[r], cnt = ts.cnt[r];
@@ -795,9 +805,13 @@ __device__ __forceinline__ void scatter_tile(const GatherStage& st, const StageM
                 }
             }
 #pragma unroll
-            for (int j = 0; j < U; ++j) scatter_candidate(st, a0, a1, a2, tx0, ty0, ua, ub, va, vb, q[j], g0[j], g1[j], g2[j]);
+            for (int j = 0; j < U; ++j) {
+                const int code = scatter_candidate(st, a0, a1, a2, tx0, ty0, ua, ub, va, vb, q[j], g0[j], g1[j], g2[j]);
+                n_in += code >= 1; n_tap += code == 2;
+            }
         }
     }
+    if (st.dbg) { atomicAdd(&st.dbg[2], (unsigned long long)n_in); atomicAdd(&st.dbg[3], (unsigned long long)n_tap); }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = ((ts.acc[0][c][tid] + ts.acc[1][c][tid]) + ts.acc[2][c][tid]) + ts.acc[3][c][tid];
@@ -953,7 +967,8 @@ __global__ __launch_bounds__(256) void warp_a_bwd_kernel(const float* __restrict
 // the same in the tile-owned scatter form (scatter_tile)
 __global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restrict__ g, int Hs, int Ws,
                                                           const double* __restrict__ desc, const float2* __restrict__ uv,
-                                                          const StageMap* __restrict__ maps, float* __restrict__ gsrc, int n_cut, int Ha, int Wa) {
+                                                          const StageMap* __restrict__ maps, float* __restrict__ gsrc, int n_cut, int Ha, int Wa,
+                                                          unsigned long long* dbg) {
     __shared__ TileScatter ts;
     const int tiles = (Ws + TILE_W - 1) / TILE_W;
     const int n = blockIdx.y;
@@ -974,7 +989,7 @@ __global__ __launch_bounds__(256) void warp_a_bwd2_kernel(const float* __restric
         return;
     }
     const StageMap sm = maps[n];          // uniform address: scalar loads
-    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane};
+    GatherStage st{d + D_M1, (int)d[D_GRID1], mode, Wa, Ha, Ws, Hs, gi, uv + (size_t)n * plane, dbg};
     float o[3];
     scatter_tile(st, sm, ts, tx0, ty0, o);
     if (live) {
@@ -1151,7 +1166,8 @@ __global__ __launch_bounds__(256) void warp_b_bwd_kernel(int Ha, int Wa, const d
 // pass 2 in the tile-owned scatter form (scatter_tile)
 __global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const double* __restrict__ desc, const float* __restrict__ g,
                                                           const float* __restrict__ grgb, const float2* __restrict__ uv,
-                                                          const StageMap* __restrict__ maps, float* __restrict__ ga, int n_cut, int S) {
+                                                          const StageMap* __restrict__ maps, float* __restrict__ ga, int n_cut, int S,
+                                                          unsigned long long* dbg) {
     __shared__ TileScatter ts;
     const size_t plane = (size_t)S * S, aplane = (size_t)Ha * Wa;
     const int tiles = (Wa + TILE_W - 1) / TILE_W;
@@ -1175,7 +1191,7 @@ __global__ __launch_bounds__(256) void warp_b_bwd2_kernel(int Ha, int Wa, const 
         }
     } else {
         const StageMap sm = maps[n];
-        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane};
+        GatherStage st{d + D_M2, (int)d[D_GRID2], mode, S, S, q.ww, q.wh, gi, uv + (size_t)n * plane, dbg ? dbg + 4 : nullptr};
         scatter_tile(st, sm, ts, ax0 - q.ox, ay0 - q.oy, o);
         if (!live) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
     }
@@ -1436,6 +1452,26 @@ static bool cutout_bwd_gather() {
     return v;
 }
 
+// PRX_CUTOUT_DBG=1: count the scatter's work (candidates visited / inside their rectangle / contributing) per stage and print
+// the totals when the process exits (diagnostic; adds global atomics, so do not time with it on)
+static unsigned long long* cutout_dbg() {
+    static unsigned long long* buf = [] () -> unsigned long long* {
+        const char* e = getenv("PRX_CUTOUT_DBG");
+        if (!(e && e[0] == '1')) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(p, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        static unsigned long long* keep = (unsigned long long*)p;
+        atexit([] {
+            unsigned long long h[8];
+            if (hipMemcpy(h, keep, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[prx cutout scatter] stage A: visited %llu rects %llu in-rect %llu contributing %llu | stage B: visited %llu rects %llu in-rect %llu contributing %llu\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        });
+        return keep;
+    }();
+    return buf;
+}
+
 // The scatter runs one tile per 256-thread workgroup (per-wave accumulator planes) by default; PRX_CUTOUT_BWD=wave selects the
 // one-wave-per-tile form.  Measured at the headline (profiles/r03_cfg1_kernel_stats.csv, r03b): stage B / stage A
 // 187 / 170 us (workgroup), 209 / 184 us (wave), 150 / 255 us (round-2 gather): neither more tiles in flight nor the removed
@@ -1479,7 +1515,7 @@ int prx_warp_a_bwd(const float* g, int Hs, int Ws, const double* desc, float* uv
         PRX_LAUNCH_CHECK();
         if (cutout_bwd_block())
             hipLaunchKernelGGL(warp_a_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
-                               gsrc_priv, n_cut, Ha, Wa);
+                               gsrc_priv, n_cut, Ha, Wa, cutout_dbg());
         else
             hipLaunchKernelGGL(warp_a_bwd3_kernel, dim3(tx * ty, n_cut), dim3(64), 0, s, g, Hs, Ws, desc, (const float2*)uv, (const StageMap*)gsrc,
                                gsrc_priv, n_cut, Ha, Wa);
@@ -1516,7 +1552,7 @@ int prx_warp_b_bwd(const float* a, int Ha, int Wa, const double* desc, const flo
         PRX_LAUNCH_CHECK();
         if (cutout_bwd_block())
             hipLaunchKernelGGL(warp_b_bwd2_kernel, dim3(tx * ty, n_cut), dim3(256), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
-                               (const StageMap*)maps_scratch, ga, n_cut, S);
+                               (const StageMap*)maps_scratch, ga, n_cut, S, cutout_dbg());
         else
             hipLaunchKernelGGL(warp_b_bwd3_kernel, dim3(tx * ty, n_cut), dim3(64), 0, s, Ha, Wa, desc, g, grgb, (const float2*)uv,
                                (const StageMap*)maps_scratch, ga, n_cut, S);
