@@ -44,6 +44,7 @@ def make_saturation_loss(device):
 
     class SaturationLoss(LossInterface):
         needs_full_batch = True          # std over ALL cutout pixels: scored on the gathered batch when sharded
+        supports_graph_replay = True     # device tensors in, device tensors out: no host draw, upload or branch
 
         def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
             res = []
@@ -130,8 +131,10 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the extra legs (headline config, 1 GPU): it/s of the other precisions and dL/dz parity of every mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the iteration from a captured hipGraph (measured neutral on MI355X: the loop is GPU-bound)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the iteration from a captured hipGraph.  Default: on for cfg3 (its StyleLoss plugin is bound by the "
+                         "host's launch rate when launched eagerly), off for cfg1 / cfg2 (measured neutral: GPU-bound)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-sample-cutn", type=int, default=None)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -185,7 +188,9 @@ def main():
 
     it = 0
     graphed = False
-    if args.graph and world == 1:
+    if args.graph is None:
+        args.graph = args.config == "cfg3"
+    if args.graph and world == 1:        # N > 1 stays on eager launches (collectives inside a capture: not validated on a node)
         graphed = sess.enable_graph(warmup=max(warmup - 1, 1))      # warm-up iterations run inside
         it = sess.cur_iteration
     for _ in range(0 if graphed else warmup):

@@ -101,6 +101,29 @@ class HipAdam(torch.optim.Optimizer):
         self._hyper = self._ring.dev if self._ring is not None else torch.zeros(4, dtype=torch.float32, device=p.device)
         self.clamped_last_step = False   # did the last step() apply the fused clip_z bounds?
 
+    @classmethod
+    def from_adam(cls, opt: "torch.optim.Adam"):
+        """A plain `torch.optim.Adam` over ONE group of device tensors (what a drawer plugin's `get_opts` returns: FftDrawer,
+        fftdrawer.py:65-69) as the replayable fused kernel: same update rule, moments and step count carried over.  None
+        when the optimiser uses anything the kernel does not implement."""
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("weight_decay", 0) != 0 or g.get("differentiable") or \
+                isinstance(g["lr"], torch.Tensor) or not all(p.is_cuda and p.dtype == torch.float32 for p in g["params"]):
+            return None
+        new = cls(g["params"], lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])
+        steps = set()
+        for p in g["params"]:
+            st = opt.state.get(p)
+            if st:
+                steps.add(int(st["step"]))
+                new.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"]}
+        if len(steps) > 1 or (steps and len(new.state) != len(g["params"])):
+            return None                      # parameters at different step counts: one shared bias correction cannot serve them
+        new._t = steps.pop() if steps else 0
+        return new
+
     def prepare_step(self):
         """host side of the next step(): advance t and stage {lr/bc1, sqrt(bc2)} (stream-ordered H2D)"""
         g = self.param_groups[0]
@@ -414,6 +437,12 @@ class Session:
                 mk.prepare(iteration=it, fill=fill)
             else:
                 mk.iteration, mk.fill = it, fill
+        # custom losses with a host half (StyleLoss: numpy sampling tables).  Only once static buffers are on: in plain eager
+        # use a plugin draws inside get_loss, where the reference draws -- the order of numpy's global stream across plugins
+        # is then the reference's by construction.
+        for t in self.custom_losses:
+            if getattr(t["loss"], "graph_capturable", False) and hasattr(t["loss"], "host_prep"):
+                t["loss"].host_prep(self.args, it)
         self._host_ready = True
 
     def _device_step(self):
@@ -454,23 +483,44 @@ class Session:
                 mk._prepared = False
 
     # ------------------------------------------------------------------ hipGraph capture
+    def _custom_graph_state(self, it):
+        """what the custom losses bake into a captured iteration besides tensor values (e.g. StyleLoss's skip / every
+        schedule): a replay is valid only while this is unchanged"""
+        return tuple(t["loss"].graph_state(self.args, it) if hasattr(t["loss"], "graph_state") else None for t in self.custom_losses)
+
     def enable_graph(self, warmup: int = 3):
-        """Capture the device side of one iteration (≈590 kernel launches) in a hipGraph and replay it from then on.
-        Host-drawn inputs reach the graph through fixed device buffers (cutout descriptors, Adam scalars).  Falls back
-        to eager launches when something in the session cannot be captured (custom optimisers, batches > 1, ...)."""
-        z = self.drawer.get_z()
-        if z is None or not (z.is_cuda and all(isinstance(o, HipAdam) for o in self.opts)) or self.batches != 1 or self.auto_stop:
+        """Capture the device side of one iteration (≈590 kernel launches for the headline; ≈7 000 for configs[3], whose
+        StyleLoss plugin is otherwise bound by the host's launch rate) in a hipGraph and replay it from then on.
+        Host-drawn inputs reach the graph through fixed device buffers (cutout descriptors, Adam scalars, a plugin's sampling
+        tables: `host_prep`).  Falls back to eager launches when something in the session cannot be captured (foreign
+        optimisers, plugins that do not declare `supports_graph_replay`, batches > 1, ...)."""
+        if self.batches != 1 or self.auto_stop or not self.opts:
+            return False
+        params = [p for o in self.opts for g in o.param_groups for p in g["params"]]
+        if not params or not all(p.is_cuda for p in params):
+            return False
+        dev = params[0].device
+        # the fused Adam kernel reads its step scalars from a fixed device buffer; a drawer plugin's plain torch Adam (FftDrawer)
+        # keeps them on the host, so it is swapped for the kernel (same rule, state carried over) -- for a replayed session only
+        opts = [o if isinstance(o, HipAdam) else HipAdam.from_adam(o) for o in self.opts]
+        if any(o is None for o in opts):
             return False
         if getattr(self.args, "transparent", False):      # the RGBA squash uses this iteration's host-drawn gray as a constant
             return False
         # image / spot prompts go through the cached-transform path, which stages a fresh descriptor table per call
         if any(self.pmsImageTable.values()) or any(self.spotPmsTable.values()) or any(self.spotOffPmsTable.values()):
             return False
-        dev = z.device
+        if not all(getattr(t["loss"], "supports_graph_replay", False) for t in self.custom_losses):
+            return False                 # a plugin's get_loss may draw, upload or branch on the host: it has to say that it does not
         for mk in self.cutoutsTable.values():
             if not hasattr(mk, "enable_static_buffers") or getattr(mk, "fixed_params", None) is not None:
                 return False
+        for mk in self.cutoutsTable.values():
             mk.enable_static_buffers(dev)
+        for t in self.custom_losses:
+            if hasattr(t["loss"], "enable_static_buffers"):
+                t["loss"].enable_static_buffers(dev)
+        self.opts = opts
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -488,11 +538,24 @@ class Session:
         for o in self.opts:
             o.prepare_step()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._device_step()
-        # the capture pass does not execute: its staged inputs (cutout descriptors, Adam scalars) are consumed by the first
-        # replay, i.e. by the next train() call, which therefore must not draw again
+        try:
+            with torch.cuda.graph(graph):
+                self._device_step()
+        except Exception as e:           # an op that cannot be captured (a sync, a pageable copy, ...): stay on eager launches
+            import warnings
+            warnings.warn(f"hipGraph capture of the iteration failed ({type(e).__name__}: {e}); staying on eager launches")
+            torch.cuda.synchronize(dev)
+            for o in self.opts:          # the aborted capture consumed the staged step: rewind it, the eager step stages again
+                o._t -= 1
+                o._pending = False
+                for st in o.state.values():
+                    st["step"] = o._t
+            self._drop_graph()
+            return False
+        # the capture pass does not execute: its staged inputs (cutout descriptors, Adam scalars, sampling tables) are
+        # consumed by the first replay, i.e. by the next train() call, which therefore must not draw again
         self._graph = graph
+        self._graph_state = self._custom_graph_state(self.cur_iteration)
         self._staged_for_replay = True
         return True
 
@@ -526,6 +589,9 @@ class Session:
                 self.re_average_z()
             if cur_it in self.learning_rate_drops:
                 rebuild = True
+            if self._graph is not None and not getattr(self, "_staged_for_replay", False) and \
+                    self._graph_state != self._custom_graph_state(cur_it):
+                self._drop_graph()       # a plugin's schedule changed what the captured iteration baked in: eager from here
             if self._graph is not None:
                 if getattr(self, "_staged_for_replay", False):
                     self._staged_for_replay = False     # inputs staged by enable_graph for the captured iteration

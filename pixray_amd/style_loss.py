@@ -101,11 +101,31 @@ class Vgg16Extractor:
         return sample_hypercolumns(self(X), samps)
 
 
-def sample_hypercolumns(feat: Sequence[torch.Tensor], samps: int) -> torch.Tensor:
-    """`forward_samples_hypercolumn` (StyleLoss.py:49-81) on channels-last maps: `samps` random pixel positions of the
-    input, followed down the pyramid by halving (the reference halves whenever a map is smaller than the one before it),
-    one column of all 2179 channels per position -> [1, 2179, samps], detached."""
-    H, W = feat[0].shape[1], feat[0].shape[2]
+def vgg_map_shapes(H: int, W: int):
+    """(h, w) of the extractor's ten maps for an H x W input (torchvision VGG16 `features`, 2x2/2 max pools, floor):
+    input, relu1_1, relu1_2 | relu2_1, relu2_2 | relu3_1, relu3_2, relu3_3 | relu4_3 | relu5_3"""
+    out = [(H, W)] * 3
+    h, w = H // 2, W // 2
+    out += [(h, w)] * 2
+    h, w = h // 2, w // 2
+    out += [(h, w)] * 3
+    h, w = h // 2, w // 2
+    out += [(h, w)]
+    h, w = h // 2, w // 2
+    out += [(h, w)]
+    return out
+
+
+def _map_shapes(feat: Sequence[torch.Tensor]):
+    return [(int(f.shape[1]), int(f.shape[2])) for f in feat]
+
+
+def _draw_hypercolumn_rows(shapes, samps: int) -> np.ndarray:
+    """The host half of `forward_samples_hypercolumn` (StyleLoss.py:49-81): `samps` random pixel positions of the input,
+    followed down the pyramid by halving (the reference halves whenever a map is smaller than the one before it) -> the row
+    of every position in every map's [h*w, C] matrix, int64 [L, samples].  Consumes numpy's global generator exactly as the
+    reference does; depends on the map SHAPES only, so it can run before the maps exist (`draw_plan`)."""
+    H, W = shapes[0]
     # The reference shuffles the [H*W, 2] coordinate table in place and keeps the first `samps` rows.  numpy's row shuffle
     # of a 2-D array is an interpreted per-row swap (0.3 s at 512x512); shuffling a 1-D index array walks the same
     # Fisher-Yates loop with the same `random_interval` draws in C (tests/test_host_logic.py pins both the permutation and
@@ -117,17 +137,27 @@ def sample_hypercolumns(feat: Sequence[torch.Tensor], samps: int) -> torch.Tenso
     # meshgrid(arange(H), arange(W)) is [W, H]-shaped ('xy' indexing): flat position p holds (p % H, p // H)
     xx = (idx % H).astype(np.int64)
     yy = (idx // H).astype(np.int64)
-    rows = np.empty((len(feat), samples), np.int64)
-    for i, layer in enumerate(feat):
-        if i > 0 and layer.shape[1] < feat[i - 1].shape[1]:
+    rows = np.empty((len(shapes), samples), np.int64)
+    for i, (h, w) in enumerate(shapes):
+        if i > 0 and h < shapes[i - 1][0]:
             xx = xx / 2.0
             yy = yy / 2.0
-        xx = np.clip(xx, 0, layer.shape[1] - 1).astype(np.int32)
-        yy = np.clip(yy, 0, layer.shape[2] - 1).astype(np.int32)
-        rows[i] = xx.astype(np.int64) * layer.shape[2] + yy.astype(np.int64)
-    rows_d = _upload(rows, feat[0].device)
-    cols = [layer.reshape(-1, layer.shape[3]).index_select(0, rows_d[i]).detach() for i, layer in enumerate(feat)]   # [samples, C]
+        xx = np.clip(xx, 0, h - 1).astype(np.int32)
+        yy = np.clip(yy, 0, w - 1).astype(np.int32)
+        rows[i] = xx.astype(np.int64) * w + yy.astype(np.int64)
+    return rows
+
+
+def _gather_hypercolumns(feat: Sequence[torch.Tensor], rows_d: torch.Tensor) -> torch.Tensor:
+    """the device half: one column of all 2179 channels per drawn position -> [1, 2179, n], detached"""
+    cols = [layer.reshape(-1, layer.shape[3]).index_select(0, rows_d[i]).detach() for i, layer in enumerate(feat)]   # [n, C]
     return torch.cat(cols, 1).t().unsqueeze(0).contiguous()
+
+
+def sample_hypercolumns(feat: Sequence[torch.Tensor], samps: int) -> torch.Tensor:
+    """`forward_samples_hypercolumn` (StyleLoss.py:49-81) on channels-last maps -> [1, 2179, samps], detached"""
+    rows = _draw_hypercolumn_rows(_map_shapes(feat), samps)
+    return _gather_hypercolumns(feat, _upload(rows, feat[0].device))
 
 
 # ---------------------------------------------------------------------------------------------- image pyramid
@@ -173,17 +203,15 @@ def _sample_grid(h: int, w: int):
     return xx.flatten(), xy.flatten()
 
 
-def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Tensor], xx, xy):
-    """`spatial_feature_extract` (StyleLoss.py:169-223): bilinear samples of every map of both feature lists at the same
-    positions (halved whenever the resolution drops), concatenated over channels, plus the two (finally halved) coordinate
-    channels -> two [1, 2181, n, 1] tensors."""
-    dev = feat_a[0].device
-    L, n = len(feat_a), len(xx)
+def _draw_bilinear_tables(shapes, xx, xy):
+    """The host half of `spatial_feature_extract` (StyleLoss.py:169-223): for every map the four tap rows and tap weights of
+    each position (halved whenever the resolution drops), then the two (finally halved) coordinate channels ->
+    rows int64 [L, 4, n], wts fp32 [4L+2, n].  No random draws; depends on the map shapes only."""
+    L, n = len(shapes), len(xx)
     rows = np.empty((L, 4, n), np.int64)
     wts = np.empty((L * 4 + 2, n), np.float32)        # per layer w00 w01 w10 w11, then the two coordinate channels
-    for i in range(L):
-        fa = feat_a[i]
-        if i > 0 and feat_a[i - 1].shape[1] > fa.shape[1]:
+    for i, (hh, ww) in enumerate(shapes):
+        if i > 0 and shapes[i - 1][0] > hh:
             xx = xx / 2.0
             xy = xy / 2.0
         xxm = np.floor(xx).astype(np.float32)
@@ -194,7 +222,6 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
         wts[4 * i + 1] = (1. - xxr) * xyr
         wts[4 * i + 2] = xxr * (1. - xyr)
         wts[4 * i + 3] = xxr * xyr
-        hh, ww = fa.shape[1], fa.shape[2]
         xi = np.clip(xxm.astype(np.int32), 0, hh - 1).astype(np.int64)
         yi = np.clip(xym.astype(np.int32), 0, ww - 1).astype(np.int64)
         xi1, yi1 = np.clip(xi + 1, 0, hh - 1), np.clip(yi + 1, 0, ww - 1)
@@ -204,8 +231,14 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
         rows[i, 3] = xi1 * ww + yi1
     wts[4 * L] = np.asarray(xx, dtype=np.float32)
     wts[4 * L + 1] = np.asarray(xy, dtype=np.float32)
-    rows_d = _upload(rows, dev)                             # two stream-ordered uploads for the whole pyramid
-    wts_d = _upload(wts, dev)                               # [4L+2, n]
+    return rows, wts
+
+
+def _bilinear_columns_dev(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Tensor], rows_d, wts_d):
+    """The device half: bilinear samples of every map of both feature lists at the tabulated positions, concatenated over
+    channels, plus the two coordinate channels -> two [1, 2181, n, 1] tensors."""
+    dev = feat_a[0].device
+    L = len(feat_a)
     if dev.type == "cuda":
         # one gather launch per feature list (and one scatter launch in its backward) instead of ~11 torch ops per map:
         # the host-side launch cost of the composed form bounded the whole configs[3] iteration.  Device tensors ALWAYS take
@@ -231,6 +264,66 @@ def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Ten
     a = torch.cat(ca + [cx, cy], 1).t()[None, :, :, None]
     b = torch.cat(cb + [cx, cy], 1).t()[None, :, :, None]
     return a, b
+
+
+def _bilinear_columns(feat_a: Sequence[torch.Tensor], feat_b: Sequence[torch.Tensor], xx, xy):
+    """`spatial_feature_extract` (StyleLoss.py:169-223) -> two [1, 2181, n, 1] tensors"""
+    rows, wts = _draw_bilinear_tables(_map_shapes(feat_a), xx, xy)
+    dev = feat_a[0].device
+    return _bilinear_columns_dev(feat_a, feat_b, _upload(rows, dev), _upload(wts, dev))   # two stream-ordered uploads
+
+
+# ---------------------------------------------------------------------------------------------- the draws of one evaluation
+STYLE_DRAWS, STYLE_SAMPLES, PAIR_SAMPLES, EVALUATIONS = 5, 1000, 1024, 3      # StyleLoss.py:357-362, 330, 372
+
+
+def loss_scales(H: int, W: int):
+    """StyleLoss.py:399-403: coarse to fine over the power-of-two scales whose short side keeps >= 33 px"""
+    return [2 ** s for s in range(10) if min(H, W) // (2 ** s) >= 33][::-1]
+
+
+class ScaleDraws:
+    """the host-drawn tables of one scale: `style_rows` int64 [L, 5*1000] (the five style hyper-column draws side by side)
+    and, per evaluation of the refolded image, the bilinear (rows, wts) pair.  Entries are numpy arrays until `to_device`
+    (or a `StyleLoss` staging ring) replaces them with device tensors."""
+
+    def __init__(self, style_rows, pairs):
+        self.style_rows = style_rows
+        self.pairs = pairs
+
+    def tables(self):
+        return [self.style_rows] + [t for pr in self.pairs for t in pr]
+
+    @staticmethod
+    def from_tables(tables):
+        return ScaleDraws(tables[0], [(tables[1 + 2 * k], tables[2 + 2 * k]) for k in range((len(tables) - 1) // 2)])
+
+
+def draw_plan(H: int, W: int, style_h: int, style_w: int) -> List[ScaleDraws]:
+    """Every table one `strotss_loss` evaluation of an H x W image (style image style_h x style_w) takes from numpy's global
+    generator, drawn in the reference's order -- per scale: five shuffles of the style positions (StyleLoss.py:357-362), the
+    sampling grid's two offsets (153-167), then a reshuffle of the grid's x and y lists before the 2nd and the 3rd evaluation
+    (376-379).  All of it depends on tensor SHAPES only, which is what lets the host make an iteration's draws ahead of the
+    device work (and lets the device work be captured in a hipGraph that reads the tables from fixed buffers)."""
+    plan = []
+    for scale in loss_scales(H, W):
+        s_shapes = vgg_map_shapes(style_h // scale, style_w // scale)
+        style_rows = np.concatenate([_draw_hypercolumn_rows(s_shapes, STYLE_SAMPLES) for _ in range(STYLE_DRAWS)], axis=1)
+        c_shapes = vgg_map_shapes(H // scale, W // scale)
+        xx, xy = _sample_grid(*c_shapes[0])
+        pairs = []
+        for it in range(EVALUATIONS):
+            if it != 0:
+                np.random.shuffle(xx)
+                np.random.shuffle(xy)
+            pairs.append(_draw_bilinear_tables(c_shapes, xx[:PAIR_SAMPLES], xy[:PAIR_SAMPLES]))
+        plan.append(ScaleDraws(style_rows, pairs))
+    return plan
+
+
+def plan_to_device(plan: List[ScaleDraws], device) -> List[ScaleDraws]:
+    """stream-ordered uploads of a drawn plan (eager launches; a graph-replayed session stages through fixed buffers instead)"""
+    return [ScaleDraws.from_tables([_upload(t, device) for t in sd.tables()]) for sd in plan]
 
 
 # ---------------------------------------------------------------------------------------------- distances and losses
@@ -287,10 +380,9 @@ def _moment_loss(a, b):
     return loss + torch.abs(cov_x - cov_y).mean()
 
 
-def _pair_loss(feat_result, feat_content, feat_style, xx, xy, content_weight, moment_weight=1.0):
-    """`calculate_loss` (StyleLoss.py:325-347)"""
-    n = 1024
-    res, con = _bilinear_columns(feat_result, feat_content, xx[:n], xy[:n])
+def _pair_loss(feat_result, feat_content, feat_style, rows_d, wts_d, content_weight, moment_weight=1.0):
+    """`calculate_loss` (StyleLoss.py:325-347) at the tabulated 1024 positions"""
+    res, con = _bilinear_columns_dev(feat_result, feat_content, rows_d, wts_d)
     loss_content = _self_similarity_loss(res, con)
     sty = feat_style.view(1, feat_style.shape[1], -1, 1)
     loss_remd = _remd(res[:, :N_FEATURE_CHANNELS], sty[:, :N_FEATURE_CHANNELS])
@@ -300,43 +392,60 @@ def _pair_loss(feat_result, feat_content, feat_style, xx, xy, content_weight, mo
     return (content_weight * loss_content + loss_style) / (content_weight + 1.0 + moment_weight)
 
 
-def _scale_loss(result, content, style, content_weight, lr, extractor, style_maps=None, recompute=False):
+def _check_shapes(feat, H, W, what):
+    if _map_shapes(feat) != vgg_map_shapes(H, W):
+        raise ValueError(f"StyleLoss: the extractor's {what} maps {_map_shapes(feat)} are not VGG16's for a {H}x{W} input "
+                         f"{vgg_map_shapes(H, W)}; the sampling tables are drawn from the VGG16 shapes")
+
+
+def _scale_loss(result, content, style, content_weight, lr, extractor, draws: ScaleDraws, style_maps=None, recompute=False):
     """`scale_loss` (StyleLoss.py:349-389): 5 x 1000 style hyper-columns, one sampling grid, three evaluations of the
-    refolded image (the grid is reshuffled before the 2nd and 3rd).  The reference runs VGG16 on the (frozen) style image
-    for each of the 5 draws; the maps are the same every time, so they are computed once (`style_maps`: the caller's copy
-    from an earlier iteration) and only the sampling is repeated.  `recompute=True` is the reference's schedule verbatim (one
+    refolded image (the grid is reshuffled before the 2nd and 3rd) -- the positions come drawn in `draws` (`draw_plan`).
+    The reference runs VGG16 on the (frozen) style image for each of the 5 draws; the maps are the same every time, so they
+    are computed once (`style_maps`: the caller's copy from an earlier iteration) and the five draws are gathered in one pass
+    (columns in draw order, as the reference concatenates them).  `recompute=True` is the reference's schedule verbatim (one
     VGG pass per draw): what bench.py's CPU-baseline leg times."""
     pyramid = _laplace_pyramid(result, 5)
     feat_content = extractor(content)
+    _check_shapes(feat_content, content.shape[2], content.shape[3], "content")
     if recompute:
         with torch.no_grad():
-            feat_style = torch.cat([extractor.forward_samples_hypercolumn(style, samps=1000) for _ in range(5)], dim=2)
+            n = draws.style_rows.shape[1] // STYLE_DRAWS
+            feat_style = torch.cat([_gather_hypercolumns(extractor(style), draws.style_rows[:, k * n:(k + 1) * n])
+                                    for k in range(STYLE_DRAWS)], dim=2)
     else:
         if style_maps is None:
             with torch.no_grad():
                 style_maps = [f.detach() for f in extractor(style)]
-        feat_style = torch.cat([sample_hypercolumns(style_maps, 1000) for _ in range(5)], dim=2)
-    xx, xy = _sample_grid(feat_content[0].shape[1], feat_content[0].shape[2])
+        _check_shapes(style_maps, style.shape[2], style.shape[3], "style")
+        with torch.no_grad():
+            feat_style = _gather_hypercolumns(style_maps, draws.style_rows)
     total = 0.0
-    for it in range(3):
+    for it in range(EVALUATIONS):
         stylized = _fold_pyramid(pyramid)
-        if it != 0:
-            np.random.shuffle(xx)
-            np.random.shuffle(xy)
-        total = total + _pair_loss(extractor(stylized), feat_content, feat_style, xx, xy, content_weight) * lr
+        rows_d, wts_d = draws.pairs[it]
+        total = total + _pair_loss(extractor(stylized), feat_content, feat_style, rows_d, wts_d, content_weight) * lr
     return total
 
 
-def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None, style_cache=None, recompute=False):
+def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None, style_cache=None, recompute=False, plan=None):
     """`strotss_loss` (StyleLoss.py:392-431): coarse-to-fine over the scales whose short side is >= 33 px; the running
     `result` image is the upsampled previous result plus the Laplacian of the content at that scale; only the finest scale
-    carries weight 1 (the others 2e-3), the content weight halves per scale"""
+    carries weight 1 (the others 2e-3), the content weight halves per scale.  `plan`: this evaluation's sampling tables
+    already on the device (`draw_plan` + `plan_to_device`, or a StyleLoss staging ring); drawn here when absent.
+    `style_cache` may also hold the resized style image per scale (a frozen input: resized once)."""
     H, W = out_tensor.shape[2], out_tensor.shape[3]
-    scales = [2 ** s for s in range(10) if min(H, W) // (2 ** s) >= 33][::-1]
+    scales = loss_scales(H, W)
+    if plan is None:
+        plan = plan_to_device(draw_plan(H, W, style_tensor.shape[2], style_tensor.shape[3]), out_tensor.device)
     total, lr, result = 0.0, 2e-3, None
-    for scale in scales:
+    for scale, draws in zip(scales, plan):
         content = _resample(out_tensor, [H // scale, W // scale])
-        style = _resample(style_tensor, [style_tensor.shape[2] // scale, style_tensor.shape[3] // scale])
+        style = style_cache.get(("image", scale)) if style_cache is not None else None
+        if style is None:
+            style = _resample(style_tensor, [style_tensor.shape[2] // scale, style_tensor.shape[3] // scale])
+            if style_cache is not None and not style_tensor.requires_grad:
+                style_cache[("image", scale)] = style
         if scale == scales[0]:
             result = _laplacian(content) + style.mean(2, keepdim=True).mean(3, keepdim=True)
         elif scale == scales[-1]:
@@ -350,7 +459,7 @@ def strotss_loss(out_tensor, style_tensor, content_weight=16.0, extractor=None, 
             if maps is None:
                 with torch.no_grad():
                     maps = style_cache[scale] = [f.detach() for f in extractor(style)]
-        total = total + _scale_loss(result, content, style, content_weight, lr, extractor, maps, recompute)
+        total = total + _scale_loss(result, content, style, content_weight, lr, extractor, draws, maps, recompute)
         content_weight /= 2.0
     return total
 
@@ -368,7 +477,54 @@ class StyleLoss(LossInterface):
         self.extractor = extractor
         self.vgg_params = vgg_params
         self.style = style_image
+        # hipGraph replay (engine.Session.enable_graph): the iteration's numpy draws are made by `host_prep` BEFORE the device
+        # work and reach it through fixed device buffers, so `get_loss` launches the same kernels on the same addresses
+        # every iteration.  Off until `enable_static_buffers`: plain eager use draws inside `get_loss`, where the reference does.
+        self._static_device = None
+        self._rings = None              # one PinnedRing per table of the plan
+        self._staged = None             # (cur_iteration, plan on the device) made by host_prep, consumed by get_loss
+        self._out_hw = None             # canvas size seen by the last get_loss (host_prep runs before the drawer's synth)
         super().__init__(**kwargs)
+
+    # ------------------------------------------------------------------ graph-replay protocol (engine.Session)
+    @property
+    def supports_graph_replay(self):
+        """engine.Session.enable_graph asks every plugin: can its device work be captured once and replayed?  Yes, through
+        `enable_static_buffers` + `host_prep` -- unless the reference's recompute schedule is on (it is the CPU baseline's)"""
+        return not self.reference_schedule
+
+    @property
+    def graph_capturable(self):
+        """with static buffers on, `get_loss` makes no host draw, upload or data-dependent host decision"""
+        return self._static_device is not None and not self.reference_schedule
+
+    def enable_static_buffers(self, device):
+        self._static_device = torch.device(device)
+
+    def is_active(self, args, cur_iteration) -> bool:
+        """the reference's schedule (StyleLoss.py:491-496): silent for `--styleloss_skip` iterations, then every
+        `--styleloss_every`-th"""
+        return cur_iteration >= args.styleloss_skip and cur_iteration % args.styleloss_every == 0
+
+    def graph_state(self, args, cur_iteration):
+        """what a captured iteration baked in besides tensor values: a replay is valid only while this is unchanged"""
+        return (self.is_active(args, cur_iteration), self._out_hw)
+
+    def host_prep(self, args, cur_iteration):
+        """Host side of iteration `cur_iteration` (called by Session._host_prep once static buffers are on): the draws of
+        `draw_plan`, staged to the fixed device buffers through rings of pinned memory (the host may run iterations ahead
+        of the queued copies)."""
+        self._staged = None
+        if self._static_device is None or self._out_hw is None or self.resized is None or not self.is_active(args, cur_iteration):
+            return
+        from .cutouts import PinnedRing
+        H, W = self._out_hw
+        tables = [t for sd in draw_plan(H, W, int(self.resized.shape[2]), int(self.resized.shape[3])) for t in sd.tables()]
+        if self._rings is None or [tuple(r.dev.shape) for r in self._rings] != [t.shape for t in tables]:
+            self._rings = [PinnedRing(t.shape, torch.from_numpy(t).dtype, self._static_device) for t in tables]
+        devs = [ring.stage(torch.from_numpy(t)) for ring, t in zip(self._rings, tables)]
+        per_scale = len(devs) // len(loss_scales(H, W))
+        self._staged = (cur_iteration, [ScaleDraws.from_tables(devs[k:k + per_scale]) for k in range(0, len(devs), per_scale)])
 
     @staticmethod
     def add_settings(parser):
@@ -402,9 +558,12 @@ class StyleLoss(LossInterface):
             self.resized = F.interpolate(self.style.to(out.device, torch.float32), out.size()[2:4], mode="bicubic",
                                          align_corners=False)
             self._style_cache = {}
-        if globals["cur_iteration"] < args.styleloss_skip:
+        self._out_hw = (int(out.shape[2]), int(out.shape[3]))
+        staged, self._staged = self._staged, None
+        if not self.is_active(args, globals["cur_iteration"]):
             return torch.tensor(0.0)
-        if globals["cur_iteration"] % args.styleloss_every != 0:
-            return torch.tensor(0.0)
+        plan = None
+        if staged is not None and staged[0] == globals["cur_iteration"]:
+            plan = staged[1]
         return strotss_loss(out, self.resized, args.styleloss_content_weight, extractor=self.extractor,
-                            style_cache=self._style_cache, recompute=self.reference_schedule)
+                            style_cache=self._style_cache, recompute=self.reference_schedule, plan=plan)

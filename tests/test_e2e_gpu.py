@@ -532,7 +532,7 @@ def test_fft_drawer_plugin_on_the_hip_path():
     pm = Prompt(api.seeded_unit_vectors(1, 128, 9).to(DEV), 1.0, float("-inf")).to(DEV)
     sess = Session(dr, {"tiny-B/32": perc}, {224: mk}, {"tiny-B/32": [pm]}, custom_losses=[{"loss": _Saturation(device=DEV), "weight": 1.0}],
                    seed=1)
-    assert not sess.enable_graph()                      # foreign optimiser: stays on eager launches
+    assert not sess.enable_graph()                      # a plugin that does not declare supports_graph_replay: eager launches
     p0 = dr.params[0].detach().clone()
     first = None
     for it in range(6):
@@ -589,6 +589,88 @@ def test_config3_custom_loss_stack_styleloss_plus_saturation_on_the_fft_drawer()
             assert len(vals) == 3 and all(math.isfinite(v) for v in vals)
             assert (vals[1] == 0.0) == (it < 2)              # StyleLoss is silent before --styleloss_skip
             assert (dr.params[0].detach() - p0).abs().max() > 0
+
+
+def test_config3_stack_replayed_from_a_hipgraph_matches_eager_launches():
+    """configs[3]'s plugin stack (fft drawer with its own torch Adam, StyleLoss with numpy-drawn sampling tables,
+    SaturationLoss) captured in a hipGraph and replayed: the drawer's Adam is swapped for the fused kernel (state carried
+    over), StyleLoss's draws are made by host_prep() and reach the captured kernels through fixed buffers.  Teacher-forced
+    like the headline's replay test (the loop is chaotic): before every compared step both sessions get the same spectrum and
+    Adam moments, and numpy's global stream is rewound so that both make the same draws."""
+    import argparse
+    import warnings
+    from pixray_amd import style_loss as sl
+    from pixray_amd.cutouts import MakeCutouts
+    from pixray_amd.engine import HipAdam, Session
+    from pixray_amd.fft_drawer import FftDrawer
+    from pixray_amd.perceptor import get_clip_perceptor
+    from pixray_amd.prompt import Prompt
+
+    class SaturationLoss(LossInterface):     # Losses/SaturationLoss.py:15-30
+        supports_graph_replay = True
+
+        def get_loss(self, cur_cutouts, out, args, globals=None, lossGlobals=None):
+            res = []
+            for _, cutouts in cur_cutouts.items():
+                px = cutouts.permute(0, 2, 3, 1).reshape(-1, 3)
+                rg, yb = px[:, 0] - px[:, 1], 0.5 * (px[:, 0] + px[:, 1]) - px[:, 2]
+                rg_std, rg_mean = torch.std_mean(rg)
+                yb_std, yb_mean = torch.std_mean(yb)
+                res.append(-(torch.sqrt(rg_std ** 2 + yb_std ** 2) + .3 * torch.sqrt(rg_mean ** 2 + yb_mean ** 2)) / 10.0)
+            return res
+
+    def build():
+        st = types.SimpleNamespace(size=(96, 80), fft_use="fft", fft_decay=1.5, fft_lrate=0.3)
+        dr = FftDrawer(st)
+        dr.load_model(st, DEV)
+        dr.init_from_tensor(None)
+        perc = get_clip_perceptor("tiny-B/32", DEV, max_batch=8)
+        mk = MakeCutouts(224, 8, generator=torch.Generator().manual_seed(3), aspect_width=96 / 80)
+        mk.noise_fac = 0.0                # device randn streams differ between capture and eager; compare without noise
+        pm = Prompt(api.seeded_unit_vectors(1, 128, 9).to(DEV), 1.0, float("-inf")).to(DEV)
+        args = sl.StyleLoss.add_settings(argparse.ArgumentParser()).parse_args(["--styleloss_skip", "1", "--styleloss_content_weight", "8"])
+        style = sl.StyleLoss(vgg_params=weights.synthetic_vgg16_params(0),
+                             style_image=torch.rand(1, 3, 50, 60, generator=torch.Generator().manual_seed(4)), device=DEV)
+        args = style.parse_settings(args)
+        sess = Session(dr, {"tiny-B/32": perc}, {224: mk}, {"tiny-B/32": [pm]}, args=args, seed=1,
+                       custom_losses=[{"loss": style, "weight": 1.0}, {"loss": SaturationLoss(device=DEV), "weight": 1.0}])
+        return sess, dr, style
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, da, _ = build()
+        b, db, style_b = build()
+        np.random.seed(0)
+        for it in range(3):
+            a.train(it)
+        np.random.seed(0)
+        assert b.enable_graph(warmup=2)      # iterations 0, 1 eagerly (StyleLoss silent at 0); iteration 2 is captured and staged
+        assert isinstance(b.opts[0], HipAdam) and b.opts[0]._t == 3 and style_b.graph_capturable
+        b.train(2)                            # first replay
+        pa, pb = da.params[0], db.params[0]
+        oa, ob = a.opts[0], b.opts[0]
+        for it in range(3, 7):
+            with torch.no_grad():
+                pb.copy_(pa)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    ob.state[pb][k].copy_(oa.state[pa][k])
+            state = np.random.get_state()
+            a.train(it)
+            np.random.set_state(state)
+            b.train(it)
+            la = [float(l.detach()) for l in a.last_losses]
+            lb = [float(l.detach()) for l in b.last_losses]
+            assert len(la) == len(lb) == 3 and la[1] != 0.0
+            for x, y in zip(la, lb):
+                assert abs(x - y) <= 2e-3 * max(1.0, abs(x)), (it, la, lb)
+            d = (pa.detach() - pb.detach()).abs()
+            # same kernels on the same inputs; index_add atomics of the torch ops reorder and the two Adam implementations
+            # round differently; Adam turns a sign flip of a ~0 gradient component into a 2*lr step difference
+            assert (d > 1e-3).float().mean().item() < 2e-2, (it, d.max().item())
+        assert b._graph is not None
+        # a schedule change that the captured iteration baked in sends the session back to eager launches
+        b.args.styleloss_every = 2
+        assert b.train(7) and b._graph is None and float(b.last_losses[1].detach()) == 0.0
 
 
 def test_overlay_image_goes_through_the_hip_encoder():

@@ -641,3 +641,15 @@ def test_custom_backward_last_is_the_same_gradient():
         grads.append(captured["g"])
     assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-8)
     assert (grads[0] - grads[1]).abs().max() <= 1e-6 * grads[0].abs().max()
+
+
+def test_fused_adam_stands_in_only_for_a_plain_device_adam():
+    """engine.HipAdam.from_adam (hipGraph replay of a drawer plugin with its own torch Adam): anything the fused kernel does
+    not implement -- host tensors, several groups, amsgrad / weight decay / maximize, another optimiser class -- is refused,
+    and the session then stays on eager launches"""
+    from pixray_amd.engine import HipAdam
+    p = torch.zeros(4, requires_grad=True)
+    assert HipAdam.from_adam(torch.optim.Adam([p], 0.1)) is None                       # host tensor
+    assert HipAdam.from_adam(torch.optim.SGD([p], 0.1)) is None
+    assert HipAdam.from_adam(torch.optim.AdamW([p], 0.1)) is None
+    assert HipAdam.from_adam(torch.optim.Adam([{"params": [p]}, {"params": [torch.zeros(2, requires_grad=True)]}], 0.1)) is None

@@ -134,3 +134,73 @@ def test_torchvision_vgg16_checkpoint_adapter():
     del sd["module.features.28.bias"]
     with pytest.raises(KeyError):
         checkpoints.vgg16_from_torchvision(sd)
+
+
+class _FakeRing:
+    """cutouts.PinnedRing without pinned memory: one fixed 'device' buffer per table, filled by stage()"""
+
+    def __init__(self, shape, dtype, device, slots=4):
+        self.dev = torch.empty(shape, dtype=dtype, device=device)
+        self.stages = 0
+
+    def stage(self, value):
+        self.dev.copy_(value)
+        self.stages += 1
+        return self.dev
+
+
+def test_draw_plan_consumes_numpys_stream_like_the_loss_body(extractor):
+    """`draw_plan` (all of an evaluation's numpy draws, made from tensor SHAPES ahead of the device work) leaves numpy's
+    global generator exactly where an evaluation that draws as it goes leaves it, and yields the same loss"""
+    img = torch.from_numpy(GOLD["img_a"])
+    style = torch.from_numpy(GOLD["style_a"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(11)
+        la = sl.strotss_loss(img, style, 8.0, extractor=extractor)
+        after_a = np.random.randint(1 << 30)
+        np.random.seed(11)
+        plan = sl.plan_to_device(sl.draw_plan(img.shape[2], img.shape[3], style.shape[2], style.shape[3]), img.device)
+        after_b = np.random.randint(1 << 30)
+        lb = sl.strotss_loss(img, style, 8.0, extractor=extractor, plan=plan)
+    assert after_a == after_b
+    assert float(la) == float(lb)
+    assert sl.vgg_map_shapes(img.shape[2], img.shape[3]) == [tuple(f.shape[1:3]) for f in extractor(img)]
+
+
+def test_staged_tables_for_graph_replay_match_drawing_inside_get_loss(extractor, monkeypatch):
+    """the hipGraph-replay protocol of the plugin on CPU tensors (rings of pinned memory replaced by plain buffers):
+    host_prep() makes the iteration's draws and stages them into FIXED buffers, get_loss() consumes them -- same loss as the
+    eager plugin with the same numpy seed, buffers reused from one iteration to the next, and graph_state() reports the
+    --styleloss_skip / --styleloss_every schedule a captured iteration bakes in"""
+    from pixray_amd import cutouts
+    monkeypatch.setattr(cutouts, "PinnedRing", _FakeRing)
+    img = torch.from_numpy(GOLD["img_a"])
+    style = torch.from_numpy(GOLD["style_a"])
+    args = sl.StyleLoss.add_settings(argparse.ArgumentParser()).parse_args(["--styleloss_skip", "2", "--styleloss_every", "2",
+                                                                           "--styleloss_content_weight", "8"])
+    eager = sl.StyleLoss(extractor=extractor, style_image=style, device="cpu")
+    staged = sl.StyleLoss(extractor=extractor, style_image=style, device="cpu")
+    assert staged.supports_graph_replay and not staged.graph_capturable
+    assert not sl.StyleLoss(extractor=extractor, style_image=style, device="cpu", reference_schedule=True).supports_graph_replay
+    staged.enable_static_buffers("cpu")
+    assert staged.graph_capturable
+    ptrs = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(6):
+            np.random.seed(100 + it)
+            le = eager.get_loss({}, img, args, globals={"cur_iteration": it})
+            np.random.seed(100 + it)
+            staged.host_prep(args, it)                  # iteration 0: canvas size not seen yet -> nothing staged, get_loss draws
+            used_stage = staged._staged is not None
+            ls = staged.get_loss({}, img, args, globals={"cur_iteration": it})
+            active = it >= 2 and it % 2 == 0
+            assert staged.graph_state(args, it) == (active, (img.shape[2], img.shape[3]))
+            assert used_stage == active
+            assert (float(le) != 0.0) == active and float(le) == float(ls)
+            if active:
+                now = [r.dev.data_ptr() for r in staged._rings]
+                assert ptrs is None or ptrs == now      # the device work of every iteration reads the same addresses
+                ptrs = now
+    assert all(r.stages == 2 for r in staged._rings)        # iterations 2 and 4
