@@ -461,7 +461,11 @@ class Session:
             else:
                 loss = sum(lossAll)
                 loss.backward()
-            self.last_losses = lossAll
+            # values only: holding the loss tensors themselves would keep this iteration's autograd graph -- every Function's
+            # ctx with its workspace and its runner handle -- alive until the NEXT iteration replaces them, i.e. a handle
+            # could be destroyed (hipFree) in the middle of a later iteration, which a hipGraph capture does not survive
+            self.last_losses = [l.detach() if isinstance(l, torch.Tensor) else l for l in lossAll]
+            del lossAll
         for opt in self.opts:
             opt.step()
         self._clip_z()
@@ -495,26 +499,26 @@ class Session:
         tables: `host_prep`).  Falls back to eager launches when something in the session cannot be captured (foreign
         optimisers, plugins that do not declare `supports_graph_replay`, batches > 1, ...)."""
         if self.batches != 1 or self.auto_stop or not self.opts:
-            return False
+            return self._no_graph("batches > 1, auto_stop, or no optimiser")
         params = [p for o in self.opts for g in o.param_groups for p in g["params"]]
         if not params or not all(p.is_cuda for p in params):
-            return False
+            return self._no_graph("optimised tensors are not on a GPU")
         dev = params[0].device
         # the fused Adam kernel reads its step scalars from a fixed device buffer; a drawer plugin's plain torch Adam (FftDrawer)
         # keeps them on the host, so it is swapped for the kernel (same rule, state carried over) -- for a replayed session only
         opts = [o if isinstance(o, HipAdam) else HipAdam.from_adam(o) for o in self.opts]
         if any(o is None for o in opts):
-            return False
+            return self._no_graph("an optimiser the fused Adam kernel cannot stand in for")
         if getattr(self.args, "transparent", False):      # the RGBA squash uses this iteration's host-drawn gray as a constant
-            return False
+            return self._no_graph("--transparent draws a host-side gray per iteration")
         # image / spot prompts go through the cached-transform path, which stages a fresh descriptor table per call
         if any(self.pmsImageTable.values()) or any(self.spotPmsTable.values()) or any(self.spotOffPmsTable.values()):
-            return False
+            return self._no_graph("image / spot prompts stage a fresh descriptor table per call")
         if not all(getattr(t["loss"], "supports_graph_replay", False) for t in self.custom_losses):
-            return False                 # a plugin's get_loss may draw, upload or branch on the host: it has to say that it does not
+            return self._no_graph("a custom loss does not declare supports_graph_replay")   # a plugin's get_loss may draw, upload or branch on the host: it has to say that it does not
         for mk in self.cutoutsTable.values():
             if not hasattr(mk, "enable_static_buffers") or getattr(mk, "fixed_params", None) is not None:
-                return False
+                return self._no_graph("a cutout module without static descriptor buffers (or with fixed parameters)")
         for mk in self.cutoutsTable.values():
             mk.enable_static_buffers(dev)
         for t in self.custom_losses:
@@ -533,7 +537,7 @@ class Session:
         torch.cuda.synchronize(dev)
         if self.cur_iteration >= self.iterations or self.cur_iteration in self.learning_rate_drops or \
                 self.apply_overlay(self.cur_iteration) or not all(isinstance(o, HipAdam) for o in self.opts):
-            return False                 # the next iteration is not a plain one: stay eager (call enable_graph again later)
+            return self._no_graph("the next iteration is not a plain one")     # the next iteration is not a plain one: stay eager (call enable_graph again later)
         self._host_prep(self.cur_iteration)
         for o in self.opts:
             o.prepare_step()
@@ -541,23 +545,35 @@ class Session:
         try:
             with torch.cuda.graph(graph):
                 self._device_step()
-        except Exception as e:           # an op that cannot be captured (a sync, a pageable copy, ...): stay on eager launches
+        except Exception as e:           # an op that cannot be captured (a sync, a pageable copy, a hipFree, ...)
+            reason = f"capture failed: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}"
+            try:                         # is the device usable again (an invalidated capture may stay open on the capture stream)?
+                torch.cuda.synchronize(dev)
+                torch.zeros(1).to(dev).cpu()
+            except Exception as e2:
+                raise RuntimeError(f"hipGraph {reason}; the aborted capture left the device unusable in this process "
+                                   f"({type(e2).__name__}): run without enable_graph()") from e
             import warnings
-            warnings.warn(f"hipGraph capture of the iteration failed ({type(e).__name__}: {e}); staying on eager launches")
-            torch.cuda.synchronize(dev)
+            warnings.warn(f"hipGraph {reason}; staying on eager launches")
             for o in self.opts:          # the aborted capture consumed the staged step: rewind it, the eager step stages again
                 o._t -= 1
                 o._pending = False
                 for st in o.state.values():
                     st["step"] = o._t
             self._drop_graph()
-            return False
+            return self._no_graph(reason)
         # the capture pass does not execute: its staged inputs (cutout descriptors, Adam scalars, sampling tables) are
         # consumed by the first replay, i.e. by the next train() call, which therefore must not draw again
         self._graph = graph
         self._graph_state = self._custom_graph_state(self.cur_iteration)
         self._staged_for_replay = True
+        self.graph_error = None
         return True
+
+    def _no_graph(self, reason: str) -> bool:
+        """enable_graph's refusals, kept for the caller (`graph_error`)"""
+        self.graph_error = reason
+        return False
 
     def apply_overlay(self, cur_it: int) -> bool:
         """pixray.py:1431-1434"""
@@ -616,7 +632,7 @@ class Session:
                         rebuild = self.checkdrop(cur_it, lossAll)
                     loss = sum(lossAll)
                     loss.backward()
-                    self.last_losses = lossAll
+                    self.last_losses = [l.detach() if isinstance(l, torch.Tensor) else l for l in lossAll]
                 for opt in self.opts:
                     opt.step()
                 self._clip_z()

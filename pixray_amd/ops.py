@@ -26,6 +26,27 @@ def _stream():
     return _lib.current_stream()
 
 
+_DEFERRED_DESTROY = []
+
+
+def _destroy_handle(fn_name: str, h) -> None:
+    """`prx_*_destroy` frees device memory (hipFree), which a hipGraph capture in progress does not survive: a handle whose
+    last reference drops during a capture (an autograd ctx released by the captured backward, the garbage collector) is
+    parked and destroyed by the next handle destruction outside a capture (or at interpreter exit with the process)."""
+    try:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        capturing = False
+    if capturing:
+        _DEFERRED_DESTROY.append((fn_name, h))
+        return
+    lib = _lib.load()
+    while _DEFERRED_DESTROY:
+        n, hh = _DEFERRED_DESTROY.pop()
+        getattr(lib, n)(hh)
+    getattr(lib, fn_name)(h)
+
+
 def _weight_array(tensors: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -112,7 +133,7 @@ class ClipVitHandle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_clip_vit_destroy(h)
+                _destroy_handle("prx_clip_vit_destroy", h)
             except Exception:
                 pass
             self.h = None
@@ -160,7 +181,7 @@ class ClipResNetHandle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_clip_resnet_destroy(h)
+                _destroy_handle("prx_clip_resnet_destroy", h)
             except Exception:
                 pass
             self.h = None
@@ -263,7 +284,7 @@ class ClipTextHandle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_clip_text_destroy(h)
+                _destroy_handle("prx_clip_text_destroy", h)
             except Exception:
                 pass
             self.h = None
@@ -334,7 +355,7 @@ class VqganHandle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_vqgan_destroy(h)
+                _destroy_handle("prx_vqgan_destroy", h)
             except Exception:
                 pass
             self.h = None
@@ -420,7 +441,7 @@ class VqganEncHandle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_vqgan_enc_destroy(h)
+                _destroy_handle("prx_vqgan_enc_destroy", h)
             except Exception:
                 pass
             self.h = None
@@ -524,7 +545,7 @@ class Vgg16Handle:
         h = getattr(self, "h", None)
         if h is not None and h.value:
             try:
-                _lib.load().prx_vgg16_destroy(h)
+                _destroy_handle("prx_vgg16_destroy", h)
             except Exception:
                 pass
             self.h = None

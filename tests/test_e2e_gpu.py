@@ -644,7 +644,7 @@ def test_config3_stack_replayed_from_a_hipgraph_matches_eager_launches():
         for it in range(3):
             a.train(it)
         np.random.seed(0)
-        assert b.enable_graph(warmup=2)      # iterations 0, 1 eagerly (StyleLoss silent at 0); iteration 2 is captured and staged
+        assert b.enable_graph(warmup=2), b.graph_error     # iterations 0, 1 eagerly (StyleLoss silent at 0); iteration 2 is captured and staged
         assert isinstance(b.opts[0], HipAdam) and b.opts[0]._t == 3 and style_b.graph_capturable
         b.train(2)                            # first replay
         pa, pb = da.params[0], db.params[0]
