@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+# before anything touches the GPU: hipGraph replay is only safe with the runtime's graph packet capture off (pixray_amd/__init__.py)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

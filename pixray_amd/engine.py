@@ -498,6 +498,12 @@ class Session:
         Host-drawn inputs reach the graph through fixed device buffers (cutout descriptors, Adam scalars, a plugin's sampling
         tables: `host_prep`).  Falls back to eager launches when something in the session cannot be captured (foreign
         optimisers, plugins that do not declare `supports_graph_replay`, batches > 1, ...)."""
+        import os
+        from . import GRAPH_ENV
+        if os.environ.get(GRAPH_ENV) != "0":
+            # ROCm 7.2: with packet capture on, a replayed graph's kernel arguments live in memory that a later hipMalloc may
+            # be handed -- any fresh allocation between replays can corrupt them (tools/debug_capture.py, DESIGN.md section 6)
+            return self._no_graph(f"{GRAPH_ENV}=0 must be in the environment before the HIP runtime starts")
         if self.batches != 1 or self.auto_stop or not self.opts:
             return self._no_graph("batches > 1, auto_stop, or no optimiser")
         params = [p for o in self.opts for g in o.param_groups for p in g["params"]]
