@@ -670,11 +670,9 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                 const float4 v = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
                 const int row = rbase + i * 32 + lr, col = cbase + lc;
                 if (row < d.M && col < d.N) {
-                    if (p.splits > 1) {
-                        float* q = &p.ws[((size_t)split * d.M + row) * d.N + col];
-                        if (p.counters) st4_agent(q, v);       // reduced in this launch by the last-arriving split (splitk_tail)
-                        else *reinterpret_cast<float4*>(q) = v;
-                    } else {
+                    if (p.splits > 1)
+                        *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
+                    else {
                         const float4 o = epilogue_store4<T16>(d, row, col, v);
                         if (gnb) gnb_accum(d, gc, row, col, o, gs0, gs1);
                         else {
@@ -723,11 +721,9 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row >= d.M) continue;
-                if (p.splits > 1) {
-                    float* q = &p.ws[((size_t)split * d.M + row) * d.N + col];
-                    if (p.counters) st1_agent(q, acc[i][j][r]);
-                    else *q = acc[i][j][r];
-                } else
+                if (p.splits > 1)
+                    p.ws[((size_t)split * d.M + row) * d.N + col] = acc[i][j][r];
+                else
                     epilogue_store<T16>(d, row, col, acc[i][j][r]);
             }
         }

@@ -130,32 +130,11 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
 
 
 
-// Agent-scope (device-coherent) accesses for the split-K partials: relaxed atomics carry the sc1 bit, i.e. the store is written through
-// to the point where every XCD sees it and the load is served from there -- no L2 write-back / invalidate of the whole cache, which is
-// what an agent-scope FENCE costs (measured: __threadfence() per workgroup made the headline's split launches 25 us slower each, it
-// also drops the operand tiles the other workgroups of the XCD are sharing).
-__device__ __forceinline__ void st4_agent(float* p, float4 v) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    const unsigned long long a = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
-    const unsigned long long b = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
-    __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 ld4_agent(const float* p) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float*>(p));
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-}
-__device__ __forceinline__ void st1_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld1_agent(const float* p) { return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // ---- split-K without a second launch ---------------------------------------------------------------------------------
 // Every workgroup of an output tile (one per K split) stores its partial tile to `ws`, then announces itself on the tile's
 // arrival counter; the LAST one to arrive sums the partials in split order 0..S-1 (the same order, hence the same bits, as
-// splitk_reduce_kernel), runs the epilogue for the tile and puts the counter back to zero for the next launch.  The partials
-// of a fused launch are stored and loaded with agent-scope accesses (st4_agent / ld4_agent); the ordering around the arrival
-// counter then only needs this workgroup's own accesses to have completed (workgroup-scope fences = s_waitcnt), no cache flush.
+// splitk_reduce_kernel), runs the epilogue for the tile and puts the counter back to zero for the next launch.  Release /
+// acquire: agent-scope fences around the counter (the partials of the other splits were written on other XCDs).
 // `scratch`: >= 520 bytes of the block's LDS that nothing else uses any more.  NTHREADS = blockDim.x.
 template <typename TOp, int BM, int BN, int NTHREADS>
 __device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, void* scratch) {
@@ -163,12 +142,12 @@ __device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, v
     double* gacc = reinterpret_cast<double*>(scratch);              // [32 groups][sum, sumsq]
     int* flag = reinterpret_cast<int*>(gacc + 64);
     const int tid = threadIdx.x;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this thread's (write-through) partial stores have completed ...
-    __syncthreads();                                                // ... and so have the whole block's, before the arrival
+    __threadfence();                                                // this thread's partials are visible device-wide ...
+    __syncthreads();                                                // ... and so are the whole block's, before the arrival
     if (tid == 0) *flag = atomicAdd(&p.counters[tm * p.tiles_n + tn], 1);
     __syncthreads();
     if (*flag != p.splits - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the partial loads below are issued after the arrival was seen
+    __threadfence();                                                // acquire: the other splits' partials
     const size_t total = (size_t)d.M * d.N;
     if (p.vec_epi) {
         const bool do_stats = d.gn_stats != nullptr;
@@ -177,6 +156,7 @@ __device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, v
         const int run = do_stats ? (d.gn_gs >> 2) : 1;              // consecutive lanes (4 columns each) sharing a group
         constexpr int QPR = BN / 4;                                 // column quads per tile row
         constexpr int ITERS = (BM * QPR) / NTHREADS;
+        const size_t pstride = total >> 2;
 #pragma unroll 1
         for (int it = 0; it < ITERS; ++it) {
             const int i = it * NTHREADS + tid;
@@ -185,18 +165,18 @@ __device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, v
             float s0 = 0.f, s1 = 0.f;
             if (live) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float* pf = p.ws + (size_t)row * d.N + col;
+                const float4* part = reinterpret_cast<const float4*>(p.ws) + (((size_t)row * d.N + col) >> 2);
                 int s = 0;
                 for (; s + 4 <= p.splits; s += 4) {
-                    const float4 w0 = ld4_agent(pf + (size_t)s * total), w1 = ld4_agent(pf + (size_t)(s + 1) * total);
-                    const float4 w2 = ld4_agent(pf + (size_t)(s + 2) * total), w3 = ld4_agent(pf + (size_t)(s + 3) * total);
+                    const float4 w0 = part[(size_t)s * pstride], w1 = part[(size_t)(s + 1) * pstride];
+                    const float4 w2 = part[(size_t)(s + 2) * pstride], w3 = part[(size_t)(s + 3) * pstride];
                     v.x += w0.x; v.y += w0.y; v.z += w0.z; v.w += w0.w;
                     v.x += w1.x; v.y += w1.y; v.z += w1.z; v.w += w1.w;
                     v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
                     v.x += w3.x; v.y += w3.y; v.z += w3.z; v.w += w3.w;
                 }
                 for (; s < p.splits; ++s) {
-                    const float4 w = ld4_agent(pf + (size_t)s * total);
+                    const float4 w = part[(size_t)s * pstride];
                     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                 }
                 const float4 o = epilogue_store4<TOp>(d, row, col, v);
@@ -228,7 +208,7 @@ __device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, v
             if (row >= d.M || col >= d.N) continue;
             const size_t idx = (size_t)row * d.N + col;
             float v = 0.f;
-            for (int s = 0; s < p.splits; ++s) v += ld1_agent(p.ws + (size_t)s * total + idx);
+            for (int s = 0; s < p.splits; ++s) v += p.ws[(size_t)s * total + idx];
             epilogue_store<TOp>(d, row, col, v);
         }
     }
