@@ -73,11 +73,6 @@ struct GemmCtx {
     int conv_c64 = 1;                 // scalar-tap conv gather when Cin % 64 == 0
     int wide_tile = 128;
     int big_tile = 0;            // > 0: use the 8-wave 256 x 128 tile when it gives >= big_tile * 256 tiles (PRX_BIG_TILE)
-    int fused_splitk = 1;        // 1: the last-arriving split of a tile reduces it inside the GEMM kernel (no splitk_reduce pass); PRX_SPLITK_FUSED
-    int* counters = nullptr;     // [kMaxFusedTiles] arrival counters of this context (device, zero between launches; lazily allocated)
-    static constexpr int kMaxFusedTiles = 4096;
-    int* tile_counters();        // null when the allocation fails (the launch then falls back to the separate reduce pass)
-    ~GemmCtx();
     int tile8p = 128;            // > 0: 256 x 256 tiles on the 8-phase kernel (gemm8p.hip) are CONSIDERED from this many tiles on (PRX_GEMM_8P;
                                  // gemm.hip plan_8phase then decides by cost: full rounds of 256 tiles on it, the remainder rows on the 4-wave kernels)
     std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic

@@ -706,7 +706,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                 }
             }
         }
-        if (p.splits > 1 && p.counters) splitk_tail<T16, BM, BN, NWM * 128>(p, tm, tn, lds);
         return;
     }
     const int row0 = tm * BM + wm * (BM / NWM) + 4 * (lane >> 5);
@@ -727,7 +726,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                     epilogue_store<T16>(d, row, col, acc[i][j][r]);
             }
         }
-    if (p.splits > 1 && p.counters) splitk_tail<T16, BM, BN, NWM * 128>(p, tm, tn, lds);
 }
 
 template <typename TOp>
@@ -897,23 +895,6 @@ GemmCtx::GemmCtx() {
     big_tile = env_int("PRX_BIG_TILE", 0);
     tile8p = env_int("PRX_GEMM_8P", 128);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
-    fused_splitk = env_int("PRX_SPLITK_FUSED", 1);
-}
-
-GemmCtx::~GemmCtx() {
-    if (counters) (void)hipFree(counters);
-}
-
-int* GemmCtx::tile_counters() {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!counters) {
-        // first split-K launch of this context (a warm-up iteration, never inside a hipGraph capture: synchronous calls)
-        void* q = nullptr;
-        if (hipMalloc(&q, sizeof(int) * kMaxFusedTiles) != hipSuccess) return nullptr;
-        if (hipMemset(q, 0, sizeof(int) * kMaxFusedTiles) != hipSuccess) { (void)hipFree(q); return nullptr; }
-        counters = (int*)q;
-    }
-    return counters;
 }
 
 void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, int bn, int splits) {
@@ -931,7 +912,6 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -3) { c->use_glds = splits; return; }      // (-3, x, on/off): direct-to-LDS v2 kernel vs register-staged v1
     if (bm == -5) { c->conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
     if (bm == -6) { c->tile8p = splits; return; }        // (-6, x, n): 256 x 256 8-phase tiles from n tiles on (0 = never)
-    if (bm == -7) { c->fused_splitk = splits; return; }  // (-7, x, on/off): split-K reduced by the last-arriving split vs a second pass
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
@@ -1135,7 +1115,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     splits = ceil_div(a.kt_total, a.kt_per_split);
     a.splits = splits;
     a.ws = ws;
-    a.counters = nullptr;
 
     GemmProfRec rec{};
     bool prof = false;
@@ -1168,9 +1147,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         // the 128-wide tiles it halves the occupancy and loses 15-25 %.
         int stages = (BM == 64 && BN == 64) ? 3 : 2;
         if (cx.force_stages) stages = cx.force_stages;
-        // split-K: let the last-arriving split of each tile reduce it (only this kernel family has the in-kernel tail; a
-        // context-less launch or > kMaxFusedTiles tiles keeps the separate pass)
-        if (splits > 1 && ctx && cx.fused_splitk && tiles <= GemmCtx::kMaxFusedTiles) a.counters = ctx->tile_counters();
         if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp, c64); else launch_glds_256<2>(a, grid, stream, zp, c64); }
         else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
         else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages, c64);
@@ -1179,7 +1155,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     else if (BM == 128 && BN == 64) launch_cfg<128, 64>(a, grid, stream);
     else launch_cfg<64, 64>(a, grid, stream);
     PRX_LAUNCH_CHECK();
-    if (splits > 1 && !a.counters) {
+    if (splits > 1) {
         size_t total = (size_t)d.M * d.N;
         int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
         PRX_OP_DISPATCH(d.f32, d.h16, T, hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, a));

@@ -12,7 +12,6 @@ struct GemmArgs {
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     int xcd_swizzle;
     float* ws;
-    int* counters;   // split-K arrival counters, one per output tile, zero between launches (null: separate reduce pass)
 };
 
 __device__ __forceinline__ float quickgelu_f(float t) { return t * sigmoidf_(1.702f * t); }
@@ -128,92 +127,6 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
     return v;
 }
 
-
-
-// ---- split-K without a second launch ---------------------------------------------------------------------------------
-// Every workgroup of an output tile (one per K split) stores its partial tile to `ws`, then announces itself on the tile's
-// arrival counter; the LAST one to arrive sums the partials in split order 0..S-1 (the same order, hence the same bits, as
-// splitk_reduce_kernel), runs the epilogue for the tile and puts the counter back to zero for the next launch.  Release /
-// acquire: agent-scope fences around the counter (the partials of the other splits were written on other XCDs).
-// `scratch`: >= 520 bytes of the block's LDS that nothing else uses any more.  NTHREADS = blockDim.x.
-template <typename TOp, int BM, int BN, int NTHREADS>
-__device__ __forceinline__ void splitk_tail(const GemmArgs& p, int tm, int tn, void* scratch) {
-    const GemmDesc& d = p.d;
-    double* gacc = reinterpret_cast<double*>(scratch);              // [32 groups][sum, sumsq]
-    int* flag = reinterpret_cast<int*>(gacc + 64);
-    const int tid = threadIdx.x;
-    __threadfence();                                                // this thread's partials are visible device-wide ...
-    __syncthreads();                                                // ... and so are the whole block's, before the arrival
-    if (tid == 0) *flag = atomicAdd(&p.counters[tm * p.tiles_n + tn], 1);
-    __syncthreads();
-    if (*flag != p.splits - 1) return;
-    __threadfence();                                                // acquire: the other splits' partials
-    const size_t total = (size_t)d.M * d.N;
-    if (p.vec_epi) {
-        const bool do_stats = d.gn_stats != nullptr;
-        if (do_stats && tid < 64) gacc[tid] = 0.0;
-        if (do_stats) __syncthreads();
-        const int run = do_stats ? (d.gn_gs >> 2) : 1;              // consecutive lanes (4 columns each) sharing a group
-        constexpr int QPR = BN / 4;                                 // column quads per tile row
-        constexpr int ITERS = (BM * QPR) / NTHREADS;
-        const size_t pstride = total >> 2;
-#pragma unroll 1
-        for (int it = 0; it < ITERS; ++it) {
-            const int i = it * NTHREADS + tid;
-            const int row = tm * BM + i / QPR, col = tn * BN + (i % QPR) * 4;
-            const bool live = row < d.M && col < d.N;
-            float s0 = 0.f, s1 = 0.f;
-            if (live) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4* part = reinterpret_cast<const float4*>(p.ws) + (((size_t)row * d.N + col) >> 2);
-                int s = 0;
-                for (; s + 4 <= p.splits; s += 4) {
-                    const float4 w0 = part[(size_t)s * pstride], w1 = part[(size_t)(s + 1) * pstride];
-                    const float4 w2 = part[(size_t)(s + 2) * pstride], w3 = part[(size_t)(s + 3) * pstride];
-                    v.x += w0.x; v.y += w0.y; v.z += w0.z; v.w += w0.w;
-                    v.x += w1.x; v.y += w1.y; v.z += w1.z; v.w += w1.w;
-                    v.x += w2.x; v.y += w2.y; v.z += w2.z; v.w += w2.w;
-                    v.x += w3.x; v.y += w3.y; v.z += w3.z; v.w += w3.w;
-                }
-                for (; s < p.splits; ++s) {
-                    const float4 w = part[(size_t)s * pstride];
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                }
-                const float4 o = epilogue_store4<TOp>(d, row, col, v);
-                if (do_stats && d.gnb_x) gnb_accum(d, gnb_load(d, col), row, col, o, s0, s1);
-                else {
-                    s0 = (o.x + o.y) + (o.z + o.w);
-                    s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-                }
-            }
-            if (do_stats) {
-                // lanes of one group are an aligned run inside a tile row (gn_gs divides BN): fixed-order butterfly, then one
-                // double add per run (double: the order of the LDS atomics varies, see splitk_reduce_kernel)
-                for (int o = 1; o < run && o < 64; o <<= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-                if (live && (tid & (run - 1)) == 0) {
-                    const int g = col / d.gn_gs;
-                    atomicAdd(&gacc[g * 2], (double)s0);
-                    atomicAdd(&gacc[g * 2 + 1], (double)s1);
-                }
-            }
-        }
-        if (do_stats) {
-            __syncthreads();
-            if (tid < 64 && gacc[tid] != 0.0) atomicAdd(&d.gn_stats[tid], gacc[tid]);
-        }
-    } else {
-#pragma unroll 1
-        for (int i = tid; i < BM * BN; i += NTHREADS) {
-            const int row = tm * BM + i / BN, col = tn * BN + i % BN;
-            if (row >= d.M || col >= d.N) continue;
-            const size_t idx = (size_t)row * d.N + col;
-            float v = 0.f;
-            for (int s = 0; s < p.splits; ++s) v += p.ws[(size_t)s * total + idx];
-            epilogue_store<TOp>(d, row, col, v);
-        }
-    }
-    if (tid == 0) atomicExch(&p.counters[tm * p.tiles_n + tn], 0);  // ready for the next launch (stream order)
-}
 
 }  // namespace prx_gemm_dev
 

@@ -111,33 +111,6 @@ def test_gemm_f32_A_and_epilogues(gemm_variant):
     assert rel_l2(out3, 0.5 * (bf(A32).float() @ Bt.float().T) + bm[:, None]) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
-@pytest.mark.parametrize("splits", [2, 5, 9])
-def test_splitk_reduced_by_the_last_arriving_split_is_bit_identical_to_the_reduce_pass(tile, splits):
-    """split-K without a second launch (gemm_epi.h splitk_tail): the last split of a tile to arrive sums the partials in
-    split order and runs the epilogue -- the same additions in the same order as splitk_reduce_kernel, so the two are compared
-    BITWISE, on ragged shapes with every epilogue term, repeatedly (the arrival counters must be back at zero after each launch)"""
-    lib = _lib.load()
-    torch.manual_seed(11)
-    try:
-        for (M, N, K) in [(256, 512, 4608), (1000, 200, 1096), (257, 136, 640), (3200, 768, 768)]:
-            A = bf(torch.randn(M, K, device=DEV))
-            Bt = bf(torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K))
-            bias = torch.randn(N, device=DEV)
-            resid = torch.randn(M, N, device=DEV)
-            lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], splits)
-            lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 0)
-            ref, ref_b, _ = run_gemm(A, Bt, M, N, K, bias_n=bias, resid=resid, want_bf16=True)
-            lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 1)
-            for rep in range(3):
-                out, ob, _ = run_gemm(A, Bt, M, N, K, bias_n=bias, resid=resid, want_bf16=True)
-                assert torch.equal(out, ref) and torch.equal(ob, ref_b), (M, N, K, rep, (out - ref).abs().max().item())
-            assert rel_l2(ref, A.float() @ Bt.float().T + bias + resid) < 2e-5
-    finally:
-        lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
-        lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 1)
-
-
 @pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("stages", [2, 3, 4])
 @pytest.mark.parametrize("splits", [1, 3])
