@@ -193,7 +193,13 @@ class GemmProfile:
 
     def __init__(self, sess: Session):
         self.lib = _lib.load()
-        self.ctxs = session_gemm_contexts(sess)
+        self.sess = sess
+
+    @property
+    def ctxs(self):
+        # resolved at every use: a runner handle can be re-created behind the session's back (Vgg16Extractor.reserve grows its
+        # handle when a larger input arrives), and a cached `prx_gemm_ctx*` would then point into freed memory
+        return session_gemm_contexts(self.sess)
 
     def enable(self, on: bool = True):
         for c in self.ctxs:
