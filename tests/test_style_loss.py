@@ -64,13 +64,16 @@ def test_hypercolumn_sampling_matches_the_reference_golden(extractor):
 
 
 @pytest.mark.skipif(not rx.available(), reason="/root/reference not present (GPU box)")
-def test_strotss_against_the_reference_code_run_live(extractor):
-    """another size (three scales) and seed than the fixtures, the reference's functions executed here"""
+@pytest.mark.parametrize("hw", [(132, 140), (77, 131)], ids=lambda t: f"{t[0]}x{t[1]}")
+def test_strotss_against_the_reference_code_run_live(extractor, hw):
+    """other sizes and seeds than the fixtures, the reference's functions executed here: three scales on an even canvas, and an
+    odd non-square one (every max pool floors an odd side, the sampling grid is ragged, the coarsest maps are 4 x 8) -- the sizes
+    `draw_plan` has to predict from the canvas shape alone"""
     ns = rx.styleloss_ns()
     ref_ex = rx.reference_vgg_extractor(ns, weights.synthetic_vgg16_params(0))
     g = torch.Generator().manual_seed(31)
-    img = torch.rand(1, 3, 132, 140, generator=g)
-    style = torch.rand(1, 3, 132, 140, generator=g)
+    img = torch.rand(1, 3, *hw, generator=g)
+    style = torch.rand(1, 3, *hw, generator=g)
     a = img.clone().requires_grad_(True)
     b = img.clone().requires_grad_(True)
     with warnings.catch_warnings():
