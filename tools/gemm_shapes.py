@@ -1,5 +1,7 @@
 """Per-shape table of the GEMM-engine launches of one optimisation iteration (run on the GPU box).
 
+    python tools/gemm_shapes.py [steps] [cfg1|cfg2|cfg3] [cutn]
+
 Enables the engine's HIP-event profiling for a few iterations of the headline session, dumps one row per launch
 (PRX_GEMM_PROFILE_DUMP) and aggregates by (M, N, K, A mode, tile, split-K)."""
 import collections
@@ -9,6 +11,8 @@ import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+config = sys.argv[2] if len(sys.argv) > 2 else "cfg1"
+cutn = int(sys.argv[3]) if len(sys.argv) > 3 else None
 path = os.path.join(tempfile.gettempdir(), "prx_gemm_dump.csv")
 if os.path.exists(path):
     os.remove(path)
@@ -18,8 +22,13 @@ import torch
 from pixray_amd import _lib, api
 
 dev = torch.device("cuda", 0)
-sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
-                                    num_cuts=64, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev)
+custom, largs = (), None
+if config == "cfg3":
+    import numpy as np
+    import bench
+    np.random.seed(0)
+    custom, largs = bench.cfg3_custom_losses(dev, None)
+sess = api.build_workload(config, num_cuts=cutn, device=dev, custom_losses=custom, args=largs)
 for i in range(3):
     sess.train(i)
 torch.cuda.synchronize()
