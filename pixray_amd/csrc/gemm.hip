@@ -998,7 +998,11 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
 int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
     static const GemmCtx k_default;      // immutable: heuristics only
     const GemmCtx& cx = ctx ? *ctx : k_default;
-    const bool forced = cx.force_bm != 0 || !cx.rules.empty();
+    bool forced = cx.force_bm != 0;
+    if (!forced && !cx.rules.empty()) {          // a per-shape rule overrides the plan for THAT shape only (in-pipeline sweeps)
+        const int mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32;
+        for (const GemmTileRule& r : cx.rules) forced = forced || (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode);
+    }
     if (!forced && d.M > 0 && d.N > 0 && d.K > 0) {
         const Plan8p p = plan_8phase(d, cx);
         if (p.main_rows >= d.M) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 1);

@@ -2,7 +2,12 @@
 
 For each of the heaviest problem shapes of the headline iteration, try every tile shape x a few split-K factors through
 `prx_gemm_tile_rule`, time that shape's launches with the engine's HIP events while the rest of the iteration runs
-unchanged (cold weights, real neighbours), and print what beats the heuristic by more than the noise."""
+unchanged (cold weights, real neighbours), and print what beats the heuristic by more than the noise.
+
+    python tools/gemm_rules.py [top shapes] [steps] [cfg1|cfg2|cfg3] [cutn]
+
+Candidates include 256x256 (the 8-phase kernel on the whole problem, no row peeling) wherever it is eligible, and the 4-wave
+tiles for shapes the planner gives to the 8-phase kernel -- a rule replaces the plan for its own shape only."""
 import collections
 import ctypes
 import os
@@ -12,14 +17,21 @@ import tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+config = sys.argv[3] if len(sys.argv) > 3 else "cfg1"
+cutn = int(sys.argv[4]) if len(sys.argv) > 4 else None
 path = os.path.join(tempfile.gettempdir(), "prx_gemm_rules.csv")
 os.environ["PRX_GEMM_PROFILE_DUMP"] = path
 import torch
 from pixray_amd import _lib, api
 
 dev = torch.device("cuda", 0)
-sess = api.build_vqgan_clip_session(size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
-                                    num_cuts=64, learning_rate=0.2, iterations=10 ** 9, seed=0, device=dev)
+custom, largs = (), None
+if config == "cfg3":
+    import numpy as np
+    import bench
+    np.random.seed(0)
+    custom, largs = bench.cfg3_custom_losses(dev, None)
+sess = api.build_workload(config, num_cuts=cutn, device=dev, custom_losses=custom, args=largs)
 lib = _lib.load()
 prof = api.GemmProfile(sess)
 it = [0]
@@ -61,8 +73,10 @@ for key in order:
     kt = (K + 63) // 64
     row = f"{M:6d} {N:5d} {K:5d} m{mode} x{cnt:4.1f}  heuristic {cfg0[0]}x{cfg0[1]} s{cfg0[2]}: {us0:6.1f} / {us0b:6.1f} us |"
     best = (min(us0, us0b), cfg0)
-    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+    for bm, bn in ((256, 256), (128, 128), (128, 64), (64, 64)):
         if N <= 64 and bn > 64:
+            continue
+        if bm == 256 and (mode != 0 or K % 128 or M < 2048 or N < 256):      # the 8-phase kernel: row-major 16-bit operands, K % 128 == 0
             continue
         tiles = -(-M // bm) * -(-N // bn)
         cands = {1}
