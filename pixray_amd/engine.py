@@ -506,6 +506,9 @@ class Session:
             return self._no_graph(f"{GRAPH_ENV}=0 must be in the environment before the HIP runtime starts")
         if self.batches != 1 or self.auto_stop or not self.opts:
             return self._no_graph("batches > 1, auto_stop, or no optimiser")
+        if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and os.environ.get("PRX_GRAPH_WITH_COLLECTIVES") != "1":
+            # the all-reduce of dL/d(image) would be captured with the iteration; RCCL inside a capture has not been run on a node
+            return self._no_graph("world_size > 1: collectives inside a capture are not validated (PRX_GRAPH_WITH_COLLECTIVES=1 to try)")
         params = [p for o in self.opts for g in o.param_groups for p in g["params"]]
         if not params or not all(p.is_cuda for p in params):
             return self._no_graph("optimised tensors are not on a GPU")
