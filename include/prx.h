@@ -387,6 +387,11 @@ void prx_gemm_tile_override(prx_gemm_ctx* c, int bm, int bn, int splits);
  * the rule, M = 0 drops all rules */
 void prx_gemm_tile_rule(prx_gemm_ctx* c, int M, int N, int K, int mode, int bm, int bn, int splits);
 
+/* what the launch planner does with a row-major 16-bit C[M,N] = A[M,K] * Bt[N,K]^T (no launch, no device needed): returns the number of
+ * leading rows it gives to the 256 x 256 8-phase kernel -- M (all), 0 (none: 4-wave kernels), or a multiple of 256 in between
+ * (whole rounds of 256 tiles on the 8-phase kernel, the remaining rows on the 4-wave kernels).  c may be NULL (default tuning). */
+int prx_gemm_plan_rows_8phase(prx_gemm_ctx* c, int M, int N, int K);
+
 /* per-launch GEMM timing (HIP events on the launch stream) for bench.py */
 void prx_profile_gemm_enable(prx_gemm_ctx* c, int on);
 int prx_profile_gemm_collect(prx_gemm_ctx* c, double* total_ms, double* total_flop, long long* launches);

@@ -74,6 +74,7 @@ prx_gemm_ctx* prx_gemm_ctx_create(void) { return (prx_gemm_ctx*)new GemmCtx(); }
 void prx_gemm_ctx_destroy(prx_gemm_ctx* c) { delete (GemmCtx*)c; }
 void prx_profile_gemm_enable(prx_gemm_ctx* c, int on) { prx_gemm_ctx_profile_enable((GemmCtx*)c, on); }
 void prx_gemm_tile_override(prx_gemm_ctx* c, int bm, int bn, int splits) { prx_gemm_ctx_force_tile((GemmCtx*)c, bm, bn, splits); }
+int prx_gemm_plan_rows_8phase(prx_gemm_ctx* c, int M, int N, int K) { return prx_gemm_plan_rows_8phase_impl((const GemmCtx*)c, M, N, K); }
 void prx_gemm_tile_rule(prx_gemm_ctx* c, int M, int N, int K, int mode, int bm, int bn, int splits) {
     prx_gemm_ctx_tile_rule((GemmCtx*)c, M, N, K, mode, bm, bn, splits);
 }

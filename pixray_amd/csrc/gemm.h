@@ -85,6 +85,7 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits);   // (0,0,
 void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, int bn, int splits);   // bm=0 drops it, M=0 drops all
 void prx_gemm_ctx_profile_enable(GemmCtx* c, int on);
 int prx_gemm_ctx_profile_collect(GemmCtx* c, double* total_ms, double* total_flop, long long* launches);
+int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K);   // host-only: the planner's decision for a plain row-major 16-bit product
 
 // Launch on `stream`.  `ws` is a scratch buffer for split-K partials (may be
 // null -> split-K disabled).  Returns 0 or a negative error code.

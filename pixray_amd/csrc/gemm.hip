@@ -995,6 +995,14 @@ static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
 
 static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx, int use8p);
 
+int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K) {
+    static const GemmCtx k_default;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    GemmDesc d;
+    d.a_mode = PRX_A_ROWMAJOR; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldb = K;
+    return plan_8phase(d, c ? *c : k_default).main_rows;
+}
+
 int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
     static const GemmCtx k_default;      // immutable: heuristics only
     const GemmCtx& cx = ctx ? *ctx : k_default;

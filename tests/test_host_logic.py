@@ -653,3 +653,32 @@ def test_fused_adam_stands_in_only_for_a_plain_device_adam():
     assert HipAdam.from_adam(torch.optim.SGD([p], 0.1)) is None
     assert HipAdam.from_adam(torch.optim.AdamW([p], 0.1)) is None
     assert HipAdam.from_adam(torch.optim.Adam([{"params": [p]}, {"params": [torch.zeros(2, requires_grad=True)]}], 0.1)) is None
+
+
+def test_gemm_planner_gives_the_8phase_kernel_whole_rounds_of_tiles():
+    """The launch planner (gemm.hip plan_8phase, queried through prx_gemm_plan_rows_8phase: host code, no device): the 256 x 256
+    8-phase kernel gets problems that fill the 256 CUs with whole rounds of 256 x 256 tiles, the rows of a ragged last round go
+    to the 4-wave kernels, and everything small -- the headline's M = 3200 products -- stays on the 4-wave kernels.  The shapes
+    are the ViT products of BASELINE.json configs[1..3] as measured in profiles/r03_cfg{2,3}_gemm_shapes.txt."""
+    from pixray_amd import _lib
+    lib = _lib.load()
+    plan = lambda M, N, K: lib.prx_gemm_plan_rows_8phase(None, M, N, K)
+    # configs[1], ViT-B/32 at 64 cutouts: 13 row tiles x 3..12 column tiles never reach a round of 256
+    for N, K in ((3072, 768), (768, 3072), (2304, 768), (768, 2304), (768, 768)):
+        assert plan(3200, N, K) == 0
+    # configs[3], ViT-L/14 at 256 cutouts: M = 65 792 = 257 row tiles
+    assert plan(65792, 1024, 4096) == 65536          # 256 row tiles x 4 = 4 whole rounds; the 257th row tile is peeled
+    assert plan(65792, 1024, 1024) == 65536
+    assert plan(65792, 1024, 3072) == 65536
+    assert plan(65792, 4096, 1024) == 65792          # 4112 tiles = 16.06 rounds: peeling would leave 94 % of a problem on the 4-wave kernels
+    assert plan(65792, 3072, 1024) == 65792
+    # configs[2], ViT-B/16 at 128 cutouts: M = 25 216 = 98.5 row tiles
+    assert plan(25216, 768, 3072) == 21760           # 85 row tiles x 3 = 255 tiles: one round, 3 456 rows peeled
+    assert plan(25216, 768, 768) == 21760
+    assert plan(25216, 3072, 768) == 25216
+    # not eligible: K not a multiple of 128; too few tiles
+    assert plan(65792, 1024, 592) == 0
+    assert plan(1024, 1024, 4096) == 0
+    for M, N, K in ((65792, 1024, 4096), (25216, 768, 3072), (8192, 8192, 8192)):
+        r = plan(M, N, K)
+        assert r == M or r % 256 == 0
