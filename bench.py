@@ -362,7 +362,7 @@ def main():
             "config": {"workload": wl["text"] if cutn == wl["num_cuts"] else wl["text"] + f" [run at {cutn} cutouts per perceptor]",
                        "weights": "seeded random, real architectures", "cutouts_per_gpu": cutn // world,
                        "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU",
-                       "launch": "hipGraph replay" if graphed else "eager",
+                       "launch": "hipGraph replay" if graphed else ("eager" + (f" (replay refused: {sess.graph_error})" if args.graph and getattr(sess, "graph_error", None) else "")),
                        "precision": {"fp16": "IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16: the reference's CLIP arithmetic on a GPU), "
                                              "fp32 accumulate / residual streams / norms, power-of-two gradient scale in the backward",
                                      "bf16": "bf16 MFMA operands, fp32 accumulate / residual streams / norms",
