@@ -247,6 +247,7 @@ class Session:
         self.last_losses: Optional[List[torch.Tensor]] = None
         self.last_embeds = None
         self._graph = None
+        self.graph_error = None          # why the last enable_graph() refused (None: not asked, or captured)
         self._host_ready = False
         self.cur_fill = 0.0
         self._shard_cutouts()
