@@ -894,6 +894,8 @@ GemmCtx::GemmCtx() {
     wide_tile = env_int("PRX_WIDE_TILE", 128);
     big_tile = env_int("PRX_BIG_TILE", 0);
     tile8p = env_int("PRX_GEMM_8P", 128);
+    fit = env_int("PRX_GEMM_FIT", 1);
+    fit_flags = env_int("PRX_FIT_FLAGS", 1);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
@@ -912,6 +914,8 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -3) { c->use_glds = splits; return; }      // (-3, x, on/off): direct-to-LDS v2 kernel vs register-staged v1
     if (bm == -5) { c->conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
     if (bm == -6) { c->tile8p = splits; return; }        // (-6, x, n): 256 x 256 8-phase tiles from n tiles on (0 = never)
+    if (bm == -7) { c->fit = splits; return; }           // (-7, x, on/off): fit tiles (gemmfit.hip)
+    if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (stagger, wide stores)
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
@@ -1071,6 +1075,21 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // very large problems (ViT-L/14 at 256 cutouts: M = 65 792): the 8-wave 256 x 128 tile, when it still fills the chip
     // several times over (A/B switch, off by default: see DESIGN.md section 6)
     if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
+    // fit tiles (gemmfit.hip): one workgroup per CU when a 160- or 80-row tile grid matches the chip (M = 3200: 240 tiles)
+    if (cx.fit && !use8p) {
+        struct Fit { int bm, bn; double eff; };
+        const Fit fits[3] = {{160, 256, 1.0}, {160, 192, 0.97}, {80, 128, 0.85}};
+        double best = 0.0;
+        for (const Fit& f : fits) {
+            if (!prx_gemmfit_eligible(d, f.bm, f.bn) || d.N < f.bn) continue;
+            const int t = ntiles(f.bm, f.bn);
+            if (t > 2 * n_cu) continue;                                   // a one- or two-round kernel by construction
+            const double fill = (double)t / ((double)ceil_div(t, n_cu) * n_cu);
+            const double waste = ((double)ceil_div(d.M, f.bm) * f.bm / d.M) * ((double)ceil_div(d.N, f.bn) * f.bn / d.N);
+            const double score = fill * f.eff / waste;
+            if (score > best && fill / waste >= 0.8) { best = score; BM = f.bm; BN = f.bn; }
+        }
+    }
     if (use8p) { BM = 256; BN = 256; }          // planned by plan_8phase (prx_gemm_launch)
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; }
     int rule_splits = 0;
@@ -1080,6 +1099,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
             if (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode) { BM = r.bm; BN = r.bn; rule_splits = r.splits; }
     }
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
+    bool fit_tile = prx_gemmfit_tile(BM, BN, nullptr);
+    if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { BM = 128; BN = 128; fit_tile = false; }
     if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
     const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
@@ -1089,7 +1110,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     a.kt_total = ceil_div(d.K, bk);
     int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16 && !(BM == 256 && BN == 256)) {
+    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16 && !(BM == 256 && BN == 256) && !fit_tile) {
         // few tiles, long K (the 16x16 / 32x32 decoder convs): aim at ~320 blocks, >= 4 K tiles per split
         splits = std::max(1, std::min(std::min((320 + tiles / 2) / tiles, a.kt_total / 4), 32));
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
@@ -1100,7 +1121,11 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
                 al(d.aux, opa) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
                 (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, opa) && al(d.out_bf16_pre, opa) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
-    if ((cx.force_splits > 0 || rule_splits > 0) && ws) {
+    if (fit_tile && !a.vec_epi) {               // the fit kernel has the vector epilogue only
+        BM = 128; BN = 128; fit_tile = false;
+        a.tiles_m = ceil_div(d.M, BM); a.tiles_n = ceil_div(d.N, BN); tiles = a.tiles_m * a.tiles_n;
+    }
+    if ((cx.force_splits > 0 || rule_splits > 0) && ws && !fit_tile) {
         splits = std::min(rule_splits > 0 ? rule_splits : cx.force_splits, a.kt_total);
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
     }
@@ -1112,6 +1137,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     if (cx.xcd_swizzle == 3) a.xcd_swizzle = tiles >= 16;
     // 8-phase tiles (tools/micro/gemm8p.hip): +11 % at M = 65 792, N = 1024 and at M = 25 216, N = 3072; -2 % at 8192^3
     if (BM == 256 && BN == 256 && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 512 && d.N <= 4096;
+    if (fit_tile && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 16;
     if (d.gnb_x) {
         PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
                     "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");
@@ -1122,6 +1148,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && cx.use_glds,
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
+    a.fit_flags = fit_tile ? cx.fit_flags : 0;          // gemmfit.hip A/B switches (PRX_FIT_FLAGS)
     a.kt_per_split = ceil_div(a.kt_total, splits);
     if (BM == 256 && BN == 256) a.kt_per_split = (a.kt_per_split + 1) & ~1;      // the 8-phase loop body covers two K tiles
     splits = ceil_div(a.kt_total, a.kt_per_split);
@@ -1149,6 +1176,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         else launch_f32<64, 64>(a, grid, stream);
     } else if (BM == 256 && BN == 256) {
         prx_gemm8p_launch(a, grid, stream);
+    } else if (fit_tile) {
+        prx_gemmfit_launch(a, BM, BN, grid, stream);
     } else if (!d.a_is_f32 && cx.use_glds) {
         const bf16_t* zp = zero_page_for_current_device();
         PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");

@@ -11,6 +11,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     int xcd_swizzle;
+    int fit_flags;   // gemmfit.hip: bit 0 = staggered wave groups; bits 2, 3 = timing experiments (no epilogue / no main loop)
     float* ws;
 };
 
@@ -76,55 +77,97 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     if (d.out_bf16) op_st(reinterpret_cast<TOp*>(d.out_bf16), (size_t)row * d.ldc_bf16 + col, v);
 }
 
-// 4 consecutive columns at once (all pointers / leading dimensions checked 16-byte friendly by the host)
+// The VALUE part of the epilogue on 4 consecutive columns, operands already in registers: alpha, bias_n[col..], bias_m[row]
+// (zeros when absent), dQuickGELU / ReLU-mask forms on `aux`, residual, ReLU, QuickGELU.  `pre` receives the (operand-rounded)
+// pre-activation of PRX_ACT_QUICKGELU.  has_resid: d.resid != nullptr (its 4 values are in `res`).
 template <typename TOp>
-__device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
-    const TOp* aux = reinterpret_cast<const TOp*>(d.aux);
-    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;     // uniform address: a scalar load
+__device__ __forceinline__ float4 epilogue_math4(int act, float alpha, float4 v, const float4& bias, float bias_m, const float (&aux)[4],
+                                                 bool has_resid, const float4& res, float4& pre) {
     v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-    if (d.bias_n) {
-        const float4 b = *reinterpret_cast<const float4*>(d.bias_n + col);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (d.bias_m) { const float b = d.bias_m[row]; v.x += b; v.y += b; v.z += b; v.w += b; }
-    if (d.act == PRX_ACT_MUL_DQUICKGELU) {
-        float t[4];
-        op_ld4(aux, (size_t)row * d.ldaux + col, t);
-        v.x *= dquickgelu_f(t[0]); v.y *= dquickgelu_f(t[1]); v.z *= dquickgelu_f(t[2]); v.w *= dquickgelu_f(t[3]);
+    v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+    v.x += bias_m; v.y += bias_m; v.z += bias_m; v.w += bias_m;
+    if (act == PRX_ACT_MUL_DQUICKGELU) {
+        v.x *= dquickgelu_f(aux[0]); v.y *= dquickgelu_f(aux[1]); v.z *= dquickgelu_f(aux[2]); v.w *= dquickgelu_f(aux[3]);
     }
     // ReLU backward: the mask (aux > 0) multiplies the product (MUL_RELUMASK) or the product + residual (RELUMASK_POST)
-    float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST) {
-        float t[4];
-        op_ld4(aux, (size_t)row * d.ldaux + col, t);
-        keep = make_float4(t[0] > 0.f ? 1.f : 0.f, t[1] > 0.f ? 1.f : 0.f, t[2] > 0.f ? 1.f : 0.f, t[3] > 0.f ? 1.f : 0.f);
+    const bool masked = act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
+    const bool k0 = !masked || aux[0] > 0.f, k1 = !masked || aux[1] > 0.f, k2 = !masked || aux[2] > 0.f, k3 = !masked || aux[3] > 0.f;
+    if (act == PRX_ACT_MUL_RELUMASK) {
+        if (!k0) v.x = 0.f;
+        if (!k1) v.y = 0.f;
+        if (!k2) v.z = 0.f;
+        if (!k3) v.w = 0.f;
     }
-    if (d.act == PRX_ACT_MUL_RELUMASK) {
-        if (keep.x == 0.f) v.x = 0.f;
-        if (keep.y == 0.f) v.y = 0.f;
-        if (keep.z == 0.f) v.z = 0.f;
-        if (keep.w == 0.f) v.w = 0.f;
-    }
-    if (d.resid) {
-        const float4 r = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        if (d.act == PRX_ACT_RELUMASK_POST) {
-            if (keep.x == 0.f) v.x = 0.f;
-            if (keep.y == 0.f) v.y = 0.f;
-            if (keep.z == 0.f) v.z = 0.f;
-            if (keep.w == 0.f) v.w = 0.f;
+    if (has_resid) {
+        v.x += res.x; v.y += res.y; v.z += res.z; v.w += res.w;
+        if (act == PRX_ACT_RELUMASK_POST) {
+            if (!k0) v.x = 0.f;
+            if (!k1) v.y = 0.f;
+            if (!k2) v.z = 0.f;
+            if (!k3) v.w = 0.f;
         }
     }
-    if (d.act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (d.act == PRX_ACT_QUICKGELU) {
-        const TOp p0 = op_cvt<TOp>(v.x), p1 = op_cvt<TOp>(v.y), p2 = op_cvt<TOp>(v.z), p3 = op_cvt<TOp>(v.w);
-        if (d.out_bf16_pre)
-            op_st4(reinterpret_cast<TOp*>(d.out_bf16_pre), (size_t)row * d.ldc_bf16 + col, (float)p0, (float)p1, (float)p2, (float)p3);
-        v.x = quickgelu_f((float)p0); v.y = quickgelu_f((float)p1); v.z = quickgelu_f((float)p2); v.w = quickgelu_f((float)p3);
+    if (act == PRX_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (act == PRX_ACT_QUICKGELU) {
+        // the saved pre-activation is what the backward differentiates: activate its rounded value
+        pre = make_float4((float)op_cvt<TOp>(v.x), (float)op_cvt<TOp>(v.y), (float)op_cvt<TOp>(v.z), (float)op_cvt<TOp>(v.w));
+        v.x = quickgelu_f(pre.x); v.y = quickgelu_f(pre.y); v.z = quickgelu_f(pre.z); v.w = quickgelu_f(pre.w);
     }
+    return v;
+}
+
+// ... with the operand loads (all pointers / leading dimensions checked 16-byte friendly by the host)
+template <typename TOp>
+__device__ __forceinline__ float4 epilogue_value4(const GemmDesc& d, int row, int col, float4 v, float4& pre) {
+    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;     // uniform address: a scalar load
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias_n) bias = *reinterpret_cast<const float4*>(d.bias_n + col);
+    const float bias_m = d.bias_m ? d.bias_m[row] : 0.f;
+    float aux[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.act == PRX_ACT_MUL_DQUICKGELU || d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST)
+        op_ld4(reinterpret_cast<const TOp*>(d.aux), (size_t)row * d.ldaux + col, aux);
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.resid) res = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
+    return epilogue_math4<TOp>(d.act, alpha, v, bias, bias_m, aux, d.resid != nullptr, res, pre);
+}
+
+template <typename TOp>
+__device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, int col, float4 v) {
+    float4 pre;
+    v = epilogue_value4<TOp>(d, row, col, v, pre);
+    if (d.act == PRX_ACT_QUICKGELU && d.out_bf16_pre)
+        op_st4(reinterpret_cast<TOp*>(d.out_bf16_pre), (size_t)row * d.ldc_bf16 + col, pre.x, pre.y, pre.z, pre.w);
     if (d.out_f32) *reinterpret_cast<float4*>(d.out_f32 + (size_t)row * d.ldc_f32 + col) = v;
     if (d.out_bf16) op_st4(reinterpret_cast<TOp*>(d.out_bf16), (size_t)row * d.ldc_bf16 + col, v.x, v.y, v.z, v.w);
     return v;
+}
+
+// 8 consecutive columns (16-bit operand types only; the host checked col % 8 == 0-friendly pointers: 16-byte aligned 16-bit
+// outputs with ldc_bf16 % 8 == 0): the 16-bit outputs leave as ONE 16-byte store per lane -- the store tail of a one-round
+// kernel is bound by store instructions, not bytes (cdna_hip_programming.md T21)
+template <typename T16>
+__device__ __forceinline__ void epilogue_store8(const GemmDesc& d, int row, int col, float4 v0, float4 v1) {
+    typedef __attribute__((ext_vector_type(8))) T16 t16x8;
+    float4 p0, p1;
+    v0 = epilogue_value4<T16>(d, row, col, v0, p0);
+    v1 = epilogue_value4<T16>(d, row, col + 4, v1, p1);
+    if (d.act == PRX_ACT_QUICKGELU && d.out_bf16_pre) {
+        t16x8 r;
+        r[0] = op_cvt<T16>(p0.x); r[1] = op_cvt<T16>(p0.y); r[2] = op_cvt<T16>(p0.z); r[3] = op_cvt<T16>(p0.w);
+        r[4] = op_cvt<T16>(p1.x); r[5] = op_cvt<T16>(p1.y); r[6] = op_cvt<T16>(p1.z); r[7] = op_cvt<T16>(p1.w);
+        *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16_pre) + (size_t)row * d.ldc_bf16 + col) = r;
+    }
+    if (d.out_f32) {
+        float* o = d.out_f32 + (size_t)row * d.ldc_f32 + col;
+        *reinterpret_cast<float4*>(o) = v0;
+        *reinterpret_cast<float4*>(o + 4) = v1;
+    }
+    if (d.out_bf16) {
+        t16x8 r;
+        r[0] = op_cvt<T16>(v0.x); r[1] = op_cvt<T16>(v0.y); r[2] = op_cvt<T16>(v0.z); r[3] = op_cvt<T16>(v0.w);
+        r[4] = op_cvt<T16>(v1.x); r[5] = op_cvt<T16>(v1.y); r[6] = op_cvt<T16>(v1.z); r[7] = op_cvt<T16>(v1.w);
+        *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = r;
+    }
 }
 
 
@@ -133,3 +176,8 @@ __device__ __forceinline__ float4 epilogue_store4(const GemmDesc& d, int row, in
 // gemm8p.hip: the 256 x 256 8-phase kernel (row-major 16-bit operands, K % 128 == 0, no fused GroupNorm statistics)
 bool prx_gemm8p_eligible(const GemmDesc& d);
 void prx_gemm8p_launch(const prx_gemm_dev::GemmArgs& a, dim3 grid, hipStream_t s);      // grid = (tiles, splits), kt_per_split even
+// gemmfit.hip: tiles that match the chip for M = 3200-class problems (160 x 256, 160 x 192, 80 x 128 with two K groups);
+// row-major 16-bit operands, K % (64 ks) == 0, vector epilogue, no split-K, no fused GroupNorm statistics
+bool prx_gemmfit_tile(int bm, int bn, int* ks);
+bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn);
+void prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (tiles, 1)

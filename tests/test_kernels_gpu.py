@@ -150,6 +150,90 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
+@pytest.mark.parametrize("tile", [(160, 256), (160, 192), (80, 128)])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("stagger", [1, 0])
+def test_gemm_fit_tiles(tile, prec, stagger):
+    """the fit-tile kernel (gemmfit.hip: 160 x 256, 160 x 192, 80 x 128 with two K groups) forced on ragged and exact shapes, every
+    epilogue form the ViT tower uses (bias + QuickGELU with both 16-bit outputs, dQuickGELU(aux), bias + residual -> fp32,
+    plain 16-bit), both 16-bit formats, staggered wave groups on and off; vs an fp32 product of the same rounded operands"""
+    lib = _lib.load()
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    tol16 = 4e-3 if prec == "bf16" else 5e-4
+    torch.manual_seed(11)
+    try:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, stagger)
+        for (M, N, K) in [(3200, 768, 768), (1000, 200, 1152), (333, 520, 256), (81, 136, 128), (160, 256, 384)]:
+            A = torch.randn(M, K, device=DEV).to(dt)
+            Bt = (torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K)).to(dt)
+            bias = torch.randn(N, device=DEV)
+            resid = torch.randn(M, N, device=DEV)
+            aux = torch.randn(M, N, device=DEV).to(dt)
+            prod = A.float() @ Bt.float().T
+
+            def run(**kw):
+                g = GemmArgs()
+                g.A = A.data_ptr(); g.a_is_f32 = 0; g.a_mode = 0; g.lda = K
+                g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+                g.alpha = kw.get("alpha", 1.0); g.f32 = 0 if prec == "bf16" else 2
+                outs = {}
+                if kw.get("bias"): g.bias_n = bias.data_ptr()
+                if kw.get("resid"): g.resid = resid.data_ptr(); g.ldr = N
+                if kw.get("aux"): g.aux = aux.data_ptr(); g.ldaux = N
+                g.act = kw.get("act", 0)
+                if kw.get("f32"):
+                    outs["f32"] = torch.full((M, N), float("nan"), device=DEV); g.out_f32 = outs["f32"].data_ptr(); g.ldc_f32 = N
+                if kw.get("o16"):
+                    outs["o16"] = torch.full((M, N), float("nan"), device=DEV, dtype=dt); g.out_bf16 = outs["o16"].data_ptr()
+                if kw.get("pre"):
+                    outs["pre"] = torch.full((M, N), float("nan"), device=DEV, dtype=dt); g.out_bf16_pre = outs["pre"].data_ptr()
+                g.ldc_bf16 = N
+                call("prx_k_gemm", g, None, 0, stream())
+                torch.cuda.synchronize()
+                return outs
+
+            o = run(bias=True, resid=True, f32=True, o16=True, alpha=0.5)
+            ref = 0.5 * prod + bias + resid
+            assert rel_l2(o["f32"], ref) < 2e-5, (M, N, K, rel_l2(o["f32"], ref))
+            assert rel_l2(o["o16"], ref) < tol16
+            o = run(bias=True, act=1, o16=True, pre=True)
+            pre = (prod + bias).to(dt).float()
+            assert rel_l2(o["pre"], pre) < tol16 and rel_l2(o["o16"], pre * torch.sigmoid(1.702 * pre)) < tol16
+            o = run(aux=True, act=2, o16=True)
+            sg = torch.sigmoid(1.702 * aux.float())
+            assert rel_l2(o["o16"], prod * (sg * (1 + 1.702 * aux.float() * (1 - sg)))) < tol16
+            o = run(o16=True)
+            assert rel_l2(o["o16"], prod) < tol16
+            assert not torch.isnan(o["o16"].float()).any()
+    finally:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
+
+
+def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
+    """the planner gives the ViT-B/32 products of 64 cutouts (M = 3200) one workgroup per CU: 240 tiles of 160 x 256, 160 x 192 or
+    80 x 128, and the result is the 4-wave kernels' to fp32 round-off (another K summation order on the two-K-group tile)"""
+    lib = _lib.load()
+    torch.manual_seed(3)
+    for (M, N, K) in [(3200, 3072, 768), (3200, 2304, 768), (3200, 768, 3072)]:
+        A = torch.randn(M, K, device=DEV).to(torch.float16)
+        Bt = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.float16)
+        outs = []
+        for fit in (1, 0):
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, fit)
+            g = GemmArgs()
+            g.A = A.data_ptr(); g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+            g.alpha = 1.0; g.f32 = 2
+            out = torch.full((M, N), float("nan"), device=DEV); g.out_f32 = out.data_ptr(); g.ldc_f32 = N
+            call("prx_k_gemm", g, None, 0, stream())
+            torch.cuda.synchronize()
+            outs.append(out)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 1)
+        assert rel_l2(outs[0], outs[1]) < 2e-6
+        assert rel_l2(outs[0], A.float() @ Bt.float().T) < 2e-5
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [
     (16, 16, 256, 512, 0, 1), (32, 32, 512, 256, 1, 1), (64, 64, 128, 128, 0, 1), (8, 12, 32, 40, 1, 2),
     (256, 256, 128, 128, 0, 1), (64, 64, 8, 128, 0, 1),
