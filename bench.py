@@ -120,6 +120,24 @@ class CollectiveTimer:
         return {k: round(v / steps, 4) for k, v in out.items()}
 
 
+def spawn_command(n, argv, port=None):
+    """the command line `python bench.py --gpus n` re-executes itself under (one rank per GPU of this node over RCCL)"""
+    import socket
+    if port is None:
+        with socket.socket() as so:              # a free rendezvous port on the loopback interface
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL / IPC handles need the dmabuf path on this driver
+    return subprocess.call(spawn_command(n, argv), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +159,25 @@ def main():
     ap.add_argument("--cpu-sample-cutn", type=int, default=None)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--phase-steps", type=int, default=2, help="iterations of the synchronised phase breakdown (0: skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch mechanics only: every rank joins a gloo group on the host, rank 0 prints {world, ranks} and exits "
+                         "(CPU test of the bare `--gpus N` form; no GPU touched)")
     args = ap.parse_args()
+
+    if args.dry_run:
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+        import torch.distributed as dist
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        seen = [rank]
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            seen = [None] * world
+            dist.all_gather_object(seen, rank)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "world": world, "ranks": sorted(seen), "gpus": args.gpus}), flush=True)
+        return
 
     import torch
     from pixray_amd import _lib, api
@@ -155,8 +191,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one process per GPU, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` form does; rank 0 prints the JSON line
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (got {world}): launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` "
+                         f"or bare `python bench.py --gpus {args.gpus}`")
+    # PRX_ONE_DEVICE=1 + PRX_DIST_BACKEND=gloo: every rank on cuda:0 with the host-side bootstrap on gloo and ALL THREE collectives
+    # of the iteration on the C-ABI one-shot exchange (csrc/comm.hip) -- how the multi-rank path is exercised end to end where
+    # only one GPU is reachable (RCCL refuses two ranks on one device; the exchange does not care where the peer window lives)
+    one_device = os.environ.get("PRX_ONE_DEVICE") == "1"
+    backend = os.environ.get("PRX_DIST_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
+    if backend != "nccl":
+        os.environ["PRX_ONESHOT_ALLREDUCE"] = "1"          # gloo carries the bootstrap and the barriers only
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -165,7 +216,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
     torch.manual_seed(1234 + rank)          # per-rank device noise streams (host-side draws are seeded identically)
 
@@ -205,7 +259,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
@@ -362,6 +416,10 @@ def main():
             "config": {"workload": wl["text"] if cutn == wl["num_cuts"] else wl["text"] + f" [run at {cutn} cutouts per perceptor]",
                        "weights": "seeded random, real architectures", "cutouts_per_gpu": cutn // world,
                        "parallelism": f"cutout-sharded x{world}, all-reduce of dL/d(image)" if world > 1 else "single GPU",
+                       "exchange": (None if world == 1 else
+                                    ("C-ABI one-shot direct-write all-reduce (prx_allreduce, csrc/comm.hip) for all three collectives"
+                                     if getattr(sess, "comm", None) is not None or os.environ.get("PRX_ONESHOT_ALLREDUCE") == "1"
+                                     else "RCCL through torch.distributed (nccl)") + (", every rank on ONE device (protocol test)" if one_device else "")),
                        "launch": "hipGraph replay" if graphed else ("eager" + (f" (replay refused: {sess.graph_error})" if args.graph and getattr(sess, "graph_error", None) else "")),
                        "precision": {"fp16": "IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16: the reference's CLIP arithmetic on a GPU), "
                                              "fp32 accumulate / residual streams / norms, power-of-two gradient scale in the backward",

@@ -68,7 +68,7 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len);
  *                  of bf16's 8.  Conversions saturate at +-65504, and every runner backward runs under a power-of-two
  *                  gradient scale S chosen ON THE DEVICE from the gradient entering it (S * max|g| in [8, 16); no host
  *                  synchronisation; exact, because each backward op is linear in the incoming gradient and ClampWithGrad /
- *                  ReLU masks only read signs) that is removed before anything leaves the handle.  The VQGAN encoder, the CLIP text tower and the VGG16 extractor stay bf16 / fp32. */
+ *                  ReLU masks only read signs) that is removed before anything leaves the handle.  The VGG16 extractor of the StyleLoss plugin has the same three modes; the VQGAN encoder and the CLIP text tower (forward only) stay bf16 / fp32. */
 #define PRX_PREC_BF16 0
 #define PRX_PREC_F32 1
 #define PRX_PREC_F16 2
@@ -208,8 +208,9 @@ int prx_vqgan_encode(prx_vqgan_enc* h, const float* img, float* z, float* z_pre,
  * x: [3,H,W] fp32, already in the extractor's input space (StyleLoss.py:41-45 normalises outside this call).
  * feats[k] (k = 0..8, or NULL when not wanted): fp32 NHWC [h_k*w_k, C_k], shape from prx_vgg16_feature_shape.
  * workspace: caller-owned device buffer of prx_vgg16_workspace_bytes(H, W) bytes holding this forward's activations; the
- * matching backward reads it, so any number of forward passes can be alive at once.  precision: PRX_PREC_BF16 | PRX_PREC_F32
- * (the workspace of the exact mode is twice as large).
+ * matching backward reads it, so any number of forward passes can be alive at once.  precision: PRX_PREC_BF16 | PRX_PREC_F16 |
+ * PRX_PREC_F32 (the workspace of the exact mode is twice as large; the half mode's backward runs under the power-of-two
+ * gradient scale described at PRX_PREC_F16, chosen from max |g_feats| on the device).
  * backward: g_feats[k] fp32 NHWC gradient of feature k (or NULL); g_x: [3,H,W] fp32, overwritten. */
 typedef struct prx_vgg16 prx_vgg16;
 int prx_vgg16_create(prx_vgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, int precision,
@@ -419,6 +420,15 @@ int prx_comm_create(prx_comm** out, int rank, int world, size_t max_bytes);
 int prx_comm_export(prx_comm* c, void* handle_out);
 int prx_comm_connect(prx_comm* c, const void* handles);
 int prx_allreduce_grad(prx_comm* c, float* grad, size_t n, prx_stream_t stream);
+/* the same exchange for the two scalar-sized collectives of the sharded iteration, so that a C-ABI caller needs nothing else:
+ * PRX_COMM_MAX_F32 for the {-min, max} pair of the batch-global renormalisation (slip.py:21-36), PRX_COMM_SUM_F64 for its four
+ * backward sums.  n_words counts 4-byte words (a double = 2), a multiple of 4; data 16-byte aligned.  A wait that times out
+ * poisons the result with NaN (never a plausible partial sum) and is reported by prx_comm_status.  The kernel's <= 64 blocks
+ * must be co-resident (they are on an otherwise idle stream; see csrc/comm.hip). */
+#define PRX_COMM_SUM_F32 0
+#define PRX_COMM_MAX_F32 1
+#define PRX_COMM_SUM_F64 2
+int prx_allreduce(prx_comm* c, void* data, size_t n_words, int op, prx_stream_t stream);
 int prx_comm_status(prx_comm* c);
 void prx_comm_destroy(prx_comm* c);
 

@@ -57,22 +57,29 @@ def iteration_chunked(workload: str, cutn: int, seed: int = 0, prm: Optional[Dic
         x = clip_vit_ref.preprocess(cuts_d[S])
         x_val = x.detach()
         gx = torch.zeros_like(x_val)
+        # the tower's Prompt list, as workload_ref.iteration builds it: the seeded stand-in at weight 1 and pixray's default
+        # `textoff` vector prompt at 0.1 where the reference's table has the tower (pixray.py:887-915)
         e_t = api.seeded_unit_vectors(1, cfg.output_dim, seed + 2 + (mi if kind == "vqgan" else 0))
-        prompt = prompt_ref.Prompt(e_t, 1.0, float("-inf"))
-        loss_t, embs = 0.0, []
+        prompts = [prompt_ref.Prompt(e_t, 1.0, float("-inf"))]
+        for vp in api.WORKLOADS[workload]["vector_prompts"]:
+            table = api.load_vector_table(vp)
+            if name in table:
+                prompts.append(prompt_ref.Prompt(torch.tensor(table[name], dtype=torch.float32), 0.1, float("-inf")))
+        loss_t, embs = [0.0] * len(prompts), []
         for c0 in range(0, cutn, chunk):
             t1 = time.perf_counter()
             xc = x_val[c0:c0 + chunk].clone().requires_grad_(True)
             e = _tower(tkind, cfg, params, xc)
-            l = prompt(e) * (e.shape[0] / cutn)
-            (g,) = torch.autograd.grad(l, xc)
+            ls = [pr(e) * (e.shape[0] / cutn) for pr in prompts]
+            (g,) = torch.autograd.grad(sum(ls), xc)
             gx[c0:c0 + chunk] = g
-            loss_t += float(l.detach())
+            for i, l in enumerate(ls):
+                loss_t[i] += float(l.detach())
             embs.append(e.detach())
             say(f"{name}: cutouts {c0}..{c0 + e.shape[0] - 1} {time.perf_counter() - t1:.1f}s")
         (g,) = torch.autograd.grad(x, cuts_d[S], gx)
         g_cuts[S] += g
-        losses.append(loss_t)
+        losses += loss_t
         emb = torch.cat(embs)
     if custom:
         terms = []

@@ -122,7 +122,21 @@ def _metrics(a: torch.Tensor, b: torch.Tensor) -> Tuple[float, float]:
 def _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=0.2, precision=None):
     from pixray_amd import api
     return api.build_vqgan_clip_session(size=size, vqgan_model=vqgan_model, clip_model=clip_model, num_cuts=cutn,
-                                        seed=seed, device=device, learning_rate=lr, precision=precision)
+                                        seed=seed, device=device, learning_rate=lr, precision=precision,
+                                        vector_prompts=("textoff",), stand_in_prompt=True)
+
+
+def prompt_list(clip_model, clip_cfg, seed):
+    """the Prompts of the harness as (embed, weight, stop): the seeded stand-in for a text prompt at weight 1, and pixray's
+    DEFAULT second prompt -- `--vector_prompts textoff`, weight 0.1 x 1 (pixray.py:887-915, 1732) -- from the reference's own
+    table (the one real CLIP-space vector the reference holds; towers without a row in it, e.g. the tiny test towers, go
+    without, as the reference does)"""
+    from pixray_amd import api
+    out = [(api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2), 1.0, float("-inf"))]
+    table = api.load_vector_table("textoff")
+    if clip_model in table:
+        out.append((torch.tensor(table[clip_model], dtype=torch.float32), 0.1, float("-inf")))
+    return out
 
 
 def _oracle_inputs(vqgan_model, clip_model, seed):
@@ -169,13 +183,13 @@ def compare_one_iteration(vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     mk = sess.cutoutsTable[S]
     mk.fixed_params = prm
     z0 = sess.drawer.get_z().detach().cpu().clone()
-    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    prompts = prompt_list(clip_model, clip_cfg, seed)
     losses = sess.ascend_txt()
     loss = sum(losses)
     loss.backward()
     dz = sess.drawer.get_z().grad.detach().cpu()
     img_hip = sess.drawer.synth(0).detach().cpu()
-    ref = oracle_iteration(vq_params, vq_cfg, clip_params, clip_cfg, z0, prm, [(emb_p, 1.0, float("-inf"))], S)
+    ref = oracle_iteration(vq_params, vq_cfg, clip_params, clip_cfg, z0, prm, prompts, S)
     idx_ref, _ = vqgan_ref.vq_indices(z0.movedim(1, 3).reshape(-1, z0.shape[1]), vq_params["quantize.embedding.weight"])
     rel, cos = _metrics(dz, ref["dz"])
     erel, _ = _metrics(sess.last_embeds, ref["emb"])
@@ -229,7 +243,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     z_ref = sess.drawer.get_z().detach().cpu().clone().requires_grad_(True)
     opt = torch.optim.Adam([z_ref], lr=lr)
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
-    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    prompts = prompt_list(clip_model, clip_cfg, seed)
     dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok = [], [], [], [], [], [], []
     for it in range(k):
         prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
@@ -252,7 +266,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         idx_ref, _ = vqgan_ref.vq_indices(z_ref.detach().movedim(1, 3).reshape(-1, z_ref.shape[1]),
                                           vq_params["quantize.embedding.weight"])
         opt.zero_grad()
-        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z_ref, prm, [(emb_p, 1.0, float("-inf"))], S)
+        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z_ref, prm, prompts, S)
         sum(losses).backward()
         r, c = _metrics(dz_hip, z_ref.grad)
         dz_rel.append(r); dz_cos.append(c)
@@ -289,13 +303,13 @@ def time_oracle_iterations(n_iters=3, warmup=1, vqgan_model="imagenet_f16_16384"
     z = torch.randn(1, vq_cfg.z_channels, size[1] // f, size[0] // f, generator=g).requires_grad_(True)
     opt = torch.optim.Adam([z], lr=lr)
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
-    emb_p = api.seeded_unit_vectors(1, clip_cfg.output_dim, seed + 2)
+    prompts = prompt_list(clip_model, clip_cfg, seed)
     times = []
     for it in range(warmup + n_iters):
         t0 = time.perf_counter()
         prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
         opt.zero_grad()
-        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, [(emb_p, 1.0, float("-inf"))], S)
+        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z, prm, prompts, S)
         sum(losses).backward()
         opt.step()
         with torch.no_grad():

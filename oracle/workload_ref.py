@@ -137,6 +137,10 @@ def iteration(workload: str, cutn: int, seed: int = 0, prm: Optional[Dict[int, d
         emb = encode(tkind, cfg, params, cuts[S])
         e = api.seeded_unit_vectors(1, cfg.output_dim, seed + 2 + (mi if kind == "vqgan" else 0))
         losses.append(prompt_ref.Prompt(e, 1.0, float("-inf"))(emb))
+        for vp in api.WORKLOADS[workload]["vector_prompts"]:          # pixray's default `textoff` x0.1 (pixray.py:887-915)
+            table = api.load_vector_table(vp)
+            if name in table:
+                losses.append(prompt_ref.Prompt(torch.tensor(table[name], dtype=torch.float32), 0.1, float("-inf"))(emb))
     for t in custom:
         r = t["loss"].get_loss(cuts, img, args, globals={"cur_iteration": cur_iteration, "embeds": emb}, lossGlobals={})
         losses += [t["weight"] * l for l in (r if isinstance(r, (list, tuple)) else [r])]
@@ -151,15 +155,18 @@ def _metrics(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item(), (a @ b / (a.norm() * b.norm() + 1e-300)).item()
 
 
-def hip_gradient(workload: str, cutn: int, prec: str, prm, seed: int = 0, device: str = "cuda:0", custom_hip=(), args=None):
+def hip_gradient(workload: str, cutn: int, prec: str, prm, seed: int = 0, device: str = "cuda:0", custom_hip=(), args=None, before=None):
     """one iteration of the HIP path (product session, `prec` operand precision) on the explicit draws `prm`
-    -> dict(grad, losses, embeds, start), everything on the CPU"""
+    -> dict(grad, losses, embeds, start), everything on the CPU.  `before()` runs right in front of the iteration (e.g. seeding
+    numpy's global generator, which the StyleLoss plugin samples from, the way the oracle side was seeded)"""
     from pixray_amd import api
     sess = api.build_workload(workload, num_cuts=cutn, precision=prec, device=device, seed=seed, custom_losses=custom_hip, args=args)
     for S, mk in sess.cutoutsTable.items():
         mk.fixed_params = prm[S]
     leaf = sess.drawer.get_z() if sess.drawer.get_z() is not None else sess.drawer.params[0]
     start = leaf.detach().cpu().clone()
+    if before is not None:
+        before()
     losses = sess.ascend_txt()
     sum(losses).backward()
     out = dict(grad=leaf.grad.detach().cpu(), losses=[float(l.detach()) for l in losses], embeds=sess.last_embeds.detach().cpu(),
@@ -177,7 +184,7 @@ def compare_with(ref: dict, hip: dict) -> Dict[str, float]:
 
 
 def compare_workload(workload: str, cutn: int, precisions=("bf16",), seed: int = 0, device: str = "cuda:0", custom_factory=None,
-                     custom_ref=(), args=None, ref: Optional[dict] = None) -> Dict[str, Dict[str, float]]:
+                     custom_ref=(), args=None, ref: Optional[dict] = None, before=None) -> Dict[str, Dict[str, float]]:
     """gradient w.r.t. the optimised tensor (z, or the fft drawer's spectrum) after ONE iteration: HIP path (one session per
     entry of `precisions`) vs this oracle (evaluated once, or handed in as `ref` -- e.g. a committed full-size fixture of
     tools/fullsize_oracle.py), same weights, same start, same explicit augmentation draws and noise.
@@ -186,8 +193,10 @@ def compare_workload(workload: str, cutn: int, precisions=("bf16",), seed: int =
     out, grads = {}, {}
     for prec in precisions:
         custom_hip = custom_factory(prec) if custom_factory is not None else ()
-        hip = hip_gradient(workload, cutn, prec, prm, seed, device, custom_hip, args)
+        hip = hip_gradient(workload, cutn, prec, prm, seed, device, custom_hip, args, before)
         if ref is None:
+            if before is not None:
+                before()
             ref = iteration(workload, cutn, seed, prm, state=hip["start"], custom=custom_ref, args=args)
         out[prec] = compare_with(ref, hip)
         grads[prec] = hip["grad"]

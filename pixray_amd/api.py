@@ -35,6 +35,23 @@ def _maybe_oneshot_comm(group, rank, world_size, size):
     return OneShotComm(group, rank, world_size, max_bytes=4 * 4 * int(size[0]) * int(size[1]))
 
 
+VECTORS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors")
+
+
+def load_vector_table(f1: str) -> dict:
+    """pixray.py:891-904: a vector prompt names a json table {CLIP model name: [[...]]}: a path containing 'json' is opened as
+    it is, a bare name is `vectors/<name>.json` -- relative to the working directory as in the reference, else the copy this
+    package ships (`textoff`, pixray's DEFAULT --vector_prompts, pixray.py:1732; tools/make_vectors.py)"""
+    if "json" in f1:
+        path = f1
+    else:
+        path = os.path.join("vectors", f"{f1}.json")
+        if not os.path.exists(path):
+            path = os.path.join(VECTORS_DIR, f"{f1}.json")
+    with open(path) as f:
+        return json.load(f)
+
+
 def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32",
                              num_cuts=64, learning_rate=0.2, iterations=250, prompt_embeds: Optional[torch.Tensor] = None,
                              prompt_weight=1.0, extra_prompts: Sequence = (), seed=0, device="cuda", group=None, rank=0,
@@ -42,15 +59,18 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
                              vector_prompts: Sequence[str] = (), init_image: Optional[torch.Tensor] = None, tokenizer=None,
                              clip_text_params=None, image_prompts: Sequence[torch.Tensor] = (), image_prompt_weight=None,
                              image_prompt_shuffle: bool = False, init_weight: float = 0.0, init_weight_dist: float = 0.0,
-                             init_weight_pix: float = 0.0, init_weight_cos: float = 0.0, overlay_image=None,
+                             init_weight_pix: float = 0.0, init_weight_cos: float = 0.0, stand_in_prompt: bool = False,
+                             overlay_image=None,
                              overlay_every: int = 10, overlay_offset: int = 0, overlay_until: Optional[int] = None,
                              overlay_alpha: Optional[int] = None, precision: Optional[str] = None) -> Session:
     """The headline configuration of BASELINE.json configs[1]: VqganDrawer + one CLIP ViT perceptor + MakeCutouts +
     a text-like Prompt (precomputed embedding; random unit vector when none is given) + Adam on z.
 
     `prompts`: pixray text prompts "text[:weight[:stop]]" (pixray.py:859-877), encoded by the HIP text tower (needs the
-    CLIP merges table, pixray_amd/tokenizer.py); `vector_prompts`: paths of json files {model name: [[...]]} with
-    precomputed CLIP-space vectors, "path[:weight[:stop]]", weighted x0.1 as pixray.py:879-915 does; `init_image`:
+    CLIP merges table, pixray_amd/tokenizer.py); `vector_prompts`: names ("textoff": pixray's default, shipped under
+    pixray_amd/vectors/) or json paths of tables {model name: [[...]]} with precomputed CLIP-space vectors,
+    "name[:weight[:stop]]", weighted x0.1 as pixray.py:887-915 does; `stand_in_prompt`: keep the seeded unit vector that stands
+    in for a text prompt (no CLIP text checkpoint offline) next to the vector prompts; `init_image`:
     [1,3,H,W] in [0,1], encoded to the starting z by the HIP VQGAN encoder (pixray.py:696-718); `image_prompts`: target
     images [1,3,H,W] in [0,1] turned into per-iteration throwaway Prompts through the cached cutout transforms
     (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`);
@@ -82,16 +102,15 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
         for prompt in prompts:                                                              # pixray.py:859-877
             txt, weight, stop = parse_prompt(prompt)
             pms.append(Prompt(perceptor.encode_text(txt).float(), weight, stop).to(dev))
-        for vp in vector_prompts:                                                           # pixray.py:879-915
-            path, weight, stop = parse_prompt(vp)
-            with open(path) as f:
-                table = json.load(f)
-            if name not in table:
-                print(f"WARNING: no vector for {name} in {path}!")
+        for vp in vector_prompts:                                                           # pixray.py:887-915
+            f1, weight, stop = parse_prompt(vp)
+            table = load_vector_table(f1)
+            if name not in table:                       # pixray.py:906-910: warn and go on without it
+                print(f"WARNING: no vector for {name} in {f1}!")
                 continue
             pms.append(Prompt(torch.tensor(table[name], dtype=torch.float32), 0.1 * weight, stop).to(dev))
         pe = prompt_embeds[name] if isinstance(prompt_embeds, dict) else (prompt_embeds if mi == 0 else None)
-        if pe is None and not pms:
+        if pe is None and (stand_in_prompt or not pms):
             pe = seeded_unit_vectors(1, perceptor.output_dim, seed + 2 + mi)
         if pe is not None:
             pms.insert(0, Prompt(pe.to(dev), prompt_weight, float("-inf")).to(dev))
@@ -140,11 +159,15 @@ def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=2
 # BASELINE.json `configs` as (builder kwargs); configs[0] is the CPU plumbing case (tests/test_host_logic.py), configs[4]
 # (vdiff) has no source in the reference checkout
 WORKLOADS = {
-    "cfg1": dict(kind="vqgan", size=(256, 256), clip_model="ViT-B/32", num_cuts=64,
-                 text="vqgan imagenet_f16_16384 256x256 + CLIP ViT-B/32 + 64 cutouts, 1 prompt, Adam lr 0.2"),
-    "cfg2": dict(kind="vqgan", size=(512, 512), clip_model=["ViT-B/16", "RN50x4"], num_cuts=128,
-                 text="vqgan imagenet_f16_16384 512x512 + CLIP ViT-B/16 + RN50x4 ensemble, 128 cutouts per perceptor, Adam lr 0.2"),
-    "cfg3": dict(kind="fft", size=(512, 512), clip_model="ViT-L/14", num_cuts=256,
+    # every configuration carries pixray's default second prompt, `--vector_prompts textoff` at weight x0.1 (pixray.py:887-915,
+    # 1732), wherever the reference's table has the tower (it has no ViT-L/14 row: the reference warns and goes on without it)
+    "cfg1": dict(kind="vqgan", size=(256, 256), clip_model="ViT-B/32", num_cuts=64, vector_prompts=("textoff",),
+                 text="vqgan imagenet_f16_16384 256x256 + CLIP ViT-B/32 + 64 cutouts, 2 prompts (text-prompt stand-in x1.0 + the "
+                      "reference's default `textoff` vector prompt x0.1), Adam lr 0.2"),
+    "cfg2": dict(kind="vqgan", size=(512, 512), clip_model=["ViT-B/16", "RN50x4"], num_cuts=128, vector_prompts=("textoff",),
+                 text="vqgan imagenet_f16_16384 512x512 + CLIP ViT-B/16 + RN50x4 ensemble, 128 cutouts per perceptor, 2 prompts per "
+                      "perceptor (stand-in + `textoff` x0.1), Adam lr 0.2"),
+    "cfg3": dict(kind="fft", size=(512, 512), clip_model="ViT-L/14", num_cuts=256, vector_prompts=(),
                  text="fft spectrum drawer 512x512 + CLIP ViT-L/14 + 256 cutouts + StyleLoss (VGG16 STROTSS) + SaturationLoss, Adam lr 0.3"),
 }
 
@@ -158,7 +181,8 @@ def build_workload(name: str, *, num_cuts=None, precision=None, device="cuda", g
     if w["kind"] == "vqgan":
         return build_vqgan_clip_session(size=w["size"], vqgan_model="imagenet_f16_16384", clip_model=w["clip_model"], num_cuts=n,
                                         learning_rate=0.2, iterations=10 ** 9, seed=seed, device=device, group=group, rank=rank,
-                                        world_size=world_size, precision=precision, custom_losses=custom_losses)
+                                        world_size=world_size, precision=precision, custom_losses=custom_losses,
+                                        vector_prompts=w["vector_prompts"], stand_in_prompt=True)
     sess = build_fft_clip_session(size=w["size"], clip_model=w["clip_model"], num_cuts=n, iterations=10 ** 9, seed=seed,
                                   device=device, group=group, rank=rank, world_size=world_size, custom_losses=custom_losses,
                                   args=args, precision=precision)

@@ -56,10 +56,20 @@ __device__ __forceinline__ char* slot_of(char* win, int parity, int rank, int wo
     return win + sizeof(CommWindowHdr) + ((size_t)parity * world + rank) * max_bytes;
 }
 
+// OP: PRX_COMM_SUM_F32 (the image gradient), PRX_COMM_MAX_F32 (the {-min, max} pair of the batch-global renormalisation,
+// slip.py:21-36) or PRX_COMM_SUM_F64 (its four backward sums); `n` counts 4-byte words, padded to a multiple of 4 by the host.
+//
+// CO-RESIDENCY: a block waits (step 3) for flags that its own rank raises only after ALL of this launch's blocks have arrived
+// (step 2), so every block of the launch must be resident at once.  The launch is <= COMM_BLOCKS = 64 blocks of 256 threads
+// with no LDS to speak of and a few dozen registers -- a quarter of the CUs at one block each, and a CU takes eight such
+// blocks -- so it is resident as a whole whenever the device is not fully occupied by OTHER streams' long-running kernels;
+// the Session issues it on the iteration's own stream, where nothing else runs beside it.  A launch that could not become
+// resident ends in the bounded wait below, i.e. in a reported error, not in a hang.
+template <int OP>
 __global__ __launch_bounds__(COMM_THREADS) void oneshot_allreduce_kernel(CommPeers peers, float* __restrict__ data, size_t n, int rank, int world,
                                                                         size_t max_bytes, unsigned long long seq, int* __restrict__ err) {
     const int parity = (int)(seq & 1);
-    const size_t n4 = n >> 2;                                  // float4 chunks (n is padded to a multiple of 4 by the host side)
+    const size_t n4 = n >> 2;                                  // 16-byte chunks
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
     // (1) push: my vector into slot[rank] of every window
     const float4* src = reinterpret_cast<const float4*>(data);
@@ -72,7 +82,9 @@ __global__ __launch_bounds__(COMM_THREADS) void oneshot_allreduce_kernel(CommPee
     __syncthreads();
     CommWindowHdr* mine = reinterpret_cast<CommWindowHdr*>(peers.win[rank]);
     __shared__ int last;
+    __shared__ int timed_out;
     if (threadIdx.x == 0) {
+        timed_out = 0;
         const unsigned prev = __hip_atomic_fetch_add(&mine->arrive[parity], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last = prev == gridDim.x - 1;
         if (last) {
@@ -88,19 +100,33 @@ __global__ __launch_bounds__(COMM_THREADS) void oneshot_allreduce_kernel(CommPee
             long long spins = 0;
             while (ld_flag_sys(&mine->flag[parity][r]) != seq) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1ll << 26)) { if (err) atomicExch(err, 1 + r); break; }
+                if (++spins > (1ll << 26)) { if (err) atomicExch(err, 1 + r); timed_out = 1; break; }
             }
+            if (timed_out) break;
         }
         __threadfence_system();
     }
     __syncthreads();
-    // (4) sum the slots in rank order (identical on every rank)
+    // (4) combine the slots in rank order (identical on every rank).  After a timed-out wait the slots are not all this call's
+    // data: the result is poisoned with NaN instead of a plausible partial sum, and prx_comm_status reports the rank
     float4* out = reinterpret_cast<float4*>(data);
+    if (timed_out) {
+        const float q = __builtin_nanf("");
+        for (size_t i = tid; i < n4; i += nthr) out[i] = make_float4(q, q, q, q);
+        return;
+    }
     for (size_t i = tid; i < n4; i += nthr) {
         float4 acc = reinterpret_cast<const float4*>(slot_of(peers.win[rank], parity, 0, world, max_bytes))[i];
         for (int r = 1; r < world; ++r) {
             const float4 v = reinterpret_cast<const float4*>(slot_of(peers.win[rank], parity, r, world, max_bytes))[i];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (OP == PRX_COMM_SUM_F32) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            else if (OP == PRX_COMM_MAX_F32) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+            else {
+                double2 a = __builtin_bit_cast(double2, acc);
+                const double2 b = __builtin_bit_cast(double2, v);
+                a.x += b.x; a.y += b.y;
+                acc = __builtin_bit_cast(float4, a);
+            }
         }
         out[i] = acc;
     }
@@ -173,22 +199,32 @@ int prx_comm_connect(prx_comm* c, const void* handles) {
     return 0;
 }
 
-// In-place SUM over ranks of n floats on `stream`; every rank must call it with the same n, in the same order.
-int prx_allreduce_grad(prx_comm* c, float* grad, size_t n, prx_stream_t stream) {
-    PRX_REQUIRE(c && grad, "allreduce_grad: null argument");
-    PRX_REQUIRE(c->connected, "allreduce_grad: prx_comm_connect has not been called");
-    PRX_REQUIRE(n % 4 == 0 && ((uintptr_t)grad & 15) == 0, "allreduce_grad: the vector must be 16-byte aligned with a length multiple of 4 (n=%zu)", n);
-    PRX_REQUIRE(n * sizeof(float) <= c->max_bytes, "allreduce_grad: %zu bytes exceed the window slot (%zu)", n * sizeof(float), c->max_bytes);
+// In-place reduction over ranks on `stream`; every rank must call it with the same op and length, in the same order.
+// n_words: the vector's length in 4-byte words (a double counts 2), a multiple of 4; 16-byte aligned.
+int prx_allreduce(prx_comm* c, void* data, size_t n_words, int op, prx_stream_t stream) {
+    PRX_REQUIRE(c && data, "allreduce: null argument");
+    PRX_REQUIRE(c->connected, "allreduce: prx_comm_connect has not been called");
+    PRX_REQUIRE(op == PRX_COMM_SUM_F32 || op == PRX_COMM_MAX_F32 || op == PRX_COMM_SUM_F64, "allreduce: unknown op %d", op);
+    PRX_REQUIRE(n_words % 4 == 0 && ((uintptr_t)data & 15) == 0, "allreduce: the vector must be 16-byte aligned with a length multiple of 16 bytes (n_words=%zu)", n_words);
+    PRX_REQUIRE(n_words * sizeof(float) <= c->max_bytes, "allreduce: %zu bytes exceed the window slot (%zu)", n_words * sizeof(float), c->max_bytes);
     if (c->world == 1) return 0;
     CommPeers peers;
     for (int i = 0; i < COMM_MAX_WORLD; ++i) peers.win[i] = c->peer[i];
     ++c->seq;
-    const int blocks = (int)std::min<size_t>(COMM_BLOCKS, std::max<size_t>(1, (n / 4 + COMM_THREADS - 1) / COMM_THREADS));
-    hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(blocks), dim3(COMM_THREADS), 0, (hipStream_t)stream, peers, grad, n, c->rank, c->world,
-                       c->max_bytes, c->seq, c->err);
+    const int blocks = (int)std::min<size_t>(COMM_BLOCKS, std::max<size_t>(1, (n_words / 4 + COMM_THREADS - 1) / COMM_THREADS));
+    hipStream_t st = (hipStream_t)stream;
+    float* f = (float*)data;
+    if (op == PRX_COMM_SUM_F32)
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
+    else if (op == PRX_COMM_MAX_F32)
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_MAX_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
+    else
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F64>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
     PRX_LAUNCH_CHECK();
     return 0;
 }
+// the image-gradient all-reduce (SUM, fp32): the exchange step the north star names
+int prx_allreduce_grad(prx_comm* c, float* grad, size_t n, prx_stream_t stream) { return prx_allreduce(c, grad, n, PRX_COMM_SUM_F32, stream); }
 
 // 0 = no wait has timed out so far; r + 1 = a wait for rank r's data gave up (synchronises the device)
 int prx_comm_status(prx_comm* c) {

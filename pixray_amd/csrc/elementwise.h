@@ -24,4 +24,10 @@ int prx_adam_clamp(float* z, float* m, float* v, const float* g, const float* zm
 int prx_adam_clamp_dev(float* z, float* m, float* v, const float* g, const float* zmin, const float* zmax, int hw,
                        size_t n, const float* hyper, float b1, float b2, float eps, hipStream_t s);
 int prx_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s, int h16 = 0);
+// the same over several tensors (one common S): part holds count * nparts_each floats
+int prx_grad_scale_multi(const float* const* gs, const size_t* ns, int count, float* part, int nparts_each, int target_log2,
+                         float* scale2, hipStream_t s);
 int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+// x[i] *= *scale with a DEVICE scalar: applies the half mode's power-of-two gradient scale to an fp32 gradient BEFORE it is
+// rounded to half (scaling in a GEMM epilogue would come after the operand conversion and lose the small entries to subnormals)
+int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s);

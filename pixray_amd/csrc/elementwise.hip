@@ -236,6 +236,12 @@ __global__ __launch_bounds__(256) void grad_scale_final_kernel(const float* __re
     }
 }
 
+// x *= *scale (a device scalar; the half mode's power-of-two gradient scale, so the product is exact)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, size_t n, const float* __restrict__ scale) {
+    const float sc = *scale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc;
+}
+
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -299,6 +305,27 @@ int prx_grad_scale(const float* g, size_t n, float* part, int nparts, int target
     hipLaunchKernelGGL(amax_partial_kernel, dim3(blocks), dim3(256), 0, s, g, n, part);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(256), 0, s, part, blocks, target_log2, scale2);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_grad_scale_multi(const float* const* gs, const size_t* ns, int count, float* part, int nparts_each, int target_log2,
+                         float* scale2, hipStream_t s) {
+    PRX_REQUIRE(count >= 1 && nparts_each >= 1 && (long long)count * nparts_each <= 4096, "grad_scale_multi: bad partial layout");
+    int used = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!gs[i] || ns[i] == 0) continue;
+        const int blocks = (int)std::min<size_t>((ns[i] + 1023) / 1024 + 1, (size_t)nparts_each);
+        hipLaunchKernelGGL(amax_partial_kernel, dim3(blocks), dim3(256), 0, s, gs[i], ns[i], part + used);
+        PRX_LAUNCH_CHECK();
+        used += blocks;
+    }
+    PRX_REQUIRE(used > 0, "grad_scale_multi: no gradient tensor");
+    hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(256), 0, s, part, used, target_log2, scale2);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, n, scale);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -507,7 +507,11 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     {   GemmDesc d; d.A = r->de; d.a_is_f32 = 1; d.lda = r->out_dim; d.B = r->WcT; d.ldb = r->out_dim; d.M = n; d.N = C; d.K = r->out_dim;
         d.out_bf16 = r->do0; d.ldc_bf16 = C;
         // half mode: the whole backward runs scaled by a power of two S chosen from max|d e|; stem1_bwd unscales
-        if (r->h16) { if ((e = prx_grad_scale(r->de, (size_t)n * r->out_dim, r->gs + 2, 64, prx_grad_target_log2(), r->gs, s))) return e; d.alpha_dev = r->gs; }
+        // (S multiplies d e in fp32 before the load converts it to half: see vit.hip)
+        if (r->h16) {
+            if ((e = prx_grad_scale(r->de, (size_t)n * r->out_dim, r->gs + 2, 64, prx_grad_target_log2(), r->gs, s))) return e;
+            if ((e = prx_scale_dev(r->de, (size_t)n * r->out_dim, r->gs, s))) return e;
+        }
         if ((e = rg(r, d, s))) return e; }
     RLAUNCH(tok0_scatter_kernel, (size_t)n * T * C, r->do0, r->dtok, n, T, C);
     if (r->f32) { if ((e = prx_mha_bwd_f32((const float*)r->qkv, (const float*)r->att, (const float*)r->dtok, r->lse, (float*)r->dqkv, n, T, C, r->heads, s))) return e; }

@@ -3,7 +3,9 @@
 // [1,3,6,8,11,13,15,22,29] = relu1_1 1_2 2_1 2_2 3_1 3_2 3_3 4_3 5_3).  Batch 1, any H x W up to the size given at
 // creation (STROTSS runs the extractor on a pyramid of image sizes).
 //
-// Layout: activations are NHWC bf16 (the implicit-GEMM engine's operand), every conv3x3+bias+ReLU is ONE launch of
+// Three operand precisions (prx.h PRX_PREC_*): bf16, IEEE half (with the power-of-two gradient scale of common.h in the
+// backward), exact f32.
+// Layout: activations are NHWC 16-bit (the implicit-GEMM engine's operand), every conv3x3+bias+ReLU is ONE launch of
 // the MFMA engine with the ReLU in its epilogue; captured layers also get their fp32 NHWC feature map written by the
 // same epilogue.  The 3-channel input is padded to 8 channels.  2x2/2 max pooling keeps a 2-bit argmax per output.
 // Backward per conv, top down: G = (gradient from the layer above, through the pool's argmax when there is one)
@@ -12,6 +14,7 @@
 // at once (STROTSS accumulates its loss over many extractor calls before one backward).
 #include "vgg.h"
 #include "gemm.h"
+#include "elementwise.h"
 #include <vector>
 #include <algorithm>
 
@@ -62,11 +65,11 @@ __global__ __launch_bounds__(256) void vgg_pack_kernel(const float* __restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += (size_t)gridDim.x * blockDim.x) {
         if (i < total) {
             const int ci = (int)(i % CiP), tap = (int)((i / CiP) % 9), co = (int)(i / ((size_t)9 * CiP));
-            Wf[i] = ci < Cin ? (TOp)w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : (TOp)0.f;
+            Wf[i] = op_cvt<TOp>(ci < Cin ? w[(((size_t)co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : 0.f);
         } else {
             const size_t j = i - total;
             const int co = (int)(j % Cout), tap = (int)((j / Cout) % 9), ci = (int)(j / ((size_t)9 * Cout));
-            Wd[j] = ci < Cin ? (TOp)w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)] : (TOp)0.f;
+            Wd[j] = op_cvt<TOp>(ci < Cin ? w[(((size_t)co * Cin + ci) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)] : 0.f);
         }
     }
 }
@@ -81,9 +84,12 @@ __global__ __launch_bounds__(256) void vgg_input_kernel(const float* __restrict_
     }
 }
 // dgrad of conv1_1 [HW][8] fp32 -> g_x [3][H][W]
-__global__ __launch_bounds__(256) void vgg_input_grad_kernel(const float* __restrict__ d, float* __restrict__ gx, int HW) {
+// `unscale`: device scalar 1/S of the half mode's gradient scale, or null
+__global__ __launch_bounds__(256) void vgg_input_grad_kernel(const float* __restrict__ d, float* __restrict__ gx, int HW,
+                                                             const float* __restrict__ unscale) {
+    const float u = unscale ? *unscale : 1.f;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-        gx[p] = d[(size_t)p * 8]; gx[HW + p] = d[(size_t)p * 8 + 1]; gx[2 * (size_t)HW + p] = d[(size_t)p * 8 + 2];
+        gx[p] = u * d[(size_t)p * 8]; gx[HW + p] = u * d[(size_t)p * 8 + 1]; gx[2 * (size_t)HW + p] = u * d[(size_t)p * 8 + 2];
     }
 }
 
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void vgg_maxpool_kernel(const void* __restrict
         float v = (float)p[C]; if (v > best) { best = v; a = 1; }
         v = (float)p[(size_t)W * C]; if (v > best) { best = v; a = 2; }
         v = (float)p[(size_t)W * C + C]; if (v > best) { best = v; a = 3; }
-        out[idx] = (TOp)best;
+        out[idx] = op_cvt<TOp>(best);
         arg[idx] = (unsigned char)a;
     }
 }
@@ -112,10 +118,13 @@ __global__ __launch_bounds__(256) void vgg_maxpool_kernel(const void* __restrict
 // gpre = [act > 0] * (above + gcap) as bf16, for one conv layer's output map [H*W][C].
 //   above: fp32 gradient w.r.t. what the next conv read -- this map itself (arg == nullptr), or its 2x2 max-pooled
 //   version [H/2*W/2][C] routed through `arg`; may be null.  gcap: fp32 gradient of the captured feature; may be null.
+//   gscale: device scalar S of the half mode (common.h): the captured gradients enter the backward as S * gcap, in fp32 and
+//   BEFORE the conversion to half (`above` already carries S); null otherwise.
 template <typename TOp>
 __global__ __launch_bounds__(256) void vgg_combine_kernel(const float* __restrict__ above, const unsigned char* __restrict__ arg,
                                                           const float* __restrict__ gcap, const void* __restrict__ act_,
-                                                          void* __restrict__ gpre_, int H, int W, int C) {
+                                                          void* __restrict__ gpre_, int H, int W, int C, const float* __restrict__ gscale) {
+    const float S = gscale ? *gscale : 1.f;
     const TOp* act = reinterpret_cast<const TOp*>(act_);
     TOp* gpre = reinterpret_cast<TOp*>(gpre_);
     const int Ho = H / 2, Wo = W / 2;
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256) void vgg_combine_kernel(const float* __restric
                 v = above[idx];
             }
         }
-        if (gcap) v += gcap[idx];
-        gpre[idx] = ((float)act[idx] > 0.f) ? (TOp)v : (TOp)0.f;
+        if (gcap) v += S * gcap[idx];
+        gpre[idx] = op_cvt<TOp>(((float)act[idx] > 0.f) ? v : 0.f);
     }
 }
 
@@ -146,7 +155,9 @@ struct VConv { int Cin, CiP, Cout; void *Wf, *Wd; float* b; };   // weight packs
 
 struct PrxVgg16 {
     int max_h, max_w;
-    int f32;          // PRX_PREC_*
+    int prec;         // PRX_PREC_*
+    int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    float* gs;        // half mode: device {S, 1/S} of the backward in flight + partial maxima; else null
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
     VConv conv[NCONV];
@@ -173,22 +184,19 @@ int valloc_op(PrxVgg16* v, void** p, size_t count) {
     return 0;
 }
 #define VLAUNCH(kernel, total, ...)                                                                                      \
-    do {                                                                                                                 \
-        if (v->f32) hipLaunchKernelGGL(kernel<float>, dim3(vgrid(total)), dim3(256), 0, s, __VA_ARGS__);                 \
-        else        hipLaunchKernelGGL(kernel<bf16_t>, dim3(vgrid(total)), dim3(256), 0, s, __VA_ARGS__);                \
-    } while (0)
+    PRX_OP_DISPATCH(v->f32, v->h16, TV, hipLaunchKernelGGL(kernel<TV>, dim3(vgrid(total)), dim3(256), 0, s, __VA_ARGS__))
 
 int vconv(PrxVgg16* v, const void* x, int H, int W, int Cin, const void* Bt, int Cout, const float* bias, int act,
           float* of, void* ob, hipStream_t s) {
     GemmDesc d; d.A = x; d.a_mode = PRX_A_CONV3X3; d.lda = Cin; d.B = Bt; d.ldb = 9 * Cin; d.M = H * W; d.N = Cout; d.K = 9 * Cin;
     d.H = H; d.W = W; d.Cin = Cin; d.bias_n = bias; d.act = act;
     d.out_f32 = of; d.ldc_f32 = Cout; d.out_bf16 = ob; d.ldc_bf16 = Cout;
-    d.f32 = v->f32;
+    d.f32 = v->f32; d.h16 = v->h16;
     return prx_gemm_launch(d, v->ws, v->ws_bytes, s, &v->gctx);
 }
 }  // namespace
 
-long long prx_vgg16_workspace_bytes_impl(int H, int W, int precision) { return (H < 16 || W < 16) ? -1 : (long long)vlayout(H, W, precision).total; }
+long long prx_vgg16_workspace_bytes_impl(int H, int W, int precision) { return (H < 16 || W < 16) ? -1 : (long long)vlayout(H, W, prec_is_f32(precision)).total; }
 GemmCtx* prx_vgg16_gemm_ctx_impl(PrxVgg16* v) { return v ? &v->gctx : nullptr; }
 
 int prx_vgg16_feature_shape_impl(int H, int W, int k, int* h, int* w, int* c) {
@@ -201,11 +209,12 @@ int prx_vgg16_feature_shape_impl(int H, int W, int k, int* h, int* w, int* c) {
 
 // weights: torchvision order, {weight [Cout,Cin,3,3], bias [Cout]} for the 13 convs (fp32, device)
 int prx_vgg16_create_impl(PrxVgg16** out, const float* const* weights, int n_weights, int max_h, int max_w, int precision, hipStream_t s) {
-    PRX_REQUIRE(precision == PRX_PREC_BF16 || precision == PRX_PREC_F32, "vgg16_create: unknown precision %d", precision);
+    PRX_REQUIRE(prec_valid(precision), "vgg16_create: unknown precision %d", precision);
     PRX_REQUIRE(out && weights && n_weights == 2 * NCONV, "vgg16_create: expected %d weight tensors, got %d", 2 * NCONV, n_weights);
     PRX_REQUIRE(max_h >= 16 && max_w >= 16, "vgg16_create: the input must be at least 16x16 (got %dx%d)", max_h, max_w);
     PrxVgg16* v = new PrxVgg16();
-    v->max_h = max_h; v->max_w = max_w; v->f32 = precision;
+    v->max_h = max_h; v->max_w = max_w; v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
+    v->gs = nullptr;
     auto fail = [&](int e) { prx_vgg16_destroy_impl(v); return e; };
     for (int l = 0; l < NCONV; ++l) {
         VConv& c = v->conv[l];
@@ -222,6 +231,7 @@ int prx_vgg16_create_impl(PrxVgg16** out, const float* const* weights, int n_wei
     if ((e = valloc(v, &v->dA, big)) || (e = valloc(v, &v->dB, big)) || (e = valloc_op(v, &v->gpre, big))) return fail(e);
     v->ws_bytes = (size_t)64 << 20;
     if ((e = valloc(v, &v->ws, v->ws_bytes / sizeof(float)))) return fail(e);
+    if (v->h16 && (e = valloc(v, &v->gs, (size_t)2 + NFEAT * 256))) return fail(e);
     *out = v;
     return 0;
 }
@@ -266,6 +276,17 @@ int prx_vgg16_backward_impl(PrxVgg16* v, int H, int W, const void* workspace, co
     PRX_REQUIRE(H >= 16 && W >= 16 && H <= v->max_h && W <= v->max_w, "vgg16_backward: input %dx%d outside [16x16, %dx%d]", H, W, v->max_h, v->max_w);
     const VLayout L = vlayout(H, W, v->f32);
     const char* base = (const char*)workspace;
+    if (v->h16) {
+        // half mode: the whole backward runs under a power-of-two scale S chosen on the device from max |g_feats| (exact: every
+        // op below is linear in the incoming gradients, the ReLU masks and pool routes only read the forward); vgg_combine
+        // multiplies the captured gradients by S before the conversion to half, vgg_input_grad removes it
+        const float* gp[NFEAT]; size_t gn[NFEAT];
+        for (int l = 0; l < NCONV; ++l)
+            if (kFeat[l] >= 0) { gp[kFeat[l]] = g_feats[kFeat[l]]; gn[kFeat[l]] = (size_t)L.h[kStage[l]] * L.w[kStage[l]] * kCout[l]; }
+        bool any = false;
+        for (int k = 0; k < NFEAT; ++k) any = any || gp[k] != nullptr;
+        if (any) { int e = prx_grad_scale_multi(gp, gn, NFEAT, v->gs + 2, 256, prx_grad_target_log2(), v->gs, s); if (e) return e; }
+    }
     const float* above = nullptr;     // gradient w.r.t. the input of conv l+1
     float* bufs[2] = {v->dA, v->dB};
     int flip = 0;
@@ -277,7 +298,8 @@ int prx_vgg16_backward_impl(PrxVgg16* v, int H, int W, const void* workspace, co
         const bool pooled_above = above && l + 1 < NCONV && kStage[l + 1] != st;
         const unsigned char* arg = pooled_above ? (const unsigned char*)(base + L.arg[st]) : nullptr;
         const size_t n = (size_t)L.h[st] * L.w[st] * c.Cout;
-        VLAUNCH(vgg_combine_kernel, n, above, arg, gcap, (const void*)(base + L.act[l]), v->gpre, L.h[st], L.w[st], c.Cout);
+        VLAUNCH(vgg_combine_kernel, n, above, arg, gcap, (const void*)(base + L.act[l]), v->gpre, L.h[st], L.w[st], c.Cout,
+                (const float*)v->gs);
         PRX_LAUNCH_CHECK();
         float* dst = bufs[flip]; flip ^= 1;
         int e = vconv(v, v->gpre, L.h[st], L.w[st], c.Cout, c.Wd, c.CiP, nullptr, PRX_ACT_NONE, dst, nullptr, s);
@@ -285,7 +307,8 @@ int prx_vgg16_backward_impl(PrxVgg16* v, int H, int W, const void* workspace, co
         above = dst;
     }
     if (above) {
-        hipLaunchKernelGGL(vgg_input_grad_kernel, dim3(vgrid((size_t)H * W)), dim3(256), 0, s, above, g_x, H * W);
+        hipLaunchKernelGGL(vgg_input_grad_kernel, dim3(vgrid((size_t)H * W)), dim3(256), 0, s, above, g_x, H * W,
+                           (const float*)(v->gs ? v->gs + 1 : nullptr));
         PRX_LAUNCH_CHECK();
     } else {
         PRX_CHECK_HIP(hipMemsetAsync(g_x, 0, sizeof(float) * 3 * (size_t)H * W, s));

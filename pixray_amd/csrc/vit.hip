@@ -285,8 +285,13 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     if ((r = prx_l2norm_bwd(v->e, d_embeds, v->de, n, v->out_dim, s))) return r;
     {   GemmDesc d; d.A = v->de; d.a_is_f32 = 1; d.lda = v->out_dim; d.B = v->proj; d.ldb = v->out_dim;
         d.M = n; d.N = W; d.K = v->out_dim; d.out_f32 = v->dhpost; d.ldc_f32 = W;
-        // half mode: everything below runs scaled by a power of two S chosen from max|d e| (exact: the backward is linear in g)
-        if (v->h16) { if ((r = prx_grad_scale(v->de, (size_t)n * v->out_dim, v->gs + 2, 64, prx_grad_target_log2(), v->gs, s))) return r; d.alpha_dev = v->gs; }
+        // half mode: everything below runs scaled by a power of two S chosen from max|d e| (exact: the backward is linear in g).
+        // S multiplies d e in fp32, BEFORE the GEMM's load converts it to half: entries of d e are ~1e-5 at the headline and
+        // shrink with the prompt weight and the world size -- unscaled they would land in half's subnormals or flush to zero
+        if (v->h16) {
+            if ((r = prx_grad_scale(v->de, (size_t)n * v->out_dim, v->gs + 2, 64, prx_grad_target_log2(), v->gs, s))) return r;
+            if ((r = prx_scale_dev(v->de, (size_t)n * v->out_dim, v->gs, s))) return r;
+        }
         if ((r = vit_gemm(v, d, s))) return r; }
     // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
     PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));

@@ -181,6 +181,10 @@ class Session:
         # optional C-ABI exchange (pixray_amd.comm.OneShotComm over `prx_allreduce_grad`): carries the per-step all-reduce of
         # dL/d(image) instead of torch.distributed; None = RCCL through torch.distributed
         self.comm = comm
+        self.comm_check_every = 50        # iterations between prx_comm_status checks (each one synchronises the device)
+        if comm is not None:              # the perceptors' two scalar-sized collectives ride the same exchange (ops._ClipEncodeFn)
+            for p_ in perceptors.values():
+                p_.comm = comm
         self.perceptors = perceptors
         self.cutoutsTable = cutouts
         self.cutoutSizeTable = {name: p.input_resolution for name, p in perceptors.items()}
@@ -500,11 +504,17 @@ class Session:
         tables: `host_prep`).  Falls back to eager launches when something in the session cannot be captured (foreign
         optimisers, plugins that do not declare `supports_graph_replay`, batches > 1, ...)."""
         import os
-        from . import GRAPH_ENV
-        if os.environ.get(GRAPH_ENV) != "0":
+        from . import graph_replay_refusal
+        why = graph_replay_refusal()
+        if why:
             # ROCm 7.2: with packet capture on, a replayed graph's kernel arguments live in memory that a later hipMalloc may
-            # be handed -- any fresh allocation between replays can corrupt them (tools/debug_capture.py, DESIGN.md section 6)
-            return self._no_graph(f"{GRAPH_ENV}=0 must be in the environment before the HIP runtime starts")
+            # be handed -- any fresh allocation between replays can corrupt them (tools/debug_capture.py, DESIGN.md section 6).
+            # The flag must have been in place BEFORE the runtime started: a value set after the first HIP call is never read
+            return self._no_graph(why)
+        if warmup < 1:
+            # a plugin with host-drawn inputs (StyleLoss) stages them in host_prep only once it has seen one evaluation; capturing
+            # a cold first evaluation would bake its draws and pinned uploads into the graph
+            return self._no_graph("warmup >= 1 is required: plugins size their staging buffers during one eager iteration")
         if self.batches != 1 or self.auto_stop or not self.opts:
             return self._no_graph("batches > 1, auto_stop, or no optimiser")
         if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and os.environ.get("PRX_GRAPH_WITH_COLLECTIVES") != "1":
@@ -610,6 +620,8 @@ class Session:
             cur_it = self.cur_iteration
         self.cur_iteration = cur_it
         rebuild = False
+        if self.comm is not None and cur_it % self.comm_check_every == self.comm_check_every - 1:
+            self.comm.check()            # a timed-out wait of the one-shot exchange poisoned a gradient with NaN: fail loudly (synchronises)
         if cur_it < self.iterations:
             if self.apply_overlay(cur_it):
                 self.re_average_z()

@@ -209,7 +209,7 @@ class _ClipEncodeFn(torch.autograd.Function):
     differentiates.  Nothing is ever differentiated through another call's activations."""
 
     @staticmethod
-    def forward(ctx, cutouts, handle, group):
+    def forward(ctx, cutouts, handle, group, comm=None):
         _need_cuda(cutouts)
         cutouts = cutouts.contiguous().float()
         n = cutouts.shape[0]
@@ -218,11 +218,15 @@ class _ClipEncodeFn(torch.autograd.Function):
         dev = cutouts.device
         mm = torch.empty(2, device=dev)
         call(handle.abi + "_minmax", handle.h, cutouts, n, mm, _stream())
-        if group is not None:
-            # batch-global renorm couples every cutout (slip.py:21-36): min/max over all ranks
-            import torch.distributed as dist
+        if group is not None or comm is not None:
+            # batch-global renorm couples every cutout (slip.py:21-36): min/max over all ranks -- on the C-ABI one-shot exchange
+            # (csrc/comm.hip) when the session has one, else torch.distributed (RCCL)
             mm[0].neg_()
-            dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+            if comm is not None:
+                comm.all_reduce_(mm, "max")
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
             mm[0].neg_()
         emb = torch.empty(n, handle.cfg.output_dim, device=dev)
         call(handle.abi + "_encode", handle.h, cutouts, n, mm, emb, _stream())
@@ -231,6 +235,7 @@ class _ClipEncodeFn(torch.autograd.Function):
         ctx.save_for_backward(cutouts, mm)
         ctx.handle = handle
         ctx.group = group
+        ctx.comm = comm
         return emb
 
     @staticmethod
@@ -247,16 +252,18 @@ class _ClipEncodeFn(torch.autograd.Function):
             ctx.generation = handle.generation
         acc = torch.empty(4, device=dev, dtype=torch.float64)
         call(handle.abi + "_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
-        if ctx.group is not None:
+        if ctx.comm is not None:
+            ctx.comm.all_reduce_(acc, "sum")
+        elif ctx.group is not None:
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=ctx.group)
         gc = torch.empty_like(cutouts)
         call(handle.abi + "_backward_finish", handle.h, cutouts, mm, acc, gc, _stream())
-        return gc, None, None
+        return gc, None, None, None
 
 
-def clip_encode_image(cutouts, handle: ClipVitHandle, group=None):
-    return _ClipEncodeFn.apply(cutouts, handle, group)
+def clip_encode_image(cutouts, handle: ClipVitHandle, group=None, comm=None):
+    return _ClipEncodeFn.apply(cutouts, handle, group, comm)
 
 
 class _ClipTextCfg(ctypes.Structure):
@@ -518,8 +525,6 @@ class Vgg16Handle:
 
     def __init__(self, params, max_hw, device, precision=None):
         self.precision = precision_code(precision)
-        if self.precision == 2:        # PRX_PREC_F16: the extractor has no half instantiation (include/prx.h) -- bf16 operands
-            self.precision = 0
         ws = []
         for i in VGG16_CONV_INDICES:
             ws.append(params[f"features.{i}.weight"].to(device=device, dtype=torch.float32).contiguous())

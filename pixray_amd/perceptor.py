@@ -36,7 +36,7 @@ class ClipVitPerceptor:
             raise NotImplementedError("apply_preprocess=False is not supported by the fused path")
         if imgs.shape[0] > self.handle.max_batch:
             raise ValueError(f"batch {imgs.shape[0]} exceeds the perceptor capacity {self.handle.max_batch}")
-        return ops.clip_encode_image(imgs, self.handle, self.group)
+        return ops.clip_encode_image(imgs, self.handle, self.group, getattr(self, "comm", None))
 
     # -- text side (slip.py:68-74) ---------------------------------------------------------------------------------
     def _text(self):

@@ -60,7 +60,7 @@ class Vgg16Extractor:
 
     def __init__(self, space: str = "uniform", params=None, device=None, max_hw=(64, 64), precision=None):
         self.space = space
-        self.precision = precision      # None / "fp16" / "bf16" -> bf16 extractor | "f32" (exact-f32 MFMA parity mode)
+        self.precision = precision      # None / "fp16" (IEEE-half operands, the default) | "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         if params is None:
             path = os.environ.get("PIXRAY_VGG16_CKPT")

@@ -9,6 +9,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -49,6 +50,15 @@ def _worker(rank, world, port, q):
     v = torch.tensor([1.0 + rank, -2.0 * (rank + 1), 0.5], device="cuda")[1:]       # 2 floats at a 4-byte offset
     comm.all_reduce_sum_(v)
     res["small"] = v.cpu().numpy()
+    # (c) the two scalar-sized collectives of the sharded iteration on the same exchange: MAX of the {-min, max} pair (slip.py:21-36),
+    # SUM of the four fp64 renormalisation sums
+    mm = torch.tensor([-0.25 - rank, 0.75 + 0.125 * rank], device="cuda")
+    comm.all_reduce_(mm, "max")
+    res["max"] = mm.cpu().numpy()
+    acc = torch.tensor([1e-9 * (rank + 1), 1.0 + rank, 3.0, 2.0 ** 40 * (rank + 1)], device="cuda", dtype=torch.float64)
+    comm.all_reduce_(acc, "sum")
+    res["f64"] = acc.cpu().numpy()
+    comm.check()
     res["status"] = comm.status()
     q.put((rank, res))
     dist.barrier()
@@ -84,6 +94,33 @@ def test_oneshot_allreduce_two_processes_one_device():
         assert np.array_equal(a, b), "ranks diverged"                 # summed in rank order on every rank: bit-identical
         assert np.array_equal(a, want.numpy()), it                     # 2 addends: the fp32 sum is exact to the last bit
     assert np.allclose(got[0]["small"], [-6.0, 1.0]) and np.array_equal(got[0]["small"], got[1]["small"])
+    for r in range(world):
+        assert np.array_equal(got[r]["max"], np.float32([-0.25, 0.875]))
+        assert np.array_equal(got[r]["f64"], np.float64([3e-9, 3.0, 6.0, 3 * 2.0 ** 40]))
+
+
+def test_bench_gpus_2_bare_launch_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` with no launcher: spawns its two ranks itself, shards the cutouts, runs all three collectives of
+    the iteration on the C-ABI one-shot exchange (both ranks on cuda:0, gloo for the bootstrap only) and prints ONE JSON line.
+    The sharded loss equals the single-process run's to fp16 round-off of the tower batch split."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PRX_ONE_DEVICE="1", PRX_DIST_BACKEND="gloo")
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-modes", "--profile-steps", "1", "--phase-steps", "0"]
+    recs = {}
+    for n in (2, 1):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + common, capture_output=True, text=True,
+                             timeout=900, env=env if n > 1 else {k: v for k, v in env.items() if not k.startswith("PRX_")})
+        assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        recs[n] = json.loads(lines[0])
+    r2, r1 = recs[2], recs[1]
+    assert r2["n_gpus"] == 2 and r2["config"]["cutouts_per_gpu"] == 32 and "one-shot" in r2["config"]["exchange"]
+    assert r2["value"] > 0 and np.isfinite(r2["final_loss"])
+    assert abs(r2["final_loss"] - r1["final_loss"]) < 5e-2 * abs(r1["final_loss"]), (r2["final_loss"], r1["final_loss"])
 
 
 def test_oneshot_allreduce_world_one_is_the_identity():

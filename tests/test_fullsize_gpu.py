@@ -44,19 +44,26 @@ def test_config2_full_size_128_cutouts_vs_golden_oracle():
     assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
     assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
     assert r["fp16"]["grad_rel_l2"] < 2e-2 and r["fp16"]["grad_cosine"] > 0.999, r["fp16"]
-    assert r["bf16"]["grad_rel_l2"] < 5e-2 and r["bf16"]["grad_cosine"] > 0.998, r["bf16"]
+    assert r["bf16"]["grad_rel_l2"] < 2e-2 and r["bf16"]["grad_cosine"] > 0.999, r["bf16"]       # measured 1.2e-2 / 0.99992 in round 3
 
 
 def test_config3_full_size_256_cutouts_vs_golden_oracle():
+    """BASELINE.json configs[3] with its WHOLE custom_loss stack -- StyleLoss (HIP VGG16 extractor + STROTSS) + SaturationLoss --
+    at 256 cutouts, against the committed oracle fixture (CPU VGG16, the plugin's numpy draws seeded identically)."""
     import bench
     from oracle import workload_ref
     from pixray_amd import api
+    z = np.load(os.path.join(HERE, "golden", "fullsize_cfg3.npz"))
     ref = _golden("cfg3")
     assert ref["cutn"] == api.WORKLOADS["cfg3"]["num_cuts"] == 256
+    assert int(z["n_terms"]) == 3 == len(ref["losses"])          # prompt, StyleLoss, SaturationLoss (ViT-L/14 has no `textoff` row)
+    np_seed = int(z["np_seed"])
+    largs = bench.cfg3_custom_losses(DEV, "f32")[1]
     r = workload_ref.compare_workload("cfg3", ref["cutn"], precisions=("f32", "fp16", "bf16"), seed=ref["seed"], ref=ref,
-                                      custom_factory=lambda prec: [{"loss": bench.make_saturation_loss(DEV), "weight": 1.0}])
+                                      custom_factory=lambda prec: bench.cfg3_custom_losses(DEV, prec)[0], args=largs,
+                                      before=lambda: np.random.seed(np_seed))
     _log("cfg3", r)
-    assert r["f32"]["loss_abs_err"] < 1e-5 and r["f32"]["embeds_rel_l2"] < 1e-4
+    assert r["f32"]["loss_abs_err"] < 2e-5 and r["f32"]["embeds_rel_l2"] < 1e-4, r["f32"]
     assert r["f32"]["grad_rel_l2"] < 5e-4 and r["f32"]["grad_cosine"] > 0.999999, r["f32"]
     assert r["fp16"]["grad_rel_l2"] < 2e-2 and r["fp16"]["grad_cosine"] > 0.999, r["fp16"]
     assert r["bf16"]["grad_rel_l2"] < 2e-2 and r["bf16"]["grad_cosine"] > 0.999, r["bf16"]

@@ -683,3 +683,30 @@ def test_gemm_planner_gives_the_8phase_kernel_whole_rounds_of_tiles():
     for M, N, K in ((65792, 1024, 4096), (25216, 768, 3072), (8192, 8192, 8192)):
         r = plan(M, N, K)
         assert r == M or r % 256 == 0
+
+
+def test_bench_bare_gpus_form_spawns_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher (it raised SystemExit) re-executes itself under
+    torch.distributed.run with the driver's own flags; --dry-run checks the mechanics on the host: N ranks rendezvous on
+    127.0.0.1, rank 0 prints ONE JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.remove(root)
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "2"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"dry_run": True, "world": 2, "ranks": [0, 1], "gpus": 2}
