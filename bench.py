@@ -265,6 +265,11 @@ def main():
     ms_per_step = 1e3 * elapsed / steps
     value = steps / elapsed
     loss = float(sum(l.detach() for l in sess.last_losses))
+    if world > 1:      # a rank's terms are its shard's share (weight / world) of the prompt losses: the step's loss is their sum over ranks
+        import torch.distributed as dist
+        lt = torch.tensor([loss], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=group)
+        loss = float(lt.item())
 
     # ---- per-collective device time (N > 1, or the forced 1-rank group) ------------------------------------------------
     collectives = None

@@ -105,6 +105,14 @@ typedef struct prx_gemm_args {
     prx_gemm_ctx* ctx;  /* tuning / timing context or NULL (built-in heuristics) */
 } prx_gemm_args;
 int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream);
+/* The same product with the decoder's fused GroupNorm sums in the epilogue (taming `Normalize`, 32 groups of gn_gs = N / 32
+ * consecutive channels; call site vqgan.py:195): gn_stats (double[64], pre-zeroed, accumulated with atomics) receives per group
+ * {sum, sum of squares} of the fp32 output -- or, when gnb_x is given (the forward INPUT [M, N] of the GroupNorm whose output
+ * gradient this product is, with its forward sums gnb_fstats and affine parameters), that GroupNorm's backward sums
+ * {sum dxhat, sum dxhat * xhat}.  Needs N == 32 * gn_gs, gn_gs a multiple of 4, 16-bit operands. */
+int prx_k_gemm_gn(const prx_gemm_args* g, double* gn_stats, int gn_gs, const float* gnb_x, const double* gnb_fstats,
+                  const float* gnb_gamma, const float* gnb_beta, int gnb_swish, float gnb_eps, void* ws, size_t ws_bytes,
+                  prx_stream_t stream);
 
 /* taming `Normalize` = GroupNorm(32, C, eps 1e-6) (+ swish `nonlinearity`) on an NHWC fp32
  * tensor x[NB][P][C]  [UPSTREAM taming/modules/diffusionmodules/model.py; call site vqgan.py:195].

@@ -49,10 +49,8 @@ int prx_device_info(int* cu_count, char* arch_name, int arch_name_len) {
     return 0;
 }
 
-int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int desc_of(const prx_gemm_args* g, GemmDesc& d) {
     PRX_REQUIRE(g != nullptr, "prx_k_gemm: null args");
-    GemmDesc d;
     PRX_REQUIRE(prec_valid(g->f32), "prx_k_gemm: unknown operand precision %d", g->f32);
     d.f32 = prec_is_f32(g->f32); d.h16 = prec_is_h16(g->f32);
     d.A = g->A; d.a_is_f32 = g->a_is_f32; d.a_mode = g->a_mode; d.lda = g->lda;
@@ -67,7 +65,24 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
     d.out_f32 = g->out_f32; d.ldc_f32 = g->ldc_f32;
     d.out_bf16 = g->out_bf16; d.out_bf16_pre = g->out_bf16_pre;
     d.ldc_bf16 = g->ldc_bf16;
-    return prx_gemm_launch(d, (float*)ws, ws_bytes, stream, (GemmCtx*)g->ctx);
+    return 0;
+}
+int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream_) {
+    GemmDesc d;
+    int r = desc_of(g, d);
+    if (r) return r;
+    return prx_gemm_launch(d, (float*)ws, ws_bytes, (hipStream_t)stream_, (GemmCtx*)g->ctx);
+}
+int prx_k_gemm_gn(const prx_gemm_args* g, double* gn_stats, int gn_gs, const float* gnb_x, const double* gnb_fstats,
+                  const float* gnb_gamma, const float* gnb_beta, int gnb_swish, float gnb_eps, void* ws, size_t ws_bytes,
+                  prx_stream_t stream_) {
+    GemmDesc d;
+    int r = desc_of(g, d);
+    if (r) return r;
+    PRX_REQUIRE(gn_stats != nullptr, "prx_k_gemm_gn: null gn_stats");
+    d.gn_stats = gn_stats; d.gn_gs = gn_gs;
+    d.gnb_x = gnb_x; d.gnb_fstats = gnb_fstats; d.gnb_gamma = gnb_gamma; d.gnb_beta = gnb_beta; d.gnb_swish = gnb_swish; d.gnb_eps = gnb_eps;
+    return prx_gemm_launch(d, (float*)ws, ws_bytes, (hipStream_t)stream_, (GemmCtx*)g->ctx);
 }
 
 prx_gemm_ctx* prx_gemm_ctx_create(void) { return (prx_gemm_ctx*)new GemmCtx(); }

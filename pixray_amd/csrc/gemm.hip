@@ -881,6 +881,10 @@ const bf16_t* zero_page_for_current_device() {
     return g_zero_page[dev];
 }
 
+}  // namespace
+const bf16_t* prx_gemm_zero_page() { return zero_page_for_current_device(); }
+namespace {
+
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 }  // namespace
@@ -896,6 +900,7 @@ GemmCtx::GemmCtx() {
     tile8p = env_int("PRX_GEMM_8P", 128);
     fit = env_int("PRX_GEMM_FIT", 1);
     fit_flags = env_int("PRX_FIT_FLAGS", 1);
+    fit_conv = env_int("PRX_FIT_CONV", 1);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
@@ -915,7 +920,8 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -5) { c->conv_c64 = splits; return; }      // (-5, x, on/off): scalar-tap conv gather (Cin % 64 == 0)
     if (bm == -6) { c->tile8p = splits; return; }        // (-6, x, n): 256 x 256 8-phase tiles from n tiles on (0 = never)
     if (bm == -7) { c->fit = splits; return; }           // (-7, x, on/off): fit tiles (gemmfit.hip)
-    if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (stagger, wide stores)
+    if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
+    if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
@@ -1075,20 +1081,12 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // very large problems (ViT-L/14 at 256 cutouts: M = 65 792): the 8-wave 256 x 128 tile, when it still fills the chip
     // several times over (A/B switch, off by default: see DESIGN.md section 6)
     if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
-    // fit tiles (gemmfit.hip): one workgroup per CU when a 160- or 80-row tile grid matches the chip (M = 3200: 240 tiles)
-    if (cx.fit && !use8p) {
-        struct Fit { int bm, bn; double eff; };
-        const Fit fits[3] = {{160, 256, 1.0}, {160, 192, 0.97}, {80, 128, 0.85}};
-        double best = 0.0;
-        for (const Fit& f : fits) {
-            if (!prx_gemmfit_eligible(d, f.bm, f.bn) || d.N < f.bn) continue;
-            const int t = ntiles(f.bm, f.bn);
-            if (t > 2 * n_cu) continue;                                   // a one- or two-round kernel by construction
-            const double fill = (double)t / ((double)ceil_div(t, n_cu) * n_cu);
-            const double waste = ((double)ceil_div(d.M, f.bm) * f.bm / d.M) * ((double)ceil_div(d.N, f.bn) * f.bn / d.N);
-            const double score = fill * f.eff / waste;
-            if (score > best && fill / waste >= 0.8) { best = score; BM = f.bm; BN = f.bn; }
-        }
+    // fit tiles (gemmfit.hip): one workgroup per CU when a tile grid matches the chip (M = 3200: 240 tiles; the decoder's
+    // batch-1 convolutions: K split over the wave groups of a workgroup instead of over workgroups + a reduce launch)
+    if (cx.fit && !use8p && (d.a_mode == PRX_A_ROWMAJOR || cx.fit_conv)) {
+        int fbm = 0, fbn = 0;
+        prx_gemmfit_plan(d, n_cu, &fbm, &fbn);
+        if (fbm) { BM = fbm; BN = fbn; }
     }
     if (use8p) { BM = 256; BN = 256; }          // planned by plan_8phase (prx_gemm_launch)
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; }
@@ -1177,7 +1175,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     } else if (BM == 256 && BN == 256) {
         prx_gemm8p_launch(a, grid, stream);
     } else if (fit_tile) {
-        prx_gemmfit_launch(a, BM, BN, grid, stream);
+        int e = prx_gemmfit_launch(a, BM, BN, grid, stream);
+        if (e) return e;
     } else if (!d.a_is_f32 && cx.use_glds) {
         const bf16_t* zp = zero_page_for_current_device();
         PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");

@@ -176,8 +176,9 @@ __device__ __forceinline__ void epilogue_store8(const GemmDesc& d, int row, int 
 // gemm8p.hip: the 256 x 256 8-phase kernel (row-major 16-bit operands, K % 128 == 0, no fused GroupNorm statistics)
 bool prx_gemm8p_eligible(const GemmDesc& d);
 void prx_gemm8p_launch(const prx_gemm_dev::GemmArgs& a, dim3 grid, hipStream_t s);      // grid = (tiles, splits), kt_per_split even
-// gemmfit.hip: tiles that match the chip for M = 3200-class problems (160 x 256, 160 x 192, 80 x 128 with two K groups);
-// row-major 16-bit operands, K % (64 ks) == 0, vector epilogue, no split-K, no fused GroupNorm statistics
+// gemmfit.hip: tiles whose count matches the chip (row-major 16-bit operands or implicit 3x3 convolutions with Cin % 64 == 0,
+// K % (64 ks) == 0, 16-byte-friendly epilogue operands, no split-K across workgroups)
 bool prx_gemmfit_tile(int bm, int bn, int* ks);
 bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn);
-void prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (tiles, 1)
+void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn);          // *bm = 0: leave the problem to the 4-wave kernels
+int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (tiles, 1)

@@ -1,28 +1,38 @@
-// "Fit-tile" member of the GEMM engine (gemm.h): row-major 16-bit operands, tiles whose count matches the chip.
+// "Fit-tile" member of the GEMM engine (gemm.h): 16-bit operands, tiles whose COUNT matches the chip (one workgroup per CU),
+// row-major products and implicit 3x3 convolutions.
 //
-// Why: the ViT-B/32 tower at the headline's 64 cutouts is M = 64 * 50 = 3200 token rows.  With the power-of-two tiles of
-// gemm.hip a product has 150 / 300 / 600 tiles for 256 CUs (128x128 / 128x64 / 64x64): either 40 % of the chip idles or a
-// second, mostly empty round runs, and the small tiles that do fill the chip move twice the L2->LDS bytes per flop
-// (64 B/clk/CU on that path: a 64x64 tile is bound by it at half the MFMA rate).  M = 3200 = 20 * 160 = 40 * 80, so:
-//     N = 3072 (FC1, W2^T dgrad, patch dgrad)   160 x 256 tiles   20 x 12 = 240 workgroups
-//     N = 2304 (QKV)                            160 x 192 tiles   20 x 12 = 240
-//     N =  768 (proj, FC2, the other dgrads)     80 x 128 tiles   40 x  6 = 240, K split over two wave groups
-// i.e. one workgroup per CU on 94 % of the chip, 49 - 98 MFMA flops per L2->LDS byte.  The same tiles fit the sharded
-// batches (32 / 16 / 8 cutouts: M = 1600 / 800 / 400 are multiples of 80).
+// Why: the hot products of the headline iteration are small.  The ViT-B/32 tower at 64 cutouts is M = 64 * 50 = 3200 token
+// rows; the VQGAN decoder is batch 1, M = 256 ... 65 536 pixels by N = 128 ... 512 channels.  With the power-of-two tiles of
+// gemm.hip such a product has 150 / 300 / 600 tiles for 256 CUs, or 8 - 64 tiles that need split-K across workgroups plus a
+// reduce launch: either 40 % of the chip idles, or a second mostly empty round runs, or partial sums make a round trip through
+// HBM; and the small tiles that do fill the chip move twice the L2->LDS bytes per flop (64 B/clk/CU on that path).  Here the
+// tile is chosen so that the grid is ~240 - 256 workgroups, and when that makes the tile small the K loop is split over the
+// wave groups of ONE workgroup (KS) and summed through LDS -- no workspace, no second launch:
+//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 256 (240 tiles)   N = 2304 -> 160 x 192 (240)   N = 768 -> 80 x 128, KS 2 (240)
+//     decoder 256^2 level: 65 536 x 128 -> 256 x 128 (256)      128^2: 128 x 128 / 128 x 64 KS 2     64^2: 64 x 64 KS 2
+//                  32^2:   32 x 64 KS 4 / 16 x 64 KS 4           16^2:  256 x 512 x 4608 -> 16 x 32, KS 8 (256 tiles)
+// The same tiles fit the sharded batches (32 / 16 / 8 cutouts: M = 1600 / 800 / 400 are multiples of 80).
 //
-// Structure: 8 waves (two per SIMD, so one wave's DMA issue / LDS reads overlap its partner's MFMAs), 16x16x32 MFMAs
-// (80 = 5 x 16 rows per wave), wave tile 80 x (16 FN).  Operands HBM -> LDS by global_load_lds_dwordx4 into a 3-deep ring
-// of K tiles (BK = 64; KS = 2: a stage holds two consecutive K tiles, one per wave group) with counted s_waitcnt vmcnt and
-// one raw s_barrier per stage: two stages of DMA stay in flight across the barrier.  Swizzle as in gemm.hip (LDS chunk c of row r
-// holds source chunk c ^ ((r >> 1) & 7), applied on the DMA source address and on the fragment read; conflict-free for the
-// 16x16x32 operand layout too: a ds_read_b128 lane group covers rows {0-3, 12-15} of one chunk and rows {4-11} of the next).
-// Rows >= M / columns >= N are clamped on the source side.  The epilogue is the engine's (gemm_epi.h), staged per wave
-// through LDS so that all global accesses are 16 bytes (8 consecutive columns per lane), its HBM reads prefetched.
+// Structure: 8 waves (two per SIMD), 16x16x32 MFMAs, wave tile (16 FM) x (16 FN).  Operands HBM -> LDS by
+// global_load_lds_dwordx4 into a 3-deep ring of stages (a stage = KS consecutive K tiles of BK = 64, one per wave group) with
+// counted s_waitcnt vmcnt and one raw s_barrier per stage: two stages of DMA stay in flight across the barrier.  The two halves
+// of the workgroup issue their DMA at opposite ends of a stage (staggered wave groups, see the main loop).  Swizzle as in
+// gemm.hip (LDS chunk c of row r holds source chunk c ^ ((r >> 1) & 7), applied on the DMA source address and on the fragment
+// read; conflict-free for the 16x16x32 operand layout too).  Rows >= M / columns >= N are clamped on the source side (row-major)
+// or read the zero page (convolution: as its padding does).  Implicit convolution (CONV): Cin % 64 == 0, so a K tile lies inside
+// ONE filter tap, which is wave-uniform per DMA piece; the per-lane gather address is row term[ky] + column term[kx] from six
+// values computed once (gemm.hip's C64 scheme), optionally through the fused nearest-2x upsample.
+// Epilogue: the engine's (gemm_epi.h) on 8 consecutive columns per lane, staged per wave through LDS, 16-byte accesses, its HBM
+// reads prefetched; the next GroupNorm's sums or a GroupNorm-backward's sums (GemmDesc::gn_stats / gnb_*) in a fixed summation
+// order up to the final fp64 atomics.
 //
-// Requirements (checked by prx_gemmfit_eligible): row-major 16-bit A, K % (64 KS) == 0, N % 8 == 0 with 16-byte-friendly
-// epilogue operands, no split-K, no fused GroupNorm sums.
+// Requirements (prx_gemmfit_eligible): 16-bit A (row-major, or NHWC with Cin % 64 == 0 and up in {0, 1}), K % (64 KS) == 0,
+// N % 8 == 0 with 16-byte-friendly epilogue operands, at most one of {residual, aux, GroupNorm-backward input} (so not
+// PRX_ACT_RELUMASK_POST, which reads a residual and a mask), no split-K across workgroups.
 #include "gemm_epi.h"
 #include <type_traits>
+
+const bf16_t* prx_gemm_zero_page();       // gemm.hip: 256 bytes of zeros on the current device
 
 namespace {
 using namespace prx_gemm_dev;
@@ -40,9 +50,28 @@ __device__ __forceinline__ f32x4 fit_mfma(const bf16x8& a, const bf16x8& b, cons
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// GroupNorm-backward sums on prefetched x (gemm_epi.h gnb_accum with the load taken out)
+__device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst& c, const float4& x, const float4& o, float& s0, float& s1) {
+    const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
+    const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (xv[i] - c.mean) * c.rstd;
+        float gy = gv[i];
+        if (d.gnb_swish) {
+            const float y = xh * gav[i] + bev[i];
+            const float sg = sigmoidf_(y);
+            gy *= sg * (1.f + y * (1.f - sg));
+        }
+        const float dxh = gy * gav[i];
+        s0 += dxh;
+        s1 += dxh * xh;
+    }
+}
+
 // WGM x WGN waves per K group, KS K groups; wave tile (16 FM) x (16 FN); block tile BM x BN = (16 FM WGM) x (16 FN WGN).
-template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
-__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const GemmArgs p) {
+template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
     constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN;
     constexpr int SUB = (BM + BN) * FIT_BK;              // elements of one K tile (A rows, then B rows)
@@ -52,6 +81,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     constexpr int TN = 16 * FN;
     static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole DMA pieces");
     static_assert(FIT_STAGES * STAGE * 2 <= 160 * 1024, "ring exceeds the LDS");
+    static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
 
     __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the only __shared__ object
 
@@ -67,11 +97,15 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
 
     // ---- DMA coordinates: slot j of this wave moves piece min(wave + NW j, NP - 1) of every stage -----------------------
-    const char* const Abase = reinterpret_cast<const char*>(d.A);
-    const char* const Bbase = reinterpret_cast<const char*>(d.B);
+    const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
+    const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
     const int lrow = lane >> 3, cpos = lane & 7;
-    unsigned voff[PW];                                    // per-lane byte offset from the operand base at K tile 0
-    int pieceA[PW], pieceOff[PW];                         // wave-uniform: operand select, LDS element offset inside a stage
+    unsigned voff[PW];                                    // per-lane ELEMENT offset from the operand base at K tile 0 (conv A: the chunk only)
+    int pieceA[PW], pieceOff[PW], pieceSub[PW];           // wave-uniform: operand select, LDS element offset inside a stage, K tile inside the stage
+    // implicit convolution: per-lane row / column terms of the three taps per axis and their validity bits (bit ky, bit 3 + kx)
+    int c_r1[CONV ? PW : 1], c_rd0[CONV ? PW : 1], c_rd2[CONV ? PW : 1], c_c1[CONV ? PW : 1], c_cd0[CONV ? PW : 1], c_cd2[CONV ? PW : 1];
+    int c_ok[CONV ? PW : 1];
+    int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         int pc = wave + NW * j;
@@ -82,24 +116,59 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         const int chunk = cpos ^ ((r >> 1) & 7);
         pieceA[j] = isA;
         pieceOff[j] = pc * (8 * FIT_BK);
+        pieceSub[j] = sub;
         if (isA) {
-            int g = tm * BM + r;
-            g = g < d.M ? g : d.M - 1;
-            voff[j] = ((unsigned)g * (unsigned)d.lda + (unsigned)(sub * FIT_BK + chunk * 8)) * 2u;
+            const int g = tm * BM + r;
+            if constexpr (CONV) {
+                voff[j] = (unsigned)(chunk * 8);
+                const int Hs = d.up == 1 ? (d.H >> 1) : d.H, Ws = d.up == 1 ? (d.W >> 1) : d.W;
+                const int hw = d.H * d.W;
+                const int b = g / hw, rem = g - b * hw, y = rem / d.W, x = rem - y * d.W;
+                int okm = 0, ro[3], co[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int yy = y + t - 1, xx = x + t - 1;
+                    if (g < d.M && yy >= 0 && yy < d.H) okm |= 1 << t;
+                    if (xx >= 0 && xx < d.W) okm |= 8 << t;
+                    ro[t] = (b * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
+                    co[t] = d.up ? (xx >> 1) : xx;
+                }
+                c_ok[j] = okm;
+                c_r1[j] = ro[1]; c_rd0[j] = ro[0] - ro[1]; c_rd2[j] = ro[2] - ro[1];
+                c_c1[j] = co[1]; c_cd0[j] = co[0] - co[1]; c_cd2[j] = co[2] - co[1];
+                s_tap[j] = (sub * FIT_BK) / d.Cin;
+                s_c0[j] = sub * FIT_BK - s_tap[j] * d.Cin;
+            } else {
+                const int gc = g < d.M ? g : d.M - 1;
+                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * FIT_BK + chunk * 8);
+            }
         } else {
             int g = tn * BN + r;
             g = g < d.N ? g : d.N - 1;
-            voff[j] = ((unsigned)g * (unsigned)d.ldb + (unsigned)(sub * FIT_BK + chunk * 8)) * 2u;
+            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * FIT_BK + chunk * 8);
+            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd0[j] = c_rd2[j] = c_c1[j] = c_cd0[j] = c_cd2[j] = 0; s_tap[j] = s_c0[j] = 0; }
         }
     }
+    // stages are issued in K order, exactly once each
     auto issue = [&](int it, int stage) {
-        const size_t kbytes = (size_t)it * (FIT_BK * KS * 2);
-        const char* const a_ = Abase + kbytes;
-        const char* const b_ = Bbase + kbytes;
+        const size_t kel = (size_t)it * (FIT_BK * KS);
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const char* const s_ = pieceA[j] ? a_ : b_;
-            __builtin_amdgcn_global_load_lds((fit_gptr)(s_ + voff[j]), (fit_lptr)(lds + stage * STAGE + pieceOff[j]), 16, 0, 0);
+            const bf16_t* src;
+            if (CONV && pieceA[j]) {
+                const int tap = s_tap[j];
+                const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - 3 * ky;
+                const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
+                const int ro = c_r1[j] + (my0 & c_rd0[j]) + (my2 & c_rd2[j]);
+                const int co = c_c1[j] + (mx0 & c_cd0[j]) + (mx2 & c_cd2[j]);
+                const bool ok = ((c_ok[j] >> ky) & (c_ok[j] >> (3 + kx)) & 1) != 0;
+                src = ok ? Ap + (long long)(ro + co) * d.lda + (s_c0[j] + (int)voff[j]) : zero_page;
+                s_c0[j] += FIT_BK * KS;
+                while (s_c0[j] >= d.Cin) { s_c0[j] -= d.Cin; ++s_tap[j]; }
+            } else {
+                src = (pieceA[j] ? Ap : Bp) + kel + voff[j];
+            }
+            __builtin_amdgcn_global_load_lds((fit_gptr)src, (fit_lptr)(lds + stage * STAGE + pieceOff[j]), 16, 0, 0);
         }
     };
 
@@ -115,8 +184,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // both 32-wide k steps' fragments are fetched up front into two register sets (the waits the compiler then places are
-    // counted lgkmcnt: the first MFMAs start when their operands arrive, the second set lands under them)
     auto compute = [&](int stage) {
         const bf16_t* const As = lds + stage * STAGE + a_el;
         const bf16_t* const Bs = lds + stage * STAGE + b_el;
@@ -173,36 +240,38 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- K groups: partner sums through LDS.  Group 0 keeps row fragments [0, FM0), group 1 the rest -------------------
+    // ---- K groups: every wave dumps the 16-row slabs it does not OWN (slab i belongs to group i % KS); the owner adds the
+    // other groups' partials in group order.  One barrier, no workspace, a fixed summation order.
     float* const fl = reinterpret_cast<float*>(lds);
-    constexpr int FM0 = KS == 2 ? (FM + 1) / 2 : FM;
-    constexpr int DUMP = KS == 2 ? NWT * FM * FN * 256 : 0;        // floats: every wave dumps the fragments it does not keep
-    if constexpr (KS == 2) {
-        float* const mine = fl + wt * (FM * FN * 256);
+    constexpr int DUMP = KS > 1 ? NW * FM * FN * 256 : 0;          // floats
+    static_assert((DUMP + NW * 16 * (TN + 4) + KS * WGM * (BN / 2)) * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
+    if constexpr (KS > 1) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const bool keep = (kg == 0) == (i < FM0);
-            if (!keep) {
+            if (i % KS == kg) continue;
 #pragma unroll
-                for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(mine + (i * FN + j) * 256 + lane * 4) = acc[i][j];
-            }
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(fl + ((kg * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4) = acc[i][j];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const bool keep = (kg == 0) == (i < FM0);
-            if (keep) {
+            if (i % KS != kg) continue;
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(mine + (i * FN + j) * 256 + lane * 4);
+            for (int g = 0; g < KS; ++g) {
+                if (g == kg) continue;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] += *reinterpret_cast<const f32x4*>(fl + ((g * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4);
             }
         }
     }
 
-    // ---- epilogue: per wave, one 16-row fragment row at a time through a private LDS slab; 8 consecutive columns per lane, so
-    // the 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
-    // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual or aux rows, bias) is fetched for the whole
-    // wave tile BEFORE the first store: the compiler cannot move a load above an earlier store that may alias it, and with one
-    // workgroup per CU nothing else hides a chain of FM x NPASS dependent load round trips (measured: 19 of FC1's 32 us).
+    // ---- epilogue: per wave, one 16-row slab at a time through a private LDS slab; 8 consecutive columns per lane, so the
+    // 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
+    // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual, aux or GroupNorm-input rows, bias) is
+    // fetched for the whole wave tile BEFORE the first store: the compiler cannot move a load above an earlier store that may
+    // alias it, and with one workgroup per CU nothing else hides a chain of dependent load round trips.
     typedef __attribute__((ext_vector_type(8))) T16 t16x8;
     constexpr int LDW = TN + 4;                 // padded row (floats), rows stay 16-byte aligned
     constexpr int LPR = TN / 8;                 // lanes per row
@@ -217,16 +286,20 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
     const bool has_resid = d.resid != nullptr;
     const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
+    const bool do_stats = d.gn_stats != nullptr;
+    const bool gnb = do_stats && d.gnb_x != nullptr;
     float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
     if (d.bias_n && col_ok) {
         bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
         bias1 = *reinterpret_cast<const float4*>(d.bias_n + col + 4);
     }
-    uint4 pf[FM][NPASS][2];                     // residual (2 x 16 bytes) or aux (16 bytes) of this lane's 8 columns
+    GnbConst gc0{}, gc1{};
+    if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
+    uint4 pf[FM][NPASS][2];                     // residual / GroupNorm input (2 x 16 bytes) or aux (16 bytes) of this lane's 8 columns
     float pbm[FM][NPASS];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const bool keep = KS == 1 || ((kg == 0) == (i < FM0));
+        const bool keep = KS == 1 || i % KS == kg;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
@@ -234,8 +307,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             pf[i][ps][0] = pf[i][ps][1] = uint4{0u, 0u, 0u, 0u};
             pbm[i][ps] = 0.f;
             if (ok) {
-                if (has_resid) {
-                    const float* r_ = d.resid + (size_t)row * d.ldr + col;
+                if (has_resid || gnb) {
+                    const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
                     pf[i][ps][0] = *reinterpret_cast<const uint4*>(r_);
                     pf[i][ps][1] = *reinterpret_cast<const uint4*>(r_ + 4);
                 } else if (need_aux) {
@@ -245,9 +318,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             }
         }
     }
+    float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        if (KS == 2 && ((kg == 0) != (i < FM0))) continue;
+        if (KS > 1 && i % KS != kg) continue;
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -287,40 +361,133 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                 q[4] = op_cvt<T16>(v1.x); q[5] = op_cvt<T16>(v1.y); q[6] = op_cvt<T16>(v1.z); q[7] = op_cvt<T16>(v1.w);
                 *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = q;
             }
+            if (gnb) {
+                fit_gnb_accum(d, gc0, __builtin_bit_cast(float4, pf[i][ps][0]), v0, gsa0, gsa1);
+                fit_gnb_accum(d, gc1, __builtin_bit_cast(float4, pf[i][ps][1]), v1, gsb0, gsb1);
+            } else if (do_stats) {
+                gsa0 += (v0.x + v0.y) + (v0.z + v0.w);
+                gsa1 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
+                gsb0 += (v1.x + v1.y) + (v1.z + v1.w);
+                gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+            }
+        }
+    }
+    // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot
+    // each summed in a fixed order, then one fp64 atomic per group and moment (the only order-dependent step, ~1e-16 relative)
+    if (do_stats) {
+        if constexpr ((LPR & (LPR - 1)) == 0) {
+            float* const gpart = fl + DUMP + NW * (16 * LDW);          // [KS * WGM][BN / 4 quads][2]
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                gsa0 += __shfl_xor(gsa0, o, 64); gsa1 += __shfl_xor(gsa1, o, 64);
+                gsb0 += __shfl_xor(gsb0, o, 64); gsb1 += __shfl_xor(gsb1, o, 64);
+            }
+            if (lane < LPR) {
+                float* const w_ = gpart + ((kg * WGM + wm) * (BN / 4) + wn * (TN / 4) + lane * 2) * 2;
+                w_[0] = gsa0; w_[1] = gsa1; w_[2] = gsb0; w_[3] = gsb1;
+            }
+            __syncthreads();
+            const int qpg = d.gn_gs >> 2;                  // quads per group
+            const int ngrp = BN / d.gn_gs;                 // groups covered by this block tile
+            if (tid < ngrp * 2) {
+                const int gl = tid >> 1, mom = tid & 1;
+                const int gcol = tn * BN + gl * d.gn_gs;
+                if (gcol < d.N) {
+                    double a2 = 0.0;
+                    for (int w2 = 0; w2 < KS * WGM; ++w2)
+                        for (int q = 0; q < qpg; ++q) a2 += (double)gpart[(w2 * (BN / 4) + gl * qpg + q) * 2 + mom];
+                    atomicAdd(&d.gn_stats[(size_t)(gcol / d.gn_gs) * 2 + mom], a2);
+                }
+            }
         }
     }
 }
 
 template <int WGM, int WGN, int FM, int FN, int KS>
-void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s) {
+void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
     constexpr int threads = 64 * WGM * WGN * KS;
-    if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, half_t>), grid, dim3(threads), 0, s, a);
-    else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, bf16_t>), grid, dim3(threads), 0, s, a);
+    const bool conv = a.d.a_mode == PRX_A_CONV3X3;
+    if (a.d.h16) {
+        if (conv) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t>), grid, dim3(threads), 0, s, a, zp);
+        else      hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t>), grid, dim3(threads), 0, s, a, zp);
+    } else {
+        if (conv) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t>), grid, dim3(threads), 0, s, a, zp);
+        else      hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t>), grid, dim3(threads), 0, s, a, zp);
+    }
+}
+
+// the tile shapes this kernel exists in
+struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
+const FitTile kFitTiles[] = {
+    {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {128, 128, 1, 32, 0.85}, {80, 128, 2, 32, 0.85},
+    {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
+};
+const FitTile* fit_tile(int bm, int bn) {
+    for (const FitTile& t : kFitTiles)
+        if (t.bm == bm && t.bn == bn) return &t;
+    return nullptr;
 }
 }  // namespace
 
-// The tile shapes this kernel exists in: (160, 256), (160, 192), (80, 128).  ks = K groups of that tile.
 bool prx_gemmfit_tile(int bm, int bn, int* ks) {
-    int k = 0;
-    if (bm == 160 && bn == 256) k = 1;
-    else if (bm == 160 && bn == 192) k = 1;
-    else if (bm == 80 && bn == 128) k = 2;
-    if (ks) *ks = k;
-    return k != 0;
+    const FitTile* t = fit_tile(bm, bn);
+    if (ks) *ks = t ? t->ks : 0;
+    return t != nullptr;
 }
 bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
-    int ks = 0;
-    if (!prx_gemmfit_tile(bm, bn, &ks)) return false;
+    const FitTile* ft = fit_tile(bm, bn);
+    if (!ft) return false;
+    const int ks = ft->ks;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // null passes
     // the epilogue handles 8 consecutive columns per lane with 16-byte accesses
     const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
                         al16(d.out_bf16_pre) && (!d.resid || d.ldr % 4 == 0) && (!d.aux || d.ldaux % 8 == 0) &&
                         (!d.out_f32 || d.ldc_f32 % 4 == 0) && ((!d.out_bf16 && !d.out_bf16_pre) || d.ldc_bf16 % 8 == 0);
-    return !d.f32 && !d.a_is_f32 && d.a_mode == PRX_A_ROWMAJOR && d.K % (FIT_BK * ks) == 0 && d.gn_stats == nullptr && epi_ok &&
-           (unsigned long long)d.M * d.lda < (1ull << 31) && (unsigned long long)d.N * d.ldb < (1ull << 31);
+    // GroupNorm sums: the lanes of a column quad are reduced by a butterfly (16 FN / 8 lanes per row: a power of two), a
+    // group is a whole number of quads inside the block tile, and the GroupNorm-backward input has the output's layout
+    bool stats_ok = true;
+    if (d.gn_stats) {
+        const int lpr = ft->tn / 8;
+        stats_ok = (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
+                   (!d.gnb_x || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
+    }
+    const bool a_ok = d.a_mode == PRX_A_ROWMAJOR
+                          ? (unsigned long long)d.M * d.lda < (1ull << 31)
+                          : (d.a_mode == PRX_A_CONV3X3 && d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
+                             d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
+    // the epilogue prefetches ONE row operand per output row into shared registers: residual, aux, or the GroupNorm input
+    const bool one_operand = !(d.resid && d.aux) && !(d.gnb_x && (d.resid || d.aux));
+    return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && one_operand && d.M >= 1 &&
+           (unsigned long long)d.N * d.ldb < (1ull << 31);
 }
-void prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
-    if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1>(a, grid, s);
-    else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1>(a, grid, s);
-    else launch_fit<1, 4, 5, 2, 2>(a, grid, s);
+// planner: the fit tile (if any) whose grid fills the chip best; *bm = 0 when the 4-wave kernels should keep the problem
+void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
+    *bm = *bn = 0;
+    double best = 0.0;
+    for (const FitTile& t : kFitTiles) {
+        if (d.N < t.bn && !(t.bn <= 64)) continue;
+        if (!prx_gemmfit_eligible(d, t.bm, t.bn)) continue;
+        const int tiles = ceil_div(d.M, t.bm) * ceil_div(d.N, t.bn);
+        if (tiles > 2 * n_cu) continue;                                   // a one- or two-round kernel by construction
+        const double fill = (double)tiles / ((double)ceil_div(tiles, n_cu) * n_cu);
+        const double waste = ((double)ceil_div(d.M, t.bm) * t.bm / d.M) * ((double)ceil_div(d.N, t.bn) * t.bn / d.N);
+        const double score = fill * t.eff / waste;
+        if (score > best && fill / waste >= 0.8) { best = score; *bm = t.bm; *bn = t.bn; }
+    }
+}
+int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
+    const bf16_t* zp = prx_gemm_zero_page();
+    PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
+    if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1>(a, grid, s, zp);
+    else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1>(a, grid, s, zp);
+    else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);
+    else if (bm == 128 && bn == 128) launch_fit<2, 4, 4, 2, 1>(a, grid, s, zp);
+    else if (bm == 80 && bn == 128) launch_fit<1, 4, 5, 2, 2>(a, grid, s, zp);
+    else if (bm == 128 && bn == 64) launch_fit<2, 2, 4, 2, 2>(a, grid, s, zp);
+    else if (bm == 64 && bn == 64) launch_fit<2, 2, 2, 2, 2>(a, grid, s, zp);
+    else if (bm == 32 && bn == 64) launch_fit<1, 2, 2, 2, 4>(a, grid, s, zp);
+    else if (bm == 16 && bn == 64) launch_fit<1, 2, 1, 2, 4>(a, grid, s, zp);
+    else if (bm == 16 && bn == 32) launch_fit<1, 1, 1, 2, 8>(a, grid, s, zp);
+    else PRX_REQUIRE(false, "gemmfit: no kernel for a %d x %d tile", bm, bn);
+    return 0;
 }

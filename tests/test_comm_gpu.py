@@ -96,7 +96,7 @@ def test_oneshot_allreduce_two_processes_one_device():
     assert np.allclose(got[0]["small"], [-6.0, 1.0]) and np.array_equal(got[0]["small"], got[1]["small"])
     for r in range(world):
         assert np.array_equal(got[r]["max"], np.float32([-0.25, 0.875]))
-        assert np.array_equal(got[r]["f64"], np.float64([3e-9, 3.0, 6.0, 3 * 2.0 ** 40]))
+        assert np.array_equal(got[r]["f64"], np.float64([1e-9 * 1 + 1e-9 * 2, 3.0, 6.0, 3 * 2.0 ** 40]))      # summed in rank order
 
 
 def test_bench_gpus_2_bare_launch_two_ranks_on_one_device():

@@ -150,11 +150,11 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
-@pytest.mark.parametrize("tile", [(160, 256), (160, 192), (80, 128)])
+@pytest.mark.parametrize("tile", [(160, 256), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("stagger", [1, 0])
 def test_gemm_fit_tiles(tile, prec, stagger):
-    """the fit-tile kernel (gemmfit.hip: 160 x 256, 160 x 192, 80 x 128 with two K groups) forced on ragged and exact shapes, every
+    """the fit-tile kernel (gemmfit.hip: every tile shape, 1 / 2 / 4 / 8 K groups) forced on ragged and exact shapes, every
     epilogue form the ViT tower uses (bias + QuickGELU with both 16-bit outputs, dQuickGELU(aux), bias + residual -> fp32,
     plain 16-bit), both 16-bit formats, staggered wave groups on and off; vs an fp32 product of the same rounded operands"""
     lib = _lib.load()
@@ -164,7 +164,7 @@ def test_gemm_fit_tiles(tile, prec, stagger):
     try:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, stagger)
-        for (M, N, K) in [(3200, 768, 768), (1000, 200, 1152), (333, 520, 256), (81, 136, 128), (160, 256, 384)]:
+        for (M, N, K) in [(3200, 768, 768), (1000, 200, 1152), (333, 520, 512), (81, 136, 1024), (160, 256, 1536)]:
             A = torch.randn(M, K, device=DEV).to(dt)
             Bt = (torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K)).to(dt)
             bias = torch.randn(N, device=DEV)
@@ -206,9 +206,95 @@ def test_gemm_fit_tiles(tile, prec, stagger):
             o = run(o16=True)
             assert rel_l2(o["o16"], prod) < tol16
             assert not torch.isnan(o["o16"].float()).any()
+            o = run(bias=True, act=3, f32=True)                                   # PRX_ACT_RELU
+            assert rel_l2(o["f32"], torch.relu(prod + bias)) < 2e-5
+            o = run(aux=True, act=4, f32=True)                                    # PRX_ACT_MUL_RELUMASK
+            assert rel_l2(o["f32"], prod * (aux.float() > 0)) < 2e-5
+            o = run(aux=True, resid=True, act=5, f32=True)                        # PRX_ACT_RELUMASK_POST: residual AND mask -> 4-wave kernels
+            assert rel_l2(o["f32"], (prod + resid) * (aux.float() > 0)) < 2e-5
     finally:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
+
+
+FIT_TILES = [(160, 256), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+FIT_KS = {(160, 256): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
+
+
+@pytest.mark.parametrize("tile", FIT_TILES)
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
+    """every fit tile on implicit 3x3 convolutions (plain and through the fused nearest-2x upsample, ragged M against the tile,
+    batch 2) with the decoder's epilogues: bias + residual + fp32 / 16-bit outputs + the NEXT GroupNorm's sums, and a dgrad-shaped
+    launch accumulating a GroupNorm-BACKWARD's sums; against torch conv2d on the same rounded operands and fp64 sums"""
+    lib = _lib.load()
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    torch.manual_seed(5)
+    ks = FIT_KS[tile]
+    ran = 0
+    try:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
+        for (H, W, Cin, Cout, up, NB) in [(32, 32, 128, 128, 1, 1), (24, 40, 64, 256, 0, 2), (16, 16, 512, 128, 0, 1)]:
+            if (9 * Cin) % (64 * ks) or (tile == (160, 192)):        # K must split over the K groups; 160 x 192 has no GroupNorm-sum epilogue
+                continue
+            ran += 1
+            hin, win = (H // 2, W // 2) if up else (H, W)
+            x = torch.randn(NB, Cin, hin, win, device=DEV)
+            w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(9 * Cin)
+            bias = torch.randn(Cout, device=DEV)
+            M = NB * H * W
+            resid = torch.randn(M, Cout, device=DEV)
+            x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dt)
+            w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dt)
+            xr = x.to(dt).float()
+            if up:
+                xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+            ref = F.conv2d(xr, w.to(dt).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(M, Cout) + resid
+            gs = Cout // 32
+            stats = torch.zeros(64, device=DEV, dtype=torch.float64)
+
+            def args():
+                g = GemmArgs()
+                g.A = x_nhwc.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
+                g.M, g.N, g.K = M, Cout, 9 * Cin
+                g.H, g.W, g.Cin, g.up = H, W, Cin, up
+                g.alpha = 1.0; g.f32 = 0 if prec == "bf16" else 2
+                return g
+            g = args()
+            g.bias_n = bias.data_ptr(); g.resid = resid.data_ptr(); g.ldr = Cout
+            out = torch.full((M, Cout), float("nan"), device=DEV); g.out_f32 = out.data_ptr(); g.ldc_f32 = Cout
+            o16 = torch.full((M, Cout), float("nan"), device=DEV, dtype=dt); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = Cout
+            call("prx_k_gemm_gn", g, stats, gs, None, None, None, None, 0, 1e-6, None, 0, stream())
+            torch.cuda.synchronize()
+            assert rel_l2(out, ref) < 2e-5, (tile, H, W, Cin, Cout, up, rel_l2(out, ref))
+            assert rel_l2(o16, ref) < (4e-3 if prec == "bf16" else 5e-4)
+            o64 = out.double().view(M, 32, gs)
+            want = torch.stack([o64.sum(dim=(0, 2)), (o64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1)
+            assert torch.allclose(stats, want, rtol=1e-5, atol=1e-3), (tile, (stats - want).abs().max())
+            # GroupNorm-backward sums of a dgrad-shaped launch: out = d(GN output); xg = that GroupNorm's forward input
+            xg = torch.randn(M, Cout, device=DEV)
+            x64 = xg.double().view(M, 32, gs)
+            fstats = torch.stack([x64.sum(dim=(0, 2)), (x64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1).contiguous()
+            gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+            bst = torch.zeros(64, device=DEV, dtype=torch.float64)
+            g2 = args()
+            out2 = torch.full((M, Cout), float("nan"), device=DEV); g2.out_f32 = out2.data_ptr(); g2.ldc_f32 = Cout
+            call("prx_k_gemm_gn", g2, bst, gs, xg, fstats, gamma, beta, 1, 1e-6, None, 0, stream())
+            torch.cuda.synchronize()
+            assert rel_l2(out2, ref - resid - bias) < 2e-5
+            n = M * gs
+            mean = fstats.view(32, 2)[:, 0] / n
+            var = (fstats.view(32, 2)[:, 1] / n - mean ** 2).clamp(min=0)
+            rstd = 1.0 / torch.sqrt(var + 1e-6)
+            xh = (x64 - mean.view(1, 32, 1)) * rstd.view(1, 32, 1)
+            y = xh.float().double() * gamma.double().view(1, 32, gs) + beta.double().view(1, 32, gs)
+            sg = torch.sigmoid(y)
+            dxh = out2.double().view(M, 32, gs) * (sg * (1 + y * (1 - sg))) * gamma.double().view(1, 32, gs)
+            wantb = torch.stack([dxh.sum(dim=(0, 2)), (dxh * xh).sum(dim=(0, 2))], dim=1).reshape(-1)
+            assert torch.allclose(bst, wantb, rtol=5e-4, atol=5e-2), (tile, (bst - wantb).abs().max())
+        assert ran or tile == (160, 192)
+    finally:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
 
 
 def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
