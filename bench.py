@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "f32": 157.3}
+PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "f32": 157.3, "ref": 2500.0}
 # algorithmic work per iteration at the headline config; the other configurations report
 # the contraction flops the engine executed (sum of 2MNK over its launches, split-K counted once)
 GFLOP_DECODER_256 = 506.0 + 2.1
@@ -76,7 +76,9 @@ def cfg3_custom_losses(device, precision, on_cpu=False):
                              reference_schedule=True)
         sat = workload_ref.SaturationLossRef()
     else:
-        ext = sl.Vgg16Extractor(space=args.styleloss_ospace, params=params, device=device, max_hw=(512, 512), precision=precision)
+        from pixray_amd._lib import split_precision
+        ext = sl.Vgg16Extractor(space=args.styleloss_ospace, params=params, device=device, max_hw=(512, 512),
+                                precision=split_precision(precision)[1])
         style = sl.StyleLoss(extractor=ext, style_image=style_img, device=device)
         sat = make_saturation_loss(device)
     args = style.parse_settings(args)
@@ -145,8 +147,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["cfg1", "cfg2", "cfg3"], default="cfg1")
     ap.add_argument("--cutn", type=int, default=None, help="cutouts (default: the configuration's own count)")
-    ap.add_argument("--precision", choices=["fp16", "bf16", "f32"], default="fp16",
-                    help="operand precision of the timed run: fp16 (default; the reference's own GPU arithmetic for CLIP, slip.py:175), "
+    ap.add_argument("--precision", choices=["fp16", "bf16", "f32", "ref"], default="fp16",
+                    help="operand precision of the timed run: ref = the reference's own mix on a GPU (fp32 VQGAN decoder on the exact-f32 "
+                         "MFMA + fp16 CLIP towers; cfg1 / cfg2), fp16 (default; the reference's own GPU arithmetic for CLIP, slip.py:175), "
                          "bf16, or f32 (exact-f32 MFMA parity mode)")
     ap.add_argument("--no-other-modes", action="store_true",
                     help="skip the extra legs (headline config, 1 GPU): it/s of the other precisions and dL/dz parity of every mode")
@@ -184,7 +187,7 @@ def main():
 
     wl = api.WORKLOADS[args.config]
     cutn = args.cutn if args.cutn else wl["num_cuts"]
-    heavy = args.config != "cfg1" or args.precision == "f32"
+    heavy = args.config != "cfg1" or args.precision in ("f32", "ref")
     steps = args.steps if args.steps is not None else (10 if heavy else 30)
     warmup = args.warmup if args.warmup is not None else (2 if heavy else 5)
 
@@ -353,11 +356,11 @@ def main():
         sess = None
         torch.cuda.empty_cache()
         other_modes = {}
-        for prec in ("fp16", "bf16", "f32"):
+        for prec in ("fp16", "ref", "bf16", "f32"):
             if prec == args.precision:
                 continue
             s2 = api.build_workload(args.config, num_cuts=cutn, precision=prec, device=dev)
-            n2, w2 = (10, 2) if prec == "f32" else (steps, warmup)
+            n2, w2 = (10, 2) if prec in ("f32", "ref") else (steps, warmup)
             for i in range(w2):
                 s2.train(i)
             torch.cuda.synchronize(dev)
@@ -367,7 +370,9 @@ def main():
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t1
             other_modes[prec] = {"value": round(n2 / dt, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt / n2, 3), "steps": n2,
-                                 "warmup": w2, "frac_of_mfma_peak": round((n2 / dt) * per_gpu_gflop * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4)}
+                                 "warmup": w2,
+                                 # "ref" mixes two MFMA peaks (f32 decoder, fp16 tower): no single roofline fraction
+                                 "frac_of_mfma_peak": None if prec == "ref" else round((n2 / dt) * per_gpu_gflop * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4)}
             del s2
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
@@ -376,7 +381,7 @@ def main():
             ref = None
             parity = {"what": "dL/dz after ONE iteration vs the fp32 CPU oracle, same seeds and explicit augmentation draws "
                               "(SURVEY.md 8d gates: f32 rel-L2 <= 1e-4 jitter off / 1e-3 on; fp16, bf16 rel-L2 <= 2e-2 and cosine >= 0.999)"}
-            for prec in ("fp16", "bf16", "f32"):
+            for prec in ("fp16", "ref", "bf16", "f32"):
                 hip = workload_ref.hip_gradient(args.config, cutn, prec, prm, 0, str(dev))
                 if ref is None:
                     ref = workload_ref.iteration(args.config, cutn, 0, prm, state=hip["start"])
@@ -429,7 +434,9 @@ def main():
                        "precision": {"fp16": "IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16: the reference's CLIP arithmetic on a GPU), "
                                              "fp32 accumulate / residual streams / norms, power-of-two gradient scale in the backward",
                                      "bf16": "bf16 MFMA operands, fp32 accumulate / residual streams / norms",
-                                     "f32": "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)"}[args.precision]},
+                                     "f32": "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)",
+                                     "ref": "the reference's own mix on a GPU: fp32 VQGAN decoder (every decoder contraction on "
+                                            "v_mfma_f32_32x32x2_f32, vqgan.py:124-140) + IEEE-half CLIP tower (slip.py:175)"}[args.precision]},
             "final_loss": round(loss, 5),
             "per_gpu_gflop_per_step": round(per_gpu_gflop, 1) if per_gpu_gflop else None,
             "iter_mfma_frac": round(iter_frac, 4) if iter_frac else None,

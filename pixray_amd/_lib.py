@@ -69,6 +69,15 @@ def precision_code(precision) -> int:
     raise ValueError(f"unknown precision {precision!r} (want 'fp16', 'bf16' or 'f32')")
 
 
+def split_precision(precision):
+    """(drawer precision, perceptor precision) of a session-level precision.  "ref" is the REFERENCE's own arithmetic mix on a
+    GPU: the VQGAN decoder in fp32 (taming's VQModel stays fp32, vqgan.py:124-140) and the CLIP towers in IEEE half
+    (clip.load keeps fp16 weights / activations, slip.py:175) -- here: exact-f32 MFMA decoder + fp16-operand towers."""
+    if isinstance(precision, str) and precision.lower() in ("ref", "reference", "mixed"):
+        return "f32", "fp16"
+    return precision, precision
+
+
 def precision_name(precision) -> str:
     return {PREC_F16: "fp16", PREC_BF16: "bf16", PREC_F32: "f32"}[precision_code(precision)]
 

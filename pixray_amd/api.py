@@ -76,14 +76,16 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     (pixray.py:823-835, 1307-1336); `init_weight*`: the z / pixel regularisers of pixray.py:1351-1375 (need `init_image`);
     `overlay_*`: a PIL image (or path) pasted over the current image every `overlay_every` iterations and re-encoded by the HIP
     VQGAN encoder (pixray.py:731-747, 1408-1420); `precision`: "fp16" (the default: IEEE-half MFMA operands, the reference's own GPU arithmetic for CLIP,
-    slip.py:175), "bf16" (the same rate, 8 significand bits) or "f32" (every
-    contraction on the exact-f32 MFMA: the parity mode the bf16 numbers are measured against)."""
+    slip.py:175), "bf16" (the same rate, 8 significand bits), "f32" (every
+    contraction on the exact-f32 MFMA: the parity mode the bf16 numbers are measured against) or "ref" (the reference's own
+    mix on a GPU: fp32 VQGAN decoder, vqgan.py:124-140, + fp16 CLIP towers)."""
     _lib.load()   # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
     dev = torch.device(device)
+    drawer_precision, precision = _lib.split_precision(precision)      # "ref": f32 decoder + fp16 towers (the reference's GPU mix)
     settings = types.SimpleNamespace(vqgan_model=vqgan_model, size=tuple(size), weight_seed=seed,
-                                     vqgan_config=None, vqgan_checkpoint=None, precision=precision)
+                                     vqgan_config=None, vqgan_checkpoint=None, precision=drawer_precision)
     drawer = VqganDrawer(settings)
     drawer.load_model(settings, dev)
     drawer.init_from_tensor(None if init_image is None else init_image.to(dev) * 2 - 1)
@@ -146,6 +148,7 @@ def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=2
     drawer.load_model(st, dev)
     drawer.init_from_tensor(None)
     per_rank = num_cuts // world_size
+    precision = _lib.split_precision(precision)[1]        # no decoder here: "ref" = the fp16 tower
     perceptor = get_clip_perceptor(clip_model, dev, max_batch=per_rank, seed=seed + 1, group=group, precision=precision)
     mk = MakeCutouts(perceptor.input_resolution, num_cuts, generator=torch.Generator().manual_seed(1000 + seed),
                      aspect_width=size[0] / size[1])

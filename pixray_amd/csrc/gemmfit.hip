@@ -94,7 +94,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
 
     int bid = blockIdx.x;
     if (p.xcd_swizzle) bid = (int)xcd_linear(bid, gridDim.x);
-    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+    // tile order: consecutive tiles (an XCD owns a contiguous range of them) share their A row panel (row-major order) or, for
+    // weight-heavy problems (N > M: the decoder's 16^2 / 32^2 convolutions), their B column panel (bit 4: column-major order),
+    // so that the larger operand is fetched into ONE L2 instead of all eight
+    int tm, tn;
+    if (p.fit_flags & 16) { tn = bid / p.tiles_m; tm = bid - tn * p.tiles_m; }
+    else                  { tm = bid / p.tiles_n; tn = bid - tm * p.tiles_n; }
 
     // ---- DMA coordinates: slot j of this wave moves piece min(wave + NW j, NP - 1) of every stage -----------------------
     const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);

@@ -710,3 +710,35 @@ def test_bench_bare_gpus_form_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec == {"dry_run": True, "world": 2, "ranks": [0, 1], "gpus": 2}
+
+
+def test_reference_precision_mix_splits_into_f32_decoder_and_fp16_towers():
+    from pixray_amd import _lib
+    assert _lib.split_precision("ref") == ("f32", "fp16") and _lib.split_precision("REF") == ("f32", "fp16")
+    for p in ("fp16", "bf16", "f32", None):
+        assert _lib.split_precision(p) == (p, p)
+    assert _lib.precision_code(_lib.split_precision("ref")[0]) == _lib.PREC_F32
+    assert _lib.precision_code(_lib.split_precision("ref")[1]) == _lib.PREC_F16
+
+
+def test_default_vector_prompt_table_is_the_references():
+    """pixray's default `--vector_prompts textoff` (pixray.py:887-915, 1732): the package ships the reference's table rows for
+    the towers it implements, value for value (checked against /root/reference when present), resolved like the reference
+    resolves a bare name; a tower without a row is skipped with the reference's warning"""
+    import json
+    from pixray_amd import api
+    t = api.load_vector_table("textoff")
+    assert set(t) == {"RN50", "RN50x4", "ViT-B/32", "ViT-B/16"}
+    assert len(t["ViT-B/32"]) == 1 and len(t["ViT-B/32"][0]) == 512 and len(t["RN50x4"][0]) == 640
+    src = "/root/reference/vectors/textoff.json"
+    if os.path.exists(src):
+        with open(src) as f:
+            ref = json.load(f)
+        for k in t:
+            assert t[k] == ref[k]
+    assert api.WORKLOADS["cfg1"]["vector_prompts"] == ("textoff",) and api.WORKLOADS["cfg3"]["vector_prompts"] == ()
+    from oracle import step_ref
+    from pixray_amd import weights
+    pl = step_ref.prompt_list("ViT-B/32", weights.CLIP_CONFIGS["ViT-B/32"], 0)
+    assert len(pl) == 2 and pl[1][1] == 0.1 and pl[0][1] == 1.0 and tuple(pl[1][0].shape) == (1, 512)
+    assert len(step_ref.prompt_list("tiny-B/32", weights.CLIP_CONFIGS["tiny-B/32"], 0)) == 1

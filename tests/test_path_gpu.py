@@ -585,14 +585,26 @@ def test_make_cutouts_spot_masks_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------ VGG16 extractor (StyleLoss plugin)
+# Gates of the VGG16 extractor and of the STROTSS loss on top of it, per operand precision (features rel-L2, input-gradient
+# rel-L2 / cosine).  The exact-f32 mode is the parity statement: fp32 round-off against the oracle.  The 16-bit modes are gated
+# at their MEASURED values (tools/vgg_precision_probe.py, log committed as profiles/r04_vgg_precision_probe.txt): this probe
+# differentiates random cotangents through 13 conv+ReLU layers of a seeded random network, where a pre-activation rounded
+# across zero flips a ReLU mask -- fp16 0.9979..0.9983 / 5.8e-2..6.6e-2, bf16 0.984..0.986 / 0.17..0.18; end to end (configs[3]
+# at its 256 cutouts WITH the StyleLoss term, tests/test_fullsize_gpu.py) the stated 2e-2 / 0.999 gate applies.
+VGG_GATES = {"f32": dict(feat=1e-5, grad_rel=1e-4, grad_cos=0.9999999, strotss_val=1e-5, strotss_rel=1e-3, strotss_cos=0.999999),
+             "fp16": dict(feat=2e-3, grad_rel=9e-2, grad_cos=0.997, strotss_val=1e-3, strotss_rel=1.6e-1, strotss_cos=0.99),
+             "bf16": dict(feat=1.5e-2, grad_rel=2.5e-1, grad_cos=0.975, strotss_val=5e-3, strotss_rel=3.5e-1, strotss_cos=0.94)}
+
+
+@pytest.mark.parametrize("precision", ["f32", "fp16", "bf16"])
 @pytest.mark.parametrize("H,W", [(64, 48), (50, 70), (128, 128)])
-def test_vgg16_features_and_input_gradient_match_the_oracle(H, W):
-    """the nine captured ReLU maps (Losses/StyleLoss.py:31) and d(sum_k <feat_k, r_k>)/dx against the fp32 oracle; odd
-    sizes exercise the floor of the 2x2 pools.  bf16 operands through up to 13 conv+ReLU layers: 2e-2 on the maps; the
-    gradient additionally sees ReLU masks flip where a bf16-rounded pre-activation changes sign (cosine bound)."""
+def test_vgg16_features_and_input_gradient_match_the_oracle(H, W, precision):
+    """the nine captured ReLU maps (Losses/StyleLoss.py:31) and d(sum_k <feat_k, r_k>)/dx against the fp32 oracle in all three
+    operand precisions; odd sizes exercise the floor of the 2x2 pools"""
     from oracle import vgg_ref
+    gate = VGG_GATES[precision]
     params = weights.synthetic_vgg16_params(0)
-    handle = ops.Vgg16Handle(params, (128, 128), torch.device(DEV))
+    handle = ops.Vgg16Handle(params, (128, 128), torch.device(DEV), precision=precision)
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(1, 3, H, W, generator=g) * 2 - 1)
     xn = vgg_ref.normalise(x)
@@ -604,12 +616,12 @@ def test_vgg16_features_and_input_gradient_match_the_oracle(H, W):
     rs = []
     for k, (f, r) in enumerate(zip(got, ref)):
         assert tuple(f.shape) == (1, r.shape[2], r.shape[3], r.shape[1]), (k, f.shape, r.shape)
-        assert rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()) < 2e-2, (k, rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()))
+        assert rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()) < gate["feat"], (k, rel_l2(f.permute(0, 3, 1, 2).cpu(), r.detach()))
         rs.append(torch.randn(r.shape, generator=g) / math.sqrt(r.numel()))
     sum((r_ * f_).sum() for r_, f_ in zip(rs, ref)).backward()
     sum((r_.permute(0, 2, 3, 1).to(DEV) * f_).sum() for r_, f_ in zip(rs, got)).backward()
     cs, rl = cosine(xd.grad.cpu(), xo.grad), rel_l2(xd.grad.cpu(), xo.grad)
-    assert cs > 0.98 and rl < 2e-1, (cs, rl)
+    assert cs > gate["grad_cos"] and rl < gate["grad_rel"], (precision, cs, rl)
     # a gradient on one early feature only: the layers above it are skipped
     xd2 = xn.to(DEV).requires_grad_(True)
     f2 = ops.vgg16_features(xd2, handle)
@@ -618,18 +630,20 @@ def test_vgg16_features_and_input_gradient_match_the_oracle(H, W):
     ref2 = vgg_ref.forward_base(params, xo)[1:]
     (rs[1] * ref2[1]).sum().backward()
     cs, rl = cosine(xd2.grad.cpu(), xo.grad), rel_l2(xd2.grad.cpu(), xo.grad)
-    assert cs > 0.995 and rl < 8e-2, (cs, rl)       # two bf16 conv layers + the mask flips of relu1_1
+    assert cs > max(gate["grad_cos"], 0.995) and rl < min(gate["grad_rel"], 8e-2), (precision, cs, rl)       # two conv layers + the mask flips of relu1_1
 
 
-def test_style_loss_on_the_hip_extractor_tracks_the_oracle_extractor():
+@pytest.mark.parametrize("precision", ["f32", "fp16", "bf16"])
+def test_style_loss_on_the_hip_extractor_tracks_the_oracle_extractor(precision):
     """the StyleLoss plugin's STROTSS loss (arithmetic pinned to the reference's own code on CPU, tests/test_style_loss.py)
     with the HIP VGG16 extractor against the same plugin on the CPU oracle's features, same numpy seed -> same sampled
-    positions.  bf16 features move the nearest-neighbour choices of the relaxed EMD a little: 3 % on the value, cosine
-    0.9 on the image gradient."""
+    positions.  Exact-f32 extractor: the value to 1e-5 and the image gradient to 1e-3 (measured 1.5e-7 / 1.7e-4: a handful of
+    nearest-neighbour choices of the relaxed EMD sit on fp32 ties); 16-bit extractors at their measured values (VGG_GATES)."""
     import warnings
     import numpy as np
     from oracle import vgg_ref
     from pixray_amd import style_loss as sl
+    gate = VGG_GATES[precision]
     params = weights.synthetic_vgg16_params(0)
 
     class OracleExtractor:
@@ -649,8 +663,8 @@ def test_style_loss_on_the_hip_extractor_tracks_the_oracle_extractor():
         np.random.seed(3)
         la = sl.strotss_loss(a, style, 16.0, extractor=OracleExtractor())
         np.random.seed(3)
-        lb = sl.strotss_loss(b, style.to(DEV), 16.0, extractor=sl.Vgg16Extractor(params=params, device=DEV, max_hw=(96, 80)))
+        lb = sl.strotss_loss(b, style.to(DEV), 16.0, extractor=sl.Vgg16Extractor(params=params, device=DEV, max_hw=(96, 80), precision=precision))
     (ga,) = torch.autograd.grad(la, a)
     (gb,) = torch.autograd.grad(lb, b)
-    assert abs(float(la.detach()) - float(lb.detach())) < 3e-2 * abs(float(la.detach())), (float(la.detach()), float(lb.detach()))
-    assert cosine(gb.cpu(), ga) > 0.9, cosine(gb.cpu(), ga)
+    assert abs(float(la.detach()) - float(lb.detach())) < gate["strotss_val"] * abs(float(la.detach())), (float(la.detach()), float(lb.detach()))
+    assert cosine(gb.cpu(), ga) > gate["strotss_cos"] and rel_l2(gb.cpu(), ga) < gate["strotss_rel"], (cosine(gb.cpu(), ga), rel_l2(gb.cpu(), ga))
