@@ -42,6 +42,8 @@ constexpr int FIT_STAGES = 3;
 typedef const __attribute__((address_space(1))) void* fit_gptr;
 typedef __attribute__((address_space(3))) void* fit_lptr;
 
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+
 template <typename T16>
 __device__ __forceinline__ f32x4 fit_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
     if constexpr (std::is_same<T16, half_t>::value)
@@ -97,9 +99,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // tile order: consecutive tiles (an XCD owns a contiguous range of them) share their A row panel (row-major order) or, for
     // weight-heavy problems (N > M: the decoder's 16^2 / 32^2 convolutions), their B column panel (bit 4: column-major order),
     // so that the larger operand is fetched into ONE L2 instead of all eight
-    int tm, tn;
-    if (p.fit_flags & 16) { tn = bid / p.tiles_m; tm = bid - tn * p.tiles_m; }
-    else                  { tm = bid / p.tiles_n; tn = bid - tm * p.tiles_n; }
+    // A workgroup handles `reps` consecutive tiles along N (rep_m = 0) or along M (rep_m = 1), one after the other: the stores of
+    // tile r drain from the L2 while tile r + 1 runs its K loop (a one-tile workgroup ends in an epilogue nothing overlaps:
+    // FC1 writes 39 MB, of which the 32 MB of L2 absorb about a quarter -- measured 14 of its 33 us), and the operand panel the
+    // tiles share is re-read from the L2 it already sits in.
+    const int reps = p.reps > 0 ? p.reps : 1;
+    const int gm = p.rep_m ? ceil_div_dev(p.tiles_m, reps) : p.tiles_m, gn = p.rep_m ? p.tiles_n : ceil_div_dev(p.tiles_n, reps);
+    int sm, sn;                                          // super-tile coordinates
+    if (p.fit_flags & 16) { sn = bid / gm; sm = bid - sn * gm; }
+    else                  { sm = bid / gn; sn = bid - sm * gn; }
+  for (int rep = 0; rep < reps; ++rep) {
+    const int tm = p.rep_m ? sm * reps + rep : sm, tn = p.rep_m ? sn : sn * reps + rep;
+    if (tm >= p.tiles_m || tn >= p.tiles_n) break;      // wave-uniform: a ragged last super-tile
 
     // ---- DMA coordinates: slot j of this wave moves piece min(wave + NW j, NP - 1) of every stage -----------------------
     const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
@@ -406,6 +417,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             }
         }
     }
+    if (rep + 1 < reps) __syncthreads();     // the epilogue's LDS scratch is the next tile's ring
+  }
 }
 
 template <int WGM, int WGN, int FM, int FN, int KS>
@@ -424,8 +437,15 @@ void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
 // the tile shapes this kernel exists in
 struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
 const FitTile kFitTiles[] = {
-    {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {128, 128, 1, 32, 0.85}, {80, 128, 2, 32, 0.85},
-    {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
+    {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
+    {80, 128, 2, 32, 0.85}, {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
+};
+// plans the planner may pick: a tile, processed `reps` at a time along N (rep_m = 0) or M (rep_m = 1) by one workgroup
+struct FitPlan { int bm, bn, reps, rep_m; double eff; };
+const FitPlan kFitPlans[] = {
+    {160, 128, 2, 0, 1.04},      // N = 3072 at M = 3200 (FC1, W2^T dgrad): 240 workgroups x 2 tiles, the first tile's stores drain under the second
+    {80, 128, 3, 0, 0.90},       // N = 2304 (QKV): 240 workgroups x 3 tiles
+    {128, 128, 2, 1, 0.97},      // the decoder's 256^2 level (65 536 x 128): 256 workgroups x 2 row tiles
 };
 const FitTile* fit_tile(int bm, int bn) {
     for (const FitTile& t : kFitTiles)
@@ -465,20 +485,26 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && one_operand && d.M >= 1 &&
            (unsigned long long)d.N * d.ldb < (1ull << 31);
 }
-// planner: the fit tile (if any) whose grid fills the chip best; *bm = 0 when the 4-wave kernels should keep the problem
-void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
-    *bm = *bn = 0;
+// planner: the fit tile (if any) whose grid fills the chip best; *bm = 0 when the 4-wave kernels should keep the problem.
+// reps / rep_m: tiles per workgroup and their direction (1, 0: one tile per workgroup)
+void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int allow_reps, int* bm, int* bn, int* reps, int* rep_m) {
+    *bm = *bn = 0; *reps = 1; *rep_m = 0;
     double best = 0.0;
-    for (const FitTile& t : kFitTiles) {
-        if (d.N < t.bn && !(t.bn <= 64)) continue;
-        if (!prx_gemmfit_eligible(d, t.bm, t.bn)) continue;
-        const int tiles = ceil_div(d.M, t.bm) * ceil_div(d.N, t.bn);
-        if (tiles > 2 * n_cu) continue;                                   // a one- or two-round kernel by construction
-        const double fill = (double)tiles / ((double)ceil_div(tiles, n_cu) * n_cu);
-        const double waste = ((double)ceil_div(d.M, t.bm) * t.bm / d.M) * ((double)ceil_div(d.N, t.bn) * t.bn / d.N);
-        const double score = fill * t.eff / waste;
-        if (score > best && fill / waste >= 0.8) { best = score; *bm = t.bm; *bn = t.bn; }
-    }
+    auto consider = [&](int tbm, int tbn, int r, int rm, double eff) {
+        if (d.N < tbn && !(tbn <= 64)) return;
+        if (!prx_gemmfit_eligible(d, tbm, tbn)) return;
+        const int tm_ = ceil_div(d.M, tbm), tn_ = ceil_div(d.N, tbn);
+        if (r > 1 && (rm ? tm_ : tn_) % r != 0) return;                    // whole super-tiles only
+        const int wgs = rm ? (tm_ / r) * tn_ : tm_ * (tn_ / r);
+        if (wgs > 2 * n_cu) return;                                        // a one- or two-round kernel by construction
+        const double fill = (double)wgs / ((double)ceil_div(wgs, n_cu) * n_cu);
+        const double waste = ((double)tm_ * tbm / d.M) * ((double)tn_ * tbn / d.N);
+        const double score = fill * eff / waste;
+        if (score > best && fill / waste >= 0.8) { best = score; *bm = tbm; *bn = tbn; *reps = r; *rep_m = rm; }
+    };
+    for (const FitTile& t : kFitTiles) consider(t.bm, t.bn, 1, 0, t.eff);
+    if (allow_reps)
+        for (const FitPlan& q : kFitPlans) consider(q.bm, q.bn, q.reps, q.rep_m, q.eff);
 }
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
@@ -486,6 +512,7 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 gri
     if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1>(a, grid, s, zp);
     else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);
+    else if (bm == 160 && bn == 128) launch_fit<2, 4, 5, 2, 1>(a, grid, s, zp);
     else if (bm == 128 && bn == 128) launch_fit<2, 4, 4, 2, 1>(a, grid, s, zp);
     else if (bm == 80 && bn == 128) launch_fit<1, 4, 5, 2, 2>(a, grid, s, zp);
     else if (bm == 128 && bn == 64) launch_fit<2, 2, 4, 2, 2>(a, grid, s, zp);

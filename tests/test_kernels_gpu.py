@@ -318,6 +318,28 @@ def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 1)
         assert rel_l2(outs[0], outs[1]) < 2e-6
         assert rel_l2(outs[0], A.float() @ Bt.float().T) < 2e-5
+    # the decoder's 256^2 level (two row tiles per workgroup) and a 16^2 convolution (8 K groups), planner's choice vs 4-wave kernels
+    for (H, Cin, Cout) in [(256, 128, 128), (16, 512, 512)]:
+        x = torch.randn(1, Cin, H, H, device=DEV)
+        w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(9 * Cin)
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(torch.float16)
+        w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(torch.float16)
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+        outs = []
+        for fit in (1, 0):
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, fit)
+            g = GemmArgs()
+            g.A = x_nhwc.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
+            g.M, g.N, g.K = H * H, Cout, 9 * Cin
+            g.H, g.W, g.Cin, g.up = H, H, Cin, 0
+            g.alpha = 1.0; g.f32 = 2
+            out = torch.full((H * H, Cout), float("nan"), device=DEV); g.out_f32 = out.data_ptr(); g.ldc_f32 = Cout
+            call("prx_k_gemm", g, ws, ws.numel(), stream())
+            torch.cuda.synchronize()
+            outs.append(out)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -7, 0, 1)
+        ref = F.conv2d(x.to(torch.float16).float(), w.to(torch.float16).float(), None, padding=1).permute(0, 2, 3, 1).reshape(H * H, Cout)
+        assert rel_l2(outs[0], outs[1]) < 2e-6 and rel_l2(outs[0], ref) < 2e-5
 
 
 @pytest.mark.parametrize("H,W,Cin,Cout,up,NB", [
