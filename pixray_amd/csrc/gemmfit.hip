@@ -8,8 +8,9 @@
 // HBM; and the small tiles that do fill the chip move twice the L2->LDS bytes per flop (64 B/clk/CU on that path).  Here the
 // tile is chosen so that the grid is ~240 - 256 workgroups, and when that makes the tile small the K loop is split over the
 // wave groups of ONE workgroup (KS) and summed through LDS -- no workspace, no second launch:
-//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 256 (240 tiles)   N = 2304 -> 160 x 192 (240)   N = 768 -> 80 x 128, KS 2 (240)
-//     decoder 256^2 level: 65 536 x 128 -> 256 x 128 (256)      128^2: 128 x 128 / 128 x 64 KS 2     64^2: 64 x 64 KS 2
+//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 128, two per workgroup (240 workgroups)   N = 2304 -> 160 x 192 (240)
+//                          N = 768 -> 80 x 128, KS 2 (240)
+//     decoder 256^2 level: 65 536 x 128 -> 128 x 128, two per workgroup (256)   128^2: 128 x 128 / 128 x 64 KS 2   64^2: 64 x 64 KS 2
 //                  32^2:   32 x 64 KS 4 / 16 x 64 KS 4           16^2:  256 x 512 x 4608 -> 16 x 32, KS 8 (256 tiles)
 // The same tiles fit the sharded batches (32 / 16 / 8 cutouts: M = 1600 / 800 / 400 are multiples of 80).
 //
@@ -31,6 +32,8 @@
 // PRX_ACT_RELUMASK_POST, which reads a residual and a mask), no split-K across workgroups.
 #include "gemm_epi.h"
 #include <type_traits>
+#include <algorithm>
+#include <stdlib.h>
 
 const bf16_t* prx_gemm_zero_page();       // gemm.hip: 256 bytes of zeros on the current device
 
@@ -68,6 +71,191 @@ __device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst&
         const float dxh = gy * gav[i];
         s0 += dxh;
         s1 += dxh * xh;
+    }
+}
+
+// The part of a fit kernel behind its K loop, shared by the ring kernel and the streaming kernel: the K groups' partial sums
+// through LDS, then the engine's epilogue.  `fl`: the workgroup's LDS as floats (fit_scratch_floats<...>() of them), free of
+// any other use; every wave of the workgroup calls this.
+template <int WGM, int WGN, int FM, int FN, int KS>
+constexpr int fit_scratch_floats() {
+    return (KS > 1 ? WGM * WGN * KS * FM * FN * 256 : 0) + WGM * WGN * KS * 16 * (16 * FN + 4) + KS * WGM * (16 * FN * WGN / 2);
+}
+template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
+__device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
+                                           int wt, int wm, int wn, int lane) {
+    constexpr int NWT = WGM * WGN, NW = NWT * KS;
+    constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN, TN = 16 * FN;
+    const GemmDesc& d = p.d;
+    const int tid = threadIdx.x;
+    const int l15 = lane & 15, kq = lane >> 4;
+    // ---- K groups: every wave dumps the 16-row slabs it does not OWN (slab i belongs to group i % KS); the owner adds the
+    // other groups' partials in group order.  One barrier, no workspace, a fixed summation order.
+    constexpr int DUMP = KS > 1 ? NW * FM * FN * 256 : 0;          // floats
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if (i % KS == kg) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(fl + ((kg * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if (i % KS != kg) continue;
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                if (g == kg) continue;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] += *reinterpret_cast<const f32x4*>(fl + ((g * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4);
+            }
+        }
+    }
+
+    // ---- epilogue: per wave, one 16-row slab at a time through a private LDS slab; 8 consecutive columns per lane, so the
+    // 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
+    // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual, aux or GroupNorm-input rows, bias) is
+    // fetched for the whole wave tile BEFORE the first store: the compiler cannot move a load above an earlier store that may
+    // alias it, and with one workgroup per CU nothing else hides a chain of dependent load round trips.
+    typedef __attribute__((ext_vector_type(8))) T16 t16x8;
+    constexpr int LDW = TN + 4;                 // padded row (floats), rows stay 16-byte aligned
+    constexpr int LPR = TN / 8;                 // lanes per row
+    constexpr int RPP = 64 / LPR;               // rows per pass
+    constexpr int NPASS = (16 + RPP - 1) / RPP;
+    float* const stage = fl + DUMP + wave * (16 * LDW);
+    const int rbase = tm * BM + wm * (16 * FM), cbase = tn * BN + wn * TN;
+    const int lr0 = lane / LPR, lc = (lane - lr0 * LPR) * 8;
+    const int col = cbase + lc;
+    const bool col_ok = lane < RPP * LPR && col < d.N;        // N % 8 == 0: a lane's 8 columns are in range together
+    const int act = d.act;
+    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
+    const bool has_resid = d.resid != nullptr;
+    const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
+    const bool do_stats = d.gn_stats != nullptr;
+    const bool gnb = do_stats && d.gnb_x != nullptr;
+    float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
+    if (d.bias_n && col_ok) {
+        bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
+        bias1 = *reinterpret_cast<const float4*>(d.bias_n + col + 4);
+    }
+    GnbConst gc0{}, gc1{};
+    if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
+    // slabs are handled FMC at a time: the prefetch of a chunk is (2 x 16 bytes + 1) registers per slab and pass on top of the
+    // accumulators, and the wide wave tiles (16+ fragments) have no room for all of them at once
+    constexpr int FMC = FM * FN > 12 ? 2 : FM;
+    float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
+#pragma unroll
+    for (int i0 = 0; i0 < FM; i0 += FMC) {
+        uint4 pf[FMC][NPASS][2];                // residual / GroupNorm input (2 x 16 bytes) or aux (16 bytes) of this lane's 8 columns
+        float pbm[FMC][NPASS];
+#pragma unroll
+        for (int ic = 0; ic < FMC; ++ic) {
+            const int i = i0 + ic;
+            const bool keep = i < FM && (KS == 1 || i % KS == kg);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
+                const bool ok = keep && col_ok && lr < 16 && row < d.M;
+                pf[ic][ps][0] = pf[ic][ps][1] = uint4{0u, 0u, 0u, 0u};
+                pbm[ic][ps] = 0.f;
+                if (ok) {
+                    if (has_resid || gnb) {
+                        const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
+                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
+                        pf[ic][ps][1] = *reinterpret_cast<const uint4*>(r_ + 4);
+                    } else if (need_aux) {
+                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T16*>(d.aux) + (size_t)row * d.ldaux + col);
+                    }
+                    if (d.bias_m) pbm[ic][ps] = d.bias_m[row];
+                }
+            }
+        }
+#pragma unroll
+        for (int ic = 0; ic < FMC; ++ic) {
+            const int i = i0 + ic;
+            if (i >= FM) continue;
+            if (KS > 1 && i % KS != kg) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * LDW + j * 16 + l15] = acc[i][j][r];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
+                if (!(col_ok && lr < 16 && row < d.M)) continue;
+                float4 v0 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
+                float4 v1 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc + 4]);
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, p0, p1;
+                if (has_resid) {
+                    r0 = __builtin_bit_cast(float4, pf[ic][ps][0]);
+                    r1 = __builtin_bit_cast(float4, pf[ic][ps][1]);
+                } else if (need_aux) {
+                    const t16x8 ax = __builtin_bit_cast(t16x8, pf[ic][ps][0]);
+                    a0[0] = (float)ax[0]; a0[1] = (float)ax[1]; a0[2] = (float)ax[2]; a0[3] = (float)ax[3];
+                    a1[0] = (float)ax[4]; a1[1] = (float)ax[5]; a1[2] = (float)ax[6]; a1[3] = (float)ax[7];
+                }
+                v0 = epilogue_math4<T16>(act, alpha, v0, bias0, pbm[ic][ps], a0, has_resid, r0, p0);
+                v1 = epilogue_math4<T16>(act, alpha, v1, bias1, pbm[ic][ps], a1, has_resid, r1, p1);
+                if (act == PRX_ACT_QUICKGELU && d.out_bf16_pre) {
+                    t16x8 q;
+                    q[0] = op_cvt<T16>(p0.x); q[1] = op_cvt<T16>(p0.y); q[2] = op_cvt<T16>(p0.z); q[3] = op_cvt<T16>(p0.w);
+                    q[4] = op_cvt<T16>(p1.x); q[5] = op_cvt<T16>(p1.y); q[6] = op_cvt<T16>(p1.z); q[7] = op_cvt<T16>(p1.w);
+                    *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16_pre) + (size_t)row * d.ldc_bf16 + col) = q;
+                }
+                if (d.out_f32) {
+                    float* o = d.out_f32 + (size_t)row * d.ldc_f32 + col;
+                    *reinterpret_cast<float4*>(o) = v0;
+                    *reinterpret_cast<float4*>(o + 4) = v1;
+                }
+                if (d.out_bf16) {
+                    t16x8 q;
+                    q[0] = op_cvt<T16>(v0.x); q[1] = op_cvt<T16>(v0.y); q[2] = op_cvt<T16>(v0.z); q[3] = op_cvt<T16>(v0.w);
+                    q[4] = op_cvt<T16>(v1.x); q[5] = op_cvt<T16>(v1.y); q[6] = op_cvt<T16>(v1.z); q[7] = op_cvt<T16>(v1.w);
+                    *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = q;
+                }
+                if (gnb) {
+                    fit_gnb_accum(d, gc0, __builtin_bit_cast(float4, pf[ic][ps][0]), v0, gsa0, gsa1);
+                    fit_gnb_accum(d, gc1, __builtin_bit_cast(float4, pf[ic][ps][1]), v1, gsb0, gsb1);
+                } else if (do_stats) {
+                    gsa0 += (v0.x + v0.y) + (v0.z + v0.w);
+                    gsa1 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
+                    gsb0 += (v1.x + v1.y) + (v1.z + v1.w);
+                    gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+                }
+            }
+        }
+    }
+    // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot
+    // each summed in a fixed order, then one fp64 atomic per group and moment (the only order-dependent step, ~1e-16 relative)
+    if (do_stats) {
+        if constexpr ((LPR & (LPR - 1)) == 0) {
+            float* const gpart = fl + DUMP + NW * (16 * LDW);          // [KS * WGM][BN / 4 quads][2]
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                gsa0 += __shfl_xor(gsa0, o, 64); gsa1 += __shfl_xor(gsa1, o, 64);
+                gsb0 += __shfl_xor(gsb0, o, 64); gsb1 += __shfl_xor(gsb1, o, 64);
+            }
+            if (lane < LPR) {
+                float* const w_ = gpart + ((kg * WGM + wm) * (BN / 4) + wn * (TN / 4) + lane * 2) * 2;
+                w_[0] = gsa0; w_[1] = gsa1; w_[2] = gsb0; w_[3] = gsb1;
+            }
+            __syncthreads();
+            const int qpg = d.gn_gs >> 2;                  // quads per group
+            const int ngrp = BN / d.gn_gs;                 // groups covered by this block tile
+            if (tid < ngrp * 2) {
+                const int gl = tid >> 1, mom = tid & 1;
+                const int gcol = tn * BN + gl * d.gn_gs;
+                if (gcol < d.N) {
+                    double a2 = 0.0;
+                    for (int w2 = 0; w2 < KS * WGM; ++w2)
+                        for (int q = 0; q < qpg; ++q) a2 += (double)gpart[(w2 * (BN / 4) + gl * qpg + q) * 2 + mom];
+                    atomicAdd(&d.gn_stats[(size_t)(gcol / d.gn_gs) * 2 + mom], a2);
+                }
+            }
+        }
     }
 }
 
@@ -117,10 +305,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
     const int lrow = lane >> 3, cpos = lane & 7;
     unsigned voff[PW];                                    // per-lane ELEMENT offset from the operand base at K tile 0 (conv A: the chunk only)
-    int pieceA[PW], pieceOff[PW], pieceSub[PW];           // wave-uniform: operand select, LDS element offset inside a stage, K tile inside the stage
-    // implicit convolution: per-lane row / column terms of the three taps per axis and their validity bits (bit ky, bit 3 + kx)
-    int c_r1[CONV ? PW : 1], c_rd0[CONV ? PW : 1], c_rd2[CONV ? PW : 1], c_c1[CONV ? PW : 1], c_cd0[CONV ? PW : 1], c_cd2[CONV ? PW : 1];
-    int c_ok[CONV ? PW : 1];
+    int pieceA[PW], pieceOff[PW];                         // wave-uniform: operand select, LDS element offset inside a stage
+    // implicit convolution, per lane and slot: source row term of the centre tap (c_r1) and the two row deltas packed as 16-bit halves
+    // (c_rd: tap row 0 low, tap row 2 high), source column of the centre tap (c_c1), and one word of flags (c_ok): bit ky / bit 3 + kx =
+    // tap row / column inside the image, bit 6 = the left tap's source column is one less, bit 7 = the right tap's is one more
+    // (with the fused nearest-2x upsample neighbouring taps can share a source column)
+    int c_r1[CONV ? PW : 1], c_rd[CONV ? PW : 1], c_c1[CONV ? PW : 1], c_ok[CONV ? PW : 1];
     int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
@@ -132,7 +322,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         const int chunk = cpos ^ ((r >> 1) & 7);
         pieceA[j] = isA;
         pieceOff[j] = pc * (8 * FIT_BK);
-        pieceSub[j] = sub;
         if (isA) {
             const int g = tm * BM + r;
             if constexpr (CONV) {
@@ -149,9 +338,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                     ro[t] = (b * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
                     co[t] = d.up ? (xx >> 1) : xx;
                 }
+                if (co[0] != co[1]) okm |= 64;
+                if (co[2] != co[1]) okm |= 128;
                 c_ok[j] = okm;
-                c_r1[j] = ro[1]; c_rd0[j] = ro[0] - ro[1]; c_rd2[j] = ro[2] - ro[1];
-                c_c1[j] = co[1]; c_cd0[j] = co[0] - co[1]; c_cd2[j] = co[2] - co[1];
+                c_r1[j] = ro[1]; c_rd[j] = ((ro[0] - ro[1]) & 0xffff) | ((ro[2] - ro[1]) << 16);
+                c_c1[j] = co[1];
                 s_tap[j] = (sub * FIT_BK) / d.Cin;
                 s_c0[j] = sub * FIT_BK - s_tap[j] * d.Cin;
             } else {
@@ -162,7 +353,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             int g = tn * BN + r;
             g = g < d.N ? g : d.N - 1;
             voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * FIT_BK + chunk * 8);
-            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd0[j] = c_rd2[j] = c_c1[j] = c_cd0[j] = c_cd2[j] = 0; s_tap[j] = s_c0[j] = 0; }
+            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; }
         }
     }
     // stages are issued in K order, exactly once each
@@ -175,8 +366,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                 const int tap = s_tap[j];
                 const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - 3 * ky;
                 const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
-                const int ro = c_r1[j] + (my0 & c_rd0[j]) + (my2 & c_rd2[j]);
-                const int co = c_c1[j] + (mx0 & c_cd0[j]) + (mx2 & c_cd2[j]);
+                const int ro = c_r1[j] + (my0 & ((c_rd[j] << 16) >> 16)) + (my2 & (c_rd[j] >> 16));
+                const int co = c_c1[j] - (mx0 & ((c_ok[j] >> 6) & 1)) + (mx2 & ((c_ok[j] >> 7) & 1));
                 const bool ok = ((c_ok[j] >> ky) & (c_ok[j] >> (3 + kx)) & 1) != 0;
                 src = ok ? Ap + (long long)(ro + co) * d.lda + (s_c0[j] + (int)voff[j]) : zero_page;
                 s_c0[j] += FIT_BK * KS;
@@ -256,188 +447,31 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- K groups: every wave dumps the 16-row slabs it does not OWN (slab i belongs to group i % KS); the owner adds the
-    // other groups' partials in group order.  One barrier, no workspace, a fixed summation order.
-    float* const fl = reinterpret_cast<float*>(lds);
-    constexpr int DUMP = KS > 1 ? NW * FM * FN * 256 : 0;          // floats
-    static_assert((DUMP + NW * 16 * (TN + 4) + KS * WGM * (BN / 2)) * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
-    if constexpr (KS > 1) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            if (i % KS == kg) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                *reinterpret_cast<f32x4*>(fl + ((kg * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4) = acc[i][j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            if (i % KS != kg) continue;
-#pragma unroll
-            for (int g = 0; g < KS; ++g) {
-                if (g == kg) continue;
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] += *reinterpret_cast<const f32x4*>(fl + ((g * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4);
-            }
-        }
-    }
-
-    // ---- epilogue: per wave, one 16-row slab at a time through a private LDS slab; 8 consecutive columns per lane, so the
-    // 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
-    // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual, aux or GroupNorm-input rows, bias) is
-    // fetched for the whole wave tile BEFORE the first store: the compiler cannot move a load above an earlier store that may
-    // alias it, and with one workgroup per CU nothing else hides a chain of dependent load round trips.
-    typedef __attribute__((ext_vector_type(8))) T16 t16x8;
-    constexpr int LDW = TN + 4;                 // padded row (floats), rows stay 16-byte aligned
-    constexpr int LPR = TN / 8;                 // lanes per row
-    constexpr int RPP = 64 / LPR;               // rows per pass
-    constexpr int NPASS = (16 + RPP - 1) / RPP;
-    float* const stage = fl + DUMP + wave * (16 * LDW);
-    const int rbase = tm * BM + wm * (16 * FM), cbase = tn * BN + wn * TN;
-    const int lr0 = lane / LPR, lc = (lane - lr0 * LPR) * 8;
-    const int col = cbase + lc;
-    const bool col_ok = lane < RPP * LPR && col < d.N;        // N % 8 == 0: a lane's 8 columns are in range together
-    const int act = d.act;
-    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
-    const bool has_resid = d.resid != nullptr;
-    const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
-    const bool do_stats = d.gn_stats != nullptr;
-    const bool gnb = do_stats && d.gnb_x != nullptr;
-    float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
-    if (d.bias_n && col_ok) {
-        bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
-        bias1 = *reinterpret_cast<const float4*>(d.bias_n + col + 4);
-    }
-    GnbConst gc0{}, gc1{};
-    if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
-    uint4 pf[FM][NPASS][2];                     // residual / GroupNorm input (2 x 16 bytes) or aux (16 bytes) of this lane's 8 columns
-    float pbm[FM][NPASS];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const bool keep = KS == 1 || i % KS == kg;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
-            const bool ok = keep && col_ok && lr < 16 && row < d.M;
-            pf[i][ps][0] = pf[i][ps][1] = uint4{0u, 0u, 0u, 0u};
-            pbm[i][ps] = 0.f;
-            if (ok) {
-                if (has_resid || gnb) {
-                    const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
-                    pf[i][ps][0] = *reinterpret_cast<const uint4*>(r_);
-                    pf[i][ps][1] = *reinterpret_cast<const uint4*>(r_ + 4);
-                } else if (need_aux) {
-                    pf[i][ps][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T16*>(d.aux) + (size_t)row * d.ldaux + col);
-                }
-                if (d.bias_m) pbm[i][ps] = d.bias_m[row];
-            }
-        }
-    }
-    float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        if (KS > 1 && i % KS != kg) continue;
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * LDW + j * 16 + l15] = acc[i][j][r];
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
-            if (!(col_ok && lr < 16 && row < d.M)) continue;
-            float4 v0 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
-            float4 v1 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc + 4]);
-            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, p0, p1;
-            if (has_resid) {
-                r0 = __builtin_bit_cast(float4, pf[i][ps][0]);
-                r1 = __builtin_bit_cast(float4, pf[i][ps][1]);
-            } else if (need_aux) {
-                const t16x8 ax = __builtin_bit_cast(t16x8, pf[i][ps][0]);
-                a0[0] = (float)ax[0]; a0[1] = (float)ax[1]; a0[2] = (float)ax[2]; a0[3] = (float)ax[3];
-                a1[0] = (float)ax[4]; a1[1] = (float)ax[5]; a1[2] = (float)ax[6]; a1[3] = (float)ax[7];
-            }
-            v0 = epilogue_math4<T16>(act, alpha, v0, bias0, pbm[i][ps], a0, has_resid, r0, p0);
-            v1 = epilogue_math4<T16>(act, alpha, v1, bias1, pbm[i][ps], a1, has_resid, r1, p1);
-            if (act == PRX_ACT_QUICKGELU && d.out_bf16_pre) {
-                t16x8 q;
-                q[0] = op_cvt<T16>(p0.x); q[1] = op_cvt<T16>(p0.y); q[2] = op_cvt<T16>(p0.z); q[3] = op_cvt<T16>(p0.w);
-                q[4] = op_cvt<T16>(p1.x); q[5] = op_cvt<T16>(p1.y); q[6] = op_cvt<T16>(p1.z); q[7] = op_cvt<T16>(p1.w);
-                *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16_pre) + (size_t)row * d.ldc_bf16 + col) = q;
-            }
-            if (d.out_f32) {
-                float* o = d.out_f32 + (size_t)row * d.ldc_f32 + col;
-                *reinterpret_cast<float4*>(o) = v0;
-                *reinterpret_cast<float4*>(o + 4) = v1;
-            }
-            if (d.out_bf16) {
-                t16x8 q;
-                q[0] = op_cvt<T16>(v0.x); q[1] = op_cvt<T16>(v0.y); q[2] = op_cvt<T16>(v0.z); q[3] = op_cvt<T16>(v0.w);
-                q[4] = op_cvt<T16>(v1.x); q[5] = op_cvt<T16>(v1.y); q[6] = op_cvt<T16>(v1.z); q[7] = op_cvt<T16>(v1.w);
-                *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = q;
-            }
-            if (gnb) {
-                fit_gnb_accum(d, gc0, __builtin_bit_cast(float4, pf[i][ps][0]), v0, gsa0, gsa1);
-                fit_gnb_accum(d, gc1, __builtin_bit_cast(float4, pf[i][ps][1]), v1, gsb0, gsb1);
-            } else if (do_stats) {
-                gsa0 += (v0.x + v0.y) + (v0.z + v0.w);
-                gsa1 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
-                gsb0 += (v1.x + v1.y) + (v1.z + v1.w);
-                gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
-            }
-        }
-    }
-    // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot
-    // each summed in a fixed order, then one fp64 atomic per group and moment (the only order-dependent step, ~1e-16 relative)
-    if (do_stats) {
-        if constexpr ((LPR & (LPR - 1)) == 0) {
-            float* const gpart = fl + DUMP + NW * (16 * LDW);          // [KS * WGM][BN / 4 quads][2]
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) {
-                gsa0 += __shfl_xor(gsa0, o, 64); gsa1 += __shfl_xor(gsa1, o, 64);
-                gsb0 += __shfl_xor(gsb0, o, 64); gsb1 += __shfl_xor(gsb1, o, 64);
-            }
-            if (lane < LPR) {
-                float* const w_ = gpart + ((kg * WGM + wm) * (BN / 4) + wn * (TN / 4) + lane * 2) * 2;
-                w_[0] = gsa0; w_[1] = gsa1; w_[2] = gsb0; w_[3] = gsb1;
-            }
-            __syncthreads();
-            const int qpg = d.gn_gs >> 2;                  // quads per group
-            const int ngrp = BN / d.gn_gs;                 // groups covered by this block tile
-            if (tid < ngrp * 2) {
-                const int gl = tid >> 1, mom = tid & 1;
-                const int gcol = tn * BN + gl * d.gn_gs;
-                if (gcol < d.N) {
-                    double a2 = 0.0;
-                    for (int w2 = 0; w2 < KS * WGM; ++w2)
-                        for (int q = 0; q < qpg; ++q) a2 += (double)gpart[(w2 * (BN / 4) + gl * qpg + q) * 2 + mom];
-                    atomicAdd(&d.gn_stats[(size_t)(gcol / d.gn_gs) * 2 + mom], a2);
-                }
-            }
-        }
-    }
+    static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
+    fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
     if (rep + 1 < reps) __syncthreads();     // the epilogue's LDS scratch is the next tile's ring
   }
 }
 
-template <int WGM, int WGN, int FM, int FN, int KS>
+template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
 void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
     constexpr int threads = 64 * WGM * WGN * KS;
     const bool conv = a.d.a_mode == PRX_A_CONV3X3;
-    if (a.d.h16) {
-        if (conv) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t>), grid, dim3(threads), 0, s, a, zp);
-        else      hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t>), grid, dim3(threads), 0, s, a, zp);
-    } else {
-        if (conv) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t>), grid, dim3(threads), 0, s, a, zp);
-        else      hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t>), grid, dim3(threads), 0, s, a, zp);
+    if constexpr (HAS_CONV) {
+        if (conv) {
+            if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t>), grid, dim3(threads), 0, s, a, zp);
+            else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t>), grid, dim3(threads), 0, s, a, zp);
+            return;
+        }
     }
+    if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t>), grid, dim3(threads), 0, s, a, zp);
+    else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t>), grid, dim3(threads), 0, s, a, zp);
 }
 
 // the tile shapes this kernel exists in
 struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
 const FitTile kFitTiles[] = {
-    {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
+    {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
     {80, 128, 2, 32, 0.85}, {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
 };
 // plans the planner may pick: a tile, processed `reps` at a time along N (rep_m = 0) or M (rep_m = 1) by one workgroup
@@ -463,6 +497,7 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     const FitTile* ft = fit_tile(bm, bn);
     if (!ft) return false;
     const int ks = ft->ks;
+    const int wave_tn = ft->tn;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // null passes
     // the epilogue handles 8 consecutive columns per lane with 16-byte accesses
     const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
@@ -472,13 +507,14 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     // group is a whole number of quads inside the block tile, and the GroupNorm-backward input has the output's layout
     bool stats_ok = true;
     if (d.gn_stats) {
-        const int lpr = ft->tn / 8;
+        const int lpr = wave_tn / 8;
         stats_ok = (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
                    (!d.gnb_x || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
     }
     const bool a_ok = d.a_mode == PRX_A_ROWMAJOR
                           ? (unsigned long long)d.M * d.lda < (1ull << 31)
-                          : (d.a_mode == PRX_A_CONV3X3 && d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
+                          : (d.a_mode == PRX_A_CONV3X3 && bm % 80 != 0 &&          // the 80-row-granular tiles are the token-batch (row-major) ones
+                             d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
                              d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
     // the epilogue prefetches ONE row operand per output row into shared registers: residual, aux, or the GroupNorm input
     const bool one_operand = !(d.resid && d.aux) && !(d.gnb_x && (d.resid || d.aux));
@@ -502,6 +538,11 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int allow_reps, int* bm, int*
         const double score = fill * eff / waste;
         if (score > best && fill / waste >= 0.8) { best = score; *bm = tbm; *bn = tbn; *reps = r; *rep_m = rm; }
     };
+    // weight-heavy products with FEW output rows (a 16^2 / 8^2 / 4^2 map of the StyleLoss extractor, M = 16 ... 256 by 512 channels
+    // over K = 4608): no tile grid fills the chip, but the smallest tile with 8 K groups per workgroup still streams the weight
+    // matrix through 16 ... 256 workgroups in ~9 us where a 128 x 64 tile with split-K + reduce takes 22 - 47 (measured:
+    // profiles/r04_small_m_streaming_vs_ring.txt) -- the fill rule below does not apply to them
+    if ((long long)d.M * d.N <= 256ll * 512 && d.K >= 2048 && d.N >= 32 && prx_gemmfit_eligible(d, 16, 32)) { *bm = 16; *bn = 32; return; }
     for (const FitTile& t : kFitTiles) consider(t.bm, t.bn, 1, 0, t.eff);
     if (allow_reps)
         for (const FitPlan& q : kFitPlans) consider(q.bm, q.bn, q.reps, q.rep_m, q.eff);
@@ -509,12 +550,11 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int allow_reps, int* bm, int*
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
     PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
-    if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1>(a, grid, s, zp);
-    else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1>(a, grid, s, zp);
+    if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);
-    else if (bm == 160 && bn == 128) launch_fit<2, 4, 5, 2, 1>(a, grid, s, zp);
+    else if (bm == 160 && bn == 128) launch_fit<2, 4, 5, 2, 1, false>(a, grid, s, zp);
     else if (bm == 128 && bn == 128) launch_fit<2, 4, 4, 2, 1>(a, grid, s, zp);
-    else if (bm == 80 && bn == 128) launch_fit<1, 4, 5, 2, 2>(a, grid, s, zp);
+    else if (bm == 80 && bn == 128) launch_fit<1, 4, 5, 2, 2, false>(a, grid, s, zp);
     else if (bm == 128 && bn == 64) launch_fit<2, 2, 4, 2, 2>(a, grid, s, zp);
     else if (bm == 64 && bn == 64) launch_fit<2, 2, 2, 2, 2>(a, grid, s, zp);
     else if (bm == 32 && bn == 64) launch_fit<1, 2, 2, 2, 4>(a, grid, s, zp);

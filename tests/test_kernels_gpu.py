@@ -150,7 +150,7 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
-@pytest.mark.parametrize("tile", [(160, 256), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
+@pytest.mark.parametrize("tile", [(160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("stagger", [1, 0])
 def test_gemm_fit_tiles(tile, prec, stagger):
@@ -217,8 +217,8 @@ def test_gemm_fit_tiles(tile, prec, stagger):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
 
 
-FIT_TILES = [(160, 256), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
-FIT_KS = {(160, 256): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
+FIT_TILES = [(160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+FIT_KS = {(160, 128): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
 
 
 @pytest.mark.parametrize("tile", FIT_TILES)
@@ -234,8 +234,8 @@ def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
     ran = 0
     try:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
-        for (H, W, Cin, Cout, up, NB) in [(32, 32, 128, 128, 1, 1), (24, 40, 64, 256, 0, 2), (16, 16, 512, 128, 0, 1)]:
-            if (9 * Cin) % (64 * ks) or (tile == (160, 192)):        # K must split over the K groups; 160 x 192 has no GroupNorm-sum epilogue
+        for (H, W, Cin, Cout, up, NB) in [(32, 32, 128, 128, 1, 1), (24, 40, 64, 256, 0, 2), (16, 16, 512, 128, 0, 1), (16, 24, 256, 128, 1, 2)]:
+            if (9 * Cin) % (64 * ks) or tile[0] % 80 == 0:           # K must split over the K groups; the 80-row-granular tiles are row-major only
                 continue
             ran += 1
             hin, win = (H // 2, W // 2) if up else (H, W)
@@ -292,7 +292,7 @@ def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
             dxh = out2.double().view(M, 32, gs) * (sg * (1 + y * (1 - sg))) * gamma.double().view(1, 32, gs)
             wantb = torch.stack([dxh.sum(dim=(0, 2)), (dxh * xh).sum(dim=(0, 2))], dim=1).reshape(-1)
             assert torch.allclose(bst, wantb, rtol=5e-4, atol=5e-2), (tile, (bst - wantb).abs().max())
-        assert ran or tile == (160, 192)
+        assert ran or tile[0] % 80 == 0
     finally:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
 

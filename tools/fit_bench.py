@@ -24,8 +24,8 @@ h16 = torch.float16
 
 # (M, N, K, tag, epilogue, fit tile)
 shapes = [
-    (3200, 3072, 768, "FC1 (bias, QuickGELU, 2 x 16-bit out)", "fc1", (160, 256)),
-    (3200, 3072, 768, "W2T dgrad (dQuickGELU(aux), 16-bit out)", "dgelu", (160, 256)),
+    (3200, 3072, 768, "FC1 (bias, QuickGELU, 2 x 16-bit out)", "fc1", (160, 128)),
+    (3200, 3072, 768, "W2T dgrad (dQuickGELU(aux), 16-bit out)", "dgelu", (160, 128)),
     (3200, 768, 3072, "FC2 (bias, resid, f32 out)", "resid", (80, 128)),
     (3200, 768, 3072, "W1T dgrad (f32 out)", "f32", (80, 128)),
     (3200, 2304, 768, "QKV (bias, 16-bit out)", "bias16", (160, 192)),
@@ -35,7 +35,7 @@ shapes = [
     (3136, 768, 3072, "patch embed (f32 out)", "f32", (80, 128)),
     (1600, 3072, 768, "FC1 @32 cutouts", "fc1", (80, 128)),
     (1000, 200, 1152, "ragged M, N (bias, resid)", "resid", (80, 128)),
-    (333, 520, 256, "ragged M, N (bias16)", "bias16", (160, 256)),
+    (333, 520, 256, "ragged M, N (bias16)", "bias16", (160, 128)),
     (333, 520, 256, "ragged M, N (bias16) 160x192", "bias16", (160, 192)),
 ]
 
