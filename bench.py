@@ -311,14 +311,14 @@ def main():
             ms = max(raw_ms - ev_over_ms * n, 0.5 * raw_ms)
             achieved = flop / (ms * 1e-3) / 1e12
             gemm_gflop_step = flop / args.profile_steps / 1e9
-            kern = (f"gemm_glds_kernel<BM,BN,AMODE,STAGES,..> ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
+            kern = (f"GEMM engine: gemmfit_kernel<WGM,WGN,FM,FN,KS,CONV> + gemm_glds_kernel / gemm8p_kernel ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
                     if args.precision != "f32"
                     else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
             # HBM-side bytes per launch come from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
             # command, gfx950 FETCH correction applied): not measurable from inside this process, so `traffic` is null here
             # and the committed profile of the round is quoted next to it when there is one for this configuration
             pmc = None
-            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (3, 2))
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (4, 3, 2))
                              if os.path.exists(q)), "")
             if args.precision != "f32" and pmc_path:
                 with open(pmc_path) as f:

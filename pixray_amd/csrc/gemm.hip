@@ -901,7 +901,6 @@ GemmCtx::GemmCtx() {
     fit = env_int("PRX_GEMM_FIT", 1);
     fit_flags = env_int("PRX_FIT_FLAGS", 1);
     fit_conv = env_int("PRX_FIT_CONV", 1);
-    fit_reps = env_int("PRX_FIT_REPS", 1);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
 }
 
@@ -922,8 +921,8 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -6) { c->tile8p = splits; return; }        // (-6, x, n): 256 x 256 8-phase tiles from n tiles on (0 = never)
     if (bm == -7) { c->fit = splits; return; }           // (-7, x, on/off): fit tiles (gemmfit.hip)
     if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
+    if (bm == -12) { c->force_fit = splits; return; }    // (-12, x, on/off): a forced 128 x 128 / 128 x 64 / 64 x 64 / 256 x 128 tile means the fit kernel of that shape
     if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
-    if (bm == -10) { c->fit_reps = splits; return; }     // (-10, x, on/off): several tiles per workgroup where the planner has such a plan
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
@@ -1006,6 +1005,7 @@ static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
 }
 
 static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx, int use8p);
+static bool fourwave_tile(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64) || (bm == 256 && bn == 128); }
 
 int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K) {
     static const GemmCtx k_default;
@@ -1085,25 +1085,27 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
     // fit tiles (gemmfit.hip): one workgroup per CU when a tile grid matches the chip (M = 3200: 240 tiles; the decoder's
     // batch-1 convolutions: K split over the wave groups of a workgroup instead of over workgroups + a reduce launch)
-    int fit_reps = 1, fit_rep_m = 0;
+    // (three tile shapes -- 128 x 128, 128 x 64, 64 x 64 -- exist in BOTH kernel families: `fit_tile` says which one is meant)
+    bool fit_tile = false;
     if (cx.fit && !use8p && (d.a_mode == PRX_A_ROWMAJOR || cx.fit_conv)) {
         int fbm = 0, fbn = 0;
-        prx_gemmfit_plan(d, n_cu, cx.fit_reps, &fbm, &fbn, &fit_reps, &fit_rep_m);
-        if (fbm) { BM = fbm; BN = fbn; }
-        else { fit_reps = 1; fit_rep_m = 0; }
+        prx_gemmfit_plan(d, n_cu, &fbm, &fbn);
+        if (fbm) { BM = fbm; BN = fbn; fit_tile = true; }
     }
-    if (use8p) { BM = 256; BN = 256; }          // planned by plan_8phase (prx_gemm_launch)
-    if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; fit_reps = 1; fit_rep_m = 0; }
+    if (use8p) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)
+    // a forced tile selects the fit kernel when the override says so (cx.force_fit), or when only that family has the shape
+    if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; fit_tile = prx_gemmfit_tile(BM, BN, nullptr) && (cx.force_fit || !fourwave_tile(BM, BN)); }
     int rule_splits = 0;
     if (!cx.rules.empty()) {
         const int mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32;
         for (const GemmTileRule& r : cx.rules)
-            if (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode) { BM = r.bm; BN = r.bn; rule_splits = r.splits; fit_reps = 1; fit_rep_m = 0; }
+            if (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode) {
+                BM = r.bm; BN = r.bn; rule_splits = r.splits;
+                fit_tile = prx_gemmfit_tile(BM, BN, nullptr) && !fourwave_tile(BM, BN);
+            }
     }
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
-    bool fit_tile = prx_gemmfit_tile(BM, BN, nullptr);
-    if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { BM = 128; BN = 128; fit_tile = false; }
-    if (!fit_tile) { fit_reps = 1; fit_rep_m = 0; }
+    if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { fit_tile = false; if (!fourwave_tile(BM, BN)) { BM = 128; BN = 128; } }
     if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
     const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
@@ -1151,7 +1153,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && cx.use_glds,
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
-    a.reps = fit_tile ? fit_reps : 1; a.rep_m = fit_tile ? fit_rep_m : 0;
     a.fit_flags = fit_tile ? (cx.fit_flags & 15) : 0;   // gemmfit.hip A/B switches (PRX_FIT_FLAGS)
     if (fit_tile && (cx.fit_flags & 32) == 0 && d.N > d.M) a.fit_flags |= 16;      // weight-heavy: column-major tile order (bit 5 of the switch word turns it off)
     a.kt_per_split = ceil_div(a.kt_total, splits);
@@ -1170,12 +1171,11 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_CHECK_HIP(hipEventCreate(&rec.a));
         PRX_CHECK_HIP(hipEventCreate(&rec.b));
         rec.flop = 2.0 * d.M * d.N * d.K;
-        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32 + 8 * d.f32; rec.bm = BM; rec.bn = BN; rec.splits = splits;
+        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32 + 8 * d.f32; rec.bm = fit_tile ? BM + 1000 : BM; rec.bn = BN; rec.splits = splits;      // + 1000: the fit kernel of that tile shape
         PRX_CHECK_HIP(hipEventRecord(rec.a, stream));
     }
 
     dim3 grid(tiles, splits);
-    if (fit_tile && a.reps > 1) grid.x = a.rep_m ? ceil_div(a.tiles_m, a.reps) * a.tiles_n : a.tiles_m * ceil_div(a.tiles_n, a.reps);
     if (d.f32) {
         if (BM == 128 && BN == 128) launch_f32<128, 128>(a, grid, stream);
         else if (BM == 128 && BN == 64) launch_f32<128, 64>(a, grid, stream);

@@ -11,7 +11,6 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     int xcd_swizzle;
-    int reps, rep_m; // gemmfit.hip: tiles per workgroup (0 / 1: one) and their direction (0: along N, 1: along M)
     int fit_flags;   // gemmfit.hip: bit 0 = staggered wave groups; bits 2, 3 = timing experiments (no epilogue / no main loop); bit 4 = column-major tile order
     float* ws;
 };
@@ -181,5 +180,5 @@ void prx_gemm8p_launch(const prx_gemm_dev::GemmArgs& a, dim3 grid, hipStream_t s
 // K % (64 ks) == 0, 16-byte-friendly epilogue operands, no split-K across workgroups)
 bool prx_gemmfit_tile(int bm, int bn, int* ks);
 bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn);
-void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int allow_reps, int* bm, int* bn, int* reps, int* rep_m);   // *bm = 0: leave it to the 4-wave kernels
-int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (workgroups, 1); a.reps tiles per workgroup
+void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn);   // *bm = 0: leave it to the 4-wave kernels
+int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (tiles, 1)

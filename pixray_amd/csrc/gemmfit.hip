@@ -8,9 +8,8 @@
 // HBM; and the small tiles that do fill the chip move twice the L2->LDS bytes per flop (64 B/clk/CU on that path).  Here the
 // tile is chosen so that the grid is ~240 - 256 workgroups, and when that makes the tile small the K loop is split over the
 // wave groups of ONE workgroup (KS) and summed through LDS -- no workspace, no second launch:
-//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 128, two per workgroup (240 workgroups)   N = 2304 -> 160 x 192 (240)
-//                          N = 768 -> 80 x 128, KS 2 (240)
-//     decoder 256^2 level: 65 536 x 128 -> 128 x 128, two per workgroup (256)   128^2: 128 x 128 / 128 x 64 KS 2   64^2: 64 x 64 KS 2
+//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 256 (240 tiles)   N = 2304 -> 160 x 192 (240)   N = 768 -> 80 x 128, KS 2 (240)
+//     decoder 256^2 level: 65 536 x 128 -> 256 x 128 (256)      128^2: 128 x 128 / 128 x 64 KS 2     64^2: 64 x 64 KS 2
 //                  32^2:   32 x 64 KS 4 / 16 x 64 KS 4           16^2:  256 x 512 x 4608 -> 16 x 32, KS 8 (256 tiles)
 // The same tiles fit the sharded batches (32 / 16 / 8 cutouts: M = 1600 / 800 / 400 are multiples of 80).
 //
@@ -144,7 +143,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
     // slabs are handled FMC at a time: the prefetch of a chunk is (2 x 16 bytes + 1) registers per slab and pass on top of the
     // accumulators, and the wide wave tiles (16+ fragments) have no room for all of them at once
-    constexpr int FMC = FM * FN > 12 ? 2 : FM;
+    constexpr int FMC = FM * FN > 16 ? 3 : FM;
     float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
 #pragma unroll
     for (int i0 = 0; i0 < FM; i0 += FMC) {
@@ -287,18 +286,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // tile order: consecutive tiles (an XCD owns a contiguous range of them) share their A row panel (row-major order) or, for
     // weight-heavy problems (N > M: the decoder's 16^2 / 32^2 convolutions), their B column panel (bit 4: column-major order),
     // so that the larger operand is fetched into ONE L2 instead of all eight
-    // A workgroup handles `reps` consecutive tiles along N (rep_m = 0) or along M (rep_m = 1), one after the other: the stores of
-    // tile r drain from the L2 while tile r + 1 runs its K loop (a one-tile workgroup ends in an epilogue nothing overlaps:
-    // FC1 writes 39 MB, of which the 32 MB of L2 absorb about a quarter -- measured 14 of its 33 us), and the operand panel the
-    // tiles share is re-read from the L2 it already sits in.
-    const int reps = p.reps > 0 ? p.reps : 1;
-    const int gm = p.rep_m ? ceil_div_dev(p.tiles_m, reps) : p.tiles_m, gn = p.rep_m ? p.tiles_n : ceil_div_dev(p.tiles_n, reps);
-    int sm, sn;                                          // super-tile coordinates
-    if (p.fit_flags & 16) { sn = bid / gm; sm = bid - sn * gm; }
-    else                  { sm = bid / gn; sn = bid - sm * gn; }
-  for (int rep = 0; rep < reps; ++rep) {
-    const int tm = p.rep_m ? sm * reps + rep : sm, tn = p.rep_m ? sn : sn * reps + rep;
-    if (tm >= p.tiles_m || tn >= p.tiles_n) break;      // wave-uniform: a ragged last super-tile
+    int tm, tn;
+    if (p.fit_flags & 16) { tn = bid / p.tiles_m; tm = bid - tn * p.tiles_m; }
+    else                  { tm = bid / p.tiles_n; tn = bid - tm * p.tiles_n; }
 
     // ---- DMA coordinates: slot j of this wave moves piece min(wave + NW j, NP - 1) of every stage -----------------------
     const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
@@ -449,8 +439,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     }
     static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
     fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
-    if (rep + 1 < reps) __syncthreads();     // the epilogue's LDS scratch is the next tile's ring
-  }
 }
 
 template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
@@ -471,15 +459,8 @@ void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
 // the tile shapes this kernel exists in
 struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
 const FitTile kFitTiles[] = {
-    {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
+    {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
     {80, 128, 2, 32, 0.85}, {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
-};
-// plans the planner may pick: a tile, processed `reps` at a time along N (rep_m = 0) or M (rep_m = 1) by one workgroup
-struct FitPlan { int bm, bn, reps, rep_m; double eff; };
-const FitPlan kFitPlans[] = {
-    {160, 128, 2, 0, 1.04},      // N = 3072 at M = 3200 (FC1, W2^T dgrad): 240 workgroups x 2 tiles, the first tile's stores drain under the second
-    {80, 128, 3, 0, 0.90},       // N = 2304 (QKV): 240 workgroups x 3 tiles
-    {128, 128, 2, 1, 0.97},      // the decoder's 256^2 level (65 536 x 128): 256 workgroups x 2 row tiles
 };
 const FitTile* fit_tile(int bm, int bn) {
     for (const FitTile& t : kFitTiles)
@@ -522,35 +503,32 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
            (unsigned long long)d.N * d.ldb < (1ull << 31);
 }
 // planner: the fit tile (if any) whose grid fills the chip best; *bm = 0 when the 4-wave kernels should keep the problem.
-// reps / rep_m: tiles per workgroup and their direction (1, 0: one tile per workgroup)
-void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int allow_reps, int* bm, int* bn, int* reps, int* rep_m) {
-    *bm = *bn = 0; *reps = 1; *rep_m = 0;
+void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
+    *bm = *bn = 0;
     double best = 0.0;
-    auto consider = [&](int tbm, int tbn, int r, int rm, double eff) {
+    auto consider = [&](int tbm, int tbn, double eff) {
         if (d.N < tbn && !(tbn <= 64)) return;
         if (!prx_gemmfit_eligible(d, tbm, tbn)) return;
         const int tm_ = ceil_div(d.M, tbm), tn_ = ceil_div(d.N, tbn);
-        if (r > 1 && (rm ? tm_ : tn_) % r != 0) return;                    // whole super-tiles only
-        const int wgs = rm ? (tm_ / r) * tn_ : tm_ * (tn_ / r);
+        const int wgs = tm_ * tn_;
         if (wgs > 2 * n_cu) return;                                        // a one- or two-round kernel by construction
         const double fill = (double)wgs / ((double)ceil_div(wgs, n_cu) * n_cu);
         const double waste = ((double)tm_ * tbm / d.M) * ((double)tn_ * tbn / d.N);
         const double score = fill * eff / waste;
-        if (score > best && fill / waste >= 0.8) { best = score; *bm = tbm; *bn = tbn; *reps = r; *rep_m = rm; }
+        if (score > best && fill / waste >= 0.8) { best = score; *bm = tbm; *bn = tbn; }
     };
     // weight-heavy products with FEW output rows (a 16^2 / 8^2 / 4^2 map of the StyleLoss extractor, M = 16 ... 256 by 512 channels
     // over K = 4608): no tile grid fills the chip, but the smallest tile with 8 K groups per workgroup still streams the weight
     // matrix through 16 ... 256 workgroups in ~9 us where a 128 x 64 tile with split-K + reduce takes 22 - 47 (measured:
     // profiles/r04_small_m_streaming_vs_ring.txt) -- the fill rule below does not apply to them
     if ((long long)d.M * d.N <= 256ll * 512 && d.K >= 2048 && d.N >= 32 && prx_gemmfit_eligible(d, 16, 32)) { *bm = 16; *bn = 32; return; }
-    for (const FitTile& t : kFitTiles) consider(t.bm, t.bn, 1, 0, t.eff);
-    if (allow_reps)
-        for (const FitPlan& q : kFitPlans) consider(q.bm, q.bn, q.reps, q.rep_m, q.eff);
+    for (const FitTile& t : kFitTiles) consider(t.bm, t.bn, t.eff);
 }
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
     PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
-    if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
+    if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1, false>(a, grid, s, zp);
+    else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);
     else if (bm == 160 && bn == 128) launch_fit<2, 4, 5, 2, 1, false>(a, grid, s, zp);
     else if (bm == 128 && bn == 128) launch_fit<2, 4, 4, 2, 1>(a, grid, s, zp);

@@ -150,7 +150,7 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
-@pytest.mark.parametrize("tile", [(160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
+@pytest.mark.parametrize("tile", [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("stagger", [1, 0])
 def test_gemm_fit_tiles(tile, prec, stagger):
@@ -162,6 +162,7 @@ def test_gemm_fit_tiles(tile, prec, stagger):
     tol16 = 4e-3 if prec == "bf16" else 5e-4
     torch.manual_seed(11)
     try:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 1)        # the shapes both families have: the fit kernel
         lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, stagger)
         for (M, N, K) in [(3200, 768, 768), (1000, 200, 1152), (333, 520, 512), (81, 136, 1024), (160, 256, 1536)]:
@@ -215,10 +216,11 @@ def test_gemm_fit_tiles(tile, prec, stagger):
     finally:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
 
 
-FIT_TILES = [(160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
-FIT_KS = {(160, 128): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
+FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+FIT_KS = {(160, 256): 1, (160, 128): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
 
 
 @pytest.mark.parametrize("tile", FIT_TILES)
@@ -233,6 +235,7 @@ def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
     ks = FIT_KS[tile]
     ran = 0
     try:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 1)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), tile[0], tile[1], 1)
         for (H, W, Cin, Cout, up, NB) in [(32, 32, 128, 128, 1, 1), (24, 40, 64, 256, 0, 2), (16, 16, 512, 128, 0, 1), (16, 24, 256, 128, 1, 2)]:
             if (9 * Cin) % (64 * ks) or tile[0] % 80 == 0:           # K must split over the K groups; the 80-row-granular tiles are row-major only
@@ -295,6 +298,7 @@ def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
         assert ran or tile[0] % 80 == 0
     finally:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
 
 
 def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():

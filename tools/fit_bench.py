@@ -20,12 +20,13 @@ cold = len(sys.argv) > 1 and sys.argv[1] == "cold"
 ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
 lib = _lib.load()
 ctx = _lib.tool_ctx()
+lib.prx_gemm_tile_override(ctx, -12, 0, 1)      # forced tiles of the shapes both kernel families have mean the fit kernel
 h16 = torch.float16
 
 # (M, N, K, tag, epilogue, fit tile)
 shapes = [
-    (3200, 3072, 768, "FC1 (bias, QuickGELU, 2 x 16-bit out)", "fc1", (160, 128)),
-    (3200, 3072, 768, "W2T dgrad (dQuickGELU(aux), 16-bit out)", "dgelu", (160, 128)),
+    (3200, 3072, 768, "FC1 (bias, QuickGELU, 2 x 16-bit out)", "fc1", (160, 256)),
+    (3200, 3072, 768, "W2T dgrad (dQuickGELU(aux), 16-bit out)", "dgelu", (160, 256)),
     (3200, 768, 3072, "FC2 (bias, resid, f32 out)", "resid", (80, 128)),
     (3200, 768, 3072, "W1T dgrad (f32 out)", "f32", (80, 128)),
     (3200, 2304, 768, "QKV (bias, 16-bit out)", "bias16", (160, 192)),

@@ -48,8 +48,9 @@ for line in open(path):
     a[0] += 1; a[1] += float(us)
 print(f"total {ms.value / steps:.3f} ms/iter, {fl.value / steps / 1e9:.0f} GFLOP/iter, {n.value // steps} launches/iter, "
       f"{fl.value / ms.value / 1e9:.0f} TFLOP/s")
-print(f"{'M':>6} {'N':>5} {'K':>5} mode tile    sp  n/it  avg_us  ms/it   TF")
+print(f"{'M':>6} {'N':>5} {'K':>5} mode tile       sp  n/it  avg_us  ms/it   TF     (fit: gemmfit.hip, one workgroup per CU)")
 for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     M, N, K, mode, bm, bn, sp = key
     avg = us / cnt
-    print(f"{M:6d} {N:5d} {K:5d} {mode:4d} {bm:3d}x{bn:<3d} {sp:3d} {cnt / steps:5.1f} {avg:7.1f} {us / steps / 1e3:6.3f} {2.0 * M * N * K / avg / 1e6:5.0f}")
+    tile = f"fit{bm - 1000}x{bn}" if bm >= 1000 else f"{bm}x{bn}"
+    print(f"{M:6d} {N:5d} {K:5d} {mode:4d} {tile:<10s} {sp:3d} {cnt / steps:5.1f} {avg:7.1f} {us / steps / 1e3:6.3f} {2.0 * M * N * K / avg / 1e6:5.0f}")

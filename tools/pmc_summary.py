@@ -16,7 +16,7 @@ from collections import OrderedDict
 fetch_csv, write_csv, iters, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 
 FAMILIES = [
-    ("GEMM engine (gemm_glds_kernel / gemm8p_kernel / gemm_kernel / splitk_reduce, all shapes)", r"gemm_glds_kernel|gemm8p_kernel|gemm_kernel|gemm_f32_kernel|splitk_reduce"),
+    ("GEMM engine (gemmfit_kernel / gemm_glds_kernel / gemm8p_kernel / gemm_kernel / splitk_reduce, all shapes)", r"gemmfit_kernel|gemm_glds_kernel|gemm8p_kernel|gemm_kernel|gemm_f32_kernel|splitk_reduce"),
     ("GroupNorm kernels", r"gn_stats|gn_apply"),
     ("LayerNorm", r"ln_fwd|ln_bwd"),
     ("ViT attention", r"mha_"),
