@@ -233,7 +233,19 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     image -- one step later, so two free-running trajectories (even fp32 CPU vs fp32 CUDA of the reference itself)
     decorrelate within a few steps.  Parity is therefore checked TEACHER-FORCED: both sides start every step from the
     oracle's z (and, for the HIP optimiser, the oracle's Adam moments), the per-step dL/dz and the resulting z are
-    compared, and the free-running HIP loss curve is reported next to the oracle's for information."""
+    compared, and the free-running HIP loss curve is reported next to the oracle's for information.
+
+    The teacher forcing extends to the image.  The reference's dL/d(image) is not a continuous function of the image:
+    MakeCutouts' adaptive max pool (pixray.py:477) routes a window's gradient to its first maximum, and once the
+    optimiser has driven pixels onto the clamp bounds (ClampWithGrad, vqgan.py:188: exactly 0.0 / 1.0 -- ~3 % of the
+    image after two steps) whole windows tie, so a pixel that lands 1e-7 inside instead of on the bound re-routes gradient
+    spikes that carry most of |dL/d(image)| (measured with the ORACLE ALONE at the oracle's step-2 state: noise of 1e-6 on
+    the image changes its dL/d(image) by 0.55-0.63 rel-L2 and its dL/dz by up to 0.17).  Two correct implementations
+    whose images agree to rounding therefore disagree on dL/dz at such states by a tie, not by an error.  So every step
+    (a) gates the image itself (`image_rel_l2_max`), and (b) evaluates the oracle's cutouts -> CLIP -> loss gradient AT
+    THE HIP PATH'S IMAGE (same values, same ties) and chains it through the oracle's own decoder backward at the oracle's
+    z: dz_ref = J_decoder_ref(z)^T dL/d(image)_ref(image_hip).  Every stage of the HIP iteration is still compared with the
+    oracle's arithmetic; only the amplification of image rounding through the ties is taken out."""
     from pixray_amd import api
     sess = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr, precision=precision)
     free = _build_hip(vqgan_model, clip_model, size, cutn, seed, device, lr=lr, precision=precision)      # free-running copy
@@ -244,7 +256,15 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     opt = torch.optim.Adam([z_ref], lr=lr)
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
     prompts = prompt_list(clip_model, clip_cfg, seed)
-    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok = [], [], [], [], [], [], []
+    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok, img_rel = [], [], [], [], [], [], [], []
+    seen = {}
+    synth_and_filter = sess.do_synth_and_filter
+
+    def capture(result):
+        out, alpha = synth_and_filter(result)
+        seen["img"] = out.detach().float().cpu().clone()
+        return out, alpha
+    sess.do_synth_and_filter = capture
     for it in range(k):
         prm = _draws(cutn, S, seed, it, aspect=size[0] / size[1])
         mk.fixed_params = prm
@@ -266,8 +286,14 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         idx_ref, _ = vqgan_ref.vq_indices(z_ref.detach().movedim(1, 3).reshape(-1, z_ref.shape[1]),
                                           vq_params["quantize.embedding.weight"])
         opt.zero_grad()
-        losses, *_ = oracle_losses(vq_params, vq_cfg, clip_params, clip_cfg, z_ref, prm, prompts, S)
-        sum(losses).backward()
+        img_ref = vqgan_ref.synth(vq_params, z_ref, vq_cfg.oracle_cfg())
+        img_rel.append(_metrics(seen["img"], img_ref)[0])
+        img_in = seen["img"].clone().requires_grad_(True)
+        cut = cutouts_ref.make_cutouts(img_in, prm, S)
+        emb = clip_vit_ref.encode_image(clip_params, cut, patch=clip_cfg.patch_size, heads=clip_cfg.heads, layers=clip_cfg.layers)
+        losses = [prompt_ref.Prompt(e, w, s)(emb) for (e, w, s) in prompts]
+        g_img, = torch.autograd.grad(sum(losses), img_in)
+        z_ref.grad, = torch.autograd.grad(img_ref, z_ref, g_img)
         r, c = _metrics(dz_hip, z_ref.grad)
         dz_rel.append(r); dz_cos.append(c)
         idx_ok.append(float((idx_hip == idx_ref).float().mean()))
@@ -281,6 +307,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         free_idx_ok.append(float((free.drawer.handle.last_indices.cpu().long() == idx_ref).float().mean()))
     z_free = free.drawer.get_z().detach().cpu()
     return dict(steps=k, dz_rel_l2_max=max(dz_rel), dz_cosine_min=min(dz_cos), vq_index_agreement_min=min(idx_ok),
+                image_rel_l2_max=max(img_rel), dz_rel_l2=dz_rel,
                 z_after_step_max_abs_err=max(z_err), loss_oracle=loss_ref, loss_hip_free_running=loss_free,
                 # the FREE-RUNNING copy against the oracle's trajectory ("z after 10 Adam steps"): only
                 # meaningful while both sides still select the same codes at every step

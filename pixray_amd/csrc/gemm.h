@@ -76,7 +76,9 @@ struct GemmCtx {
     int tile8p = 128;            // > 0: 256 x 256 tiles on the 8-phase kernel (gemm8p.hip) are CONSIDERED from this many tiles on (PRX_GEMM_8P;
                                  // gemm.hip plan_8phase then decides by cost: full rounds of 256 tiles on it, the remainder rows on the 4-wave kernels)
     int fit_flags = 1;           // gemmfit.hip A/B switches: bit 0 staggered wave groups (PRX_FIT_FLAGS)
+    int n_cu = 0;                // compute units of the device this context launches on (0: not asked yet; planners then assume 256)
     int force_fit = 0;           // with force_bm: the tile shapes both kernel families have mean the fit kernel (tests, tools)
+    int dbg_only = -2, dbg_count = 0;   // bisection aid (override -13)
     int fit_conv = 1;            // ... for the implicit 3x3 convolutions as well (PRX_FIT_CONV)
     int fit = 1;                 // fit tiles (gemmfit.hip) when their grid fills the chip better (PRX_GEMM_FIT)
     std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic

@@ -923,6 +923,7 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
     if (bm == -12) { c->force_fit = splits; return; }    // (-12, x, on/off): a forced 128 x 128 / 128 x 64 / 64 x 64 / 256 x 128 tile means the fit kernel of that shape
     if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
+    if (bm == -13) { c->dbg_only = splits; c->dbg_count = 0; return; }   // (-13, x, i): bisection aid -- only the i-th fit convolution (-1: all, counting; -2: off)
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
 }
@@ -973,7 +974,7 @@ static Plan8p plan_8phase(const GemmDesc& d, const GemmCtx& cx) {
     if (cx.tile8p <= 0 || !prx_gemm8p_eligible(d)) return p;
     const int tm = ceil_div(d.M, 256), tn = ceil_div(d.N, 256), tiles = tm * tn;
     if (tiles < cx.tile8p) return p;
-    const int n_cu = 256;
+    const int n_cu = cx.n_cu > 0 ? cx.n_cu : 256;       // the launching context's device (256 on MI355X; the host-only planner query assumes it)
     const double t_round = 1.7 * (d.K / 64) + 11.0;                                    // us
     auto t_4wave = [&](int rows) { return rows <= 0 ? 0.0 : 2.0 * rows * (double)d.N * d.K / 650e6 + 8.0; };   // us
     const int rounds_all = ceil_div(tiles, n_cu);
@@ -1017,6 +1018,13 @@ int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K) {
 
 int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
     static const GemmCtx k_default;      // immutable: heuristics only
+    if (ctx && ctx->n_cu == 0) {         // the planners count tiles against THIS device's CUs (cost constants stay MI355X's)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            ctx->n_cu = cus;
+        else
+            ctx->n_cu = 256;
+    }
     const GemmCtx& cx = ctx ? *ctx : k_default;
     bool forced = cx.force_bm != 0;
     if (!forced && !cx.rules.empty()) {          // a per-shape rule overrides the plan for THAT shape only (in-pipeline sweeps)
@@ -1061,7 +1069,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
     // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the
     // per-tile efficiency (bigger wave tiles do more MFMA per LDS byte).
-    const int n_cu = 256;
+    const int n_cu = cx.n_cu > 0 ? cx.n_cu : 256;
     int BM = 128, BN = 128;
     auto ntiles = [&](int bm, int bn) { return ceil_div(d.M, bm) * ceil_div(d.N, bn); };
     {
@@ -1090,6 +1098,10 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     if (cx.fit && !use8p && (d.a_mode == PRX_A_ROWMAJOR || cx.fit_conv)) {
         int fbm = 0, fbn = 0;
         prx_gemmfit_plan(d, n_cu, &fbm, &fbn);
+        if (fbm && ctx && d.a_mode != PRX_A_ROWMAJOR && cx.dbg_only >= -1) {       // bisection aid: only the dbg_only-th fit convolution since the last reset
+            const int idx = ctx->dbg_count++;
+            if (cx.dbg_only >= 0 && idx != cx.dbg_only) fbm = 0;
+        }
         if (fbm) { BM = fbm; BN = fbn; fit_tile = true; }
     }
     if (use8p) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)

@@ -326,6 +326,19 @@ static int zero_if_padded(const PrxVqgan* v, void* buf, size_t rows, int P, hipS
     return 0;
 }
 
+
+// PRX_VQ_TRACE=1 (debugging aid): L2 norm of every stage's output, forward and backward, on stderr
+static void vq_trace(const char* tag, int i, const float* p, size_t n, hipStream_t s) {
+    static const bool on = getenv("PRX_VQ_TRACE") != nullptr;
+    if (!on || !p) return;
+    std::vector<float> h(n);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), p, n * sizeof(float), hipMemcpyDeviceToHost);
+    double q = 0, mx = 0;
+    for (float x : h) { q += (double)x * x; mx = fabs(x) > mx ? fabs(x) : mx; }
+    fprintf(stderr, "[vq] %s %2d n=%zu l2 %.9e max %.6e\n", tag, i, n, sqrt(q), mx);
+}
+
 static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) {
     if (v->f32) {
         d.f32 = 1; d.a_is_f32 = 0;
@@ -460,6 +473,9 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             sr = nx && nx->C == b.C && fusable(v, b.C);
             x = b.out; x_bf = b.out_bf;
         }
+        {   const int Pq = st.kind == 0 ? v->res[st.idx].rh * v->res[st.idx].rw : st.kind == 1 ? v->attn[st.idx].rh * v->attn[st.idx].rw : v->ups[st.idx].rh * v->ups[st.idx].rw;
+            const int Cq = st.kind == 0 ? v->res[st.idx].Cout : st.kind == 1 ? v->attn[st.idx].C : v->ups[st.idx].C;
+            vq_trace("fwd", si, x, (size_t)Pq * Cq, s); }
     }
     v->x_last = x;
     const int PH = v->H * v->W;
@@ -559,6 +575,9 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             if ((r = prx_upsample2x_bwd(t1.f, t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s, v->h16))) return r;
             std::swap(g, t2);
         }
+        {   const int Pq = st.kind == 0 ? v->res[st.idx].rh * v->res[st.idx].rw : st.kind == 1 ? v->attn[st.idx].rh * v->attn[st.idx].rw : v->ups[st.idx].rh * v->ups[st.idx].rw / 4;
+            const int Cq = st.kind == 0 ? v->res[st.idx].Cin : st.kind == 1 ? v->attn[st.idx].C : v->ups[st.idx].C;
+            vq_trace("bwd", si, g.f, (size_t)Pq * Cq, s); }
     }
     // conv_in, post_quant_conv, straight-through VQ (ReplaceGrad, vqgan.py:48-58)
     if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, v->w0, t1.f, s, v->dpq_bf))) return r;

@@ -111,6 +111,48 @@ def test_gemm_f32_A_and_epilogues(gemm_variant):
     assert rel_l2(out3, 0.5 * (bf(A32).float() @ Bt.float().T) + bm[:, None]) < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_gemm_8phase_kernel_ragged_edges_and_epilogues(prec):
+    """gemm8p_kernel (256 x 256 tiles, 8 waves, 8-phase main loop) forced on shapes whose M and N are NOT multiples of 256 (the
+    source-side clamp of rows >= M / columns >= N), K = 128 (a single loop body, the drain path only) up to K = 1536, both 16-bit
+    formats, with the fused epilogue (bias + residual, fp32 + 16-bit outputs; bias + QuickGELU with the pre-activation copy);
+    against an fp32 product of the same rounded operands"""
+    lib = _lib.load()
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    tol16 = 4e-3 if prec == "bf16" else 5e-4
+    torch.manual_seed(23)
+    try:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 256, 256, 1)
+        for (M, N, K) in [(300, 520, 256), (257, 255 + 1, 128), (1000, 264, 1536), (513, 768, 384)]:
+            A = torch.randn(M, K, device=DEV).to(dt)
+            Bt = (torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K)).to(dt)
+            bias = torch.randn(N, device=DEV)
+            resid = torch.randn(M, N, device=DEV)
+            prod = A.float() @ Bt.float().T
+            g = GemmArgs()
+            g.A = A.data_ptr(); g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+            g.alpha = 1.0; g.f32 = 0 if prec == "bf16" else 2
+            g.bias_n = bias.data_ptr(); g.resid = resid.data_ptr(); g.ldr = N
+            out = torch.full((M, N), float("nan"), device=DEV); g.out_f32 = out.data_ptr(); g.ldc_f32 = N
+            o16 = torch.full((M, N), float("nan"), device=DEV, dtype=dt); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = N
+            call("prx_k_gemm", g, None, 0, stream())
+            torch.cuda.synchronize()
+            ref = prod + bias + resid
+            assert rel_l2(out, ref) < 2e-5, (M, N, K, rel_l2(out, ref))
+            assert rel_l2(o16, ref) < tol16 and not torch.isnan(o16.float()).any()
+            g2 = GemmArgs()
+            g2.A = A.data_ptr(); g2.lda = K; g2.B = Bt.data_ptr(); g2.ldb = K; g2.M, g2.N, g2.K = M, N, K
+            g2.alpha = 1.0; g2.f32 = g.f32; g2.bias_n = bias.data_ptr(); g2.act = 1
+            u = torch.full((M, N), float("nan"), device=DEV, dtype=dt); g2.out_bf16 = u.data_ptr()
+            t = torch.full((M, N), float("nan"), device=DEV, dtype=dt); g2.out_bf16_pre = t.data_ptr(); g2.ldc_bf16 = N
+            call("prx_k_gemm", g2, None, 0, stream())
+            torch.cuda.synchronize()
+            pre = (prod + bias).to(dt).float()
+            assert rel_l2(t, pre) < tol16 and rel_l2(u, pre * torch.sigmoid(1.702 * pre)) < tol16
+    finally:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+
+
 @pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("stages", [2, 3, 4])
 @pytest.mark.parametrize("splits", [1, 3])
