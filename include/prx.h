@@ -241,6 +241,30 @@ int prx_hypercolumns_fwd(const float* const* feats, const int* channels, int n_l
 int prx_hypercolumns_bwd(float* const* g_feats, const int* channels, int n_layers, const long long* rows, const float* weights,
                          int n, const float* g_out, int ldo, prx_stream_t s);
 
+/* --- STROTSS distance arithmetic of the StyleLoss plugin (Losses/StyleLoss.py:225-293), csrc/strotss.hip.  All matrices fp32
+ * row-major on the device; the products G = X Y^T are the caller's (plain library GEMMs).
+ * xs / ys: the squared row norms `pairwise_distances_cos` / `_sq_l2` take (225-237), the caller's reductions.
+ * remd_fwd (`style_loss`, 272-293): G [n, m], xs [n], ys [m] -> stats = {max(rmean, cmean), rmean, cmean} where rmean / cmean are
+ *   the means of the row / column minima of M = 1 - (G / |x|) / |y| (+ sqrt(clamp(|x|^2 + |y|^2 - 2 G, 1e-5, 1e5) / d) when l2:
+ *   the 3-channel palette term); rowpack [n] / colpack [m]: {ordered value << 32 | position} of each minimum (ties: smallest
+ *   position), kept for the backward.
+ * remd_bwd: dX [n, d] = g_out[0] * d stats[0] / dX, visiting only the n + m selected pairs (X [n, d], Y [m, d]; Y takes no gradient:
+ *   it is the style image's), a row's pairs in chunks of 32 per workgroup, added in ascending column order (no floating-point
+ *   atomics).  d <= 4096; workspace: remd_bwd_workspace_bytes(n, m, d) bytes, 16-byte aligned.
+ * selfsim_fwd (`content_loss`, 246-265): out[0] = mean |D(X, X) - D(Y, Y)| from Gx = X X^T, Gy = Y Y^T [n, n]; partial: n doubles.
+ * selfsim_bwd: Sx / Sy [n, lds] = dL/dG + (dL/dG)^T of each product and cx / cy [n] such that dX = Sx X + cx (.) X (rows scaled),
+ *   dY = Sy Y + cy (.) Y. */
+long long prx_strotss_remd_bwd_workspace_bytes(int n, int m, int d);
+int prx_strotss_remd_fwd(const float* G, int ldg, const float* xs, const float* ys, int n, int m, int l2, int d,
+                         unsigned long long* rowpack, unsigned long long* colpack, float* stats, prx_stream_t s);
+int prx_strotss_remd_bwd(const float* G, int ldg, const float* X, int ldx, const float* Y, int ldy, int d, const float* xs, const float* ys,
+                         const unsigned long long* rowpack, const unsigned long long* colpack, int n, int m, int l2, const float* stats,
+                         const float* g_out, void* workspace, long long workspace_bytes, float* dX, int lddx, prx_stream_t s);
+int prx_strotss_selfsim_fwd(const float* Gx, int ldgx, const float* xs, const float* Gy, int ldgy, const float* ys, int n,
+                            double* partial, float* out, prx_stream_t s);
+int prx_strotss_selfsim_bwd(const float* Gx, int ldgx, const float* xs, const float* Gy, int ldgy, const float* ys, int n,
+                            const float* g_out, float* Sx, float* Sy, int lds, float* cx, float* cy, prx_stream_t s);
+
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
  * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
  *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination

@@ -628,6 +628,97 @@ def hypercolumns(feats, rows, wts):
     return _HypercolumnsFn.apply(rows, wts, *[f.contiguous() for f in feats])
 
 
+def _f32c(t, what):
+    _need_cuda(t)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise PrxError(f"{what}: expected a 2-D fp32 device tensor, got {tuple(t.shape)} {t.dtype}")
+    return t.contiguous()
+
+
+def _row_sumsq(X):
+    """|x_i|^2 as `pairwise_distances_cos` takes it ((x ** 2).sum(1), Losses/StyleLoss.py:227): the same reduction, so that the
+    distance matrix -- and with it every arg-minimum -- is bit for bit the composed expression's"""
+    return (X * X).sum(1)
+
+
+class _RemdFn(torch.autograd.Function):
+    """`style_loss` (Losses/StyleLoss.py:272-293) on columns X [n, d] (differentiated) and Y [m, d] (the style image's: no
+    gradient): max of the mean row minimum and the mean column minimum of the cosine (+ L2 when `l2`) distance matrix.  The
+    product X Y^T is a library GEMM; the distance / minima pass and the backward over the n + m selected pairs are
+    csrc/strotss.hip.  `ys`: |y_j|^2, the caller's (the same style columns serve three evaluations)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, ys, l2):
+        X, Y = _f32c(X, "strotss_remd X"), _f32c(Y, "strotss_remd Y")
+        n, d = int(X.shape[0]), int(X.shape[1])
+        m = int(Y.shape[0])
+        if int(Y.shape[1]) != d or tuple(ys.shape) != (m,):
+            raise PrxError(f"strotss_remd: X {tuple(X.shape)}, Y {tuple(Y.shape)}, ys {tuple(ys.shape)} do not match")
+        G = torch.mm(X, Y.t())
+        xs = _row_sumsq(X)
+        packs = torch.empty(n + m, dtype=torch.int64, device=X.device)
+        stats = torch.empty(4, dtype=torch.float32, device=X.device)
+        call("prx_strotss_remd_fwd", G, m, xs, ys, n, m, int(bool(l2)), d, packs, packs[n:], stats, _stream())
+        ctx.save_for_backward(G, X, Y, xs, ys, packs, stats)
+        ctx.l2 = int(bool(l2))
+        return stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        G, X, Y, xs, ys, packs, stats = ctx.saved_tensors
+        n, d, m = int(X.shape[0]), int(X.shape[1]), int(Y.shape[0])
+        g = g.to(torch.float32).reshape(1).contiguous()
+        dX = torch.empty_like(X)
+        nbytes = int(_lib.load().prx_strotss_remd_bwd_workspace_bytes(n, m, d))
+        work = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+        call("prx_strotss_remd_bwd", G, m, X, d, Y, d, d, xs, ys, packs, packs[n:], n, m, ctx.l2, stats, g, work, nbytes, dX, d, _stream())
+        return dX, None, None, None
+
+
+def strotss_remd(X, Y, ys=None, l2=False):
+    if Y.requires_grad:
+        raise PrxError("strotss_remd: the style columns take no gradient")
+    if ys is None:
+        ys = _row_sumsq(Y.detach())
+    return _RemdFn.apply(X, Y, ys, l2)
+
+
+class _SelfSimFn(torch.autograd.Function):
+    """`content_loss` (Losses/StyleLoss.py:246-265): mean |cosine self-distance matrix of X - that of Y|, both [n, d] and both
+    differentiated.  Products: library GEMMs; the distance passes: csrc/strotss.hip (the backward returns the symmetrised
+    d/dG, so each operand costs one product)."""
+
+    @staticmethod
+    def forward(ctx, X, Y):
+        X, Y = _f32c(X, "strotss_selfsim X"), _f32c(Y, "strotss_selfsim Y")
+        if X.shape != Y.shape:
+            raise PrxError(f"strotss_selfsim: X {tuple(X.shape)} and Y {tuple(Y.shape)} differ")
+        n = int(X.shape[0])
+        Gx, Gy = torch.mm(X, X.t()), torch.mm(Y, Y.t())
+        xs, ys = _row_sumsq(X), _row_sumsq(Y)
+        partial = torch.empty(n, dtype=torch.float64, device=X.device)
+        out = torch.empty(1, dtype=torch.float32, device=X.device)
+        call("prx_strotss_selfsim_fwd", Gx, n, xs, Gy, n, ys, n, partial, out, _stream())
+        ctx.save_for_backward(Gx, Gy, xs, ys, X, Y)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        Gx, Gy, xs, ys, X, Y = ctx.saved_tensors
+        n = int(X.shape[0])
+        g = g.to(torch.float32).reshape(1).contiguous()
+        S = torch.empty(2, n, n, dtype=torch.float32, device=X.device)
+        c = torch.empty(2, n, dtype=torch.float32, device=X.device)
+        call("prx_strotss_selfsim_bwd", Gx, n, xs, Gy, n, ys, n, g, S[0], S[1], n, c[0], c[1], _stream())
+        dX = torch.addcmul(torch.mm(S[0], X), X, c[0].unsqueeze(1)) if ctx.needs_input_grad[0] else None
+        dY = torch.addcmul(torch.mm(S[1], Y), Y, c[1].unsqueeze(1)) if ctx.needs_input_grad[1] else None
+        return dX, dY
+
+
+def strotss_selfsim(X, Y):
+    return _SelfSimFn.apply(X, Y)
+
+
 def vgg16_features(x, handle: Vgg16Handle):
     """x [1,3,H,W] (already normalised for VGG) -> the nine captured feature maps as NHWC fp32 tensors [1,h,w,C]
     (channels-last is the engine's layout; `f.permute(0,3,1,2)` is the reference's NCHW view)."""

@@ -346,48 +346,98 @@ def _columns(t):
 
 
 def _self_similarity_loss(a, b):
-    """`content_loss` (StyleLoss.py:246-265): mean |cosine self-distance matrix of a - that of b|, coordinates dropped"""
+    """`content_loss` (StyleLoss.py:246-265): mean |cosine self-distance matrix of a - that of b|, coordinates dropped.
+    Device tensors: two library products + one pass over both (csrc/strotss.hip) instead of the composed chain below, which
+    stays the CPU form (what tests/test_style_loss.py pins to the reference's goldens and the kernel test compares with)."""
     X = _columns(a)[:, :-2]
     Y = _columns(b)[:, :-2]
+    if X.is_cuda:
+        from . import ops
+        return ops.strotss_selfsim(X, Y)
+    return _selfsim_composed(X, Y)
+
+
+def _selfsim_composed(X, Y):
+    """the reference's expression on columns (StyleLoss.py:257-265)"""
     return torch.abs(_cos_dist(X, X) - _cos_dist(Y, Y)).mean()
 
 
 _YUV = ((0.577350, 0.577350, 0.577350), (-0.577350, 0.788675, -0.211325), (-0.577350, -0.211325, 0.788675))
 
 
-def _remd(a, b):
+class StyleStats:
+    """what `calculate_loss` (StyleLoss.py:325-347) derives from the style columns alone -- the same 5000 columns serve the
+    three evaluations of a scale, the reference recomputes all of it each time: the YUV palette columns, the squared norms of
+    both, the mean and the covariance (a 47 GFLOP product at 2179 channels).  Values are what the composed expressions give."""
+
+    def __init__(self, sty):
+        Y = _columns(sty)                                             # [m, 2179]
+        self.Y = Y.contiguous()
+        C = _const("yuv", _YUV, Y.device).to(Y.dtype)
+        self.Y3 = torch.mm(C, Y[:, :3].t()).t().contiguous()
+        self.mu = Y.mean(0, keepdim=True)
+        Yc = Y - self.mu
+        self.cov = torch.mm(Yc.t(), Yc) / (Y.shape[0] - 1)
+        self.ys, self.ys3 = (self.Y ** 2).sum(1), (self.Y3 ** 2).sum(1)
+
+
+def _remd(a, b, stats: "StyleStats" = None):
     """`style_loss` (StyleLoss.py:272-293): relaxed EMD = max of the two mean nearest-neighbour distances; 3-channel
-    inputs are compared in a YUV-like space with cosine + L2 distance"""
+    inputs are compared in a YUV-like space with cosine + L2 distance.  Device tensors: one library product, one distance /
+    minima pass, and a backward over the n + m selected pairs (csrc/strotss.hip) -- the composed form below differentiates
+    through a dense [n, m] gradient matrix that has one non-zero per row and per column."""
     d = a.shape[1]
     X, Y = _columns(a), _columns(b)
+    if X.is_cuda:
+        from . import ops
+        if d == 3:
+            C = _const("yuv", _YUV, X.device).to(X.dtype)
+            X = torch.mm(C, X.t()).t()
+            if stats is not None:
+                return ops.strotss_remd(X, stats.Y3, stats.ys3, l2=True)
+            return ops.strotss_remd(X, torch.mm(C, Y.t()).t(), l2=True)
+        if stats is not None and d == stats.Y.shape[1]:
+            return ops.strotss_remd(X, stats.Y, stats.ys)
+        return ops.strotss_remd(X, Y)
     if d == 3:
         C = _const("yuv", _YUV, X.device).to(X.dtype)
         X, Y = torch.mm(C, X.t()).t(), torch.mm(C, Y.t()).t()
+    return _remd_composed(X, Y, d == 3)
+
+
+def _remd_composed(X, Y, l2: bool):
+    """the reference's expression on columns X [n, d], Y [m, d] (StyleLoss.py:283-291)"""
     M = _cos_dist(X, Y)
-    if d == 3:
+    if l2:
         M = M + _l2_dist(X, Y)
     return torch.max(M.min(1)[0].mean(), M.min(0)[0].mean())
 
 
-def _moment_loss(a, b):
+def _moment_loss(a, b, stats: "StyleStats" = None):
     """`moment_loss` with moments [1, 2] (StyleLoss.py:295-323): mean |difference of means| + mean |difference of covariances|"""
-    X, Y = _columns(a), _columns(b)
-    mu_x, mu_y = X.mean(0, keepdim=True), Y.mean(0, keepdim=True)
-    loss = torch.abs(mu_x - mu_y).mean()
-    Xc, Yc = X - mu_x, Y - mu_y
+    X = _columns(a)
+    mu_x = X.mean(0, keepdim=True)
+    Xc = X - mu_x
     cov_x = torch.mm(Xc.t(), Xc) / (X.shape[0] - 1)
-    cov_y = torch.mm(Yc.t(), Yc) / (Y.shape[0] - 1)
-    return loss + torch.abs(cov_x - cov_y).mean()
+    if stats is not None:
+        mu_y, cov_y = stats.mu, stats.cov
+    else:
+        Y = _columns(b)
+        mu_y = Y.mean(0, keepdim=True)
+        Yc = Y - mu_y
+        cov_y = torch.mm(Yc.t(), Yc) / (Y.shape[0] - 1)
+    return torch.abs(mu_x - mu_y).mean() + torch.abs(cov_x - cov_y).mean()
 
 
-def _pair_loss(feat_result, feat_content, feat_style, rows_d, wts_d, content_weight, moment_weight=1.0):
-    """`calculate_loss` (StyleLoss.py:325-347) at the tabulated 1024 positions"""
+def _pair_loss(feat_result, feat_content, feat_style, rows_d, wts_d, content_weight, moment_weight=1.0, stats: "StyleStats" = None):
+    """`calculate_loss` (StyleLoss.py:325-347) at the tabulated 1024 positions; `stats`: the style-only quantities of
+    `feat_style`, when the caller evaluates the same style columns more than once"""
     res, con = _bilinear_columns_dev(feat_result, feat_content, rows_d, wts_d)
     loss_content = _self_similarity_loss(res, con)
     sty = feat_style.view(1, feat_style.shape[1], -1, 1)
-    loss_remd = _remd(res[:, :N_FEATURE_CHANNELS], sty[:, :N_FEATURE_CHANNELS])
-    loss_moment = _moment_loss(res[:, :-2], sty)
-    loss_moment = loss_moment + (1. / max(content_weight, 1.)) * _remd(res[:, :3], sty[:, :3])
+    loss_remd = _remd(res[:, :N_FEATURE_CHANNELS], sty[:, :N_FEATURE_CHANNELS], stats)
+    loss_moment = _moment_loss(res[:, :-2], sty, stats)
+    loss_moment = loss_moment + (1. / max(content_weight, 1.)) * _remd(res[:, :3], sty[:, :3], stats)
     loss_style = loss_remd + moment_weight * loss_moment
     return (content_weight * loss_content + loss_style) / (content_weight + 1.0 + moment_weight)
 
@@ -421,10 +471,14 @@ def _scale_loss(result, content, style, content_weight, lr, extractor, draws: Sc
         with torch.no_grad():
             feat_style = _gather_hypercolumns(style_maps, draws.style_rows)
     total = 0.0
+    stats = None
+    if not recompute:
+        with torch.no_grad():
+            stats = StyleStats(feat_style.view(1, feat_style.shape[1], -1, 1))
     for it in range(EVALUATIONS):
         stylized = _fold_pyramid(pyramid)
         rows_d, wts_d = draws.pairs[it]
-        total = total + _pair_loss(extractor(stylized), feat_content, feat_style, rows_d, wts_d, content_weight) * lr
+        total = total + _pair_loss(extractor(stylized), feat_content, feat_style, rows_d, wts_d, content_weight, stats=stats) * lr
     return total
 
 

@@ -599,6 +599,56 @@ def test_mha_general_fwd_bwd(N, T, qs):
         assert e < 1.5e-2, (nm, e)
 
 
+@pytest.mark.parametrize("n,m", [(300, 777), (640, 200), (1024, 5000)])
+@pytest.mark.parametrize("l2", [False, True])
+def test_strotss_relaxed_emd_kernels_match_the_composed_torch_expression(n, m, l2):
+    """csrc/strotss.hip against the plugin's own chain (Losses/StyleLoss.py:272-293) on the device: value, and the gradient
+    over the n + m selected pairs against autograd through the dense distance matrix.  n < m: the column branch of the max
+    carries the gradient; n > m: the row branch.  l2: the 3-channel palette form (cosine + L2)."""
+    from pixray_amd import ops, style_loss as sl
+    g = torch.Generator(device=DEV).manual_seed(100 * n + m + l2)
+    d = 3 if l2 else 515
+    X = (torch.randn(n, d, device=DEV, generator=g).abs() + 0.05 * torch.randn(n, d, device=DEV, generator=g))
+    Y = (torch.randn(m, d, device=DEV, generator=g).abs() + 0.05 * torch.randn(m, d, device=DEV, generator=g))
+    # hubs, as real feature columns have them: half of the style columns sit next to one of five rows of X, so those rows collect
+    # ~m / 10 column minima each -- several 32-pair chunks of the backward, reduced in order
+    hub = torch.arange(0, m, 2, device=DEV)
+    Y[hub] = X[hub % 5] * (1.0 + 0.1 * torch.rand(hub.numel(), 1, device=DEV, generator=g)) + 0.01 * torch.randn(hub.numel(), d, device=DEV, generator=g)
+    Xa = X.clone().requires_grad_(True)
+    va = sl._remd_composed(Xa, Y, l2)
+    (va * 1.7).backward()
+    Xb = X.clone().requires_grad_(True)
+    vb = ops.strotss_remd(Xb, Y, l2=l2)
+    (vb * 1.7).backward()
+    assert abs(float(va.detach()) - float(vb.detach())) <= 2e-6 * abs(float(va.detach())), (float(va.detach()), float(vb.detach()))
+    rel = float((Xb.grad - Xa.grad).norm() / Xa.grad.norm())
+    assert rel < 2e-5, rel
+    assert int((Xa.grad.abs().sum(1) > 0).sum()) == int((Xb.grad.abs().sum(1) > 0).sum())      # the same rows are selected
+    # reproducible: packed {value, position} minima, a fixed pair order, no floating-point atomics
+    Xc = X.clone().requires_grad_(True)
+    (ops.strotss_remd(Xc, Y, l2=l2) * 1.7).backward()
+    assert torch.equal(Xc.grad, Xb.grad)
+
+
+def test_strotss_self_similarity_kernels_match_the_composed_torch_expression():
+    """`content_loss` (Losses/StyleLoss.py:246-265): both operands are differentiated"""
+    from pixray_amd import ops, style_loss as sl
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for n, d in ((257, 130), (1024, 2179)):
+        X = torch.randn(n, d, device=DEV, generator=g).abs()
+        Y = (X + 0.3 * torch.randn(n, d, device=DEV, generator=g)).abs()
+        Xa, Ya = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+        va = sl._selfsim_composed(Xa, Ya)
+        (va * 0.6).backward()
+        Xb, Yb = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+        vb = ops.strotss_selfsim(Xb, Yb)
+        (vb * 0.6).backward()
+        assert abs(float(va.detach()) - float(vb.detach())) <= 2e-6 * abs(float(va.detach())), (float(va.detach()), float(vb.detach()))
+        for a, b in ((Xa.grad, Xb.grad), (Ya.grad, Yb.grad)):
+            rel = float((b - a).norm() / a.norm())
+            assert rel < 5e-5, (n, d, rel)
+
+
 def test_hypercolumns_match_the_composed_torch_expression():
     """StyleLoss `spatial_feature_extract` (Losses/StyleLoss.py:169-223) in one gather launch: the CUDA branch of
     style_loss._bilinear_columns against its own composed torch branch (what runs on CPU tensors and is pinned to the
