@@ -236,8 +236,8 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     compared, and the free-running HIP loss curve is reported next to the oracle's for information.
 
     The teacher forcing extends to the image.  The reference's dL/d(image) is not a continuous function of the image:
-    MakeCutouts' adaptive max pool (pixray.py:477) routes a window's gradient to its first maximum, and once the
-    optimiser has driven pixels onto the clamp bounds (ClampWithGrad, vqgan.py:188: exactly 0.0 / 1.0 -- ~3 % of the
+    MakeCutouts' adaptive max pool (pixray.py:443,463) routes a window's gradient to its first maximum, and once the
+    optimiser has driven pixels onto the clamp bounds (clamp_with_grad, vqgan.py:195: exactly 0.0 / 1.0 -- ~3 % of the
     image after two steps) whole windows tie, so a pixel that lands 1e-7 inside instead of on the bound re-routes gradient
     spikes that carry most of |dL/d(image)| (measured with the ORACLE ALONE at the oracle's step-2 state: noise of 1e-6 on
     the image changes its dL/d(image) by 0.55-0.63 rel-L2 and its dL/dz by up to 0.17).  Two correct implementations
