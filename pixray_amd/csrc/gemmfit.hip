@@ -290,6 +290,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     if (p.fit_flags & 16) { tn = bid / p.tiles_m; tm = bid - tn * p.tiles_m; }
     else                  { tm = bid / p.tiles_n; tn = bid - tm * p.tiles_n; }
 
+    // K is cut into KS contiguous ranges, one per K group (group g: K tiles [g nkg, (g + 1) nkg)): consecutive stages of a group
+    // walk consecutive K tiles, so an implicit convolution changes its tap only every Cin / 64 stages
+    const int nkg = p.kt_total / KS;
     // ---- DMA coordinates: slot j of this wave moves piece min(wave + NW j, NP - 1) of every stage -----------------------
     const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
     const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
@@ -302,6 +305,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // (with the fused nearest-2x upsample neighbouring taps can share a source column)
     int c_r1[CONV ? PW : 1], c_rd[CONV ? PW : 1], c_c1[CONV ? PW : 1], c_ok[CONV ? PW : 1];
     int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
+    int s_cur[CONV ? PW : 1];                             // wave-uniform: the tap c_off was computed for (-1: none yet)
+    int c_off[CONV ? PW : 1];                             // per lane: element offset of the tap's source pixel + the lane's chunk, < 0: padding
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         int pc = wave + NW * j;
@@ -333,35 +338,40 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                 c_ok[j] = okm;
                 c_r1[j] = ro[1]; c_rd[j] = ((ro[0] - ro[1]) & 0xffff) | ((ro[2] - ro[1]) << 16);
                 c_c1[j] = co[1];
-                s_tap[j] = (sub * FIT_BK) / d.Cin;
-                s_c0[j] = sub * FIT_BK - s_tap[j] * d.Cin;
+                s_tap[j] = (sub * nkg * FIT_BK) / d.Cin;
+                s_c0[j] = sub * nkg * FIT_BK - s_tap[j] * d.Cin;
+                s_cur[j] = -1; c_off[j] = -1;
             } else {
                 const int gc = g < d.M ? g : d.M - 1;
-                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * FIT_BK + chunk * 8);
+                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
             }
         } else {
             int g = tn * BN + r;
             g = g < d.N ? g : d.N - 1;
-            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * FIT_BK + chunk * 8);
-            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; }
+            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
+            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; s_cur[j] = -1; c_off[j] = -1; }
         }
     }
     // stages are issued in K order, exactly once each
     auto issue = [&](int it, int stage) {
-        const size_t kel = (size_t)it * (FIT_BK * KS);
+        const size_t kel = (size_t)it * FIT_BK;
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             const bf16_t* src;
             if (CONV && pieceA[j]) {
                 const int tap = s_tap[j];
-                const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - 3 * ky;
-                const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
-                const int ro = c_r1[j] + (my0 & ((c_rd[j] << 16) >> 16)) + (my2 & (c_rd[j] >> 16));
-                const int co = c_c1[j] - (mx0 & ((c_ok[j] >> 6) & 1)) + (mx2 & ((c_ok[j] >> 7) & 1));
-                const bool ok = ((c_ok[j] >> ky) & (c_ok[j] >> (3 + kx)) & 1) != 0;
-                src = ok ? Ap + (long long)(ro + co) * d.lda + (s_c0[j] + (int)voff[j]) : zero_page;
-                s_c0[j] += FIT_BK * KS;
-                while (s_c0[j] >= d.Cin) { s_c0[j] -= d.Cin; ++s_tap[j]; }
+                if (tap != s_cur[j]) {                       // wave-uniform: a new tap every Cin / 64 stages
+                    const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - 3 * ky;
+                    const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
+                    const int ro = c_r1[j] + (my0 & ((c_rd[j] << 16) >> 16)) + (my2 & (c_rd[j] >> 16));
+                    const int co = c_c1[j] - (mx0 & ((c_ok[j] >> 6) & 1)) + (mx2 & ((c_ok[j] >> 7) & 1));
+                    const bool ok = ((c_ok[j] >> ky) & (c_ok[j] >> (3 + kx)) & 1) != 0;
+                    c_off[j] = ok ? (ro + co) * d.lda + (int)voff[j] : -1;      // M * lda < 2^31 (eligibility)
+                    s_cur[j] = tap;
+                }
+                src = c_off[j] >= 0 ? Ap + (size_t)(unsigned)(c_off[j] + s_c0[j]) : zero_page;
+                s_c0[j] += FIT_BK;
+                if (s_c0[j] >= d.Cin) { s_c0[j] -= d.Cin; ++s_tap[j]; }
             } else {
                 src = (pieceA[j] ? Ap : Bp) + kel + voff[j];
             }
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // while all eight issue; staggered, one wave of a SIMD computes while the other issues.  The late group's pieces of
     // stage T + 2 are issued after every wave passed barrier T (stage T - 1 was read before it: WAR), and are waited for by
     // the same counted wait in front of barrier T + 2.
-    const int nk = (p.fit_flags & 8) ? 0 : p.kt_total / KS;      // bit 3 (timing experiments only): no main loop
+    const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
     const bool late = (p.fit_flags & 1) && wave >= NW / 2;
     if (0 < nk) issue(0, 0);
     if (1 < nk) issue(1, 1);
