@@ -104,46 +104,60 @@ __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restric
     if (lane == 0) out[i] = ss;
 }
 
+// 64 tokens x 128 codes per workgroup, 4 tokens x 8 codes per thread on packed fp32 FMAs (v_pk_fma_f32: two codes per lane and
+// instruction); every (token, code) product is still ONE chain of fused multiply-adds over k = 0 .. D - 1, so distances -- and the
+// selected codes -- are bit for bit those of the scalar formulation this replaces (91 -> see profiles; fp32 VALU bound).
+typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int VQ_CODES = 128, VQ_CPAD = VQ_CODES + 4;
 __global__ __launch_bounds__(256) void vq_dist_kernel(const float* __restrict__ z, long long tok_stride,
                                                       long long ch_stride, const float* __restrict__ codebook,
                                                       const float* __restrict__ cnorm, int P, int NC, int D,
                                                       float* __restrict__ pmin, int* __restrict__ pidx) {
-    __shared__ float Xs[16][64 + 1];
-    __shared__ float Cs[16][64 + 1];
+    __shared__ __attribute__((aligned(16))) float Xs[16][64];
+    __shared__ __attribute__((aligned(16))) float Cs[16][VQ_CPAD];
     __shared__ float red_v[64][16];
     __shared__ int red_i[64][16];
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;   // tx: code quad, ty: token quad
-    const int p0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    float acc[4][4];
+    const int tx = tid & 15, ty = tid >> 4;   // tx: code quads tx and 16 + tx of the tile, ty: token quad
+    const int p0 = blockIdx.y * 64, c0 = blockIdx.x * VQ_CODES;
+    vq_f32x2 acc[4][4];                       // [token][code pair]: codes tx*4 + {0,1}, {2,3}, 64 + tx*4 + {0,1}, {2,3}
     float xn[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = vq_f32x2{0.f, 0.f};
     for (int k0 = 0; k0 < D; k0 += 16) {
-        // load 64 tokens x 16 k and 64 codes x 16 k
+        // 64 tokens x 16 k (strided source: NCHW or NHWC) and 128 codes x 16 k (rows of the codebook: k contiguous, 16-byte loads)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int e = tid + 256 * r;           // 0..1023
-            int kk = e >> 6, t = e & 63;     // tokens contiguous in NCHW (stride 1 along p)
-            int p = p0 + t;
+            const int e = tid + 256 * r;     // 0..1023
+            const int kk = e >> 6, t = e & 63;
+            const int p = p0 + t;
             Xs[kk][t] = (p < P) ? z[(long long)(k0 + kk) * ch_stride + (long long)p * tok_stride] : 0.f;
-            int cc = e >> 4, kc = e & 15;    // codebook row-major: k contiguous
-            int c = c0 + cc;
-            Cs[kc][cc] = (c < NC) ? codebook[(size_t)c * D + k0 + kc] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = tid + 256 * r;     // 0..511
+            const int cc = e >> 2, q = e & 3;
+            const int c = c0 + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < NC) v = *reinterpret_cast<const float4*>(codebook + (size_t)c * D + k0 + 4 * q);
+            Cs[4 * q + 0][cc] = v.x; Cs[4 * q + 1][cc] = v.y; Cs[4 * q + 2][cc] = v.z; Cs[4 * q + 3][cc] = v.w;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            float xa[4], cb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; cb[i] = Cs[kk][tx * 4 + i]; }
+            const float4 xa = *reinterpret_cast<const float4*>(&Xs[kk][ty * 4]);
+            const float4 ca = *reinterpret_cast<const float4*>(&Cs[kk][tx * 4]);
+            const float4 cb = *reinterpret_cast<const float4*>(&Cs[kk][64 + tx * 4]);
+            const vq_f32x2 cp[4] = {vq_f32x2{ca.x, ca.y}, vq_f32x2{ca.z, ca.w}, vq_f32x2{cb.x, cb.y}, vq_f32x2{cb.z, cb.w}};
+            const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                xn[i] = fmaf(xa[i], xa[i], xn[i]);
+                xn[i] = fmaf(xv[i], xv[i], xn[i]);
+                const vq_f32x2 xx = vq_f32x2{xv[i], xv[i]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xa[i], cb[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_elementwise_fma(xx, cp[j], acc[i][j]);
             }
         }
         __syncthreads();
@@ -152,10 +166,11 @@ __global__ __launch_bounds__(256) void vq_dist_kernel(const float* __restrict__ 
     for (int i = 0; i < 4; ++i) {
         float best = INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = c0 + tx * 4 + j;
+        for (int j = 0; j < 8; ++j) {          // ascending code index: the first minimum wins
+            const int c = c0 + (j < 4 ? tx * 4 + j : 64 + tx * 4 + (j - 4));
             if (c < NC) {
-                float d = (xn[i] + cnorm[c]) - 2.f * acc[i][j];
+                const float a = (j & 1) ? acc[i][j >> 1].y : acc[i][j >> 1].x;
+                float d = (xn[i] + cnorm[c]) - 2.f * a;
                 if (d < best) { best = d; bi = c; }
             }
         }
@@ -165,8 +180,10 @@ __global__ __launch_bounds__(256) void vq_dist_kernel(const float* __restrict__ 
     __syncthreads();
     if (tid < 64) {
         float best = red_v[tid][0]; int bi = red_i[tid][0];
-        for (int j = 1; j < 16; ++j)
-            if (red_v[tid][j] < best) { best = red_v[tid][j]; bi = red_i[tid][j]; }
+        for (int j = 1; j < 16; ++j) {         // a thread's codes are not contiguous: ties go to the smaller index explicitly
+            const float v = red_v[tid][j]; const int id = red_i[tid][j];
+            if (v < best || (v == best && id < bi)) { best = v; bi = id; }
+        }
         int p = p0 + tid;
         if (p < P) { pmin[(size_t)p * gridDim.x + blockIdx.x] = best; pidx[(size_t)p * gridDim.x + blockIdx.x] = bi; }
     }
@@ -225,7 +242,8 @@ int prx_sqnorm_rows(const float* w, float* out, int rows, int D, hipStream_t s) 
 int prx_vq_nearest(const float* z, long long tok_stride, long long ch_stride, const float* codebook, const float* cnorm,
                    int P, int NC, int D, float* pmin, int* pidx, int* idx_out, float* zq, hipStream_t s) {
     PRX_REQUIRE(D % 16 == 0, "vq: D %% 16 != 0");
-    const int ntiles = ceil_div(NC, 64);
+    PRX_REQUIRE(((uintptr_t)codebook & 15) == 0, "vq: the codebook must be 16-byte aligned");
+    const int ntiles = ceil_div(NC, VQ_CODES);      // <= ceil(NC / 64): the scratch contract of prompt_vq.h still covers it
     hipLaunchKernelGGL(vq_dist_kernel, dim3(ntiles, ceil_div(P, 64)), dim3(256), 0, s, z, tok_stride, ch_stride, codebook,
                        cnorm, P, NC, D, pmin, pidx);
     PRX_LAUNCH_CHECK();
