@@ -8,9 +8,13 @@ The geometric and colour operators are kornia==0.6.2 (/root/reference/requiremen
 which is NOT vendored; their published algorithms are restated here the way kornia builds
 them -- normalised homographies + `F.grid_sample` / `F.affine_grid` -- following
 SURVEY.md Appendix A.3.  The product computes the same maps in pixel space inside one HIP
-kernel, so agreement between the two is a real check of both.  Parity status: **unpinned**
-(the reference's tests hold no fixture for this path; no second implementation of kornia's
-augmentations is available offline).
+kernel, so agreement between the two is a real check of both.  Parity status: the CONVENTIONS
+(which align_corners flag / padding each kornia 0.6.2 call passes: table below) are **unpinned** --
+from the published 0.6.2 sources, kornia is not installable offline and the reference's tests hold
+no fixture for this path.  The REALISATION of those conventions is pinned end to end (value, each
+flag flipped, image gradient by finite differences) by a second implementation that shares nothing
+with this file: numpy float64 closed-form pixel maps + scipy.ndimage.map_coordinates + colorsys
+(tests/_independent_cutouts.py, tests/test_oracle_pins.py).
 
 Pipeline (pixray.py):
   pooled = (AdaptiveAvgPool2d(S)(img) + AdaptiveMaxPool2d(S)(img)) / 2            461-463 (same for every cutout)

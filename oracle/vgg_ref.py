@@ -6,7 +6,12 @@ Reference: `Vgg16_Extractor` (/root/reference/Losses/StyleLoss.py:24-47): `torch
 [1,3,6,8,11,13,15,22,29] (ReLU outputs relu1_1 .. relu5_3; the ReLUs are in-place); `forward` first maps a [-1,1] image to
 ImageNet-normalised space unless space == 'vgg'.  torchvision is not installed here and no VGG16 checkpoint exists offline,
 so the layer list is restated from torchvision's published cfg "D" (conv3x3 pad 1 + ReLU, 2x2/2 max-pool after blocks of
-2,2,3,3,3 convs): **parity unpinned** for the weights' layout; the arithmetic is plain F.conv2d / F.max_pool2d."""
+2,2,3,3,3 convs).  Pins: (1) tests/test_oracle_pins.py::test_vgg_oracle_vs_the_reference_extractor_class_run_live runs the
+reference's OWN class (AST-extracted, executed) around an nn.Sequential of that layout and requires the same ten maps;
+(2) tests/golden/styleloss_golden.npz (STROTSS value + image gradient through the reference's class and functions) is
+reproduced on this extractor (tests/test_style_loss.py).  What stays from knowledge: that torchvision's `vgg16().features`
+IS cfg "D" with these state-dict keys (`features.{0,2,5,...}.weight/bias`; tests/test_style_loss.py::
+test_torchvision_vgg16_checkpoint_adapter covers the key layout the loader expects)."""
 from typing import Dict, List
 
 import torch

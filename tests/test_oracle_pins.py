@@ -176,6 +176,85 @@ def test_color_jitter_gradcheck_f64_away_from_ties():
     assert (y - x.detach()).abs().max() < 1e-7           # kornia's eps = 1e-8 in the saturation denominator
 
 
+# ------------------------------------------------------------------------------------------------ a second implementation, end to end
+import pytest  # noqa: E402
+
+import _independent_cutouts as indep  # noqa: E402
+
+_E2E_CASES = [(40, 40, 12, 10, 0, 1.0, 0), (40, 40, 12, 10, 1, 1.0, 1), (36, 54, 12, 10, 0, 1.5, 2), (54, 36, 12, 10, 1, 36 / 54, 3),
+              (33, 47, 9, 7, 2, 47 / 33, 4)]
+
+
+def _e2e_inputs(H, W, S, cutn, it, aspect, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(1, 3, H, W, generator=g)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=it, aspect=aspect)
+    prm["noise"] = torch.randn(cutn, 3, S, S, generator=g)
+    return img, prm
+
+
+@pytest.mark.parametrize("case", _E2E_CASES)
+def test_make_cutouts_vs_the_independent_scipy_colorsys_implementation(case):
+    """`oracle/cutouts_ref.make_cutouts` END TO END (pooling, aspect rescale, perspective, resized crop, affine + fill, centre
+    crop, padded perspective, ColorJitter in either order, noise; reflection and border iterations; square, wide and tall
+    canvases; non-divisible pooling windows) against tests/_independent_cutouts.py: numpy float64 closed-form pixel maps +
+    scipy.ndimage.map_coordinates + colorsys, no torch, no normalised grids (its module docstring has the side-by-side).
+    fp32 round-off is the only difference allowed."""
+    H, W, S, cutn, it, aspect, seed = case
+    img, prm = _e2e_inputs(*case)
+    ref = cutouts_ref.make_cutouts(img, prm, S).double().numpy()
+    out = indep.make_cutouts(img[0].double().numpy(), indep.params_to_numpy(prm), S)
+    assert ref.shape == out.shape == (cutn, 3, S, S)
+    assert np.abs(ref - out).max() < 3e-6, np.abs(ref - out).max()
+    # the cached-transform replay (pixray.py:480-486) through the same second implementation
+    refc = cutouts_ref.make_cutouts_cached(img, prm, S).double().numpy()
+    outc = indep.make_cutouts_cached(img[0].double().numpy(), indep.params_to_numpy(prm), S)
+    assert np.abs(refc - outc).max() < 3e-6, np.abs(refc - outc).max()
+
+
+@pytest.mark.parametrize("flag", ["perspective_align_corners", "affine_align_corners", "crop_align_corners"])
+def test_each_align_corners_convention_moves_both_implementations_alike(flag):
+    """flipping ONE kornia flag changes the oracle's output by 1e-2 ... 2e-1, and the independent implementation follows it
+    to round-off: the closed-form reading of each flag (half-pixel-class scale / shift) is the one the oracle realises."""
+    case = _E2E_CASES[3]
+    S = case[2]
+    img, prm = _e2e_inputs(*case)
+    cv = {flag: not cutouts_ref.CONVENTIONS[flag]}
+    base = cutouts_ref.make_cutouts(img, prm, S).double().numpy()
+    ref = cutouts_ref.make_cutouts(img, prm, S, conventions=cv).double().numpy()
+    out = indep.make_cutouts(img[0].double().numpy(), indep.params_to_numpy(prm), S, conventions=cv)
+    assert np.abs(ref - base).max() > 5e-3
+    assert np.abs(ref - out).max() < 3e-6
+
+
+def test_oracle_image_gradient_vs_finite_differences_of_the_independent_implementation():
+    """d(sum(cutouts * proj)) / d(image) from the ORACLE's autograd against central differences of the INDEPENDENT forward
+    (float64, ColorJitter off, pooling maxima separated): the backward the HIP kernels are compared with is the derivative of a
+    function that was not written by the same hand."""
+    S, cutn, H, W = 6, 5, 12, 12
+    nz = int(0.6 * cutn)
+    g = torch.Generator().manual_seed(21)
+    prm = pc.sample_cutout_params(cutn, S, g, iteration=0)
+    prm["z_jit_apply"] = torch.zeros(nz, dtype=torch.bool)
+    prm["w_jit_apply"] = torch.zeros(cutn - nz, dtype=torch.bool)
+    img = torch.rand(1, 3, H, W, generator=g, dtype=torch.float64)
+    img += torch.linspace(0, 0.5, img.numel(), dtype=torch.float64).reshape(img.shape)[..., torch.randperm(W, generator=g)]
+    proj = torch.randn(cutn, 3, S, S, dtype=torch.float64, generator=g)
+    x = img.clone().requires_grad_(True)
+    (cutouts_ref.make_cutouts(x, prm, S) * proj).sum().backward()
+    p_np, proj_np = indep.params_to_numpy(prm), proj.numpy()
+    base = img[0].numpy()
+    eps = 1e-6
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        c, y, xx = rng.integers(3), rng.integers(H), rng.integers(W)
+        hi, lo = base.copy(), base.copy()
+        hi[c, y, xx] += eps
+        lo[c, y, xx] -= eps
+        fd = ((indep.make_cutouts(hi, p_np, S) - indep.make_cutouts(lo, p_np, S)) * proj_np).sum() / (2 * eps)
+        assert abs(fd - float(x.grad[0, c, y, xx])) < 1e-6 + 1e-5 * abs(fd), (c, y, xx, fd, float(x.grad[0, c, y, xx]))
+
+
 # ------------------------------------------------------------------------------------------------ CLIP ModifiedResNet blocks
 class _Bottleneck(nn.Module):
     """openai/CLIP clip/model.py `Bottleneck` as published (expansion 4; all strides through AvgPool2d; the downsample branch
@@ -316,3 +395,77 @@ def test_resnet_oracle_whole_tower_vs_torch_nn_assembly():
             inplanes = planes * 4
     want = clip_resnet_ref.attention_pool(p, y, cfg.heads)       # pinned on its own above
     assert (got - want).abs().max() < 1e-5 * max(1.0, want.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ fft drawer (configs[3])
+def test_fft_oracle_inverse_transform_is_the_definition_of_irfft2():
+    """`oracle/fft_ref.inverse_real_dft2` against (a) the double sum written as python loops over a tiny spectrum -- including
+    non-zero imaginary parts in the DC and Nyquist columns, which a complex-to-real transform must ignore -- and (b)
+    numpy's pocketfft `irfft2` for even / odd widths and heights"""
+    from oracle import fft_ref
+    g = torch.Generator().manual_seed(0)
+    for (h, w) in [(4, 6), (5, 7), (6, 5), (3, 4)]:
+        wf = fft_ref.n_freq_columns(w)
+        spec = torch.randn(2, h, wf, 2, generator=g, dtype=torch.float64)
+        got = fft_ref.inverse_real_dft2(spec, h, w).numpy()
+        S = spec[..., 0].numpy() + 1j * spec[..., 1].numpy()
+        want = np.zeros((2, h, w))
+        for n in range(2):
+            for y in range(h):
+                for x in range(w):
+                    acc = 0.0
+                    for v in range(w // 2 + 1):
+                        col = sum(S[n, u, v] * np.exp(2j * math.pi * u * y / h) for u in range(h))
+                        if v == 0 or (w % 2 == 0 and v == w // 2):
+                            acc += (col * np.exp(2j * math.pi * v * x / w)).real
+                        else:
+                            acc += 2 * (col * np.exp(2j * math.pi * v * x / w)).real
+                    want[n, y, x] = acc / math.sqrt(h * w)
+        assert np.abs(got - want).max() < 1e-12, (h, w)
+        lib = np.fft.irfft2(S[..., : w // 2 + 1], s=(h, w), norm="ortho")
+        assert np.abs(got - lib).max() < 1e-12, (h, w)
+
+
+@pytest.mark.parametrize("size", [(96, 64), (45, 32), (64, 33), (31, 17)])
+def test_fft_drawer_plugin_on_the_cpu_vs_the_explicit_dft_oracle(size):
+    """the product's `FftDrawer` (torch.fft + einsum; the same class runs on rocFFT on the GPU) against oracle/fft_ref.py
+    (explicit DFT sums in float64, no FFT library): identical seeded start, image to fp32 round-off, gradient w.r.t. the spectrum
+    to 1e-6 -- even and odd canvas sizes (the odd-width spectrum carries the surplus column of the lucid frequency helper)"""
+    import types
+    from oracle import fft_ref
+    from pixray_amd.fft_drawer import FftDrawer
+    st = types.SimpleNamespace(size=size, fft_use="fft", fft_decay=1.5, fft_lrate=0.3, weight_seed=3)
+    dr = FftDrawer(st)
+    dr.load_model(st, "cpu")
+    dr.init_from_tensor(None)
+    p = fft_ref.rand_init(size, 3)
+    assert torch.equal(p.detach(), dr.params[0].detach())
+    a, b = dr.synth(0), fft_ref.synth(p, size)
+    assert a.shape == b.shape == (1, 3, size[1], size[0])
+    assert float((a - b).detach().abs().max()) < 1e-6
+    proj = torch.randn(a.shape, generator=torch.Generator().manual_seed(1))
+    (ga,) = torch.autograd.grad((a * proj).sum(), dr.params[0])
+    (gb,) = torch.autograd.grad((b * proj).sum(), p)
+    assert float((ga - gb).norm() / gb.norm()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ VGG16 extractor (StyleLoss)
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout")
+def test_vgg_oracle_vs_the_reference_extractor_class_run_live():
+    """`oracle/vgg_ref.forward` against the reference's OWN `Vgg16_Extractor.forward` (Losses/StyleLoss.py:24-47, pulled out by
+    AST and executed) wrapped around an nn.Sequential laid out like torchvision's vgg16().features: the same ten maps, bit for
+    bit in both input spaces -- the capture indices [1,3,6,8,11,13,15,22,29] and the ImageNet normalisation are the
+    reference's, executed, not restated"""
+    import _refextract as rx
+    from oracle import vgg_ref
+    params = weights.synthetic_vgg16_params(0)
+    ns = rx.styleloss_ns()
+    x = torch.rand(2, 3, 48, 40, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    for space in ("uniform", "vgg"):
+        ref = rx.reference_vgg_extractor(ns, params, space)(x.clone())
+        got = vgg_ref.forward(params, x.clone(), space)
+        assert len(ref) == len(got) == 10
+        for i, (r, o) in enumerate(zip(ref, got)):
+            assert r.shape == o.shape, (space, i)
+            # map 0 is the normalised input; the reference's in-place ReLUs overwrite the captured conv outputs, as here
+            assert float((r - o).abs().max()) <= 1e-6 * max(1.0, float(r.abs().max())), (space, i)
