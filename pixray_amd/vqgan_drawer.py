@@ -58,7 +58,12 @@ class VqganDrawer(DrawingInterface):
         f = 2 ** (self.cfg.num_resolutions - 1)
         w, h = self.size
         if w % f or h % f:
-            raise ValueError(f"size {self.size} must be a multiple of {f} (pixray.py:621-626 rounds it for you)")
+            # the reference's drawer takes its latent size from the init tensor, which do_init has already rounded down to
+            # a multiple of 2^(num_resolutions-1) (pixray.py:621-626); this drawer fixes its size here, so it rounds the same way
+            w, h = (w // f) * f, (h // f) * f
+            if w == 0 or h == 0:
+                raise ValueError(f"size {self.size} is smaller than one latent cell ({f} x {f} pixels)")
+            self.size = (w, h)
         self.latent_hw = (h // f, w // f)
         self._params = params
         self.handle = ops.VqganHandle(self.cfg, params, self.latent_hw, self.device, precision=self.precision)
