@@ -193,6 +193,19 @@ def call(name: str, *args):
     return rc
 
 
+def device_available() -> bool:
+    """is a ROCm device visible?  (One function, so that the CPU emulation of the kernels -- tests/_emu.py, test
+    infrastructure -- can stand in for a device; the product has no CPU path.)"""
+    import torch
+    return torch.cuda.is_available()
+
+
+def require_device() -> None:
+    load()      # fail loudly if the HIP extension is missing
+    if not device_available():
+        raise PrxError("no ROCm device visible: the hot path has no CPU fallback")
+
+
 def current_stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream

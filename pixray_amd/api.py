@@ -80,8 +80,7 @@ def build_vqgan_clip_session(*, size=(256, 256), vqgan_model="imagenet_f16_16384
     contraction on the exact-f32 MFMA: the parity mode the bf16 numbers are measured against) or "ref" (the reference's own
     mix on a GPU: fp32 VQGAN decoder, vqgan.py:124-140, + fp16 CLIP towers)."""
     _lib.load()   # fail loudly if the HIP extension is missing
-    if not torch.cuda.is_available():
-        raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
+    _lib.require_device()
     dev = torch.device(device)
     drawer_precision, precision = _lib.split_precision(precision)      # "ref": f32 decoder + fp16 towers (the reference's GPU mix)
     settings = types.SimpleNamespace(vqgan_model=vqgan_model, size=tuple(size), weight_seed=seed,
@@ -140,8 +139,7 @@ def build_fft_clip_session(*, size=(512, 512), clip_model="ViT-L/14", num_cuts=2
     StyleLoss + SaturationLoss; `args` is what their `parse_settings` returned)."""
     from .fft_drawer import FftDrawer
     _lib.load()
-    if not torch.cuda.is_available():
-        raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
+    _lib.require_device()
     dev = torch.device(device)
     st = types.SimpleNamespace(size=tuple(size), fft_use="fft", fft_decay=fft_decay, fft_lrate=fft_lrate, weight_seed=seed)
     drawer = FftDrawer(st)

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
 
     // ---- epilogue: every wave stages its 32 x 64 slabs row-major through its OWN LDS region (no workgroup barrier: a wave's
     // ds_write -> ds_read of the same bytes is ordered by the LDS queue), so that bias / residual / aux loads and all stores
-    // are 8-16-byte accesses of 4 consecutive columns per lane
+    // are 8-16-byte accesses of 4 consecutive columns per lane.  (The /*hipemu:wave_sync*/ comments mark where the lanes of a wave
+    // exchange data relying on lockstep execution: tools/hipemu turns them into fiber synchronisation, the GPU build sees nothing.)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                          \
                     stage[((r & 3) + 8 * (r >> 2) + srow) * LDW + j * 32 + scol] = acc[I][j][r];                         \
+            /*hipemu:wave_sync*/                                                                                        \
             _Pragma("unroll") for (int rr = 0; rr < 32; rr += 4) {                                                      \
                 const int lr = rr + lr0;                                                                                \
                 const float4 v = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);                               \
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
                     else epilogue_store4<T16>(d, row, col, v);                                                          \
                 }                                                                                                       \
             }                                                                                                           \
+            /*hipemu:wave_sync*/                                                                                        \
         } while (0)
         G8_EPI_BLOCK(0); G8_EPI_BLOCK(1); G8_EPI_BLOCK(2); G8_EPI_BLOCK(3);
 #undef G8_EPI_BLOCK

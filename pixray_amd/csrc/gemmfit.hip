@@ -180,6 +180,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * LDW + j * 16 + l15] = acc[i][j][r];
+            /*hipemu:wave_sync*/                    // the slab is exchanged between the lanes of ONE wave, which runs in lockstep (the CPU emulation of tools/hipemu synchronises its fibers at these markers)
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
@@ -225,6 +226,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                     gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
                 }
             }
+            /*hipemu:wave_sync*/                    // every lane has read the slab before the next one is written over it
         }
     }
     // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot

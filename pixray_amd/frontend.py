@@ -496,8 +496,7 @@ def _hip_parts(args, device):
     from .perceptor import get_clip_perceptor
     from .prompt import Prompt
     _lib.load()
-    if not torch.cuda.is_available():
-        raise _lib.PrxError("no ROCm device visible: the hot path has no CPU fallback")
+    _lib.require_device()
     prec = _lib.split_precision(getattr(args, "precision", None))[1]
 
     def perceptor_factory(name, index):

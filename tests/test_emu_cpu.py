@@ -1,0 +1,113 @@
+"""The product's HIP kernels, run on the CPU.
+
+`tools/hipemu` compiles the SAME sources as libprx_hip.so (pixray_amd/csrc/*.hip, all of them) for the host against a stand-in
+<hip/hip_runtime.h>: every work-item is a fiber, __syncthreads / wave shuffles / ballots suspend until the workgroup / wave
+has arrived, `v_mfma_*` (32x32x16, 16x16x32, 32x32x2 f32) and `global_load_lds` are emulated with the hardware's register
+layouts, atomics are plain read-modify-writes.  `tests/_emu.py` points the ctypes loader at that library, so the same Python
+wrappers and the same C ABI drive it on CPU tensors.  These tests are the GPU suite's own test functions (`-m gpu`, imported and
+called with their device switched to "cpu") on a subset sized for a CPU: they check the kernels' LOGIC -- indexing, tiling,
+swizzles, epilogues, reductions, the runners' data flow -- against the oracle in a container that has no GPU.  They say nothing
+about speed, and the product never loads this library (the HIP path still fails loudly without a device).
+
+What the emulation cannot see: anything that depends on real concurrency between waves (missing barriers that happen to work
+sequentially), register / LDS capacity, and instruction-level hazards."""
+import os
+import shutil
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import _emu  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None,
+                                reason="needs the ROCm host clang++ and make to build tools/hipemu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    with _emu.enable() as lib:
+        import test_kernels_gpu as tk
+        import test_path_gpu as tp
+        for m in (tk, tp):
+            m.DEV = "cpu"
+        yield types_ns(lib=lib, tk=tk, tp=tp)
+        for m in (tk, tp):
+            m.DEV = "cuda"
+
+
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
+def test_emulated_library_exports_the_whole_c_abi(emu):
+    from pixray_amd import _lib
+    assert emu.lib.prx_abi_version() == 2
+    assert len(_lib._protos) >= 79 and all(hasattr(emu.lib, name) for name in _lib._protos)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM engine
+def test_gemm_kernels_4wave_fit_and_8phase(emu):
+    tk = emu.tk
+    tk.test_gemm_rowmajor_bf16(100, 72, 136, 1)                                   # ragged M / N, K not a multiple of 64 (4-wave, 32x32x16)
+    tk.test_gemm_rowmajor_bf16(64, 64, 64, 0)                                     # the register-staged variant
+    tk.test_gemm_forced_tiles_stages_splitk((64, 64), 3, 3)                       # 3-deep DMA ring + split-K workspace + reduce
+    tk.test_gemm_8phase_kernel_ragged_edges_and_epilogues("fp16")                 # 256 x 256 8-phase kernel, staggered wave rows
+
+
+def test_fit_kernel_implicit_conv_and_groupnorm_epilogue_sums(emu):
+    emu.tk.test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums((64, 64), "fp16")  # 16x16x32 MFMA, K groups through LDS, GN / GN-backward sums
+    emu.tk.test_gemm_conv3x3(16, 16, 128, 128, 0, 1, 1)
+    emu.tk.test_gemm_conv3x3_stride2_down(12, 20, 64, 72, 2)
+
+
+def test_norms_attention_layout_and_image_head_kernels(emu):
+    tk = emu.tk
+    tk.test_groupnorm_fwd_bwd(256, 512, 1)
+    tk.test_layernorm_fwd_bwd(257, 1024)
+    tk.test_transpose_softmax_upsample_layout()
+    tk.test_image_head()
+    tk.test_mha_fwd_bwd(3, 64)
+    tk.test_mha_general_fwd_bwd(2, 65, 1.0)
+
+
+def test_strotss_and_hypercolumn_kernels(emu):
+    emu.tk.test_strotss_relaxed_emd_kernels_match_the_composed_torch_expression(300, 777, False)
+    emu.tk.test_strotss_relaxed_emd_kernels_match_the_composed_torch_expression(640, 200, True)
+    emu.tk.test_hypercolumns_match_the_composed_torch_expression()
+
+
+# ------------------------------------------------------------------------------------------------ the path's own ops
+def test_cutouts_forward_and_backward_kernels_vs_oracle(emu):
+    tp = emu.tp
+    tp.test_make_cutouts_vs_oracle(5, 64, 40, 3, "noise")
+    tp.test_make_cutouts_non_square_canvas_vs_oracle(64, 112, 64, 1)
+    tp.test_make_cutouts_spot_masks_vs_oracle()
+    tp.test_make_cutouts_cached_transform_path_vs_oracle(0)
+
+
+def test_prompt_vq_and_adam_kernels_vs_oracle(emu):
+    tp = emu.tp
+    tp.test_prompt_loss_vs_oracle(64, 3, 512, -0.5, float("-inf"))
+    tp.test_adam_clamp_vs_torch()
+    tp.test_vq_nearest_vs_oracle()
+
+
+def test_clip_vit_runner_vs_oracle(emu):
+    emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
+
+
+def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
+    """synth (VQ + VQGAN decode + clamp) -> cutouts -> CLIP ViT -> prompt loss -> backward to z: the smoke test's toy graph,
+    IEEE-half operands, every kernel emulated.  The numbers reproduce the GPU's (profiles/: dz rel-L2 2.4e-2 on this graph)."""
+    from oracle import step_ref
+    r = step_ref.compare_one_iteration(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(64, 64), cutn=8, seed=0, precision="fp16",
+                                       device="cpu")
+    assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
+    assert r["image_rel_l2"] < 2e-3 and r["embeds_rel_l2"] < 3e-3
+    assert r["dz_rel_l2"] < 3e-2 and r["dz_cosine"] > 0.999, r

@@ -1,0 +1,226 @@
+// hipemu runtime: runs one workgroup at a time; every work-item is a ucontext fiber.  See hip/hip_runtime.h.
+#include "hip/hip_runtime.h"
+#undef threadIdx
+#undef blockIdx
+#undef blockDim
+#undef gridDim
+#include <sys/mman.h>
+#include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+namespace hipemu {
+Idx g_tid, g_bid;
+dim3 g_bdim, g_gdim;
+
+namespace {
+enum State { READY, AT_BARRIER, AT_WAVE, DONE };
+constexpr size_t STACK = 256 * 1024;
+struct Fiber {
+    void* rsp;                 // saved stack pointer while the fiber is switched out
+    State st;
+    Idx tid;
+    WaveReduce reduce;         // set by wave_collective: run ONCE per wave when every live lane has arrived
+    alignas(32) unsigned char deposit[DEPOSIT];
+};
+struct Wave {
+    alignas(32) unsigned char snap[64][DEPOSIT];
+    alignas(32) unsigned char result[64][RESULT];
+    unsigned long long snap_mask;
+};
+std::vector<Fiber> fibers;
+std::vector<void*> stacks;
+std::vector<Wave> waves;
+void* sched_rsp = nullptr;
+int cur = -1, nthreads = 0;
+const std::function<void()>* body_fn = nullptr;
+bool in_kernel = false;
+
+// A minimal x86-64 SysV context switch (callee-saved registers + stack pointer): ucontext's swapcontext makes a sigprocmask
+// system call per switch, and a wave collective is 64 switches.
+extern "C" void hipemu_switch(void** save_rsp, void* load_rsp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+void fiber_main() {
+    (*body_fn)();
+    fibers[cur].st = DONE;
+    hipemu_switch(&fibers[cur].rsp, sched_rsp);
+    abort();                   // a finished fiber is never resumed
+}
+void yield(State s) {
+    fibers[cur].st = s;
+    hipemu_switch(&fibers[cur].rsp, sched_rsp);
+}
+void* stack_for(int i) {
+    while ((int)stacks.size() <= i) {
+        void* p = mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) { fprintf(stderr, "hipemu: cannot map a fiber stack\n"); abort(); }
+        stacks.push_back(p);
+    }
+    return stacks[i];
+}
+
+void run_block() {
+    const int n = nthreads;
+    if ((int)fibers.size() < n) fibers.resize(n);
+    const int nw = (n + 63) / 64;
+    if ((int)waves.size() < nw) waves.resize(nw);
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = fibers[i];
+        // fresh stack: six zeroed callee-saved registers, the entry point as the return address, and a slot that leaves the
+        // stack pointer congruent to 8 mod 16 at the entry, as after a call
+        void** top = reinterpret_cast<void**>(static_cast<char*>(stack_for(i)) + STACK);
+        top[-1] = nullptr;
+        top[-2] = reinterpret_cast<void*>(&fiber_main);
+        for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+        f.rsp = &top[-8];
+        f.reduce = nullptr;
+        f.st = READY;
+        f.tid.x = i % g_bdim.x;
+        f.tid.y = (i / g_bdim.x) % g_bdim.y;
+        f.tid.z = i / (g_bdim.x * g_bdim.y);
+    }
+    int live = n;
+    while (live > 0) {
+        bool progressed = false;
+        for (int i = 0; i < n; ++i) {
+            if (fibers[i].st != READY) continue;
+            cur = i;
+            g_tid = fibers[i].tid;
+            hipemu_switch(&sched_rsp, fibers[i].rsp);
+            progressed = true;
+            if (fibers[i].st == DONE) --live;
+        }
+        // wave collectives: release a wave once all of its live lanes have arrived
+        for (int w = 0; w < nw; ++w) {
+            int waiting = 0, alive = 0;
+            const int lo = w * 64, hi = std::min(n, lo + 64);
+            for (int i = lo; i < hi; ++i) {
+                if (fibers[i].st == AT_WAVE) ++waiting;
+                if (fibers[i].st != DONE) ++alive;
+            }
+            if (waiting > 0 && waiting == alive) {
+                waves[w].snap_mask = 0;
+                WaveReduce red = nullptr;
+                for (int i = lo; i < hi; ++i)
+                    if (fibers[i].st == AT_WAVE) {
+                        memcpy(waves[w].snap[i - lo], fibers[i].deposit, DEPOSIT);
+                        waves[w].snap_mask |= 1ull << (i - lo);
+                        fibers[i].st = READY;
+                        if (fibers[i].reduce) red = fibers[i].reduce;
+                        fibers[i].reduce = nullptr;
+                    }
+                if (red) red(waves[w].snap, waves[w].snap_mask, waves[w].result);
+                progressed = true;
+            }
+        }
+        // workgroup barrier: release once every live work-item waits at it
+        int at_bar = 0;
+        for (int i = 0; i < n; ++i) at_bar += fibers[i].st == AT_BARRIER;
+        if (at_bar > 0 && at_bar == live) {
+            for (int i = 0; i < n; ++i)
+                if (fibers[i].st == AT_BARRIER) fibers[i].st = READY;
+            progressed = true;
+        }
+        if (!progressed) {
+            fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %d live work-items, %d at the barrier; the others wait in a wave "
+                            "collective that their wave mates never reach (divergent collective / barrier)\n",
+                    g_bid.x, g_bid.y, g_bid.z, live, at_bar);
+            abort();
+        }
+    }
+}
+}  // namespace
+
+namespace {
+void on_segv(int sig) {
+    void* bt[64];
+    const int n = backtrace(bt, 64);
+    fprintf(stderr, "hipemu: signal %d in block (%u,%u,%u) work-item %d\n", sig, g_bid.x, g_bid.y, g_bid.z, cur);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(139);
+}
+}  // namespace
+
+void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+    static bool traced = false;
+    if (!traced && getenv("HIPEMU_TRACE")) {       // a backtrace instead of a bare crash (set before the first launch)
+        static char alt[1 << 16];
+        stack_t ss{alt, 0, sizeof(alt)};
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa{};
+        sa.sa_handler = on_segv;
+        sa.sa_flags = SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGBUS, &sa, nullptr);
+        traced = true;
+    }
+    static const bool log = getenv("HIPEMU_LOG") != nullptr;
+    if (log) fprintf(stderr, "hipemu: launch grid (%u,%u,%u) block (%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z);
+    if (in_kernel) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
+    nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 0 || nthreads > 1024) { fprintf(stderr, "hipemu: bad block size %d\n", nthreads); abort(); }
+    in_kernel = true;
+    body_fn = &body;
+    g_bdim = block;
+    g_gdim = grid;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_bid = Idx{bx, by, bz};
+                run_block();
+            }
+    in_kernel = false;
+    body_fn = nullptr;
+}
+
+void syncthreads() { yield(AT_BARRIER); }
+
+void wave_exchange(const void* mine, size_t bytes) {
+    if (bytes > DEPOSIT) { fprintf(stderr, "hipemu: wave exchange of %zu bytes\n", bytes); abort(); }
+    memcpy(fibers[cur].deposit, mine, bytes);
+    yield(AT_WAVE);
+}
+const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce) {
+    if (bytes > DEPOSIT) { fprintf(stderr, "hipemu: wave collective of %zu bytes\n", bytes); abort(); }
+    memcpy(fibers[cur].deposit, mine, bytes);
+    fibers[cur].reduce = reduce;
+    yield(AT_WAVE);
+    return waves[cur / 64].result[cur & 63];
+}
+void wave_sync() { yield(AT_WAVE); }
+const void* wave_slot(int lane) {
+    if (lane < 0 || lane > 63) return nullptr;
+    const Wave& w = waves[cur / 64];
+    return ((w.snap_mask >> lane) & 1) ? w.snap[lane] : nullptr;
+}
+int lane_id() { return cur & 63; }
+unsigned long long wave_live_mask() {
+    unsigned long long m = 0;
+    const int lo = (cur / 64) * 64, hi = std::min(nthreads, lo + 64);
+    for (int i = lo; i < hi; ++i)
+        if (fibers[i].st != DONE) m |= 1ull << (i - lo);
+    return m;
+}
+}  // namespace hipemu
