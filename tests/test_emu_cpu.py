@@ -111,3 +111,71 @@ def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
     assert r["indices_equal"] and r["loss_abs_err"] < 2e-3
     assert r["image_rel_l2"] < 2e-3 and r["embeds_rel_l2"] < 3e-3
     assert r["dz_rel_l2"] < 3e-2 and r["dz_cosine"] > 0.999, r
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 on the emulated kernels
+def _dist_worker(rank, world, port, cutn, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    with _emu.enable():
+        from pixray_amd import api
+        sess = api.build_vqgan_clip_session(size=(64, 64), vqgan_model="tiny_f4", clip_model="tiny-B/32", num_cuts=cutn, seed=3, device="cpu",
+                                            group=dist.group.WORLD if world > 1 else None, rank=rank, world_size=world, precision="fp16",
+                                            learning_rate=0.1, iterations=10)
+        # the same explicit draws (incl. the noise tensor, which a session otherwise draws per rank on the device) everywhere
+        from pixray_amd import cutouts as pc
+        for size, mk in sess.cutoutsTable.items():
+            g = torch.Generator().manual_seed(77)
+            prm = pc.sample_cutout_params(cutn, size, g, iteration=0, fill=0.5)
+            prm["noise"] = torch.randn(cutn, 3, size, size, generator=g)
+            mk.fixed_params = prm
+        sess.train(0)
+        z = sess.drawer.get_z()
+        q.put((rank, z.detach().numpy().copy(), z.grad.detach().numpy().copy(), float(sum(l.detach() for l in sess.last_losses))))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_emulated_kernels_match_one_process():
+    """SURVEY.md section 8(e) with the PRODUCT's parts end to end: two gloo ranks, each running the emulated HIP kernels on its
+    half of the cutouts -- the batch-global min / max all-reduce in front of the tower, the fp64 renormalisation sums behind its
+    backward, the global-mean prompt denominator, the dL/d(image) all-reduce in front of the replicated decoder backward, the same
+    Adam step on every rank -- against one process on the whole batch."""
+    import torch.multiprocessing as mp
+    import test_dist_cpu as td
+    _emu.build()
+    ctx = mp.get_context("spawn")
+    cutn = 4
+
+    def run(world):
+        q, port = ctx.Queue(), td._free_port()
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, cutn, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted(td._collect(q, procs, world, timeout=600), key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=120)
+                assert p.exitcode == 0
+            return res
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+    (_, z0, g0, l0), (_, z1, g1, l1) = run(2)
+    ((_, zr, gr, lr),) = run(1)
+    z0, g0, z1, g1, zr, gr = [torch.from_numpy(t) for t in (z0, g0, z1, g1, zr, gr)]
+    assert torch.equal(z0, z1) and torch.equal(g0, g1), "ranks diverged"
+    # the same cutouts through the same kernels; the tower's GEMMs see 100 instead of 200 token rows (other tiles, another
+    # summation order in fp32) and the image gradient is summed across the ranks: half-precision round-off, not more
+    rel = float((g0 - gr).norm() / gr.norm())
+    assert rel < 5e-3, rel
+    assert abs((l0 + l1) - lr) < 2e-3
+    # the first Adam step moves every entry by +-lr = 0.1 (sign of its gradient): entries whose gradient is round-off around zero may go
+    # the other way (a difference of up to 0.2), all the others land on the same value
+    assert float((z0 - zr).abs().max()) < 0.21 and float(((z0 - zr).abs() > 1e-3).float().mean()) < 0.02
