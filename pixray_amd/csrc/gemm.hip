@@ -1166,6 +1166,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
     a.fit_flags = fit_tile ? (cx.fit_flags & 15) : 0;   // gemmfit.hip A/B switches (PRX_FIT_FLAGS)
+    if (fit_tile && (cx.fit_flags & 64)) a.fit_flags |= 32;                // bit 6 of the switch word: producer-wave variants (kernel flag bit 5)
     if (fit_tile && (cx.fit_flags & 32) == 0 && d.N > d.M) a.fit_flags |= 16;      // weight-heavy: column-major tile order (bit 5 of the switch word turns it off)
     a.kt_per_split = ceil_div(a.kt_total, splits);
     if (BM == 256 && BN == 256) a.kt_per_split = (a.kt_per_split + 1) & ~1;      // the 8-phase loop body covers two K tiles

@@ -66,6 +66,37 @@ def test_fit_kernel_implicit_conv_and_groupnorm_epilogue_sums(emu):
     emu.tk.test_gemm_conv3x3_stride2_down(12, 20, 64, 72, 2)
 
 
+def test_fit_kernel_producer_wave_variants(emu):
+    """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
+    DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""
+    import math
+    from pixray_amd import _lib
+    from pixray_amd._lib import GemmArgs, call
+    lib, ctx = emu.lib, _lib.tool_ctx()
+    torch.manual_seed(5)
+    try:
+        lib.prx_gemm_tile_override(ctx, -12, 0, 1)
+        lib.prx_gemm_tile_override(ctx, -8, 0, 65)
+        for tile in emu.tk.PROD_TILES:
+            lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
+            for (M, N, K) in [(333, 520, 512), (81, 136, 1024)]:
+                A = torch.randn(M, K).to(torch.float16)
+                Bt = (torch.randn(N, K) / math.sqrt(K)).to(torch.float16)
+                bias, resid = torch.randn(N), torch.randn(M, N)
+                g = GemmArgs()
+                g.A = A.data_ptr(); g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+                g.alpha = 0.5; g.f32 = 2; g.bias_n = bias.data_ptr(); g.resid = resid.data_ptr(); g.ldr = N
+                out = torch.full((M, N), float("nan")); g.out_f32 = out.data_ptr(); g.ldc_f32 = N
+                o16 = torch.full((M, N), float("nan"), dtype=torch.float16); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = N
+                call("prx_k_gemm", g, None, 0, 0)
+                ref = 0.5 * (A.float() @ Bt.float().T) + bias + resid
+                assert emu.tk.rel_l2(out, ref) < 2e-5 and emu.tk.rel_l2(o16, ref) < 5e-4, (tile, M, N, K)
+    finally:
+        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
+        lib.prx_gemm_tile_override(ctx, -8, 0, 1)
+        lib.prx_gemm_tile_override(ctx, -12, 0, 0)
+
+
 def test_norms_attention_layout_and_image_head_kernels(emu):
     tk = emu.tk
     tk.test_groupnorm_fwd_bwd(256, 512, 1)

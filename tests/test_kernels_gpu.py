@@ -2,6 +2,7 @@
 PyTorch fp32 reference of the same op evaluated on the same (bf16-rounded where the kernel
 consumes bf16) inputs.  Tolerances are written next to each check."""
 import math
+import os
 
 import pytest
 import torch
@@ -259,6 +260,19 @@ def test_gemm_fit_tiles(tile, prec, stagger):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
+
+
+PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128)]
+
+
+@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
+                    reason="producer-wave fit kernels: validated on the CPU emulation only so far (tests/test_emu_cpu.py); "
+                           "PRX_TEST_EXPERIMENTAL=1 runs them on the device -- wrap the first run in a short `timeout`")
+@pytest.mark.parametrize("tile", PROD_TILES, ids=lambda t: f"{t[0]}x{t[1]}")
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_gemm_fit_producer_wave_variants(tile, prec):
+    """fit_flags bit 6: four extra waves issue all of the workgroup's DMA (gemmfit.hip NPROD); same products, same epilogues"""
+    test_gemm_fit_tiles(tile, prec, 65)
 
 
 FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
