@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 5, FIRST gpurun call (~8 GPU-minutes): everything that was prepared on the CPU emulation in round 4 (no GPU minutes
+# were left) gets its first run on the device, shortest and most hang-prone first, each step under its own timeout.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/r05_first_call.sh'
+# 1. producer-wave fit kernels (gemmfit.hip NPROD = 4): the barrier protocol relies on ended waves not being waited for.
+# 2. the same build's headline bench, baseline vs PRX_FIT_FLAGS=65 (producer waves on every tile that has the variant).
+# 3. stand-alone per-shape timings of the two (tools/fit_bench.py: `producer waves` column).
+# 4. the front end on the HIP parts and the full GPU suite.
+set -u
+mkdir -p gpurun_out
+export PRX_TEST_EXPERIMENTAL=1
+timeout 150 python -m pytest tests/test_kernels_gpu.py -x -q -k "producer_wave" > gpurun_out/r05_producer_tests.log 2>&1; echo "producer tests rc=$?"
+tail -3 gpurun_out/r05_producer_tests.log
+timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_base.json 2> gpurun_out/r05_bench_base.err; echo "bench base rc=$?"
+PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_prod.json 2> gpurun_out/r05_bench_prod.err; echo "bench producers rc=$?"
+python - <<'PY'
+import json
+for tag in ("base", "prod"):
+    try:
+        line = [l for l in open(f"gpurun_out/r05_bench_{tag}.json") if l.startswith("{")][-1]
+        d = json.loads(line)
+        print(tag, d["value"], d["unit"], "ms/step", d["ms_per_step"], "roofline", d.get("roofline", {}).get("frac"))
+    except Exception as e:
+        print(tag, "no line:", e)
+PY
+timeout 150 python tools/fit_bench.py > gpurun_out/r05_fit_bench.log 2>&1; echo "fit_bench rc=$?"
+cut -c1-60,150-400 gpurun_out/r05_fit_bench.log | head -20
+unset PRX_TEST_EXPERIMENTAL
+timeout 120 python -m pytest tests/test_zz_frontend_gpu.py -x -q > gpurun_out/r05_frontend.log 2>&1; echo "frontend rc=$?"; tail -2 gpurun_out/r05_frontend.log
