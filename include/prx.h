@@ -229,6 +229,21 @@ int prx_vgg16_feature_shape(int H, int W, int k, int* h, int* w, int* c);
 int prx_vgg16_forward(prx_vgg16* h, const float* x, int H, int W, void* workspace, float* const* feats, prx_stream_t s);
 int prx_vgg16_backward(prx_vgg16* h, int H, int W, const void* workspace, const float* const* g_feats, float* g_x, prx_stream_t s);
 
+/* --- the fft drawer's spectrum -> image map and its backward (BASELINE.json configs[3]; fftdrawer.py:45-62 `init_from_tensor`,
+ * 79-86 `synth`: aphantasia fft_image(sd 0.01, decay_power) + to_valid_rgb(colors), evaluated at `contrast`):
+ *   image = sigmoid(colour matrix (irfft2(scale * spectrum, s = (H, W), norm = "ortho") * contrast / std))
+ * The inverse real transform runs as exact-f32 GEMMs against twiddle matrices built in float64 at creation (no FFT library;
+ * csrc/fft_drawer.hip).  params / g_params: fp32 [3][H][Wf][2] (real, imaginary), Wf = prx_fft_drawer_freq_columns() =
+ * W/2 + 1, or W/2 + 2 for an odd W (the surplus column of the lucid frequency helper is ignored and gets a zero gradient).
+ * image / g_image: fp32 [3][H][W] in (0,1).  backward differentiates the LAST synth of the handle (it keeps the
+ * un-normalised image and its moments).  Asynchronous on `stream`; one handle per canvas size, not shared between threads. */
+typedef struct prx_fft_drawer prx_fft_drawer;
+prx_fft_drawer* prx_fft_drawer_create(int W, int H, float decay, float colors);
+void prx_fft_drawer_destroy(prx_fft_drawer* h);
+int prx_fft_drawer_freq_columns(const prx_fft_drawer* h);
+int prx_fft_drawer_synth(prx_fft_drawer* h, const float* params, float contrast, float* image, prx_stream_t stream);
+int prx_fft_drawer_backward(prx_fft_drawer* h, const float* g_image, float* g_params, prx_stream_t stream);
+
 /* --- STROTSS hyper-column sampling of the StyleLoss plugin (`spatial_feature_extract`, Losses/StyleLoss.py:169-223): n
  * positions, one bilinear sample of each of n_layers NHWC fp32 feature maps per position, concatenated over channels, plus
  * the two coordinate channels -> out [n, ldo] (ldo >= sum(channels) + 2).

@@ -1,12 +1,16 @@
 """`FftDrawer` with the reference's drawer surface (/root/reference/fftdrawer.py:13-110): the image is a learnable
 Fourier spectrum (BASELINE.json configs[3]: "fftdrawer 512x512").
 
-A drawer *plugin*, not part of the HIP hot path: `synth()` hands the loop a [1,3,H,W] tensor in [0,1] and everything
-downstream (cutouts, CLIP tower, loss, backward to the image) runs on the HIP kernels; the spectrum -> image map itself
-is an inverse real FFT (`torch.fft.irfftn` = rocFFT on MI355X) plus elementwise colour work.
+A drawer *plugin* (the reference's drawers are plugins too): `synth()` hands the loop a [1,3,H,W] tensor in [0,1] and
+everything downstream (cutouts, CLIP tower, loss, backward to the image) runs on the HIP kernels.  The spectrum -> image map
+itself has two implementations: plain torch (`torch.fft.irfftn` = rocFFT on MI355X, plus elementwise colour work; the default)
+and -- PRX_FFT_HIP=1 -- `csrc/fft_drawer.hip`: the inverse real transform as exact-f32 GEMMs on the engine against float64-built
+twiddle matrices, the std / colour / sigmoid tail and the whole backward in five small kernels (no FFT library, 15 launches per
+forward + backward instead of ~40 torch ops).  Both are checked against the explicit-DFT oracle (oracle/fft_ref.py).
 
 The reference delegates the parameterisation to `aphantasia.image.fft_image / to_valid_rgb` (eps696/aphantasia@7e6b3bb,
-requirements.txt, absent offline) [UPSTREAM]; restated here from the published algorithm (**parity unpinned**):
+requirements.txt, absent offline) [UPSTREAM]; restated here from the published algorithm (the transform is pinned to its
+definition by the oracle; aphantasia's constants -- colour matrix, 1/max(W,H) floor -- stay from the published source):
   params  = N(0, 0.01) real/imag spectrum [1, 3, H, W/2+1, 2]
   scale   = sqrt(W*H) / max(|f|, 1/max(W,H)) ** decay         (|f| = radial rfft2 frequency)
   image   = irfft2(scale * params, norm="ortho");  image *= contrast / image.std()
@@ -58,6 +62,12 @@ class FftDrawer(DrawingInterface):
 
     def load_model(self, settings, device):
         self.device = torch.device(device)
+        # PRX_FFT_HIP=1: the spectrum -> image map on the exact-f32 GEMM engine (csrc/fft_drawer.hip) instead of torch.fft / rocFFT.
+        # Validated against oracle/fft_ref.py on the CPU emulation of the kernels (tests/test_emu_cpu.py); off by default until it
+        # has run on the device (tests/test_zz_frontend_gpu.py::test_fft_drawer_hip_path, PRX_TEST_EXPERIMENTAL=1).
+        import os
+        self.hip = os.environ.get("PRX_FFT_HIP", "0") == "1" and (self.device.type == "cuda" or getattr(settings, "fft_hip_force", False))
+        self._handle = None
 
     def rand_init(self, toksX=None, toksY=None):
         self.init_from_tensor(None)
@@ -102,6 +112,12 @@ class FftDrawer(DrawingInterface):
         if cur_iteration is not None and cur_iteration < 0:
             return self.img
         h, w = self.canvas_height, self.canvas_width
+        if getattr(self, "hip", False):
+            from . import ops
+            if self._handle is None:
+                self._handle = ops.FftDrawerHandle(w, h, decay=self.decay, colors=1.5)
+            self.img = ops.fft_synth(self.params[0], self._handle, 0.9)
+            return self.img
         spec = torch.view_as_complex((self._scale * self.params[0]).contiguous())
         image = torch.fft.irfftn(spec, s=(h, w), dim=(-2, -1), norm="ortho")
         image = image * 0.9 / image.std()                                             # contrast=0.9 (fftdrawer.py:84)

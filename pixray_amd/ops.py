@@ -723,3 +723,50 @@ def vgg16_features(x, handle: Vgg16Handle):
     """x [1,3,H,W] (already normalised for VGG) -> the nine captured feature maps as NHWC fp32 tensors [1,h,w,C]
     (channels-last is the engine's layout; `f.permute(0,3,1,2)` is the reference's NCHW view)."""
     return _Vgg16Fn.apply(x, handle)
+
+
+# --------------------------------------------------------------------------------------- fft drawer (configs[3])
+class FftDrawerHandle:
+    """`prx_fft_drawer` (csrc/fft_drawer.hip): spectrum [1,3,H,Wf,2] -> image [1,3,H,W] as exact-f32 GEMMs against twiddle
+    matrices, and its backward.  One handle per canvas size."""
+
+    def __init__(self, width: int, height: int, decay: float = 1.5, colors: float = 1.5):
+        lib = _lib.load()
+        self.h = lib.prx_fft_drawer_create(int(width), int(height), float(decay), float(colors))
+        if not self.h:
+            raise PrxError("prx_fft_drawer_create failed: " + _lib.last_error())
+        self.width, self.height = int(width), int(height)
+        self.freq_columns = lib.prx_fft_drawer_freq_columns(self.h)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                _destroy_handle("prx_fft_drawer_destroy", h)
+            except Exception:
+                pass
+
+
+class _FftSynthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, handle, contrast):
+        _need_cuda(params)
+        p = params.detach().contiguous().float()
+        if tuple(p.shape) != (1, 3, handle.height, handle.freq_columns, 2):
+            raise PrxError(f"fft drawer: spectrum {tuple(p.shape)} does not fit a {handle.width} x {handle.height} canvas")
+        img = torch.empty(1, 3, handle.height, handle.width, device=p.device)
+        call("prx_fft_drawer_synth", handle.h, p, float(contrast), img, _stream())
+        ctx.handle, ctx.shape = handle, p.shape
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        gp = torch.empty(ctx.shape, device=g.device)
+        call("prx_fft_drawer_backward", ctx.handle.h, g, gp, _stream())
+        return gp, None, None
+
+
+def fft_synth(params: torch.Tensor, handle: FftDrawerHandle, contrast: float = 0.9) -> torch.Tensor:
+    """differentiable w.r.t. `params`; a backward differentiates the handle's LAST synth (one synth per backward, as the loop does)"""
+    return _FftSynthFn.apply(params, handle, contrast)

@@ -144,6 +144,45 @@ def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
     assert r["dz_rel_l2"] < 3e-2 and r["dz_cosine"] > 0.999, r
 
 
+@pytest.mark.parametrize("size", [(96, 64), (45, 32), (64, 33)])
+def test_fft_drawer_hip_path_vs_the_explicit_dft_oracle(emu, size):
+    """csrc/fft_drawer.hip (PRX_FFT_HIP=1: pack, two exact-f32 GEMM stages against twiddle matrices, std / colour / sigmoid tail;
+    the transposed chain backwards) against oracle/fft_ref.py: image and d/d(spectrum), even and odd canvas sizes"""
+    from oracle import fft_ref
+    from pixray_amd import ops
+    h = ops.FftDrawerHandle(size[0], size[1])
+    p = fft_ref.rand_init(size, 3)
+    assert h.freq_columns == p.shape[3]
+    q = p.detach().clone().requires_grad_(True)
+    a, b = ops.fft_synth(q, h, 0.9), fft_ref.synth(p, size)
+    assert float((a - b).detach().abs().max()) < 2e-6
+    proj = torch.randn(a.shape, generator=torch.Generator().manual_seed(1))
+    (ga,) = torch.autograd.grad((a * proj).sum(), q)
+    (gb,) = torch.autograd.grad((b * proj).sum(), p)
+    assert float((ga - gb).norm() / gb.norm()) < 5e-6
+    if size[0] % 2:                                      # the surplus frequency column of an odd width: no gradient
+        assert float(ga[..., -1, :].abs().max()) == 0.0
+
+
+def test_fft_drawer_plugin_switches_to_the_hip_path(emu, monkeypatch):
+    import types
+    from oracle import fft_ref
+    from pixray_amd.fft_drawer import FftDrawer
+    monkeypatch.setenv("PRX_FFT_HIP", "1")
+    st = types.SimpleNamespace(size=(40, 24), fft_use="fft", fft_decay=1.5, fft_lrate=0.3, weight_seed=2, fft_hip_force=True)
+    dr = FftDrawer(st)
+    dr.load_model(st, "cpu")
+    dr.init_from_tensor(None)
+    assert dr.hip
+    img = dr.synth(0)
+    ref = fft_ref.synth(dr.params[0].detach(), (40, 24))
+    assert float((img - ref).detach().abs().max()) < 2e-6
+    img.sum().backward()
+    assert dr.params[0].grad is not None and torch.isfinite(dr.params[0].grad).all()
+    opt = dr.get_opts()[0]
+    opt.step()                                            # the plugin's own Adam over the spectrum (fftdrawer.py:65-69)
+
+
 # ------------------------------------------------------------------------------------------------ N > 1 on the emulated kernels
 def _dist_worker(rank, world, port, cutn, q):
     import torch.distributed as dist

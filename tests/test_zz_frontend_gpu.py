@@ -42,3 +42,27 @@ def test_settings_to_png_on_the_hip_path(tmp_path):
     a = np.asarray(Image.open(os.path.join(s.outdir, "steps", "frame_0000.png")), dtype=np.int32)
     b = np.asarray(Image.open(os.path.join(s.outdir, "steps", "frame_0006.png")), dtype=np.int32)
     assert np.abs(a - b).max() > 0                                      # the image moved
+
+
+@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
+                    reason="csrc/fft_drawer.hip: validated on the CPU emulation only so far (tests/test_emu_cpu.py)")
+@pytest.mark.parametrize("size", [(96, 64), (45, 32), (512, 512)])
+def test_fft_drawer_hip_path(size, monkeypatch):
+    """PRX_FFT_HIP=1 on the device: image and d/d(spectrum) against the explicit-DFT oracle, and against the torch.fft path"""
+    import types
+    from oracle import fft_ref
+    from pixray_amd.fft_drawer import FftDrawer
+    monkeypatch.setenv("PRX_FFT_HIP", "1")
+    st = types.SimpleNamespace(size=size, fft_use="fft", fft_decay=1.5, fft_lrate=0.3, weight_seed=3)
+    dr = FftDrawer(st)
+    dr.load_model(st, "cuda")
+    dr.init_from_tensor(None)
+    assert dr.hip
+    img = dr.synth(0)
+    p = fft_ref.rand_init(size, 3)
+    ref = fft_ref.synth(p, size)
+    assert float((img.detach().cpu() - ref.detach()).abs().max()) < 5e-6
+    proj = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    (g,) = torch.autograd.grad((img * proj.cuda()).sum(), dr.params[0])
+    (gr,) = torch.autograd.grad((ref * proj).sum(), p)
+    assert float((g.cpu() - gr).norm() / gr.norm()) < 2e-5

@@ -9,7 +9,7 @@
 set -u
 mkdir -p gpurun_out
 export PRX_TEST_EXPERIMENTAL=1
-timeout 150 python -m pytest tests/test_kernels_gpu.py -x -q -k "producer_wave" > gpurun_out/r05_producer_tests.log 2>&1; echo "producer tests rc=$?"
+timeout 150 python -m pytest tests/test_kernels_gpu.py tests/test_zz_frontend_gpu.py -q -k "producer_wave or fft_drawer_hip" > gpurun_out/r05_producer_tests.log 2>&1; echo "producer tests rc=$?"
 tail -3 gpurun_out/r05_producer_tests.log
 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_base.json 2> gpurun_out/r05_bench_base.err; echo "bench base rc=$?"
 PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_prod.json 2> gpurun_out/r05_bench_prod.err; echo "bench producers rc=$?"
