@@ -77,7 +77,10 @@ def test_fit_kernel_producer_wave_variants(emu):
     try:
         lib.prx_gemm_tile_override(ctx, -12, 0, 1)
         lib.prx_gemm_tile_override(ctx, -8, 0, 65)
-        for tile in emu.tk.PROD_TILES:
+        # both DMA completion models: deferred (data lands only when the producers' counted wait retires it: a missing or short
+        # wait shows as stale LDS) and eager (data lands at issue: a stage overwritten while still being read shows)
+        for eager, tile in [(e, t) for e in (0, 1) for t in emu.tk.PROD_TILES]:
+            lib.hipemu_set_dma_eager(eager)
             lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
             for (M, N, K) in [(333, 520, 512), (81, 136, 1024)]:
                 A = torch.randn(M, K).to(torch.float16)
@@ -92,9 +95,23 @@ def test_fit_kernel_producer_wave_variants(emu):
                 ref = 0.5 * (A.float() @ Bt.float().T) + bias + resid
                 assert emu.tk.rel_l2(out, ref) < 2e-5 and emu.tk.rel_l2(o16, ref) < 5e-4, (tile, M, N, K)
     finally:
+        lib.hipemu_set_dma_eager(0)
         lib.prx_gemm_tile_override(ctx, 0, 0, 0)
         lib.prx_gemm_tile_override(ctx, -8, 0, 1)
         lib.prx_gemm_tile_override(ctx, -12, 0, 0)
+
+
+def test_dma_rings_under_the_eager_completion_model_too(emu):
+    """the default model of the emulation retires a `global_load_lds` only at the counted wait that covers it (the latest legal
+    completion); the rings of the 4-wave, fit and 8-phase kernels once more with the data landing AT ISSUE (the earliest), which is
+    what exposes a stage that is overwritten while another wave still reads it"""
+    try:
+        emu.lib.hipemu_set_dma_eager(1)
+        emu.tk.test_gemm_forced_tiles_stages_splitk((64, 64), 3, 1)
+        emu.tk.test_gemm_8phase_kernel_ragged_edges_and_epilogues("bf16")
+        emu.tk.test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums((64, 64), "bf16")
+    finally:
+        emu.lib.hipemu_set_dma_eager(0)
 
 
 def test_norms_attention_layout_and_image_head_kernels(emu):

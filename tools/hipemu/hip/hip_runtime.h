@@ -123,6 +123,8 @@ typedef void (*WaveReduce)(unsigned char (*deposits)[DEPOSIT], unsigned long lon
 const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce);
 const void* wave_slot(int lane);          // a lane's deposit of the last exchange (nullptr: that lane is not live)
 int lane_id();
+void dma_issue(const void* src, void* dst, int bytes);
+void waitcnt_vm(int n);
 void wave_sync();                     // all live lanes of the wave arrive (lockstep points: /*hipemu:wave_sync*/ markers in the sources)
 unsigned long long wave_live_mask();
 }  // namespace hipemu
@@ -134,7 +136,7 @@ unsigned long long wave_live_mask();
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
 
-static inline void __syncthreads() { hipemu::syncthreads(); }
+static inline void __syncthreads() { hipemu::waitcnt_vm(0); hipemu::syncthreads(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 static inline void __threadfence_system() {}
@@ -245,10 +247,17 @@ using std::max;
 using std::min;
 
 // ---- LDS DMA: global_load_lds_dwordx4 -- every lane moves `size` bytes from ITS global address to (wave-uniform LDS base) +
-// lane * size (+ the instruction offset).  Executed at once: a legal completion order for code that waits (vmcnt) and
-// synchronises before it reads, and that never overwrites a buffer somebody may still read.
+// lane * size (+ the instruction offset).  Two completion models (HIPEMU_DMA):
+//   deferred (default)  the bytes are read at issue and LAND only when the issuing wave's counted wait retires them
+//                       (hipemu::waitcnt_vm(n): all but the newest n of this lane's DMA instructions; __syncthreads() implies
+//                       n = 0, as HIP's fence does; the raw s_barrier does NOT; the end of the kernel does) -- the latest legal
+//                       completion: code that reads a stage before it waited for it sees stale LDS;
+//   eager               they land at issue -- the earliest legal completion: code that overwrites a stage somebody still
+//                       reads is caught.
+// vmcnt also counts ordinary vector loads / stores on the hardware; the K loops that use counted waits issue nothing else
+// between them, so counting DMA instructions is exact there.
 #define __builtin_amdgcn_global_load_lds(gptr, lptr, size, offset, aux) \
-    memcpy((char*)(lptr) + hipemu::lane_id() * (size) + (offset), (const void*)(gptr), (size))
+    hipemu::dma_issue((const void*)(gptr), (char*)(lptr) + hipemu::lane_id() * (size) + (offset), (size))
 
 // ---- MFMA (wave-wide matrix instructions) as wave collectives, CDNA3/4 register layouts:
 //   32x32xK (K = 16 16-bit / 2 f32): A lane l holds row l % 32, k-slice l / 32;  B lane l holds column l % 32, k-slice l / 32;

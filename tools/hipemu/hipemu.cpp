@@ -5,6 +5,7 @@
 #undef blockDim
 #undef gridDim
 #include <sys/mman.h>
+#include <deque>
 #include <vector>
 #include <execinfo.h>
 #include <signal.h>
@@ -17,11 +18,13 @@ dim3 g_bdim, g_gdim;
 namespace {
 enum State { READY, AT_BARRIER, AT_WAVE, DONE };
 constexpr size_t STACK = 256 * 1024;
+struct Dma { void* dst; int bytes; unsigned char data[16]; };
 struct Fiber {
     void* rsp;                 // saved stack pointer while the fiber is switched out
     State st;
     Idx tid;
     WaveReduce reduce;         // set by wave_collective: run ONCE per wave when every live lane has arrived
+    std::deque<Dma> dma;       // this lane's DMA instructions in flight (deferred completion model)
     alignas(32) unsigned char deposit[DEPOSIT];
 };
 struct Wave {
@@ -62,8 +65,16 @@ hipemu_switch:
     ret
 .size hipemu_switch, .-hipemu_switch
 )");
+void retire(Fiber& f, size_t keep) {
+    while (f.dma.size() > keep) {
+        const Dma& d = f.dma.front();
+        memcpy(d.dst, d.data, d.bytes);
+        f.dma.pop_front();
+    }
+}
 void fiber_main() {
     (*body_fn)();
+    retire(fibers[cur], 0);    // a kernel's memory operations have all completed when it ends
     fibers[cur].st = DONE;
     hipemu_switch(&fibers[cur].rsp, sched_rsp);
     abort();                   // a finished fiber is never resumed
@@ -96,6 +107,7 @@ void run_block() {
         for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
         f.rsp = &top[-8];
         f.reduce = nullptr;
+        f.dma.clear();
         f.st = READY;
         f.tid.x = i % g_bdim.x;
         f.tid.y = (i / g_bdim.x) % g_bdim.y;
@@ -209,7 +221,17 @@ const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce) {
     yield(AT_WAVE);
     return waves[cur / 64].result[cur & 63];
 }
+int dma_eager = -1;          // -1: read HIPEMU_DMA at the first DMA; hipemu_set_dma_eager() overrides
 void wave_sync() { yield(AT_WAVE); }
+void dma_issue(const void* src, void* dst, int bytes) {
+    if (dma_eager < 0) dma_eager = getenv("HIPEMU_DMA") && !strcmp(getenv("HIPEMU_DMA"), "eager");
+    if (dma_eager || bytes > 16) { memcpy(dst, src, bytes); return; }
+    Dma d;
+    d.dst = dst; d.bytes = bytes;
+    memcpy(d.data, src, bytes);
+    fibers[cur].dma.push_back(d);
+}
+void waitcnt_vm(int n) { if (cur >= 0 && in_kernel) retire(fibers[cur], n < 0 ? 0 : (size_t)n); }
 const void* wave_slot(int lane) {
     if (lane < 0 || lane > 63) return nullptr;
     const Wave& w = waves[cur / 64];
@@ -224,3 +246,6 @@ unsigned long long wave_live_mask() {
     return m;
 }
 }  // namespace hipemu
+
+// tests switch the DMA completion model between kernels (deferred: the latest legal completion; eager: the earliest)
+extern "C" void hipemu_set_dma_eager(int on) { hipemu::dma_eager = on ? 1 : 0; }
