@@ -597,31 +597,60 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
         checkpoints.vqgan_config_from_taming_yaml(dict(model=dict(target="taming.models.other.Thing", params={})))
 
 
-def test_gemm_engine_kernels_have_no_scratch():
-    """The GEMM kernels take their descriptor by value; one epilogue variant written the wrong way made hipcc keep that struct
-    on the stack (320 bytes of scratch per lane in EVERY kernel of the file) and the engine ran 3x slower with all parity
-    tests green.  The resource report of the compiler is the guard: no kernel of gemm.hip may use scratch."""
+def _kernel_scratch(src: str):
+    """[(kernel name, scratch bytes per lane)] of every gfx950 kernel of a .hip source.  Read from the object file the build
+    left beside it (the AMDGPU metadata note of the device code object inside its fat binary: a second or two) when that object
+    is newer than the source and every header; otherwise the source is compiled with the resource remarks on (minutes)."""
+    import glob
     import re
     import shutil
     import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = src[:-4] + ".o"
+    deps = [src] + glob.glob(os.path.join(os.path.dirname(src), "*.h")) + glob.glob(os.path.join(os.path.dirname(src), "*.inc"))
+    fresh = os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)
+    if fresh and all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        with tempfile.TemporaryDirectory() as tmp:
+            fat, co = os.path.join(tmp, "k.fatbin"), os.path.join(tmp, "k.co")
+            subprocess.run([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj], check=True)
+            targets = subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--list", "--type=o", f"--input={fat}"],
+                                     capture_output=True, text=True, check=True).stdout.split()
+            target = next(t for t in targets if "gfx950" in t)
+            subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--targets={target}",
+                            f"--output={co}"], check=True)
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+        names = re.findall(r"^\s*\.name:\s+(\S+)", notes, flags=re.M)
+        scratch = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+        assert len(names) == len(scratch) and names, (len(names), len(scratch))
+        return list(zip(names, scratch))
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch)
+    return list(zip(names, scratch))
+
+
+def test_gemm_engine_kernels_have_no_scratch():
+    """The GEMM kernels take their descriptor by value; one epilogue variant written the wrong way made hipcc keep that struct
+    on the stack (320 bytes of scratch per lane in EVERY kernel of the file) and the engine ran 3x slower with all parity
+    tests green.  The compiler's resource figures are the guard: no kernel of gemm.hip / gemmfit.hip may use scratch."""
+    import re
     for fname, at_least in (("gemm.hip", 20), ("gemmfit.hip", 6)):
-        src = os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc", fname)
-        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
-                              "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-2000:]
-        names = re.findall(r"Function Name: (\S+)", out.stderr)
-        scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-        assert len(names) == len(scratch) and len(names) >= at_least
+        kernels = _kernel_scratch(os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc", fname))
+        assert len(kernels) >= at_least
         # the producer-wave A/B variants of the fit kernel (template argument NPROD = 4, off by default: gemmfit.hip) live on
         # 168 registers; two of the four spill a few slots OUTSIDE the K loop (the producers' piece table, the epilogue) -- bounded
         # here, to be removed or fixed once the variants have been measured
         experimental = re.compile(r"gemmfit_kernelI.*Li4EEEv")
-        bad = [(n, s) for n, s in zip(names, scratch) if s != 0 and not experimental.search(n)]
+        bad = [(n, s) for n, s in kernels if s != 0 and not experimental.search(n)]
         assert not bad, bad
-        assert all(s <= 256 for n, s in zip(names, scratch) if experimental.search(n))
+        assert all(s <= 256 for n, s in kernels if experimental.search(n))
 
 
 def test_custom_backward_last_is_the_same_gradient():
