@@ -6,6 +6,7 @@
 // (slip.py:176).  With precision == PRX_PREC_F32 the same operand buffers hold fp32, the GEMMs run on
 // v_mfma_f32_32x32x2_f32 and attention on the fp32 kernels of attention_f32.hip: the exact parity mode.
 #include "vit.h"
+#include <stdlib.h>
 #include "gemm.h"
 #include "norms.h"
 #include "attention.h"
@@ -90,6 +91,11 @@ struct PrxVit {
     float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
     float* ws; size_t ws_bytes;
     int cur_n;
+    // PRX_VIT_CLS_TAIL=1 (an A/B switch, off by default): only the class token of the LAST block's output is ever read (ln_post on
+    // token 0, slip.py:66 / clip VisionTransformer), so that block's out-projection, MLP and their backward run on the n class-token
+    // rows (row stride T * width into the same buffers) instead of all n * T token rows: the same values for everything that is
+    // read, 3 + 3 of the tower's 48 + 48 wide products reduced to M = n.  K and V of that block still need every token.
+    int cls_tail;
 };
 
 namespace {
@@ -136,6 +142,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
     v->gs = nullptr;
+    { const char* e = getenv("PRX_VIT_CLS_TAIL"); v->cls_tail = (e && atoi(e) != 0 && layers > 0) ? 1 : 0; }
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -254,15 +261,20 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         if (v->f32) { if ((r = prx_mha_fwd_f32((const float*)y.qkv, (float*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
         else if (T <= 64) { if ((r = prx_mha_fwd((const bf16_t*)y.qkv, (bf16_t*)v->att_o, n, T, W, v->heads, s, v->h16))) return r; }
         else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s, v->h16))) return r; att = y.o_save; }
-        {   GemmDesc d; d.A = att; d.lda = W; d.B = y.Wo; d.ldb = W; d.M = R; d.N = W; d.K = W;
-            d.bias_n = y.bo; d.resid = y.x_in; d.ldr = W; d.out_f32 = y.x_mid; d.ldc_f32 = W;
+        // the class-token tail: rows = the n class tokens, reached through a row stride of T * W in the token-major buffers;
+        // LN / MLP intermediates of those rows are stored densely ([n][...]) at the start of their buffers
+        const bool tail = v->cls_tail && l == v->layers - 1;
+        const int rows = tail ? n : R;
+        const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
+        {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
+            d.bias_n = y.bo; d.resid = y.x_in; d.ldr = ldt; d.out_f32 = y.x_mid; d.ldc_f32 = ldt;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = ln_op(v, y.x_mid, W, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, R, s))) return r;
-        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
+        if ((r = ln_op(v, y.x_mid, ldt, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, rows, s))) return r;
+        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = rows; d.N = 4 * W; d.K = W;
             d.bias_n = y.b1; d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
-            d.bias_n = y.b2; d.resid = y.x_mid; d.ldr = W; d.out_f32 = x_next; d.ldc_f32 = W;
+        {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
+            d.bias_n = y.b2; d.resid = y.x_mid; d.ldr = ldt; d.out_f32 = x_next; d.ldc_f32 = ldt;
             if ((r = vit_gemm(v, d, s))) return r; }
     }
     // ln_post on the class token, projection, L2 normalisation (slip.py:66)
@@ -300,17 +312,23 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
                        nullptr, 0, v->dx, (long long)T * W, v->dx_bf, n, s))) return r;
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
+        // the class-token tail (see the forward): the gradient entering the last block is non-zero on the class-token rows only
+        const bool tail = v->cls_tail && l == v->layers - 1;
+        const int rows = tail ? n : R;
+        const int ldt = tail ? T * W : W;
         // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
-        {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.W2T; d.ldb = W; d.M = R; d.N = 4 * W; d.K = W;
+        {   GemmDesc d; d.A = v->dx_bf; d.lda = ldt; d.B = y.W2T; d.ldb = W; d.M = rows; d.N = 4 * W; d.K = W;
             d.act = PRX_ACT_MUL_DQUICKGELU; d.aux = y.t; d.ldaux = 4 * W; d.out_bf16 = v->dt; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = R; d.N = W; d.K = 4 * W;
+        {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = ln_bwd_op(v, v->dh, W, y.x_mid, W, y.ln2_g, y.mean2, y.rstd2, v->dx, W, v->dx, W, v->dx_bf, R, s))) return r;
+        if ((r = ln_bwd_op(v, v->dh, W, y.x_mid, ldt, y.ln2_g, y.mean2, y.rstd2, v->dx, ldt, v->dx, ldt, v->dx_bf, rows, s))) return r;
         // attention: x_mid = x_in + out_proj(mha(ln_1(x_in)))
-        {   GemmDesc d; d.A = v->dx_bf; d.lda = W; d.B = y.WoT; d.ldb = W; d.M = R; d.N = W; d.K = W;
-            d.out_bf16 = v->do_; d.ldc_bf16 = W;
+        if (tail)       // d(attention output) is written on the class-token rows only: the other rows must read as zero
+            PRX_CHECK_HIP(hipMemsetAsync(v->do_, 0, op_esz(v->f32) * (size_t)R * W, s));
+        {   GemmDesc d; d.A = v->dx_bf; d.lda = ldt; d.B = y.WoT; d.ldb = W; d.M = rows; d.N = W; d.K = W;
+            d.out_bf16 = v->do_; d.ldc_bf16 = ldt;
             if ((r = vit_gemm(v, d, s))) return r; }
         if (v->f32) { if ((r = prx_mha_bwd_f32((const float*)y.qkv, (const float*)y.o_save, (const float*)v->do_, y.lse, (float*)v->dqkv, n, T, W, v->heads, s))) return r; }
         else if (T <= 64) { if ((r = prx_mha_bwd((const bf16_t*)y.qkv, (const bf16_t*)v->do_, (bf16_t*)v->dqkv, n, T, W, v->heads, s, v->h16))) return r; }

@@ -150,6 +150,30 @@ def test_clip_vit_runner_vs_oracle(emu):
     emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
 
 
+def test_vit_class_token_tail_is_the_same_tower(emu, monkeypatch):
+    """PRX_VIT_CLS_TAIL=1 (vit.hip, an A/B switch that is off by default): the last block's out-projection, MLP and their backward on
+    the class-token rows only -- nothing else of that block's output is ever read.  Exact-f32 mode: bit for bit the full tower
+    (embeddings and d/d(cutouts)); fp16: the same up to the summation order of other GEMM tiles"""
+    from pixray_amd import ops, weights
+    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    p = weights.synthetic_clip_vit_params(cfg, 2)
+    g = torch.Generator().manual_seed(0)
+    cuts, ge = torch.rand(5, 3, 224, 224, generator=g), torch.randn(5, cfg.output_dim, generator=g)
+    for prec, tol in (("f32", 0.0), ("fp16", 2e-3)):
+        out = {}
+        for tail in ("0", "1"):
+            monkeypatch.setenv("PRX_VIT_CLS_TAIL", tail)
+            h = ops.ClipVitHandle(cfg, p, max_batch=5, device="cpu", precision=prec)
+            x = cuts.clone().requires_grad_(True)
+            e = ops.clip_encode_image(x, h)
+            (gx,) = torch.autograd.grad(e, x, ge)
+            out[tail] = (e.detach().clone(), gx.clone())
+        for a, b in zip(out["0"], out["1"]):
+            assert float((a - b).norm() / a.norm()) <= tol, prec
+    monkeypatch.setenv("PRX_VIT_CLS_TAIL", "1")
+    emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
+
+
 def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
     """synth (VQ + VQGAN decode + clamp) -> cutouts -> CLIP ViT -> prompt loss -> backward to z: the smoke test's toy graph,
     IEEE-half operands, every kernel emulated.  The numbers reproduce the GPU's (profiles/: dz rel-L2 2.4e-2 on this graph)."""
