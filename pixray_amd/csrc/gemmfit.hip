@@ -268,7 +268,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
 // wave has nothing else to do, holds no accumulators, and sits on the SIMD as a third wave (the compute waves' register budget
 // drops to 512 / 3 = 168).  Protocol: the ring of 3 stages and the one barrier per stage are unchanged; the counted wait in
 // front of barrier T is executed by the producers (vmcnt is per wave: only the issuer can wait for its pieces), the compute
-// waves only arrive.  Producers end after the main loop; an ended wave is not waited for by later barriers.
+// waves only arrive.  After the main loop the producers only mirror the epilogue's barriers, then end.
 template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16, int NPROD = 0>
 __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
@@ -453,6 +453,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
             if (t < nk) { FIT_PSTEP(t, 1); ++t; }
 #undef FIT_PSTEP
             __builtin_amdgcn_s_barrier();   // the compute waves' "ring is dead" barrier
+            // the producers stay for the barriers of fit_finish (one for the K groups' partial sums, one for the GroupNorm sums:
+            // both conditions are uniform over the workgroup), so that nothing depends on how a barrier counts ended waves
+            if (p.fit_flags & 4) return;
+            if constexpr (KS > 1) __builtin_amdgcn_s_barrier();
+            if constexpr (((TN / 8) & (TN / 8 - 1)) == 0)
+                if (p.d.gn_stats != nullptr) __builtin_amdgcn_s_barrier();
             return;
         }
         int t = 0;

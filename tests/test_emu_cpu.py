@@ -79,6 +79,7 @@ def test_fit_kernel_producer_wave_variants(emu):
         lib.prx_gemm_tile_override(ctx, -8, 0, 65)
         # both DMA completion models: deferred (data lands only when the producers' counted wait retires it: a missing or short
         # wait shows as stale LDS) and eager (data lands at issue: a stage overwritten while still being read shows)
+        lib.hipemu_set_strict_barrier(1)      # producers and compute waves must execute the same barriers, to the last one
         for eager, tile in [(e, t) for e in (0, 1) for t in emu.tk.PROD_TILES]:
             lib.hipemu_set_dma_eager(eager)
             lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
@@ -96,6 +97,7 @@ def test_fit_kernel_producer_wave_variants(emu):
                 assert emu.tk.rel_l2(out, ref) < 2e-5 and emu.tk.rel_l2(o16, ref) < 5e-4, (tile, M, N, K)
     finally:
         lib.hipemu_set_dma_eager(0)
+        lib.hipemu_set_strict_barrier(0)
         lib.prx_gemm_tile_override(ctx, 0, 0, 0)
         lib.prx_gemm_tile_override(ctx, -8, 0, 1)
         lib.prx_gemm_tile_override(ctx, -12, 0, 0)

@@ -123,6 +123,7 @@ typedef void (*WaveReduce)(unsigned char (*deposits)[DEPOSIT], unsigned long lon
 const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce);
 const void* wave_slot(int lane);          // a lane's deposit of the last exchange (nullptr: that lane is not live)
 int lane_id();
+void set_strict_barrier(bool on);
 void dma_issue(const void* src, void* dst, int bytes);
 void waitcnt_vm(int n);
 void wave_sync();                     // all live lanes of the wave arrive (lockstep points: /*hipemu:wave_sync*/ markers in the sources)

@@ -39,6 +39,7 @@ void* sched_rsp = nullptr;
 int cur = -1, nthreads = 0;
 const std::function<void()>* body_fn = nullptr;
 bool in_kernel = false;
+bool strict_barrier = false;   // abort when a barrier is released although part of the workgroup has ended (the hardware allows it)
 
 // A minimal x86-64 SysV context switch (callee-saved registers + stack pointer): ucontext's swapcontext makes a sigprocmask
 // system call per switch, and a wave collective is 64 switches.
@@ -151,6 +152,11 @@ void run_block() {
         int at_bar = 0;
         for (int i = 0; i < n; ++i) at_bar += fibers[i].st == AT_BARRIER;
         if (at_bar > 0 && at_bar == live) {
+            if (strict_barrier && live < n) {
+                fprintf(stderr, "hipemu: strict barriers: block (%u,%u,%u) releases a barrier with %d of %d work-items already ended\n",
+                        g_bid.x, g_bid.y, g_bid.z, n - live, n);
+                abort();
+            }
             for (int i = 0; i < n; ++i)
                 if (fibers[i].st == AT_BARRIER) fibers[i].st = READY;
             progressed = true;
@@ -222,6 +228,7 @@ const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce) {
     return waves[cur / 64].result[cur & 63];
 }
 int dma_eager = -1;          // -1: read HIPEMU_DMA at the first DMA; hipemu_set_dma_eager() overrides
+void set_strict_barrier(bool on) { strict_barrier = on; }
 void wave_sync() { yield(AT_WAVE); }
 void dma_issue(const void* src, void* dst, int bytes) {
     if (dma_eager < 0) dma_eager = getenv("HIPEMU_DMA") && !strcmp(getenv("HIPEMU_DMA"), "eager");
@@ -249,3 +256,5 @@ unsigned long long wave_live_mask() {
 
 // tests switch the DMA completion model between kernels (deferred: the latest legal completion; eager: the earliest)
 extern "C" void hipemu_set_dma_eager(int on) { hipemu::dma_eager = on ? 1 : 0; }
+// every work-item of a workgroup must take part in every barrier (checks that role-split kernels mirror each other's barriers)
+extern "C" void hipemu_set_strict_barrier(int on) { hipemu::set_strict_barrier(on != 0); }
