@@ -587,11 +587,19 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
     PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
-    if (a.fit_flags & 32) {        // producer-wave variants (A/B switch; the tiles of the headline configuration's wide products)
+    if (a.fit_flags & 32) {        // producer-wave variants (A/B switch)
         if (bm == 80 && bn == 128) { launch_fit<1, 4, 5, 2, 2, false, 4>(a, grid, s, zp); return 0; }
         if (bm == 160 && bn == 256) { launch_fit<2, 4, 5, 4, 1, false, 4>(a, grid, s, zp); return 0; }
         if (bm == 160 && bn == 192) { launch_fit<2, 4, 5, 3, 1, false, 4>(a, grid, s, zp); return 0; }
         if (bm == 256 && bn == 128) { launch_fit<4, 2, 4, 4, 1, true, 4>(a, grid, s, zp); return 0; }
+        // the decoder's smaller tiles: their implicit-convolution gather arithmetic (half a stage's cost on these tiles, DESIGN.md
+        // section 6) moves to the producers with the DMA
+        if (bm == 128 && bn == 128) { launch_fit<2, 4, 4, 2, 1, true, 4>(a, grid, s, zp); return 0; }
+        if (bm == 128 && bn == 64) { launch_fit<2, 2, 4, 2, 2, true, 4>(a, grid, s, zp); return 0; }
+        if (bm == 64 && bn == 64) { launch_fit<2, 2, 2, 2, 2, true, 4>(a, grid, s, zp); return 0; }
+        if (bm == 32 && bn == 64) { launch_fit<1, 2, 2, 2, 4, true, 4>(a, grid, s, zp); return 0; }
+        if (bm == 16 && bn == 64) { launch_fit<1, 2, 1, 2, 4, true, 4>(a, grid, s, zp); return 0; }
+        if (bm == 16 && bn == 32) { launch_fit<1, 1, 1, 2, 8, true, 4>(a, grid, s, zp); return 0; }
     }
     if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1, false>(a, grid, s, zp);
     else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);

@@ -95,6 +95,12 @@ def test_fit_kernel_producer_wave_variants(emu):
                 call("prx_k_gemm", g, None, 0, 0)
                 ref = 0.5 * (A.float() @ Bt.float().T) + bias + resid
                 assert emu.tk.rel_l2(out, ref) < 2e-5 and emu.tk.rel_l2(o16, ref) < 5e-4, (tile, M, N, K)
+        # the implicit-convolution form (gather arithmetic on the producers) with the GroupNorm sums, smallest and largest tile
+        lib.hipemu_set_dma_eager(0)
+        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
+        lib.prx_gemm_tile_override(ctx, -8, 0, 65)
+        for tile in ((16, 32), (256, 128)):
+            emu.tk.test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, "fp16")
     finally:
         lib.hipemu_set_dma_eager(0)
         lib.hipemu_set_strict_barrier(0)

@@ -262,7 +262,7 @@ def test_gemm_fit_tiles(tile, prec, stagger):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
 
 
-PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128)]
+PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128), (128, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
 
 
 @pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
@@ -273,6 +273,13 @@ PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128)]
 def test_gemm_fit_producer_wave_variants(tile, prec):
     """fit_flags bit 6: four extra waves issue all of the workgroup's DMA (gemmfit.hip NPROD); same products, same epilogues"""
     test_gemm_fit_tiles(tile, prec, 65)
+    if tile[0] % 80:                    # the tiles that also exist as implicit convolutions: gather arithmetic on the producers
+        lib = _lib.load()
+        try:
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 65)
+            test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec)
+        finally:
+            lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
 
 
 FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
