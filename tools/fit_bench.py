@@ -122,7 +122,7 @@ for M, N, K, tag, epi, tile in shapes:
     res = {}
     variants = dict(engine=(0, 0, 0, 0), fit0=(tile[0], tile[1], 1, 0), fit=(tile[0], tile[1], 1, 1),
                     loop=(tile[0], tile[1], 1, 1 + 4), epi=(tile[0], tile[1], 1, 1 + 8))
-    if tile in ((80, 128), (160, 256), (160, 192), (256, 128)):      # producer-wave variants (gemmfit.hip NPROD = 4, switch bit 6)
+    if tile != (160, 128):      # producer-wave variants (gemmfit.hip NPROD = 4, switch bit 6): every tile but 160 x 128
         variants.update(prod=(tile[0], tile[1], 1, 65), prodloop=(tile[0], tile[1], 1, 65 + 4))
     for name, (bm, bn, fit, flags) in variants.items():
         lib.prx_gemm_tile_override(ctx, -8, 0, flags)

@@ -28,5 +28,7 @@ for tag in ("base", "prod", "cls", "both"):
 PY
 timeout 150 python tools/fit_bench.py > gpurun_out/r05_fit_bench.log 2>&1; echo "fit_bench rc=$?"
 cut -c1-60,150-400 gpurun_out/r05_fit_bench.log | head -20
+timeout 150 python tools/fit_conv_bench.py > gpurun_out/r05_fit_conv_bench.log 2>&1; echo "fit_conv_bench rc=$?"
+cut -c1-400 gpurun_out/r05_fit_conv_bench.log | head -12
 unset PRX_TEST_EXPERIMENTAL
 timeout 120 python -m pytest tests/test_zz_frontend_gpu.py -x -q > gpurun_out/r05_frontend.log 2>&1; echo "frontend rc=$?"; tail -2 gpurun_out/r05_frontend.log
