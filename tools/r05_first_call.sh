@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, FIRST gpurun call (~8 GPU-minutes): everything that was prepared on the CPU emulation in round 4 (no GPU minutes
+# Round 5, FIRST gpurun call (~10 GPU-minutes): everything that was prepared on the CPU emulation in round 4 (no GPU minutes
 # were left) gets its first run on the device, shortest and most hang-prone first, each step under its own timeout.
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/r05_first_call.sh'
 # 1. producer-wave fit kernels (gemmfit.hip NPROD = 4): the barrier protocol relies on ended waves not being waited for.
@@ -12,10 +12,10 @@ mkdir -p gpurun_out
 export PRX_TEST_EXPERIMENTAL=1
 timeout 150 python -m pytest tests/test_kernels_gpu.py tests/test_zz_frontend_gpu.py -q -k "producer_wave or fft_drawer_hip" > gpurun_out/r05_producer_tests.log 2>&1; echo "producer tests rc=$?"
 tail -3 gpurun_out/r05_producer_tests.log
-timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_base.json 2> gpurun_out/r05_bench_base.err; echo "bench base rc=$?"
-PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_prod.json 2> gpurun_out/r05_bench_prod.err; echo "bench producers rc=$?"
-PRX_VIT_CLS_TAIL=1 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_cls.json 2> gpurun_out/r05_bench_cls.err; echo "bench class-token tail rc=$?"
-PRX_VIT_CLS_TAIL=1 PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 30 --warmup 5 > gpurun_out/r05_bench_both.json 2> gpurun_out/r05_bench_both.err; echo "bench both rc=$?"
+timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_base.json 2> gpurun_out/r05_bench_base.err; echo "bench base rc=$?"
+PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_prod.json 2> gpurun_out/r05_bench_prod.err; echo "bench producers rc=$?"
+PRX_VIT_CLS_TAIL=1 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_cls.json 2> gpurun_out/r05_bench_cls.err; echo "bench class-token tail rc=$?"
+PRX_VIT_CLS_TAIL=1 PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_both.json 2> gpurun_out/r05_bench_both.err; echo "bench both rc=$?"
 python - <<'PY'
 import json
 for tag in ("base", "prod", "cls", "both"):
