@@ -182,6 +182,28 @@ def test_vit_class_token_tail_is_the_same_tower(emu, monkeypatch):
     emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
 
 
+def test_tower_lanes_are_the_same_tower(emu, monkeypatch):
+    """PRX_VIT_LANES=K (ops.TowerLanes, an A/B switch that is off by default): the cutout batch as K chunk chains on K handles (on a
+    GPU: K streams) with the batch-global min / max taken once and the renormalisation sums of the chunks added before any chunk
+    finishes its backward -- the arithmetic of cutout sharding inside one process.  Here the chunks run one after the other (the
+    emulation has no streams): embeddings and d/d(cutouts) of 2 and 3 lanes (7 cutouts: ragged chunks) against the single chain"""
+    from pixray_amd.perceptor import get_clip_perceptor
+    g = torch.Generator().manual_seed(0)
+    cuts, ge = torch.rand(7, 3, 224, 224, generator=g), torch.randn(7, 128, generator=g)
+    out = {}
+    for k in ("1", "2", "3"):
+        monkeypatch.setenv("PRX_VIT_LANES", k)
+        p = get_clip_perceptor("tiny-B/32", "cpu", max_batch=7, seed=3, precision="fp16")
+        assert (p.lanes is not None) == (k != "1")
+        x = cuts.clone().requires_grad_(True)
+        e = p.encode_image(x)
+        (gx,) = torch.autograd.grad(e, x, ge)
+        out[k] = (e.detach().clone(), gx.clone())
+    for k in ("2", "3"):
+        assert float((out[k][0] - out["1"][0]).norm() / out["1"][0].norm()) < 1e-4
+        assert float((out[k][1] - out["1"][1]).norm() / out["1"][1].norm()) < 1e-3
+
+
 def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
     """synth (VQ + VQGAN decode + clamp) -> cutouts -> CLIP ViT -> prompt loss -> backward to z: the smoke test's toy graph,
     IEEE-half operands, every kernel emulated.  The numbers reproduce the GPU's (profiles/: dz rel-L2 2.4e-2 on this graph)."""
