@@ -426,6 +426,18 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = fit_mfma<T16>(af1[i], bf1[j], acc[i][j]);
+#if defined(PRX_FIT_SCHED) && PRX_FIT_SCHED
+        // build variant (make sched -> libprx_hip_sched.so, selected with PRX_LIB_PATH; an A/B, not the default): pin the stage's
+        // schedule to "first k-step's fragment reads | its MFMAs with the second k-step's reads issued under them | second k-step's
+        // MFMAs".  The compiler's own order re-uses fragment registers and waits lgkmcnt(0) seven times per stage.
+        // (the compiler waits lgkmcnt(0), not a count, in front of the first MFMA; so the second k-step's reads are placed BEHIND
+        // the first MFMA, where that wait no longer covers them)
+        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the first k-step's fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // the first MFMA (and the wait in front of it)
+        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the second k-step's fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - 1, 0);   // the rest of the first k-step's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);       // the second k-step's
+#endif
     };
 
     // ---- main loop: ring of 3 stages, counted waits (PW DMA instructions per wave per stage) ---------------------------
