@@ -528,7 +528,14 @@ def do_init(args, run: Optional[Run] = None, *, perceptor_factory: Optional[Call
     run.device = device = torch.device(device)
     if not hasattr(args, "precision"):
         args.precision = None
-    drawer, (sideX, sideY) = plugins.make_drawer(args, device)                                # pixray.py:612-626
+    # "ref" = the reference's own GPU mix (fp32 decoder + fp16 towers): the drawer sees its half of it
+    from . import _lib
+    session_precision = args.precision
+    args.precision = _lib.split_precision(session_precision)[0]
+    try:
+        drawer, (sideX, sideY) = plugins.make_drawer(args, device)                            # pixray.py:612-626
+    finally:
+        args.precision = session_precision
     if perceptor_factory is None:
         perceptor_factory, cutouts_factory, prompt_factory = _hip_parts(args, device)
     perceptors, cutouts = {}, {}
