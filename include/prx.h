@@ -429,7 +429,8 @@ int prx_k_mha_bwd_f32(const float* qkv, const float* out, const float* dout, con
 
 /* tuning override of the tile / split-K heuristic of one context: bm,bn in {(128,128),(128,64),(64,64),(256,128)};
  * (0,0,0) = heuristic.  Negative bm selects a switch: (-1,_,v) XCD-aware tile order 0/1/2; (-2,_,n) LDS pipeline depth;
- * (-3,_,v) 1 = direct-to-LDS v2 kernel (default), 0 = register-staged v1; (-5,_,v) scalar-tap conv gather. */
+ * (-3,_,v) 1 = direct-to-LDS v2 kernel (default), 0 = register-staged v1; (-5,_,v) scalar-tap conv gather; (-14,_,n) plan the
+ * launches of this context for n compute units (it shares the chip with concurrent chains on other streams; 0 = the device's). */
 void prx_gemm_tile_override(prx_gemm_ctx* c, int bm, int bn, int splits);
 /* the same per problem shape (tools/gemm_rules.py): mode = a_mode + 2*up + 4*a_is_f32; splits 0 = heuristic; bm = 0 drops
  * the rule, M = 0 drops all rules */

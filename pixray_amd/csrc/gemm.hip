@@ -923,6 +923,7 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
     if (bm == -12) { c->force_fit = splits; return; }    // (-12, x, on/off): a forced 128 x 128 / 128 x 64 / 64 x 64 / 256 x 128 tile means the fit kernel of that shape
     if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
+    if (bm == -14) { c->n_cu = splits; return; }         // (-14, x, n): plan for n compute units (a handle that shares the chip with concurrent chains: ops.TowerLanes); 0 = ask the device
     if (bm == -13) { c->dbg_only = splits; c->dbg_count = 0; return; }   // (-13, x, i): bisection aid -- only the i-th fit convolution (-1: all, counting; -2: off)
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;

@@ -280,6 +280,14 @@ class TowerLanes:
     def __init__(self, handles, device):
         self.handles = list(handles)
         self.device = torch.device(device)
+        # every chain gets 1/K of the chip: its launch planner should pick tiles whose grid fills THAT (at M = 1600 the 80 x 128
+        # fit tile has 120 workgroups: half a chip, rejected as a 47 % fill when planned against all 256 compute units)
+        lib = _lib.load()
+        cus = 256
+        if self.device.type == "cuda":
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        for h in self.handles:
+            lib.prx_gemm_tile_override(h.gemm_ctx, -14, 0, max(1, cus // len(self.handles)))
         self.streams = [None] + [torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
                                  for _ in self.handles[1:]]
         self.generation = 0

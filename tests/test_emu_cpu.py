@@ -200,7 +200,7 @@ def test_tower_lanes_are_the_same_tower(emu, monkeypatch):
         (gx,) = torch.autograd.grad(e, x, ge)
         out[k] = (e.detach().clone(), gx.clone())
     for k in ("2", "3"):
-        assert float((out[k][0] - out["1"][0]).norm() / out["1"][0].norm()) < 1e-4
+        assert float((out[k][0] - out["1"][0]).norm() / out["1"][0].norm()) < 1e-3        # other tiles (the lanes plan for 1/K of the chip): fp16 round-off
         assert float((out[k][1] - out["1"][1]).norm() / out["1"][1].norm()) < 1e-3
 
 
