@@ -588,6 +588,12 @@ def do_init(args, run: Optional[Run] = None, *, perceptor_factory: Optional[Call
         for m in args.clip_models:
             res = perceptors[m].input_resolution
             batch = torch.stack([_clip_preprocess(Image.open(f).convert("RGB"), res) for f in files]).to(device)
+            # the reference normalises the target images with CLIP's mean / std itself (`do_image_features`, pixray.py:567-575) and
+            # THEN hands them to the perceptor wrapper, whose encode_image renormalises (batch min / max) and normalises again
+            # (slip.py:58-66): kept, so that a target image lands where pixray puts it
+            mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=device)[:, None, None]
+            std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=device)[:, None, None]
+            batch = (batch - mean) / std
             with torch.no_grad():
                 feats = perceptors[m].encode_image(batch).float()
             pms[m].append(mk_prompt(feats, weight, stop))
