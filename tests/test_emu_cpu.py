@@ -320,3 +320,37 @@ def test_two_ranks_on_the_emulated_kernels_match_one_process():
     # the first Adam step moves every entry by +-lr = 0.1 (sign of its gradient): entries whose gradient is round-off around zero may go
     # the other way (a difference of up to 0.2), all the others land on the same value
     assert float((z0 - zr).abs().max()) < 0.21 and float(((z0 - zr).abs() > 1e-3).float().mean()) < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ the real architectures (minutes)
+_SLOW = pytest.mark.skipif(os.environ.get("PRX_EMU_SLOW", "0") != "1",
+                           reason="full-depth runners on the CPU emulation take minutes: PRX_EMU_SLOW=1 (ViT-B/32 1 min, VQGAN 256^2 4 min, "
+                                  "the headline iteration at 16 cutouts 10 min)")
+
+
+@_SLOW
+@pytest.mark.parametrize("switches", [{}, {"PRX_FIT_FLAGS": "65", "PRX_VIT_CLS_TAIL": "1"}], ids=["default", "producers+cls_tail"])
+def test_full_depth_vit_b32_runner_vs_oracle(emu, monkeypatch, switches):
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    emu.tp.test_clip_vit_vs_oracle("ViT-B/32", 8)
+
+
+@_SLOW
+@pytest.mark.parametrize("switches", [{}, {"PRX_FIT_FLAGS": "65"}], ids=["default", "producers"])
+def test_full_size_vqgan_decoder_256_vs_oracle(emu, monkeypatch, switches):
+    """taming `imagenet_f16_16384` at its own size: z [1,256,16,16] -> image [1,3,256,256] and back (253 + 253 GFLOP through the
+    emulated MFMAs), every decoder convolution on the fit kernels"""
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    emu.tp.test_vqgan_synth_vs_oracle("imagenet_f16_16384", 16)
+
+
+@_SLOW
+def test_headline_configuration_one_iteration_16_cutouts_all_switches(emu, monkeypatch):
+    """BASELINE.json configs[1] (VQGAN 256^2 + ViT-B/32, 2 prompts) at 16 cutouts with every prepared A/B switch on"""
+    from oracle import step_ref
+    for k, v in {"PRX_FIT_FLAGS": "65", "PRX_VIT_CLS_TAIL": "1", "PRX_VIT_LANES": "2"}.items():
+        monkeypatch.setenv(k, v)
+    r = step_ref.compare_one_iteration(precision="fp16", cutn=16, device="cpu")
+    assert r["indices_equal"] and r["loss_abs_err"] < 1e-3 and r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r
