@@ -257,3 +257,21 @@ def test_overlay_on_a_checkin_iteration_is_applied_once(tmp_path):
     assert calls == [0, 2]
     f0 = np.asarray(Image.open(os.path.join(s.outdir, "steps", "frame_0000.png")))
     assert f0.min() == 255            # iteration 0's check-in shows the overlaid (all white) state
+
+
+def test_command_line_entry_point(tmp_path):
+    """`python -m pixray_amd ...` = the reference's `python pixray.py ...` (pixray.py:2126-2135): an unknown drawer is a KeyError
+    from the class table, as in the reference (pixray.py:612); without a GPU the HIP parts refuse loudly after the settings
+    were resolved and logged"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pixray_amd", "--drawer", "nosuchdrawer"], capture_output=True, text=True, cwd=str(tmp_path), env=env,
+                       timeout=120)
+    assert r.returncode != 0 and "KeyError" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "pixray_amd", "--drawer", "fast_pixel", "--quality", "draft", "--outdir", str(tmp_path / "o"),
+                        "--prompts", "x", "--iterations", "2"], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=180)
+    assert "Running with 24x1 = 24 cuts" in r.stdout
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no ROCm device visible" in r.stderr
+    assert os.path.exists(tmp_path / "o" / "settings.yaml")
