@@ -254,6 +254,40 @@ def test_fft_drawer_plugin_switches_to_the_hip_path(emu, monkeypatch):
     opt.step()                                            # the plugin's own Adam over the spectrum (fftdrawer.py:65-69)
 
 
+def test_results_do_not_depend_on_the_order_waves_and_workgroups_run_in(emu):
+    """the product claims bit-reproducible gradients (no float atomics between waves; per-wave accumulator planes and fixed
+    summation orders in the cutout scatter, K groups and split-K partials added in group order): the emulation runs the waves of
+    every workgroup, and the workgroups of every grid, once first-to-last and once last-to-first (lanes of a wave keep their
+    order, as the hardware's LDS atomics do) -- cutouts forward / backward and a tower forward / backward must not change by a bit"""
+    from pixray_amd import cutouts as pc, ops, weights
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(1, 3, 40, 40, generator=g)
+    prm = pc.sample_cutout_params(6, 64, g, iteration=0)
+    prm["noise"] = torch.randn(6, 3, 64, 64, generator=g)
+    gout = torch.randn(6, 3, 64, 64, generator=g)
+    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    params = weights.synthetic_clip_vit_params(cfg, 2)
+    cuts = torch.rand(4, 3, 224, 224, generator=g)
+    res = {}
+    try:
+        for order in (0, 1):
+            emu.lib.hipemu_set_reverse_order(order)
+            mk = pc.MakeCutouts(64, 6)
+            mk.fixed_params = prm
+            x = img.clone().requires_grad_(True)
+            out = mk(x)
+            (gx,) = torch.autograd.grad(out, x, gout)
+            h = ops.ClipVitHandle(cfg, params, 4, "cpu", precision="fp16")
+            c = cuts.clone().requires_grad_(True)
+            e = ops.clip_encode_image(c, h)
+            (gc,) = torch.autograd.grad(e, c, torch.ones_like(e))
+            res[order] = (out.detach().clone(), gx.clone(), e.detach().clone(), gc.clone())
+    finally:
+        emu.lib.hipemu_set_reverse_order(0)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ N > 1 on the emulated kernels
 def _dist_worker(rank, world, port, cutn, q):
     import torch.distributed as dist

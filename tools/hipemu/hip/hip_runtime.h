@@ -124,6 +124,7 @@ const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce);
 const void* wave_slot(int lane);          // a lane's deposit of the last exchange (nullptr: that lane is not live)
 int lane_id();
 void set_strict_barrier(bool on);
+void set_reverse_order(bool on);
 void dma_issue(const void* src, void* dst, int bytes);
 void waitcnt_vm(int n);
 void wave_sync();                     // all live lanes of the wave arrive (lockstep points: /*hipemu:wave_sync*/ markers in the sources)

@@ -39,6 +39,7 @@ void* sched_rsp = nullptr;
 int cur = -1, nthreads = 0;
 const std::function<void()>* body_fn = nullptr;
 bool in_kernel = false;
+bool reverse_order = false;    // run the ready work-items of a workgroup from the last to the first (and the workgroups of a grid likewise)
 bool strict_barrier = false;   // abort when a barrier is released although part of the workgroup has ended (the hardware allows it)
 
 // A minimal x86-64 SysV context switch (callee-saved registers + stack pointer): ucontext's swapcontext makes a sigprocmask
@@ -117,7 +118,12 @@ void run_block() {
     int live = n;
     while (live > 0) {
         bool progressed = false;
-        for (int i = 0; i < n; ++i) {
+        for (int ii = 0; ii < (n + 63) / 64 * 64; ++ii) {
+            // which ready WAVE runs first must not matter to a correct kernel; the lanes of a wave keep their order (the hardware
+            // serialises the lanes of one LDS atomic in lane order: kernels may rely on that)
+            const int nwv = (n + 63) / 64;
+            const int i = reverse_order ? (nwv - 1 - ii / 64) * 64 + (ii & 63) : ii;
+            if (i >= n) continue;                                                          // a lane beyond a ragged last wave
             if (fibers[i].st != READY) continue;
             cur = i;
             g_tid = fibers[i].tid;
@@ -203,12 +209,12 @@ void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
     body_fn = &body;
     g_bdim = block;
     g_gdim = grid;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                g_bid = Idx{bx, by, bz};
-                run_block();
-            }
+    const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
+    for (unsigned long long b = 0; b < nblk; ++b) {
+        const unsigned long long lin = reverse_order ? nblk - 1 - b : b;
+        g_bid = Idx{(unsigned)(lin % grid.x), (unsigned)((lin / grid.x) % grid.y), (unsigned)(lin / ((unsigned long long)grid.x * grid.y))};
+        run_block();
+    }
     in_kernel = false;
     body_fn = nullptr;
 }
@@ -229,6 +235,7 @@ const void* wave_collective(const void* mine, size_t bytes, WaveReduce reduce) {
 }
 int dma_eager = -1;          // -1: read HIPEMU_DMA at the first DMA; hipemu_set_dma_eager() overrides
 void set_strict_barrier(bool on) { strict_barrier = on; }
+void set_reverse_order(bool on) { reverse_order = on; }
 void wave_sync() { yield(AT_WAVE); }
 void dma_issue(const void* src, void* dst, int bytes) {
     if (dma_eager < 0) dma_eager = getenv("HIPEMU_DMA") && !strcmp(getenv("HIPEMU_DMA"), "eager");
@@ -257,4 +264,6 @@ unsigned long long wave_live_mask() {
 // tests switch the DMA completion model between kernels (deferred: the latest legal completion; eager: the earliest)
 extern "C" void hipemu_set_dma_eager(int on) { hipemu::dma_eager = on ? 1 : 0; }
 // every work-item of a workgroup must take part in every barrier (checks that role-split kernels mirror each other's barriers)
+// execution order of work-items and workgroups reversed: results of a kernel that claims a fixed summation order must not change
+extern "C" void hipemu_set_reverse_order(int on) { hipemu::set_reverse_order(on != 0); }
 extern "C" void hipemu_set_strict_barrier(int on) { hipemu::set_strict_barrier(on != 0); }
