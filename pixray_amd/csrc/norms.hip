@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const
             float4 ad = reinterpret_cast<const float4*>(add)[idx];
             o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
         }
-        reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+        if (dx) reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);      // dx may be null: only the operand twin is wanted
         if (dx_bf16) {
             reinterpret_cast<bf16x4*>(dx_bf16)[idx] = to_op16x4(o[0], o[1], o[2], o[3], h16);
         }

@@ -524,7 +524,9 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             ResBlock& b = v->res[st.idx];
             const int P = b.rh * b.rw;
             if ((r = conv3_bwd(v, b.c2, g.b, false, b.rh, b.rw, t1.f, s, nullptr, &b.n2, b.h1, 1))) return r;     // d a2
-            if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, t2.f, t2.b, P, 1, s, true))) return r;            // d h1
+            // d h1: only the following dgrad reads it, as a 16-bit operand -- the fp32 copy is not written (in the exact mode the
+            // fp32 buffer IS the operand)
+            if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, v->f32 ? t2.f : nullptr, t2.b, P, 1, s, true))) return r;
             if ((r = conv3_bwd(v, b.c1, t2.b, false, b.rh, b.rw, t1.f, s, nullptr, &b.n1, b.x_in, 1))) return r;   // d a1
             const float* add = g.f;
             if (b.has_sc) {
