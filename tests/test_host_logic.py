@@ -597,7 +597,7 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
         checkpoints.vqgan_config_from_taming_yaml(dict(model=dict(target="taming.models.other.Thing", params={})))
 
 
-def _kernel_scratch(src: str):
+def _kernel_scratch(src: str, obj: str = None):
     """[(kernel name, scratch bytes per lane)] of every gfx950 kernel of a .hip source.  Read from the object file the build
     left beside it (the AMDGPU metadata note of the device code object inside its fat binary: a second or two) when that object
     is newer than the source and every header; otherwise the source is compiled with the resource remarks on (minutes)."""
@@ -607,7 +607,7 @@ def _kernel_scratch(src: str):
     import subprocess
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin"
-    obj = src[:-4] + ".o"
+    obj = obj or src[:-4] + ".o"
     deps = [src] + glob.glob(os.path.join(os.path.dirname(src), "*.h")) + glob.glob(os.path.join(os.path.dirname(src), "*.inc"))
     fresh = os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps)
     if fresh and all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
@@ -651,6 +651,12 @@ def test_gemm_engine_kernels_have_no_scratch():
         bad = [(n, s) for n, s in kernels if s != 0 and not experimental.search(n)]
         assert not bad, bad
         assert all(s <= 256 for n, s in kernels if experimental.search(n))
+    # the A/B build with the pinned stage schedule (make sched): more fragment registers live at once -- still no scratch
+    csrc = os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc")
+    sched_obj = os.path.join(csrc, "gemmfit_sched.o")
+    if os.path.exists(sched_obj):
+        kernels = _kernel_scratch(os.path.join(csrc, "gemmfit.hip"), sched_obj)
+        assert not [(n, s) for n, s in kernels if s != 0 and not experimental.search(n)]
 
 
 def test_custom_backward_last_is_the_same_gradient():
