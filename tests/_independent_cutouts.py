@@ -26,7 +26,6 @@ docstring) -- those come from the published 0.6.2 sources and stay "from knowled
 realises those stated conventions correctly through every stage and their composition.
 """
 import colorsys
-import math
 
 import numpy as np
 from scipy import ndimage

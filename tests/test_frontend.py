@@ -2,11 +2,9 @@
 the reference's own behaviour: pixray.py:1718-2135 (settings), 1145-1201 (check-in, PNG metadata), 1538-1631 (do_run, the
 animation ring), cogrun.py:25-52 (the serving generator).  The iteration runs on CPU stand-ins (the oracle's perceptor and
 cutouts, the plain-torch pixel-grid drawer): what is tested is the host logic around `engine.Session`."""
-import argparse
 import hashlib
 import os
 import sys
-import types
 
 import numpy as np
 import pytest
