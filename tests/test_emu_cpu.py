@@ -158,6 +158,28 @@ def test_clip_vit_runner_vs_oracle(emu):
     emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
 
 
+def test_the_other_runners_vs_oracle(emu):
+    """VQGAN encoder (stride-2 gather), CLIP text tower (causal general-T attention), CLIP ModifiedResNet (ReLU-mask epilogues,
+    attention pool), the cached-transform cutout path and the sharded cutout table: the runners of SURVEY.md section 8(f1, f2)"""
+    tp = emu.tp
+    tp.test_vqgan_encode_vs_oracle("tiny_f4", (40, 56))
+    tp.test_clip_text_tower_vs_oracle("tiny-B/32", 5)
+    tp.test_clip_resnet_vs_oracle("tiny-RN", 3, "fp16")
+    tp.test_make_cutouts_shard_matches_full()
+    tp.test_cutout_align_corners_convention_is_a_descriptor_field("crop_align_corners")
+
+
+def test_vgg16_extractor_exact_mode_vs_oracle(emu):
+    """the StyleLoss plugin's VGG16 runner (13 implicit convolutions with the ReLU in the epilogue, argmax max-pools, the dgrad
+    chain) in the exact-f32 mode: features and input gradient at fp32 round-off"""
+    import test_f32_mode_gpu as tf
+    tf.DEV = "cpu"
+    try:
+        tf.test_vgg16_f32_vs_oracle(64, 48)
+    finally:
+        tf.DEV = "cuda"
+
+
 def test_vit_class_token_tail_is_the_same_tower(emu, monkeypatch):
     """PRX_VIT_CLS_TAIL=1 (vit.hip, an A/B switch that is off by default): the last block's out-projection, MLP and their backward on
     the class-token rows only -- nothing else of that block's output is ever read.  Exact-f32 mode: bit for bit the full tower
