@@ -15,8 +15,9 @@ pixray drives this package unchanged:
 
 Not carried over (outside SURVEY.md section 8): the notebook display calls, `--palette` / `--transparent_weight` parsing
 helpers of util.py that belong to PaletteLoss, the SLIP perceptors, ffmpeg video / gif assembly (the frame files are written;
-`make_video` / animation gif need ffmpeg and are skipped with a message when it is absent), the vdiff drawer (its source is
-not in the reference checkout).
+`make_video` / animation gif need ffmpeg and are skipped with a message when it is absent), the per-frame target-image prompt
+table of the animation mode (`pmsTargetTable`, pixray.py:772-795: target images score every frame here), the vdiff drawer (its
+source is not in the reference checkout).
 """
 from __future__ import annotations
 
