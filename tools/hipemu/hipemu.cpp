@@ -201,6 +201,12 @@ void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
         traced = true;
     }
     static const bool log = getenv("HIPEMU_LOG") != nullptr;
+    static const bool env_once = [] {            // HIPEMU_ORDER=reverse: the same as hipemu_set_reverse_order(1), for whole test runs
+        const char* o = getenv("HIPEMU_ORDER");
+        if (o && !strcmp(o, "reverse")) reverse_order = true;
+        return true;
+    }();
+    (void)env_once;
     if (log) fprintf(stderr, "hipemu: launch grid (%u,%u,%u) block (%u,%u,%u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z);
     if (in_kernel) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
     nthreads = (int)(block.x * block.y * block.z);
