@@ -1120,6 +1120,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
     if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { fit_tile = false; if (!fourwave_tile(BM, BN)) { BM = 128; BN = 128; } }
     if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
+    if (!fit_tile && BM == 256 && BN == 128 && (d.a_is_f32 || !cx.use_glds)) BM = 128;     // the 8-wave tile exists as a DMA kernel only (16-bit A)
     const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
     a.d = d;

@@ -1,0 +1,183 @@
+"""Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv SEED N`
+from the repo root for longer runs).  Every case draws a shape (ragged against every tile), leading dimensions, operand precision,
+a fused epilogue and a kernel family (planner's choice, a forced fit tile with or without producer waves, the register-staged
+kernels, split-K, the 8-phase tile) and compares with a float64 product / torch conv2d of the same rounded operands.  Argument
+combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong."""
+import math
+import random
+
+import torch
+import torch.nn.functional as F
+
+FIT = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
+PREC = {"bf16": 0, "f32": 1, "fp16": 2}
+
+
+def _reset(lib, ctx):
+    lib.prx_gemm_tile_override(ctx, 0, 0, 0); lib.prx_gemm_tile_override(ctx, -8, 0, 1)
+    lib.prx_gemm_tile_override(ctx, -12, 0, 0); lib.prx_gemm_tile_override(ctx, -3, 0, 1)
+
+
+def _family(lib, ctx, rng, prec, conv):
+    """draws the kernel family for one case and sets the tool context's overrides accordingly"""
+    _reset(lib, ctx)
+    mode = rng.choice(["heur", "heur", "fit", "prod", "v1"] + ([] if conv else ["splitk", "8p"]))
+    if mode in ("fit", "prod") and prec != "f32":
+        t = rng.choice([t for t in FIT if not (conv and t[0] == 80)])
+        lib.prx_gemm_tile_override(ctx, -12, 0, 1); lib.prx_gemm_tile_override(ctx, t[0], t[1], 1)
+        lib.prx_gemm_tile_override(ctx, -8, 0, 65 if mode == "prod" else rng.choice([0, 1]))
+        return f"{mode}{t}"
+    if mode == "8p":
+        lib.prx_gemm_tile_override(ctx, 256, 256, 1)
+    elif mode == "v1":
+        lib.prx_gemm_tile_override(ctx, -3, 0, 0)
+    elif mode == "splitk":
+        t = rng.choice([(64, 64), (128, 64), (128, 128)])
+        lib.prx_gemm_tile_override(ctx, t[0], t[1], rng.choice([2, 3, 4]))
+        return f"{mode}{t}"
+    return mode
+
+
+def gemm_cases(lib, seed, ncase):
+    """row-major products; returns the list of failing case descriptions"""
+    from pixray_amd import _lib
+    from pixray_amd._lib import GemmArgs, call
+    ctx = _lib.tool_ctx()
+    rng = random.Random(seed)
+    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    bad = []
+    for case in range(ncase):
+        prec = rng.choice(["bf16", "fp16", "f32"])
+        dt = DT[prec]
+        kq = 4 if prec == "f32" else 8
+        M = rng.choice([1, 2, 7, 16, 33, 64, 80, 100, 129, 160, 255, 256, 257, 300, 400, 513, 640])
+        N = rng.choice([8, 16, 24, 40, 64, 72, 128, 136, 192, 200, 256, 264, 384, 520])
+        K = kq * rng.choice([1, 2, 3, 8, 9, 16, 17, 32, 48, 64, 96, 128, 144])
+        desc = _family(lib, ctx, rng, prec, conv=False)
+        g0 = torch.Generator().manual_seed(seed * 1000 + case)
+        lda = K + kq * rng.choice([0, 0, 1, 5]); ldb = K + kq * rng.choice([0, 0, 2]); ldc = N + rng.choice([0, 0, 8, 24])
+        a32 = prec != "f32" and rng.random() < 0.3                   # fp32 A converted on load
+        a_full = torch.randn(M, lda, generator=g0)
+        a_full = a_full if a32 else a_full.to(dt)
+        b_full = (torch.randn(N, ldb, generator=g0) / math.sqrt(K)).to(dt)
+        A, Bt = a_full[:, :K].to(dt), b_full[:, :K]
+        epi = rng.choice(["plain", "bias", "bias+resid", "gelu", "dgelu", "relu", "biasm", "relumask", "relumask_post"])
+        g = GemmArgs()
+        g.A = a_full.data_ptr(); g.lda = lda; g.a_is_f32 = int(a32); g.B = b_full.data_ptr(); g.ldb = ldb
+        g.M, g.N, g.K = M, N, K
+        g.alpha = rng.choice([1.0, 0.5]); g.f32 = PREC[prec]
+        ref = g.alpha * (A.double() @ Bt.double().T)
+        keep = []
+        if epi in ("bias", "bias+resid", "gelu", "relu"):
+            b = torch.randn(N, generator=g0); keep.append(b); g.bias_n = b.data_ptr(); ref = ref + b.double()
+        if epi == "biasm":
+            bm = torch.randn(M, generator=g0); keep.append(bm); g.bias_m = bm.data_ptr(); ref = ref + bm.double()[:, None]
+        if epi in ("bias+resid", "relumask_post"):
+            r = torch.randn(M, N, generator=g0); keep.append(r); g.resid = r.data_ptr(); g.ldr = N; ref = ref + r.double()
+        if epi in ("dgelu", "relumask", "relumask_post"):
+            aux = torch.randn(M, N, generator=g0).to(dt); keep.append(aux); g.aux = aux.data_ptr(); g.ldaux = N
+        if epi == "gelu":
+            g.act = 1; ref = ref * torch.sigmoid(1.702 * ref)
+        if epi == "relu":
+            g.act = 3; ref = torch.relu(ref)
+        if epi == "dgelu":
+            g.act = 2; sgm = torch.sigmoid(1.702 * aux.double()); ref = ref * (sgm * (1 + 1.702 * aux.double() * (1 - sgm)))
+        if epi == "relumask":
+            g.act = 4; ref = ref * (aux.double() > 0)
+        if epi == "relumask_post":
+            g.act = 5; ref = ref * (aux.double() > 0)
+        out_full = torch.full((M, ldc), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = ldc
+        o16_full = torch.full((M, ldc), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = ldc
+        what = f"{case} {prec} M{M} N{N} K{K} {desc} {epi} a32={int(a32)} ld {lda} {ldb} {ldc}"
+        try:
+            call("prx_k_gemm", g, ws, ws.numel(), 0)
+        except RuntimeError as e:
+            bad.append(f"ERR {what}: {str(e)[:120]}")
+            continue
+        out, o16 = out_full[:, :N], o16_full[:, :N]
+        rel = float((out.double() - ref).norm() / (ref.norm() + 1e-30))
+        rel16 = float((o16.double() - ref).norm() / (ref.norm() + 1e-30))
+        tol = 3e-6 if prec == "f32" else 2e-5
+        tol16 = {"bf16": 6e-3, "fp16": 8e-4, "f32": 3e-6}[prec]
+        if epi == "gelu" and prec != "f32":             # the activation sees the 16-bit-rounded pre-activation
+            tol, tol16 = 1e-2, 1.2e-2
+        untouched = ldc == N or (torch.isnan(out_full[:, N:]).all() and torch.isnan(o16_full[:, N:]).all())
+        if not (rel < tol and rel16 < tol16 and untouched):
+            bad.append(f"BAD {what}: rel {rel:.2e} rel16 {rel16:.2e} pad-untouched {bool(untouched)}")
+    _reset(lib, ctx)
+    return bad
+
+
+def conv_cases(lib, seed, ncase):
+    """implicit 3x3 convolutions (plain, through the nearest-2x upsample, stride-2 Downsample); returns (failures, rejected)"""
+    from pixray_amd import _lib
+    from pixray_amd._lib import GemmArgs, call
+    ctx = _lib.tool_ctx()
+    rng = random.Random(seed)
+    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    bad, rejected = [], 0
+    for case in range(ncase):
+        prec = rng.choice(["bf16", "fp16"])
+        dt = DT[prec]
+        up = rng.choice([0, 0, 1, 2])
+        Ho = rng.choice([1, 2, 3, 4, 6, 8, 10, 12, 16, 18, 24, 32]); Wo = rng.choice([1, 2, 4, 5, 6, 8, 12, 16, 20, 32, 34])
+        if up == 1:
+            Ho, Wo = 2 * Ho, 2 * Wo
+        Cin = rng.choice([8, 16, 24, 32, 40, 64, 72, 128, 136, 192, 256]); Cout = rng.choice([8, 16, 24, 40, 64, 72, 128, 136, 256])
+        NB = rng.choice([1, 1, 2, 3])
+        desc = _family(lib, ctx, rng, prec, conv=True)
+        g0 = torch.Generator().manual_seed(seed * 1000 + case)
+        hin, win = {0: (Ho, Wo), 1: (Ho // 2, Wo // 2), 2: (2 * Ho, 2 * Wo)}[up]
+        x = torch.randn(NB, Cin, hin, win, generator=g0); w = torch.randn(Cout, Cin, 3, 3, generator=g0) / math.sqrt(9 * Cin)
+        bias = torch.randn(Cout, generator=g0)
+        a32 = rng.random() < 0.5
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+        x_in = x_nhwc if a32 else x_nhwc.to(dt)
+        w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dt)
+        M = NB * Ho * Wo
+        g = GemmArgs()
+        g.A = x_in.data_ptr(); g.a_is_f32 = int(a32); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
+        g.M, g.N, g.K = M, Cout, 9 * Cin
+        g.H, g.W, g.Cin, g.up = Ho, Wo, Cin, up
+        g.alpha = 1.0; g.f32 = PREC[prec]; g.bias_n = bias.data_ptr()
+        out = torch.full((M, Cout), float("nan")); g.out_f32 = out.data_ptr(); g.ldc_f32 = Cout
+        xr = x.to(dt).float()
+        if up == 1:
+            xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+        if up == 2:
+            ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w.to(dt).float(), bias, stride=2)
+        else:
+            ref = F.conv2d(xr, w.to(dt).float(), bias, padding=1)
+        ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+        what = f"{case} {prec} {Ho}x{Wo} Cin{Cin} Cout{Cout} up{up} NB{NB} {desc} a32={int(a32)}"
+        try:
+            call("prx_k_gemm", g, ws, ws.numel(), 0)
+        except RuntimeError as e:
+            if up == 2 and (a32 or Cin % 64 or desc == "v1") and "stride-2 gather needs" in str(e):
+                rejected += 1                               # documented: the Downsample gather is a 16-bit, Cin % 64 == 0, DMA-kernel path
+            else:
+                bad.append(f"ERR {what}: {str(e)[:120]}")
+            continue
+        rel = float((out - ref).norm() / ref.norm())
+        if not rel < 2e-5:
+            bad.append(f"BAD {what}: rel {rel:.2e}")
+    _reset(lib, ctx)
+    return bad, rejected
+
+
+if __name__ == "__main__":
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _emu
+    kind, seed, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    with _emu.enable() as lib:
+        t0 = time.time()
+        res = gemm_cases(lib, seed, n) if kind == "gemm" else conv_cases(lib, seed, n)
+        bad = res if kind == "gemm" else res[0]
+        print("\n".join(bad))
+        print(f"{kind} seed {seed}: {n} cases, {len(bad)} failed" + ("" if kind == "gemm" else f", {res[1]} rejected as documented") + f", {time.time() - t0:.0f} s")
+        sys.exit(1 if bad else 0)

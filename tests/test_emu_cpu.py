@@ -66,6 +66,18 @@ def test_fit_kernel_implicit_conv_and_groupnorm_epilogue_sums(emu):
     emu.tk.test_gemm_conv3x3_stride2_down(12, 20, 64, 72, 2)
 
 
+def test_gemm_engine_random_shapes_every_kernel_family(emu):
+    """300 random row-major products and 300 random implicit convolutions (tests/_emu_fuzz.py): ragged shapes against every tile,
+    strided operands and outputs, fp32 A converted on load, every fused epilogue, every kernel family (planner's choice, forced
+    fit tiles with and without producer waves, register-staged kernels, split-K, the 8-phase tile).  Unsupported combinations have
+    to be refused, not computed wrong.  (Found: a forced / big-tile 256 x 128 launch with an fp32 A fell through to the 64 x 64
+    register-staged kernel on the 256 x 128 grid and left most of the output unwritten.)"""
+    import _emu_fuzz
+    assert _emu_fuzz.gemm_cases(emu.lib, 1, 300) == []
+    bad, rejected = _emu_fuzz.conv_cases(emu.lib, 1, 300)
+    assert bad == [] and rejected > 0
+
+
 def test_fit_kernel_producer_wave_variants(emu):
     """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
     DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""

@@ -188,6 +188,10 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
                 xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
             ref = F.conv2d(xr, bf(w).float(), bias, padding=1).permute(0, 2, 3, 1).reshape(NB * H * W, Cout)
             assert rel_l2(out, ref) < 2e-5, (H, W, Cin, Cout, up, rel_l2(out, ref))
+            # fp32 A converted on load: a register-staged kernel (the 256 x 128 tile has none and is re-planned to 128 x 128)
+            out32, _, _ = run_gemm(x.permute(0, 2, 3, 1).contiguous(), w_pack, NB * H * W, Cout, 9 * Cin, a_mode=1, lda=Cin, H=H,
+                                   W=W, Cin=Cin, up=up, bias_n=bias)
+            assert rel_l2(out32, ref) < 2e-5, (H, W, Cin, Cout, up, rel_l2(out32, ref))
     finally:
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
