@@ -261,7 +261,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     PRX_REQUIRE(cur.pos == n_w, "vqgan_create: %d weight tensors given, %d consumed", n_w, cur.pos);
     // activations / scratch
     const size_t P0 = (size_t)h0 * w0, PH = (size_t)rh * rw;
-    size_t maxPC = 0, maxAttnPC = 1;
+    size_t maxPC = P0 * (size_t)std::max(z_channels, embed_dim), maxAttnPC = 1;      // conv_in's / post_quant_conv's input gradients land in the gradient streams too
     for (auto& rb : v->res) maxPC = std::max(maxPC, (size_t)rb.rh * rb.rw * std::max(rb.Cin, rb.Cout));
     for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.rh * ub.rw * ub.C);
     for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)pad8(ab.rh * ab.rw) * (size_t)std::max(ab.C, pad8(ab.rh * ab.rw)));

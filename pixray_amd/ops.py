@@ -443,6 +443,17 @@ def clip_encode_text_tokens(tokens, handle: ClipTextHandle):
 
 
 # --------------------------------------------------------------------------------------- VQGAN
+def _single_attn_resolution(cfg) -> int:
+    """taming places AttnBlocks at every level whose NOMINAL resolution (config `resolution` halved per level) is listed in
+    `attn_resolutions`; the C ABI carries one such resolution (every published VQGAN config has one: [16], or [32]).  A config in
+    which two listed resolutions are actually visited is refused here rather than built with attention missing."""
+    visited = {cfg.resolution >> k for k in range(len(cfg.ch_mult))}
+    hits = sorted(set(int(r) for r in cfg.attn_resolutions) & visited)
+    if len(hits) > 1:
+        raise ValueError(f"VQGAN config with attention at {len(hits)} resolutions {hits}: the runner supports one")
+    return hits[0] if hits else -1
+
+
 class VqganHandle:
     """Owns a `prx_vqgan` (codebook, weight packs, activations of one forward).  `precision`: "fp16" (default) | "bf16" | "f32"."""
 
@@ -456,7 +467,7 @@ class VqganHandle:
             c.ch_mult[i] = m
         c.n_mult = len(cfg.ch_mult)
         c.num_res_blocks = cfg.num_res_blocks
-        c.attn_resolution = cfg.attn_resolutions[0] if len(cfg.attn_resolutions) else -1
+        c.attn_resolution = _single_attn_resolution(cfg)
         c.resolution = cfg.resolution
         c.z_channels = cfg.z_channels
         c.embed_dim = cfg.embed_dim
@@ -553,7 +564,7 @@ class VqganEncHandle:
             c.ch_mult[i] = m
         c.n_mult = len(cfg.ch_mult)
         c.num_res_blocks = cfg.num_res_blocks
-        c.attn_resolution = cfg.attn_resolutions[0] if len(cfg.attn_resolutions) else -1
+        c.attn_resolution = _single_attn_resolution(cfg)
         c.resolution = cfg.resolution
         c.z_channels = cfg.z_channels
         c.embed_dim = cfg.embed_dim

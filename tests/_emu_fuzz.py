@@ -1,4 +1,4 @@
-"""Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv SEED N`
+"""Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv|gn SEED N`
 from the repo root for longer runs).  Every case draws a shape (ragged against every tile), leading dimensions, operand precision,
 a fused epilogue and a kernel family (planner's choice, a forced fit tile with or without producer waves, the register-staged
 kernels, split-K, the 8-phase tile) and compares with a float64 product / torch conv2d of the same rounded operands.  Argument
@@ -22,7 +22,7 @@ def _reset(lib, ctx):
 def _family(lib, ctx, rng, prec, conv):
     """draws the kernel family for one case and sets the tool context's overrides accordingly"""
     _reset(lib, ctx)
-    mode = rng.choice(["heur", "heur", "fit", "prod", "v1"] + ([] if conv else ["splitk", "8p"]))
+    mode = rng.choice(["heur", "heur", "fit", "prod", "v1", "splitk"] + ([] if conv else ["8p"]))
     if mode in ("fit", "prod") and prec != "f32":
         t = rng.choice([t for t in FIT if not (conv and t[0] == 80)])
         lib.prx_gemm_tile_override(ctx, -12, 0, 1); lib.prx_gemm_tile_override(ctx, t[0], t[1], 1)
@@ -87,22 +87,23 @@ def gemm_cases(lib, seed, ncase):
             g.act = 4; ref = ref * (aux.double() > 0)
         if epi == "relumask_post":
             g.act = 5; ref = ref * (aux.double() > 0)
-        out_full = torch.full((M, ldc), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = ldc
-        o16_full = torch.full((M, ldc), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = ldc
+        out_full = torch.full((M + 3, ldc), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = ldc       # 3 spare rows: must stay untouched
+        o16_full = torch.full((M + 3, ldc), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = ldc
         what = f"{case} {prec} M{M} N{N} K{K} {desc} {epi} a32={int(a32)} ld {lda} {ldb} {ldc}"
         try:
             call("prx_k_gemm", g, ws, ws.numel(), 0)
         except RuntimeError as e:
             bad.append(f"ERR {what}: {str(e)[:120]}")
             continue
-        out, o16 = out_full[:, :N], o16_full[:, :N]
+        out, o16 = out_full[:M, :N], o16_full[:M, :N]
         rel = float((out.double() - ref).norm() / (ref.norm() + 1e-30))
         rel16 = float((o16.double() - ref).norm() / (ref.norm() + 1e-30))
         tol = 3e-6 if prec == "f32" else 2e-5
         tol16 = {"bf16": 6e-3, "fp16": 8e-4, "f32": 3e-6}[prec]
         if epi == "gelu" and prec != "f32":             # the activation sees the 16-bit-rounded pre-activation
             tol, tol16 = 1e-2, 1.2e-2
-        untouched = ldc == N or (torch.isnan(out_full[:, N:]).all() and torch.isnan(o16_full[:, N:]).all())
+        untouched = torch.isnan(out_full[M:]).all() and torch.isnan(o16_full[M:]).all() and (
+            ldc == N or (torch.isnan(out_full[:, N:]).all() and torch.isnan(o16_full[:, N:]).all()))
         if not (rel < tol and rel16 < tol16 and untouched):
             bad.append(f"BAD {what}: rel {rel:.2e} rel16 {rel16:.2e} pad-untouched {bool(untouched)}")
     _reset(lib, ctx)
@@ -141,7 +142,9 @@ def conv_cases(lib, seed, ncase):
         g.M, g.N, g.K = M, Cout, 9 * Cin
         g.H, g.W, g.Cin, g.up = Ho, Wo, Cin, up
         g.alpha = 1.0; g.f32 = PREC[prec]; g.bias_n = bias.data_ptr()
-        out = torch.full((M, Cout), float("nan")); g.out_f32 = out.data_ptr(); g.ldc_f32 = Cout
+        out_full = torch.full((M + 3, Cout), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout    # 3 spare rows: must stay untouched
+        o16_full = torch.full((M + 3, Cout), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = Cout
+        out = out_full[:M]
         xr = x.to(dt).float()
         if up == 1:
             xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
@@ -160,10 +163,85 @@ def conv_cases(lib, seed, ncase):
                 bad.append(f"ERR {what}: {str(e)[:120]}")
             continue
         rel = float((out - ref).norm() / ref.norm())
-        if not rel < 2e-5:
-            bad.append(f"BAD {what}: rel {rel:.2e}")
+        untouched = bool(torch.isnan(out_full[M:]).all() and torch.isnan(o16_full[M:]).all())
+        if not (rel < 2e-5 and untouched):
+            bad.append(f"BAD {what}: rel {rel:.2e} spare-rows-untouched {untouched}")
     _reset(lib, ctx)
     return bad, rejected
+
+
+def gn_cases(lib, seed, ncase):
+    """implicit convolutions with the decoder's GroupNorm epilogues (prx_k_gemm_gn): the next GroupNorm's sums, or a
+    GroupNorm-backward's sums of a dgrad-shaped launch; outputs carry 3 spare rows that must stay untouched"""
+    from pixray_amd import _lib
+    from pixray_amd._lib import GemmArgs, call
+    ctx = _lib.tool_ctx()
+    rng = random.Random(seed)
+    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    bad = []
+    for case in range(ncase):
+        prec = rng.choice(["bf16", "fp16"])
+        dt = DT[prec]
+        up = rng.choice([0, 0, 1])
+        Ho = rng.choice([1, 2, 3, 4, 7, 8, 14, 16]); Wo = rng.choice([1, 2, 5, 8, 16, 25])
+        if up == 1:
+            Ho, Wo = 2 * Ho, 2 * Wo
+        Cin = rng.choice([64, 128, 256]); Cout = rng.choice([128, 256, 512]); NB = 1
+        desc = _family(lib, ctx, rng, prec, conv=True)
+        g0 = torch.Generator().manual_seed(seed * 1000 + case)
+        hin, win = (Ho // 2, Wo // 2) if up else (Ho, Wo)
+        x = torch.randn(NB, Cin, hin, win, generator=g0); w = torch.randn(Cout, Cin, 3, 3, generator=g0) / math.sqrt(9 * Cin)
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dt)
+        w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dt)
+        M = NB * Ho * Wo
+        gs = Cout // 32
+        xr = x.to(dt).float()
+        if up:
+            xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+        ref = F.conv2d(xr, w.to(dt).float(), None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+        backward = rng.random() < 0.5
+        g = GemmArgs()
+        g.A = x_nhwc.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
+        g.M, g.N, g.K = M, Cout, 9 * Cin
+        g.H, g.W, g.Cin, g.up = Ho, Wo, Cin, up
+        g.alpha = 1.0; g.f32 = PREC[prec]
+        out_full = torch.full((M + 3, Cout), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout
+        stats_full = torch.zeros(128, dtype=torch.float64); stats_full[64:] = float("nan")        # a second block of sums behind: untouched
+        what = f"{case} {prec} {Ho}x{Wo} Cin{Cin} Cout{Cout} up{up} {desc} {'gn-backward' if backward else 'gn-forward'} sums"
+        try:
+            if backward:
+                xg = torch.randn(M, Cout, generator=g0)
+                x64 = xg.double().view(M, 32, gs)
+                fstats = torch.stack([x64.sum(dim=(0, 2)), (x64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1).contiguous()
+                gamma, beta = torch.randn(Cout, generator=g0), torch.randn(Cout, generator=g0)
+                call("prx_k_gemm_gn", g, stats_full, gs, xg, fstats, gamma, beta, 1, 1e-6, ws, ws.numel(), 0)
+            else:
+                call("prx_k_gemm_gn", g, stats_full, gs, None, None, None, None, 0, 1e-6, ws, ws.numel(), 0)
+        except RuntimeError as e:
+            if not (desc == "v1" and "need the v2 kernel" in str(e)):          # documented: the register-staged kernels have no sums epilogue
+                bad.append(f"ERR {what}: {str(e)[:120]}")
+            continue
+        out = out_full[:M]
+        o64 = out.double().view(M, 32, gs)
+        if backward:
+            n = M * gs
+            mean = fstats.view(32, 2)[:, 0] / n
+            rstd = 1.0 / torch.sqrt((fstats.view(32, 2)[:, 1] / n - mean ** 2).clamp(min=0) + 1e-6)
+            xh = (x64 - mean.view(1, 32, 1)) * rstd.view(1, 32, 1)
+            y = xh.float().double() * gamma.double().view(1, 32, gs) + beta.double().view(1, 32, gs)
+            sg = torch.sigmoid(y)
+            dxh = o64 * (sg * (1 + y * (1 - sg))) * gamma.double().view(1, 32, gs)
+            want = torch.stack([dxh.sum(dim=(0, 2)), (dxh * xh).sum(dim=(0, 2))], dim=1).reshape(-1)
+            close = torch.allclose(stats_full[:64], want, rtol=5e-4, atol=5e-2)
+        else:
+            want = torch.stack([o64.sum(dim=(0, 2)), (o64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1)
+            close = torch.allclose(stats_full[:64], want, rtol=1e-5, atol=1e-3)
+        rel = float((out - ref).norm() / ref.norm())
+        untouched = bool(torch.isnan(out_full[M:]).all() and torch.isnan(stats_full[64:]).all())
+        if not (rel < 2e-5 and close and untouched):
+            bad.append(f"BAD {what}: rel {rel:.2e} sums-match {bool(close)} spare-untouched {untouched}")
+    _reset(lib, ctx)
+    return bad
 
 
 if __name__ == "__main__":
@@ -176,8 +254,8 @@ if __name__ == "__main__":
     kind, seed, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     with _emu.enable() as lib:
         t0 = time.time()
-        res = gemm_cases(lib, seed, n) if kind == "gemm" else conv_cases(lib, seed, n)
-        bad = res if kind == "gemm" else res[0]
+        res = {"gemm": gemm_cases, "conv": conv_cases, "gn": gn_cases}[kind](lib, seed, n)
+        bad = res[0] if kind == "conv" else res
         print("\n".join(bad))
-        print(f"{kind} seed {seed}: {n} cases, {len(bad)} failed" + ("" if kind == "gemm" else f", {res[1]} rejected as documented") + f", {time.time() - t0:.0f} s")
+        print(f"{kind} seed {seed}: {n} cases, {len(bad)} failed" + (f", {res[1]} rejected as documented" if kind == "conv" else "") + f", {time.time() - t0:.0f} s")
         sys.exit(1 if bad else 0)

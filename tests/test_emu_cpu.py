@@ -78,6 +78,36 @@ def test_gemm_engine_random_shapes_every_kernel_family(emu):
     assert bad == [] and rejected > 0
 
 
+def test_gemm_groupnorm_epilogues_random_shapes(emu):
+    """the decoder's fused GroupNorm sums (forward, and a GroupNorm-backward's of a dgrad-shaped launch) over random conv shapes
+    and kernel families incl. split-K; spare output rows and a second block of sums behind the first must stay untouched"""
+    import _emu_fuzz
+    assert _emu_fuzz.gn_cases(emu.lib, 0, 150) == []
+
+
+def test_device_allocations_are_red_zoned_and_the_decoder_fits_a_wide_latent(emu):
+    """tools/hipemu gives every hipMalloc a red zone checked after each launch.  Found with it: a decoder whose z_channels exceed
+    its widest block (256 latent channels into a 128-channel network) wrote conv_in's input gradient past the gradient stream
+    buffers (sized from the blocks alone).  Runs that configuration; an overrun aborts the process."""
+    import test_path_gpu as tp
+    from pixray_amd import weights
+    weights.VQGAN_CONFIGS["wide-latent"] = weights.VqganConfig(ch=128, ch_mult=(1,), num_res_blocks=2, attn_resolutions=(16,),
+                                                               resolution=16, z_channels=256, embed_dim=256, n_embed=64)
+    try:
+        ref, out, gref, gd, idx_ref, idx = tp._vqgan_case("wide-latent", (2, 3), 3)
+        assert tp.rel_l2(out, ref) < 2e-2 and tp.rel_l2(gd, gref) < 5e-2 and torch.equal(idx, idx_ref)
+    finally:
+        del weights.VQGAN_CONFIGS["wide-latent"]
+    # two attention resolutions that are both visited cannot be expressed in the C ABI: refused by name, not built wrong
+    from pixray_amd import ops
+    cfg = weights.VqganConfig(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16, 32), resolution=32, z_channels=128,
+                              embed_dim=128, n_embed=64)
+    with pytest.raises(ValueError, match="attention at 2 resolutions"):
+        ops.VqganHandle(cfg, weights.synthetic_vqgan_params(cfg, 0), (2, 2), "cpu")
+    assert ops._single_attn_resolution(weights.VqganConfig()) == 16
+    assert ops._single_attn_resolution(weights.VqganConfig(attn_resolutions=(16, 32), resolution=32, ch_mult=(1,))) == 32
+
+
 def test_fit_kernel_producer_wave_variants(emu):
     """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
     DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""

@@ -77,8 +77,11 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : 2; }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// device allocations carry a 4 KB red zone on both sides; every launch end and every hipFree checks them (hipemu.cpp), so a
+// kernel that writes past a workspace is named at the launch that did it instead of corrupting a neighbour silently
+namespace hipemu { void* dev_alloc(size_t n); void dev_free(void* p); }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)hipemu::dev_alloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipFree(void* p) { hipemu::dev_free(p); return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -6,6 +6,7 @@
 #undef gridDim
 #include <sys/mman.h>
 #include <deque>
+#include <map>
 #include <vector>
 #include <execinfo.h>
 #include <signal.h>
@@ -187,6 +188,51 @@ void on_segv(int sig) {
 }
 }  // namespace
 
+// ---- guarded device allocations ---------------------------------------------------------------------------------
+namespace {
+constexpr size_t GUARD = 4096;
+constexpr unsigned char GUARD_BYTE = 0xA5;
+std::map<char*, size_t>& live_allocs() { static std::map<char*, size_t> m; return m; }
+unsigned long long launch_count = 0;
+bool zone_clean(const char* z) {
+    for (size_t i = 0; i < GUARD; ++i) if ((unsigned char)z[i] != GUARD_BYTE) return false;
+    return true;
+}
+void check_guards(const char* when) {
+    for (auto& kv : live_allocs()) {
+        const bool lo = zone_clean(kv.first - GUARD), hi = zone_clean(kv.first + kv.second);
+        if (lo && hi) continue;
+        const char* z = lo ? kv.first + kv.second : kv.first - GUARD;
+        size_t first = 0;
+        while ((unsigned char)z[first] == GUARD_BYTE) ++first;
+        size_t last = GUARD - 1;
+        while ((unsigned char)z[last] == GUARD_BYTE) --last;
+        fprintf(stderr, "hipemu: %s: write %s a device allocation of %zu bytes (bytes %zu..%zu of the %s red zone), launch #%llu\n", when,
+                lo ? "past the end of" : "before the start of", kv.second, first, last, lo ? "upper" : "lower", launch_count);
+        void* bt[48];
+        backtrace_symbols_fd(bt, backtrace(bt, 48), 2);
+        abort();
+    }
+}
+}  // namespace
+void* dev_alloc(size_t n) {
+    const size_t body = (n + 255) / 256 * 256;
+    char* raw = (char*)aligned_alloc(4096, body + 2 * GUARD);
+    if (!raw) return nullptr;
+    memset(raw, GUARD_BYTE, GUARD);
+    memset(raw + GUARD + n, GUARD_BYTE, body - n + GUARD);        // the red zone starts at the first byte past the request
+    live_allocs()[raw + GUARD] = n;
+    return raw + GUARD;
+}
+void dev_free(void* p) {
+    if (!p) return;
+    auto it = live_allocs().find((char*)p);
+    if (it == live_allocs().end()) { fprintf(stderr, "hipemu: hipFree of a pointer hipMalloc did not return\n"); abort(); }
+    check_guards("hipFree");
+    live_allocs().erase(it);
+    free((char*)p - GUARD);
+}
+
 void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
     static bool traced = false;
     if (!traced && getenv("HIPEMU_TRACE")) {       // a backtrace instead of a bare crash (set before the first launch)
@@ -223,6 +269,8 @@ void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
     }
     in_kernel = false;
     body_fn = nullptr;
+    ++launch_count;
+    check_guards("kernel launch");
 }
 
 void syncthreads() { yield(AT_BARRIER); }
