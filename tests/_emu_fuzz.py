@@ -1,8 +1,9 @@
-"""Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv|gn SEED N`
+"""Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv|gn|vit|vqgan|runners SEED N`
 from the repo root for longer runs).  Every case draws a shape (ragged against every tile), leading dimensions, operand precision,
 a fused epilogue and a kernel family (planner's choice, a forced fit tile with or without producer waves, the register-staged
 kernels, split-K, the 8-phase tile) and compares with a float64 product / torch conv2d of the same rounded operands.  Argument
-combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong."""
+combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong.  The second half sweeps the
+RUNNERS (ViT, VQGAN decoder and encoder, ModifiedResNet) over random geometries against the fp32 oracle."""
 import math
 import random
 
@@ -244,6 +245,109 @@ def gn_cases(lib, seed, ncase):
     return bad
 
 
+# ---------------------------------------------------------------------------------------------- runners on random geometries
+def vit_cases(lib, seed, ncase):
+    """CLIP ViT runner: random patch size / grid / width / depth / embedding width / batch against the fp32 oracle (forward and the
+    gradient w.r.t. the cutouts)"""
+    import test_path_gpu as tp
+    from pixray_amd import weights
+    rng = random.Random(seed)
+    bad = []
+    for i in range(ncase):
+        patch = rng.choice([8, 14, 16, 32]); side = rng.choice([1, 2, 3, 4, 5, 7, 9, 12, 16])
+        width = rng.choice([256, 512, 768]); layers = rng.choice([1, 2, 3]); out = rng.choice([64, 128, 200, 512]); nb = rng.choice([1, 2, 3, 5])
+        name = f"fuzz-vit-{seed}-{i}"
+        weights.CLIP_CONFIGS[name] = weights.ClipVitConfig(name, patch * side, patch, width, layers, width // 64, out)
+        what = f"{i} res {patch * side} patch {patch} ({side * side + 1} tokens) width {width} layers {layers} out {out} batch {nb}"
+        try:
+            ref, o, gref, gd = tp._clip_case(name, nb, seed * 100 + i)
+            r1, r2 = tp.rel_l2(o, ref), tp.rel_l2(gd, gref)
+            if not (r1 < 2e-2 and r2 < 3e-2):
+                bad.append(f"BAD {what}: out {r1:.1e} grad {r2:.1e}")
+        except Exception as e:      # noqa: BLE001 -- a sweep reports every failure
+            bad.append(f"ERR {what}: {type(e).__name__} {str(e)[:160]}")
+        finally:
+            del weights.CLIP_CONFIGS[name]
+    return bad
+
+
+def vqgan_cases(lib, seed, ncase):
+    """VQGAN decoder runner: random depth / channel multipliers / blocks / latent channels / attention placement / non-square
+    latents down to 1 x 1 against the fp32 oracle (image, gradient w.r.t. z, chosen codes)"""
+    import test_path_gpu as tp
+    from pixray_amd import weights
+    rng = random.Random(seed)
+    bad = []
+    for i in range(ncase):
+        nlev = rng.choice([1, 2, 3]); ch = rng.choice([128, 256]); mult = tuple([1] + [rng.choice([1, 2]) for _ in range(nlev - 1)])
+        nrb = rng.choice([1, 2]); zc = rng.choice([128, 256]); hw = (rng.choice([1, 2, 3, 4, 5, 8]), rng.choice([1, 2, 3, 6, 8]))
+        res = 16 * 2 ** (nlev - 1) * rng.choice([1, 2]); attn = rng.choice([(16,), (), (32,)])
+        name = f"fuzz-vqgan-{seed}-{i}"
+        weights.VQGAN_CONFIGS[name] = weights.VqganConfig(ch=ch, ch_mult=mult, num_res_blocks=nrb, attn_resolutions=attn, resolution=res,
+                                                         z_channels=zc, embed_dim=zc, n_embed=rng.choice([64, 200, 512]))
+        what = f"{i} ch {ch} mult {mult} blocks {nrb} z {zc} latent {hw} resolution {res} attention {attn}"
+        try:
+            ref, out, gref, gd, idx_ref, idx = tp._vqgan_case(name, hw, seed * 100 + i)
+            r1, r2 = tp.rel_l2(out, ref), tp.rel_l2(gd, gref)
+            # (a 1 x 1 or 1 x 2 latent normalises over 4-8 values per group: the gradient is that sensitive to operand rounding)
+            if not (r1 < 3e-2 and r2 < (6e-2 if hw[0] * hw[1] > 2 else 2e-1) and float((idx_ref != idx).float().mean()) < 0.02):
+                bad.append(f"BAD {what}: image {r1:.1e} grad {r2:.1e} codes differing {int((idx_ref != idx).sum())}")
+        except Exception as e:      # noqa: BLE001
+            bad.append(f"ERR {what}: {type(e).__name__} {str(e)[:160]}")
+        finally:
+            del weights.VQGAN_CONFIGS[name]
+    return bad
+
+
+def resnet_encoder_cases(lib, seed, ncase):
+    """CLIP ModifiedResNet runner (exact-f32 and fp16 operands) and the VQGAN encoder runner on random geometries"""
+    import test_path_gpu as tp
+    from oracle import clip_resnet_ref, vqgan_ref
+    from pixray_amd import ops, weights
+    rng = random.Random(seed)
+    bad = []
+    for i in range(ncase):
+        try:
+            if rng.random() < 0.4:
+                width = rng.choice([16, 32, 64, 80]); res = 32 * rng.choice([1, 2, 3]); layers = tuple(rng.choice([1, 2]) for _ in range(4))
+                out = rng.choice([64, 96]); nb = rng.choice([1, 2, 3]); prec = rng.choice(["f32", "fp16"])
+                what = f"{i} resnet width {width} res {res} layers {layers} out {out} batch {nb} {prec}"
+                cfg = weights.ClipResNetConfig(f"fuzz-rn-{i}", res, width, layers, width * 32 // 64, out)
+                p = weights.synthetic_clip_resnet_params(cfg, seed=seed * 100 + i)
+                h = ops.ClipResNetHandle(cfg, p, max_batch=nb, device="cpu", precision=prec)
+                g = torch.Generator().manual_seed(i)
+                cut = torch.rand(nb, 3, res, res, generator=g); ge = torch.randn(nb, out, generator=g)
+                cr = cut.clone().requires_grad_(True)
+                ref = clip_resnet_ref.encode_image(p, cr, layers=cfg.layers, heads=cfg.heads)
+                (gref,) = torch.autograd.grad(ref, cr, ge)
+                cd = cut.clone().requires_grad_(True)
+                emb = ops.clip_encode_image(cd, h)
+                (gd,) = torch.autograd.grad(emb, cd, ge)
+                r1, r2 = tp.rel_l2(emb, ref), tp.rel_l2(gd, gref)
+                ok = (r1 < 2e-4 and r2 < 2e-3) if prec == "f32" else (r1 < 2e-2 and r2 < 3e-1)      # fp16: ReLU-mask flips (test_path_gpu.py)
+            else:
+                nlev = rng.choice([1, 2, 3]); mult = tuple([1] + [rng.choice([1, 2]) for _ in range(nlev - 1)])
+                nrb = rng.choice([1, 2]); zc = rng.choice([64, 128, 256]); f = 2 ** (nlev - 1)
+                hw = (f * rng.choice([1, 2, 3, 5, 8]), f * rng.choice([1, 2, 4, 7]))
+                res = 16 * f * rng.choice([1, 2]); attn = rng.choice([(16,), (), (32,)])
+                what = f"{i} encoder mult {mult} blocks {nrb} z {zc} image {hw} resolution {res} attention {attn}"
+                cfg = weights.VqganConfig(ch=128, ch_mult=mult, num_res_blocks=nrb, attn_resolutions=attn, resolution=res, z_channels=zc,
+                                          embed_dim=zc, n_embed=rng.choice([64, 200]))
+                p = weights.synthetic_vqgan_encoder_params(cfg, seed=seed * 100 + i)
+                eh = ops.VqganEncHandle(cfg, p, hw, "cpu")
+                img = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(i)) * 2 - 1
+                z, idx, pre = ops.vqgan_encode(img, eh, return_pre=True)
+                with torch.no_grad():
+                    z_ref, idx_ref, pre_ref = vqgan_ref.encode(p, img, cfg.oracle_cfg())
+                r1, r2 = tp.rel_l2(pre, pre_ref), 0.0
+                ok = r1 < 2e-2 and z.shape == z_ref.shape
+            if not ok:
+                bad.append(f"BAD {what}: {r1:.1e} {r2:.1e}")
+        except Exception as e:      # noqa: BLE001
+            bad.append(f"ERR {what}: {type(e).__name__} {str(e)[:160]}")
+    return bad
+
+
 if __name__ == "__main__":
     import os
     import sys
@@ -254,7 +358,10 @@ if __name__ == "__main__":
     kind, seed, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     with _emu.enable() as lib:
         t0 = time.time()
-        res = {"gemm": gemm_cases, "conv": conv_cases, "gn": gn_cases}[kind](lib, seed, n)
+        import test_path_gpu
+        test_path_gpu.DEV = "cpu"
+        res = {"gemm": gemm_cases, "conv": conv_cases, "gn": gn_cases, "vit": vit_cases, "vqgan": vqgan_cases,
+               "runners": resnet_encoder_cases}[kind](lib, seed, n)
         bad = res[0] if kind == "conv" else res
         print("\n".join(bad))
         print(f"{kind} seed {seed}: {n} cases, {len(bad)} failed" + (f", {res[1]} rejected as documented" if kind == "conv" else "") + f", {time.time() - t0:.0f} s")

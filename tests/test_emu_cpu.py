@@ -108,6 +108,16 @@ def test_device_allocations_are_red_zoned_and_the_decoder_fits_a_wide_latent(emu
     assert ops._single_attn_resolution(weights.VqganConfig(attn_resolutions=(16, 32), resolution=32, ch_mult=(1,))) == 32
 
 
+def test_runners_on_random_geometries(emu):
+    """a few random geometries per runner (tests/_emu_fuzz.py; `python tests/_emu_fuzz.py vit|vqgan|runners SEED N` for long sweeps):
+    ViT (patch / grid / width / depth / batch), VQGAN decoder (depth, multipliers, latent channels, attention placement, latents
+    down to 1 x 1), ModifiedResNet (exact-f32 and fp16) and the VQGAN encoder, each against the fp32 oracle under the red zones"""
+    import _emu_fuzz
+    assert _emu_fuzz.vit_cases(emu.lib, 2, 2) == []
+    assert _emu_fuzz.vqgan_cases(emu.lib, 2, 4) == []
+    assert _emu_fuzz.resnet_encoder_cases(emu.lib, 2, 6) == []
+
+
 def test_fit_kernel_producer_wave_variants(emu):
     """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
     DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""
