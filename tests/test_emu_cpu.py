@@ -433,7 +433,7 @@ def test_two_ranks_on_the_emulated_kernels_match_one_process():
 # ------------------------------------------------------------------------------------------------ the real architectures (minutes)
 _SLOW = pytest.mark.skipif(os.environ.get("PRX_EMU_SLOW", "0") != "1",
                            reason="full-depth runners on the CPU emulation take minutes: PRX_EMU_SLOW=1 (ViT-B/32 1 min, VQGAN 256^2 4 min, "
-                                  "the headline iteration at 16 cutouts 10 min)")
+                                  "the headline iteration at 16 cutouts 10 min, seven session-level GPU tests 1 min each)")
 
 
 @_SLOW
@@ -462,3 +462,27 @@ def test_headline_configuration_one_iteration_16_cutouts_all_switches(emu, monke
         monkeypatch.setenv(k, v)
     r = step_ref.compare_one_iteration(precision="fp16", cutn=16, device="cpu")
     assert r["indices_equal"] and r["loss_abs_err"] < 1e-3 and r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r
+
+
+@_SLOW
+@pytest.mark.parametrize("name", ["test_widescreen_one_iteration_vs_oracle", "test_custom_loss_and_filter_compose_with_native_ops",
+                                  "test_image_prompts_and_init_regularisers_vs_oracle", "test_two_perceptors_share_one_decoder_pass",
+                                  "test_text_prompt_vector_prompt_and_init_image_session", "test_overlay_image_goes_through_the_hip_encoder",
+                                  "test_cutout_shards_reproduce_the_unsharded_gradient"])
+def test_session_level_gpu_tests_on_the_emulated_kernels(emu, monkeypatch, tmp_path, name):
+    """the GPU suite's session-level tests (tests/test_e2e_gpu.py: image prompts and init regularisers, two perceptors on one decoder
+    pass, text / vector prompts + init image, the overlay through the HIP encoder, custom losses and filters, the widescreen canvas,
+    cutout shards) with the session built on the emulated device; about a minute each"""
+    import inspect
+    import test_e2e_gpu as te
+    from pixray_amd import api
+    build = api.build_vqgan_clip_session
+    monkeypatch.setattr(api, "build_vqgan_clip_session", lambda *a, **k: build(*a, **{**k, "device": "cpu"}))
+    monkeypatch.setattr(te, "DEV", "cpu")
+    fn = getattr(te, name)
+    kw = {}
+    if "precision" in inspect.signature(fn).parameters:
+        kw["precision"] = "fp16"
+    if "tmp_path" in inspect.signature(fn).parameters:
+        kw["tmp_path"] = tmp_path
+    fn(**kw)
