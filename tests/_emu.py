@@ -15,6 +15,8 @@ EMU_LIB = os.path.join(EMU_DIR, "libprx_emu.so")
 
 
 def build() -> str:
+    if os.environ.get("HIPEMU_LIB"):           # a checking build made by hand (tools/hipemu/Makefile, SAN=...)
+        return os.environ["HIPEMU_LIB"]
     subprocess.run(["make", "-C", EMU_DIR, "-j", str(os.cpu_count() or 4)], check=True, stdout=subprocess.DEVNULL)
     return EMU_LIB
 
@@ -22,10 +24,10 @@ def build() -> str:
 @contextlib.contextmanager
 def enable():
     from pixray_amd import _lib, ops
-    build()
+    emu_lib = build()
     saved = dict(avail_fn=_lib.device_available, path=_lib.LIB_PATH, lib=_lib._lib, protos=_lib._protos, ctx=_lib._tool_ctx, stream=_lib.current_stream,
                  need=ops._need_cuda, warr=ops._weight_array, sync=torch.cuda.synchronize, avail=torch.cuda.is_available)
-    _lib.LIB_PATH, _lib._lib, _lib._protos, _lib._tool_ctx = EMU_LIB, None, None, None
+    _lib.LIB_PATH, _lib._lib, _lib._protos, _lib._tool_ctx = emu_lib, None, None, None
     _lib.current_stream = lambda: 0
     _lib.device_available = lambda: True
     ops._need_cuda = lambda *ts: None

@@ -217,7 +217,7 @@ void check_guards(const char* when) {
 }  // namespace
 void* dev_alloc(size_t n) {
     const size_t body = (n + 255) / 256 * 256;
-    char* raw = (char*)aligned_alloc(4096, body + 2 * GUARD);
+    char* raw = (char*)aligned_alloc(4096, (body + 2 * GUARD + 4095) / 4096 * 4096);
     if (!raw) return nullptr;
     memset(raw, GUARD_BYTE, GUARD);
     memset(raw + GUARD + n, GUARD_BYTE, body - n + GUARD);        // the red zone starts at the first byte past the request
@@ -244,6 +244,7 @@ void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
         sa.sa_flags = SA_ONSTACK;
         sigaction(SIGSEGV, &sa, nullptr);
         sigaction(SIGBUS, &sa, nullptr);
+        sigaction(SIGILL, &sa, nullptr);       // -fsanitize-trap builds
         traced = true;
     }
     static const bool log = getenv("HIPEMU_LOG") != nullptr;
