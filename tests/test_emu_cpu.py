@@ -486,3 +486,13 @@ def test_session_level_gpu_tests_on_the_emulated_kernels(emu, monkeypatch, tmp_p
     if "tmp_path" in inspect.signature(fn).parameters:
         kw["tmp_path"] = tmp_path
     fn(**kw)
+
+
+@_SLOW
+def test_front_end_on_the_emulated_hip_parts(emu, monkeypatch, tmp_path):
+    """tests/test_zz_frontend_gpu.py's settings -> PNG run (HIP VQGAN drawer, cutouts, CLIP tower, prompt loss; 7 iterations of the
+    reduced configuration) with the session on the emulated device; the optimiser is torch's Adam here (the fused kernel is chosen
+    for device tensors), everything else is the product path"""
+    import test_zz_frontend_gpu as tf
+    monkeypatch.setattr(tf, "DEV", "cpu")
+    tf.test_settings_to_png_on_the_hip_path(tmp_path)

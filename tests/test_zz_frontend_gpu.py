@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 pytestmark = pytest.mark.gpu
+DEV = None          # None: the front end's own choice (cuda:0 on a GPU box); tests/test_emu_cpu.py sets "cpu" for the emulated device
 
 
 def test_settings_to_png_on_the_hip_path(tmp_path):
@@ -22,9 +23,10 @@ def test_settings_to_png_on_the_hip_path(tmp_path):
                         display_every=4, outdir=str(tmp_path / "out"), seed=3, skip_args=True, init_noise="none", vector_prompts="none",
                         noise_prompt_seeds=[1, 2], noise_prompt_weights=[1.0, 0.5], precision="fp16", learning_rate_drops=[])
     s = fe.apply_settings(run=run)
-    sess = fe.do_init(s, run)
+    sess = fe.do_init(s, run, device=DEV)
     assert sess.drawer.size == (64, 64)                                 # 66 rounded down to a multiple of 2^(resolutions-1)
-    assert sess.drawer.get_z().is_cuda and isinstance(sess.opts[0], HipAdam)
+    if DEV is None:
+        assert sess.drawer.get_z().is_cuda and isinstance(sess.opts[0], HipAdam)
     assert len(sess.pmsTable["tiny-B/32"]) == 2
     z0 = sess.drawer.get_z_copy()
     seen = []
