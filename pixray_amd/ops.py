@@ -105,6 +105,20 @@ def make_cutouts(img, desc, noise, S, base_hw=None, spot_mask=None):
 
 
 # --------------------------------------------------------------------------------------- CLIP ViT
+def _weights_in_abi_order(params, shapes, device, what):
+    """the C ABI takes bare device pointers in a documented order (include/prx.h): a missing tensor or one whose shape is not the
+    one the configuration implies would be read out of bounds on the device, so both are refused here by name"""
+    ws = []
+    for name, shape in shapes.items():
+        if name not in params:
+            raise KeyError(f"{what}: the weights have no tensor named {name!r}")
+        t = params[name]
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what}: {name} has shape {tuple(t.shape)}, the configuration implies {tuple(shape)}")
+        ws.append(t.to(device=device, dtype=torch.float32).contiguous())
+    return ws
+
+
 class ClipVitHandle:
     """Owns a `prx_clip_vit` (packed weights + activation workspace for `max_batch` cutouts).
     `precision`: "fp16" (default) / "bf16" (fast paths) or "f32" (exact-f32 MFMA parity mode, include/prx.h PRX_PREC_*)."""
@@ -112,8 +126,7 @@ class ClipVitHandle:
 
     def __init__(self, cfg, params, max_batch: int, device, precision=None):
         from .weights import clip_vit_param_shapes
-        names = list(clip_vit_param_shapes(cfg).keys())
-        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        ws = _weights_in_abi_order(params, clip_vit_param_shapes(cfg), device, f"CLIP ViT {getattr(cfg, 'name', '')}")
         self.precision = precision_code(precision)
         c = _ClipCfg(cfg.input_resolution, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch, self.precision)
         h = ctypes.c_void_p()
@@ -155,7 +168,8 @@ class ClipResNetHandle:
     abi = "prx_clip_resnet"
 
     def __init__(self, cfg, params, max_batch: int, device, precision=None):
-        from .weights import fold_clip_resnet_params
+        from .weights import clip_resnet_param_shapes, fold_clip_resnet_params
+        _weights_in_abi_order(params, clip_resnet_param_shapes(cfg), "cpu", f"CLIP ModifiedResNet {getattr(cfg, 'name', '')}")   # names / shapes only
         folded = fold_clip_resnet_params(cfg, params)
         ws = [t.to(device=device, dtype=torch.float32).contiguous() for t in folded.values()]
         self.precision = precision_code(precision)
@@ -404,8 +418,7 @@ class ClipTextHandle:
 
     def __init__(self, cfg, params, max_batch: int, device):
         from .weights import clip_text_param_shapes
-        names = list(clip_text_param_shapes(cfg).keys())
-        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        ws = _weights_in_abi_order(params, clip_text_param_shapes(cfg), device, f"CLIP text tower {getattr(cfg, 'name', '')}")
         c = _ClipTextCfg(cfg.vocab_size, cfg.context_length, cfg.width, cfg.layers, cfg.heads, cfg.output_dim, max_batch)
         h = ctypes.c_void_p()
         call("prx_clip_text_create", ctypes.addressof(h), ctypes.addressof(c), _keep(self, _weight_array(ws)), len(ws), _stream())
@@ -459,8 +472,7 @@ class VqganHandle:
 
     def __init__(self, cfg, params, latent_hw, device, precision=None):
         from .weights import vqgan_param_shapes
-        names = list(vqgan_param_shapes(cfg).keys())
-        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        ws = _weights_in_abi_order(params, vqgan_param_shapes(cfg), device, "VQGAN decoder")
         c = _VqganCfg()
         c.ch = cfg.ch
         for i, m in enumerate(cfg.ch_mult):
@@ -556,8 +568,7 @@ class VqganEncHandle:
 
     def __init__(self, cfg, params, image_hw, device, in_channels: int = 3):
         from .weights import vqgan_encoder_param_shapes
-        names = list(vqgan_encoder_param_shapes(cfg, in_channels).keys())
-        ws = [params[k].to(device=device, dtype=torch.float32).contiguous() for k in names]
+        ws = _weights_in_abi_order(params, vqgan_encoder_param_shapes(cfg, in_channels), device, "VQGAN encoder")
         c = _VqganCfg()
         c.ch = cfg.ch
         for i, m in enumerate(cfg.ch_mult):
@@ -664,10 +675,8 @@ class Vgg16Handle:
 
     def __init__(self, params, max_hw, device, precision=None):
         self.precision = precision_code(precision)
-        ws = []
-        for i in VGG16_CONV_INDICES:
-            ws.append(params[f"features.{i}.weight"].to(device=device, dtype=torch.float32).contiguous())
-            ws.append(params[f"features.{i}.bias"].to(device=device, dtype=torch.float32).contiguous())
+        from .weights import vgg16_param_shapes
+        ws = _weights_in_abi_order(params, vgg16_param_shapes(), device, "VGG16")
         h = ctypes.c_void_p()
         call("prx_vgg16_create", ctypes.addressof(h), _keep(self, _weight_array(ws)), len(ws), int(max_hw[0]), int(max_hw[1]),
              self.precision, _stream())

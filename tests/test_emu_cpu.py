@@ -118,6 +118,33 @@ def test_runners_on_random_geometries(emu):
     assert _emu_fuzz.resnet_encoder_cases(emu.lib, 2, 6) == []
 
 
+def test_handles_refuse_weights_whose_shapes_do_not_fit_the_configuration(emu):
+    """the C ABI takes bare pointers: a tensor smaller than the configuration implies would be read out of bounds on the device
+    (AddressSanitizer on the emulated create shows exactly that), so the Python handles check names and shapes first"""
+    from pixray_amd import ops, weights
+    cfg = weights.VQGAN_CONFIGS["tiny_f4"]
+    p = dict(weights.synthetic_vqgan_params(cfg, 0))
+    name = next(k for k in p if k.endswith("conv_in.weight"))
+    bad = dict(p); bad[name] = bad[name][:, :-1].contiguous()
+    with pytest.raises(ValueError, match="the configuration implies"):
+        ops.VqganHandle(cfg, bad, (4, 4), "cpu")
+    del bad[name]
+    with pytest.raises(KeyError, match="no tensor named"):
+        ops.VqganHandle(cfg, bad, (4, 4), "cpu")
+    vcfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    vp = dict(weights.synthetic_clip_vit_params(vcfg, 0))
+    vp["conv1.weight"] = vp["conv1.weight"][:, :, :16].contiguous()
+    with pytest.raises(ValueError, match="conv1.weight"):
+        ops.ClipVitHandle(vcfg, vp, max_batch=1, device="cpu")
+    g = dict(weights.synthetic_vgg16_params(0)); g["features.0.bias"] = g["features.0.bias"][:32]
+    with pytest.raises(ValueError, match="features.0.bias"):
+        ops.Vgg16Handle(g, (32, 32), torch.device("cpu"), precision="f32")
+    rcfg = weights.CLIP_RESNET_CONFIGS["tiny-RN"]
+    rp = dict(weights.synthetic_clip_resnet_params(rcfg, 0)); rp.pop("layer1.0.bn1.running_var")
+    with pytest.raises(KeyError, match="running_var"):
+        ops.ClipResNetHandle(rcfg, rp, max_batch=1, device="cpu")
+
+
 def test_fit_kernel_producer_wave_variants(emu):
     """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
     DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""
