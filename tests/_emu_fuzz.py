@@ -2,7 +2,8 @@
 from the repo root for longer runs).  Every case draws a shape (ragged against every tile), leading dimensions, operand precision,
 a fused epilogue and a kernel family (planner's choice, a forced fit tile with or without producer waves, the register-staged
 kernels, split-K, the 8-phase tile) and compares with a float64 product / torch conv2d of the same rounded operands.  Argument
-combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong.  The second half sweeps the
+combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong.  `device="cuda"` runs the same
+sweeps on the GPU (tests/test_kernels_gpu.py).  The second half sweeps the
 RUNNERS (ViT, VQGAN decoder and encoder, ModifiedResNet) over random geometries against the fp32 oracle."""
 import math
 import random
@@ -13,6 +14,13 @@ import torch.nn.functional as F
 FIT = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
 PREC = {"bf16": 0, "f32": 1, "fp16": 2}
+
+
+def _host(t):
+    """a result back on the host (after the device has finished, when there is one)"""
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    return t.cpu()
 
 
 def _reset(lib, ctx):
@@ -40,13 +48,13 @@ def _family(lib, ctx, rng, prec, conv):
     return mode
 
 
-def gemm_cases(lib, seed, ncase):
+def gemm_cases(lib, seed, ncase, device="cpu"):
     """row-major products; returns the list of failing case descriptions"""
     from pixray_amd import _lib
     from pixray_amd._lib import GemmArgs, call
     ctx = _lib.tool_ctx()
     rng = random.Random(seed)
-    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=device)
     bad = []
     for case in range(ncase):
         prec = rng.choice(["bf16", "fp16", "f32"])
@@ -65,19 +73,20 @@ def gemm_cases(lib, seed, ncase):
         A, Bt = a_full[:, :K].to(dt), b_full[:, :K]
         epi = rng.choice(["plain", "bias", "bias+resid", "gelu", "dgelu", "relu", "biasm", "relumask", "relumask_post"])
         g = GemmArgs()
-        g.A = a_full.data_ptr(); g.lda = lda; g.a_is_f32 = int(a32); g.B = b_full.data_ptr(); g.ldb = ldb
+        a_dev, b_dev = a_full.to(device), b_full.to(device)
+        g.A = a_dev.data_ptr(); g.lda = lda; g.a_is_f32 = int(a32); g.B = b_dev.data_ptr(); g.ldb = ldb
         g.M, g.N, g.K = M, N, K
         g.alpha = rng.choice([1.0, 0.5]); g.f32 = PREC[prec]
         ref = g.alpha * (A.double() @ Bt.double().T)
         keep = []
         if epi in ("bias", "bias+resid", "gelu", "relu"):
-            b = torch.randn(N, generator=g0); keep.append(b); g.bias_n = b.data_ptr(); ref = ref + b.double()
+            b = torch.randn(N, generator=g0); keep.append(b.to(device)); g.bias_n = keep[-1].data_ptr(); ref = ref + b.double()
         if epi == "biasm":
-            bm = torch.randn(M, generator=g0); keep.append(bm); g.bias_m = bm.data_ptr(); ref = ref + bm.double()[:, None]
+            bm = torch.randn(M, generator=g0); keep.append(bm.to(device)); g.bias_m = keep[-1].data_ptr(); ref = ref + bm.double()[:, None]
         if epi in ("bias+resid", "relumask_post"):
-            r = torch.randn(M, N, generator=g0); keep.append(r); g.resid = r.data_ptr(); g.ldr = N; ref = ref + r.double()
+            r = torch.randn(M, N, generator=g0); keep.append(r.to(device)); g.resid = keep[-1].data_ptr(); g.ldr = N; ref = ref + r.double()
         if epi in ("dgelu", "relumask", "relumask_post"):
-            aux = torch.randn(M, N, generator=g0).to(dt); keep.append(aux); g.aux = aux.data_ptr(); g.ldaux = N
+            aux = torch.randn(M, N, generator=g0).to(dt); keep.append(aux.to(device)); g.aux = keep[-1].data_ptr(); g.ldaux = N
         if epi == "gelu":
             g.act = 1; ref = ref * torch.sigmoid(1.702 * ref)
         if epi == "relu":
@@ -88,14 +97,15 @@ def gemm_cases(lib, seed, ncase):
             g.act = 4; ref = ref * (aux.double() > 0)
         if epi == "relumask_post":
             g.act = 5; ref = ref * (aux.double() > 0)
-        out_full = torch.full((M + 3, ldc), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = ldc       # 3 spare rows: must stay untouched
-        o16_full = torch.full((M + 3, ldc), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = ldc
+        out_full = torch.full((M + 3, ldc), float("nan"), device=device); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = ldc       # 3 spare rows: must stay untouched
+        o16_full = torch.full((M + 3, ldc), float("nan"), dtype=dt, device=device); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = ldc
         what = f"{case} {prec} M{M} N{N} K{K} {desc} {epi} a32={int(a32)} ld {lda} {ldb} {ldc}"
         try:
             call("prx_k_gemm", g, ws, ws.numel(), 0)
         except RuntimeError as e:
             bad.append(f"ERR {what}: {str(e)[:120]}")
             continue
+        out_full, o16_full = _host(out_full), _host(o16_full)
         out, o16 = out_full[:M, :N], o16_full[:M, :N]
         rel = float((out.double() - ref).norm() / (ref.norm() + 1e-30))
         rel16 = float((o16.double() - ref).norm() / (ref.norm() + 1e-30))
@@ -111,13 +121,13 @@ def gemm_cases(lib, seed, ncase):
     return bad
 
 
-def conv_cases(lib, seed, ncase):
+def conv_cases(lib, seed, ncase, device="cpu"):
     """implicit 3x3 convolutions (plain, through the nearest-2x upsample, stride-2 Downsample); returns (failures, rejected)"""
     from pixray_amd import _lib
     from pixray_amd._lib import GemmArgs, call
     ctx = _lib.tool_ctx()
     rng = random.Random(seed)
-    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=device)
     bad, rejected = [], 0
     for case in range(ncase):
         prec = rng.choice(["bf16", "fp16"])
@@ -139,13 +149,13 @@ def conv_cases(lib, seed, ncase):
         w_pack = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dt)
         M = NB * Ho * Wo
         g = GemmArgs()
+        x_in, w_pack, bias_dev = x_in.to(device), w_pack.to(device), bias.to(device)
         g.A = x_in.data_ptr(); g.a_is_f32 = int(a32); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
         g.M, g.N, g.K = M, Cout, 9 * Cin
         g.H, g.W, g.Cin, g.up = Ho, Wo, Cin, up
-        g.alpha = 1.0; g.f32 = PREC[prec]; g.bias_n = bias.data_ptr()
-        out_full = torch.full((M + 3, Cout), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout    # 3 spare rows: must stay untouched
-        o16_full = torch.full((M + 3, Cout), float("nan"), dtype=dt); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = Cout
-        out = out_full[:M]
+        g.alpha = 1.0; g.f32 = PREC[prec]; g.bias_n = bias_dev.data_ptr()
+        out_full = torch.full((M + 3, Cout), float("nan"), device=device); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout    # 3 spare rows: must stay untouched
+        o16_full = torch.full((M + 3, Cout), float("nan"), dtype=dt, device=device); g.out_bf16 = o16_full.data_ptr(); g.ldc_bf16 = Cout
         xr = x.to(dt).float()
         if up == 1:
             xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
@@ -163,6 +173,8 @@ def conv_cases(lib, seed, ncase):
             else:
                 bad.append(f"ERR {what}: {str(e)[:120]}")
             continue
+        out_full, o16_full = _host(out_full), _host(o16_full)
+        out = out_full[:M]
         rel = float((out - ref).norm() / ref.norm())
         untouched = bool(torch.isnan(out_full[M:]).all() and torch.isnan(o16_full[M:]).all())
         if not (rel < 2e-5 and untouched):
@@ -171,14 +183,14 @@ def conv_cases(lib, seed, ncase):
     return bad, rejected
 
 
-def gn_cases(lib, seed, ncase):
+def gn_cases(lib, seed, ncase, device="cpu"):
     """implicit convolutions with the decoder's GroupNorm epilogues (prx_k_gemm_gn): the next GroupNorm's sums, or a
     GroupNorm-backward's sums of a dgrad-shaped launch; outputs carry 3 spare rows that must stay untouched"""
     from pixray_amd import _lib
     from pixray_amd._lib import GemmArgs, call
     ctx = _lib.tool_ctx()
     rng = random.Random(seed)
-    ws = torch.empty(16 << 20, dtype=torch.uint8)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device=device)
     bad = []
     for case in range(ncase):
         prec = rng.choice(["bf16", "fp16"])
@@ -202,12 +214,14 @@ def gn_cases(lib, seed, ncase):
         ref = F.conv2d(xr, w.to(dt).float(), None, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
         backward = rng.random() < 0.5
         g = GemmArgs()
+        x_nhwc, w_pack = x_nhwc.to(device), w_pack.to(device)
         g.A = x_nhwc.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
         g.M, g.N, g.K = M, Cout, 9 * Cin
         g.H, g.W, g.Cin, g.up = Ho, Wo, Cin, up
         g.alpha = 1.0; g.f32 = PREC[prec]
-        out_full = torch.full((M + 3, Cout), float("nan")); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout
+        out_full = torch.full((M + 3, Cout), float("nan"), device=device); g.out_f32 = out_full.data_ptr(); g.ldc_f32 = Cout
         stats_full = torch.zeros(128, dtype=torch.float64); stats_full[64:] = float("nan")        # a second block of sums behind: untouched
+        stats_full = stats_full.to(device)
         what = f"{case} {prec} {Ho}x{Wo} Cin{Cin} Cout{Cout} up{up} {desc} {'gn-backward' if backward else 'gn-forward'} sums"
         try:
             if backward:
@@ -215,13 +229,15 @@ def gn_cases(lib, seed, ncase):
                 x64 = xg.double().view(M, 32, gs)
                 fstats = torch.stack([x64.sum(dim=(0, 2)), (x64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1).contiguous()
                 gamma, beta = torch.randn(Cout, generator=g0), torch.randn(Cout, generator=g0)
-                call("prx_k_gemm_gn", g, stats_full, gs, xg, fstats, gamma, beta, 1, 1e-6, ws, ws.numel(), 0)
+                dev = [t.to(device) for t in (xg, fstats, gamma, beta)]
+                call("prx_k_gemm_gn", g, stats_full, gs, dev[0], dev[1], dev[2], dev[3], 1, 1e-6, ws, ws.numel(), 0)
             else:
                 call("prx_k_gemm_gn", g, stats_full, gs, None, None, None, None, 0, 1e-6, ws, ws.numel(), 0)
         except RuntimeError as e:
             if not (desc == "v1" and "need the v2 kernel" in str(e)):          # documented: the register-staged kernels have no sums epilogue
                 bad.append(f"ERR {what}: {str(e)[:120]}")
             continue
+        out_full, stats_full = _host(out_full), _host(stats_full)
         out = out_full[:M]
         o64 = out.double().view(M, 32, gs)
         if backward:

@@ -270,6 +270,25 @@ PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128), (128, 128), (128, 6
 
 
 @pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
+                    reason="the random-shape sweeps have run on the CPU emulation only so far (tests/test_emu_cpu.py); they force the "
+                           "producer-wave variants too: PRX_TEST_EXPERIMENTAL=1, first run under a short `timeout`")
+@pytest.mark.parametrize("kind", ["gemm", "conv", "gn"])
+def test_gemm_engine_random_shapes_on_the_device(kind):
+    """tests/_emu_fuzz.py on the GPU: 600 random products / 600 random implicit convolutions / 300 GroupNorm-epilogue launches over
+    every kernel family, spare rows and columns of the outputs checked for stray writes"""
+    import _emu_fuzz
+    lib = _lib.load()
+    if kind == "gemm":
+        bad = _emu_fuzz.gemm_cases(lib, 11, 600, device=DEV)
+    elif kind == "conv":
+        bad, rejected = _emu_fuzz.conv_cases(lib, 11, 600, device=DEV)
+        assert rejected > 0
+    else:
+        bad = _emu_fuzz.gn_cases(lib, 11, 300, device=DEV)
+    assert bad == [], "\n".join(bad[:20])
+
+
+@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
                     reason="producer-wave fit kernels: validated on the CPU emulation only so far (tests/test_emu_cpu.py); "
                            "PRX_TEST_EXPERIMENTAL=1 runs them on the device -- wrap the first run in a short `timeout`")
 @pytest.mark.parametrize("tile", PROD_TILES, ids=lambda t: f"{t[0]}x{t[1]}")

@@ -13,6 +13,8 @@ mkdir -p gpurun_out
 export PRX_TEST_EXPERIMENTAL=1
 timeout 150 python -m pytest tests/test_kernels_gpu.py tests/test_zz_frontend_gpu.py -q -k "producer_wave or fft_drawer_hip or tower_lanes" > gpurun_out/r05_producer_tests.log 2>&1; echo "producer tests rc=$?"
 tail -3 gpurun_out/r05_producer_tests.log
+timeout 240 python -m pytest tests/test_kernels_gpu.py -q -k "random_shapes_on_the_device" > gpurun_out/r05_sweeps.log 2>&1; echo "random-shape sweeps on the device rc=$?"
+tail -25 gpurun_out/r05_sweeps.log | cut -c1-300
 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_base.json 2> gpurun_out/r05_bench_base.err; echo "bench base rc=$?"
 PRX_FIT_FLAGS=65 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_prod.json 2> gpurun_out/r05_bench_prod.err; echo "bench producers rc=$?"
 PRX_VIT_CLS_TAIL=1 timeout 200 python bench.py --steps 40 --warmup 8 --no-other-modes --no-cpu-baseline > gpurun_out/r05_bench_cls.json 2> gpurun_out/r05_bench_cls.err; echo "bench class-token tail rc=$?"
