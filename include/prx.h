@@ -281,7 +281,7 @@ int prx_strotss_selfsim_bwd(const float* Gx, int ldgx, const float* xs, const fl
                             const float* g_out, float* Sx, float* Sy, int lds, float* cx, float* cy, prx_stream_t s);
 
 /* --- MakeCutouts.forward (pixray.py:445-511) with explicit randomness.
- * desc: fp64 [n_cut][32] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
+ * desc: fp64 [n_cut][36] per-cutout descriptor (built by pixray_amd/cutouts.py::build_descriptors):
  *   [0..8] stage-A 3x3, [9..17] stage-B 3x3: kornia's src_norm_trans_dst_norm (normalised destination
  *          coords -> normalised source coords, [0,W-1]->[-1,1] convention),
  *   [18] stage-A mode, [19] stage-B mode (0 copy, 1 zeros, 2 border, 3 reflection, 4 fill, 5 reflection under align_corners=True),
@@ -292,11 +292,14 @@ int prx_strotss_selfsim_bwd(const float* Gx, int ldgx, const float* xs, const fl
  *   1 warp_affine(align_corners=False): F.affine_grid pixel-centre grid (RandomAffine); 2 warp_affine(align_corners=True):
  *   corner-aligned grid sampled with (g+1)/2*(W-1) (RandomResizedCrop / CenterCrop via crop_by_transform_mat);
  *   3 warp_perspective(align_corners=True) (the cached-transform path, pixray.py:482-485),
- *   [28..31] stage-B source window (x, y, width, height) inside the stage-A image.
+ *   [28..31] stage-B source window (x, y, width, height) inside the stage-A image,
+ *   [32] noise seed (an integer < 2^53, 0 = none): with `noise` NULL and a non-zero factor [25] the cutout's additive N(0,1)
+ *        draws (pixray.py:508-510, randn_like) are generated in the kernel -- Philox4x32-10 keyed by the seed, counter = pixel
+ *        index, Box-Muller; [33..35] reserved (zero).
  * Geometry: the canvas is pooled to [3,S,S] (pixray.py:463); on a W != H canvas the reference rescales that to the
  * canvas aspect (pixray.py:468-472): the "base" image [3,Hb,Wb] with Hb == S or Wb == S (Hb = Wb = S on a square
  * canvas, `base` may then be NULL).  Stage A renders [n_cut,3,Hb,Wb] from the base, stage B the S x S cutouts.
- * noise: fp32 [n_cut,3,S,S] N(0,1) draws or NULL.  pooled/argmax/base/stage_a are caller-owned save-for-backward
+ * noise: fp32 [n_cut,3,S,S] explicit N(0,1) draws (parity tests hand the oracle's), or NULL (see [32]).  pooled/argmax/base/stage_a are caller-owned save-for-backward
  * buffers ([3,S,S] f32, [3,S,S] i32, [3,Hb,Wb] f32, [n_cut,3,Hb,Wb] f32).
  * spot_mask (optional): uint8 [3,S,S]; pooled pixels where it is non-zero are set to 0 (spot prompts, pixray.py:453-466). */
 int prx_cutouts_forward(const float* img, int H, int W, const double* desc, const float* noise, const unsigned char* spot_mask,
@@ -394,10 +397,11 @@ void prx_clip_text_destroy(prx_clip_text* h);
 int prx_clip_text_encode(prx_clip_text* h, const int* tokens, int n, float* embeds, prx_stream_t s);
 
 /* --- Prompt.forward (pixray.py:275-280) fused with its backward.
- * rowloss[i] = sum_j sign(w) * 2*asin(|x^_i - e^_j|/2)^2 (forward value: |w| * sum(rowloss)/denom);
+ * rowloss[i] = sum_j sign(w) * 2*asin(|x^_i - e^_j|/2)^2;  *loss (optional, may be NULL) = |w| * sum(rowloss) / denom, the value
+ * Prompt.forward returns (rows added in a fixed order);
  * grad = d/d input of |w| * mean(max(sign(w) d, stop)) with the mean over `denom` (= global n*m) pairs. */
 int prx_prompt_loss_fwd_bwd(const float* input, const float* embed, int n, int m, int D, float weight, float stop,
-                            float denom, float* rowloss, float* grad, prx_stream_t s);
+                            float denom, float* rowloss, float* grad, float* loss, prx_stream_t s);
 
 /* --- optim.Adam([z], lr) step (pixray.py:539,1484-1485) fused with VqganDrawer.clip_z (vqgan.py:202-204).
  * z/exp_avg/exp_avg_sq/grad: [1,C,hw] fp32; zmin/zmax per channel or NULL; step is 1-based. */

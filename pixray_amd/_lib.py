@@ -16,11 +16,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER_PATH = os.path.join(_ROOT, "include", "prx.h")
 LIB_PATH = os.path.join(_HERE, "csrc", "libprx_hip.so")
-# PRX_LIB_PATH: another build of the SAME library (e.g. `make -C pixray_amd/csrc sched` -> libprx_hip_sched.so, the fit kernels with a
-# pinned stage schedule, for an A/B); a bare file name is looked up beside the default
-if os.environ.get("PRX_LIB_PATH"):
-    _alt = os.environ["PRX_LIB_PATH"]
-    LIB_PATH = _alt if os.path.isabs(_alt) else os.path.join(_HERE, "csrc", _alt)
 
 
 class PrxError(RuntimeError):

@@ -204,9 +204,6 @@ def session_gemm_contexts(sess: Session):
         h = getattr(p, "handle", None)
         if h is not None and hasattr(h, "gemm_ctx"):
             ctxs.append(h.gemm_ctx)
-        lanes = getattr(p, "lanes", None)               # PRX_VIT_LANES: the extra chunk handles launch GEMMs too
-        for hx in (lanes.handles[1:] if lanes is not None else ()):
-            ctxs.append(hx.gemm_ctx)
     for t in sess.custom_losses:
         owner = getattr(t["loss"], "extractor", None) or t["loss"]       # StyleLoss keeps its VGG16 runner in `.extractor`
         h = getattr(owner, "handle", None)

@@ -1,6 +1,6 @@
 #pragma once
 #include "common.h"
-#define PRX_CUT_DESC_WORDS 32
+#define PRX_CUT_DESC_WORDS 36
 int prx_pool_fwd(const float* img, float* pooled, int* argmax, const unsigned char* mask, int C, int H, int W, int S, hipStream_t s);
 int prx_pool_bwd(const float* g, const int* argmax, const unsigned char* mask, float* gimg, int C, int H, int W, int S, hipStream_t s);
 // stage A renders Ha x Wa images from the shared Hs x Ws source; stage B reads them through the descriptor's window

@@ -22,12 +22,13 @@
 
 namespace {
 
-constexpr int DESC_WORDS = 32;
+constexpr int DESC_WORDS = 36;
 // descriptor word offsets (all stored as fp64; the two 3x3 matrices map NORMALISED destination coordinates to
 // NORMALISED source coordinates exactly as kornia builds them, so sampling positions round like the oracle's)
 enum { D_M1 = 0, D_M2 = 9, D_MODE1 = 18, D_MODE2 = 19, D_FILL = 20, D_JIT = 21, D_SAT = 22, D_HUE = 23,
        D_SATFIRST = 24, D_NOISE = 25, D_GRID1 = 26, D_GRID2 = 27,
-       D_WOX = 28, D_WOY = 29, D_WW = 30, D_WH = 31 };   // stage-B source window inside the stage-A image (x, y, width, height)
+       D_WOX = 28, D_WOY = 29, D_WW = 30, D_WH = 31,     // stage-B source window inside the stage-A image (x, y, width, height)
+       D_SEED = 32 };   // != 0 and no noise tensor given: the additive N(0,1) draws of this cutout come from Philox4x32-10 keyed by it (words 33-35 spare)
 // grid flavour of a stage = which kornia 0.6.2 call built its sampling grid AND the align_corners flag that call passed to
 // F.grid_sample (the convention is part of the descriptor, not an assumption of the kernel):
 //   GRID_MESH       warp_perspective(align_corners=False): create_meshgrid + transform_points, sampled with (g+1)*W/2 - 0.5
@@ -1055,6 +1056,30 @@ __device__ __forceinline__ SrcWin src_window(const double* d) {
     return q;
 }
 
+// The additive noise of pixray.py:508-510 (`batch + fac * randn_like(batch)`) drawn inside the kernel when the caller hands no
+// noise tensor: Philox4x32-10 (Salmon et al., SC'11; the generator behind torch.randn on a GPU) keyed by the cutout's seed word,
+// counter = the pixel index, two Box-Muller pairs per call -> the pixel's three channels.  Saves the randn launch, its 12 bytes
+// per pixel of stores and their re-read here.
+__device__ __forceinline__ void philox_normal3(unsigned long long seed, unsigned pix, float (&z)[3]) {
+    unsigned c0 = pix, c1 = 0u, c2 = 0x5bd1e995u, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = (float)(c1 >> 8) * (1.f / 16777216.f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = (float)(c3 >> 8) * (1.f / 16777216.f);
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    float s0, q0, s1, q1;
+    sincosf(6.283185307179586f * u1, &s0, &q0);
+    sincosf(6.283185307179586f * u3, &s1, &q1);
+    z[0] = r0 * q0; z[1] = r0 * s0; z[2] = r1 * q1;
+    (void)s1;
+}
+
 __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict__ a, int Ha, int Wa, const double* __restrict__ desc,
                                                          const float* __restrict__ noise, float* __restrict__ out,
                                                          int n_cut, int S) {
@@ -1080,10 +1105,13 @@ __global__ __launch_bounds__(256) void warp_b_fwd_kernel(const float* __restrict
         if (d[D_JIT] != 0.0) jitter_d<0>(rgb, (float)d[D_SAT], (float)d[D_HUE], d[D_SATFIRST] != 0.0);
         const float nf = (float)d[D_NOISE];
         float* o = out + (size_t)n * 3 * plane + pix;
+        float zn[3] = {0.f, 0.f, 0.f};
+        if (!noise && nf != 0.f && d[D_SEED] != 0.0) philox_normal3((unsigned long long)d[D_SEED], (unsigned)pix, zn);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = rgb[c].v;
             if (noise) v += nf * noise[(size_t)n * 3 * plane + c * plane + pix];
+            else v += nf * zn[c];
             o[c * plane] = v;
         }
     }
@@ -1299,9 +1327,24 @@ __global__ __launch_bounds__(256) void rescale_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, size_t n,
                                                              float* __restrict__ part) {
     float mn = INFINITY, mx = -INFINITY;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = x[i];
-        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)x) & 15) == 0) {           // 16-byte loads, two in flight per lane (one pass over 38.5 MB at the headline: HBM-bound)
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const size_t n4 = n >> 2;
+        size_t i = tid;
+        for (; i + nthr < n4; i += 2 * nthr) {
+            const float4 a = x4[i], b = x4[i + nthr];
+            mn = fminf(fminf(mn, fminf(a.x, a.y)), fminf(fminf(a.z, a.w), fminf(fminf(b.x, b.y), fminf(b.z, b.w))));
+            mx = fmaxf(fmaxf(mx, fmaxf(a.x, a.y)), fmaxf(fmaxf(a.z, a.w), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+        }
+        for (; i < n4; i += nthr) {
+            const float4 a = x4[i];
+            mn = fminf(fminf(mn, fminf(a.x, a.y)), fminf(a.z, a.w));
+            mx = fmaxf(fmaxf(mx, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+        }
+        for (size_t j = (n4 << 2) + tid; j < n; j += nthr) { const float v = x[j]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    } else {
+        for (size_t i = tid; i < n; i += nthr) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
     }
     mn = wave_min(mn); mx = wave_max(mx);
     __shared__ float s[8];

@@ -51,8 +51,11 @@ __global__ __launch_bounds__(256) void fft_pack_kernel(const float* __restrict__
     }
 }
 
-// acc[0] += sum x, acc[1] += sum x^2 (float64), acc[2] += sum x * y when y is given
-__global__ __launch_bounds__(256) void fft_moments_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n, double* __restrict__ acc) {
+// Moments in float64 with a FIXED summation order (the image's std scales every pixel and every gradient entry: the drawer is
+// bit-reproducible run to run, like the rest of the path): every block writes its three partial sums, one block adds them up
+// part[b][0] = sum x, part[b][1] = sum x^2, part[b][2] = sum x * y (when y is given) over block b's grid-stride share
+constexpr int FFT_MOM_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void fft_moments_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n, double* __restrict__ part) {
     __shared__ double red[3][4];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -65,11 +68,26 @@ __global__ __launch_bounds__(256) void fft_moments_kernel(const float* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&acc[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&acc[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-        if (y) atomicAdd(&acc[2], red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        part[(size_t)blockIdx.x * 3 + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
     }
+}
+// acc[k] = sum_b part[b][k], one block: thread t adds blocks t, t + 256, ... in that order, then a fixed butterfly and wave order
+__global__ __launch_bounds__(256) void fft_moments_final_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ acc) {
+    __shared__ double red[3][4];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += part[(size_t)b * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s[0]; red[1][wave] = s[1]; red[2][wave] = s[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) acc[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 struct FftStd { float mean, sigma; };
@@ -178,7 +196,7 @@ struct prx_fft_drawer {
     float* dxT = nullptr;        // [3][W][HP]
     float* dc1t = nullptr;       // [3 HP2][WP]
     float* dP = nullptr;         // [3 HP2][K1p]
-    double* acc = nullptr;       // [6]: forward sums (0..2), backward sums (3..5)
+    double* acc = nullptr;       // [6]: forward sums (0..2), backward sums (3..5); then [FFT_MOM_BLOCKS][3] block partials
     float* ws = nullptr;         // split-K workspace of the engine
     size_t ws_bytes = 0;
     float contrast = 0.9f;
@@ -255,7 +273,7 @@ prx_fft_drawer* prx_fft_drawer_create(int W, int H, float decay, float colors) {
     dev(&h->dxT, (size_t)3 * W * HP); dev(&h->dc1t, (size_t)3 * HP2 * WP); dev(&h->dP, (size_t)3 * HP2 * K1p);
     h->ws_bytes = (size_t)32 << 20;
     dev(&h->ws, h->ws_bytes / sizeof(float));
-    if (ok && hipMalloc(&h->acc, 6 * sizeof(double)) != hipSuccess) ok = false;
+    if (ok && hipMalloc(&h->acc, (6 + 3 * FFT_MOM_BLOCKS) * sizeof(double)) != hipSuccess) ok = false;
     // padding rows of dC1T are an A operand of the last backward GEMM: never written, so zeroed once
     if (ok && hipMemset(h->dc1t, 0, (size_t)3 * HP2 * WP * sizeof(float)) != hipSuccess) ok = false;
     if (!ok) { prx_set_error("fft drawer: device allocation failed"); prx_fft_drawer_destroy(h); return nullptr; }
@@ -287,8 +305,10 @@ int prx_fft_drawer_synth(prx_fft_drawer* h, const float* params, float contrast,
         rc = gemm_f32(h, h->T2, HP2, h->c1 + (size_t)c * HP2, 3 * HP2, H, W, HP2, h->x + (size_t)c * P, W, s);
         if (rc) return rc;
     }
-    PRX_CHECK_HIP(hipMemsetAsync(h->acc, 0, 6 * sizeof(double), s));
-    hipLaunchKernelGGL(fft_moments_kernel, dim3(fgrid(3 * P)), dim3(256), 0, s, h->x, (const float*)nullptr, 3 * P, h->acc);
+    const int mb = std::min(fgrid(3 * P), FFT_MOM_BLOCKS);
+    hipLaunchKernelGGL(fft_moments_kernel, dim3(mb), dim3(256), 0, s, h->x, (const float*)nullptr, 3 * P, h->acc + 6);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fft_moments_final_kernel, dim3(1), dim3(256), 0, s, h->acc + 6, mb, h->acc);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(fft_tail_fwd_kernel, dim3(fgrid(P)), dim3(256), 0, s, h->x, h->acc, contrast, h->cm, image, P);
     PRX_LAUNCH_CHECK();
@@ -302,8 +322,10 @@ int prx_fft_drawer_backward(prx_fft_drawer* h, const float* g_image, float* g_pa
     const size_t P = (size_t)H * W;
     hipLaunchKernelGGL(fft_tail_bwd_gy_kernel, dim3(fgrid(P)), dim3(256), 0, s, h->x, g_image, h->acc, h->contrast, h->cm, h->gy, P);
     PRX_LAUNCH_CHECK();
-    PRX_CHECK_HIP(hipMemsetAsync(h->acc + 3, 0, 3 * sizeof(double), s));
-    hipLaunchKernelGGL(fft_moments_kernel, dim3(fgrid(3 * P)), dim3(256), 0, s, h->gy, h->x, 3 * P, h->acc + 3);
+    const int mb = std::min(fgrid(3 * P), FFT_MOM_BLOCKS);
+    hipLaunchKernelGGL(fft_moments_kernel, dim3(mb), dim3(256), 0, s, h->gy, h->x, 3 * P, h->acc + 6);
+    PRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fft_moments_final_kernel, dim3(1), dim3(256), 0, s, h->acc + 6, mb, h->acc + 3);
     PRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(fft_tail_bwd_dx_kernel, dim3(fgrid((size_t)3 * W * HP)), dim3(256), 0, s, h->x, h->gy, h->acc, h->acc + 3, h->contrast,
                        h->dxT, H, W, HP);

@@ -923,7 +923,6 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
     if (bm == -12) { c->force_fit = splits; return; }    // (-12, x, on/off): a forced 128 x 128 / 128 x 64 / 64 x 64 / 256 x 128 tile means the fit kernel of that shape
     if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
-    if (bm == -14) { c->n_cu = splits; return; }         // (-14, x, n): plan for n compute units (a handle that shares the chip with concurrent chains: ops.TowerLanes); 0 = ask the device
     if (bm == -13) { c->dbg_only = splits; c->dbg_count = 0; return; }   // (-13, x, i): bisection aid -- only the i-th fit convolution (-1: all, counting; -2: off)
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
@@ -1168,7 +1167,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
     a.fit_flags = fit_tile ? (cx.fit_flags & 15) : 0;   // gemmfit.hip A/B switches (PRX_FIT_FLAGS)
-    if (fit_tile && (cx.fit_flags & 64)) a.fit_flags |= 32;                // bit 6 of the switch word: producer-wave variants (kernel flag bit 5)
     if (fit_tile && (cx.fit_flags & 32) == 0 && d.N > d.M) a.fit_flags |= 16;      // weight-heavy: column-major tile order (bit 5 of the switch word turns it off)
     a.kt_per_split = ceil_div(a.kt_total, splits);
     if (BM == 256 && BN == 256) a.kt_per_split = (a.kt_per_split + 1) & ~1;      // the 8-phase loop body covers two K tiles

@@ -80,7 +80,7 @@ template <int WGM, int WGN, int FM, int FN, int KS>
 constexpr int fit_scratch_floats() {
     return (KS > 1 ? WGM * WGN * KS * FM * FN * 256 : 0) + WGM * WGN * KS * 16 * (16 * FN + 4) + KS * WGM * (16 * FN * WGN / 2);
 }
-template <int WGM, int WGN, int FM, int FN, int KS, typename T16, int FMC_MAX = 99>
+template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
 __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
                                            int wt, int wm, int wn, int lane) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
@@ -143,8 +143,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
     // slabs are handled FMC at a time: the prefetch of a chunk is (2 x 16 bytes + 1) registers per slab and pass on top of the
     // accumulators, and the wide wave tiles (16+ fragments) have no room for all of them at once
-    constexpr int FMC0 = FM * FN > 16 ? 3 : FM;
-    constexpr int FMC = FMC0 < FMC_MAX ? FMC0 : FMC_MAX;      // FMC_MAX: the producer-wave variants live on 168 registers
+    constexpr int FMC = FM * FN > 16 ? 3 : FM;
     float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
 #pragma unroll
     for (int i0 = 0; i0 < FM; i0 += FMC) {
@@ -262,35 +261,24 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
 }
 
 // WGM x WGN waves per K group, KS K groups; wave tile (16 FM) x (16 FN); block tile BM x BN = (16 FM WGM) x (16 FN WGN).
-// NPROD > 0 (fit_flags bit 5, an A/B switch): NPROD extra PRODUCER waves issue all of the workgroup's DMA, the NW compute waves
-// issue none.  A global_load_lds instruction holds the issuing wave until the CU's load path takes its kilobyte (60 - 185 cycles
-// each beside MFMAs, MI355X_MICROARCH.md), PW of them per wave and stage -- time in which that wave feeds no MFMA.  A producer
-// wave has nothing else to do, holds no accumulators, and sits on the SIMD as a third wave (the compute waves' register budget
-// drops to 512 / 3 = 168).  Protocol: the ring of 3 stages and the one barrier per stage are unchanged; the counted wait in
-// front of barrier T is executed by the producers (vmcnt is per wave: only the issuer can wait for its pieces), the compute
-// waves only arrive.  After the main loop the producers only mirror the epilogue's barriers, then end.
-template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16, int NPROD = 0>
-__global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
+template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
-    constexpr int NWI = NPROD > 0 ? NPROD : NW;          // waves that issue DMA
     constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN;
     constexpr int SUB = (BM + BN) * FIT_BK;              // elements of one K tile (A rows, then B rows)
     constexpr int STAGE = KS * SUB;                      // elements of one ring stage
     constexpr int NA = BM / 8, NB = BN / 8, NPS = NA + NB, NP = KS * NPS;   // DMA pieces (8 rows x 128 B) per stage
-    constexpr int PW = (NP + NWI - 1) / NWI;             // pieces per issuing wave per stage (the last ones may be duplicates)
+    constexpr int PW = (NP + NW - 1) / NW;               // pieces per wave per stage (the last ones may be duplicates)
     constexpr int TN = 16 * FN;
     static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole DMA pieces");
     static_assert(FIT_STAGES * STAGE * 2 <= 160 * 1024, "ring exceeds the LDS");
     static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
-    static_assert(NPROD == 0 || NPROD == 4, "one producer wave per SIMD");
 
     __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the only __shared__ object
 
     const GemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = NPROD > 0 && wave >= NW;       // wave-uniform
-    const int iw = NPROD > 0 ? wave - NW : wave;         // index among the issuing waves (meaningless for a compute wave when NPROD > 0)
     const int kg = wave / NWT;                           // K group of this wave
     const int wt = wave - kg * NWT;
     const int wm = wt / WGN, wn = wt - wm * WGN;
@@ -307,7 +295,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
     // K is cut into KS contiguous ranges, one per K group (group g: K tiles [g nkg, (g + 1) nkg)): consecutive stages of a group
     // walk consecutive K tiles, so an implicit convolution changes its tap only every Cin / 64 stages
     const int nkg = p.kt_total / KS;
-    // ---- DMA coordinates: slot j of issuing wave iw moves piece min(iw + NWI j, NP - 1) of every stage ------------------
+    // ---- DMA coordinates: slot j of wave w moves piece min(w + NW j, NP - 1) of every stage ----------------------------
     const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
     const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
     const int lrow = lane >> 3, cpos = lane & 7;
@@ -321,10 +309,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
     int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
     int s_cur[CONV ? PW : 1];                             // wave-uniform: the tap c_off was computed for (-1: none yet)
     int c_off[CONV ? PW : 1];                             // per lane: element offset of the tap's source pixel + the lane's chunk, < 0: padding
-    if (NPROD == 0 || producer)
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
-        int pc = iw + NWI * j;
+        int pc = wave + NW * j;
         pc = pc < NP ? pc : NP - 1;
         const int sub = pc / NPS, q = pc - sub * NPS;
         const bool isA = q < NA;
@@ -426,18 +413,17 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = fit_mfma<T16>(af1[i], bf1[j], acc[i][j]);
-#if defined(PRX_FIT_SCHED) && PRX_FIT_SCHED
-        // build variant (make sched -> libprx_hip_sched.so, selected with PRX_LIB_PATH; an A/B, not the default): pin the stage's
-        // schedule to "first k-step's fragment reads | its MFMAs with the second k-step's reads issued under them | second k-step's
-        // MFMAs".  The compiler's own order re-uses fragment registers and waits lgkmcnt(0) seven times per stage.
-        // (the compiler waits lgkmcnt(0), not a count, in front of the first MFMA; so the second k-step's reads are placed BEHIND
-        // the first MFMA, where that wait no longer covers them)
+        // The stage's schedule is pinned to "first k-step's fragment reads | its MFMAs with the second k-step's reads issued under
+        // them | second k-step's MFMAs": left to itself the compiler re-uses fragment registers and waits lgkmcnt(0) seven times
+        // per stage (18 ds_read_b128 / 40 MFMAs for FC1's tile); pinned, one LDS latency is exposed per stage.  (The compiler
+        // waits lgkmcnt(0), not a count, in front of the first MFMA, so the second k-step's reads are placed BEHIND the first
+        // MFMA, where that wait no longer covers them.)  Round-5 A/B on the device: engine 4.90 -> 4.76 ms per iteration,
+        // profiles/r05_first_call/.
         __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the first k-step's fragments
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // the first MFMA (and the wait in front of it)
         __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the second k-step's fragments
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - 1, 0);   // the rest of the first k-step's MFMAs
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);       // the second k-step's
-#endif
     };
 
     // ---- main loop: ring of 3 stages, counted waits (PW DMA instructions per wave per stage) ---------------------------
@@ -448,40 +434,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
     // stage T + 2 are issued after every wave passed barrier T (stage T - 1 was read before it: WAR), and are waited for by
     // the same counted wait in front of barrier T + 2.
     const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
-    if constexpr (NPROD > 0) {
-        if (producer) {
-            if (0 < nk) issue(0, 0);
-            if (1 < nk) issue(1, 1);
-#define FIT_PSTEP(T, ST)                                                                                                \
-    do {                                                                                                                \
-        if ((T) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");                                    \
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
-        __builtin_amdgcn_s_barrier();       /* stage T landed; the compute waves are done reading stage T - 1 */         \
-        if ((T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                               \
-    } while (0)
-            int t = 0;
-            for (; t + 3 <= nk; t += 3) { FIT_PSTEP(t, 0); FIT_PSTEP(t + 1, 1); FIT_PSTEP(t + 2, 2); }
-            if (t < nk) { FIT_PSTEP(t, 0); ++t; }
-            if (t < nk) { FIT_PSTEP(t, 1); ++t; }
-#undef FIT_PSTEP
-            __builtin_amdgcn_s_barrier();   // the compute waves' "ring is dead" barrier
-            // the producers stay for the barriers of fit_finish (one for the K groups' partial sums, one for the GroupNorm sums:
-            // both conditions are uniform over the workgroup), so that nothing depends on how a barrier counts ended waves
-            if (p.fit_flags & 4) return;
-            if constexpr (KS > 1) __builtin_amdgcn_s_barrier();
-            if constexpr (((TN / 8) & (TN / 8 - 1)) == 0)
-                if (p.d.gn_stats != nullptr) __builtin_amdgcn_s_barrier();
-            return;
-        }
-        int t = 0;
-        for (; t + 3 <= nk; t += 3) {
-            __builtin_amdgcn_s_barrier(); compute(0);
-            __builtin_amdgcn_s_barrier(); compute(1);
-            __builtin_amdgcn_s_barrier(); compute(2);
-        }
-        if (t < nk) { __builtin_amdgcn_s_barrier(); compute(0); ++t; }
-        if (t < nk) { __builtin_amdgcn_s_barrier(); compute(1); ++t; }
-    } else {
     const bool late = (p.fit_flags & 1) && wave >= NW / 2;
     if (0 < nk) issue(0, 0);
     if (1 < nk) issue(1, 1);
@@ -499,7 +451,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
     if (t < nk) { FIT_STEP(t, 0); ++t; }
     if (t < nk) { FIT_STEP(t, 1); ++t; }
 #undef FIT_STEP
-    }
     __builtin_amdgcn_s_barrier();           // the ring is dead: LDS is reused below
 
     if (p.fit_flags & 4) {                  // bit 2 (timing experiments only): no epilogue -- keep the accumulators alive
@@ -510,22 +461,22 @@ __global__ __launch_bounds__(64 * (WGM * WGN * KS + NPROD)) void gemmfit_kernel(
         return;
     }
     static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
-    fit_finish<WGM, WGN, FM, FN, KS, T16, (NPROD > 0 ? 1 : 99)>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
+    fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
 }
 
-template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true, int NPROD = 0>
+template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
 void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
-    constexpr int threads = 64 * (WGM * WGN * KS + NPROD);
+    constexpr int threads = 64 * WGM * WGN * KS;
     const bool conv = a.d.a_mode == PRX_A_CONV3X3;
     if constexpr (HAS_CONV) {
         if (conv) {
-            if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t, NPROD>), grid, dim3(threads), 0, s, a, zp);
-            else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t, NPROD>), grid, dim3(threads), 0, s, a, zp);
+            if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t>), grid, dim3(threads), 0, s, a, zp);
+            else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t>), grid, dim3(threads), 0, s, a, zp);
             return;
         }
     }
-    if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t, NPROD>), grid, dim3(threads), 0, s, a, zp);
-    else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t, NPROD>), grid, dim3(threads), 0, s, a, zp);
+    if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t>), grid, dim3(threads), 0, s, a, zp);
+    else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t>), grid, dim3(threads), 0, s, a, zp);
 }
 
 // the tile shapes this kernel exists in
@@ -599,20 +550,6 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
     PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
-    if (a.fit_flags & 32) {        // producer-wave variants (A/B switch)
-        if (bm == 80 && bn == 128) { launch_fit<1, 4, 5, 2, 2, false, 4>(a, grid, s, zp); return 0; }
-        if (bm == 160 && bn == 256) { launch_fit<2, 4, 5, 4, 1, false, 4>(a, grid, s, zp); return 0; }
-        if (bm == 160 && bn == 192) { launch_fit<2, 4, 5, 3, 1, false, 4>(a, grid, s, zp); return 0; }
-        if (bm == 256 && bn == 128) { launch_fit<4, 2, 4, 4, 1, true, 4>(a, grid, s, zp); return 0; }
-        // the decoder's smaller tiles: their implicit-convolution gather arithmetic (half a stage's cost on these tiles, DESIGN.md
-        // section 6) moves to the producers with the DMA
-        if (bm == 128 && bn == 128) { launch_fit<2, 4, 4, 2, 1, true, 4>(a, grid, s, zp); return 0; }
-        if (bm == 128 && bn == 64) { launch_fit<2, 2, 4, 2, 2, true, 4>(a, grid, s, zp); return 0; }
-        if (bm == 64 && bn == 64) { launch_fit<2, 2, 2, 2, 2, true, 4>(a, grid, s, zp); return 0; }
-        if (bm == 32 && bn == 64) { launch_fit<1, 2, 2, 2, 4, true, 4>(a, grid, s, zp); return 0; }
-        if (bm == 16 && bn == 64) { launch_fit<1, 2, 1, 2, 4, true, 4>(a, grid, s, zp); return 0; }
-        if (bm == 16 && bn == 32) { launch_fit<1, 1, 1, 2, 8, true, 4>(a, grid, s, zp); return 0; }
-    }
     if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1, false>(a, grid, s, zp);
     else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);

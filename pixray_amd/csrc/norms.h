@@ -14,4 +14,5 @@ int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const f
                       float* out_f32, float* mean, float* rstd, int rows, int C, float eps, hipStream_t s, int h16 = 0);
 int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
-                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s, int h16 = 0);
+                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s, int h16 = 0,
+                      int add_every = 0);   // add_every > 0: `add` is read on the rows that are multiples of it only (it is taken as zero elsewhere)

@@ -250,10 +250,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ add,
                                                      long long ldadd, float* __restrict__ dx, long long lddx,
-                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C, int xcd, int h16) {
+                                                     bf16_t* __restrict__ dx_bf16, long long lddxb, int rows, int C, int xcd, int h16, int add_every) {
     const int lane = threadIdx.x & 63;
     const int row = (xcd ? xcd_linear(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (add_every > 0 && row % add_every != 0) add = nullptr;      // wave-uniform
     const int nv = C >> 8;
     const float mean = mean_in[row], rstd = rstd_in[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
@@ -351,15 +352,15 @@ int prx_layernorm_fwd(const float* x, long long ldx, const float* gamma, const f
 
 int prx_layernorm_bwd(const float* g, long long ldg, const float* x, long long ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* add, long long ldadd, float* dx,
-                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s, int h16) {
+                      long long lddx, bf16_t* dx_bf16, long long lddxb, int rows, int C, hipStream_t s, int h16, int add_every) {
     PRX_REQUIRE(C % 256 == 0 && C <= 2048, "layernorm bwd: C must be a multiple of 256 and <= 2048 (C=%d)", C);
     dim3 grid(ceil_div(rows, 4));
     if (C <= 1024)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16);
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16, add_every);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, s, g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx,
-                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16);
+                           lddx, dx_bf16, lddxb, rows, C, prx_xcd_local(), h16, add_every);
     PRX_LAUNCH_CHECK();
     return 0;
 }

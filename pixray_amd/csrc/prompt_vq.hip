@@ -8,12 +8,9 @@ namespace {
 
 // One wave per input row i.  rowloss[i] = sum_j sign(w) * 2*asin(|xn_i - en_j|/2)^2   (forward value, no stop)
 // grad[i][:] = d/dx_i of  |w| * mean_ij max(sign(w)*d_ij, stop)   with mean over `denom` pairs.
-__global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
-                                                          int n, int m, int D, float weight, float stop, float denom,
-                                                          float* __restrict__ rowloss, float* __restrict__ grad) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+__device__ __forceinline__ float prompt_loss_row(const float* __restrict__ x, const float* __restrict__ embed, int i, int lane,
+                                                int n, int m, int D, float weight, float stop, float denom,
+                                                float* __restrict__ rowloss, float* __restrict__ grad) {
     constexpr int MAXE = 16;  // D <= 1024
     const int ne = D / 64;
     float xv[MAXE], gacc[MAXE];
@@ -60,6 +57,26 @@ __global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restric
     for (int e = 0; e < MAXE; ++e)
         if (e < ne) grad[(size_t)i * D + e * 64 + lane] = sc * (gacc[e] - xv[e] * ixn * dot) * ixn;
     if (lane == 0) rowloss[i] = loss;
+    return loss;
+}
+
+// ONE workgroup of 16 waves walks the rows (wave w: rows w, w + 16, ...), so that the scalar the loop adds up -- loss =
+// |w| * sum(rowloss) / denom, pixray.py:280 -- leaves the same launch in a fixed summation order (it used to take a torch
+// reduction and a scalar multiply per Prompt and iteration); the work is n * m * D = 64 x 2 x 512 values.
+__global__ __launch_bounds__(1024) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
+                                                           int n, int m, int D, float weight, float stop, float denom,
+                                                           float* __restrict__ rowloss, float* __restrict__ grad, float* __restrict__ loss_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float wsum[16];
+    float wacc = 0.f;
+    for (int i = wave; i < n; i += 16) wacc += prompt_loss_row(x, embed, i, lane, n, m, D, weight, stop, denom, rowloss, grad);
+    if (lane == 0) wsum[wave] = wacc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        *loss_out = t * (fabsf(weight) / denom);
+    }
 }
 
 // e_hat = e/|e|  (slip.py:66) and its backward  de = (g - e_hat (e_hat.g))/|e|
@@ -217,10 +234,10 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict_
 }  // namespace
 
 int prx_prompt_loss(const float* x, const float* embed, int n, int m, int D, float weight, float stop, float denom,
-                    float* rowloss, float* grad, hipStream_t s) {
+                    float* rowloss, float* grad, float* loss, hipStream_t s) {
     PRX_REQUIRE(D % 64 == 0 && D <= 1024, "prompt_loss: D must be a multiple of 64 and <= 1024 (D=%d)", D);
-    hipLaunchKernelGGL(prompt_loss_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, x, embed, n, m, D, weight, stop, denom,
-                       rowloss, grad);
+    hipLaunchKernelGGL(prompt_loss_kernel, dim3(1), dim3(1024), 0, s, x, embed, n, m, D, weight, stop, denom,
+                       rowloss, grad, loss);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -91,11 +91,11 @@ struct PrxVit {
     float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
     float* ws; size_t ws_bytes;
     int cur_n;
-    // PRX_VIT_CLS_TAIL=1 (an A/B switch, off by default): only the class token of the LAST block's output is ever read (ln_post on
-    // token 0, slip.py:66 / clip VisionTransformer), so that block's out-projection, MLP and their backward run on the n class-token
-    // rows (row stride T * width into the same buffers) instead of all n * T token rows: the same values for everything that is
-    // read, 3 + 3 of the tower's 48 + 48 wide products reduced to M = n.  K and V of that block still need every token.
-    int cls_tail;
+    // The class-token tail: only the class token of the LAST block's output is ever read (ln_post on token 0, slip.py:66 / clip
+    // VisionTransformer), so that block's out-projection, MLP and their backward run on the n class-token rows (row stride
+    // T * width into the same buffers) instead of all n * T token rows: the same values for everything that is read, 3 + 3 of
+    // the tower's 48 + 48 wide products reduced to M = n.  K and V of that block still need every token.  (Round-5 A/B on the
+    // device: 140.1 -> 141.2 and 138.0 -> 139.5 it/s, profiles/r05_first_call/, r05_timeline/.)
 };
 
 namespace {
@@ -142,7 +142,6 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
     v->gs = nullptr;
-    { const char* e = getenv("PRX_VIT_CLS_TAIL"); v->cls_tail = (e && atoi(e) != 0 && layers > 0) ? 1 : 0; }
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -225,9 +224,9 @@ static int ln_op(PrxVit* v, const float* x, long long ldx, const float* g, const
 // LayerNorm backward producing the fp32 gradient stream + its operand twin (the same buffer in the exact mode)
 static int ln_bwd_op(PrxVit* v, const float* g, long long ldg, const float* x, long long ldx, const float* gamma, const float* mean,
                      const float* rstd, const float* add, long long ldadd, float* dx, long long lddx, void* dx_op, int rows,
-                     hipStream_t s) {
+                     hipStream_t s, int add_every = 0) {
     return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, v->f32 ? nullptr : (bf16_t*)dx_op, lddx, rows,
-                             v->width, s, v->h16);
+                             v->width, s, v->h16, add_every);
 }
 
 int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
@@ -263,7 +262,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s, v->h16))) return r; att = y.o_save; }
         // the class-token tail: rows = the n class tokens, reached through a row stride of T * W in the token-major buffers;
         // LN / MLP intermediates of those rows are stored densely ([n][...]) at the start of their buffers
-        const bool tail = v->cls_tail && l == v->layers - 1;
+        const bool tail = l == v->layers - 1;
         const int rows = tail ? n : R;
         const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
         {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
@@ -305,15 +304,17 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
             if ((r = prx_scale_dev(v->de, (size_t)n * v->out_dim, v->gs, s))) return r;
         }
         if ((r = vit_gemm(v, d, s))) return r; }
-    // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs
-    PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
-    if (!v->f32) PRX_CHECK_HIP(hipMemsetAsync(v->dx_bf, 0, sizeof(bf16_t) * (size_t)R * W, s));
+    // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs.  It enters the last
+    // block on the class-token rows only; that block's kernels read those rows alone (the class-token tail) until its ln_1
+    // backward, which takes the incoming gradient as zero on every other row (add_every = T) and writes all of them -- so the
+    // streams need no clearing (two fills of 14.7 MB per iteration at the headline)
+    if (v->layers == 0) PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
     if ((r = ln_bwd_op(v, v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
                        nullptr, 0, v->dx, (long long)T * W, v->dx_bf, n, s))) return r;
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
         // the class-token tail (see the forward): the gradient entering the last block is non-zero on the class-token rows only
-        const bool tail = v->cls_tail && l == v->layers - 1;
+        const bool tail = l == v->layers - 1;
         const int rows = tail ? n : R;
         const int ldt = tail ? T * W : W;
         // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))
@@ -336,7 +337,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
             d.out_f32 = v->dh; d.ldc_f32 = W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = ln_bwd_op(v, v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, R, s))) return r;
+        if ((r = ln_bwd_op(v, v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, R, s, tail ? T : 0))) return r;
     }
     // ln_pre backward (in place on dx), then patch-embed dgrad
     if ((r = ln_bwd_op(v, v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s))) return r;

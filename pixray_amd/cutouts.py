@@ -19,7 +19,7 @@ from torch import nn
 
 from . import ops
 
-DESC_WORDS = 32
+DESC_WORDS = 36
 MODE_IDENT, MODE_ZEROS, MODE_BORDER, MODE_REFLECT, MODE_FILL, MODE_REFLECT_AC = 0, 1, 2, 3, 4, 5
 GRID_MESH, GRID_AFFINE, GRID_AFFINE_AC, GRID_MESH_AC = 0, 1, 2, 3
 
@@ -162,7 +162,7 @@ def _np(t):
 
 
 def build_descriptors(p: Dict[str, torch.Tensor], S: int, conventions: Optional[Dict[str, bool]] = None) -> torch.Tensor:
-    """[cutn, 32] fp64 descriptor table for prx_cutouts_forward (layout: include/prx.h).
+    """[cutn, 36] fp64 descriptor table for prx_cutouts_forward (layout: include/prx.h).
 
     Each stage carries kornia's `src_norm_trans_dst_norm` 3x3 (the inverse of normalize_homography(M) with
     the [0, W-1] -> [-1, 1] convention) plus the grid flavour that produced the sampling grid in kornia 0.6.2:
@@ -239,6 +239,8 @@ def build_descriptors(p: Dict[str, torch.Tensor], S: int, conventions: Optional[
         desc[nz:, 23] = (p["w_hue"].float() * (2.0 * math.pi)).double().numpy()
         desc[nz:, 24] = float(bool(p["w_sat_first"]))
     desc[:, 25] = _np(p["noise_fac"])
+    if "noise_seed" in p:                 # in-kernel N(0,1) draws (csrc/cutouts.hip philox_normal3) when no explicit noise tensor is handed over
+        desc[:, 32] = _np(p["noise_seed"])
     return torch.from_numpy(desc)
 
 
@@ -336,6 +338,11 @@ class MakeCutouts(nn.Module):
         self.fixed_params = None   # tests / parity: use these draws instead of sampling
         self.conventions = None    # overrides of KORNIA_062_CONVENTIONS (which align_corners flag each kornia call passes)
 
+    def _noise_keys(self):
+        if getattr(self, "_noise_gen", None) is None:
+            self._noise_gen = torch.Generator().manual_seed((self.generator.initial_seed() * 2654435761 + 0x5bd1e995) % (2 ** 63))
+        return self._noise_gen
+
     # -- host part: draw this iteration's parameters and stage the descriptor table ---------------------------------
     def enable_static_buffers(self, device):
         """Keep the descriptor table in a fixed device buffer (fed from a pinned host buffer) so the device part of
@@ -352,6 +359,10 @@ class MakeCutouts(nn.Module):
         S = self.cut_size
         prm = self.fixed_params if self.fixed_params is not None else sample_cutout_params(
             self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill, aspect=self.aspect_width)
+        if self.noise_fac and prm.get("noise") is None and "noise_seed" not in prm:
+            # the reference's randn_like (pixray.py:510) is drawn inside the stage-B kernel: one Philox key per cutout and
+            # iteration, from a stream of its own so that the augmentation draws above stay where they were
+            prm = dict(prm, noise_seed=torch.randint(1, 2 ** 31 - 1, (self.cutn,), generator=self._noise_keys()))
         self.last_params = prm
         desc = build_descriptors(prm, S, self.conventions)
         self.transforms = desc          # this iteration's geometry (opaque, like the reference's composed 3x3 cache)
@@ -382,8 +393,9 @@ class MakeCutouts(nn.Module):
             facs = _uniform(self.generator, (self.cutn,), 0.0, self.noise_fac).float()
             desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp,
                                             self.conventions)
-            noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32) if self.noise_fac else None
-            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), noise, S, base_size(S, asp), spot_mask)
+            if self.noise_fac:
+                desc[:, 32] = torch.randint(1, 2 ** 31 - 1, (self.cutn,), generator=self._noise_keys()).double()    # noise drawn in the kernel
+            return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), None, S, base_size(S, asp), spot_mask)
         if not getattr(self, "_prepared", False):
             self.prepare()
         self._prepared = False
@@ -391,10 +403,7 @@ class MakeCutouts(nn.Module):
         desc_dev = self._desc_dev
         if desc_dev.device != input.device:
             desc_dev = desc_dev.to(input.device, non_blocking=True)
-        noise = prm.get("noise")
-        if noise is None and self.noise_fac:
-            # device-side N(0,1) draws, as the reference's randn_like (pixray.py:510)
-            noise = torch.randn(hi - lo, 3, S, S, device=input.device, dtype=torch.float32)
-        elif noise is not None:
+        noise = prm.get("noise")          # explicit draws (parity tests); otherwise the kernel draws them (descriptor word 32)
+        if noise is not None:
             noise = noise[lo:hi].to(input.device, dtype=torch.float32).contiguous()
         return ops.make_cutouts(input, desc_dev, noise, S, base_size(S, float(prm["aspect"]) if "aspect" in prm else 1.0), spot_mask)

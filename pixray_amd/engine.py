@@ -16,6 +16,8 @@ ClampWithGrad's backward, vqgan.py:76-79, is not linear in the incoming gradient
 """
 from __future__ import annotations
 
+import functools
+import operator
 import types
 from typing import Dict, List, Optional, Sequence
 
@@ -464,8 +466,8 @@ class Session:
                 if custom:
                     sum(custom).backward()
             else:
-                loss = sum(lossAll)
-                loss.backward()
+                loss = functools.reduce(operator.add, lossAll)      # one add per extra term (sum() starts from 0: one launch more)
+                loss.backward(gradient=self._unit_grad(loss))       # a resident 1.0 instead of a ones_like fill per iteration
             # values only: holding the loss tensors themselves would keep this iteration's autograd graph -- every Function's
             # ctx with its workspace and its runner handle -- alive until the NEXT iteration replaces them, i.e. a handle
             # could be destroyed (hipFree) in the middle of a later iteration, which a hipGraph capture does not survive
@@ -474,6 +476,12 @@ class Session:
         for opt in self.opts:
             opt.step()
         self._clip_z()
+
+    def _unit_grad(self, loss):
+        u = getattr(self, "_unit", None)
+        if u is None or u.device != loss.device or u.dtype != loss.dtype or u.shape != loss.shape:
+            u = self._unit = torch.ones_like(loss)
+        return u
 
     def _clip_z(self):
         """drawer.clip_z() (pixray.py:1487); a drawer with a fused Adam+clamp kernel skips its own clamp only when every

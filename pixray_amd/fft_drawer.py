@@ -3,10 +3,11 @@ Fourier spectrum (BASELINE.json configs[3]: "fftdrawer 512x512").
 
 A drawer *plugin* (the reference's drawers are plugins too): `synth()` hands the loop a [1,3,H,W] tensor in [0,1] and
 everything downstream (cutouts, CLIP tower, loss, backward to the image) runs on the HIP kernels.  The spectrum -> image map
-itself has two implementations: plain torch (`torch.fft.irfftn` = rocFFT on MI355X, plus elementwise colour work; the default)
-and -- PRX_FFT_HIP=1 -- `csrc/fft_drawer.hip`: the inverse real transform as exact-f32 GEMMs on the engine against float64-built
-twiddle matrices, the std / colour / sigmoid tail and the whole backward in five small kernels (no FFT library, 15 launches per
-forward + backward instead of ~40 torch ops).  Both are checked against the explicit-DFT oracle (oracle/fft_ref.py).
+itself runs on `csrc/fft_drawer.hip` when the drawer lives on a GPU: the inverse real transform as exact-f32 GEMMs on the engine
+against float64-built twiddle matrices, the std / colour / sigmoid tail and the whole backward in small kernels (no FFT library,
+17 launches per forward + backward instead of ~40 torch ops; bit-reproducible: the std's sums are taken in a fixed order).  A
+drawer created on the CPU (the CPU plumbing tests, configs[0]-style runs) evaluates the same map with plain torch
+(`torch.fft.irfftn`).  Both are checked against the explicit-DFT oracle (oracle/fft_ref.py).
 
 The reference delegates the parameterisation to `aphantasia.image.fft_image / to_valid_rgb` (eps696/aphantasia@7e6b3bb,
 requirements.txt, absent offline) [UPSTREAM]; restated here from the published algorithm (the transform is pinned to its
@@ -62,11 +63,10 @@ class FftDrawer(DrawingInterface):
 
     def load_model(self, settings, device):
         self.device = torch.device(device)
-        # PRX_FFT_HIP=1: the spectrum -> image map on the exact-f32 GEMM engine (csrc/fft_drawer.hip) instead of torch.fft / rocFFT.
-        # Validated against oracle/fft_ref.py on the CPU emulation of the kernels (tests/test_emu_cpu.py); off by default until it
-        # has run on the device (tests/test_zz_frontend_gpu.py::test_fft_drawer_hip_path, PRX_TEST_EXPERIMENTAL=1).
-        import os
-        self.hip = os.environ.get("PRX_FFT_HIP", "0") == "1" and (self.device.type == "cuda" or getattr(settings, "fft_hip_force", False))
+        # on a GPU the spectrum -> image map runs on the exact-f32 GEMM engine (csrc/fft_drawer.hip), not on torch.fft / rocFFT
+        # (oracle/fft_ref.py agreement on the device: tests/test_zz_frontend_gpu.py::test_fft_drawer_hip_path; `fft_hip_force`
+        # lets the CPU emulation of the kernels stand in for the device in tests/test_emu_cpu.py)
+        self.hip = self.device.type == "cuda" or bool(getattr(settings, "fft_hip_force", False))
         self._handle = None
 
     def rand_init(self, toksX=None, toksY=None):

@@ -280,134 +280,6 @@ def clip_encode_image(cutouts, handle: ClipVitHandle, group=None, comm=None):
     return _ClipEncodeFn.apply(cutouts, handle, group, comm)
 
 
-class TowerLanes:
-    """K tower handles of one perceptor + K - 1 side streams: the cutout batch is cut into K chunks whose forward / backward
-    chains run CONCURRENTLY on one GPU (PRX_VIT_LANES=K, an A/B switch; off by default).
-
-    Why: the tower is ~200 dependent launches per iteration, and every kernel boundary on a stream costs a few microseconds
-    in which the chip drains and refills (profiles/r04_cfg1_kernel_stats.csv: a 4.2-5 us floor under kernels that do nothing).
-    Two half-size chains on two streams overlap one chain's boundaries with the other's kernels; the fit tiles keep their
-    grid at half the batch (M = 1600 = 20 x 80 rows: 120 workgroups per kernel, two kernels fill the chip).  The arithmetic is
-    the cutout-sharded one inside one process: batch-global min / max taken once over the whole
-    batch, the four renormalisation sums of the chunks added before any chunk finishes its backward."""
-
-    def __init__(self, handles, device):
-        self.handles = list(handles)
-        self.device = torch.device(device)
-        # every chain gets 1/K of the chip: its launch planner should pick tiles whose grid fills THAT (at M = 1600 the 80 x 128
-        # fit tile has 120 workgroups: half a chip, rejected as a 47 % fill when planned against all 256 compute units)
-        lib = _lib.load()
-        cus = 256
-        if self.device.type == "cuda":
-            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        for h in self.handles:
-            lib.prx_gemm_tile_override(h.gemm_ctx, -14, 0, max(1, cus // len(self.handles)))
-        self.streams = [None] + [torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-                                 for _ in self.handles[1:]]
-        self.generation = 0
-
-    def chunks(self, n):
-        k = len(self.handles)
-        per = -(-n // k)
-        return [(i * per, min(n, (i + 1) * per)) for i in range(k) if i * per < n]
-
-    def fork(self):
-        """marks the point of the current stream every lane's next piece of work has to wait for (its inputs are ready there).
-        Taken BEFORE lane 0's work is enqueued on the current stream itself: a wait on the stream's tail instead would order
-        the side lanes behind lane 0's whole chain."""
-        if self.device.type != "cuda":
-            return None
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        return ev
-
-    def run(self, lane, fn, tensors=(), after=None):
-        """fn(stream handle) on lane `lane`'s stream, ordered after the event `after` (from fork()); `tensors` were allocated on
-        the current stream and are used on the lane's (the caching allocator must not recycle them under it)"""
-        st = self.streams[lane]
-        if st is None:
-            return fn(_stream())
-        if after is not None:
-            st.wait_event(after)
-        with torch.cuda.stream(st):
-            for t in tensors:
-                t.record_stream(st)
-            return fn(st.cuda_stream)
-
-    def join(self):
-        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        for st in self.streams:
-            if st is not None:
-                cur.wait_stream(st)
-
-
-class _ClipEncodeLanesFn(torch.autograd.Function):
-    """_ClipEncodeFn over a TowerLanes: one autograd node, K concurrent chunk chains inside its forward and its backward"""
-
-    @staticmethod
-    def forward(ctx, cutouts, lanes):
-        _need_cuda(cutouts)
-        cutouts = cutouts.contiguous().float()
-        n = cutouts.shape[0]
-        h0 = lanes.handles[0]
-        R = h0.cfg.input_resolution
-        assert cutouts.shape[1:] == (3, R, R), f"perceptor expects [n,3,{R},{R}] cutouts"
-        dev = cutouts.device
-        mm = torch.empty(2, device=dev)
-        call(h0.abi + "_minmax", h0.h, cutouts, n, mm, _stream())          # lane 0's handle has room for the whole batch
-        emb = torch.empty(n, h0.cfg.output_dim, device=dev)
-        ready = lanes.fork()
-        for lane, (lo, hi) in enumerate(lanes.chunks(n)):
-            h = lanes.handles[lane]
-            lanes.run(lane, lambda s, h=h, lo=lo, hi=hi: call(h.abi + "_encode", h.h, cutouts[lo:hi], hi - lo, mm, emb[lo:hi], s),
-                      (cutouts, mm, emb), ready)
-            h.generation += 1
-        lanes.join()
-        lanes.generation += 1
-        ctx.generation = lanes.generation
-        ctx.save_for_backward(cutouts, mm)
-        ctx.lanes = lanes
-        return emb
-
-    @staticmethod
-    def backward(ctx, g):
-        cutouts, mm = ctx.saved_tensors
-        lanes = ctx.lanes
-        g = g.contiguous().float()
-        dev, n = g.device, cutouts.shape[0]
-        chunks = lanes.chunks(n)
-        if lanes.generation != ctx.generation:      # another forward ran on these handles since ours: restore our activations
-            scratch = torch.empty(n, lanes.handles[0].cfg.output_dim, device=dev)
-            ready = lanes.fork()
-            for lane, (lo, hi) in enumerate(chunks):
-                h = lanes.handles[lane]
-                lanes.run(lane, lambda s, h=h, lo=lo, hi=hi: call(h.abi + "_encode", h.h, cutouts[lo:hi], hi - lo, mm, scratch[lo:hi], s),
-                          (cutouts, mm, scratch), ready)
-            lanes.join()
-            lanes.generation += 1
-            ctx.generation = lanes.generation
-        accs = torch.empty(len(chunks), 4, device=dev, dtype=torch.float64)
-        ready = lanes.fork()
-        for lane, (lo, hi) in enumerate(chunks):
-            h = lanes.handles[lane]
-            lanes.run(lane, lambda s, h=h, lo=lo, hi=hi, lane=lane: call(h.abi + "_backward_reduce", h.h, cutouts[lo:hi], mm, g[lo:hi],
-                                                                         accs[lane], s), (cutouts, mm, g, accs), ready)
-        lanes.join()
-        acc = accs.sum(0)                           # fixed order: chunk 0 + chunk 1 + ...
-        gc = torch.empty_like(cutouts)
-        ready = lanes.fork()
-        for lane, (lo, hi) in enumerate(chunks):
-            h = lanes.handles[lane]
-            lanes.run(lane, lambda s, h=h, lo=lo, hi=hi: call(h.abi + "_backward_finish", h.h, cutouts[lo:hi], mm, acc, gc[lo:hi], s),
-                      (cutouts, mm, acc, gc), ready)
-        lanes.join()
-        return gc, None
-
-
-def clip_encode_image_lanes(cutouts, lanes: TowerLanes):
-    return _ClipEncodeLanesFn.apply(cutouts, lanes)
-
-
 class _ClipTextCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("vocab_size", "context_length", "width", "layers", "heads", "output_dim",
                                             "max_batch")]
@@ -629,12 +501,12 @@ class _PromptLossFn(torch.autograd.Function):
         e = embed.contiguous().float()
         n, D = x.shape
         m = e.shape[0]
-        rowloss = torch.empty(n, device=x.device)
+        rowloss = torch.empty(n + 1, device=x.device)          # [n] row values, then the scalar |w| * sum / denom from the same launch
         grad = torch.empty_like(x)
         den = float(denom) if denom is not None else float(n * m)
-        call("prx_prompt_loss_fwd_bwd", x, e, n, m, D, float(weight), float(stop), den, rowloss, grad, _stream())
+        call("prx_prompt_loss_fwd_bwd", x, e, n, m, D, float(weight), float(stop), den, rowloss, grad, rowloss[n:], _stream())
         ctx.save_for_backward(grad)
-        return rowloss.sum() * (abs(float(weight)) / den)
+        return rowloss[n]
 
     @staticmethod
     def backward(ctx, g):

@@ -26,15 +26,6 @@ class ClipVitPerceptor:
             self.handle = ops.ClipResNetHandle(cfg, params, max_batch, self.device, precision=precision)
         else:
             self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device, precision=precision)
-        # PRX_VIT_LANES=K (an A/B switch, off by default): K chunk chains of the batch on K streams of ONE GPU (ops.TowerLanes);
-        # not combined with cutout sharding across GPUs (a rank's shard is already the small batch)
-        import os
-        k = int(os.environ.get("PRX_VIT_LANES", "1") or 1)
-        self.lanes = None
-        if k > 1 and group is None and not isinstance(cfg, ClipResNetConfig) and max_batch >= 2 * k:
-            per = -(-max_batch // k)
-            extra = [ops.ClipVitHandle(cfg, params, per, self.device, precision=precision) for _ in range(k - 1)]
-            self.lanes = ops.TowerLanes([self.handle] + extra, self.device)
 
     def preprocess(self, imgs, input_range=None):
         raise NotImplementedError("preprocessing (slip.py:21-42,58-60) is fused into encode_image on this path")
@@ -45,8 +36,6 @@ class ClipVitPerceptor:
             raise NotImplementedError("apply_preprocess=False is not supported by the fused path")
         if imgs.shape[0] > self.handle.max_batch:
             raise ValueError(f"batch {imgs.shape[0]} exceeds the perceptor capacity {self.handle.max_batch}")
-        if self.lanes is not None and self.group is None and getattr(self, "comm", None) is None and imgs.shape[0] >= 2 * len(self.lanes.handles):
-            return ops.clip_encode_image_lanes(imgs, self.lanes)
         return ops.clip_encode_image(imgs, self.handle, self.group, getattr(self, "comm", None))
 
     # -- text side (slip.py:68-74) ---------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Random-shape sweeps of the GEMM engine on the emulated kernels (tests/test_emu_cpu.py; `python tests/_emu_fuzz.py gemm|conv|gn|vit|vqgan|runners SEED N`
 from the repo root for longer runs).  Every case draws a shape (ragged against every tile), leading dimensions, operand precision,
-a fused epilogue and a kernel family (planner's choice, a forced fit tile with or without producer waves, the register-staged
+a fused epilogue and a kernel family (planner's choice, a forced fit tile, the register-staged
 kernels, split-K, the 8-phase tile) and compares with a float64 product / torch conv2d of the same rounded operands.  Argument
 combinations the engine documents as unsupported must be REJECTED (rc != 0), never computed wrong.  `device="cuda"` runs the same
 sweeps on the GPU (tests/test_kernels_gpu.py).  The second half sweeps the
@@ -31,11 +31,11 @@ def _reset(lib, ctx):
 def _family(lib, ctx, rng, prec, conv):
     """draws the kernel family for one case and sets the tool context's overrides accordingly"""
     _reset(lib, ctx)
-    mode = rng.choice(["heur", "heur", "fit", "prod", "v1", "splitk"] + ([] if conv else ["8p"]))
-    if mode in ("fit", "prod") and prec != "f32":
+    mode = rng.choice(["heur", "heur", "fit", "fit", "v1", "splitk"] + ([] if conv else ["8p"]))
+    if mode == "fit" and prec != "f32":
         t = rng.choice([t for t in FIT if not (conv and t[0] == 80)])
         lib.prx_gemm_tile_override(ctx, -12, 0, 1); lib.prx_gemm_tile_override(ctx, t[0], t[1], 1)
-        lib.prx_gemm_tile_override(ctx, -8, 0, 65 if mode == "prod" else rng.choice([0, 1]))
+        lib.prx_gemm_tile_override(ctx, -8, 0, rng.choice([0, 1]))
         return f"{mode}{t}"
     if mode == "8p":
         lib.prx_gemm_tile_override(ctx, 256, 256, 1)

@@ -69,7 +69,7 @@ def test_fit_kernel_implicit_conv_and_groupnorm_epilogue_sums(emu):
 def test_gemm_engine_random_shapes_every_kernel_family(emu):
     """300 random row-major products and 300 random implicit convolutions (tests/_emu_fuzz.py): ragged shapes against every tile,
     strided operands and outputs, fp32 A converted on load, every fused epilogue, every kernel family (planner's choice, forced
-    fit tiles with and without producer waves, register-staged kernels, split-K, the 8-phase tile).  Unsupported combinations have
+    fit tiles, register-staged kernels, split-K, the 8-phase tile).  Unsupported combinations have
     to be refused, not computed wrong.  (Found: a forced / big-tile 256 x 128 launch with an fp32 A fell through to the 64 x 64
     register-staged kernel on the 256 x 128 grid and left most of the output unwritten.)"""
     import _emu_fuzz
@@ -145,47 +145,42 @@ def test_handles_refuse_weights_whose_shapes_do_not_fit_the_configuration(emu):
         ops.ClipResNetHandle(rcfg, rp, max_batch=1, device="cpu")
 
 
-def test_fit_kernel_producer_wave_variants(emu):
-    """gemmfit.hip NPROD = 4 (fit_flags bit 6, an A/B switch that is off by default): four extra waves issue the workgroup's
-    DMA, the eight compute waves none -- ragged shapes, a fused epilogue and the 16-bit output, on all four tiles it exists for"""
-    import math
-    from pixray_amd import _lib
-    from pixray_amd._lib import GemmArgs, call
-    lib, ctx = emu.lib, _lib.tool_ctx()
-    torch.manual_seed(5)
-    try:
-        lib.prx_gemm_tile_override(ctx, -12, 0, 1)
-        lib.prx_gemm_tile_override(ctx, -8, 0, 65)
-        # both DMA completion models: deferred (data lands only when the producers' counted wait retires it: a missing or short
-        # wait shows as stale LDS) and eager (data lands at issue: a stage overwritten while still being read shows)
-        lib.hipemu_set_strict_barrier(1)      # producers and compute waves must execute the same barriers, to the last one
-        for eager, tile in [(e, t) for e in (0, 1) for t in emu.tk.PROD_TILES]:
-            lib.hipemu_set_dma_eager(eager)
-            lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
-            for (M, N, K) in [(333, 520, 512), (81, 136, 1024)]:
-                A = torch.randn(M, K).to(torch.float16)
-                Bt = (torch.randn(N, K) / math.sqrt(K)).to(torch.float16)
-                bias, resid = torch.randn(N), torch.randn(M, N)
-                g = GemmArgs()
-                g.A = A.data_ptr(); g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
-                g.alpha = 0.5; g.f32 = 2; g.bias_n = bias.data_ptr(); g.resid = resid.data_ptr(); g.ldr = N
-                out = torch.full((M, N), float("nan")); g.out_f32 = out.data_ptr(); g.ldc_f32 = N
-                o16 = torch.full((M, N), float("nan"), dtype=torch.float16); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = N
-                call("prx_k_gemm", g, None, 0, 0)
-                ref = 0.5 * (A.float() @ Bt.float().T) + bias + resid
-                assert emu.tk.rel_l2(out, ref) < 2e-5 and emu.tk.rel_l2(o16, ref) < 5e-4, (tile, M, N, K)
-        # the implicit-convolution form (gather arithmetic on the producers) with the GroupNorm sums, smallest and largest tile
-        lib.hipemu_set_dma_eager(0)
-        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
-        lib.prx_gemm_tile_override(ctx, -8, 0, 65)
-        for tile in ((16, 32), (256, 128)):
-            emu.tk.test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, "fp16")
-    finally:
-        lib.hipemu_set_dma_eager(0)
-        lib.hipemu_set_strict_barrier(0)
-        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
-        lib.prx_gemm_tile_override(ctx, -8, 0, 1)
-        lib.prx_gemm_tile_override(ctx, -12, 0, 0)
+def test_cutout_noise_drawn_in_the_kernel(emu):
+    """pixray.py:508-510 (`batch + fac * randn_like(batch)`) without a noise tensor: the stage-B kernel draws N(0,1) itself
+    (Philox4x32-10 keyed by descriptor word 32, counter = pixel index, Box-Muller).  Zero canvas, identity geometry, factor 1:
+    the output IS the noise -- moments, independence of channels / neighbours / cutouts, same key -> same bits, and a shard of
+    the batch sees the draws the whole batch sees"""
+    from pixray_amd import cutouts as pc, ops
+    n, S = 6, 64
+    desc = torch.zeros(n, pc.DESC_WORDS, dtype=torch.float64)
+    desc[:, 0:9] = torch.eye(3, dtype=torch.float64).reshape(9); desc[:, 9:18] = desc[:, 0:9]
+    desc[:, 18] = pc.MODE_IDENT; desc[:, 19] = pc.MODE_IDENT
+    desc[:, 25] = 1.0
+    desc[:, 28:32] = torch.tensor([0.0, 0.0, float(S), float(S)], dtype=torch.float64)
+    desc[:, 32] = torch.tensor([11, 12, 13, 2 ** 31 - 2, 15, 11], dtype=torch.float64)        # first and last cutout share a key
+    img = torch.zeros(1, 3, S, S)
+    z = ops.make_cutouts(img, desc, None, S)
+    assert z.shape == (n, 3, S, S) and torch.isfinite(z).all()
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    assert abs(float((z ** 3).mean())) < 0.06 and abs(float((z ** 4).mean()) - 3.0) < 0.15
+    assert torch.equal(z[0], z[5]) and not torch.equal(z[0], z[1])
+    flat = z[:5].reshape(5, 3, -1)
+    c = lambda a, b: abs(float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())))
+    assert c(flat[:, 0], flat[:, 1]) < 0.02 and c(flat[:, 0], flat[:, 2]) < 0.02 and c(flat[:, 1], flat[:, 2]) < 0.02   # channels
+    assert c(flat[:, :, 1:], flat[:, :, :-1]) < 0.02 and c(flat[0], flat[1]) < 0.03                                      # neighbours, cutouts
+    assert torch.equal(ops.make_cutouts(img, desc, None, S), z)
+    assert torch.equal(ops.make_cutouts(img, desc[2:4].contiguous(), None, S), z[2:4])
+    desc[:, 32] = 0.0                                                                           # no key, no tensor: no noise
+    assert float(ops.make_cutouts(img, desc, None, S).abs().max()) == 0.0
+    # the module draws one key per cutout and iteration from a stream of its own: the augmentation draws stay where they were
+    mk = pc.MakeCutouts(S, 4, noise_fac=0.1, generator=torch.Generator().manual_seed(5))
+    mk.prepare(iteration=0, fill=0.5)
+    k0 = mk.last_params["noise_seed"].clone()
+    ref = pc.sample_cutout_params(4, S, torch.Generator().manual_seed(5), 0, 0.1, fill=0.5)
+    assert all(torch.equal(mk.last_params[k], v) for k, v in ref.items() if isinstance(v, torch.Tensor))
+    mk(torch.rand(1, 3, S, S))
+    mk.prepare(iteration=1, fill=0.5)
+    assert not torch.equal(mk.last_params["noise_seed"], k0)
 
 
 def test_dma_rings_under_the_eager_completion_model_too(emu):
@@ -259,52 +254,6 @@ def test_vgg16_extractor_exact_mode_vs_oracle(emu):
         tf.DEV = "cuda"
 
 
-def test_vit_class_token_tail_is_the_same_tower(emu, monkeypatch):
-    """PRX_VIT_CLS_TAIL=1 (vit.hip, an A/B switch that is off by default): the last block's out-projection, MLP and their backward on
-    the class-token rows only -- nothing else of that block's output is ever read.  Exact-f32 mode: bit for bit the full tower
-    (embeddings and d/d(cutouts)); fp16: the same up to the summation order of other GEMM tiles"""
-    from pixray_amd import ops, weights
-    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
-    p = weights.synthetic_clip_vit_params(cfg, 2)
-    g = torch.Generator().manual_seed(0)
-    cuts, ge = torch.rand(5, 3, 224, 224, generator=g), torch.randn(5, cfg.output_dim, generator=g)
-    for prec, tol in (("f32", 0.0), ("fp16", 2e-3)):
-        out = {}
-        for tail in ("0", "1"):
-            monkeypatch.setenv("PRX_VIT_CLS_TAIL", tail)
-            h = ops.ClipVitHandle(cfg, p, max_batch=5, device="cpu", precision=prec)
-            x = cuts.clone().requires_grad_(True)
-            e = ops.clip_encode_image(x, h)
-            (gx,) = torch.autograd.grad(e, x, ge)
-            out[tail] = (e.detach().clone(), gx.clone())
-        for a, b in zip(out["0"], out["1"]):
-            assert float((a - b).norm() / a.norm()) <= tol, prec
-    monkeypatch.setenv("PRX_VIT_CLS_TAIL", "1")
-    emu.tp.test_clip_vit_vs_oracle("tiny-B/32", 4)
-
-
-def test_tower_lanes_are_the_same_tower(emu, monkeypatch):
-    """PRX_VIT_LANES=K (ops.TowerLanes, an A/B switch that is off by default): the cutout batch as K chunk chains on K handles (on a
-    GPU: K streams) with the batch-global min / max taken once and the renormalisation sums of the chunks added before any chunk
-    finishes its backward -- the arithmetic of cutout sharding inside one process.  Here the chunks run one after the other (the
-    emulation has no streams): embeddings and d/d(cutouts) of 2 and 3 lanes (7 cutouts: ragged chunks) against the single chain"""
-    from pixray_amd.perceptor import get_clip_perceptor
-    g = torch.Generator().manual_seed(0)
-    cuts, ge = torch.rand(7, 3, 224, 224, generator=g), torch.randn(7, 128, generator=g)
-    out = {}
-    for k in ("1", "2", "3"):
-        monkeypatch.setenv("PRX_VIT_LANES", k)
-        p = get_clip_perceptor("tiny-B/32", "cpu", max_batch=7, seed=3, precision="fp16")
-        assert (p.lanes is not None) == (k != "1")
-        x = cuts.clone().requires_grad_(True)
-        e = p.encode_image(x)
-        (gx,) = torch.autograd.grad(e, x, ge)
-        out[k] = (e.detach().clone(), gx.clone())
-    for k in ("2", "3"):
-        assert float((out[k][0] - out["1"][0]).norm() / out["1"][0].norm()) < 1e-3        # other tiles (the lanes plan for 1/K of the chip): fp16 round-off
-        assert float((out[k][1] - out["1"][1]).norm() / out["1"][1].norm()) < 1e-3
-
-
 def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
     """synth (VQ + VQGAN decode + clamp) -> cutouts -> CLIP ViT -> prompt loss -> backward to z: the smoke test's toy graph,
     IEEE-half operands, every kernel emulated.  The numbers reproduce the GPU's (profiles/: dz rel-L2 2.4e-2 on this graph)."""
@@ -318,7 +267,7 @@ def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):
 
 @pytest.mark.parametrize("size", [(96, 64), (45, 32), (64, 33)])
 def test_fft_drawer_hip_path_vs_the_explicit_dft_oracle(emu, size):
-    """csrc/fft_drawer.hip (PRX_FFT_HIP=1: pack, two exact-f32 GEMM stages against twiddle matrices, std / colour / sigmoid tail;
+    """csrc/fft_drawer.hip (pack, two exact-f32 GEMM stages against twiddle matrices, std / colour / sigmoid tail;
     the transposed chain backwards) against oracle/fft_ref.py: image and d/d(spectrum), even and odd canvas sizes"""
     from oracle import fft_ref
     from pixray_amd import ops
@@ -340,7 +289,6 @@ def test_fft_drawer_plugin_switches_to_the_hip_path(emu, monkeypatch):
     import types
     from oracle import fft_ref
     from pixray_amd.fft_drawer import FftDrawer
-    monkeypatch.setenv("PRX_FFT_HIP", "1")
     st = types.SimpleNamespace(size=(40, 24), fft_use="fft", fft_decay=1.5, fft_lrate=0.3, weight_seed=2, fft_hip_force=True)
     dr = FftDrawer(st)
     dr.load_model(st, "cpu")
@@ -464,29 +412,21 @@ _SLOW = pytest.mark.skipif(os.environ.get("PRX_EMU_SLOW", "0") != "1",
 
 
 @_SLOW
-@pytest.mark.parametrize("switches", [{}, {"PRX_FIT_FLAGS": "65", "PRX_VIT_CLS_TAIL": "1"}], ids=["default", "producers+cls_tail"])
-def test_full_depth_vit_b32_runner_vs_oracle(emu, monkeypatch, switches):
-    for k, v in switches.items():
-        monkeypatch.setenv(k, v)
+def test_full_depth_vit_b32_runner_vs_oracle(emu):
     emu.tp.test_clip_vit_vs_oracle("ViT-B/32", 8)
 
 
 @_SLOW
-@pytest.mark.parametrize("switches", [{}, {"PRX_FIT_FLAGS": "65"}], ids=["default", "producers"])
-def test_full_size_vqgan_decoder_256_vs_oracle(emu, monkeypatch, switches):
+def test_full_size_vqgan_decoder_256_vs_oracle(emu):
     """taming `imagenet_f16_16384` at its own size: z [1,256,16,16] -> image [1,3,256,256] and back (253 + 253 GFLOP through the
     emulated MFMAs), every decoder convolution on the fit kernels"""
-    for k, v in switches.items():
-        monkeypatch.setenv(k, v)
     emu.tp.test_vqgan_synth_vs_oracle("imagenet_f16_16384", 16)
 
 
 @_SLOW
-def test_headline_configuration_one_iteration_16_cutouts_all_switches(emu, monkeypatch):
-    """BASELINE.json configs[1] (VQGAN 256^2 + ViT-B/32, 2 prompts) at 16 cutouts with every prepared A/B switch on"""
+def test_headline_configuration_one_iteration_16_cutouts(emu):
+    """BASELINE.json configs[1] (VQGAN 256^2 + ViT-B/32, 2 prompts) at 16 cutouts, every kernel emulated"""
     from oracle import step_ref
-    for k, v in {"PRX_FIT_FLAGS": "65", "PRX_VIT_CLS_TAIL": "1", "PRX_VIT_LANES": "2"}.items():
-        monkeypatch.setenv(k, v)
     r = step_ref.compare_one_iteration(precision="fp16", cutn=16, device="cpu")
     assert r["indices_equal"] and r["loss_abs_err"] < 1e-3 and r["dz_rel_l2"] < 2e-2 and r["dz_cosine"] > 0.999, r
 

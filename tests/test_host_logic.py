@@ -119,7 +119,7 @@ def test_ops_fail_loudly_without_a_gpu():
     with pytest.raises(_lib.PrxError):
         ops.prompt_loss(torch.randn(4, 64), torch.randn(1, 64))
     with pytest.raises(_lib.PrxError):
-        ops.make_cutouts(torch.rand(1, 3, 32, 32), torch.zeros(2, 32, dtype=torch.float64), None, 16)
+        ops.make_cutouts(torch.rand(1, 3, 32, 32), torch.zeros(2, 36, dtype=torch.float64), None, 16)
     with pytest.raises(_lib.PrxError):          # the StyleLoss hyper-column op has no CPU route either
         ops.hypercolumns([torch.randn(1, 4, 4, 3)], torch.zeros(1, 4, 2, dtype=torch.int64), torch.zeros(6, 2))
     from pixray_amd import api
@@ -140,7 +140,7 @@ def test_cutout_params_follow_the_reference_distributions():
     assert (p["z_sat"] >= 0.9).all() and (p["z_sat"] <= 1.1).all() and (p["w_hue"].abs() <= 0.1).all()
     assert (p["w_trans"].abs() <= 0.025 * 224).all() and (p["noise_fac"] <= 0.1).all()
     d = pc.build_descriptors(p, 224)
-    assert d.shape == (64, 32) and d.dtype == torch.float64 and torch.isfinite(d).all()
+    assert d.shape == (64, pc.DESC_WORDS) and d.dtype == torch.float64 and torch.isfinite(d).all()
     # same seed -> same draws (ranks must agree when the batch is sharded)
     p2 = pc.sample_cutout_params(64, 224, torch.Generator().manual_seed(0), iteration=3)
     assert torch.equal(pc.build_descriptors(p2, 224), d)
@@ -640,23 +640,11 @@ def test_gemm_engine_kernels_have_no_scratch():
     """The GEMM kernels take their descriptor by value; one epilogue variant written the wrong way made hipcc keep that struct
     on the stack (320 bytes of scratch per lane in EVERY kernel of the file) and the engine ran 3x slower with all parity
     tests green.  The compiler's resource figures are the guard: no kernel of gemm.hip / gemmfit.hip may use scratch."""
-    import re
     for fname, at_least in (("gemm.hip", 20), ("gemmfit.hip", 6)):
         kernels = _kernel_scratch(os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc", fname))
         assert len(kernels) >= at_least
-        # the producer-wave A/B variants of the fit kernel (template argument NPROD = 4, off by default: gemmfit.hip) live on
-        # 168 registers; two of the four spill a few slots OUTSIDE the K loop (the producers' piece table, the epilogue) -- bounded
-        # here, to be removed or fixed once the variants have been measured
-        experimental = re.compile(r"gemmfit_kernelI.*Li4EEEv")
-        bad = [(n, s) for n, s in kernels if s != 0 and not experimental.search(n)]
+        bad = [(n, s) for n, s in kernels if s != 0]
         assert not bad, bad
-        assert all(s <= 256 for n, s in kernels if experimental.search(n))
-    # the A/B build with the pinned stage schedule (make sched): more fragment registers live at once -- still no scratch
-    csrc = os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc")
-    sched_obj = os.path.join(csrc, "gemmfit_sched.o")
-    if os.path.exists(sched_obj):
-        kernels = _kernel_scratch(os.path.join(csrc, "gemmfit.hip"), sched_obj)
-        assert not [(n, s) for n, s in kernels if s != 0 and not experimental.search(n)]
 
 
 def test_custom_backward_last_is_the_same_gradient():

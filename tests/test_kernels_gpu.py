@@ -266,16 +266,11 @@ def test_gemm_fit_tiles(tile, prec, stagger):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
 
 
-PROD_TILES = [(80, 128), (160, 256), (160, 192), (256, 128), (128, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
-
-
-@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="the random-shape sweeps have run on the CPU emulation only so far (tests/test_emu_cpu.py); they force the "
-                           "producer-wave variants too: PRX_TEST_EXPERIMENTAL=1, first run under a short `timeout`")
 @pytest.mark.parametrize("kind", ["gemm", "conv", "gn"])
 def test_gemm_engine_random_shapes_on_the_device(kind):
     """tests/_emu_fuzz.py on the GPU: 600 random products / 600 random implicit convolutions / 300 GroupNorm-epilogue launches over
-    every kernel family, spare rows and columns of the outputs checked for stray writes"""
+    every kernel family, spare rows and columns of the outputs checked for stray writes (first run on the device in round 5:
+    profiles/r05_first_call/r05_sweeps.log)"""
     import _emu_fuzz
     lib = _lib.load()
     if kind == "gemm":
@@ -286,23 +281,6 @@ def test_gemm_engine_random_shapes_on_the_device(kind):
     else:
         bad = _emu_fuzz.gn_cases(lib, 11, 300, device=DEV)
     assert bad == [], "\n".join(bad[:20])
-
-
-@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="producer-wave fit kernels: validated on the CPU emulation only so far (tests/test_emu_cpu.py); "
-                           "PRX_TEST_EXPERIMENTAL=1 runs them on the device -- wrap the first run in a short `timeout`")
-@pytest.mark.parametrize("tile", PROD_TILES, ids=lambda t: f"{t[0]}x{t[1]}")
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
-def test_gemm_fit_producer_wave_variants(tile, prec):
-    """fit_flags bit 6: four extra waves issue all of the workgroup's DMA (gemmfit.hip NPROD); same products, same epilogues"""
-    test_gemm_fit_tiles(tile, prec, 65)
-    if tile[0] % 80:                    # the tiles that also exist as implicit convolutions: gather arithmetic on the producers
-        lib = _lib.load()
-        try:
-            lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 65)
-            test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec)
-        finally:
-            lib.prx_gemm_tile_override(_lib.tool_ctx(), -8, 0, 1)
 
 
 FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]

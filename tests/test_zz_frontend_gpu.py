@@ -46,15 +46,13 @@ def test_settings_to_png_on_the_hip_path(tmp_path):
     assert np.abs(a - b).max() > 0                                      # the image moved
 
 
-@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="csrc/fft_drawer.hip: validated on the CPU emulation only so far (tests/test_emu_cpu.py)")
 @pytest.mark.parametrize("size", [(96, 64), (45, 32), (512, 512)])
-def test_fft_drawer_hip_path(size, monkeypatch):
-    """PRX_FFT_HIP=1 on the device: image and d/d(spectrum) against the explicit-DFT oracle, and against the torch.fft path"""
+def test_fft_drawer_hip_path(size):
+    """csrc/fft_drawer.hip (the FftDrawer's map on a GPU) on the device: image and d/d(spectrum) against the explicit-DFT oracle,
+    bit-identical when evaluated twice"""
     import types
     from oracle import fft_ref
     from pixray_amd.fft_drawer import FftDrawer
-    monkeypatch.setenv("PRX_FFT_HIP", "1")
     st = types.SimpleNamespace(size=size, fft_use="fft", fft_decay=1.5, fft_lrate=0.3, weight_seed=3)
     dr = FftDrawer(st)
     dr.load_model(st, "cuda")
@@ -68,29 +66,6 @@ def test_fft_drawer_hip_path(size, monkeypatch):
     (g,) = torch.autograd.grad((img * proj.cuda()).sum(), dr.params[0])
     (gr,) = torch.autograd.grad((ref * proj).sum(), p)
     assert float((g.cpu() - gr).norm() / gr.norm()) < 2e-5
-
-
-@pytest.mark.skipif(os.environ.get("PRX_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="ops.TowerLanes: the arithmetic is validated on the CPU emulation; the stream fork / join has not run on a device yet")
-@pytest.mark.parametrize("k", [2, 4])
-def test_tower_lanes_on_streams(k, monkeypatch):
-    """PRX_VIT_LANES=K on the device: K chunk chains on K streams against the single chain, three times in a row (a missing
-    dependency between the streams shows as run-to-run differences or garbage)"""
-    from pixray_amd.perceptor import get_clip_perceptor
-    g = torch.Generator().manual_seed(0)
-    cuts, ge = torch.rand(64, 3, 224, 224, generator=g).cuda(), torch.randn(64, 512, generator=g).cuda()
-    res = {}
-    for lanes in (1, k):
-        monkeypatch.setenv("PRX_VIT_LANES", str(lanes))
-        p = get_clip_perceptor("ViT-B/32", "cuda", max_batch=64, seed=3, precision="fp16")
-        outs = []
-        for _ in range(3):
-            x = cuts.clone().requires_grad_(True)
-            e = p.encode_image(x)
-            (gx,) = torch.autograd.grad(e, x, ge)
-            outs.append((e.detach().clone(), gx.clone()))
-        torch.cuda.synchronize()
-        assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:]), "not reproducible run to run"
-        res[lanes] = outs[0]
-    assert float((res[k][0] - res[1][0]).norm() / res[1][0].norm()) < 1e-3
-    assert float((res[k][1] - res[1][1]).norm() / res[1][1].norm()) < 5e-3
+    img2 = dr.synth(0)                                                    # the std's sums are taken in a fixed order
+    (g2,) = torch.autograd.grad((img2 * proj.cuda()).sum(), dr.params[0])
+    assert torch.equal(img2, img) and torch.equal(g2, g)

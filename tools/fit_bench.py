@@ -122,8 +122,6 @@ for M, N, K, tag, epi, tile in shapes:
     res = {}
     variants = dict(engine=(0, 0, 0, 0), fit0=(tile[0], tile[1], 1, 0), fit=(tile[0], tile[1], 1, 1),
                     loop=(tile[0], tile[1], 1, 1 + 4), epi=(tile[0], tile[1], 1, 1 + 8))
-    if tile != (160, 128):      # producer-wave variants (gemmfit.hip NPROD = 4, switch bit 6): every tile but 160 x 128
-        variants.update(prod=(tile[0], tile[1], 1, 65), prodloop=(tile[0], tile[1], 1, 65 + 4))
     for name, (bm, bn, fit, flags) in variants.items():
         lib.prx_gemm_tile_override(ctx, -8, 0, flags)
         set_tile(bm, bn, fit)
@@ -150,6 +148,4 @@ for M, N, K, tag, epi, tile in shapes:
     print(f"{tag:42s} M={M:5d} N={N:5d} K={K:5d} sets={nset:2d}: engine {e[0]:6.1f} us {fl / e[0] / 1e6:5.0f} TF (err {e[1]:.1e}) | "
           f"fit {tile[0]}x{tile[1]} flags 0/1: {res['fit0'][0]:6.1f} {f[0]:6.1f} us {fl / f[0] / 1e6:5.0f} TF "
           f"(err {max(res['fit0'][1], f[1]):.1e} pre {f[2]:.1e} rerun-same {f[3] and res['fit0'][3]}) | "
-          f"loop only {res['loop'][0]:5.1f} epilogue only {res['epi'][0]:5.1f} | vendor plain {us_lib:6.1f} us {fl / us_lib / 1e6:5.0f} TF"
-          + (f" | producer waves {res['prod'][0]:6.1f} us (err {res['prod'][1]:.1e} rerun-same {res['prod'][3]}) loop only {res['prodloop'][0]:5.1f}"
-             if "prod" in res else ""), flush=True)
+          f"loop only {res['loop'][0]:5.1f} epilogue only {res['epi'][0]:5.1f} | vendor plain {us_lib:6.1f} us {fl / us_lib / 1e6:5.0f} TF", flush=True)

@@ -63,7 +63,7 @@ for H, W, Cin, Cout, up in shapes:
     res = {}
     for kind in ("rowmajor", "fwd", "fwd+gn", "dgrad", "dgrad+gnb"):
         g = args(kind)
-        for name, flags in (("all", 1), ("loop", 1 + 4), ("epi", 1 + 8), ("prod", 65), ("prodloop", 65 + 4)):   # 64: producer-wave variants
+        for name, flags in (("all", 1), ("loop", 1 + 4), ("epi", 1 + 8)):
             lib.prx_gemm_tile_override(ctx, -8, 0, flags)
             if kind == "fwd+gn":
                 fn = lambda: call("prx_k_gemm_gn", g, stats, gs, None, None, None, None, 0, 1e-6, None, 0, s)
@@ -75,5 +75,5 @@ for H, W, Cin, Cout, up in shapes:
     lib.prx_gemm_tile_override(ctx, -8, 0, 1)
     fl = 2.0 * M * Cout * K
     print(f"{H}x{W} {Cin}->{Cout} (M={M} N={Cout} K={K}): " + " | ".join(
-        f"{kind}: {res[(kind, 'all')]:5.1f} us ({fl / res[(kind, 'all')] / 1e6:4.0f} TF; loop {res[(kind, 'loop')]:5.1f}, epilogue {res[(kind, 'epi')]:5.1f}; producers {res[(kind, 'prod')]:5.1f}, their loop {res[(kind, 'prodloop')]:5.1f})"
+        f"{kind}: {res[(kind, 'all')]:5.1f} us ({fl / res[(kind, 'all')] / 1e6:4.0f} TF; loop {res[(kind, 'loop')]:5.1f}, epilogue {res[(kind, 'epi')]:5.1f})"
         for kind in ("rowmajor", "fwd", "fwd+gn", "dgrad", "dgrad+gnb")), flush=True)

@@ -150,6 +150,7 @@ static inline void __threadfence_system() {}
 #define __builtin_amdgcn_s_barrier() hipemu::syncthreads()
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
