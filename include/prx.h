@@ -398,10 +398,11 @@ int prx_clip_text_encode(prx_clip_text* h, const int* tokens, int n, float* embe
 
 /* --- Prompt.forward (pixray.py:275-280) fused with its backward.
  * rowloss[i] = sum_j sign(w) * 2*asin(|x^_i - e^_j|/2)^2;  *loss (optional, may be NULL) = |w| * sum(rowloss) / denom, the value
- * Prompt.forward returns (rows added in a fixed order);
+ * Prompt.forward returns, written by the workgroup that finishes last (rows added in a fixed order); `ticket`: one device word
+ * that is zero on entry and zero again on exit (needed with `loss`; one per stream that may run this concurrently);
  * grad = d/d input of |w| * mean(max(sign(w) d, stop)) with the mean over `denom` (= global n*m) pairs. */
 int prx_prompt_loss_fwd_bwd(const float* input, const float* embed, int n, int m, int D, float weight, float stop,
-                            float denom, float* rowloss, float* grad, float* loss, prx_stream_t s);
+                            float denom, float* rowloss, float* grad, float* loss, unsigned* ticket, prx_stream_t s);
 
 /* --- optim.Adam([z], lr) step (pixray.py:539,1484-1485) fused with VqganDrawer.clip_z (vqgan.py:202-204).
  * z/exp_avg/exp_avg_sq/grad: [1,C,hw] fp32; zmin/zmax per channel or NULL; step is 1-based. */

@@ -138,9 +138,9 @@ int prx_clip_vit_backward_finish(prx_clip_vit* h, const float* cutouts, const fl
 
 // ---- Prompt loss, optimiser -------------------------------------------------------------------
 int prx_prompt_loss_fwd_bwd(const float* input, const float* embed, int n, int m, int D, float weight, float stop,
-                            float denom, float* rowloss, float* grad, float* loss, prx_stream_t s) {
+                            float denom, float* rowloss, float* grad, float* loss, unsigned* ticket, prx_stream_t s) {
     PRX_REQUIRE(input && embed && rowloss && grad, "prx_prompt_loss_fwd_bwd: null argument");
-    return prx_prompt_loss(input, embed, n, m, D, weight, stop, denom, rowloss, grad, loss, S_(s));
+    return prx_prompt_loss(input, embed, n, m, D, weight, stop, denom, rowloss, grad, loss, ticket, S_(s));
 }
 int prx_adam_clamp_step(float* z, float* exp_avg, float* exp_avg_sq, const float* grad, const float* zmin,
                         const float* zmax, int hw, size_t n, float lr, float beta1, float beta2, float eps, int step,

@@ -96,6 +96,20 @@ __device__ __forceinline__ bf16x4 to_op16x4(float a, float b, float c, float d, 
     return r;
 }
 
+// "stream" tensors of the runners (residual streams, feature maps, their gradients): fp32, or -- s16 -- the handle's 16-bit
+// operand format (the lean layout of the half mode: one 16-bit tensor is both the saved activation and the next GEMM's operand).
+// i4: index in units of 4 elements
+// (S16 is a template argument: a run-time test between the loads of one iteration would serialise their round trips)
+template <bool S16>
+__device__ __forceinline__ float4 stream_ld4(const void* p, size_t i4, int h16) {
+    if constexpr (S16) {
+        const bf16x4 t = reinterpret_cast<const bf16x4*>(p)[i4];
+        return make_float4(from_op16(t[0], h16), from_op16(t[1], h16), from_op16(t[2], h16), from_op16(t[3], h16));
+    } else {
+        return reinterpret_cast<const float4*>(p)[i4];
+    }
+}
+
 // operand element access, generic over {bf16_t, half_t, float}
 template <typename T> __device__ __forceinline__ float op_ld(const T* p, size_t i) { return (float)p[i]; }
 template <typename T> __device__ __forceinline__ void op_st(T* p, size_t i, float v) { p[i] = (T)v; }

@@ -7,7 +7,8 @@ int prx_softmax_rows(const float* S, int lds_, float scale, void* P, int ldp, vo
                      int cols, int prec, hipStream_t s);
 int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, float scale, void* dS, int ldds,
                          void* dST, int lddst, int rows, int cols, int prec, hipStream_t s);
-int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16 = 0);
+// s16: `hi` is a 16-bit stream in the operand format (lean layout); `low` (fp32) may then be null
+int prx_upsample2x_bwd(const void* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16 = 0, int s16 = 0);
 int prx_nchw_to_nhwc(const float* in, float* out_f32, bf16_t* out_bf16, int NB, int C, int HW, int Cpad, hipStream_t s, int h16 = 0);
 int prx_nhwc_to_nchw(const float* in, int ldc, float* out, int NB, int C, int HW, hipStream_t s);
 int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int HW, hipStream_t s);

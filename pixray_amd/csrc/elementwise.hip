@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restri
 }
 
 // low[b][y][x][c] = sum over the 2x2 children of hi (NHWC fp32) -- backward of nearest-2x upsample
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ hi, float* __restrict__ low,
+template <bool S16>       // S16: `hi` is a 16-bit stream in the operand format (the lean layout)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const void* __restrict__ hi, float* __restrict__ low,
                                                              bf16_t* __restrict__ low_bf16, int NB, int Hl, int Wl,
                                                              int C, int h16) {
     const int C4 = C >> 2;
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         size_t t = pix / Wl;
         int y = (int)(t % Hl);
         int b = (int)(t / Hl);
-        const float4* h4 = reinterpret_cast<const float4*>(hi);
         size_t p00 = (((size_t)b * Hl * 2 + 2 * y) * Wh + 2 * x) * C4 + cq;
-        float4 a = h4[p00], bb = h4[p00 + C4], c = h4[p00 + (size_t)Wh * C4], d = h4[p00 + (size_t)Wh * C4 + C4];
+        float4 a = stream_ld4<S16>(hi, p00, h16), bb = stream_ld4<S16>(hi, p00 + C4, h16), c = stream_ld4<S16>(hi, p00 + (size_t)Wh * C4, h16),
+               d = stream_ld4<S16>(hi, p00 + (size_t)Wh * C4 + C4, h16);
         float4 o = make_float4((a.x + bb.x) + (c.x + d.x), (a.y + bb.y) + (c.y + d.y), (a.z + bb.z) + (c.z + d.z),
                                (a.w + bb.w) + (c.w + d.w));
-        reinterpret_cast<float4*>(low)[idx] = o;
+        if (low) reinterpret_cast<float4*>(low)[idx] = o;
         if (low_bf16) {
             reinterpret_cast<bf16x4*>(low_bf16)[idx] = to_op16x4(o.x, o.y, o.z, o.w, h16);
         }
@@ -273,10 +274,12 @@ int prx_softmax_rows_bwd(const void* P, int ldp, const float* dP, int lddp, floa
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_upsample2x_bwd(const float* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16) {
-    PRX_REQUIRE(C % 4 == 0, "upsample2x_bwd: C %% 4 != 0");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, low_bf16,
-                       NB, Hl, Wl, C, h16);
+int prx_upsample2x_bwd(const void* hi, float* low, bf16_t* low_bf16, int NB, int Hl, int Wl, int C, hipStream_t s, int h16, int s16) {
+    PRX_REQUIRE(C % 4 == 0 && (low || low_bf16), "upsample2x_bwd: C %% 4 != 0, or no output");
+    if (s16) hipLaunchKernelGGL(upsample2x_bwd_kernel<true>, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, low_bf16,
+                                NB, Hl, Wl, C, h16);
+    else hipLaunchKernelGGL(upsample2x_bwd_kernel<false>, dim3(ew_grid((size_t)NB * Hl * Wl * C / 4)), dim3(256), 0, s, hi, low, low_bf16,
+                            NB, Hl, Wl, C, h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }

@@ -39,6 +39,8 @@ struct GemmDesc {
     const float* bias_m = nullptr;
     const void* aux = nullptr; int ldaux = 0;   // operand precision
     const float* resid = nullptr; int ldr = 0;
+    const void* resid16 = nullptr;       // ... or the residual as a 16-bit stream in the operand format (the lean layout of the runners:
+                                         // residual / feature-map streams kept in IEEE half); same leading dimension `ldr`; not both
     int act = PRX_ACT_NONE;
     float* out_f32 = nullptr; int ldc_f32 = 0;
     void* out_bf16 = nullptr;        // post-activation, operand precision (the next GEMM's A)
@@ -54,6 +56,7 @@ struct GemmDesc {
     // * gamma, accumulate (sum dxhat, sum dxhat*xhat) per group into gn_stats -- saves the stats pass of the GroupNorm
     // backward (8 bytes read per element) for 4 bytes read in this epilogue.
     const float* gnb_x = nullptr;        // [M, N] fp32, the GroupNorm's forward input
+    const void* gnb_x16 = nullptr;       // ... or the same as a 16-bit stream in the operand format (lean layout); not both
     const double* gnb_fstats = nullptr;  // its forward sums [32][2]
     const float* gnb_gamma = nullptr;
     const float* gnb_beta = nullptr;
@@ -77,6 +80,7 @@ struct GemmCtx {
                                  // gemm.hip plan_8phase then decides by cost: full rounds of 256 tiles on it, the remainder rows on the 4-wave kernels)
     int fit_flags = 1;           // gemmfit.hip A/B switches: bit 0 staggered wave groups (PRX_FIT_FLAGS)
     int n_cu = 0;                // compute units of the device this context launches on (0: not asked yet; planners then assume 256)
+    int n_cu_dev = -1;           // ... and the device the count was taken from (re-asked when the context launches on another one)
     int force_fit = 0;           // with force_bm: the tile shapes both kernel families have mean the fit kernel (tests, tools)
     int dbg_only = -2, dbg_count = 0;   // bisection aid (override -13)
     int fit_conv = 1;            // ... for the implicit 3x3 convolutions as well (PRX_FIT_CONV)

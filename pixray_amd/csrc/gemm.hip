@@ -652,7 +652,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         float gs0 = 0.f, gs1 = 0.f;
         const int rbase = tm * BM + wm * (BM / NWM);
         const int cbase = tn * BN + wn * (BN / 2);
-        const bool gnb = do_stats && d.gnb_x != nullptr;
+        const bool gnb = do_stats && (d.gnb_x != nullptr || d.gnb_x16 != nullptr);
         GnbConst gc{};
         if (gnb && cbase + (lane % LPR) * 4 < d.N) gc = gnb_load(d, cbase + (lane % LPR) * 4);   // this lane's column quad is fixed
 #pragma unroll
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
                         *reinterpret_cast<float4*>(&p.ws[((size_t)split * d.M + row) * d.N + col]) = v;
                     else {
                         const float4 o = epilogue_store4<T16>(d, row, col, v);
-                        if (gnb) gnb_accum(d, gc, row, col, o, gs0, gs1);
+                        if (gnb) gnb_accum<T16>(d, gc, row, col, o, gs0, gs1);
                         else {
                             gs0 += (o.x + o.y) + (o.z + o.w);
                             gs1 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 const int row = (int)(idx / d.N);
                 col = (int)(idx - (size_t)row * d.N);
                 const float4 o = epilogue_store4<TOp>(d, row, col, v);
-                if (do_stats && d.gnb_x) gnb_accum(d, gnb_load(d, col), row, col, o, s0, s1);
+                if (do_stats && (d.gnb_x || d.gnb_x16)) gnb_accum<TOp>(d, gnb_load(d, col), row, col, o, s0, s1);
                 else {
                     s0 = (o.x + o.y) + (o.z + o.w);
                     s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
@@ -909,7 +909,10 @@ void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, i
     if (M <= 0) { c->rules.clear(); return; }
     for (size_t i = 0; i < c->rules.size(); ++i)
         if (c->rules[i].M == M && c->rules[i].N == N && c->rules[i].K == K && c->rules[i].mode == mode) { c->rules.erase(c->rules.begin() + i); break; }
-    if (bm > 0) c->rules.push_back({M, N, K, mode, bm, bn, splits});
+    // a rule names a tile of the 4-wave / 8-phase families; anything else (e.g. a profile record's "fit tile" code bm + 1000 fed
+    // back verbatim) matches no kernel and is dropped here instead of at the launch
+    const bool known = (bm == 64 && bn == 64) || (bm == 128 && (bn == 64 || bn == 128)) || (bm == 256 && (bn == 128 || bn == 256));
+    if (bm > 0 && known) c->rules.push_back({M, N, K, mode, bm, bn, splits});
 }
 
 void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
@@ -999,6 +1002,7 @@ static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
     if (d.bias_m) s.bias_m = d.bias_m + r0;
     if (d.aux) s.aux = (const char*)d.aux + (size_t)r0 * d.ldaux * esz;
     if (d.resid) s.resid = d.resid + (size_t)r0 * d.ldr;
+    if (d.resid16) s.resid16 = (const char*)d.resid16 + (size_t)r0 * d.ldr * esz;
     if (d.out_f32) s.out_f32 = d.out_f32 + (size_t)r0 * d.ldc_f32;
     if (d.out_bf16) s.out_bf16 = (char*)d.out_bf16 + (size_t)r0 * d.ldc_bf16 * esz;
     if (d.out_bf16_pre) s.out_bf16_pre = (char*)d.out_bf16_pre + (size_t)r0 * d.ldc_bf16 * esz;
@@ -1018,10 +1022,13 @@ int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K) {
 
 int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx) {
     static const GemmCtx k_default;      // immutable: heuristics only
-    if (ctx && ctx->n_cu == 0) {         // the planners count tiles against THIS device's CUs (cost constants stay MI355X's)
+    int cur_dev = -1;
+    if (ctx && (ctx->n_cu == 0 || (hipGetDevice(&cur_dev) == hipSuccess && cur_dev != ctx->n_cu_dev))) {
+        // the planners count tiles against the LAUNCHING device's CUs (cost constants stay MI355X's); re-asked when the context
+        // launches on another device than the one the count was taken from
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            ctx->n_cu = cus;
+            { ctx->n_cu = cus; ctx->n_cu_dev = dev; }
         else
             ctx->n_cu = 256;
     }
@@ -1065,6 +1072,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
                 "gemm: MUL_DQUICKGELU / MUL_RELUMASK / RELUMASK_POST need aux");
     PRX_REQUIRE(d.act != PRX_ACT_RELUMASK_POST || d.resid, "gemm: RELUMASK_POST masks product + residual: it needs resid");
     PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
+    PRX_REQUIRE(!(d.resid && d.resid16) && !(d.gnb_x && d.gnb_x16) && (!d.f32 || (!d.resid16 && !d.gnb_x16)),
+                "gemm: resid16 / gnb_x16 are the 16-bit forms of resid / gnb_x (one of each, 16-bit operand modes only)");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
     // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the
@@ -1135,7 +1144,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     auto al = [](const void* p, size_t a_) { return p == nullptr || ((uintptr_t)p % a_) == 0; };
     const size_t opa = d.f32 ? 16 : 8;   // alignment of a 4-element operand-precision access
-    a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && (d.resid == nullptr || d.ldr % 4 == 0) &&
+    a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && al(d.resid16, 8) && ((d.resid == nullptr && d.resid16 == nullptr) || d.ldr % 4 == 0) &&
                 al(d.aux, opa) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
                 (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, opa) && al(d.out_bf16_pre, opa) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
@@ -1156,10 +1165,10 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // 8-phase tiles (tools/micro/gemm8p.hip): +11 % at M = 65 792, N = 1024 and at M = 25 216, N = 3072; -2 % at 8192^3
     if (BM == 256 && BN == 256 && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 512 && d.N <= 4096;
     if (fit_tile && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 16;
-    if (d.gnb_x) {
-        PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && d.out_f32 && d.act == PRX_ACT_NONE,
-                    "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain fp32 output");
-        PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
+    if (d.gnb_x || d.gnb_x16) {
+        PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && (d.out_f32 || d.out_bf16) && d.act == PRX_ACT_NONE,
+                    "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain output");
+        PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_x16 % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
                     "gemm: gnb operands must be 16-byte aligned");
     }
     if (d.gn_stats) {

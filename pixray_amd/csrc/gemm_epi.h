@@ -36,9 +36,12 @@ __device__ __forceinline__ GnbConst gnb_load(const GemmDesc& d, int col) {
     c.be = *reinterpret_cast<const float4*>(d.gnb_beta + col);
     return c;
 }
+template <typename TOp>
 __device__ __forceinline__ void gnb_accum(const GemmDesc& d, const GnbConst& c, int row, int col, const float4& o, float& s0, float& s1) {
-    const float4 x = *reinterpret_cast<const float4*>(d.gnb_x + (size_t)row * d.N + col);
-    const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
+    float xv[4];
+    if (d.gnb_x16) op_ld4(reinterpret_cast<const TOp*>(d.gnb_x16), (size_t)row * d.N + col, xv);
+    else op_ld4(d.gnb_x, (size_t)row * d.N + col, xv);
+    const float gv[4] = {o.x, o.y, o.z, o.w};
     const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -66,6 +69,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     const bool masked = (d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST) && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f);
     if (masked && d.act == PRX_ACT_MUL_RELUMASK) v = 0.f;
     if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
+    else if (d.resid16) v += op_ld(reinterpret_cast<const TOp*>(d.resid16), (size_t)row * d.ldr + col);
     if (masked && d.act == PRX_ACT_RELUMASK_POST) v = 0.f;          // the mask after the residual add
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
@@ -128,7 +132,12 @@ __device__ __forceinline__ float4 epilogue_value4(const GemmDesc& d, int row, in
         op_ld4(reinterpret_cast<const TOp*>(d.aux), (size_t)row * d.ldaux + col, aux);
     float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d.resid) res = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
-    return epilogue_math4<TOp>(d.act, alpha, v, bias, bias_m, aux, d.resid != nullptr, res, pre);
+    else if (d.resid16) {
+        float r4[4];
+        op_ld4(reinterpret_cast<const TOp*>(d.resid16), (size_t)row * d.ldr + col, r4);
+        res = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    }
+    return epilogue_math4<TOp>(d.act, alpha, v, bias, bias_m, aux, d.resid != nullptr || d.resid16 != nullptr, res, pre);
 }
 
 template <typename TOp>

@@ -130,10 +130,11 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     const bool col_ok = lane < RPP * LPR && col < d.N;        // N % 8 == 0: a lane's 8 columns are in range together
     const int act = d.act;
     const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
-    const bool has_resid = d.resid != nullptr;
+    const bool has_resid = d.resid != nullptr || d.resid16 != nullptr;
+    const bool row16 = d.resid16 != nullptr || d.gnb_x16 != nullptr;      // the row operand (residual / GroupNorm input) is a 16-bit stream
     const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
     const bool do_stats = d.gn_stats != nullptr;
-    const bool gnb = do_stats && d.gnb_x != nullptr;
+    const bool gnb = do_stats && (d.gnb_x != nullptr || d.gnb_x16 != nullptr);
     float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
     if (d.bias_n && col_ok) {
         bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
@@ -160,7 +161,11 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                 pf[ic][ps][0] = pf[ic][ps][1] = uint4{0u, 0u, 0u, 0u};
                 pbm[ic][ps] = 0.f;
                 if (ok) {
-                    if (has_resid || gnb) {
+                    if (row16) {            // 8 columns = one 16-byte load; widened to fp32 in place below
+                        const T16* r_ = has_resid ? reinterpret_cast<const T16*>(d.resid16) + (size_t)row * d.ldr + col
+                                                  : reinterpret_cast<const T16*>(d.gnb_x16) + (size_t)row * d.N + col;
+                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
+                    } else if (has_resid || gnb) {
                         const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
                         pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
                         pf[ic][ps][1] = *reinterpret_cast<const uint4*>(r_ + 4);
@@ -189,6 +194,11 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                 float4 v1 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc + 4]);
                 float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
                 float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, p0, p1;
+                if (row16) {
+                    const t16x8 rx = __builtin_bit_cast(t16x8, pf[ic][ps][0]);
+                    pf[ic][ps][0] = __builtin_bit_cast(uint4, make_float4((float)rx[0], (float)rx[1], (float)rx[2], (float)rx[3]));
+                    pf[ic][ps][1] = __builtin_bit_cast(uint4, make_float4((float)rx[4], (float)rx[5], (float)rx[6], (float)rx[7]));
+                }
                 if (has_resid) {
                     r0 = __builtin_bit_cast(float4, pf[ic][ps][0]);
                     r1 = __builtin_bit_cast(float4, pf[ic][ps][1]);
@@ -504,8 +514,8 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     const int wave_tn = ft->tn;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // null passes
     // the epilogue handles 8 consecutive columns per lane with 16-byte accesses
-    const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
-                        al16(d.out_bf16_pre) && (!d.resid || d.ldr % 4 == 0) && (!d.aux || d.ldaux % 8 == 0) &&
+    const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.resid16) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
+                        al16(d.out_bf16_pre) && (!d.resid || d.ldr % 4 == 0) && (!d.resid16 || d.ldr % 8 == 0) && (!d.aux || d.ldaux % 8 == 0) &&
                         (!d.out_f32 || d.ldc_f32 % 4 == 0) && ((!d.out_bf16 && !d.out_bf16_pre) || d.ldc_bf16 % 8 == 0);
     // GroupNorm sums: the lanes of a column quad are reduced by a butterfly (16 FN / 8 lanes per row: a power of two), a
     // group is a whole number of quads inside the block tile, and the GroupNorm-backward input has the output's layout
@@ -513,7 +523,7 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     if (d.gn_stats) {
         const int lpr = wave_tn / 8;
         stats_ok = (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
-                   (!d.gnb_x || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
+                   al16(d.gnb_x16) && ((!d.gnb_x && !d.gnb_x16) || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
     }
     const bool a_ok = d.a_mode == PRX_A_ROWMAJOR
                           ? (unsigned long long)d.M * d.lda < (1ull << 31)
@@ -521,7 +531,8 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
                              d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
                              d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
     // the epilogue prefetches ONE row operand per output row into shared registers: residual, aux, or the GroupNorm input
-    const bool one_operand = !(d.resid && d.aux) && !(d.gnb_x && (d.resid || d.aux));
+    const bool has_res = d.resid || d.resid16, has_gnb = d.gnb_x || d.gnb_x16;
+    const bool one_operand = !(has_res && d.aux) && !(has_gnb && (has_res || d.aux));
     return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && one_operand && d.M >= 1 &&
            (unsigned long long)d.N * d.ldb < (1ull << 31);
 }

@@ -1,7 +1,7 @@
 #pragma once
 #include "common.h"
 int prx_prompt_loss(const float* x, const float* embed, int n, int m, int D, float weight, float stop, float denom,
-                    float* rowloss, float* grad, float* loss, hipStream_t s);
+                    float* rowloss, float* grad, float* loss, unsigned* ticket, hipStream_t s);
 int prx_l2norm_fwd(const float* e, float* out, int n, int D, hipStream_t s);
 int prx_l2norm_bwd(const float* e, const float* g, float* de, int n, int D, hipStream_t s);
 int prx_sqnorm_rows(const float* w, float* out, int rows, int D, hipStream_t s);

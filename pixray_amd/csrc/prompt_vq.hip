@@ -60,23 +60,28 @@ __device__ __forceinline__ float prompt_loss_row(const float* __restrict__ x, co
     return loss;
 }
 
-// ONE workgroup of 16 waves walks the rows (wave w: rows w, w + 16, ...), so that the scalar the loop adds up -- loss =
-// |w| * sum(rowloss) / denom, pixray.py:280 -- leaves the same launch in a fixed summation order (it used to take a torch
-// reduction and a scalar multiply per Prompt and iteration); the work is n * m * D = 64 x 2 x 512 values.
-__global__ __launch_bounds__(1024) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
-                                                           int n, int m, int D, float weight, float stop, float denom,
-                                                           float* __restrict__ rowloss, float* __restrict__ grad, float* __restrict__ loss_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ float wsum[16];
-    float wacc = 0.f;
-    for (int i = wave; i < n; i += 16) wacc += prompt_loss_row(x, embed, i, lane, n, m, D, weight, stop, denom, rowloss, grad);
-    if (lane == 0) wsum[wave] = wacc;
+// One wave per row, four rows per workgroup.  The scalar the loop adds up -- loss = |w| * sum(rowloss) / denom, pixray.py:280 --
+// leaves the same launch (it used to take a torch reduction and a scalar multiply per Prompt and iteration): the workgroup that
+// finishes last (a ticket counter the caller hands over zeroed; it is zero again on exit) adds the row values in a fixed order.
+__global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
+                                                          int n, int m, int D, float weight, float stop, float denom,
+                                                          float* __restrict__ rowloss, float* __restrict__ grad, float* __restrict__ loss_out,
+                                                          unsigned* __restrict__ ticket) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i < n) prompt_loss_row(x, embed, i, lane, n, m, D, weight, stop, denom, rowloss, grad);
+    if (!loss_out) return;
+    __shared__ unsigned last;
+    __threadfence();                       // this workgroup's row values are visible device-wide before its ticket is drawn
     __syncthreads();
-    if (threadIdx.x == 0 && loss_out) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += wsum[w];
-        *loss_out = t * (fabsf(weight) / denom);
-    }
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    float t = 0.f;
+    for (int r = lane; r < n; r += 64) t += *reinterpret_cast<const volatile float*>(rowloss + r);      // written by other workgroups: read past this CU's L1
+    t = wave_sum(t);
+    if (lane == 0) { *loss_out = t * (fabsf(weight) / denom); *ticket = 0u; }
 }
 
 // e_hat = e/|e|  (slip.py:66) and its backward  de = (g - e_hat (e_hat.g))/|e|
@@ -234,10 +239,11 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict_
 }  // namespace
 
 int prx_prompt_loss(const float* x, const float* embed, int n, int m, int D, float weight, float stop, float denom,
-                    float* rowloss, float* grad, float* loss, hipStream_t s) {
+                    float* rowloss, float* grad, float* loss, unsigned* ticket, hipStream_t s) {
     PRX_REQUIRE(D % 64 == 0 && D <= 1024, "prompt_loss: D must be a multiple of 64 and <= 1024 (D=%d)", D);
-    hipLaunchKernelGGL(prompt_loss_kernel, dim3(1), dim3(1024), 0, s, x, embed, n, m, D, weight, stop, denom,
-                       rowloss, grad, loss);
+    PRX_REQUIRE(!loss || ticket, "prompt_loss: the scalar result needs a zeroed ticket word");
+    hipLaunchKernelGGL(prompt_loss_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, x, embed, n, m, D, weight, stop, denom,
+                       rowloss, grad, loss, ticket);
     PRX_LAUNCH_CHECK();
     return 0;
 }

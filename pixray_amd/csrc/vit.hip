@@ -69,8 +69,9 @@ int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStrea
 struct VitLayer {
     float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *b1, *b2;
     void *Wqkv, *WqkvT, *Wo, *WoT, *W1, *W1T, *W2, *W2T;   // operand precision (bf16 | fp32)
-    // saved activations
-    float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
+    // saved activations (x_in / x_mid: the residual stream, fp32 -- or the 16-bit operand format in the lean layout)
+    void *x_in, *x_mid;
+    float *mean1, *rstd1, *mean2, *rstd2;
     void *qkv, *t;    // operand precision
     void* o_save;     // attention output, kept for the general-T backward (T > 64) and the fp32 attention
     float* lse;
@@ -88,7 +89,12 @@ struct PrxVit {
     std::vector<VitLayer> L;
     // workspace
     void *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf;   // operand precision
-    float *xpre, *mean_pre, *rstd_pre, *x_final, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
+    float *xpre, *mean_pre, *rstd_pre, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
+    void* x_final;
+    // The lean layout (half mode, PRX_LEAN): the residual stream and its gradient live in IEEE half only -- the reference's own
+    // GPU arithmetic for this tower (slip.py:175: the CLIP model runs in fp16, residual adds included).  One 16-bit tensor is
+    // the saved activation, the LayerNorm input and the residual operand of the next product; dx / dh have no fp32 copy.
+    int lean;
     float* ws; size_t ws_bytes;
     int cur_n;
     // The class-token tail: only the class token of the LAST block's output is ever read (ln_post on token 0, slip.py:66 / clip
@@ -142,6 +148,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
     v->gs = nullptr;
+    { const char* e = getenv("PRX_LEAN"); v->lean = (v->h16 && !(e && atoi(e) == 0)) ? 1 : 0; }
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -175,7 +182,8 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
         if ((r = copy_f32(v, &y.b1, q[9], 4 * W, s))) return r;
         if ((r = pack_both(v, &y.W2, &y.W2T, q[10], W, 4 * W, s))) return r;
         if ((r = copy_f32(v, &y.b2, q[11], W, s))) return r;
-        ALLOC(y.x_in, R * W); ALLOC(y.x_mid, R * W);
+        if (v->lean) { ALLOC_OP(y.x_in, R * W); ALLOC_OP(y.x_mid, R * W); }
+        else { float *a_, *b_; ALLOC(a_, R * W); ALLOC(b_, R * W); y.x_in = a_; y.x_mid = b_; }
         ALLOC(y.mean1, R); ALLOC(y.rstd1, R); ALLOC(y.mean2, R); ALLOC(y.rstd2, R);
         ALLOC_OP(y.qkv, R * 3 * W); ALLOC_OP(y.t, R * 4 * W);
         y.o_save = nullptr; y.lse = nullptr;
@@ -188,10 +196,15 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     if ((r = pack_both(v, &v->proj, &v->projT, q[2], W, out_dim, s))) return r;
     ALLOC_OP(v->A0, R * KP); ALLOC_OP(v->h, R * W); ALLOC_OP(v->att_o, R * W); ALLOC_OP(v->u, R * 4 * W);
     ALLOC_OP(v->hpost, (size_t)max_n * W); ALLOC_OP(v->dt, R * 4 * W); ALLOC_OP(v->do_, R * W); ALLOC_OP(v->dqkv, R * 3 * W);
-    ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R); ALLOC(v->x_final, R * W);
+    ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R);
+    if (v->lean) ALLOC_OP(v->x_final, R * W);
+    else { float* a_; ALLOC(a_, R * W); v->x_final = a_; }
     ALLOC(v->mean_post, max_n); ALLOC(v->rstd_post, max_n); ALLOC(v->e, (size_t)max_n * out_dim);
-    ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
-    // bf16 twins of the fp32 gradient streams (the dgrad GEMMs' A operands); the exact mode reads the fp32 streams themselves
+    v->dx = v->dh = nullptr;
+    if (!v->lean) { ALLOC(v->dx, R * W); ALLOC(v->dh, R * W); }
+    ALLOC(v->dA0, R * KP); ALLOC(v->de, (size_t)max_n * out_dim);
+    // bf16 twins of the fp32 gradient streams (the dgrad GEMMs' A operands); the exact mode reads the fp32 streams themselves;
+    // in the lean layout they ARE the gradient streams
     if (v->f32) { v->dx_bf = v->dx; v->dh_bf = v->dh; }
     else { ALLOC_OP(v->dx_bf, R * W); ALLOC_OP(v->dh_bf, R * W); }
     ALLOC(v->dhpost, (size_t)max_n * W); ALLOC(v->mm_part, 2 * 1024);
@@ -216,17 +229,18 @@ static int vit_gemm(PrxVit* v, GemmDesc& d, hipStream_t s) {
 GemmCtx* prx_vit_gemm_ctx_impl(PrxVit* v) { return v ? &v->gctx : nullptr; }
 
 // LayerNorm whose output is a GEMM operand: bf16, or fp32 in the exact mode (the kernel has both outputs)
-static int ln_op(PrxVit* v, const float* x, long long ldx, const float* g, const float* b, void* out, float* mean, float* rstd,
+static int ln_op(PrxVit* v, const void* x, long long ldx, const float* g, const float* b, void* out, float* mean, float* rstd,
                  int rows, hipStream_t s) {
     return prx_layernorm_fwd(x, ldx, g, b, v->f32 ? nullptr : (bf16_t*)out, v->f32 ? (float*)out : nullptr, mean, rstd, rows,
-                             v->width, 1e-5f, s, v->h16);
+                             v->width, 1e-5f, s, v->h16, v->lean);
 }
 // LayerNorm backward producing the fp32 gradient stream + its operand twin (the same buffer in the exact mode)
-static int ln_bwd_op(PrxVit* v, const float* g, long long ldg, const float* x, long long ldx, const float* gamma, const float* mean,
-                     const float* rstd, const float* add, long long ldadd, float* dx, long long lddx, void* dx_op, int rows,
-                     hipStream_t s, int add_every = 0) {
+// `s16`: which of x (1), g (2), add (4) are 16-bit streams (the lean layout; dx is then null and dx_op the only output)
+static int ln_bwd_op(PrxVit* v, const void* g, long long ldg, const void* x, long long ldx, const float* gamma, const float* mean,
+                     const float* rstd, const void* add, long long ldadd, float* dx, long long lddx, void* dx_op, int rows,
+                     hipStream_t s, int add_every = 0, int s16 = 0) {
     return prx_layernorm_bwd(g, ldg, x, ldx, gamma, mean, rstd, add, ldadd, dx, lddx, v->f32 ? nullptr : (bf16_t*)dx_op, lddx, rows,
-                             v->width, s, v->h16, add_every);
+                             v->width, s, v->h16, add_every, s16);
 }
 
 int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
@@ -247,11 +261,13 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
     }
     hipLaunchKernelGGL(add_cls_pos_kernel, dim3(2048), dim3(256), 0, s, v->xpre, v->cls, v->pos, n, T, W);
     PRX_LAUNCH_CHECK();
-    float* x0 = v->layers > 0 ? v->L[0].x_in : v->x_final;
-    if ((r = prx_layernorm_fwd(v->xpre, W, v->lnpre_g, v->lnpre_b, nullptr, x0, v->mean_pre, v->rstd_pre, R, W, 1e-5f, s))) return r;
+    const int lean = v->lean;
+    void* x0 = v->layers > 0 ? v->L[0].x_in : v->x_final;
+    if ((r = prx_layernorm_fwd(v->xpre, W, v->lnpre_g, v->lnpre_b, lean ? (bf16_t*)x0 : nullptr, lean ? nullptr : (float*)x0, v->mean_pre,
+                               v->rstd_pre, R, W, 1e-5f, s, v->h16))) return r;
     for (int l = 0; l < v->layers; ++l) {
         VitLayer& y = v->L[l];
-        float* x_next = (l + 1 < v->layers) ? v->L[l + 1].x_in : v->x_final;
+        void* x_next = (l + 1 < v->layers) ? v->L[l + 1].x_in : v->x_final;
         if ((r = ln_op(v, y.x_in, W, y.ln1_g, y.ln1_b, v->h, y.mean1, y.rstd1, R, s))) return r;
         {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.Wqkv; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W;
             d.bias_n = y.bqkv; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
@@ -266,14 +282,18 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         const int rows = tail ? n : R;
         const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
         {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
-            d.bias_n = y.bo; d.resid = y.x_in; d.ldr = ldt; d.out_f32 = y.x_mid; d.ldc_f32 = ldt;
+            d.bias_n = y.bo; d.ldr = ldt;
+            if (lean) { d.resid16 = y.x_in; d.out_bf16 = y.x_mid; d.ldc_bf16 = ldt; }
+            else { d.resid = (const float*)y.x_in; d.out_f32 = (float*)y.x_mid; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
         if ((r = ln_op(v, y.x_mid, ldt, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, rows, s))) return r;
         {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = rows; d.N = 4 * W; d.K = W;
             d.bias_n = y.b1; d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
         {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
-            d.bias_n = y.b2; d.resid = y.x_mid; d.ldr = ldt; d.out_f32 = x_next; d.ldc_f32 = ldt;
+            d.bias_n = y.b2; d.ldr = ldt;
+            if (lean) { d.resid16 = y.x_mid; d.out_bf16 = x_next; d.ldc_bf16 = ldt; }
+            else { d.resid = (const float*)y.x_mid; d.out_f32 = (float*)x_next; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
     }
     // ln_post on the class token, projection, L2 normalisation (slip.py:66)
@@ -308,9 +328,13 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     // block on the class-token rows only; that block's kernels read those rows alone (the class-token tail) until its ln_1
     // backward, which takes the incoming gradient as zero on every other row (add_every = T) and writes all of them -- so the
     // streams need no clearing (two fills of 14.7 MB per iteration at the headline)
-    if (v->layers == 0) PRX_CHECK_HIP(hipMemsetAsync(v->dx, 0, sizeof(float) * (size_t)R * W, s));
+    const int lean = v->lean;
+    if (v->layers == 0) PRX_CHECK_HIP(hipMemsetAsync(lean ? v->dx_bf : (void*)v->dx, 0, (lean ? sizeof(bf16_t) : sizeof(float)) * (size_t)R * W, s));
+    // lean layout: dxs / dhs are the 16-bit gradient streams themselves (no fp32 copies exist)
+    const void* dxs = lean ? v->dx_bf : (const void*)v->dx;
+    const void* dhs = lean ? v->dh_bf : (const void*)v->dh;
     if ((r = ln_bwd_op(v, v->dhpost, W, v->x_final, (long long)T * W, v->lnpost_g, v->mean_post, v->rstd_post,
-                       nullptr, 0, v->dx, (long long)T * W, v->dx_bf, n, s))) return r;
+                       nullptr, 0, v->dx, (long long)T * W, v->dx_bf, n, s, 0, lean ? 1 : 0))) return r;
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
         // the class-token tail (see the forward): the gradient entering the last block is non-zero on the class-token rows only
@@ -322,9 +346,9 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
             d.act = PRX_ACT_MUL_DQUICKGELU; d.aux = y.t; d.ldaux = 4 * W; d.out_bf16 = v->dt; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
         {   GemmDesc d; d.A = v->dt; d.lda = 4 * W; d.B = y.W1T; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
-            d.out_f32 = v->dh; d.ldc_f32 = W;
+            if (lean) { d.out_bf16 = v->dh_bf; d.ldc_bf16 = W; } else { d.out_f32 = v->dh; d.ldc_f32 = W; }
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = ln_bwd_op(v, v->dh, W, y.x_mid, ldt, y.ln2_g, y.mean2, y.rstd2, v->dx, ldt, v->dx, ldt, v->dx_bf, rows, s))) return r;
+        if ((r = ln_bwd_op(v, dhs, W, y.x_mid, ldt, y.ln2_g, y.mean2, y.rstd2, dxs, ldt, v->dx, ldt, v->dx_bf, rows, s, 0, lean ? 7 : 0))) return r;
         // attention: x_mid = x_in + out_proj(mha(ln_1(x_in)))
         if (tail)       // d(attention output) is written on the class-token rows only: the other rows must read as zero
             PRX_CHECK_HIP(hipMemsetAsync(v->do_, 0, op_esz(v->f32) * (size_t)R * W, s));
@@ -335,12 +359,12 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         else if (T <= 64) { if ((r = prx_mha_bwd((const bf16_t*)y.qkv, (const bf16_t*)v->do_, (bf16_t*)v->dqkv, n, T, W, v->heads, s, v->h16))) return r; }
         else { if ((r = prx_mha_bwd_gen((const bf16_t*)y.qkv, (const bf16_t*)y.o_save, (const bf16_t*)v->do_, y.lse, (bf16_t*)v->dqkv, n, T, W, v->heads, s, v->h16))) return r; }
         {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * W; d.B = y.WqkvT; d.ldb = 3 * W; d.M = R; d.N = W; d.K = 3 * W;
-            d.out_f32 = v->dh; d.ldc_f32 = W;
+            if (lean) { d.out_bf16 = v->dh_bf; d.ldc_bf16 = W; } else { d.out_f32 = v->dh; d.ldc_f32 = W; }
             if ((r = vit_gemm(v, d, s))) return r; }
-        if ((r = ln_bwd_op(v, v->dh, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, v->dx, W, v->dx, W, v->dx_bf, R, s, tail ? T : 0))) return r;
+        if ((r = ln_bwd_op(v, dhs, W, y.x_in, W, y.ln1_g, y.mean1, y.rstd1, dxs, W, v->dx, W, v->dx_bf, R, s, tail ? T : 0, lean ? 7 : 0))) return r;
     }
     // ln_pre backward (in place on dx), then patch-embed dgrad
-    if ((r = ln_bwd_op(v, v->dx, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s))) return r;
+    if ((r = ln_bwd_op(v, dxs, W, v->xpre, W, v->lnpre_g, v->mean_pre, v->rstd_pre, nullptr, 0, v->dh, W, v->dh_bf, R, s, 0, lean ? 2 : 0))) return r;
     {   GemmDesc d; d.A = v->dh_bf; d.lda = W; d.B = v->WpT; d.ldb = W; d.M = R; d.N = KP; d.K = W;
         d.out_f32 = v->dA0; d.ldc_f32 = KP;
         if (v->h16) d.alpha_dev = v->gs + 1;      // ... and is unscaled (1/S) here, before the (rank-summed) renormalisation sums

@@ -16,6 +16,7 @@
 #include "vit.h"  // prx_pack_* helpers
 #include <vector>
 #include <memory>
+#include <stdlib.h>
 
 namespace {
 
@@ -65,15 +66,17 @@ struct GN { int C; float *g, *b; double *stats, *bstats; int id; };
 struct ResBlock {
     int Cin, Cout, rh, rw;   // feature-map height x width (pixray sizes need not be square)
     GN n1, n2; Conv3 c1, c2; Conv1 sc; bool has_sc;
-    float *x_in, *h1, *scbuf, *out;
-    void *x_in_bf, *out_bf;     // operand twins (only where a GEMM consumes the tensor); the fp32 tensor itself in the exact mode
+    void *x_in, *h1, *scbuf, *out;   // streams: fp32, or the 16-bit operand format in the lean layout (PrxVqgan::lean)
+    void *x_in_bf, *out_bf;     // operand twins (only where a GEMM consumes the tensor); the stream itself in the exact mode and in the lean layout
 };
 struct AttnBlock {
     int C, rh, rw;
     GN n; Conv1 qkv, proj;   // qkv = [3C, C] concatenated q|k|v
-    float* x_in; void *qkvb, *Pm, *PT; float* out; void* out_bf;
+    void* x_in; void *qkvb, *Pm, *PT; void* out; void* out_bf;
+    void* qkvT;      // [3C, P8]: q^T | k^T | v^T, ONE transpose of the block's [P, 3C] q|k|v tensor in the forward -- the products that
+                     // contract over the tokens (P v forward; dS k, dS^T q backward) need that operand token-contiguous
 };
-struct UpBlock { int C, rh, rw; Conv3 c; float *x_in, *out; void *x_in_bf, *out_bf; };
+struct UpBlock { int C, rh, rw; Conv3 c; void *x_in, *out; void *x_in_bf, *out_bf; };
 
 struct Stage { int kind; int idx; };  // 0 res, 1 attn, 2 up
 
@@ -81,6 +84,11 @@ struct PrxVqgan {
     int zc, D, NC, ch, out_ch, h0, w0, H, W, nstage;
     int prec;         // PRX_PREC_*
     int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    // The lean layout (half mode, PRX_LEAN): every feature map and every gradient map lives in IEEE half ONLY -- one tensor is
+    // the saved activation (GroupNorm backward reads it), the residual operand and the next convolution's A matrix -- instead of an
+    // fp32 stream plus a 16-bit twin (40 % of the iteration's HBM writes).  GroupNorm sums are still taken from the fp32
+    // accumulators in the producing epilogue.
+    int lean;
     float* gs;        // half mode: device {S, 1/S} = the power-of-two scale of the backward in flight (common.h) + 256 partials; else null
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
@@ -88,15 +96,16 @@ struct PrxVqgan {
     Conv1 pq; Conv3 conv_in, conv_out; GN norm_out;
     std::vector<ResBlock> res; std::vector<AttnBlock> attn; std::vector<UpBlock> ups; std::vector<Stage> stages;
     // activations
-    float *zq, *h_in, *y; int* idx; void *pqo_bf, *h_in_bf, *dpq_bf;
+    float *zq, *y, *dzq; void* h_in; int* idx; void *pqo_bf, *h_in_bf, *dpq_bf;
     float *pmin; int* pidx;
     void* a;               // GN(+swish) operand, max size
     void *tA, *tB, *tC, *tD, *dqkv, *dy8;    // attention temporaries [P*C max], dgrad head input
-    float *S, *g0, *g1, *g2; // score matrix; gradient ping-pong buffers (max P*C)
-    void *g0b, *g1b, *g2b;   // their operand twins (dgrad GEMM operands); aliases of g0..g2 in the exact mode
+    float* S;                // score matrix
+    void *g0, *g1, *g2;      // gradient ping-pong streams (max P*C): fp32, 16-bit in the lean layout
+    void *g0b, *g1b, *g2b;   // their operand twins (dgrad GEMM operands); aliases of g0..g2 in the exact mode and in the lean layout
     double* all_stats; int n_gn;   // [n_gn][64] forward stats followed by [n_gn][64] backward stats
     float* ws; size_t ws_bytes;
-    float* x_last;  // input of norm_out
+    void* x_last;   // input of norm_out (a stream)
 };
 
 namespace {
@@ -117,6 +126,14 @@ int dalloc_op(PrxVqgan* v, void** p, size_t count) {   // `count` operand elemen
     return 0;
 }
 #define VALLOC_OP(ptr, count) do { int _r = dalloc_op(v, &(ptr), (count)); if (_r) return _r; } while (0)
+int dalloc_stream(PrxVqgan* v, void** p, size_t count) {   // `count` stream elements: fp32, or 16-bit in the lean layout
+    void* q = nullptr;
+    PRX_CHECK_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * (v->lean ? sizeof(bf16_t) : sizeof(float))));
+    v->allocs.push_back(q);
+    *p = q;
+    return 0;
+}
+#define VALLOC_S(ptr, count) do { int _r = dalloc_stream(v, &(ptr), (count)); if (_r) return _r; } while (0)
 
 struct WCursor { const float* const* w; int n, pos; };
 #define NEXTW(cur, dst) do { PRX_REQUIRE((cur).pos < (cur).n, "vqgan_create: weight list too short"); (dst) = (cur).w[(cur).pos++]; } while (0)
@@ -166,9 +183,9 @@ int make_res(PrxVqgan* v, int Cin, int Cout, int rh, int rw, WCursor& cur, hipSt
     const size_t P = (size_t)rh * rw;
     if (rb.has_sc) {
         if ((r = make_conv1(v, rb.sc, Cin, Cout, cur, s))) return r;
-        VALLOC(rb.scbuf, P * Cout);
+        VALLOC_S(rb.scbuf, P * Cout);
     }
-    VALLOC(rb.h1, P * Cout); VALLOC(rb.out, P * Cout);
+    VALLOC_S(rb.h1, P * Cout); VALLOC_S(rb.out, P * Cout);
     v->stages.push_back({0, (int)v->res.size()});
     v->res.push_back(rb);
     return 0;
@@ -195,7 +212,9 @@ int make_attn(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
     if ((r = make_conv1(v, ab.proj, C, C, cur, s))) return r;
     const size_t P = (size_t)rh * rw;
     const size_t P8 = (size_t)pad8((int)P);
-    VALLOC_OP(ab.qkvb, P * 3 * C); VALLOC_OP(ab.Pm, P * P8); VALLOC_OP(ab.PT, P * P8); VALLOC(ab.out, P * C);
+    VALLOC_OP(ab.qkvb, P * 3 * C); VALLOC_OP(ab.Pm, P * P8); VALLOC_OP(ab.PT, P * P8); VALLOC_S(ab.out, P * C);
+    VALLOC_OP(ab.qkvT, (size_t)3 * C * P8);
+    PRX_CHECK_HIP(hipMemsetAsync(ab.qkvT, 0, (size_t)3 * C * P8 * op_esz(v->f32), s));
     PRX_CHECK_HIP(hipMemsetAsync(ab.Pm, 0, P * P8 * op_esz(v->f32), s));      // pad columns stay zero: the kernels never write them
     PRX_CHECK_HIP(hipMemsetAsync(ab.PT, 0, P * P8 * op_esz(v->f32), s));
     v->stages.push_back({1, (int)v->attn.size()});
@@ -207,7 +226,7 @@ int make_up(PrxVqgan* v, int C, int rh, int rw, WCursor& cur, hipStream_t s) {
     ub.C = C; ub.rh = rh; ub.rw = rw;
     int r;
     if ((r = make_conv3(v, ub.c, C, C, cur, s))) return r;
-    VALLOC(ub.out, (size_t)rh * rw * C);
+    VALLOC_S(ub.out, (size_t)rh * rw * C);
     v->stages.push_back({2, (int)v->ups.size()});
     v->ups.push_back(ub);
     return 0;
@@ -224,6 +243,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     std::unique_ptr<PrxVqgan> guard(v);
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
     v->gs = nullptr;
+    { const char* e = getenv("PRX_LEAN"); v->lean = (v->h16 && !(e && atoi(e) == 0)) ? 1 : 0; }
     v->n_gn = 0; v->zc = z_channels; v->D = embed_dim; v->NC = n_embed; v->ch = ch; v->out_ch = out_ch; v->h0 = h0; v->w0 = w0;
     WCursor cur{w, n_w, 0};
     int r;
@@ -266,16 +286,16 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     for (auto& ub : v->ups) maxPC = std::max(maxPC, (size_t)ub.rh * ub.rw * ub.C);
     for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)pad8(ab.rh * ab.rw) * (size_t)std::max(ab.C, pad8(ab.rh * ab.rw)));
     VALLOC(v->zq, P0 * embed_dim); VALLOC_OP(v->pqo_bf, P0 * z_channels); VALLOC_OP(v->dpq_bf, P0 * z_channels);
-    VALLOC(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
-    VALLOC(v->y, PH * 4); VALLOC(v->idx, P0);
+    VALLOC_S(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
+    VALLOC(v->y, PH * 4); VALLOC(v->idx, P0); VALLOC(v->dzq, P0 * embed_dim);
     const int ntiles = ceil_div(n_embed, 64);
     VALLOC(v->pmin, P0 * ntiles); VALLOC(v->pidx, P0 * ntiles);
     VALLOC_OP(v->a, maxPC);
     VALLOC_OP(v->tA, maxAttnPC); VALLOC_OP(v->tB, maxAttnPC); VALLOC_OP(v->tC, maxAttnPC); VALLOC_OP(v->tD, maxAttnPC);
     VALLOC_OP(v->dqkv, maxAttnPC * 3); VALLOC_OP(v->dy8, PH * 8);
     VALLOC(v->S, maxAttnPC);
-    VALLOC(v->g0, maxPC); VALLOC(v->g1, maxPC); VALLOC(v->g2, maxPC);
-    if (v->f32) { v->g0b = v->g0; v->g1b = v->g1; v->g2b = v->g2; }     // the fp32 gradient streams are the dgrad operands
+    VALLOC_S(v->g0, maxPC); VALLOC_S(v->g1, maxPC); VALLOC_S(v->g2, maxPC);
+    if (v->f32 || v->lean) { v->g0b = v->g0; v->g1b = v->g1; v->g2b = v->g2; }     // the gradient streams are the dgrad operands
     else { VALLOC_OP(v->g0b, maxPC); VALLOC_OP(v->g1b, maxPC); VALLOC_OP(v->g2b, maxPC); }
     // bf16 twins of stage outputs that feed a GEMM directly (1x1 shortcut or upsample conv of the next stage)
     v->h_in_bf = nullptr;
@@ -283,7 +303,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
         const Stage& st = v->stages[i];
         const bool need = (st.kind == 0 && v->res[st.idx].has_sc) || st.kind == 2;
         if (!need) continue;
-        void** slot; size_t cnt; float* self;
+        void** slot; size_t cnt; void* self;
         if (i == 0) { slot = &v->h_in_bf; cnt = P0 * (size_t)(ch * ch_mult[n_mult - 1]); self = v->h_in; }
         else {
             const Stage& pr = v->stages[i - 1];
@@ -291,7 +311,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
             else if (pr.kind == 1) { AttnBlock& b = v->attn[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; self = b.out; }
             else { UpBlock& b = v->ups[pr.idx]; slot = &b.out_bf; cnt = (size_t)b.rh * b.rw * b.C; self = b.out; }
         }
-        if (v->f32) *slot = self;          // exact mode: the fp32 stage output is the operand
+        if (v->f32 || v->lean) *slot = self;          // exact mode / lean layout: the stage output is the operand
         else VALLOC_OP(*slot, cnt);
     }
     {   // one contiguous stats slab: forward stats of every GroupNorm, then the backward stats
@@ -328,9 +348,10 @@ static int zero_if_padded(const PrxVqgan* v, void* buf, size_t rows, int P, hipS
 
 
 // PRX_VQ_TRACE=1 (debugging aid): L2 norm of every stage's output, forward and backward, on stderr
-static void vq_trace(const char* tag, int i, const float* p, size_t n, hipStream_t s) {
+static void vq_trace(const PrxVqgan* v, const char* tag, int i, const void* p_, size_t n, hipStream_t s) {
     static const bool on = getenv("PRX_VQ_TRACE") != nullptr;
-    if (!on || !p) return;
+    if (!on || !p_ || v->lean) return;             // (fp32 streams only: PRX_LEAN=0 for a trace)
+    const float* p = (const float*)p_;
     std::vector<float> h(n);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), p, n * sizeof(float), hipMemcpyDeviceToHost);
@@ -349,29 +370,44 @@ static int vg(PrxVqgan* v, GemmDesc& d, hipStream_t s) {
 }
 GemmCtx* prx_vqgan_gemm_ctx_impl(PrxVqgan* v) { return v ? &v->gctx : nullptr; }
 
-static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const float* resid,
-                     float* out, int ldc, hipStream_t s, void* out_bf = nullptr, const GN* stats_for = nullptr) {
+// A GEMM's stream output / residual / GroupNorm-input operands in the handle's layout: fp32 stream (+ optional 16-bit twin), or -- lean --
+// the one 16-bit tensor
+static void out_stream(const PrxVqgan* v, GemmDesc& d, void* stream, int ld, void* twin) {
+    if (v->lean) { d.out_bf16 = stream ? stream : twin; d.ldc_bf16 = ld; }
+    else { d.out_f32 = (float*)stream; d.ldc_f32 = ld; d.out_bf16 = twin; d.ldc_bf16 = ld; }
+}
+static void resid_stream(const PrxVqgan* v, GemmDesc& d, const void* r, int ld) {
+    if (!r) return;
+    d.ldr = ld;
+    if (v->lean) d.resid16 = r; else d.resid = (const float*)r;
+}
+// `f32_out`: `out` is an fp32 buffer in every layout (the image head's input), not a stream
+static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const void* resid,
+                     void* out, int ldc, hipStream_t s, void* out_bf = nullptr, const GN* stats_for = nullptr, bool f32_out = false) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
     d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = rh * rw; d.N = c.Cout; d.K = 9 * c.Cin;
-    d.H = rh; d.W = rw; d.Cin = c.Cin; d.up = up; d.bias_n = c.b; d.resid = resid; d.ldr = c.Cout;
-    d.out_f32 = out; d.ldc_f32 = ldc; d.out_bf16 = out_bf; d.ldc_bf16 = c.Cout;
+    d.H = rh; d.W = rw; d.Cin = c.Cin; d.up = up; d.bias_n = c.b;
+    resid_stream(v, d, resid, c.Cout);
+    if (f32_out) { d.out_f32 = (float*)out; d.ldc_f32 = ldc; }
+    else { out_stream(v, d, out, ldc, out_bf); if (!v->lean) d.ldc_bf16 = c.Cout; }
     if (stats_for && stats_for->C == c.Cout && fusable(v, c.Cout)) { d.gn_stats = stats_for->stats; d.gn_gs = c.Cout / 32; }
     return vg(v, d, s);
 }
 // dgrad of a 3x3 conv: dx[res*res, Cin] = convT(dy[res*res, CoP])
 // `gnb` (+ its forward input gnb_x): the GroupNorm whose output gradient this dgrad produces -- its backward sums are
 // accumulated in the GEMM epilogue (gemm.h gnb_*), so gn_bwd can skip its statistics pass
-static void set_gnb(const PrxVqgan* v, GemmDesc& d, const GN* gnb, const float* gnb_x, int swish) {
+static void set_gnb(const PrxVqgan* v, GemmDesc& d, const GN* gnb, const void* gnb_x, int swish) {
     if (!gnb || !fusable(v, gnb->C) || d.N != gnb->C) return;
     d.gn_stats = gnb->bstats; d.gn_gs = gnb->C / 32;
-    d.gnb_x = gnb_x; d.gnb_fstats = gnb->stats; d.gnb_gamma = gnb->g; d.gnb_beta = gnb->b; d.gnb_swish = swish; d.gnb_eps = 1e-6f;
+    if (v->lean) d.gnb_x16 = gnb_x; else d.gnb_x = (const float*)gnb_x;
+    d.gnb_fstats = gnb->stats; d.gnb_gamma = gnb->g; d.gnb_beta = gnb->b; d.gnb_swish = swish; d.gnb_eps = 1e-6f;
 }
-static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, float* dx, hipStream_t s,
-                     void* dx_bf = nullptr, const GN* gnb = nullptr, const float* gnb_x = nullptr, int gnb_swish = 1) {
+static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, void* dx, hipStream_t s,
+                     void* dx_bf = nullptr, const GN* gnb = nullptr, const void* gnb_x = nullptr, int gnb_swish = 1) {
     GemmDesc d; d.A = dy; d.a_is_f32 = dy_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.CoP;
     d.B = c.Wd; d.ldb = 9 * c.CoP; d.M = rh * rw; d.N = c.Cin; d.K = 9 * c.CoP;
-    d.H = rh; d.W = rw; d.Cin = c.CoP; d.up = 0; d.out_f32 = dx; d.ldc_f32 = c.Cin;
-    d.out_bf16 = dx_bf; d.ldc_bf16 = c.Cin;
+    d.H = rh; d.W = rw; d.Cin = c.CoP; d.up = 0;
+    out_stream(v, d, dx, c.Cin, dx_bf);
     set_gnb(v, d, gnb, gnb_x, gnb_swish);
     return vg(v, d, s);
 }
@@ -383,14 +419,15 @@ static const GN* first_norm(const PrxVqgan* v, int si) {
     if (st.kind == 1) return &v->attn[st.idx].n;
     return nullptr;
 }
-static int gn_fwd(PrxVqgan* v, const GN& g, const float* x, int P, int swish, hipStream_t s, bool stats_ready = false) {
+static int gn_fwd(PrxVqgan* v, const GN& g, const void* x, int P, int swish, hipStream_t s, bool stats_ready = false) {
     return prx_groupnorm_fwd(x, g.g, g.b, g.stats, v->f32 ? nullptr : (bf16_t*)v->a, v->f32 ? (float*)v->a : nullptr, 1, P, g.C, swish,
-                             1e-6f, s, /*zero_stats=*/0, stats_ready ? 1 : 0, v->h16);
+                             1e-6f, s, /*zero_stats=*/0, stats_ready ? 1 : 0, v->h16, v->lean);
 }
-static int gn_bwd(PrxVqgan* v, const GN& g, const float* grad, const float* x, const float* add, float* dx,
+// dx: the fp32 gradient stream (may be null: only the operand twin is wanted); lean layout: dx_bf IS the stream, no fp32 output
+static int gn_bwd(PrxVqgan* v, const GN& g, const void* grad, const void* x, const void* add, void* dx,
                   void* dx_bf, int P, int swish, hipStream_t s, bool stats_ready = false) {
-    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, dx, v->f32 ? nullptr : (bf16_t*)dx_bf, 1, P, g.C, swish, 1e-6f, s,
-                             /*zero_stats=*/0, stats_ready && fusable(v, g.C) ? 1 : 0, v->h16);
+    return prx_groupnorm_bwd(grad, x, g.g, g.b, g.stats, g.bstats, add, v->lean ? nullptr : (float*)dx, v->f32 ? nullptr : (bf16_t*)dx_bf, 1, P, g.C,
+                             swish, 1e-6f, s, /*zero_stats=*/0, stats_ready && fusable(v, g.C) ? 1 : 0, v->h16, v->lean);
 }
 
 int prx_vqgan_bounds_impl(PrxVqgan* v, float* zmin, float* zmax, hipStream_t s) {
@@ -417,7 +454,7 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     const GN* nx = first_norm(v, 0);
     if ((r = conv3_fwd(v, v->conv_in, v->pqo_bf, false, v->h0, v->w0, false, nullptr, v->h_in, v->conv_in.Cout, s, v->h_in_bf, nx))) return r;
     bool sr = nx && nx->C == v->conv_in.Cout && fusable(v, nx->C);
-    float* x = v->h_in;
+    void* x = v->h_in;
     void* x_bf = v->h_in_bf;     // operand twin of x (null when no GEMM reads x directly)
     for (int si = 0; si < (int)v->stages.size(); ++si) {
         const Stage& st = v->stages[si];
@@ -428,11 +465,11 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
             b.x_in = x; b.x_in_bf = x_bf;
             if ((r = gn_fwd(v, b.n1, x, P, 1, s, sr))) return r;
             if ((r = conv3_fwd(v, b.c1, v->a, false, b.rh, b.rw, false, nullptr, b.h1, b.Cout, s, nullptr, &b.n2))) return r;
-            const float* resid = x;
+            const void* resid = x;
             if (b.has_sc) {
                 PRX_REQUIRE(x_bf != nullptr, "vqgan: missing bf16 twin for the shortcut input");
                 GemmDesc d; d.A = x_bf; d.lda = b.Cin; d.B = b.sc.W; d.ldb = b.Cin; d.M = P; d.N = b.Cout; d.K = b.Cin;
-                d.bias_n = b.sc.b; d.out_f32 = b.scbuf; d.ldc_f32 = b.Cout;
+                d.bias_n = b.sc.b; out_stream(v, d, b.scbuf, b.Cout, nullptr);
                 if ((r = vg(v, d, s))) return r;
                 resid = b.scbuf;
             }
@@ -449,18 +486,16 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
                 d.bias_n = b.qkv.b; d.out_bf16 = b.qkvb; d.ldc_bf16 = 3 * C;
                 if ((r = vg(v, d, s))) return r; }
             const int P8 = pad8(P);
-            if ((r = zero_if_padded(v, v->tA, C, P, s))) return r;
-            if ((r = prx_transpose_op(op_off(b.qkvb, 2 * C, v->f32), 3 * C, v->tA, P8, P, C, v->f32, s))) return r;  // tA = v^T [C, P8]
+            if ((r = prx_transpose_op(b.qkvb, 3 * C, b.qkvT, P8, P, 3 * C, v->f32, s))) return r;  // q^T | k^T | v^T [3C, P8] (pad columns stay zero)
             {   GemmDesc d; d.A = b.qkvb; d.lda = 3 * C; d.B = op_off(b.qkvb, C, v->f32); d.ldb = 3 * C; d.M = P; d.N = P; d.K = C;
                 d.out_f32 = v->S; d.ldc_f32 = P;
                 if ((r = vg(v, d, s))) return r; }
             if ((r = prx_softmax_rows(v->S, P, 1.f / sqrtf((float)C), b.Pm, P8, b.PT, P8, P, P, v->prec, s))) return r;
-            {   GemmDesc d; d.A = b.Pm; d.lda = P8; d.B = v->tA; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
+            {   GemmDesc d; d.A = b.Pm; d.lda = P8; d.B = op_off(b.qkvT, (size_t)2 * C * P8, v->f32); d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = v->tB; d.ldc_bf16 = C;
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->tB; d.lda = C; d.B = b.proj.W; d.ldb = C; d.M = P; d.N = C; d.K = C;
-                d.bias_n = b.proj.b; d.resid = x; d.ldr = C; d.out_f32 = b.out; d.ldc_f32 = C;
-                d.out_bf16 = b.out_bf; d.ldc_bf16 = C;
+                d.bias_n = b.proj.b; resid_stream(v, d, x, C); out_stream(v, d, b.out, C, b.out_bf);
                 if (nx && nx->C == C && fusable(v, C)) { d.gn_stats = nx->stats; d.gn_gs = C / 32; }
                 if ((r = vg(v, d, s))) return r; }
             sr = nx && nx->C == C && fusable(v, C);
@@ -475,19 +510,20 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
         }
         {   const int Pq = st.kind == 0 ? v->res[st.idx].rh * v->res[st.idx].rw : st.kind == 1 ? v->attn[st.idx].rh * v->attn[st.idx].rw : v->ups[st.idx].rh * v->ups[st.idx].rw;
             const int Cq = st.kind == 0 ? v->res[st.idx].Cout : st.kind == 1 ? v->attn[st.idx].C : v->ups[st.idx].C;
-            vq_trace("fwd", si, x, (size_t)Pq * Cq, s); }
+            vq_trace(v, "fwd", si, x, (size_t)Pq * Cq, s); }
     }
     v->x_last = x;
     const int PH = v->H * v->W;
     if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s, sr))) return r;
-    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, v->W, false, nullptr, v->y, 4, s))) return r;
+    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, v->W, false, nullptr, v->y, 4, s, nullptr, nullptr, true))) return r;
     return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
 }
 
 // Diagnostic: copy one intermediate of the last forward (fp32) to dst.  stage -2: quantised latent, -1: conv_in output,
 // 0..n-1: output of decoder stage i, n: conv_out output [H*W,4], n+1: the forward GroupNorm sums (doubles, as floats).
 long long prx_vqgan_debug_stage_impl(PrxVqgan* v, int stage, float* dst, long long max_floats, hipStream_t s) {
-    const float* src = nullptr; long long n = 0;
+    const void* src = nullptr; long long n = 0;
+    PRX_REQUIRE(!v->lean || stage == -2 || stage >= (int)v->stages.size(), "vqgan debug_stage: the stage outputs are 16-bit in the lean layout (PRX_LEAN=0 for fp32 streams)");
     const int ns = (int)v->stages.size();
     if (stage == -2) { src = v->zq; n = (long long)v->h0 * v->w0 * v->D; }
     else if (stage == -1) { src = v->h_in; n = (long long)v->h0 * v->w0 * v->conv_in.Cout; }
@@ -514,7 +550,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     if (v->h16 && (r = prx_grad_scale(g_img, (size_t)v->out_ch * PH, v->gs + 2, 256, prx_grad_target_log2(), v->gs, s))) return r;
     if ((r = prx_image_head_bwd(v->y, 4, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
                                 v->out_ch, PH, s, v->h16, v->gs))) return r;
-    struct GB { float* f; void* b; };
+    struct GB { void* f; void* b; };      // a gradient stream and its operand twin (one tensor in the exact mode and in the lean layout)
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
     if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
     if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s, true))) return r;
@@ -528,10 +564,10 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             // fp32 buffer IS the operand)
             if ((r = gn_bwd(v, b.n2, t1.f, b.h1, nullptr, v->f32 ? t2.f : nullptr, t2.b, P, 1, s, true))) return r;
             if ((r = conv3_bwd(v, b.c1, t2.b, false, b.rh, b.rw, t1.f, s, nullptr, &b.n1, b.x_in, 1))) return r;   // d a1
-            const float* add = g.f;
+            const void* add = g.f;
             if (b.has_sc) {
                 GemmDesc d; d.A = g.b; d.lda = b.Cout; d.B = b.sc.WT; d.ldb = b.Cout; d.M = P; d.N = b.Cin; d.K = b.Cout;
-                d.out_f32 = t2.f; d.ldc_f32 = b.Cin;
+                out_stream(v, d, t2.f, b.Cin, nullptr);
                 if ((r = vg(v, d, s))) return r;
                 add = t2.f;
             }
@@ -552,21 +588,19 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
             if ((r = zero_if_padded(v, v->tB, P, P, s))) return r;
             if ((r = zero_if_padded(v, v->tC, P, P, s))) return r;
             if ((r = prx_softmax_rows_bwd(b.Pm, P8, v->S, P, 1.f / sqrtf((float)C), v->tB, P8, v->tC, P8, P, P, v->prec, s))) return r;  // tB = dS, tC = dS^T
+            {   GemmDesc d; d.A = v->tB; d.lda = P8; d.B = op_off(b.qkvT, (size_t)C * P8, v->f32); d.ldb = P8; d.M = P; d.N = C; d.K = P8;
+                d.out_bf16 = v->dqkv; d.ldc_bf16 = 3 * C;                               // dq = dS k   (k^T from the forward's transpose)
+                if ((r = vg(v, d, s))) return r; }
+            {   GemmDesc d; d.A = v->tC; d.lda = P8; d.B = b.qkvT; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
+                d.out_bf16 = op_off(v->dqkv, C, v->f32); d.ldc_bf16 = 3 * C;            // dk = dS^T q  (q^T likewise)
+                if ((r = vg(v, d, s))) return r; }
             if ((r = zero_if_padded(v, v->tD, C, P, s))) return r;
-            if ((r = prx_transpose_op(op_off(b.qkvb, C, v->f32), 3 * C, v->tD, P8, P, C, v->f32, s))) return r;       // tD = k^T [C, P8]
-            {   GemmDesc d; d.A = v->tB; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
-                d.out_bf16 = v->dqkv; d.ldc_bf16 = 3 * C;                               // dq = dS k
-                if ((r = vg(v, d, s))) return r; }
-            if ((r = prx_transpose_op(b.qkvb, 3 * C, v->tD, P8, P, C, v->f32, s))) return r;           // tD = q^T (pad columns still zero)
-            {   GemmDesc d; d.A = v->tC; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
-                d.out_bf16 = op_off(v->dqkv, C, v->f32); d.ldc_bf16 = 3 * C;            // dk = dS^T q
-                if ((r = vg(v, d, s))) return r; }
             if ((r = prx_transpose_op(v->tA, C, v->tD, P8, P, C, v->f32, s))) return r;                // tD = do^T
             {   GemmDesc d; d.A = b.PT; d.lda = P8; d.B = v->tD; d.ldb = P8; d.M = P; d.N = C; d.K = P8;
                 d.out_bf16 = op_off(v->dqkv, 2 * C, v->f32); d.ldc_bf16 = 3 * C;        // dv = P^T do
                 if ((r = vg(v, d, s))) return r; }
             {   GemmDesc d; d.A = v->dqkv; d.lda = 3 * C; d.B = b.qkv.WT; d.ldb = 3 * C; d.M = P; d.N = C; d.K = 3 * C;
-                d.out_f32 = t1.f; d.ldc_f32 = C;                                         // d GN(x)
+                out_stream(v, d, t1.f, C, nullptr);                                      // d GN(x)
                 set_gnb(v, d, &b.n, b.x_in, 0);
                 if ((r = vg(v, d, s))) return r; }
             if ((r = gn_bwd(v, b.n, t1.f, b.x_in, g.f, t2.f, t2.b, P, 0, s, true))) return r;
@@ -574,19 +608,20 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
         } else {
             UpBlock& b = v->ups[st.idx];
             if ((r = conv3_bwd(v, b.c, g.b, false, b.rh, b.rw, t1.f, s))) return r;       // d up(x) at high res
-            if ((r = prx_upsample2x_bwd(t1.f, t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s, v->h16))) return r;
+            if ((r = prx_upsample2x_bwd(t1.f, v->lean ? nullptr : (float*)t2.f, v->f32 ? nullptr : (bf16_t*)t2.b, 1, b.rh / 2, b.rw / 2, b.C, s, v->h16,
+                                        v->lean))) return r;
             std::swap(g, t2);
         }
         {   const int Pq = st.kind == 0 ? v->res[st.idx].rh * v->res[st.idx].rw : st.kind == 1 ? v->attn[st.idx].rh * v->attn[st.idx].rw : v->ups[st.idx].rh * v->ups[st.idx].rw / 4;
             const int Cq = st.kind == 0 ? v->res[st.idx].Cin : st.kind == 1 ? v->attn[st.idx].C : v->ups[st.idx].C;
-            vq_trace("bwd", si, g.f, (size_t)Pq * Cq, s); }
+            vq_trace(v, "bwd", si, g.f, (size_t)Pq * Cq, s); }
     }
     // conv_in, post_quant_conv, straight-through VQ (ReplaceGrad, vqgan.py:48-58)
-    if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, v->w0, t1.f, s, v->dpq_bf))) return r;
+    if ((r = conv3_bwd(v, v->conv_in, g.b, false, v->h0, v->w0, v->lean ? nullptr : t1.f, s, v->dpq_bf))) return r;
     const int P0 = v->h0 * v->w0;
     {   GemmDesc d; d.A = v->dpq_bf; d.lda = v->zc; d.B = v->pq.WT; d.ldb = v->zc; d.M = P0; d.N = v->D; d.K = v->zc;
-        d.out_f32 = t2.f; d.ldc_f32 = v->D;
+        d.out_f32 = v->dzq; d.ldc_f32 = v->D;
         if (v->h16) d.alpha_dev = v->gs + 1;         // unscale: 1/S (exact, a power of two)
         if ((r = vg(v, d, s))) return r; }
-    return prx_nhwc_to_nchw(t2.f, v->D, dz, 1, v->D, P0, s);
+    return prx_nhwc_to_nchw(v->dzq, v->D, dz, 1, v->D, P0, s);
 }

@@ -493,6 +493,19 @@ def vqgan_encode(img, handle: VqganEncHandle, return_pre: bool = False):
 
 
 # --------------------------------------------------------------------------------------- Prompt loss
+_TICKETS = {}
+
+
+def _ticket(device):
+    """the prompt kernel's "last workgroup adds up" counter: zero on entry, zero again on exit -- one resident word per
+    (device, stream)"""
+    key = (str(device), _stream())
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 class _PromptLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, embed, weight, stop, denom):
@@ -504,7 +517,7 @@ class _PromptLossFn(torch.autograd.Function):
         rowloss = torch.empty(n + 1, device=x.device)          # [n] row values, then the scalar |w| * sum / denom from the same launch
         grad = torch.empty_like(x)
         den = float(denom) if denom is not None else float(n * m)
-        call("prx_prompt_loss_fwd_bwd", x, e, n, m, D, float(weight), float(stop), den, rowloss, grad, rowloss[n:], _stream())
+        call("prx_prompt_loss_fwd_bwd", x, e, n, m, D, float(weight), float(stop), den, rowloss, grad, rowloss[n:], _ticket(x.device), _stream())
         ctx.save_for_backward(grad)
         return rowloss[n]
 

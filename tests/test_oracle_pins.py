@@ -469,3 +469,20 @@ def test_vgg_oracle_vs_the_reference_extractor_class_run_live():
             assert r.shape == o.shape, (space, i)
             # map 0 is the normalised input; the reference's in-place ReLUs overwrite the captured conv outputs, as here
             assert float((r - o).abs().max()) <= 1e-6 * max(1.0, float(r.abs().max())), (space, i)
+
+
+# ------------------------------------------------------------------------------------------------ what the teacher-forced image rests on
+def test_reference_image_gradient_is_discontinuous_at_clamp_ties():
+    """`oracle/step_ref.compare_k_steps` evaluates the oracle's cutouts -> CLIP -> loss gradient AT THE HIP PATH'S IMAGE because
+    the reference's dL/d(image) is not a continuous function of the image once pixels sit on the bounds of `clamp_with_grad`
+    (vqgan.py:66-79): `MakeCutouts` adds an adaptive MAX pool (pixray.py:443,463) whose gradient goes to the first maximum of a
+    window, and tied windows re-route gradient spikes.  The ORACLE ALONE shows it (tools/oracle_tie_sensitivity.py; the headline
+    run is committed under profiles/): at its own state after three Adam steps on a 256 x 256 canvas (two-pixel pooling windows,
+    as at the headline), 1e-6 of image noise moves dL/d(image) by tenths -- and by 1e-3 or less once the max pool is swapped for an
+    average pool."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import oracle_tie_sensitivity as ots
+    r = ots.measure(vqgan_model="tiny_f4", clip_model="tiny-B/32", size=(256, 256), cutn=8, steps=3)
+    assert r["pixels_on_a_clamp_bound"] > 0.01, r
+    assert r["rel_max"] >= 0.3, r
+    assert r["rel_avg"] <= 1e-3, r

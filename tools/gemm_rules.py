@@ -71,6 +71,9 @@ for key in order:
     cnt, us0, cfg0 = base[key]
     us0b = base2[key][1]
     kt = (K + 63) // 64
+    if cfg0[0] >= 1000:          # profile records code a fit tile (gemmfit.hip) as bm + 1000: the fit planner owns this shape -- nothing to sweep here
+        print(f"{M:6d} {N:5d} {K:5d} m{mode} x{cnt:4.1f}  fit tile {cfg0[0] - 1000}x{cfg0[1]}: {us0:6.1f} / {us0b:6.1f} us | planner-owned, not swept")
+        continue
     row = f"{M:6d} {N:5d} {K:5d} m{mode} x{cnt:4.1f}  heuristic {cfg0[0]}x{cfg0[1]} s{cfg0[2]}: {us0:6.1f} / {us0b:6.1f} us |"
     best = (min(us0, us0b), cfg0)
     for bm, bn in ((256, 256), (128, 128), (128, 64), (64, 64)):
