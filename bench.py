@@ -249,7 +249,7 @@ def main():
     graphed = False
     if args.graph is None:
         args.graph = args.config == "cfg3"
-    if args.graph and world == 1:        # N > 1 stays on eager launches (collectives inside a capture: not validated on a node)
+    if args.graph and (world == 1 or getattr(sess, "comm", None) is not None):   # N > 1: only on the capturable one-shot exchange (engine.enable_graph)
         graphed = sess.enable_graph(warmup=max(warmup - 1, 1))      # warm-up iterations run inside
         it = sess.cur_iteration
     for _ in range(0 if graphed else warmup):
@@ -309,8 +309,18 @@ def main():
         ev_over_ms = 0.5 * sorted(x.elapsed_time(y) for x, y in pairs)[len(pairs) // 2]
         if raw_ms > 0 and n > 0:
             ms = max(raw_ms - ev_over_ms * n, 0.5 * raw_ms)
-            achieved = flop / (ms * 1e-3) / 1e12
             gemm_gflop_step = flop / args.profile_steps / 1e9
+            # ALGORITHMIC work of the engine = what the reference's op list contracts.  The ViT runner's class-token tail does not
+            # launch 6 of the last block's 8 wide products on the n * (T - 1) rows nobody reads (csrc/vit.hip); they stay counted
+            tail_gflop = 0.0
+            for p_ in sess.perceptors.values():
+                c_ = getattr(p_, "cfg", None)
+                if c_ is not None and hasattr(c_, "patch_size") and getattr(c_, "layers", 0) > 0:
+                    n_loc = cutn // world
+                    T_ = (c_.input_resolution // c_.patch_size) ** 2 + 1
+                    tail_gflop += 2 * 2.0 * (n_loc * T_ - n_loc) * (c_.width ** 2 + 2 * 4 * c_.width ** 2) / 1e9
+            gemm_gflop_alg = gemm_gflop_step + tail_gflop
+            achieved = gemm_gflop_alg * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
             kern = (f"GEMM engine: gemmfit_kernel<WGM,WGN,FM,FN,KS,CONV> + gemm_glds_kernel / gemm8p_kernel ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
                     if args.precision != "f32"
                     else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
@@ -318,16 +328,22 @@ def main():
             # command, gfx950 FETCH correction applied): not measurable from inside this process, so `traffic` is null here
             # and the committed profile of the round is quoted next to it when there is one for this configuration
             pmc = None
-            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (4, 3, 2))
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (5, 4, 3, 2))
                              if os.path.exists(q)), "")
             if args.precision != "f32" and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 pmc["source"] = os.path.relpath(pmc_path, ROOT)
+            # `traffic`: HBM-side bytes per launch of this kernel family from the committed PMC passes of this command (FETCH_SIZE
+            # and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied: tools/profile_run.sh, tools/pmc_summary.py);
+            # the counters cannot be read from inside the process, so the number is the profile's, with its source beside it
+            traffic = round(float(pmc["bytes_per_launch"])) if pmc and pmc.get("bytes_per_launch") else None
             roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": None, "traffic_pmc_profile": pmc,
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_unit": "bytes per launch (HBM-side fetch + write)" if traffic else None, "traffic_pmc_profile": pmc,
                         "launches_per_step": n // args.profile_steps,
-                        "gemm_gflop_per_step": round(gemm_gflop_step, 1),
+                        "gemm_gflop_per_step": round(gemm_gflop_alg, 1),
+                        "gemm_gflop_launched_per_step": round(gemm_gflop_step, 1),
                         "gemm_ms_per_step": round(ms / args.profile_steps, 3),
                         "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                         "event_overhead_us_removed_per_launch": round(1e3 * ev_over_ms, 2),
@@ -371,8 +387,9 @@ def main():
             dt = time.perf_counter() - t1
             other_modes[prec] = {"value": round(n2 / dt, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt / n2, 3), "steps": n2,
                                  "warmup": w2,
-                                 # "ref" mixes two MFMA peaks (f32 decoder, fp16 tower): no single roofline fraction
-                                 "frac_of_mfma_peak": None if prec == "ref" else round((n2 / dt) * per_gpu_gflop * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4)}
+                                 # "ref" mixes two MFMA peaks: against the ceiling 1 / (decoder GFLOP / f32 peak + tower GFLOP / fp16 peak)
+                                 "frac_of_mfma_peak": round((n2 / dt) * ((GFLOP_DECODER_256 * 1e9) / (PEAK_TFLOPS["f32"] * 1e12) + (GFLOP_CLIP_B32_PER_CUT * cutn * 1e9) / (PEAK_TFLOPS["fp16"] * 1e12)), 4)
+                                 if prec == "ref" else round((n2 / dt) * per_gpu_gflop * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4)}
             del s2
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:

@@ -38,7 +38,10 @@ constexpr int COMM_THREADS = 256;
 struct CommWindowHdr {                   // lives at the start of every window
     unsigned long long flag[2][COMM_MAX_WORLD];     // [parity][writer rank] = sequence number of the data in that slot
     unsigned int arrive[2];                          // local block-arrival counters (only the owner touches them)
-    unsigned int pad[14];
+    unsigned int pad0[2];
+    unsigned long long seq;                          // sequence number of the owner's LAST call (only the owner touches it): it lives on the
+                                                     // device, not in a kernel argument, so that a call captured in a hipGraph advances on replay
+    unsigned int pad[10];
 };
 static_assert(sizeof(CommWindowHdr) % 16 == 0, "slots must stay 16-byte aligned");
 
@@ -67,7 +70,10 @@ __device__ __forceinline__ char* slot_of(char* win, int parity, int rank, int wo
 // resident ends in the bounded wait below, i.e. in a reported error, not in a hang.
 template <int OP>
 __global__ __launch_bounds__(COMM_THREADS) void oneshot_allreduce_kernel(CommPeers peers, float* __restrict__ data, size_t n, int rank, int world,
-                                                                        size_t max_bytes, unsigned long long seq, int* __restrict__ err) {
+                                                                        size_t max_bytes, int* __restrict__ err) {
+    // this call's sequence number: one more than the last call's, read by every block BEFORE it counts itself in below -- the
+    // counter is bumped by the last block to arrive, i.e. after all of them have read it
+    const unsigned long long seq = reinterpret_cast<const CommWindowHdr*>(peers.win[rank])->seq + 1;
     const int parity = (int)(seq & 1);
     const size_t n4 = n >> 2;                                  // 16-byte chunks
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(COMM_THREADS) void oneshot_allreduce_kernel(CommPee
         last = prev == gridDim.x - 1;
         if (last) {
             __hip_atomic_store(&mine->arrive[parity], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for call seq + 2
+            mine->seq = seq;
             __threadfence_system();
             for (int p = 0; p < world; ++p)
                 st_flag_sys(&reinterpret_cast<CommWindowHdr*>(peers.win[p])->flag[parity][rank], seq);
@@ -210,16 +217,15 @@ int prx_allreduce(prx_comm* c, void* data, size_t n_words, int op, prx_stream_t 
     if (c->world == 1) return 0;
     CommPeers peers;
     for (int i = 0; i < COMM_MAX_WORLD; ++i) peers.win[i] = c->peer[i];
-    ++c->seq;
     const int blocks = (int)std::min<size_t>(COMM_BLOCKS, std::max<size_t>(1, (n_words / 4 + COMM_THREADS - 1) / COMM_THREADS));
     hipStream_t st = (hipStream_t)stream;
     float* f = (float*)data;
     if (op == PRX_COMM_SUM_F32)
-        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->err);
     else if (op == PRX_COMM_MAX_F32)
-        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_MAX_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_MAX_F32>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->err);
     else
-        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F64>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->seq, c->err);
+        hipLaunchKernelGGL(oneshot_allreduce_kernel<PRX_COMM_SUM_F64>, dim3(blocks), dim3(COMM_THREADS), 0, st, peers, f, n_words, c->rank, c->world, c->max_bytes, c->err);
     PRX_LAUNCH_CHECK();
     return 0;
 }

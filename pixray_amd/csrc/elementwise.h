@@ -31,4 +31,5 @@ int prx_grad_scale_multi(const float* const* gs, const size_t* ns, int count, fl
 int prx_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 // x[i] *= *scale with a DEVICE scalar: applies the half mode's power-of-two gradient scale to an fp32 gradient BEFORE it is
 // rounded to half (scaling in a GEMM epilogue would come after the operand conversion and lose the small entries to subnormals)
-int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s);
+// out16 (optional): the scaled values also as a 16-bit operand (format h16)
+int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s, bf16_t* out16 = nullptr, int h16 = 0);

@@ -238,9 +238,15 @@ __global__ __launch_bounds__(256) void grad_scale_final_kernel(const float* __re
 }
 
 // x *= *scale (a device scalar; the half mode's power-of-two gradient scale, so the product is exact)
-__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, size_t n, const float* __restrict__ scale) {
+// out16 (optional): the scaled values in the 16-bit operand format as well -- the next GEMM's A operand (a 16-bit A is what the
+// fit tiles take; an fp32 A goes to the register-staged kernels)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, size_t n, const float* __restrict__ scale, bf16_t* __restrict__ out16, int h16) {
     const float sc = *scale;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i] * sc;
+        x[i] = v;
+        if (out16) out16[i] = to_op16(v, h16);
+    }
 }
 
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -327,8 +333,8 @@ int prx_grad_scale_multi(const float* const* gs, const size_t* ns, int count, fl
     PRX_LAUNCH_CHECK();
     return 0;
 }
-int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s) {
-    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, n, scale);
+int prx_scale_dev(float* x, size_t n, const float* scale, hipStream_t s, bf16_t* out16, int h16) {
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, n, scale, out16, h16);
     PRX_LAUNCH_CHECK();
     return 0;
 }

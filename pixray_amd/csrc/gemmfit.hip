@@ -494,6 +494,7 @@ struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff
 const FitTile kFitTiles[] = {
     {160, 256, 1, 64, 1.00}, {160, 192, 1, 48, 0.97}, {256, 128, 1, 64, 0.95}, {160, 128, 1, 32, 0.90}, {128, 128, 1, 32, 0.85},
     {80, 128, 2, 32, 0.85}, {128, 64, 2, 32, 0.75}, {64, 64, 2, 32, 0.60}, {32, 64, 4, 32, 0.45}, {16, 64, 4, 32, 0.35}, {16, 32, 8, 32, 0.25},
+    {256, 16, 1, 16, 0.20},      // few output channels over many pixels (the decoder's conv_out: 128 -> 3, padded to 8): never the planner's general choice
 };
 const FitTile* fit_tile(int bm, int bn) {
     for (const FitTile& t : kFitTiles)
@@ -551,12 +552,21 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
         const double score = fill * eff / waste;
         if (score > best && fill / waste >= 0.8) { best = score; *bm = tbm; *bn = tbn; }
     };
+    // a convolution to a handful of channels over a large map (the decoder's conv_out, 128 -> 3 channels padded to 8, 65 536
+    // pixels): the general tiles would run 128-wide MFMA columns for 3 outputs (38 us on the 64 x 64 kernel); 256 pixels x 16 columns
+    if (d.a_mode == PRX_A_CONV3X3 && d.N <= 16 && d.M >= 4096 && prx_gemmfit_eligible(d, 256, 16)) { *bm = 256; *bn = 16; return; }
     // weight-heavy products with FEW output rows (a 16^2 / 8^2 / 4^2 map of the StyleLoss extractor, M = 16 ... 256 by 512 channels
     // over K = 4608): no tile grid fills the chip, but the smallest tile with 8 K groups per workgroup still streams the weight
     // matrix through 16 ... 256 workgroups in ~9 us where a 128 x 64 tile with split-K + reduce takes 22 - 47 (measured:
     // profiles/r04_small_m_streaming_vs_ring.txt) -- the fill rule below does not apply to them
-    if ((long long)d.M * d.N <= 256ll * 512 && d.K >= 2048 && d.N >= 32 && prx_gemmfit_eligible(d, 16, 32)) { *bm = 16; *bn = 32; return; }
-    for (const FitTile& t : kFitTiles) consider(t.bm, t.bn, t.eff);
+    if ((long long)d.M * d.N <= 256ll * 512 && d.K >= 512 && d.N >= 32) {
+        if (prx_gemmfit_eligible(d, 16, 32)) { *bm = 16; *bn = 32; return; }
+        // K not a multiple of 512 (8 K groups of 64): 4 K groups on the 16 x 64 tile (the decoder's conv_in, 256 -> 512 channels over
+        // K = 2304 at 16^2: 128 workgroups instead of a 64 x 64 split-K launch + reduce, 20 + 8 us)
+        if (d.N >= 64 && prx_gemmfit_eligible(d, 16, 64)) { *bm = 16; *bn = 64; return; }
+    }
+    for (const FitTile& t : kFitTiles)
+        if (t.bn >= 32) consider(t.bm, t.bn, t.eff);
 }
 int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
@@ -572,6 +582,7 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 gri
     else if (bm == 32 && bn == 64) launch_fit<1, 2, 2, 2, 4>(a, grid, s, zp);
     else if (bm == 16 && bn == 64) launch_fit<1, 2, 1, 2, 4>(a, grid, s, zp);
     else if (bm == 16 && bn == 32) launch_fit<1, 1, 1, 2, 8>(a, grid, s, zp);
+    else if (bm == 256 && bn == 16) launch_fit<8, 1, 2, 1, 1>(a, grid, s, zp);
     else PRX_REQUIRE(false, "gemmfit: no kernel for a %d x %d tile", bm, bn);
     return 0;
 }

@@ -88,7 +88,7 @@ struct PrxVit {
     float *cls, *pos, *lnpre_g, *lnpre_b, *lnpost_g, *lnpost_b;
     std::vector<VitLayer> L;
     // workspace
-    void *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf;   // operand precision
+    void *A0, *h, *att_o, *u, *hpost, *dt, *do_, *dqkv, *dx_bf, *dh_bf, *de16;   // operand precision
     float *xpre, *mean_pre, *rstd_pre, *mean_post, *rstd_post, *e, *dx, *dh, *dA0, *de, *dhpost, *mm_part;
     void* x_final;
     // The lean layout (half mode, PRX_LEAN): the residual stream and its gradient live in IEEE half only -- the reference's own
@@ -195,7 +195,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     // proj is [width, out]: forward Bt = proj^T [out, width]; dgrad Bt = proj [width, out]
     if ((r = pack_both(v, &v->proj, &v->projT, q[2], W, out_dim, s))) return r;
     ALLOC_OP(v->A0, R * KP); ALLOC_OP(v->h, R * W); ALLOC_OP(v->att_o, R * W); ALLOC_OP(v->u, R * 4 * W);
-    ALLOC_OP(v->hpost, (size_t)max_n * W); ALLOC_OP(v->dt, R * 4 * W); ALLOC_OP(v->do_, R * W); ALLOC_OP(v->dqkv, R * 3 * W);
+    ALLOC_OP(v->hpost, (size_t)max_n * W); ALLOC_OP(v->de16, (size_t)max_n * out_dim); ALLOC_OP(v->dt, R * 4 * W); ALLOC_OP(v->do_, R * W); ALLOC_OP(v->dqkv, R * 3 * W);
     ALLOC(v->xpre, R * W); ALLOC(v->mean_pre, R); ALLOC(v->rstd_pre, R);
     if (v->lean) ALLOC_OP(v->x_final, R * W);
     else { float* a_; ALLOC(a_, R * W); v->x_final = a_; }
@@ -321,7 +321,10 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
         // shrink with the prompt weight and the world size -- unscaled they would land in half's subnormals or flush to zero
         if (v->h16) {
             if ((r = prx_grad_scale(v->de, (size_t)n * v->out_dim, v->gs + 2, 64, prx_grad_target_log2(), v->gs, s))) return r;
-            if ((r = prx_scale_dev(v->de, (size_t)n * v->out_dim, v->gs, s))) return r;
+            // ... and leaves as the half operand of this product too (hpost is free by now): a 16-bit A puts the M = n product on a
+            // fit tile with K groups (6 us) instead of the register-staged 128 x 64 kernel on 12 workgroups (26 us)
+            if ((r = prx_scale_dev(v->de, (size_t)n * v->out_dim, v->gs, s, (bf16_t*)v->de16, v->h16))) return r;
+            d.A = v->de16; d.a_is_f32 = 0;
         }
         if ((r = vit_gemm(v, d, s))) return r; }
     // the residual-stream gradient is kept in fp32 (dx) with a bf16 twin (dx_bf) that feeds the dgrad GEMMs.  It enters the last

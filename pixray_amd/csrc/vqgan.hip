@@ -156,12 +156,18 @@ int make_gn(PrxVqgan* v, GN& g, int C, WCursor& cur, hipStream_t s) {
 int make_conv3(PrxVqgan* v, Conv3& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
     const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
     c.Cin = Cin; c.Cout = Cout; c.CoP = (Cout + 7) / 8 * 8;
-    VALLOC_OP(c.Wf, (size_t)Cout * 9 * Cin);
+    // the forward pack has CoP rows too (zero rows beyond Cout, zero bias): N % 8 == 0 puts conv_out (3 channels) on the MFMA tiles
+    // with vector epilogues like every other convolution; its fp32 output is [pixels][CoP]
+    VALLOC_OP(c.Wf, (size_t)c.CoP * 9 * Cin);
+    if (c.CoP != Cout) PRX_CHECK_HIP(hipMemsetAsync(c.Wf, 0, (size_t)c.CoP * 9 * Cin * op_esz(v->f32), s));
     VALLOC_OP(c.Wd, (size_t)Cin * 9 * c.CoP);
     PRX_OP_DISPATCH(v->f32, v->h16, TO,
                     hipLaunchKernelGGL(pack_conv3x3_kernel<TO>, dim3(1024), dim3(256), 0, s, w, (TO*)c.Wf, (TO*)c.Wd, Cout, Cin, c.CoP));
     PRX_LAUNCH_CHECK();
-    return copyf(v, &c.b, b, Cout, s);
+    VALLOC(c.b, c.CoP);
+    if (c.CoP != Cout) PRX_CHECK_HIP(hipMemsetAsync(c.b, 0, sizeof(float) * c.CoP, s));
+    PRX_CHECK_HIP(hipMemcpyAsync(c.b, b, sizeof(float) * Cout, hipMemcpyDeviceToDevice, s));
+    return 0;
 }
 int make_conv1(PrxVqgan* v, Conv1& c, int Cin, int Cout, WCursor& cur, hipStream_t s) {
     const float *w, *b; NEXTW(cur, w); NEXTW(cur, b);
@@ -287,7 +293,7 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     for (auto& ab : v->attn) maxAttnPC = std::max(maxAttnPC, (size_t)pad8(ab.rh * ab.rw) * (size_t)std::max(ab.C, pad8(ab.rh * ab.rw)));
     VALLOC(v->zq, P0 * embed_dim); VALLOC_OP(v->pqo_bf, P0 * z_channels); VALLOC_OP(v->dpq_bf, P0 * z_channels);
     VALLOC_S(v->h_in, P0 * (size_t)(ch * ch_mult[n_mult - 1]));
-    VALLOC(v->y, PH * 4); VALLOC(v->idx, P0); VALLOC(v->dzq, P0 * embed_dim);
+    VALLOC(v->y, PH * (size_t)v->conv_out.CoP); VALLOC(v->idx, P0); VALLOC(v->dzq, P0 * embed_dim);
     const int ntiles = ceil_div(n_embed, 64);
     VALLOC(v->pmin, P0 * ntiles); VALLOC(v->pidx, P0 * ntiles);
     VALLOC_OP(v->a, maxPC);
@@ -385,7 +391,7 @@ static void resid_stream(const PrxVqgan* v, GemmDesc& d, const void* r, int ld) 
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const void* resid,
                      void* out, int ldc, hipStream_t s, void* out_bf = nullptr, const GN* stats_for = nullptr, bool f32_out = false) {
     GemmDesc d; d.A = x; d.a_is_f32 = x_f32; d.a_mode = PRX_A_CONV3X3; d.lda = c.Cin;
-    d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = rh * rw; d.N = c.Cout; d.K = 9 * c.Cin;
+    d.B = c.Wf; d.ldb = 9 * c.Cin; d.M = rh * rw; d.N = c.CoP; d.K = 9 * c.Cin;       // CoP == Cout except for conv_out
     d.H = rh; d.W = rw; d.Cin = c.Cin; d.up = up; d.bias_n = c.b;
     resid_stream(v, d, resid, c.Cout);
     if (f32_out) { d.out_f32 = (float*)out; d.ldc_f32 = ldc; }
@@ -515,8 +521,8 @@ int prx_vqgan_synth_impl(PrxVqgan* v, const float* z, float* img, int* indices, 
     v->x_last = x;
     const int PH = v->H * v->W;
     if ((r = gn_fwd(v, v->norm_out, x, PH, 1, s, sr))) return r;
-    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, v->W, false, nullptr, v->y, 4, s, nullptr, nullptr, true))) return r;
-    return prx_image_head_fwd(v->y, 4, img, 1, v->out_ch, PH, s);
+    if ((r = conv3_fwd(v, v->conv_out, v->a, false, v->H, v->W, false, nullptr, v->y, v->conv_out.CoP, s, nullptr, nullptr, true))) return r;
+    return prx_image_head_fwd(v->y, v->conv_out.CoP, img, 1, v->out_ch, PH, s);
 }
 
 // Diagnostic: copy one intermediate of the last forward (fp32) to dst.  stage -2: quantised latent, -1: conv_in output,
@@ -532,7 +538,7 @@ long long prx_vqgan_debug_stage_impl(PrxVqgan* v, int stage, float* dst, long lo
         if (st.kind == 0) { const ResBlock& b = v->res[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.Cout; }
         else if (st.kind == 1) { const AttnBlock& b = v->attn[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.C; }
         else { const UpBlock& b = v->ups[st.idx]; src = b.out; n = (long long)b.rh * b.rw * b.C; }
-    } else if (stage == ns) { src = v->y; n = (long long)v->H * v->W * 4; }
+    } else if (stage == ns) { src = v->y; n = (long long)v->H * v->W * v->conv_out.CoP; }
     else if (stage == ns + 1) { src = reinterpret_cast<const float*>(v->all_stats); n = (long long)v->n_gn * 64 * 2; }
     else return -1;
     if (n > max_floats) n = max_floats;
@@ -548,7 +554,7 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
     // half mode: the whole backward runs under a power-of-two scale S chosen from max|dL/d(image)|; ClampWithGrad only reads signs
     if (v->h16 && (r = prx_grad_scale(g_img, (size_t)v->out_ch * PH, v->gs + 2, 256, prx_grad_target_log2(), v->gs, s))) return r;
-    if ((r = prx_image_head_bwd(v->y, 4, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
+    if ((r = prx_image_head_bwd(v->y, v->conv_out.CoP, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
                                 v->out_ch, PH, s, v->h16, v->gs))) return r;
     struct GB { void* f; void* b; };      // a gradient stream and its operand twin (one tensor in the exact mode and in the lean layout)
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};

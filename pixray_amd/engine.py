@@ -525,9 +525,13 @@ class Session:
             return self._no_graph("warmup >= 1 is required: plugins size their staging buffers during one eager iteration")
         if self.batches != 1 or self.auto_stop or not self.opts:
             return self._no_graph("batches > 1, auto_stop, or no optimiser")
-        if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and os.environ.get("PRX_GRAPH_WITH_COLLECTIVES") != "1":
-            # the all-reduce of dL/d(image) would be captured with the iteration; RCCL inside a capture has not been run on a node
-            return self._no_graph("world_size > 1: collectives inside a capture are not validated (PRX_GRAPH_WITH_COLLECTIVES=1 to try)")
+        if (self.world_size > 1 or getattr(self, "_force_hook_group", None) is not None) and self.comm is None and \
+                os.environ.get("PRX_GRAPH_WITH_COLLECTIVES") != "1":
+            # the three collectives of the iteration would be captured with it.  On the C-ABI one-shot exchange (self.comm) each is
+            # a plain kernel whose sequence number lives on the device (csrc/comm.hip): captured and replayed like any other
+            # launch.  RCCL inside a capture has not been run on a node: eager there.
+            return self._no_graph("world_size > 1 on torch.distributed collectives: not validated inside a capture "
+                                  "(PRX_ONESHOT_ALLREDUCE=1 puts them on the capturable C-ABI exchange; PRX_GRAPH_WITH_COLLECTIVES=1 to try RCCL)")
         params = [p for o in self.opts for g in o.param_groups for p in g["params"]]
         if not params or not all(p.is_cuda for p in params):
             return self._no_graph("optimised tensors are not on a GPU")

@@ -290,6 +290,7 @@ CLIP_TEXT_CONFIGS = {
     "tiny-B/32": ClipTextConfig("tiny-B/32", vocab_size=1000, context_length=77, width=256, layers=2, heads=4, output_dim=128),
     "RN50x4": ClipTextConfig("RN50x4", width=640, heads=10, output_dim=640),
     "RN50": ClipTextConfig("RN50", width=512, heads=8, output_dim=1024),
+    "RN101": ClipTextConfig("RN101", width=512, heads=8, output_dim=512),
 }
 
 
@@ -363,6 +364,7 @@ class ClipResNetConfig:
 CLIP_RESNET_CONFIGS = {
     "RN50x4": ClipResNetConfig(),
     "RN50": ClipResNetConfig("RN50", 224, 64, (3, 4, 6, 3), 32, 1024),
+    "RN101": ClipResNetConfig("RN101", 224, 64, (3, 4, 23, 3), 32, 512),      # quality `supreme` names it (pixray.py:1830)
     # reduced tower with the same operator mix (stem, stride-1 and stride-2 bottlenecks, attention pool)
     "tiny-RN": ClipResNetConfig("tiny-RN", 96, 16, (1, 2, 1, 1), 8, 64),
 }

@@ -11,7 +11,7 @@ import random
 import torch
 import torch.nn.functional as F
 
-FIT = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+FIT = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32), (256, 16)]
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}
 PREC = {"bf16": 0, "f32": 1, "fp16": 2}
 

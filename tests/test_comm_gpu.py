@@ -121,6 +121,14 @@ def test_bench_gpus_2_bare_launch_two_ranks_on_one_device():
     assert r2["n_gpus"] == 2 and r2["config"]["cutouts_per_gpu"] == 32 and "one-shot" in r2["config"]["exchange"]
     assert r2["value"] > 0 and np.isfinite(r2["final_loss"])
     assert abs(r2["final_loss"] - r1["final_loss"]) < 5e-2 * abs(r1["final_loss"]), (r2["final_loss"], r1["final_loss"])
+    # the same two ranks with the iteration captured in a hipGraph: the exchange's sequence numbers live on the device (csrc/comm.hip),
+    # so the three collectives replay like any other launch -- same losses as the eager sharded run
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--graph"] + common, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rg = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rg["config"]["launch"] == "hipGraph replay", rg["config"]["launch"]
+    assert abs(rg["final_loss"] - r2["final_loss"]) < 2e-2 * abs(r2["final_loss"]), (rg["final_loss"], r2["final_loss"])
 
 
 def test_oneshot_allreduce_world_one_is_the_identity():

@@ -118,6 +118,14 @@ def test_quality_size_and_unit_resolution(tmp_path):
         _settings(tmp_path, quality="ultra")
     with pytest.raises(SystemExit):
         _settings(tmp_path, size=None, aspect="cinema")
+    # every tower a quality preset names has a configuration (vision + text) and a row in the default vector table (pixray.py:1824-1831)
+    from pixray_amd import api, weights
+    _, s2 = _settings(tmp_path, quality="supreme", clip_models=None, size=None, num_cuts=None, iterations=None)
+    assert s2.clip_models == ["RN50x4", "RN101", "ViT-B/32", "ViT-B/16"] and s2.iterations == 400 and s2.batches == 4
+    table = api.load_vector_table("textoff")
+    for name in s2.clip_models:
+        cfg = weights.CLIP_CONFIGS.get(name) or weights.CLIP_RESNET_CONFIGS[name]
+        assert weights.CLIP_TEXT_CONFIGS[name].output_dim == cfg.output_dim == len(table[name][0]), name
 
 
 def test_outdir_template_and_yaml_config_file(tmp_path):

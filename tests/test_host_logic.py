@@ -756,7 +756,7 @@ def test_default_vector_prompt_table_is_the_references():
     import json
     from pixray_amd import api
     t = api.load_vector_table("textoff")
-    assert set(t) == {"RN50", "RN50x4", "ViT-B/32", "ViT-B/16"}
+    assert set(t) == {"RN50", "RN101", "RN50x4", "ViT-B/32", "ViT-B/16"}
     assert len(t["ViT-B/32"]) == 1 and len(t["ViT-B/32"][0]) == 512 and len(t["RN50x4"][0]) == 640
     src = "/root/reference/vectors/textoff.json"
     if os.path.exists(src):

@@ -197,7 +197,7 @@ def test_gemm_forced_tiles_stages_splitk(tile, stages, splits):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -2, 0, 0)
 
 
-@pytest.mark.parametrize("tile", [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
+@pytest.mark.parametrize("tile", [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32), (256, 16)])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("stagger", [1, 0])
 def test_gemm_fit_tiles(tile, prec, stagger):
@@ -283,8 +283,8 @@ def test_gemm_engine_random_shapes_on_the_device(kind):
     assert bad == [], "\n".join(bad[:20])
 
 
-FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
-FIT_KS = {(160, 256): 1, (160, 128): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8}
+FIT_TILES = [(160, 256), (160, 128), (160, 192), (256, 128), (128, 128), (80, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32), (256, 16)]
+FIT_KS = {(160, 256): 1, (160, 128): 1, (160, 192): 1, (256, 128): 1, (128, 128): 1, (80, 128): 2, (128, 64): 2, (64, 64): 2, (32, 64): 4, (16, 64): 4, (16, 32): 8, (256, 16): 1}
 
 
 @pytest.mark.parametrize("tile", FIT_TILES)
@@ -370,7 +370,9 @@ def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
     80 x 128, and the result is the 4-wave kernels' to fp32 round-off (another K summation order on the two-K-group tile)"""
     lib = _lib.load()
     torch.manual_seed(3)
-    for (M, N, K) in [(3200, 3072, 768), (3200, 2304, 768), (3200, 768, 3072)]:
+    # ... and the sharded batches of 2 / 4 / 8 GPUs (32 / 16 / 8 cutouts per rank: M = 1600 / 800 / 400 token rows, multiples of 80)
+    for (M, N, K) in [(3200, 3072, 768), (3200, 2304, 768), (3200, 768, 3072), (1600, 3072, 768), (1600, 768, 3072), (800, 2304, 768),
+                      (800, 768, 3072), (400, 3072, 768), (400, 768, 768), (400, 768, 3072)]:
         A = torch.randn(M, K, device=DEV).to(torch.float16)
         Bt = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.float16)
         outs = []

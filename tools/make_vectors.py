@@ -12,7 +12,7 @@ import os
 
 SRC = "/root/reference/vectors/textoff.json"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ["RN50", "RN50x4", "ViT-B/32", "ViT-B/16"]        # weights.CLIP_CONFIGS / CLIP_RESNET_CONFIGS names present in the table
+KEEP = ["RN50", "RN101", "RN50x4", "ViT-B/32", "ViT-B/16"]        # weights.CLIP_CONFIGS / CLIP_RESNET_CONFIGS names present in the table
 
 with open(SRC) as f:
     table = json.load(f)
