@@ -16,6 +16,9 @@ int prx_image_head_fwd(const float* x, int ldc, float* img, int NB, int C, int H
 // mode; the ClampWithGrad sign test is unaffected
 int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf16_t* dx_bf16, int ldo, int NB, int C,
                        int HW, hipStream_t s, int h16 = 0, const float* gscale = nullptr);
+// ... as the im2col matrix [H*W][ldk] of the 3x3 convolution that follows (tap-major, 8 channels per tap, zero padded to ldk): batch 1
+int prx_image_head_bwd_im2col(const float* x, int ldc, const float* gimg, bf16_t* col, int ldk, int C, int H, int W, hipStream_t s, int h16 = 0,
+                              const float* gscale = nullptr);
 // Power-of-two gradient scale of the half (PRX_PREC_F16) mode, chosen on the device from the gradient that enters a runner's
 // backward: scale2 = {S, 1/S} with S * max|g| in [2^(T-1), 2^T), T = target_log2 (S = 1 for all-zero / non-finite g).
 // part: nparts floats of scratch.  Two tiny launches, no host synchronisation.

@@ -173,6 +173,42 @@ __global__ __launch_bounds__(256) void image_head_bwd_kernel(const float* __rest
     }
 }
 
+// The same, written as the im2col matrix of the 3x3 convolution that follows (the dgrad of conv_out: 8 gradient channels in, K = 72):
+// col[p][tap * 8 + c] = dy[(y + ky - 1, x + kx - 1)][c] (zero outside the image), columns 72 .. ldk - 1 zero.  With K = 72 the
+// implicit-convolution kernels run their generic per-element gather (54 us for 1.2 GFLOP at 256^2); as a row-major product over
+// this matrix it is a two-stage fit-tile launch.  One thread per (pixel, tap): 8 halves = one 16-byte store.  Batch 1.
+__global__ __launch_bounds__(256) void image_head_bwd_im2col_kernel(const float* __restrict__ x, int ldc, const float* __restrict__ gimg,
+                                                                    bf16_t* __restrict__ col, int ldk, int C, int H, int W, int h16,
+                                                                    const float* __restrict__ gscale_dev) {
+    const float gscale = gscale_dev ? *gscale_dev : 1.f;
+    const int slots = ldk / 8;                      // 16-byte slots per row: 9 taps, then zero padding
+    const size_t HW = (size_t)H * W, total = HW * slots;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(idx % slots);
+        const size_t p = idx / slots;
+        const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = to_op16(0.f, h16);
+        if (tap < 9) {
+            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const size_t q = (size_t)yy * W + xx;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c < C) {
+                        const float u = (x[q * ldc + c] + 1.f) * 0.5f;
+                        const float g = gimg[(size_t)c * HW + q];
+                        const float uc = fminf(fmaxf(u, 0.f), 1.f);
+                        o[c] = to_op16((g * (u - uc) >= 0.f) ? (0.5f * gscale) * g : 0.f, h16);
+                    }
+                }
+            }
+        }
+        reinterpret_cast<bf16x8*>(col)[idx] = o;
+    }
+}
+
 // Adam (torch.optim.Adam semantics, amsgrad off, weight_decay 0) fused with clip_z.
 // z is NCHW [1, C, HW]; zmin/zmax per channel (may be null -> no clamp).
 __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ z, float* __restrict__ m,
@@ -342,6 +378,14 @@ int prx_image_head_bwd(const float* x, int ldc, const float* gimg, float* dx, bf
                        int HW, hipStream_t s, int h16, const float* gscale) {
     hipLaunchKernelGGL(image_head_bwd_kernel, dim3(ew_grid((size_t)NB * HW * ldo)), dim3(256), 0, s, x, ldc, gimg, dx,
                        dx_bf16, ldo, NB, C, HW, h16, gscale);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+int prx_image_head_bwd_im2col(const float* x, int ldc, const float* gimg, bf16_t* col, int ldk, int C, int H, int W, hipStream_t s, int h16,
+                              const float* gscale) {
+    PRX_REQUIRE(C <= 8 && ldk % 8 == 0 && ldk >= 72, "image_head_bwd_im2col: at most 8 channels, row pitch a multiple of 8 >= 72");
+    hipLaunchKernelGGL(image_head_bwd_im2col_kernel, dim3(ew_grid((size_t)H * W * (ldk / 8))), dim3(256), 0, s, x, ldc, gimg, col, ldk, C, H, W,
+                       h16, gscale);
     PRX_LAUNCH_CHECK();
     return 0;
 }

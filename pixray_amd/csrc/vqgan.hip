@@ -100,6 +100,8 @@ struct PrxVqgan {
     float *pmin; int* pidx;
     void* a;               // GN(+swish) operand, max size
     void *tA, *tB, *tC, *tD, *dqkv, *dy8;    // attention temporaries [P*C max], dgrad head input
+    void *dycol, *Wd_col;                    // 16-bit modes: the head gradient as the im2col matrix [H*W][128] of conv_out's dgrad and that dgrad's
+                                             // weight pack with its rows padded to 128 (elementwise.h prx_image_head_bwd_im2col); else null
     float* S;                // score matrix
     void *g0, *g1, *g2;      // gradient ping-pong streams (max P*C): fp32, 16-bit in the lean layout
     void *g0b, *g1b, *g2b;   // their operand twins (dgrad GEMM operands); aliases of g0..g2 in the exact mode and in the lean layout
@@ -299,6 +301,13 @@ int prx_vqgan_create_impl(PrxVqgan** out, int ch, const int* ch_mult, int n_mult
     VALLOC_OP(v->a, maxPC);
     VALLOC_OP(v->tA, maxAttnPC); VALLOC_OP(v->tB, maxAttnPC); VALLOC_OP(v->tC, maxAttnPC); VALLOC_OP(v->tD, maxAttnPC);
     VALLOC_OP(v->dqkv, maxAttnPC * 3); VALLOC_OP(v->dy8, PH * 8);
+    v->dycol = v->Wd_col = nullptr;
+    if (!v->f32 && v->conv_out.CoP == 8) {
+        const int Cin = v->conv_out.Cin;
+        VALLOC_OP(v->dycol, PH * 128); VALLOC_OP(v->Wd_col, (size_t)Cin * 128);
+        PRX_CHECK_HIP(hipMemsetAsync(v->Wd_col, 0, (size_t)Cin * 128 * sizeof(bf16_t), s));
+        PRX_CHECK_HIP(hipMemcpy2DAsync(v->Wd_col, 128 * sizeof(bf16_t), v->conv_out.Wd, 72 * sizeof(bf16_t), 72 * sizeof(bf16_t), Cin, hipMemcpyDeviceToDevice, s));
+    }
     VALLOC(v->S, maxAttnPC);
     VALLOC_S(v->g0, maxPC); VALLOC_S(v->g1, maxPC); VALLOC_S(v->g2, maxPC);
     if (v->f32 || v->lean) { v->g0b = v->g0; v->g1b = v->g1; v->g2b = v->g2; }     // the gradient streams are the dgrad operands
@@ -554,11 +563,20 @@ int prx_vqgan_backward_impl(PrxVqgan* v, const float* g_img, float* dz, hipStrea
     PRX_CHECK_HIP(hipMemsetAsync(v->all_stats + (size_t)v->n_gn * 64, 0, sizeof(double) * (size_t)v->n_gn * 64, s));
     // half mode: the whole backward runs under a power-of-two scale S chosen from max|dL/d(image)|; ClampWithGrad only reads signs
     if (v->h16 && (r = prx_grad_scale(g_img, (size_t)v->out_ch * PH, v->gs + 2, 256, prx_grad_target_log2(), v->gs, s))) return r;
-    if ((r = prx_image_head_bwd(v->y, v->conv_out.CoP, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
-                                v->out_ch, PH, s, v->h16, v->gs))) return r;
     struct GB { void* f; void* b; };      // a gradient stream and its operand twin (one tensor in the exact mode and in the lean layout)
     GB g{v->g0, v->g0b}, t1{v->g1, v->g1b}, t2{v->g2, v->g2b};
-    if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
+    if (v->dycol) {
+        // conv_out's dgrad as a row-major product over the im2col'ed head gradient (K = 72 padded to 128: two stages of a fit tile)
+        if ((r = prx_image_head_bwd_im2col(v->y, v->conv_out.CoP, g_img, (bf16_t*)v->dycol, 128, v->out_ch, v->H, v->W, s, v->h16, v->gs))) return r;
+        GemmDesc d; d.A = v->dycol; d.lda = 128; d.B = v->Wd_col; d.ldb = 128; d.M = PH; d.N = v->conv_out.Cin; d.K = 128;
+        out_stream(v, d, t1.f, v->conv_out.Cin, nullptr);
+        set_gnb(v, d, &v->norm_out, v->x_last, 1);
+        if ((r = vg(v, d, s))) return r;
+    } else {
+        if ((r = prx_image_head_bwd(v->y, v->conv_out.CoP, g_img, v->f32 ? (float*)v->dy8 : nullptr, v->f32 ? nullptr : (bf16_t*)v->dy8, v->conv_out.CoP, 1,
+                                    v->out_ch, PH, s, v->h16, v->gs))) return r;
+        if ((r = conv3_bwd(v, v->conv_out, v->dy8, false, v->H, v->W, t1.f, s, nullptr, &v->norm_out, v->x_last, 1))) return r;
+    }
     if ((r = gn_bwd(v, v->norm_out, t1.f, v->x_last, nullptr, g.f, g.b, PH, 1, s, true))) return r;
     for (int si = (int)v->stages.size() - 1; si >= 0; --si) {
         const Stage& st = v->stages[si];
