@@ -62,21 +62,6 @@ struct GemmDesc {
     const float* gnb_beta = nullptr;
     int gnb_swish = 0;
     float gnb_eps = 1e-6f;
-    // LayerNorm folded around a product (fit tiles only; the ViT runner's lean layout).  y = LN(x) W^T + b is evaluated as
-    // rstd_m (x W'^T - mean_m colsum) + b' with W' = W diag(gamma), colsum_n = sum_k W'[n][k], b' = b + W beta: the consumer reads
-    // the UN-normalised 16-bit rows x as its A operand and the LayerNorm pass between the two products disappears.
-    //   producer (the product that writes x): rowstat_out[M][N / tn][2] = (sum, sum of squares) of the ROUNDED 16-bit output values
-    //   per row and wave-tile column block (tn columns: prx_gemm_launch with plan_tn tells);
-    //   consumer: ln_rowstat = that table, ln_np blocks per row, ln_colsum [N]; the row statistics go to ln_mean_out / ln_rstd_out
-    //   (optional; the LayerNorm backward reads them)
-    float* rowstat_out = nullptr;
-    const float* ln_rowstat = nullptr; int ln_np = 0;
-    const float* ln_colsum = nullptr;
-    float ln_eps = 1e-5f;
-    float* ln_mean_out = nullptr; float* ln_rstd_out = nullptr;
-    // dry run: when set, nothing is launched; *plan_tn = the wave-tile width of the fit tile this launch would run on, 0 if it
-    // would not run on a fit tile
-    int* plan_tn = nullptr;
 };
 
 // Per-handle engine state: tuning overrides and the optional per-launch timing log.  Every runner handle owns one, so two

@@ -1040,7 +1040,6 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
     }
     if (!forced && d.M > 0 && d.N > 0 && d.K > 0) {
         const Plan8p p = plan_8phase(d, cx);
-        if (d.plan_tn && p.main_rows > 0) { *d.plan_tn = 0; return 0; }      // dry run: (partly) on the 8-phase kernel -- not a fit tile
         if (p.main_rows >= d.M) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 1);
         if (p.main_rows > 0) {
             int r = gemm_launch_one(rows_of(d, 0, p.main_rows), ws, ws_bytes, stream, ctx, 1);
@@ -1128,8 +1127,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
     if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { fit_tile = false; if (!fourwave_tile(BM, BN)) { BM = 128; BN = 128; } }
-    if (d.plan_tn) { *d.plan_tn = fit_tile ? prx_gemmfit_tn(BM, BN) : 0; return 0; }          // dry run (gemm.h)
-    PRX_REQUIRE(fit_tile || (!d.rowstat_out && !d.ln_rowstat), "gemm: the LayerNorm fold (rowstat_out / ln_rowstat) exists on the fit tiles only");
     if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
     if (!fit_tile && BM == 256 && BN == 128 && (d.a_is_f32 || !cx.use_glds)) BM = 128;     // the 8-wave tile exists as a DMA kernel only (16-bit A)
     const int bk = d.f32 ? BKF : BK;

@@ -190,5 +190,4 @@ void prx_gemm8p_launch(const prx_gemm_dev::GemmArgs& a, dim3 grid, hipStream_t s
 bool prx_gemmfit_tile(int bm, int bn, int* ks);
 bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn);
 void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn);   // *bm = 0: leave it to the 4-wave kernels
-int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);
-int prx_gemmfit_tn(int bm, int bn);        // wave-tile width of a fit tile (0: no such tile)   // grid = (tiles, 1)
+int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s);   // grid = (tiles, 1)

@@ -82,7 +82,7 @@ constexpr int fit_scratch_floats() {
 }
 template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
 __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
-                                           int wt, int wm, int wn, int lane, const float2* lnrow = nullptr) {
+                                           int wt, int wm, int wn, int lane) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
     constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN, TN = 16 * FN;
     const GemmDesc& d = p.d;
@@ -142,15 +142,6 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     }
     GnbConst gc0{}, gc1{};
     if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
-    // LayerNorm fold (gemm.h): consumer side -- v = rstd_m (acc - mean_m colsum_n), then the bias etc.; producer side -- per-row
-    // sums of the rounded 16-bit outputs over this wave tile's columns
-    const bool lnf = lnrow != nullptr && d.ln_colsum != nullptr;
-    float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0;
-    if (lnf && col_ok) {
-        cs0 = *reinterpret_cast<const float4*>(d.ln_colsum + col);
-        cs1 = *reinterpret_cast<const float4*>(d.ln_colsum + col + 4);
-    }
-    const bool rowstat = d.rowstat_out != nullptr && d.out_bf16 != nullptr;
     // slabs are handled FMC at a time: the prefetch of a chunk is (2 x 16 bytes + 1) registers per slab and pass on top of the
     // accumulators, and the wide wave tiles (16+ fragments) have no room for all of them at once
     constexpr int FMC = FM * FN > 16 ? 3 : FM;
@@ -198,16 +189,9 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
-                const bool active = col_ok && lr < 16 && row < d.M;
-                float rs = 0.f, rq = 0.f;                  // row sums of this lane's 8 rounded outputs (producer side of the fold)
-                if (active) {
+                if (!(col_ok && lr < 16 && row < d.M)) continue;
                 float4 v0 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
                 float4 v1 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc + 4]);
-                if (lnf) {
-                    const float2 ms = lnrow[wm * (16 * FM) + i * 16 + lr];          // (mean, rstd) of this output row's A row
-                    v0 = make_float4((v0.x - ms.x * cs0.x) * ms.y, (v0.y - ms.x * cs0.y) * ms.y, (v0.z - ms.x * cs0.z) * ms.y, (v0.w - ms.x * cs0.w) * ms.y);
-                    v1 = make_float4((v1.x - ms.x * cs1.x) * ms.y, (v1.y - ms.x * cs1.y) * ms.y, (v1.z - ms.x * cs1.z) * ms.y, (v1.w - ms.x * cs1.w) * ms.y);
-                }
                 float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
                 float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, p0, p1;
                 if (row16) {
@@ -241,10 +225,6 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                     q[0] = op_cvt<T16>(v0.x); q[1] = op_cvt<T16>(v0.y); q[2] = op_cvt<T16>(v0.z); q[3] = op_cvt<T16>(v0.w);
                     q[4] = op_cvt<T16>(v1.x); q[5] = op_cvt<T16>(v1.y); q[6] = op_cvt<T16>(v1.z); q[7] = op_cvt<T16>(v1.w);
                     *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = q;
-                    if (rowstat) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) { const float r_ = (float)q[k]; rs += r_; rq += r_ * r_; }
-                    }
                 }
                 if (gnb) {
                     fit_gnb_accum(d, gc0, __builtin_bit_cast(float4, pf[ic][ps][0]), v0, gsa0, gsa1);
@@ -254,15 +234,6 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                     gsa1 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
                     gsb0 += (v1.x + v1.y) + (v1.z + v1.w);
                     gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
-                }
-                }   // active
-                if constexpr ((LPR & (LPR - 1)) == 0) {
-                    if (rowstat) {              // wave-uniform: every lane takes part in the butterfly over the LPR lanes of a row
-#pragma unroll
-                        for (int o = 1; o < LPR; o <<= 1) { rs += __shfl_xor(rs, o, 64); rq += __shfl_xor(rq, o, 64); }
-                        if (active && (lane & (LPR - 1)) == 0)
-                            *reinterpret_cast<float2*>(d.rowstat_out + ((size_t)row * (d.N / TN) + (cbase / TN)) * 2) = make_float2(rs, rq);
-                    }
                 }
             }
             /*hipemu:wave_sync*/                    // every lane has read the slab before the next one is written over it
@@ -313,9 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     static_assert(FIT_STAGES * STAGE * 2 <= 160 * 1024, "ring exceeds the LDS");
     static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
 
-    __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the ring (and, behind the K loop, the epilogue's scratch)
-    __shared__ float2 lnrow[CONV ? 1 : BM];          // LayerNorm fold, consumer side: (mean, rstd) of this tile's A rows (row-major products)
-    static_assert(FIT_STAGES * STAGE * 2 + (CONV ? 1 : BM) * 8 <= 160 * 1024, "ring + row statistics exceed the LDS");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the only __shared__ object
 
     const GemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -478,24 +447,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     const bool late = (p.fit_flags & 1) && wave >= NW / 2;
     if (0 < nk) issue(0, 0);
     if (1 < nk) issue(1, 1);
-    if constexpr (!CONV) {
-        if (d.ln_rowstat) {     // LayerNorm fold, consumer side: the producer's per-row partial sums -> (mean, rstd) of this tile's rows, under the
-                                // first two stages' DMA; the K loop's barriers order these LDS writes before the epilogue reads them
-            for (int r_ = tid; r_ < BM; r_ += 64 * NW) {
-                const int row = tm * BM + r_;
-                float s_ = 0.f, q_ = 0.f;
-                if (row < d.M) {
-                    const float2* pr = reinterpret_cast<const float2*>(d.ln_rowstat) + (size_t)row * d.ln_np;
-                    for (int k = 0; k < d.ln_np; ++k) { const float2 t_ = pr[k]; s_ += t_.x; q_ += t_.y; }
-                }
-                const float mean = s_ / (float)d.K;
-                const float var = fmaxf(q_ / (float)d.K - mean * mean, 0.f);
-                const float rstd = rsqrtf(var + d.ln_eps);
-                lnrow[r_] = make_float2(mean, rstd);
-                if (tn == 0 && row < d.M && d.ln_mean_out) { d.ln_mean_out[row] = mean; d.ln_rstd_out[row] = rstd; }
-            }
-        }
-    }
 #define FIT_STEP(T, ST)                                                                                                 \
     do {                                                                                                                \
         if ((T) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");                                    \
@@ -520,8 +471,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         return;
     }
     static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
-    fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane,
-                                          (!CONV && d.ln_rowstat) ? lnrow : nullptr);
+    fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
 }
 
 template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
@@ -553,7 +503,6 @@ const FitTile* fit_tile(int bm, int bn) {
 }
 }  // namespace
 
-int prx_gemmfit_tn(int bm, int bn) { const FitTile* t = fit_tile(bm, bn); return t ? t->tn : 0; }
 bool prx_gemmfit_tile(int bm, int bn, int* ks) {
     const FitTile* t = fit_tile(bm, bn);
     if (ks) *ks = t ? t->ks : 0;
@@ -583,15 +532,9 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
                              d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
                              d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
     // the epilogue prefetches ONE row operand per output row into shared registers: residual, aux, or the GroupNorm input
-    // LayerNorm fold: producer -- a plain 16-bit output whose N is whole wave tiles of a power-of-two lane group; consumer -- row-major,
-    // unit alpha, whole-row statistics of a K-wide row
-    bool fold_ok = true;
-    if (d.rowstat_out) fold_ok = d.out_bf16 && !d.out_bf16_pre && d.act == PRX_ACT_NONE && d.N % wave_tn == 0 && ((wave_tn / 8) & (wave_tn / 8 - 1)) == 0;
-    if (d.ln_rowstat) fold_ok = fold_ok && d.a_mode == PRX_A_ROWMAJOR && d.ln_colsum && d.ln_np > 0 && d.alpha == 1.f && !d.alpha_dev && al16(d.ln_colsum) &&
-                                ((uintptr_t)d.ln_rowstat & 7) == 0;
     const bool has_res = d.resid || d.resid16, has_gnb = d.gnb_x || d.gnb_x16;
     const bool one_operand = !(has_res && d.aux) && !(has_gnb && (has_res || d.aux));
-    return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && fold_ok && one_operand && d.M >= 1 &&
+    return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && one_operand && d.M >= 1 &&
            (unsigned long long)d.N * d.ldb < (1ull << 31);
 }
 // planner: the fit tile (if any) whose grid fills the chip best; *bm = 0 when the 4-wave kernels should keep the problem.

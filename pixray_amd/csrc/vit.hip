@@ -49,26 +49,6 @@ __global__ __launch_bounds__(256) void add_cls_pos_kernel(float* __restrict__ x,
     }
 }
 
-// LayerNorm folded into the product that consumes it (gemm.h): one wave per output row n of W [N][K]
-//   Wf[n][k] = op16(W[n][k] gamma[k]);  colsum[n] = sum_k Wf[n][k] (of the ROUNDED values: what the MFMA multiplies);
-//   bias_f[n] = bias[n] + sum_k W[n][k] beta[k]
-__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ bias, bf16_t* __restrict__ Wf, float* __restrict__ colsum,
-                                                      float* __restrict__ bias_f, int N, int K, int h16) {
-    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float cs = 0.f, bb = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float w = W[(size_t)n * K + k];
-        const bf16_t r = to_op16(w * gamma[k], h16);
-        Wf[(size_t)n * K + k] = r;
-        cs += from_op16(r, h16);
-        bb += w * beta[k];
-    }
-    cs = wave_sum(cs); bb = wave_sum(bb);
-    if (lane == 0) { colsum[n] = cs; bias_f[n] = bias[n] + bb; }
-}
-
 }  // namespace
 
 int prx_pack_op(const float* in, void* out, size_t n, int prec, hipStream_t s) {
@@ -89,9 +69,6 @@ int prx_pack_transpose_bf16(const float* in, bf16_t* out, int R, int C, hipStrea
 struct VitLayer {
     float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *b1, *b2;
     void *Wqkv, *WqkvT, *Wo, *WoT, *W1, *W1T, *W2, *W2T;   // operand precision (bf16 | fp32)
-    // LayerNorm fold (lean layout): gamma-folded forward packs of Wqkv / W1 with their column sums and beta-folded biases, and the
-    // producers' per-row partial sums of x_in (written by the previous block's FC2) and x_mid (this block's projection)
-    void *Wqkv_f, *W1_f; float *cs_qkv, *bqkv_f, *cs_1, *b1_f, *rs_in, *rs_mid;
     // saved activations (x_in / x_mid: the residual stream, fp32 -- or the 16-bit operand format in the lean layout)
     void *x_in, *x_mid;
     float *mean1, *rstd1, *mean2, *rstd2;
@@ -120,9 +97,6 @@ struct PrxVit {
     int lean;
     float* ws; size_t ws_bytes;
     int cur_n;
-    // LayerNorm fold (lean layout; gemm.h): planned once per batch size -- all four products of a block must land on fit tiles.
-    // np_mid / np_in: column blocks per row in the partial-sum tables of x_mid (the projection's wave tiles) / x_in (FC2's)
-    int fold_n, fold, np_mid, np_in, fold_on;
     // The class-token tail: only the class token of the LAST block's output is ever read (ln_post on token 0, slip.py:66 / clip
     // VisionTransformer), so that block's out-projection, MLP and their backward run on the n class-token rows (row stride
     // T * width into the same buffers) instead of all n * T token rows: the same values for everything that is read, 3 + 3 of
@@ -173,8 +147,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     PrxVit* v = new PrxVit();
     v->res = res; v->patch = patch; v->width = width; v->layers = layers; v->heads = heads; v->out_dim = out_dim;
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
-    v->gs = nullptr; v->fold_n = -1; v->fold = 0; v->np_mid = v->np_in = 0;
-    { const char* e = getenv("PRX_LN_FOLD"); v->fold_on = !(e && atoi(e) == 0); }
+    v->gs = nullptr;
     { const char* e = getenv("PRX_LEAN"); v->lean = (v->h16 && !(e && atoi(e) == 0)) ? 1 : 0; }
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
@@ -212,16 +185,6 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
         if (v->lean) { ALLOC_OP(y.x_in, R * W); ALLOC_OP(y.x_mid, R * W); }
         else { float *a_, *b_; ALLOC(a_, R * W); ALLOC(b_, R * W); y.x_in = a_; y.x_mid = b_; }
         ALLOC(y.mean1, R); ALLOC(y.rstd1, R); ALLOC(y.mean2, R); ALLOC(y.rstd2, R);
-        y.Wqkv_f = y.W1_f = nullptr; y.cs_qkv = y.bqkv_f = y.cs_1 = y.b1_f = y.rs_in = y.rs_mid = nullptr;
-        if (v->lean) {
-            ALLOC_OP(y.Wqkv_f, (size_t)3 * W * W); ALLOC(y.cs_qkv, 3 * W); ALLOC(y.bqkv_f, 3 * W);
-            ALLOC_OP(y.W1_f, (size_t)4 * W * W); ALLOC(y.cs_1, 4 * W); ALLOC(y.b1_f, 4 * W);
-            hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(3 * W, 4)), dim3(256), 0, s, q[2], q[0], q[1], q[3], (bf16_t*)y.Wqkv_f, y.cs_qkv, y.bqkv_f, 3 * W, W, v->h16);
-            PRX_LAUNCH_CHECK();
-            hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(4 * W, 4)), dim3(256), 0, s, q[8], q[6], q[7], q[9], (bf16_t*)y.W1_f, y.cs_1, y.b1_f, 4 * W, W, v->h16);
-            PRX_LAUNCH_CHECK();
-            ALLOC(y.rs_in, R * (size_t)(W / 16) * 2); ALLOC(y.rs_mid, R * (size_t)(W / 16) * 2);      // <= W / 16 column blocks per row (narrowest wave tile: 16)
-        }
         ALLOC_OP(y.qkv, R * 3 * W); ALLOC_OP(y.t, R * 4 * W);
         y.o_save = nullptr; y.lse = nullptr;
         if (T > 64 || v->f32) { ALLOC_OP(y.o_save, R * W); ALLOC(y.lse, (size_t)max_n * heads * T); }
@@ -280,57 +243,6 @@ static int ln_bwd_op(PrxVit* v, const void* g, long long ldg, const void* x, lon
                              v->width, s, v->h16, add_every, s16);
 }
 
-// ---- the four wide products of a block (forward), also used for the dry-run plan of the LayerNorm fold -----------------------
-static GemmDesc vit_desc_qkv(PrxVit* v, VitLayer& y, int R, bool fold) {
-    const int W = v->width;
-    GemmDesc d; d.lda = W; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
-    if (fold) { d.A = y.x_in; d.B = y.Wqkv_f; d.bias_n = y.bqkv_f; d.ln_rowstat = y.rs_in; d.ln_np = v->np_in; d.ln_colsum = y.cs_qkv;
-                d.ln_mean_out = y.mean1; d.ln_rstd_out = y.rstd1; }
-    else { d.A = v->h; d.B = y.Wqkv; d.bias_n = y.bqkv; }
-    return d;
-}
-static GemmDesc vit_desc_proj(PrxVit* v, VitLayer& y, const void* att, int rows, int ldt, bool stats) {
-    const int W = v->width;
-    GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W; d.bias_n = y.bo; d.ldr = ldt;
-    if (v->lean) { d.resid16 = y.x_in; d.out_bf16 = y.x_mid; d.ldc_bf16 = ldt; }
-    else { d.resid = (const float*)y.x_in; d.out_f32 = (float*)y.x_mid; d.ldc_f32 = ldt; }
-    if (stats) d.rowstat_out = y.rs_mid;
-    return d;
-}
-static GemmDesc vit_desc_fc1(PrxVit* v, VitLayer& y, int rows, bool fold) {
-    const int W = v->width;
-    GemmDesc d; d.lda = W; d.ldb = W; d.M = rows; d.N = 4 * W; d.K = W;
-    d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
-    if (fold) { d.A = y.x_mid; d.B = y.W1_f; d.bias_n = y.b1_f; d.ln_rowstat = y.rs_mid; d.ln_np = v->np_mid; d.ln_colsum = y.cs_1;
-                d.ln_mean_out = y.mean2; d.ln_rstd_out = y.rstd2; }
-    else { d.A = v->h; d.B = y.W1; d.bias_n = y.b1; }
-    return d;
-}
-static GemmDesc vit_desc_fc2(PrxVit* v, VitLayer& y, void* x_next, int rows, int ldt, float* rs_next) {
-    const int W = v->width;
-    GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W; d.bias_n = y.b2; d.ldr = ldt;
-    if (v->lean) { d.resid16 = y.x_mid; d.out_bf16 = x_next; d.ldc_bf16 = ldt; }
-    else { d.resid = (const float*)y.x_mid; d.out_f32 = (float*)x_next; d.ldc_f32 = ldt; }
-    d.rowstat_out = rs_next;
-    return d;
-}
-// LayerNorm fold: on when (lean layout and) all four products of a block run on fit tiles at this batch size -- asked of the
-// engine's own planner with dry-run launches (GemmDesc::plan_tn), so tile overrides and rules are honoured
-static void vit_plan_fold(PrxVit* v, int n, hipStream_t s) {
-    v->fold_n = n; v->fold = 0;
-    if (!v->lean || v->layers < 2 || !v->fold_on) return;
-    const int W = v->width, R = n * v->T;
-    VitLayer& y = v->L[0];
-    int tn_proj = 0, tn_fc2 = 0, tn_qkv = 0, tn_fc1 = 0;
-    { GemmDesc d = vit_desc_proj(v, y, v->att_o, R, W, true); d.plan_tn = &tn_proj; if (vit_gemm(v, d, s)) return; }
-    { GemmDesc d = vit_desc_fc2(v, y, v->L[1].x_in, R, W, v->L[1].rs_in); d.plan_tn = &tn_fc2; if (vit_gemm(v, d, s)) return; }
-    if (tn_proj <= 0 || tn_fc2 <= 0 || W % tn_proj || W % tn_fc2) return;
-    v->np_mid = W / tn_proj; v->np_in = W / tn_fc2;
-    { GemmDesc d = vit_desc_qkv(v, v->L[1], R, true); d.plan_tn = &tn_qkv; if (vit_gemm(v, d, s)) return; }
-    { GemmDesc d = vit_desc_fc1(v, y, R, true); d.plan_tn = &tn_fc1; if (vit_gemm(v, d, s)) return; }
-    v->fold = tn_qkv > 0 && tn_fc1 > 0;
-}
-
 int prx_vit_minmax_impl(PrxVit* v, const float* cutouts, int n, float* mm, hipStream_t s) {
     PRX_REQUIRE(n >= 1 && n <= v->max_n, "vit: batch %d exceeds handle capacity %d", n, v->max_n);
     return prx_minmax(cutouts, (size_t)n * 3 * v->res * v->res, v->mm_part, 1024, mm, s);
@@ -353,31 +265,35 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
     void* x0 = v->layers > 0 ? v->L[0].x_in : v->x_final;
     if ((r = prx_layernorm_fwd(v->xpre, W, v->lnpre_g, v->lnpre_b, lean ? (bf16_t*)x0 : nullptr, lean ? nullptr : (float*)x0, v->mean_pre,
                                v->rstd_pre, R, W, 1e-5f, s, v->h16))) return r;
-    if (n != v->fold_n) vit_plan_fold(v, n, s);
     for (int l = 0; l < v->layers; ++l) {
         VitLayer& y = v->L[l];
         void* x_next = (l + 1 < v->layers) ? v->L[l + 1].x_in : v->x_final;
-        // the class-token tail: rows = the n class tokens, reached through a row stride of T * W in the token-major buffers;
-        // LN / MLP intermediates of those rows are stored densely ([n][...]) at the start of their buffers
-        const bool tail = l == v->layers - 1;
-        const int rows = tail ? n : R;
-        const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
-        // LayerNorm fold: ln_1 of every block but the first (its input comes from ln_pre, not from a product), ln_2 of every
-        // block but the last (the class-token tail runs its MLP on n rows)
-        const bool fold1 = v->fold && l >= 1, fold2 = v->fold && !tail;
-        if (!fold1 && (r = ln_op(v, y.x_in, W, y.ln1_g, y.ln1_b, v->h, y.mean1, y.rstd1, R, s))) return r;
-        {   GemmDesc d = vit_desc_qkv(v, y, R, fold1);
+        if ((r = ln_op(v, y.x_in, W, y.ln1_g, y.ln1_b, v->h, y.mean1, y.rstd1, R, s))) return r;
+        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.Wqkv; d.ldb = W; d.M = R; d.N = 3 * W; d.K = W;
+            d.bias_n = y.bqkv; d.out_bf16 = y.qkv; d.ldc_bf16 = 3 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
         const void* att = v->att_o;
         if (v->f32) { if ((r = prx_mha_fwd_f32((const float*)y.qkv, (float*)y.o_save, y.lse, n, T, W, v->heads, s))) return r; att = y.o_save; }
         else if (T <= 64) { if ((r = prx_mha_fwd((const bf16_t*)y.qkv, (bf16_t*)v->att_o, n, T, W, v->heads, s, v->h16))) return r; }
         else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s, v->h16))) return r; att = y.o_save; }
-        {   GemmDesc d = vit_desc_proj(v, y, att, rows, ldt, fold2);
+        // the class-token tail: rows = the n class tokens, reached through a row stride of T * W in the token-major buffers;
+        // LN / MLP intermediates of those rows are stored densely ([n][...]) at the start of their buffers
+        const bool tail = l == v->layers - 1;
+        const int rows = tail ? n : R;
+        const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
+        {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
+            d.bias_n = y.bo; d.ldr = ldt;
+            if (lean) { d.resid16 = y.x_in; d.out_bf16 = y.x_mid; d.ldc_bf16 = ldt; }
+            else { d.resid = (const float*)y.x_in; d.out_f32 = (float*)y.x_mid; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
-        if (!fold2 && (r = ln_op(v, y.x_mid, ldt, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, rows, s))) return r;
-        {   GemmDesc d = vit_desc_fc1(v, y, rows, fold2);
+        if ((r = ln_op(v, y.x_mid, ldt, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, rows, s))) return r;
+        {   GemmDesc d; d.A = v->h; d.lda = W; d.B = y.W1; d.ldb = W; d.M = rows; d.N = 4 * W; d.K = W;
+            d.bias_n = y.b1; d.act = PRX_ACT_QUICKGELU; d.out_bf16 = v->u; d.out_bf16_pre = y.t; d.ldc_bf16 = 4 * W;
             if ((r = vit_gemm(v, d, s))) return r; }
-        {   GemmDesc d = vit_desc_fc2(v, y, x_next, rows, ldt, (v->fold && !tail) ? v->L[l + 1].rs_in : nullptr);
+        {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
+            d.bias_n = y.b2; d.ldr = ldt;
+            if (lean) { d.resid16 = y.x_mid; d.out_bf16 = x_next; d.ldc_bf16 = ldt; }
+            else { d.resid = (const float*)y.x_mid; d.out_f32 = (float*)x_next; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
     }
     // ln_post on the class token, projection, L2 normalisation (slip.py:66)
