@@ -133,7 +133,10 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     const bool has_resid = d.resid != nullptr || d.resid16 != nullptr;
     const bool row16 = d.resid16 != nullptr || d.gnb_x16 != nullptr;      // the row operand (residual / GroupNorm input) is a 16-bit stream
     const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
-    const bool do_stats = d.gn_stats != nullptr;
+    // the 80-row-granular tiles are the token-batch (ViT tower) tiles: no GroupNorm there, and their epilogue is compiled without the
+    // statistics code (the fit kernels' epilogues are sensitive to every register and branch: profiles/r05_ln_fold/)
+    constexpr bool STATS = BM % 80 != 0;
+    const bool do_stats = STATS && d.gn_stats != nullptr;
     const bool gnb = do_stats && (d.gnb_x != nullptr || d.gnb_x16 != nullptr);
     float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
     if (d.bias_n && col_ok) {
@@ -523,7 +526,7 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     bool stats_ok = true;
     if (d.gn_stats) {
         const int lpr = wave_tn / 8;
-        stats_ok = (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
+        stats_ok = bm % 80 != 0 && (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
                    al16(d.gnb_x16) && ((!d.gnb_x && !d.gnb_x16) || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
     }
     const bool a_ok = d.a_mode == PRX_A_ROWMAJOR
