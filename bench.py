@@ -449,7 +449,7 @@ def main():
                                      else "RCCL through torch.distributed (nccl)") + (", every rank on ONE device (protocol test)" if one_device else "")),
                        "launch": "hipGraph replay" if graphed else ("eager" + (f" (replay refused: {sess.graph_error})" if args.graph and getattr(sess, "graph_error", None) else "")),
                        "precision": {"fp16": "IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16: the reference's CLIP arithmetic on a GPU), "
-                                             "fp32 accumulate / residual streams / norms, power-of-two gradient scale in the backward",
+                                             "fp32 accumulate and norm arithmetic, residual / feature-map streams and their gradients held in half (the lean layout: slip.py:175 runs the CLIP model in fp16, residual adds included; the fp32 VQGAN of the reference is the `ref` mode), power-of-two gradient scale in the backward",
                                      "bf16": "bf16 MFMA operands, fp32 accumulate / residual streams / norms",
                                      "f32": "exact f32: every contraction on v_mfma_f32_32x32x2_f32 (parity mode)",
                                      "ref": "the reference's own mix on a GPU: fp32 VQGAN decoder (every decoder contraction on "

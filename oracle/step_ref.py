@@ -256,7 +256,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     opt = torch.optim.Adam([z_ref], lr=lr)
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
     prompts = prompt_list(clip_model, clip_cfg, seed)
-    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok, img_rel = [], [], [], [], [], [], [], []
+    dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok, img_rel, dz_ind = [], [], [], [], [], [], [], [], []
     seen = {}
     synth_and_filter = sess.do_synth_and_filter
 
@@ -293,9 +293,18 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         emb = clip_vit_ref.encode_image(clip_params, cut, patch=clip_cfg.patch_size, heads=clip_cfg.heads, layers=clip_cfg.layers)
         losses = [prompt_ref.Prompt(e, w, s)(emb) for (e, w, s) in prompts]
         g_img, = torch.autograd.grad(sum(losses), img_in)
-        z_ref.grad, = torch.autograd.grad(img_ref, z_ref, g_img)
+        z_ref.grad, = torch.autograd.grad(img_ref, z_ref, g_img, retain_graph=True)
         r, c = _metrics(dz_hip, z_ref.grad)
         dz_rel.append(r); dz_cos.append(c)
+        # informational: the FULLY independent oracle gradient (its own image into its own cutouts -> CLIP -> loss).  Where pixels
+        # sit on a clamp bound the reference's dL/d(image) is discontinuous (tools/oracle_tie_sensitivity.py, tests/test_oracle_pins.py),
+        # so this figure can jump by tenths at a step without either side being wrong; it is reported, the gate is on the one above
+        img_own = img_ref.detach().clone().requires_grad_(True)
+        cut_o = cutouts_ref.make_cutouts(img_own, prm, S)
+        emb_o = clip_vit_ref.encode_image(clip_params, cut_o, patch=clip_cfg.patch_size, heads=clip_cfg.heads, layers=clip_cfg.layers)
+        g_own, = torch.autograd.grad(sum(prompt_ref.Prompt(e, w, s)(emb_o) for (e, w, s) in prompts), img_own)
+        dz_own, = torch.autograd.grad(img_ref, z_ref, g_own)
+        dz_ind.append(_metrics(dz_hip, dz_own)[0])
         idx_ok.append(float((idx_hip == idx_ref).float().mean()))
         opt.step()
         with torch.no_grad():
@@ -307,7 +316,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         free_idx_ok.append(float((free.drawer.handle.last_indices.cpu().long() == idx_ref).float().mean()))
     z_free = free.drawer.get_z().detach().cpu()
     return dict(steps=k, dz_rel_l2_max=max(dz_rel), dz_cosine_min=min(dz_cos), vq_index_agreement_min=min(idx_ok),
-                image_rel_l2_max=max(img_rel), dz_rel_l2=dz_rel,
+                image_rel_l2_max=max(img_rel), dz_rel_l2=dz_rel, dz_rel_l2_independent_oracle=dz_ind,
                 z_after_step_max_abs_err=max(z_err), loss_oracle=loss_ref, loss_hip_free_running=loss_free,
                 # the FREE-RUNNING copy against the oracle's trajectory ("z after 10 Adam steps"): only
                 # meaningful while both sides still select the same codes at every step

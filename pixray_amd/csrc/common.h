@@ -127,6 +127,18 @@ template <> __device__ __forceinline__ void op_ld4<half_t>(const half_t* p, size
     const f16x4 t = *reinterpret_cast<const f16x4*>(p + i);
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
+// ... returning the four values (no local array at the call site: a `float v[4]` filled through a pointer inside a conditional
+// branch kept every such array of the 128 x 128 half kernels' epilogues in scratch)
+template <typename T> __device__ __forceinline__ float4 op_ld4v(const T* p, size_t i);
+template <> __device__ __forceinline__ float4 op_ld4v<bf16_t>(const bf16_t* p, size_t i) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + i);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+template <> __device__ __forceinline__ float4 op_ld4v<half_t>(const half_t* p, size_t i) {
+    const f16x4 t = *reinterpret_cast<const f16x4*>(p + i);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+template <> __device__ __forceinline__ float4 op_ld4v<float>(const float* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
 template <typename T> __device__ __forceinline__ void op_st4(T* p, size_t i, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void op_st4<half_t>(half_t* p, size_t i, float a, float b, float c, float d) {
     f16x4 r;

@@ -39,8 +39,6 @@ struct GemmDesc {
     const float* bias_m = nullptr;
     const void* aux = nullptr; int ldaux = 0;   // operand precision
     const float* resid = nullptr; int ldr = 0;
-    const void* resid16 = nullptr;       // ... or the residual as a 16-bit stream in the operand format (the lean layout of the runners:
-                                         // residual / feature-map streams kept in IEEE half); same leading dimension `ldr`; not both
     int act = PRX_ACT_NONE;
     float* out_f32 = nullptr; int ldc_f32 = 0;
     void* out_bf16 = nullptr;        // post-activation, operand precision (the next GEMM's A)
@@ -56,11 +54,14 @@ struct GemmDesc {
     // * gamma, accumulate (sum dxhat, sum dxhat*xhat) per group into gn_stats -- saves the stats pass of the GroupNorm
     // backward (8 bytes read per element) for 4 bytes read in this epilogue.
     const float* gnb_x = nullptr;        // [M, N] fp32, the GroupNorm's forward input
-    const void* gnb_x16 = nullptr;       // ... or the same as a 16-bit stream in the operand format (lean layout); not both
     const double* gnb_fstats = nullptr;  // its forward sums [32][2]
     const float* gnb_gamma = nullptr;
     const float* gnb_beta = nullptr;
-    int gnb_swish = 0;
+    short gnb_swish = 0;
+    short row16 = 0;                     // bit 0: `resid` addresses a 16-bit stream in the operand format (the lean layout of the runners: residual /
+                                         // feature-map streams kept in IEEE half), bit 1: so does `gnb_x`.  Flags in what used to be half of an int, not a
+                                         // second pair of pointers: the descriptor travels by value, and past its round-4 size the 128 x 128 kernels keep
+                                         // it on the stack (320 bytes of scratch per lane: tests/test_host_logic.py guards that)
     float gnb_eps = 1e-6f;
 };
 
@@ -75,7 +76,6 @@ struct GemmCtx {
     int xcd_swizzle = 2;              // 0 off, 1 on, 2 narrow row-major problems only
     int conv_c64 = 1;                 // scalar-tap conv gather when Cin % 64 == 0
     int wide_tile = 128;
-    int big_tile = 0;            // > 0: use the 8-wave 256 x 128 tile when it gives >= big_tile * 256 tiles (PRX_BIG_TILE)
     int tile8p = 128;            // > 0: 256 x 256 tiles on the 8-phase kernel (gemm8p.hip) are CONSIDERED from this many tiles on (PRX_GEMM_8P;
                                  // gemm.hip plan_8phase then decides by cost: full rounds of 256 tiles on it, the remainder rows on the 4-wave kernels)
     int fit_flags = 1;           // gemmfit.hip A/B switches: bit 0 staggered wave groups (PRX_FIT_FLAGS)

@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     bf16x8 a_reg[A_CH], b_reg[B_CH];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    auto load_tiles = [&](int kt) {
+    // (always_inline on every kernel lambda: they capture the by-value descriptor by reference, and ONE call the inliner declines
+    // puts the whole descriptor on the stack -- 320 bytes of scratch per lane, tests/test_host_logic.py guards it)
+    auto load_tiles = [&](int kt) __attribute__((always_inline)) {
         const int k = kt * BK + kc * 8;
         const bool k_ok = k < d.K;
         if (AMODE == PRX_A_ROWMAJOR) {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int i = 0; i < B_CH; ++i)
             b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const bf16x8*>(Bp + b_base[i] + k) : zero8;
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i)
             *reinterpret_cast<bf16x8*>(&As[a_row[i] * LDS_LD + kc * 8]) = a_reg[i];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
     f32x4 a_reg[A_CH], b_reg[B_CH];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt) __attribute__((always_inline)) {
         const int k = kt * BKF + kc * 4;
         const bool k_ok = k < d.K;
         if (AMODE == PRX_A_ROWMAJOR) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs p) {
         for (int i = 0; i < B_CH; ++i)
             b_reg[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const f32x4*>(Bp + b_base[i] + k) : zero4;
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i)
             *reinterpret_cast<f32x4*>(&As[a_row[i] * LDS_LDF + kc * 4]) = a_reg[i];
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
     }
 
     const long long zoff = zero_page - Ap;
-    auto issue = [&](int kt, int buf) {
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
         bf16_t* As = lds + buf * TILE;
         bf16_t* Bs = As + BM * BK;
         if constexpr (C64) {
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         const int r = wn * (BN / 2) + j * 32 + frag_row;
         b_off[j] = r * BK; b_key[j] = (r >> 1) & 7;
     }
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const bf16_t* As = lds + buf * TILE;
         const bf16_t* Bs = As + BM * BK;
 #pragma unroll
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_glds_kernel(const GemmArgs p, 
         float gs0 = 0.f, gs1 = 0.f;
         const int rbase = tm * BM + wm * (BM / NWM);
         const int cbase = tn * BN + wn * (BN / 2);
-        const bool gnb = do_stats && (d.gnb_x != nullptr || d.gnb_x16 != nullptr);
+        const bool gnb = do_stats && d.gnb_x != nullptr;
         GnbConst gc{};
         if (gnb && cbase + (lane % LPR) * 4 < d.N) gc = gnb_load(d, cbase + (lane % LPR) * 4);   // this lane's column quad is fixed
 #pragma unroll
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 const int row = (int)(idx / d.N);
                 col = (int)(idx - (size_t)row * d.N);
                 const float4 o = epilogue_store4<TOp>(d, row, col, v);
-                if (do_stats && (d.gnb_x || d.gnb_x16)) gnb_accum<TOp>(d, gnb_load(d, col), row, col, o, s0, s1);
+                if (do_stats && d.gnb_x) gnb_accum<TOp>(d, gnb_load(d, col), row, col, o, s0, s1);
                 else {
                     s0 = (o.x + o.y) + (o.z + o.w);
                     s1 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
@@ -841,21 +843,6 @@ void launch_glds_s(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* ze
     if (a.d.h16) launch_glds_t<BM, BN, STAGES, half_t>(a, grid, s, zero_page, c64);
     else         launch_glds_t<BM, BN, STAGES, bf16_t>(a, grid, s, zero_page, c64);
 }
-// 256x128 tile, 8 waves (wave tile 64x64 like the 128x128 kernel): 1.5 MFMA-flops per L2->LDS byte more than 128x128
-template <int STAGES, typename T16>
-void launch_glds_256_t(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
-    if (a.d.a_mode == PRX_A_ROWMAJOR)
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_ROWMAJOR, STAGES, false, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
-    else if (c64)
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, true, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<256, 128, PRX_A_CONV3X3, STAGES, false, 4, T16>), grid, dim3(512), 0, s, a, zero_page);
-}
-template <int STAGES>
-void launch_glds_256(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, bool c64) {
-    if (a.d.h16) launch_glds_256_t<STAGES, half_t>(a, grid, s, zero_page, c64);
-    else         launch_glds_256_t<STAGES, bf16_t>(a, grid, s, zero_page, c64);
-}
 template <int BM, int BN>
 void launch_glds(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zero_page, int stages, bool c64) {
     if (stages >= 4 && (BM + BN) * BK * 2 * 4 <= 160 * 1024) launch_glds_s<BM, BN, 4>(a, grid, s, zero_page, c64);
@@ -896,7 +883,6 @@ GemmCtx::GemmCtx() {
     xcd_swizzle = env_int("PRX_XCD_SWIZZLE", 2);
     conv_c64 = env_int("PRX_CONV_C64", 1);
     wide_tile = env_int("PRX_WIDE_TILE", 128);
-    big_tile = env_int("PRX_BIG_TILE", 0);
     tile8p = env_int("PRX_GEMM_8P", 128);
     fit = env_int("PRX_GEMM_FIT", 1);
     fit_flags = env_int("PRX_FIT_FLAGS", 1);
@@ -1001,8 +987,7 @@ static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
     s.A = (const char*)d.A + (size_t)r0 * d.lda * (d.a_is_f32 ? 4 : esz);
     if (d.bias_m) s.bias_m = d.bias_m + r0;
     if (d.aux) s.aux = (const char*)d.aux + (size_t)r0 * d.ldaux * esz;
-    if (d.resid) s.resid = d.resid + (size_t)r0 * d.ldr;
-    if (d.resid16) s.resid16 = (const char*)d.resid16 + (size_t)r0 * d.ldr * esz;
+    if (d.resid) s.resid = (d.row16 & 1) ? (const float*)((const char*)d.resid + (size_t)r0 * d.ldr * esz) : d.resid + (size_t)r0 * d.ldr;
     if (d.out_f32) s.out_f32 = d.out_f32 + (size_t)r0 * d.ldc_f32;
     if (d.out_bf16) s.out_bf16 = (char*)d.out_bf16 + (size_t)r0 * d.ldc_bf16 * esz;
     if (d.out_bf16_pre) s.out_bf16_pre = (char*)d.out_bf16_pre + (size_t)r0 * d.ldc_bf16 * esz;
@@ -1010,7 +995,9 @@ static GemmDesc rows_of(const GemmDesc& d, int r0, int rows) {
 }
 
 static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream, GemmCtx* ctx, int use8p);
-static bool fourwave_tile(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64) || (bm == 256 && bn == 128); }
+// (the 8-wave 256 x 128 member of this family -- PRX_BIG_TILE, measured neutral in round 2 and never the default -- was removed in
+// round 5: the descriptor it takes by value had outgrown its register budget (320 bytes of scratch per lane); 256 x 128 is a fit tile)
+static bool fourwave_tile(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64); }
 
 int prx_gemm_plan_rows_8phase_impl(const GemmCtx* c, int M, int N, int K) {
     static const GemmCtx k_default;
@@ -1072,8 +1059,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
                 "gemm: MUL_DQUICKGELU / MUL_RELUMASK / RELUMASK_POST need aux");
     PRX_REQUIRE(d.act != PRX_ACT_RELUMASK_POST || d.resid, "gemm: RELUMASK_POST masks product + residual: it needs resid");
     PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
-    PRX_REQUIRE(!(d.resid && d.resid16) && !(d.gnb_x && d.gnb_x16) && (!d.f32 || (!d.resid16 && !d.gnb_x16)),
-                "gemm: resid16 / gnb_x16 are the 16-bit forms of resid / gnb_x (one of each, 16-bit operand modes only)");
+    PRX_REQUIRE(!d.f32 || d.row16 == 0, "gemm: 16-bit residual / GroupNorm-input streams (row16) belong to the 16-bit operand modes");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
     // Score each tile shape by how well its tile count fills whole "rounds" of resident blocks, weighted by the
@@ -1099,7 +1085,6 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     // very large problems (ViT-L/14 at 256 cutouts: M = 65 792): the 8-wave 256 x 128 tile, when it still fills the chip
     // several times over (A/B switch, off by default: see DESIGN.md section 6)
-    if (cx.big_tile && !d.f32 && d.N >= 128 && ntiles(256, 128) >= cx.big_tile * n_cu) { BM = 256; BN = 128; }
     // fit tiles (gemmfit.hip): one workgroup per CU when a tile grid matches the chip (M = 3200: 240 tiles; the decoder's
     // batch-1 convolutions: K split over the wave groups of a workgroup instead of over workgroups + a reduce launch)
     // (three tile shapes -- 128 x 128, 128 x 64, 64 x 64 -- exist in BOTH kernel families: `fit_tile` says which one is meant)
@@ -1128,7 +1113,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
     if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { fit_tile = false; if (!fourwave_tile(BM, BN)) { BM = 128; BN = 128; } }
     if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
-    if (!fit_tile && BM == 256 && BN == 128 && (d.a_is_f32 || !cx.use_glds)) BM = 128;     // the 8-wave tile exists as a DMA kernel only (16-bit A)
+    if (!fit_tile && BM == 256 && BN == 128) BM = 128;     // 256 x 128 exists as a fit tile only
     const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
     a.d = d;
@@ -1144,10 +1129,11 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     auto al = [](const void* p, size_t a_) { return p == nullptr || ((uintptr_t)p % a_) == 0; };
     const size_t opa = d.f32 ? 16 : 8;   // alignment of a 4-element operand-precision access
-    a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, 16) && al(d.resid16, 8) && ((d.resid == nullptr && d.resid16 == nullptr) || d.ldr % 4 == 0) &&
+    a.vec_epi = (d.N % 4 == 0) && al(d.bias_n, 16) && al(d.resid, (d.row16 & 1) ? 8 : 16) && (d.resid == nullptr || d.ldr % 4 == 0) &&
                 al(d.aux, opa) && (d.aux == nullptr || d.ldaux % 4 == 0) && al(d.out_f32, 16) &&
                 (d.out_f32 == nullptr || d.ldc_f32 % 4 == 0) && al(d.out_bf16, opa) && al(d.out_bf16_pre, opa) &&
                 ((d.out_bf16 == nullptr && d.out_bf16_pre == nullptr) || d.ldc_bf16 % 4 == 0) && al(ws, 16);
+    PRX_REQUIRE(d.row16 == 0 || a.vec_epi, "gemm: 16-bit residual / GroupNorm-input streams need the vector epilogue (N %% 4 == 0, aligned operands)");
     if (fit_tile && !a.vec_epi) {               // the fit kernel has the vector epilogue only
         BM = 128; BN = 128; fit_tile = false;
         a.tiles_m = ceil_div(d.M, BM); a.tiles_n = ceil_div(d.N, BN); tiles = a.tiles_m * a.tiles_n;
@@ -1165,10 +1151,10 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     // 8-phase tiles (tools/micro/gemm8p.hip): +11 % at M = 65 792, N = 1024 and at M = 25 216, N = 3072; -2 % at 8192^3
     if (BM == 256 && BN == 256 && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 512 && d.N <= 4096;
     if (fit_tile && cx.xcd_swizzle == 2) a.xcd_swizzle = tiles >= 16;
-    if (d.gnb_x || d.gnb_x16) {
+    if (d.gnb_x) {
         PRX_REQUIRE(d.gn_stats && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && (d.out_f32 || d.out_bf16) && d.act == PRX_ACT_NONE,
                     "gemm: fused GroupNorm-backward sums need gn_stats, gnb_fstats, gnb_gamma, gnb_beta and a plain output");
-        PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_x16 % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
+        PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
                     "gemm: gnb operands must be 16-byte aligned");
     }
     if (d.gn_stats) {
@@ -1217,8 +1203,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         // the 128-wide tiles it halves the occupancy and loses 15-25 %.
         int stages = (BM == 64 && BN == 64) ? 3 : 2;
         if (cx.force_stages) stages = cx.force_stages;
-        if (BM == 256 && BN == 128) { if (stages >= 3) launch_glds_256<3>(a, grid, stream, zp, c64); else launch_glds_256<2>(a, grid, stream, zp, c64); }
-        else if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
+        if (BM == 128 && BN == 128) launch_glds<128, 128>(a, grid, stream, zp, stages, c64);
         else if (BM == 128 && BN == 64) launch_glds<128, 64>(a, grid, stream, zp, stages, c64);
         else launch_glds<64, 64>(a, grid, stream, zp, stages, c64);
     } else if (BM == 128 && BN == 128) launch_cfg<128, 128>(a, grid, stream);

@@ -38,10 +38,9 @@ __device__ __forceinline__ GnbConst gnb_load(const GemmDesc& d, int col) {
 }
 template <typename TOp>
 __device__ __forceinline__ void gnb_accum(const GemmDesc& d, const GnbConst& c, int row, int col, const float4& o, float& s0, float& s1) {
-    float xv[4];
-    if (d.gnb_x16) op_ld4(reinterpret_cast<const TOp*>(d.gnb_x16), (size_t)row * d.N + col, xv);
-    else op_ld4(d.gnb_x, (size_t)row * d.N + col, xv);
-    const float gv[4] = {o.x, o.y, o.z, o.w};
+    const float4 x4 = (d.row16 & 2) ? op_ld4v(reinterpret_cast<const TOp*>(d.gnb_x), (size_t)row * d.N + col)
+                                    : *reinterpret_cast<const float4*>(d.gnb_x + (size_t)row * d.N + col);
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, gv[4] = {o.x, o.y, o.z, o.w};
     const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -68,8 +67,8 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, int row, int c
     if (d.act == PRX_ACT_MUL_DQUICKGELU) v *= dquickgelu_f(op_ld(aux, (size_t)row * d.ldaux + col));
     const bool masked = (d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST) && !(op_ld(aux, (size_t)row * d.ldaux + col) > 0.f);
     if (masked && d.act == PRX_ACT_MUL_RELUMASK) v = 0.f;
-    if (d.resid) v += d.resid[(size_t)row * d.ldr + col];
-    else if (d.resid16) v += op_ld(reinterpret_cast<const TOp*>(d.resid16), (size_t)row * d.ldr + col);
+    if (d.resid) v += d.resid[(size_t)row * d.ldr + col];       // (fp32 residual only: 16-bit streams -- row16 -- need the vector epilogue, checked on the host;
+                                                                 // this scalar form must stay small enough to unroll, or the accumulators it indexes go to scratch)
     if (masked && d.act == PRX_ACT_RELUMASK_POST) v = 0.f;          // the mask after the residual add
     if (d.act == PRX_ACT_RELU) v = fmaxf(v, 0.f);
     if (d.act == PRX_ACT_QUICKGELU) {
@@ -127,17 +126,16 @@ __device__ __forceinline__ float4 epilogue_value4(const GemmDesc& d, int row, in
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d.bias_n) bias = *reinterpret_cast<const float4*>(d.bias_n + col);
     const float bias_m = d.bias_m ? d.bias_m[row] : 0.f;
-    float aux[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d.act == PRX_ACT_MUL_DQUICKGELU || d.act == PRX_ACT_MUL_RELUMASK || d.act == PRX_ACT_RELUMASK_POST)
-        op_ld4(reinterpret_cast<const TOp*>(d.aux), (size_t)row * d.ldaux + col, aux);
+        ax = op_ld4v(reinterpret_cast<const TOp*>(d.aux), (size_t)row * d.ldaux + col);
+    const float aux[4] = {ax.x, ax.y, ax.z, ax.w};
     float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.resid) res = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
-    else if (d.resid16) {
-        float r4[4];
-        op_ld4(reinterpret_cast<const TOp*>(d.resid16), (size_t)row * d.ldr + col, r4);
-        res = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    if (d.resid) {
+        if (d.row16 & 1) res = op_ld4v(reinterpret_cast<const TOp*>(d.resid), (size_t)row * d.ldr + col);
+        else res = *reinterpret_cast<const float4*>(d.resid + (size_t)row * d.ldr + col);
     }
-    return epilogue_math4<TOp>(d.act, alpha, v, bias, bias_m, aux, d.resid != nullptr || d.resid16 != nullptr, res, pre);
+    return epilogue_math4<TOp>(d.act, alpha, v, bias, bias_m, aux, d.resid != nullptr, res, pre);
 }
 
 template <typename TOp>

@@ -130,14 +130,14 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
     const bool col_ok = lane < RPP * LPR && col < d.N;        // N % 8 == 0: a lane's 8 columns are in range together
     const int act = d.act;
     const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
-    const bool has_resid = d.resid != nullptr || d.resid16 != nullptr;
-    const bool row16 = d.resid16 != nullptr || d.gnb_x16 != nullptr;      // the row operand (residual / GroupNorm input) is a 16-bit stream
+    const bool has_resid = d.resid != nullptr;
+    const bool row16 = has_resid ? (d.row16 & 1) != 0 : (d.row16 & 2) != 0;      // the row operand (residual / GroupNorm input) is a 16-bit stream
     const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
     // the 80-row-granular tiles are the token-batch (ViT tower) tiles: no GroupNorm there, and their epilogue is compiled without the
     // statistics code (the fit kernels' epilogues are sensitive to every register and branch: profiles/r05_ln_fold/)
     constexpr bool STATS = BM % 80 != 0;
     const bool do_stats = STATS && d.gn_stats != nullptr;
-    const bool gnb = do_stats && (d.gnb_x != nullptr || d.gnb_x16 != nullptr);
+    const bool gnb = do_stats && d.gnb_x != nullptr;
     float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
     if (d.bias_n && col_ok) {
         bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
@@ -165,8 +165,8 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
                 pbm[ic][ps] = 0.f;
                 if (ok) {
                     if (row16) {            // 8 columns = one 16-byte load; widened to fp32 in place below
-                        const T16* r_ = has_resid ? reinterpret_cast<const T16*>(d.resid16) + (size_t)row * d.ldr + col
-                                                  : reinterpret_cast<const T16*>(d.gnb_x16) + (size_t)row * d.N + col;
+                        const T16* r_ = has_resid ? reinterpret_cast<const T16*>(d.resid) + (size_t)row * d.ldr + col
+                                                  : reinterpret_cast<const T16*>(d.gnb_x) + (size_t)row * d.N + col;
                         pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
                     } else if (has_resid || gnb) {
                         const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
@@ -518,8 +518,8 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     const int wave_tn = ft->tn;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // null passes
     // the epilogue handles 8 consecutive columns per lane with 16-byte accesses
-    const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.resid16) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
-                        al16(d.out_bf16_pre) && (!d.resid || d.ldr % 4 == 0) && (!d.resid16 || d.ldr % 8 == 0) && (!d.aux || d.ldaux % 8 == 0) &&
+    const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
+                        al16(d.out_bf16_pre) && (!d.resid || d.ldr % ((d.row16 & 1) ? 8 : 4) == 0) && (!d.aux || d.ldaux % 8 == 0) &&
                         (!d.out_f32 || d.ldc_f32 % 4 == 0) && ((!d.out_bf16 && !d.out_bf16_pre) || d.ldc_bf16 % 8 == 0);
     // GroupNorm sums: the lanes of a column quad are reduced by a butterfly (16 FN / 8 lanes per row: a power of two), a
     // group is a whole number of quads inside the block tile, and the GroupNorm-backward input has the output's layout
@@ -527,7 +527,7 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     if (d.gn_stats) {
         const int lpr = wave_tn / 8;
         stats_ok = bm % 80 != 0 && (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
-                   al16(d.gnb_x16) && ((!d.gnb_x && !d.gnb_x16) || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
+                   (!d.gnb_x || (d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
     }
     const bool a_ok = d.a_mode == PRX_A_ROWMAJOR
                           ? (unsigned long long)d.M * d.lda < (1ull << 31)
@@ -535,7 +535,7 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
                              d.Cin % FIT_BK == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
                              d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
     // the epilogue prefetches ONE row operand per output row into shared registers: residual, aux, or the GroupNorm input
-    const bool has_res = d.resid || d.resid16, has_gnb = d.gnb_x || d.gnb_x16;
+    const bool has_res = d.resid != nullptr, has_gnb = d.gnb_x != nullptr;
     const bool one_operand = !(has_res && d.aux) && !(has_gnb && (has_res || d.aux));
     return !d.f32 && !d.a_is_f32 && a_ok && d.K % (FIT_BK * ks) == 0 && epi_ok && stats_ok && one_operand && d.M >= 1 &&
            (unsigned long long)d.N * d.ldb < (1ull << 31);

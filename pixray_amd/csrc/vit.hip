@@ -283,7 +283,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
         {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
             d.bias_n = y.bo; d.ldr = ldt;
-            if (lean) { d.resid16 = y.x_in; d.out_bf16 = y.x_mid; d.ldc_bf16 = ldt; }
+            if (lean) { d.resid = (const float*)y.x_in; d.row16 = 1; d.out_bf16 = y.x_mid; d.ldc_bf16 = ldt; }
             else { d.resid = (const float*)y.x_in; d.out_f32 = (float*)y.x_mid; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
         if ((r = ln_op(v, y.x_mid, ldt, y.ln2_g, y.ln2_b, v->h, y.mean2, y.rstd2, rows, s))) return r;
@@ -292,7 +292,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
             if ((r = vit_gemm(v, d, s))) return r; }
         {   GemmDesc d; d.A = v->u; d.lda = 4 * W; d.B = y.W2; d.ldb = 4 * W; d.M = rows; d.N = W; d.K = 4 * W;
             d.bias_n = y.b2; d.ldr = ldt;
-            if (lean) { d.resid16 = y.x_mid; d.out_bf16 = x_next; d.ldc_bf16 = ldt; }
+            if (lean) { d.resid = (const float*)y.x_mid; d.row16 = 1; d.out_bf16 = x_next; d.ldc_bf16 = ldt; }
             else { d.resid = (const float*)y.x_mid; d.out_f32 = (float*)x_next; d.ldc_f32 = ldt; }
             if ((r = vit_gemm(v, d, s))) return r; }
     }

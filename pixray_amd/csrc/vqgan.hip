@@ -394,7 +394,8 @@ static void out_stream(const PrxVqgan* v, GemmDesc& d, void* stream, int ld, voi
 static void resid_stream(const PrxVqgan* v, GemmDesc& d, const void* r, int ld) {
     if (!r) return;
     d.ldr = ld;
-    if (v->lean) d.resid16 = r; else d.resid = (const float*)r;
+    d.resid = (const float*)r;
+    if (v->lean) d.row16 |= 1;
 }
 // `f32_out`: `out` is an fp32 buffer in every layout (the image head's input), not a stream
 static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int rh, int rw, bool up, const void* resid,
@@ -414,7 +415,8 @@ static int conv3_fwd(PrxVqgan* v, const Conv3& c, const void* x, bool x_f32, int
 static void set_gnb(const PrxVqgan* v, GemmDesc& d, const GN* gnb, const void* gnb_x, int swish) {
     if (!gnb || !fusable(v, gnb->C) || d.N != gnb->C) return;
     d.gn_stats = gnb->bstats; d.gn_gs = gnb->C / 32;
-    if (v->lean) d.gnb_x16 = gnb_x; else d.gnb_x = (const float*)gnb_x;
+    d.gnb_x = (const float*)gnb_x;
+    if (v->lean) d.row16 |= 2;
     d.gnb_fstats = gnb->stats; d.gnb_gamma = gnb->g; d.gnb_beta = gnb->b; d.gnb_swish = swish; d.gnb_eps = 1e-6f;
 }
 static int conv3_bwd(PrxVqgan* v, const Conv3& c, const void* dy, bool dy_f32, int rh, int rw, void* dx, hipStream_t s,

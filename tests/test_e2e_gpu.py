@@ -75,8 +75,12 @@ def test_headline_config_steps_teacher_forced_vs_oracle():
     trajectories of this chaotic loop cannot be compared), 5 steps to keep the CPU oracle's share short"""
     r = step_ref.compare_k_steps(5)
     print(r)
-    assert r["vq_index_agreement_min"] == 1.0
-    assert r["image_rel_l2_max"] < 2e-3, r             # the decoder alone (measured 3.5e-4 in the fp16 mode)
+    # identical z on both sides (teacher forced): the same codes, up to 2 of the 256 positions where two codes' distances tie to fp32
+    # rounding (the stand-alone nearest-code test's allowance; the oracle's z depends on the HIP image through the gradient, so
+    # which near-ties a run meets depends on the build)
+    assert r["vq_index_agreement_min"] >= 1.0 - 2.0 / 256
+    assert r["image_rel_l2_max"] < 1.5e-3, r           # the decoder alone (measured 4.4e-4 with fp32 streams, 6e-4 with the half-only streams)
+    print("independent-oracle dz (informational):", r["dz_rel_l2_independent_oracle"])
     assert r["dz_rel_l2_max"] < FAST_REL and r["dz_cosine_min"] > FAST_COS, r
     # one Adam(+clip_z) step from identical state: |dz| ~ lr, components whose gradient is ~0 can flip sign
     assert r["z_after_step_max_abs_err"] <= 2 * 0.2 + 1e-6
