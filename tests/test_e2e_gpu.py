@@ -79,7 +79,7 @@ def test_headline_config_steps_teacher_forced_vs_oracle():
     # rounding (the stand-alone nearest-code test's allowance; the oracle's z depends on the HIP image through the gradient, so
     # which near-ties a run meets depends on the build)
     assert r["vq_index_agreement_min"] >= 1.0 - 2.0 / 256
-    assert r["image_rel_l2_max"] < 1.5e-3, r           # the decoder alone (one iteration of the headline: 4.5e-4; was 2e-3 until round 5)
+    assert r["image_rel_l2_max"] < 1.5e-3, r           # the decoder alone (one iteration of the headline: 6.5e-4 with the half-only streams, profiles/r05_smoke_final.txt; the gate was 2e-3 until round 5)
     print("independent-oracle dz (informational):", r["dz_rel_l2_independent_oracle"])
     assert r["dz_rel_l2_max"] < FAST_REL and r["dz_cosine_min"] > FAST_COS, r
     # one Adam(+clip_z) step from identical state: |dz| ~ lr, components whose gradient is ~0 can flip sign
