@@ -257,6 +257,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
     zmin, zmax = vqgan_ref.z_bounds(vq_params)
     prompts = prompt_list(clip_model, clip_cfg, seed)
     dz_rel, dz_cos, z_err, idx_ok, loss_ref, loss_free, free_idx_ok, img_rel, dz_ind = [], [], [], [], [], [], [], [], []
+    vq_bad, vq_near = [], []
     seen = {}
     synth_and_filter = sess.do_synth_and_filter
 
@@ -306,6 +307,12 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         dz_own, = torch.autograd.grad(img_ref, z_ref, g_own)
         dz_ind.append(_metrics(dz_hip, dz_own)[0])
         idx_ok.append(float((idx_hip == idx_ref).float().mean()))
+        # integer work is exact: the HIP codes obey the float64 near-tie rule at the (teacher-forced, identical) z of this step --
+        # and so do the oracle's own fp32 codes, or the rule would be too tight to be a rule
+        x_flat = z_ref.detach().movedim(1, 3).reshape(-1, z_ref.shape[1])
+        bad_h, near_h, _ = vqgan_ref.vq_exactness(x_flat, vq_params["quantize.embedding.weight"], idx_hip)
+        bad_o, _, _ = vqgan_ref.vq_exactness(x_flat, vq_params["quantize.embedding.weight"], idx_ref)
+        vq_bad.append(bad_h + bad_o); vq_near.append(near_h)
         opt.step()
         with torch.no_grad():
             z_ref.copy_(vqgan_ref.clip_z(z_ref, zmin, zmax))
@@ -316,6 +323,7 @@ def compare_k_steps(k=10, vqgan_model="imagenet_f16_16384", clip_model="ViT-B/32
         free_idx_ok.append(float((free.drawer.handle.last_indices.cpu().long() == idx_ref).float().mean()))
     z_free = free.drawer.get_z().detach().cpu()
     return dict(steps=k, dz_rel_l2_max=max(dz_rel), dz_cosine_min=min(dz_cos), vq_index_agreement_min=min(idx_ok),
+                vq_exactness_violations=sum(vq_bad), vq_near_ties_per_step=vq_near,
                 image_rel_l2_max=max(img_rel), dz_rel_l2=dz_rel, dz_rel_l2_independent_oracle=dz_ind,
                 z_after_step_max_abs_err=max(z_err), loss_oracle=loss_ref, loss_hip_free_running=loss_free,
                 # the FREE-RUNNING copy against the oracle's trajectory ("z after 10 Adam steps"): only

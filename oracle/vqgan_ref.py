@@ -51,6 +51,23 @@ def vq_indices(x, codebook):
     return d.argmin(-1), d
 
 
+def vq_exactness(x, codebook, idx):
+    """The exactness rule of the nearest-code search (integer output, vqgan.py:60-64), stated without reference to any fp32
+    implementation: a position is a NEAR-TIE when its two smallest FLOAT64 distances differ by less than the fp32 rounding of
+    the distance expression ((|x|^2 + |c|^2) - 2 x.c formed in fp32: 8 ulp of the magnitude the sum is formed at).  Outside
+    that set `idx` must be the float64 argmin; inside it, it must be one of the tied codes.
+    Returns (violations, near_ties, differs_from_f64_argmin)."""
+    xd, cd, idx = x.double(), codebook.double(), idx.long()
+    d64 = (xd * xd).sum(1, keepdim=True) + (cd * cd).sum(1)[None] - 2.0 * xd @ cd.t()
+    best = d64.argmin(1)
+    top2 = d64.topk(2, dim=1, largest=False).values
+    tol = 8.0 * 2.0 ** -24 * ((xd * xd).sum(1) + (cd * cd).sum(1)[best])
+    near = (top2[:, 1] - top2[:, 0]) < tol
+    rows = torch.arange(x.shape[0])
+    ok = (idx == best) | (near & ((d64[rows, idx] - d64[rows, best]) < tol))
+    return int((~ok).sum()), int(near.sum()), int((idx != best).sum())
+
+
 class ClampWithGrad(torch.autograd.Function):  # vqgan.py:66-79
     @staticmethod
     def forward(ctx, input, min, max):

@@ -33,6 +33,9 @@
 #include <type_traits>
 #include <algorithm>
 #include <stdlib.h>
+#include <string>
+#include <string.h>
+#include <stdio.h>
 
 const bf16_t* prx_gemm_zero_page();       // gemm.hip: 256 bytes of zeros on the current device
 
@@ -45,6 +48,19 @@ typedef const __attribute__((address_space(1))) void* fit_gptr;
 typedef __attribute__((address_space(3))) void* fit_lptr;
 
 __device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+
+// Diagnostic build only (-DPRX_FIT_TRACE, tools/fit_trace.py): every wave keeps s_memtime stamps of its phases in scalar
+// registers and writes them to the caller's workspace at the very end ([workgroup][wave][8] 64-bit ticks): 0 entry, 1 DMA
+// coordinates ready, 2 first stage landed, 3 K loop done, 4 K groups summed, 5 epilogue issued, 6 its stores acknowledged.
+#ifdef PRX_FIT_TRACE
+#define FIT_TRACE_ARG , unsigned long long (&tr)[8]
+#define FIT_TRACE_PASS , tr
+#define FIT_TRACE(slot) do { tr[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FIT_TRACE_ARG
+#define FIT_TRACE_PASS
+#define FIT_TRACE(slot) do {} while (0)
+#endif
 
 template <typename T16>
 __device__ __forceinline__ f32x4 fit_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
@@ -82,7 +98,7 @@ constexpr int fit_scratch_floats() {
 }
 template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
 __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
-                                           int wt, int wm, int wn, int lane) {
+                                           int wt, int wm, int wn, int lane FIT_TRACE_ARG) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
     constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN, TN = 16 * FN;
     const GemmDesc& d = p.d;
@@ -113,6 +129,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
         }
     }
 
+    FIT_TRACE(4);
     // ---- epilogue: per wave, one 16-row slab at a time through a private LDS slab; 8 consecutive columns per lane, so the
     // 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
     // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual, aux or GroupNorm-input rows, bias) is
@@ -242,6 +259,7 @@ __device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f
             /*hipemu:wave_sync*/                    // every lane has read the slab before the next one is written over it
         }
     }
+    FIT_TRACE(5);
     // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot
     // each summed in a fixed order, then one fp64 atomic per group and moment (the only order-dependent step, ~1e-16 relative)
     if (do_stats) {
@@ -296,6 +314,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     const int wt = wave - kg * NWT;
     const int wm = wt / WGN, wn = wt - wm * WGN;
 
+#ifdef PRX_FIT_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();      // the constant 100 MHz clock, to calibrate the stamps' tick
+#endif
+    FIT_TRACE(0);
     int bid = blockIdx.x;
     if (p.xcd_swizzle) bid = (int)xcd_linear(bid, gridDim.x);
     // tile order: consecutive tiles (an XCD owns a contiguous range of them) share their A row panel (row-major order) or, for
@@ -448,6 +471,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // the same counted wait in front of barrier T + 2.
     const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
     const bool late = (p.fit_flags & 1) && wave >= NW / 2;
+    FIT_TRACE(1);
     if (0 < nk) issue(0, 0);
     if (1 < nk) issue(1, 1);
 #define FIT_STEP(T, ST)                                                                                                 \
@@ -455,6 +479,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         if ((T) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");                                    \
         else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
         __builtin_amdgcn_s_barrier();       /* stage T landed for every wave; everyone is done reading stage T - 1 */   \
+        if ((T) == 0) FIT_TRACE(2);                                                                                     \
         if (!late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                      \
         compute(ST);                                                                                                    \
         if (late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                       \
@@ -464,6 +489,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     if (t < nk) { FIT_STEP(t, 0); ++t; }
     if (t < nk) { FIT_STEP(t, 1); ++t; }
 #undef FIT_STEP
+    FIT_TRACE(3);
     __builtin_amdgcn_s_barrier();           // the ring is dead: LDS is reused below
 
     if (p.fit_flags & 4) {                  // bit 2 (timing experiments only): no epilogue -- keep the accumulators alive
@@ -474,7 +500,29 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         return;
     }
     static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
+#ifdef PRX_FIT_TRACE
+    // experiment (PRX_FIT_TRACE_REP=1, KS == 1 tiles): the epilogue a second time from the SAME code addresses -- the first pass
+    // runs it from a cold instruction cache, the second from a warm one; the second pass's stamps replace slots 1 (begin) and 2 (end)
+    const int nrep = (KS == 1 && (p.fit_flags & 64)) ? 2 : 1;
+    for (int rep = 0; rep < nrep; ++rep) {
+        if (rep) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[1] = __builtin_amdgcn_s_memtime(); }
+        fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane FIT_TRACE_PASS);
+        if (rep) { tr[2] = tr[5]; }
+        else if (nrep > 1) { tr[3] = tr[4]; tr[7] = tr[5]; }
+    }
+    if (nrep > 1) { const unsigned long long b2 = tr[1], e2 = tr[2]; tr[4] = tr[3]; tr[5] = tr[7]; tr[1] = b2; tr[2] = e2; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FIT_TRACE(6);
+    if (p.ws && lane < 8) {
+        unsigned long long v = tr[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v = lane == i ? tr[i] : v;
+        if (lane == 7) v = ((__builtin_amdgcn_s_memrealtime() - tr_real0) << 32) | (unsigned)bid;   // wave lifetime in 10 ns ticks, tile index
+        reinterpret_cast<unsigned long long*>(p.ws)[((size_t)blockIdx.x * NW + wave) * 8 + lane] = v;
+    }
+#else
     fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
+#endif
 }
 
 template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
@@ -571,9 +619,44 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
     for (const FitTile& t : kFitTiles)
         if (t.bn >= 32) consider(t.bm, t.bn, t.eff);
 }
-int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s) {
+#ifdef PRX_FIT_TRACE
+// diagnostic build: between prx_fit_trace_begin(buffer) and prx_fit_trace_end every fit launch writes its waves' phase stamps
+// to its own slice of the buffer (instead of the caller's workspace); the host keeps one text record per launch
+namespace {
+unsigned long long* g_trace_buf = nullptr;
+size_t g_trace_cap = 0, g_trace_used = 0;
+std::string g_trace_log;
+}
+extern "C" void prx_fit_trace_begin(void* buf, size_t bytes) { g_trace_buf = (unsigned long long*)buf; g_trace_cap = bytes / 8; g_trace_used = 0; g_trace_log.clear(); }
+extern "C" long long prx_fit_trace_end(char* out, size_t cap) {
+    g_trace_buf = nullptr;
+    if (out && cap) { size_t n = std::min(cap - 1, g_trace_log.size()); memcpy(out, g_trace_log.data(), n); out[n] = 0; }
+    return (long long)g_trace_log.size();
+}
+#endif
+int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a_in, int bm, int bn, dim3 grid, hipStream_t s) {
     const bf16_t* zp = prx_gemm_zero_page();
     PRX_REQUIRE(zp != nullptr, "gemm: could not allocate the zero page");
+#ifdef PRX_FIT_TRACE
+    prx_gemm_dev::GemmArgs a = a_in;
+    if (g_trace_buf) {
+        const size_t need = (size_t)grid.x * 8 * 8;
+        if (g_trace_used + need <= g_trace_cap) {
+            a.ws = reinterpret_cast<float*>(g_trace_buf + g_trace_used);
+            char line[256];
+            const GemmDesc& d = a.d;
+            snprintf(line, sizeof line, "%zu %u %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", g_trace_used, grid.x, bm, bn, d.M, d.N, d.K, d.a_mode, d.up, d.act,
+                     (int)(d.out_f32 != nullptr), (int)(d.out_bf16 != nullptr) + (int)(d.out_bf16_pre != nullptr), (int)(d.resid != nullptr) + 2 * (int)(d.aux != nullptr),
+                     (int)(d.gn_stats != nullptr) + 2 * (int)(d.gnb_x != nullptr), (int)d.row16, a.fit_flags);
+            g_trace_log += line;
+            g_trace_used += need;
+        } else a.ws = nullptr;
+    } else a.ws = nullptr;
+    static const int trace_rep = getenv("PRX_FIT_TRACE_REP") ? atoi(getenv("PRX_FIT_TRACE_REP")) : 0;
+    if (trace_rep) a.fit_flags |= 64;
+#else
+    const prx_gemm_dev::GemmArgs& a = a_in;
+#endif
     if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1, false>(a, grid, s, zp);
     else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);
