@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PRX_ABI_VERSION 2
+#define PRX_ABI_VERSION 3   /* 3: prx_gemm_args.row16; prx_prompt_loss_fwd_bwd(loss, ticket); 36-word cutout descriptors */
 
 typedef void* prx_stream_t; /* hipStream_t */
 
@@ -102,6 +102,8 @@ typedef struct prx_gemm_args {
     void* out_bf16; void* out_bf16_pre; int ldc_bf16;
     int f32;            /* operand precision, PRX_PREC_*: _F32 = A, B, aux, out_bf16, out_bf16_pre are all fp32 and the product is
                          * exact f32; _F16 = the 16-bit operands are IEEE half; _BF16 (0) = bf16 */
+    int row16;          /* 16-bit operand modes: bit 0 = `resid` addresses a 16-bit stream in the operand format (the runners' lean
+                         * layout: residual / feature-map streams kept in 16 bits), bit 1 = so does prx_k_gemm_gn's `gnb_x` */
     prx_gemm_ctx* ctx;  /* tuning / timing context or NULL (built-in heuristics) */
 } prx_gemm_args;
 int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream);
@@ -113,6 +115,10 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
 int prx_k_gemm_gn(const prx_gemm_args* g, double* gn_stats, int gn_gs, const float* gnb_x, const double* gnb_fstats,
                   const float* gnb_gamma, const float* gnb_beta, int gnb_swish, float gnb_eps, void* ws, size_t ws_bytes,
                   prx_stream_t stream);
+/* Diagnostics: how many launches of this process ran a fit kernel whose epilogue is specialised at compile time (csrc/gemmfit_kernel.h
+ * FIT_EPI_*: the descriptor patterns of the two runners, IEEE-half operands) -- tests use it to know that the specialised kernel,
+ * not the generic one, produced what they compare. */
+long long prx_gemm_fit_spec_launches(void);
 
 /* taming `Normalize` = GroupNorm(32, C, eps 1e-6) (+ swish `nonlinearity`) on an NHWC fp32
  * tensor x[NB][P][C]  [UPSTREAM taming/modules/diffusionmodules/model.py; call site vqgan.py:195].

@@ -36,7 +36,7 @@ class GemmArgs(ctypes.Structure):
         ("act", ctypes.c_int),
         ("out_f32", ctypes.c_void_p), ("ldc_f32", ctypes.c_int),
         ("out_bf16", ctypes.c_void_p), ("out_bf16_pre", ctypes.c_void_p), ("ldc_bf16", ctypes.c_int),
-        ("f32", ctypes.c_int), ("ctx", ctypes.c_void_p),
+        ("f32", ctypes.c_int), ("row16", ctypes.c_int), ("ctx", ctypes.c_void_p),
     ]
 
     def __init__(self, *a, **k):

@@ -65,6 +65,7 @@ static int desc_of(const prx_gemm_args* g, GemmDesc& d) {
     d.out_f32 = g->out_f32; d.ldc_f32 = g->ldc_f32;
     d.out_bf16 = g->out_bf16; d.out_bf16_pre = g->out_bf16_pre;
     d.ldc_bf16 = g->ldc_bf16;
+    d.row16 = (short)(g->row16 & 3);
     return 0;
 }
 int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t stream_) {

@@ -11,7 +11,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits, kt_per_split, kt_total;
     int vec_epi;   // 1: epilogue may use 4-wide vector accesses (alignment verified on the host)
     int xcd_swizzle;
-    int fit_flags;   // gemmfit.hip: bit 0 = staggered wave groups; bits 2, 3 = timing experiments (no epilogue / no main loop); bit 4 = column-major tile order
+    int fit_flags;   // gemmfit.hip: bit 0 = staggered wave groups; bits 2, 3 = timing experiments (no epilogue / no main loop); bit 4 = column-major tile order; bit 6 = generic (run-time) epilogue only
     float* ws;
 };
 

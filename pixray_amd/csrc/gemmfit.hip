@@ -1,545 +1,10 @@
-// "Fit-tile" member of the GEMM engine (gemm.h): 16-bit operands, tiles whose COUNT matches the chip (one workgroup per CU),
-// row-major products and implicit 3x3 convolutions.
-//
-// Why: the hot products of the headline iteration are small.  The ViT-B/32 tower at 64 cutouts is M = 64 * 50 = 3200 token
-// rows; the VQGAN decoder is batch 1, M = 256 ... 65 536 pixels by N = 128 ... 512 channels.  With the power-of-two tiles of
-// gemm.hip such a product has 150 / 300 / 600 tiles for 256 CUs, or 8 - 64 tiles that need split-K across workgroups plus a
-// reduce launch: either 40 % of the chip idles, or a second mostly empty round runs, or partial sums make a round trip through
-// HBM; and the small tiles that do fill the chip move twice the L2->LDS bytes per flop (64 B/clk/CU on that path).  Here the
-// tile is chosen so that the grid is ~240 - 256 workgroups, and when that makes the tile small the K loop is split over the
-// wave groups of ONE workgroup (KS) and summed through LDS -- no workspace, no second launch:
-//     ViT-B/32, M = 3200:  N = 3072 -> 160 x 256 (240 tiles)   N = 2304 -> 160 x 192 (240)   N = 768 -> 80 x 128, KS 2 (240)
-//     decoder 256^2 level: 65 536 x 128 -> 256 x 128 (256)      128^2: 128 x 128 / 128 x 64 KS 2     64^2: 64 x 64 KS 2
-//                  32^2:   32 x 64 KS 4 / 16 x 64 KS 4           16^2:  256 x 512 x 4608 -> 16 x 32, KS 8 (256 tiles)
-// The same tiles fit the sharded batches (32 / 16 / 8 cutouts: M = 1600 / 800 / 400 are multiples of 80).
-//
-// Structure: 8 waves (two per SIMD), 16x16x32 MFMAs, wave tile (16 FM) x (16 FN).  Operands HBM -> LDS by
-// global_load_lds_dwordx4 into a 3-deep ring of stages (a stage = KS consecutive K tiles of BK = 64, one per wave group) with
-// counted s_waitcnt vmcnt and one raw s_barrier per stage: two stages of DMA stay in flight across the barrier.  The two halves
-// of the workgroup issue their DMA at opposite ends of a stage (staggered wave groups, see the main loop).  Swizzle as in
-// gemm.hip (LDS chunk c of row r holds source chunk c ^ ((r >> 1) & 7), applied on the DMA source address and on the fragment
-// read; conflict-free for the 16x16x32 operand layout too).  Rows >= M / columns >= N are clamped on the source side (row-major)
-// or read the zero page (convolution: as its padding does).  Implicit convolution (CONV): Cin % 64 == 0, so a K tile lies inside
-// ONE filter tap, which is wave-uniform per DMA piece; the per-lane gather address is row term[ky] + column term[kx] from six
-// values computed once (gemm.hip's C64 scheme), optionally through the fused nearest-2x upsample.
-// Epilogue: the engine's (gemm_epi.h) on 8 consecutive columns per lane, staged per wave through LDS, 16-byte accesses, its HBM
-// reads prefetched; the next GroupNorm's sums or a GroupNorm-backward's sums (GemmDesc::gn_stats / gnb_*) in a fixed summation
-// order up to the final fp64 atomics.
-//
-// Requirements (prx_gemmfit_eligible): 16-bit A (row-major, or NHWC with Cin % 64 == 0 and up in {0, 1}), K % (64 KS) == 0,
-// N % 8 == 0 with 16-byte-friendly epilogue operands, at most one of {residual, aux, GroupNorm-backward input} (so not
-// PRX_ACT_RELUMASK_POST, which reads a residual and a mask), no split-K across workgroups.
-#include "gemm_epi.h"
-#include <type_traits>
-#include <algorithm>
-#include <stdlib.h>
-#include <string>
-#include <string.h>
-#include <stdio.h>
-
-const bf16_t* prx_gemm_zero_page();       // gemm.hip: 256 bytes of zeros on the current device
+// Fit-tile member of the GEMM engine: host side (tile table, eligibility, planner, launch dispatch) and the GENERIC kernels --
+// every tile shape with the engine's run-time epilogue, both 16-bit operand formats.  The device code lives in gemmfit_kernel.h;
+// the kernels whose epilogue is specialised at compile time are instantiated in gemmfit_spec_*.hip.
+#include "gemmfit_kernel.h"
+#include <atomic>
 
 namespace {
-using namespace prx_gemm_dev;
-
-constexpr int FIT_BK = 64;
-constexpr int FIT_STAGES = 3;
-typedef const __attribute__((address_space(1))) void* fit_gptr;
-typedef __attribute__((address_space(3))) void* fit_lptr;
-
-__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
-
-// Diagnostic build only (-DPRX_FIT_TRACE, tools/fit_trace.py): every wave keeps s_memtime stamps of its phases in scalar
-// registers and writes them to the caller's workspace at the very end ([workgroup][wave][8] 64-bit ticks): 0 entry, 1 DMA
-// coordinates ready, 2 first stage landed, 3 K loop done, 4 K groups summed, 5 epilogue issued, 6 its stores acknowledged.
-#ifdef PRX_FIT_TRACE
-#define FIT_TRACE_ARG , unsigned long long (&tr)[8]
-#define FIT_TRACE_PASS , tr
-#define FIT_TRACE(slot) do { tr[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FIT_TRACE_ARG
-#define FIT_TRACE_PASS
-#define FIT_TRACE(slot) do {} while (0)
-#endif
-
-template <typename T16>
-__device__ __forceinline__ f32x4 fit_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
-    if constexpr (std::is_same<T16, half_t>::value)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-
-// GroupNorm-backward sums on prefetched x (gemm_epi.h gnb_accum with the load taken out)
-__device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst& c, const float4& x, const float4& o, float& s0, float& s1) {
-    const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
-    const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float xh = (xv[i] - c.mean) * c.rstd;
-        float gy = gv[i];
-        if (d.gnb_swish) {
-            const float y = xh * gav[i] + bev[i];
-            const float sg = sigmoidf_(y);
-            gy *= sg * (1.f + y * (1.f - sg));
-        }
-        const float dxh = gy * gav[i];
-        s0 += dxh;
-        s1 += dxh * xh;
-    }
-}
-
-// The part of a fit kernel behind its K loop, shared by the ring kernel and the streaming kernel: the K groups' partial sums
-// through LDS, then the engine's epilogue.  `fl`: the workgroup's LDS as floats (fit_scratch_floats<...>() of them), free of
-// any other use; every wave of the workgroup calls this.
-template <int WGM, int WGN, int FM, int FN, int KS>
-constexpr int fit_scratch_floats() {
-    return (KS > 1 ? WGM * WGN * KS * FM * FN * 256 : 0) + WGM * WGN * KS * 16 * (16 * FN + 4) + KS * WGM * (16 * FN * WGN / 2);
-}
-template <int WGM, int WGN, int FM, int FN, int KS, typename T16>
-__device__ __forceinline__ void fit_finish(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
-                                           int wt, int wm, int wn, int lane FIT_TRACE_ARG) {
-    constexpr int NWT = WGM * WGN, NW = NWT * KS;
-    constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN, TN = 16 * FN;
-    const GemmDesc& d = p.d;
-    const int tid = threadIdx.x;
-    const int l15 = lane & 15, kq = lane >> 4;
-    // ---- K groups: every wave dumps the 16-row slabs it does not OWN (slab i belongs to group i % KS); the owner adds the
-    // other groups' partials in group order.  One barrier, no workspace, a fixed summation order.
-    constexpr int DUMP = KS > 1 ? NW * FM * FN * 256 : 0;          // floats
-    if constexpr (KS > 1) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            if (i % KS == kg) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                *reinterpret_cast<f32x4*>(fl + ((kg * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4) = acc[i][j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            if (i % KS != kg) continue;
-#pragma unroll
-            for (int g = 0; g < KS; ++g) {
-                if (g == kg) continue;
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] += *reinterpret_cast<const f32x4*>(fl + ((g * NWT + wt) * FM * FN + i * FN + j) * 256 + lane * 4);
-            }
-        }
-    }
-
-    FIT_TRACE(4);
-    // ---- epilogue: per wave, one 16-row slab at a time through a private LDS slab; 8 consecutive columns per lane, so the
-    // 16-bit outputs leave as 16-byte stores (the store tail of a one-round kernel is bound by store INSTRUCTIONS:
-    // cdna_hip_programming.md T21).  Everything the epilogue READS from HBM (residual, aux or GroupNorm-input rows, bias) is
-    // fetched for the whole wave tile BEFORE the first store: the compiler cannot move a load above an earlier store that may
-    // alias it, and with one workgroup per CU nothing else hides a chain of dependent load round trips.
-    typedef __attribute__((ext_vector_type(8))) T16 t16x8;
-    constexpr int LDW = TN + 4;                 // padded row (floats), rows stay 16-byte aligned
-    constexpr int LPR = TN / 8;                 // lanes per row
-    constexpr int RPP = 64 / LPR;               // rows per pass
-    constexpr int NPASS = (16 + RPP - 1) / RPP;
-    float* const stage = fl + DUMP + wave * (16 * LDW);
-    const int rbase = tm * BM + wm * (16 * FM), cbase = tn * BN + wn * TN;
-    const int lr0 = lane / LPR, lc = (lane - lr0 * LPR) * 8;
-    const int col = cbase + lc;
-    const bool col_ok = lane < RPP * LPR && col < d.N;        // N % 8 == 0: a lane's 8 columns are in range together
-    const int act = d.act;
-    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
-    const bool has_resid = d.resid != nullptr;
-    const bool row16 = has_resid ? (d.row16 & 1) != 0 : (d.row16 & 2) != 0;      // the row operand (residual / GroupNorm input) is a 16-bit stream
-    const bool need_aux = act == PRX_ACT_MUL_DQUICKGELU || act == PRX_ACT_MUL_RELUMASK || act == PRX_ACT_RELUMASK_POST;
-    // the 80-row-granular tiles are the token-batch (ViT tower) tiles: no GroupNorm there, and their epilogue is compiled without the
-    // statistics code (the fit kernels' epilogues are sensitive to every register and branch: profiles/r05_ln_fold/)
-    constexpr bool STATS = BM % 80 != 0;
-    const bool do_stats = STATS && d.gn_stats != nullptr;
-    const bool gnb = do_stats && d.gnb_x != nullptr;
-    float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
-    if (d.bias_n && col_ok) {
-        bias0 = *reinterpret_cast<const float4*>(d.bias_n + col);
-        bias1 = *reinterpret_cast<const float4*>(d.bias_n + col + 4);
-    }
-    GnbConst gc0{}, gc1{};
-    if (gnb && col_ok) { gc0 = gnb_load(d, col); gc1 = gnb_load(d, col + 4); }
-    // slabs are handled FMC at a time: the prefetch of a chunk is (2 x 16 bytes + 1) registers per slab and pass on top of the
-    // accumulators, and the wide wave tiles (16+ fragments) have no room for all of them at once
-    constexpr int FMC = FM * FN > 16 ? 3 : FM;
-    float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;    // GroupNorm sums of this lane's two column quads
-#pragma unroll
-    for (int i0 = 0; i0 < FM; i0 += FMC) {
-        uint4 pf[FMC][NPASS][2];                // residual / GroupNorm input (2 x 16 bytes) or aux (16 bytes) of this lane's 8 columns
-        float pbm[FMC][NPASS];
-#pragma unroll
-        for (int ic = 0; ic < FMC; ++ic) {
-            const int i = i0 + ic;
-            const bool keep = i < FM && (KS == 1 || i % KS == kg);
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
-                const bool ok = keep && col_ok && lr < 16 && row < d.M;
-                pf[ic][ps][0] = pf[ic][ps][1] = uint4{0u, 0u, 0u, 0u};
-                pbm[ic][ps] = 0.f;
-                if (ok) {
-                    if (row16) {            // 8 columns = one 16-byte load; widened to fp32 in place below
-                        const T16* r_ = has_resid ? reinterpret_cast<const T16*>(d.resid) + (size_t)row * d.ldr + col
-                                                  : reinterpret_cast<const T16*>(d.gnb_x) + (size_t)row * d.N + col;
-                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
-                    } else if (has_resid || gnb) {
-                        const float* r_ = has_resid ? d.resid + (size_t)row * d.ldr + col : d.gnb_x + (size_t)row * d.N + col;
-                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(r_);
-                        pf[ic][ps][1] = *reinterpret_cast<const uint4*>(r_ + 4);
-                    } else if (need_aux) {
-                        pf[ic][ps][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T16*>(d.aux) + (size_t)row * d.ldaux + col);
-                    }
-                    if (d.bias_m) pbm[ic][ps] = d.bias_m[row];
-                }
-            }
-        }
-#pragma unroll
-        for (int ic = 0; ic < FMC; ++ic) {
-            const int i = i0 + ic;
-            if (i >= FM) continue;
-            if (KS > 1 && i % KS != kg) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) stage[(4 * kq + r) * LDW + j * 16 + l15] = acc[i][j][r];
-            /*hipemu:wave_sync*/                    // the slab is exchanged between the lanes of ONE wave, which runs in lockstep (the CPU emulation of tools/hipemu synchronises its fibers at these markers)
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
-                if (!(col_ok && lr < 16 && row < d.M)) continue;
-                float4 v0 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc]);
-                float4 v1 = *reinterpret_cast<const float4*>(&stage[lr * LDW + lc + 4]);
-                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, p0, p1;
-                if (row16) {
-                    const t16x8 rx = __builtin_bit_cast(t16x8, pf[ic][ps][0]);
-                    pf[ic][ps][0] = __builtin_bit_cast(uint4, make_float4((float)rx[0], (float)rx[1], (float)rx[2], (float)rx[3]));
-                    pf[ic][ps][1] = __builtin_bit_cast(uint4, make_float4((float)rx[4], (float)rx[5], (float)rx[6], (float)rx[7]));
-                }
-                if (has_resid) {
-                    r0 = __builtin_bit_cast(float4, pf[ic][ps][0]);
-                    r1 = __builtin_bit_cast(float4, pf[ic][ps][1]);
-                } else if (need_aux) {
-                    const t16x8 ax = __builtin_bit_cast(t16x8, pf[ic][ps][0]);
-                    a0[0] = (float)ax[0]; a0[1] = (float)ax[1]; a0[2] = (float)ax[2]; a0[3] = (float)ax[3];
-                    a1[0] = (float)ax[4]; a1[1] = (float)ax[5]; a1[2] = (float)ax[6]; a1[3] = (float)ax[7];
-                }
-                v0 = epilogue_math4<T16>(act, alpha, v0, bias0, pbm[ic][ps], a0, has_resid, r0, p0);
-                v1 = epilogue_math4<T16>(act, alpha, v1, bias1, pbm[ic][ps], a1, has_resid, r1, p1);
-                if (act == PRX_ACT_QUICKGELU && d.out_bf16_pre) {
-                    t16x8 q;
-                    q[0] = op_cvt<T16>(p0.x); q[1] = op_cvt<T16>(p0.y); q[2] = op_cvt<T16>(p0.z); q[3] = op_cvt<T16>(p0.w);
-                    q[4] = op_cvt<T16>(p1.x); q[5] = op_cvt<T16>(p1.y); q[6] = op_cvt<T16>(p1.z); q[7] = op_cvt<T16>(p1.w);
-                    *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16_pre) + (size_t)row * d.ldc_bf16 + col) = q;
-                }
-                if (d.out_f32) {
-                    float* o = d.out_f32 + (size_t)row * d.ldc_f32 + col;
-                    *reinterpret_cast<float4*>(o) = v0;
-                    *reinterpret_cast<float4*>(o + 4) = v1;
-                }
-                if (d.out_bf16) {
-                    t16x8 q;
-                    q[0] = op_cvt<T16>(v0.x); q[1] = op_cvt<T16>(v0.y); q[2] = op_cvt<T16>(v0.z); q[3] = op_cvt<T16>(v0.w);
-                    q[4] = op_cvt<T16>(v1.x); q[5] = op_cvt<T16>(v1.y); q[6] = op_cvt<T16>(v1.z); q[7] = op_cvt<T16>(v1.w);
-                    *reinterpret_cast<t16x8*>(reinterpret_cast<T16*>(d.out_bf16) + (size_t)row * d.ldc_bf16 + col) = q;
-                }
-                if (gnb) {
-                    fit_gnb_accum(d, gc0, __builtin_bit_cast(float4, pf[ic][ps][0]), v0, gsa0, gsa1);
-                    fit_gnb_accum(d, gc1, __builtin_bit_cast(float4, pf[ic][ps][1]), v1, gsb0, gsb1);
-                } else if (do_stats) {
-                    gsa0 += (v0.x + v0.y) + (v0.z + v0.w);
-                    gsa1 += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w);
-                    gsb0 += (v1.x + v1.y) + (v1.z + v1.w);
-                    gsb1 += (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
-                }
-            }
-            /*hipemu:wave_sync*/                    // every lane has read the slab before the next one is written over it
-        }
-    }
-    FIT_TRACE(5);
-    // ---- GroupNorm sums: lanes of one column quad by a fixed butterfly, the waves that share the columns through one LDS slot
-    // each summed in a fixed order, then one fp64 atomic per group and moment (the only order-dependent step, ~1e-16 relative)
-    if (do_stats) {
-        if constexpr ((LPR & (LPR - 1)) == 0) {
-            float* const gpart = fl + DUMP + NW * (16 * LDW);          // [KS * WGM][BN / 4 quads][2]
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) {
-                gsa0 += __shfl_xor(gsa0, o, 64); gsa1 += __shfl_xor(gsa1, o, 64);
-                gsb0 += __shfl_xor(gsb0, o, 64); gsb1 += __shfl_xor(gsb1, o, 64);
-            }
-            if (lane < LPR) {
-                float* const w_ = gpart + ((kg * WGM + wm) * (BN / 4) + wn * (TN / 4) + lane * 2) * 2;
-                w_[0] = gsa0; w_[1] = gsa1; w_[2] = gsb0; w_[3] = gsb1;
-            }
-            __syncthreads();
-            const int qpg = d.gn_gs >> 2;                  // quads per group
-            const int ngrp = BN / d.gn_gs;                 // groups covered by this block tile
-            if (tid < ngrp * 2) {
-                const int gl = tid >> 1, mom = tid & 1;
-                const int gcol = tn * BN + gl * d.gn_gs;
-                if (gcol < d.N) {
-                    double a2 = 0.0;
-                    for (int w2 = 0; w2 < KS * WGM; ++w2)
-                        for (int q = 0; q < qpg; ++q) a2 += (double)gpart[(w2 * (BN / 4) + gl * qpg + q) * 2 + mom];
-                    atomicAdd(&d.gn_stats[(size_t)(gcol / d.gn_gs) * 2 + mom], a2);
-                }
-            }
-        }
-    }
-}
-
-// WGM x WGN waves per K group, KS K groups; wave tile (16 FM) x (16 FN); block tile BM x BN = (16 FM WGM) x (16 FN WGN).
-template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16>
-__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
-    constexpr int NWT = WGM * WGN, NW = NWT * KS;
-    constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN;
-    constexpr int SUB = (BM + BN) * FIT_BK;              // elements of one K tile (A rows, then B rows)
-    constexpr int STAGE = KS * SUB;                      // elements of one ring stage
-    constexpr int NA = BM / 8, NB = BN / 8, NPS = NA + NB, NP = KS * NPS;   // DMA pieces (8 rows x 128 B) per stage
-    constexpr int PW = (NP + NW - 1) / NW;               // pieces per wave per stage (the last ones may be duplicates)
-    constexpr int TN = 16 * FN;
-    static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole DMA pieces");
-    static_assert(FIT_STAGES * STAGE * 2 <= 160 * 1024, "ring exceeds the LDS");
-    static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
-
-    __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the only __shared__ object
-
-    const GemmDesc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave / NWT;                           // K group of this wave
-    const int wt = wave - kg * NWT;
-    const int wm = wt / WGN, wn = wt - wm * WGN;
-
-#ifdef PRX_FIT_TRACE
-    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();      // the constant 100 MHz clock, to calibrate the stamps' tick
-#endif
-    FIT_TRACE(0);
-    int bid = blockIdx.x;
-    if (p.xcd_swizzle) bid = (int)xcd_linear(bid, gridDim.x);
-    // tile order: consecutive tiles (an XCD owns a contiguous range of them) share their A row panel (row-major order) or, for
-    // weight-heavy problems (N > M: the decoder's 16^2 / 32^2 convolutions), their B column panel (bit 4: column-major order),
-    // so that the larger operand is fetched into ONE L2 instead of all eight
-    int tm, tn;
-    if (p.fit_flags & 16) { tn = bid / p.tiles_m; tm = bid - tn * p.tiles_m; }
-    else                  { tm = bid / p.tiles_n; tn = bid - tm * p.tiles_n; }
-
-    // K is cut into KS contiguous ranges, one per K group (group g: K tiles [g nkg, (g + 1) nkg)): consecutive stages of a group
-    // walk consecutive K tiles, so an implicit convolution changes its tap only every Cin / 64 stages
-    const int nkg = p.kt_total / KS;
-    // ---- DMA coordinates: slot j of wave w moves piece min(w + NW j, NP - 1) of every stage ----------------------------
-    const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
-    const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
-    const int lrow = lane >> 3, cpos = lane & 7;
-    unsigned voff[PW];                                    // per-lane ELEMENT offset from the operand base at K tile 0 (conv A: the chunk only)
-    int pieceA[PW], pieceOff[PW];                         // wave-uniform: operand select, LDS element offset inside a stage
-    // implicit convolution, per lane and slot: source row term of the centre tap (c_r1) and the two row deltas packed as 16-bit halves
-    // (c_rd: tap row 0 low, tap row 2 high), source column of the centre tap (c_c1), and one word of flags (c_ok): bit ky / bit 3 + kx =
-    // tap row / column inside the image, bit 6 = the left tap's source column is one less, bit 7 = the right tap's is one more
-    // (with the fused nearest-2x upsample neighbouring taps can share a source column)
-    int c_r1[CONV ? PW : 1], c_rd[CONV ? PW : 1], c_c1[CONV ? PW : 1], c_ok[CONV ? PW : 1];
-    int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
-    int s_cur[CONV ? PW : 1];                             // wave-uniform: the tap c_off was computed for (-1: none yet)
-    int c_off[CONV ? PW : 1];                             // per lane: element offset of the tap's source pixel + the lane's chunk, < 0: padding
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        int pc = wave + NW * j;
-        pc = pc < NP ? pc : NP - 1;
-        const int sub = pc / NPS, q = pc - sub * NPS;
-        const bool isA = q < NA;
-        const int r = (isA ? q : q - NA) * 8 + lrow;      // row inside the A (B) tile
-        const int chunk = cpos ^ ((r >> 1) & 7);
-        pieceA[j] = isA;
-        pieceOff[j] = pc * (8 * FIT_BK);
-        if (isA) {
-            const int g = tm * BM + r;
-            if constexpr (CONV) {
-                voff[j] = (unsigned)(chunk * 8);
-                const int Hs = d.up == 1 ? (d.H >> 1) : d.H, Ws = d.up == 1 ? (d.W >> 1) : d.W;
-                const int hw = d.H * d.W;
-                const int b = g / hw, rem = g - b * hw, y = rem / d.W, x = rem - y * d.W;
-                int okm = 0, ro[3], co[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int yy = y + t - 1, xx = x + t - 1;
-                    if (g < d.M && yy >= 0 && yy < d.H) okm |= 1 << t;
-                    if (xx >= 0 && xx < d.W) okm |= 8 << t;
-                    ro[t] = (b * Hs + (d.up ? (yy >> 1) : yy)) * Ws;
-                    co[t] = d.up ? (xx >> 1) : xx;
-                }
-                if (co[0] != co[1]) okm |= 64;
-                if (co[2] != co[1]) okm |= 128;
-                c_ok[j] = okm;
-                c_r1[j] = ro[1]; c_rd[j] = ((ro[0] - ro[1]) & 0xffff) | ((ro[2] - ro[1]) << 16);
-                c_c1[j] = co[1];
-                s_tap[j] = (sub * nkg * FIT_BK) / d.Cin;
-                s_c0[j] = sub * nkg * FIT_BK - s_tap[j] * d.Cin;
-                s_cur[j] = -1; c_off[j] = -1;
-            } else {
-                const int gc = g < d.M ? g : d.M - 1;
-                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
-            }
-        } else {
-            int g = tn * BN + r;
-            g = g < d.N ? g : d.N - 1;
-            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
-            if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; s_cur[j] = -1; c_off[j] = -1; }
-        }
-    }
-    // stages are issued in K order, exactly once each
-    auto issue = [&](int it, int stage) {
-        const size_t kel = (size_t)it * FIT_BK;
-#pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            const bf16_t* src;
-            if (CONV && pieceA[j]) {
-                const int tap = s_tap[j];
-                if (tap != s_cur[j]) {                       // wave-uniform: a new tap every Cin / 64 stages
-                    const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0), kx = tap - 3 * ky;
-                    const int my0 = -(int)(ky == 0), my2 = -(int)(ky == 2), mx0 = -(int)(kx == 0), mx2 = -(int)(kx == 2);
-                    const int ro = c_r1[j] + (my0 & ((c_rd[j] << 16) >> 16)) + (my2 & (c_rd[j] >> 16));
-                    const int co = c_c1[j] - (mx0 & ((c_ok[j] >> 6) & 1)) + (mx2 & ((c_ok[j] >> 7) & 1));
-                    const bool ok = ((c_ok[j] >> ky) & (c_ok[j] >> (3 + kx)) & 1) != 0;
-                    c_off[j] = ok ? (ro + co) * d.lda + (int)voff[j] : -1;      // M * lda < 2^31 (eligibility)
-                    s_cur[j] = tap;
-                }
-                src = c_off[j] >= 0 ? Ap + (size_t)(unsigned)(c_off[j] + s_c0[j]) : zero_page;
-                s_c0[j] += FIT_BK;
-                if (s_c0[j] >= d.Cin) { s_c0[j] -= d.Cin; ++s_tap[j]; }
-            } else {
-                src = (pieceA[j] ? Ap : Bp) + kel + voff[j];
-            }
-            __builtin_amdgcn_global_load_lds((fit_gptr)src, (fit_lptr)(lds + stage * STAGE + pieceOff[j]), 16, 0, 0);
-        }
-    };
-
-    // ---- fragment coordinates (16x16x32: lane -> row lane & 15, k = 8 (lane >> 4) .. + 7 of the 32-wide step) ------------
-    const int l15 = lane & 15, kq = lane >> 4, fkey = (l15 >> 1) & 7;
-    const int koff0 = ((kq ^ fkey) << 3), koff1 = (((4 + kq) ^ fkey) << 3);
-    const int a_el = kg * SUB + (wm * (16 * FM) + l15) * FIT_BK;                 // + fm * 16 * BK
-    const int b_el = kg * SUB + BM * FIT_BK + (wn * TN + l15) * FIT_BK;          // + fn * 16 * BK
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](int stage) {
-        const bf16_t* const As = lds + stage * STAGE + a_el;
-        const bf16_t* const Bs = lds + stage * STAGE + b_el;
-        bf16x8 af0[FM], bf0[FN], af1[FM], bf1[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf0[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * FIT_BK) + koff0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * FIT_BK) + koff0);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf1[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * FIT_BK) + koff1);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af1[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * FIT_BK) + koff1);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = fit_mfma<T16>(af0[i], bf0[j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = fit_mfma<T16>(af1[i], bf1[j], acc[i][j]);
-        // The stage's schedule is pinned to "first k-step's fragment reads | its MFMAs with the second k-step's reads issued under
-        // them | second k-step's MFMAs": left to itself the compiler re-uses fragment registers and waits lgkmcnt(0) seven times
-        // per stage (18 ds_read_b128 / 40 MFMAs for FC1's tile); pinned, one LDS latency is exposed per stage.  (The compiler
-        // waits lgkmcnt(0), not a count, in front of the first MFMA, so the second k-step's reads are placed BEHIND the first
-        // MFMA, where that wait no longer covers them.)  Round-5 A/B on the device: engine 4.90 -> 4.76 ms per iteration,
-        // profiles/r05_first_call/.
-        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the first k-step's fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // the first MFMA (and the wait in front of it)
-        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the second k-step's fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - 1, 0);   // the rest of the first k-step's MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);       // the second k-step's
-    };
-
-    // ---- main loop: ring of 3 stages, counted waits (PW DMA instructions per wave per stage) ---------------------------
-    // Staggered wave groups (fit_flags bit 0): waves [0, NW/2) issue their share of stage T + 2 BEFORE computing stage T, waves
-    // [NW/2, NW) -- their SIMD partners -- AFTER it.  Issuing a stage costs a wave about as long as computing one (the DMA
-    // instructions queue behind the CU's 64 B/clk load path), so with every wave in the same phase the matrix pipes idle
-    // while all eight issue; staggered, one wave of a SIMD computes while the other issues.  The late group's pieces of
-    // stage T + 2 are issued after every wave passed barrier T (stage T - 1 was read before it: WAR), and are waited for by
-    // the same counted wait in front of barrier T + 2.
-    const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
-    const bool late = (p.fit_flags & 1) && wave >= NW / 2;
-    FIT_TRACE(1);
-    if (0 < nk) issue(0, 0);
-    if (1 < nk) issue(1, 1);
-#define FIT_STEP(T, ST)                                                                                                 \
-    do {                                                                                                                \
-        if ((T) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");                                    \
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
-        __builtin_amdgcn_s_barrier();       /* stage T landed for every wave; everyone is done reading stage T - 1 */   \
-        if ((T) == 0) FIT_TRACE(2);                                                                                     \
-        if (!late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                      \
-        compute(ST);                                                                                                    \
-        if (late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                       \
-    } while (0)
-    int t = 0;
-    for (; t + 3 <= nk; t += 3) { FIT_STEP(t, 0); FIT_STEP(t + 1, 1); FIT_STEP(t + 2, 2); }
-    if (t < nk) { FIT_STEP(t, 0); ++t; }
-    if (t < nk) { FIT_STEP(t, 1); ++t; }
-#undef FIT_STEP
-    FIT_TRACE(3);
-    __builtin_amdgcn_s_barrier();           // the ring is dead: LDS is reused below
-
-    if (p.fit_flags & 4) {                  // bit 2 (timing experiments only): no epilogue -- keep the accumulators alive
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
-#ifdef PRX_FIT_TRACE
-    // experiment (PRX_FIT_TRACE_REP=1, KS == 1 tiles): the epilogue a second time from the SAME code addresses -- the first pass
-    // runs it from a cold instruction cache, the second from a warm one; the second pass's stamps replace slots 1 (begin) and 2 (end)
-    const int nrep = (KS == 1 && (p.fit_flags & 64)) ? 2 : 1;
-    for (int rep = 0; rep < nrep; ++rep) {
-        if (rep) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[1] = __builtin_amdgcn_s_memtime(); }
-        fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane FIT_TRACE_PASS);
-        if (rep) { tr[2] = tr[5]; }
-        else if (nrep > 1) { tr[3] = tr[4]; tr[7] = tr[5]; }
-    }
-    if (nrep > 1) { const unsigned long long b2 = tr[1], e2 = tr[2]; tr[4] = tr[3]; tr[5] = tr[7]; tr[1] = b2; tr[2] = e2; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FIT_TRACE(6);
-    if (p.ws && lane < 8) {
-        unsigned long long v = tr[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) v = lane == i ? tr[i] : v;
-        if (lane == 7) v = ((__builtin_amdgcn_s_memrealtime() - tr_real0) << 32) | (unsigned)bid;   // wave lifetime in 10 ns ticks, tile index
-        reinterpret_cast<unsigned long long*>(p.ws)[((size_t)blockIdx.x * NW + wave) * 8 + lane] = v;
-    }
-#else
-    fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
-#endif
-}
-
-template <int WGM, int WGN, int FM, int FN, int KS, bool HAS_CONV = true>
-void launch_fit(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
-    constexpr int threads = 64 * WGM * WGN * KS;
-    const bool conv = a.d.a_mode == PRX_A_CONV3X3;
-    if constexpr (HAS_CONV) {
-        if (conv) {
-            if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, half_t>), grid, dim3(threads), 0, s, a, zp);
-            else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, bf16_t>), grid, dim3(threads), 0, s, a, zp);
-            return;
-        }
-    }
-    if (a.d.h16) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t>), grid, dim3(threads), 0, s, a, zp);
-    else         hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, bf16_t>), grid, dim3(threads), 0, s, a, zp);
-}
-
 // the tile shapes this kernel exists in
 struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
 const FitTile kFitTiles[] = {
@@ -619,6 +84,33 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
     for (const FitTile& t : kFitTiles)
         if (t.bn >= 32) consider(t.bm, t.bn, t.eff);
 }
+static std::atomic<long long> g_spec_launches{0};
+extern "C" long long prx_gemm_fit_spec_launches(void) { return g_spec_launches.load(std::memory_order_relaxed); }
+
+// The compile-time epilogue (FIT_EPI_*) a descriptor is an instance of, FIT_EPI_GENERIC when none: IEEE-half operands, one
+// 16-bit output (plus FC1's 16-bit pre-activation), no fp32 output, no per-row bias, at most one 16-bit row operand.
+int prx_gemmfit_epi_kind(const GemmDesc& d) {
+    if (!d.h16 || d.f32 || d.a_is_f32 || d.out_f32 || !d.out_bf16 || d.bias_m) return FIT_EPI_GENERIC;
+    // 32-bit element offsets from the operand bases
+    const unsigned long long lim = 1ull << 31;
+    if ((unsigned long long)d.M * d.ldc_bf16 >= lim || (d.resid && (unsigned long long)d.M * d.ldr >= lim) ||
+        (d.aux && (unsigned long long)d.M * d.ldaux >= lim) || (unsigned long long)d.M * d.N >= lim) return FIT_EPI_GENERIC;
+    const bool stats = d.gn_stats != nullptr, gnb = d.gnb_x != nullptr;
+    if (gnb && !stats) return FIT_EPI_GENERIC;
+    switch (d.act) {
+    case PRX_ACT_NONE:
+        if (d.aux) return FIT_EPI_GENERIC;
+        if (gnb) return (!d.resid && (d.row16 & 2)) ? FIT_EPI_GNB : FIT_EPI_GENERIC;
+        if (d.resid) return (d.row16 & 1) ? (stats ? FIT_EPI_RES16_GN : FIT_EPI_RES16) : FIT_EPI_GENERIC;
+        return stats ? FIT_EPI_GN : FIT_EPI_OUT16;
+    case PRX_ACT_QUICKGELU:
+        return (d.out_bf16_pre && !d.resid && !stats) ? FIT_EPI_GELU : FIT_EPI_GENERIC;
+    case PRX_ACT_MUL_DQUICKGELU:
+        return (d.aux && !d.resid && !stats) ? FIT_EPI_DGELU : FIT_EPI_GENERIC;
+    default:
+        return FIT_EPI_GENERIC;
+    }
+}
 #ifdef PRX_FIT_TRACE
 // diagnostic build: between prx_fit_trace_begin(buffer) and prx_fit_trace_end every fit launch writes its waves' phase stamps
 // to its own slice of the buffer (instead of the caller's workspace); the host keeps one text record per launch
@@ -653,10 +145,21 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a_in, int bm, int bn, dim3 
         } else a.ws = nullptr;
     } else a.ws = nullptr;
     static const int trace_rep = getenv("PRX_FIT_TRACE_REP") ? atoi(getenv("PRX_FIT_TRACE_REP")) : 0;
-    if (trace_rep) a.fit_flags |= 64;
+    if (trace_rep) a.fit_flags |= 128;
 #else
     const prx_gemm_dev::GemmArgs& a = a_in;
 #endif
+    // the descriptor patterns of the two runners have kernels with a compile-time epilogue (gemmfit_spec_*.hip); bit 6 of the
+    // switch word (PRX_FIT_FLAGS / override -8) keeps every launch on the generic kernels (A/B runs, tests of the generic path)
+    if (!(a.fit_flags & 64)) {
+        const int epi = prx_gemmfit_epi_kind(a.d);
+        if (epi != FIT_EPI_GENERIC &&
+            (prx_gemmfit_launch_spec_tower(a, bm, bn, epi, grid, s, zp) || prx_gemmfit_launch_spec_dec_a(a, bm, bn, epi, grid, s, zp) ||
+             prx_gemmfit_launch_spec_dec_b(a, bm, bn, epi, grid, s, zp) || prx_gemmfit_launch_spec_dec_c(a, bm, bn, epi, grid, s, zp))) {
+            g_spec_launches.fetch_add(1, std::memory_order_relaxed);
+            return 0;
+        }
+    }
     if (bm == 160 && bn == 256) launch_fit<2, 4, 5, 4, 1, false>(a, grid, s, zp);
     else if (bm == 160 && bn == 192) launch_fit<2, 4, 5, 3, 1, false>(a, grid, s, zp);
     else if (bm == 256 && bn == 128) launch_fit<4, 2, 4, 4, 1>(a, grid, s, zp);

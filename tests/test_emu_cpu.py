@@ -47,7 +47,7 @@ def types_ns(**kw):
 
 def test_emulated_library_exports_the_whole_c_abi(emu):
     from pixray_amd import _lib
-    assert emu.lib.prx_abi_version() == 2
+    assert emu.lib.prx_abi_version() == 3
     assert len(_lib._protos) >= 79 and all(hasattr(emu.lib, name) for name in _lib._protos)
 
 
@@ -64,6 +64,17 @@ def test_fit_kernel_implicit_conv_and_groupnorm_epilogue_sums(emu):
     emu.tk.test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums((64, 64), "fp16")  # 16x16x32 MFMA, K groups through LDS, GN / GN-backward sums
     emu.tk.test_gemm_conv3x3(16, 16, 128, 128, 0, 1, 1)
     emu.tk.test_gemm_conv3x3_stride2_down(12, 20, 64, 72, 2)
+
+
+def test_fit_kernels_with_compile_time_epilogues_match_the_generic_kernel(emu):
+    """every specialised epilogue (OUT16, RES16, GELU, DGELU, GN, RES16_GN, GNB) of a tower tile, a K-group tower tile and decoder
+    tiles with 1 / 2 / 8 K groups: bit-identical 16-bit outputs to the generic kernel of the same launch (sigmoid forms: one half
+    ulp), spare rows untouched, GroupNorm sums equal; the launch counter proves which kernel ran (tests/test_kernels_gpu.py)"""
+    small = [(200, 136, 512), (81, 264, 1024)]
+    convs = [(8, 12, 64, 128, 0, 1), (8, 8, 512, 128, 1, 1)]
+    for tile in [(160, 192), (80, 128), (128, 128), (64, 64), (16, 32)]:
+        ran = emu.tk.fit_spec_vs_generic(tile, shapes=small, conv_shapes=convs)
+        assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or {"gn", "res16_gn", "gnb"} <= ran), (tile, ran)
 
 
 def test_gemm_engine_random_shapes_every_kernel_family(emu):

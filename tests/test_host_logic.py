@@ -105,7 +105,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH) if False else _lib.load()
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in include/prx.h but not exported"
-    assert lib.prx_abi_version() == 2
+    assert lib.prx_abi_version() == 3
     for must in ("prx_vqgan_synth", "prx_vqgan_synth_backward", "prx_cutouts_forward", "prx_cutouts_backward",
                  "prx_clip_vit_encode", "prx_clip_vit_backward_reduce", "prx_clip_vit_backward_finish",
                  "prx_prompt_loss_fwd_bwd", "prx_adam_clamp_step", "prx_last_error"):

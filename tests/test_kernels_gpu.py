@@ -365,6 +365,135 @@ def test_gemm_fit_tiles_implicit_conv_and_groupnorm_sums(tile, prec):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), -12, 0, 0)
 
 
+SPEC_TILES = [(160, 256), (160, 192), (160, 128), (80, 128), (256, 128), (128, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)]
+
+
+def fit_spec_vs_generic(tile, shapes=None, conv_shapes=None):
+    """the fit kernels with a compile-time epilogue (gemmfit_kernel.h FIT_EPI_*: OUT16, RES16, GELU, DGELU, GN, RES16_GN, GNB; IEEE-half
+    operands) against the generic kernel of the same tile on the same launch (switch-word bit 6): the arithmetic is the generic
+    epilogue's term by term, so 16-bit outputs are BIT-identical wherever no sigmoid is evaluated; QuickGELU / its derivative use
+    v_exp + v_rcp instead of a correctly rounded division (the saved pre-activation stays bit-identical, the activation moves by
+    at most one half-precision ulp); GroupNorm sums agree to the rounding of their fp32 per-lane partials"""
+    lib = _lib.load()
+    dt = torch.float16
+    ks = FIT_KS[tile]
+    tower = tile[0] % 80 == 0
+    torch.manual_seed(21)
+    ctx = _lib.tool_ctx()
+    ran = set()
+
+    def both(fn, spec=True):
+        res = []
+        for flags in (1, 65):
+            lib.prx_gemm_tile_override(ctx, -8, 0, flags)
+            n0 = lib.prx_gemm_fit_spec_launches()
+            res.append(fn())
+            assert lib.prx_gemm_fit_spec_launches() - n0 == (1 if flags == 1 and spec else 0), (tile, flags)      # the specialised kernel ran / did not run
+        lib.prx_gemm_tile_override(ctx, -8, 0, 1)
+        return res
+
+    def bits(t):
+        return t.view(torch.int16)
+    try:
+        lib.prx_gemm_tile_override(ctx, -12, 0, 1)
+        lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
+        for (M, N, K) in (shapes or [(3200, 768, 768), (1000, 200, 1152), (333, 520, 512), (81, 136, 1024)]):
+            if K % (64 * ks):
+                continue
+            A = torch.randn(M, K, device=DEV).to(dt)
+            Bt = (torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K)).to(dt)
+            bias = torch.randn(N, device=DEV)
+            ldr = N + 8
+            resid = torch.randn(M, ldr, device=DEV).to(dt)
+            aux = torch.randn(M, N, device=DEV).to(dt)
+            prod = A.float() @ Bt.float().T
+
+            def run(**kw):
+                g = GemmArgs()
+                g.A = A.data_ptr(); g.a_mode = 0; g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+                g.alpha = kw.get("alpha", 1.0); g.f32 = 2; g.act = kw.get("act", 0)
+                if kw.get("bias"): g.bias_n = bias.data_ptr()
+                if kw.get("resid"): g.resid = resid.data_ptr(); g.ldr = ldr; g.row16 = 1
+                if kw.get("aux"): g.aux = aux.data_ptr(); g.ldaux = N
+                ldc = N + 16
+                o16 = torch.full((M + 2, ldc), float("nan"), device=DEV, dtype=dt); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = ldc
+                pre = None
+                if kw.get("pre"):
+                    pre = torch.full((M + 2, ldc), float("nan"), device=DEV, dtype=dt); g.out_bf16_pre = pre.data_ptr()
+                call("prx_k_gemm", g, None, 0, stream())
+                torch.cuda.synchronize()
+                assert torch.isnan(o16[M:].float()).all() and torch.isnan(o16[:, N:].float()).all()       # spare rows / columns untouched
+                return o16[:M, :N].clone(), (pre[:M, :N].clone() if pre is not None else None)
+
+            (s16, _), (g16, _) = both(lambda: run(bias=True, alpha=0.5))                                   # OUT16
+            assert torch.equal(bits(s16), bits(g16)) and rel_l2(s16, 0.5 * prod + bias) < 5e-4
+            (s16, _), (g16, _) = both(lambda: run(bias=True, resid=True))                                  # RES16 (16-bit residual stream)
+            assert torch.equal(bits(s16), bits(g16)) and rel_l2(s16, prod + bias + resid[:, :N].float()) < 5e-4
+            ran.update(["out16", "res16"])
+            (s16, spre), (g16, gpre) = both(lambda: run(bias=True, act=1, pre=True), spec=tower)           # GELU (the tower tiles have it)
+            assert torch.equal(bits(spre), bits(gpre))
+            pre = (prod + bias).to(dt).float()
+            assert rel_l2(s16, pre * torch.sigmoid(1.702 * pre)) < 5e-4
+            d = (s16.float() - g16.float()).abs()
+            assert bool((d <= 2.0 ** -10 * g16.float().abs() + 1e-7).all()), d.max()                       # one half ulp of movement at most
+            (s16, _), (g16, _) = both(lambda: run(aux=True, act=2), spec=tower)                            # DGELU
+            sg = torch.sigmoid(1.702 * aux.float())
+            assert rel_l2(s16, prod * (sg * (1 + 1.702 * aux.float() * (1 - sg)))) < 5e-4
+            d = (s16.float() - g16.float()).abs()
+            assert bool((d <= 2.0 ** -10 * g16.float().abs() + 1e-7).all()), d.max()
+            ran.update(["gelu", "dgelu"])
+        for (H, W, Cin, Cout, up, NB) in (conv_shapes or [(32, 32, 128, 128, 1, 1), (24, 40, 64, 256, 0, 2), (16, 16, 512, 128, 0, 1)]):
+            if tower or (9 * Cin) % (64 * ks):
+                continue
+            hin, win = (H // 2, W // 2) if up else (H, W)
+            x_nhwc = torch.randn(NB, hin, win, Cin, device=DEV).to(dt)
+            w_pack = (torch.randn(Cout, 9 * Cin, device=DEV) / math.sqrt(9 * Cin)).to(dt)
+            bias = torch.randn(Cout, device=DEV)
+            M = NB * H * W
+            resid = torch.randn(M, Cout, device=DEV).to(dt)
+            gs = Cout // 32
+            xg = torch.randn(M, Cout, device=DEV).to(dt)
+            x64 = xg.double().view(M, 32, gs)
+            fstats = torch.stack([x64.sum(dim=(0, 2)), (x64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1).contiguous()
+            gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+
+            def runc(kind):
+                g = GemmArgs()
+                g.A = x_nhwc.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w_pack.data_ptr(); g.ldb = 9 * Cin
+                g.M, g.N, g.K = M, Cout, 9 * Cin
+                g.H, g.W, g.Cin, g.up = H, W, Cin, up
+                g.alpha = 1.0; g.f32 = 2; g.bias_n = bias.data_ptr()
+                o16 = torch.full((M + 2, Cout), float("nan"), device=DEV, dtype=dt); g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = Cout
+                st = torch.zeros(64, device=DEV, dtype=torch.float64)
+                if kind == "res16_gn":
+                    g.resid = resid.data_ptr(); g.ldr = Cout; g.row16 = 1
+                if kind == "gnb":
+                    g.bias_n = None; g.row16 = 2
+                    call("prx_k_gemm_gn", g, st, gs, xg, fstats, gamma, beta, 1, 1e-6, None, 0, stream())
+                else:
+                    call("prx_k_gemm_gn", g, st, gs, None, None, None, None, 0, 1e-6, None, 0, stream())
+                torch.cuda.synchronize()
+                assert torch.isnan(o16[M:].float()).all()
+                return o16[:M].clone(), st
+            for kind in ("gn", "res16_gn", "gnb"):
+                (s16, sst), (g16, gst) = both(lambda: runc(kind))
+                assert torch.equal(bits(s16), bits(g16)), (tile, kind)
+                assert torch.allclose(sst, gst, rtol=2e-6, atol=1e-3), (tile, kind, (sst - gst).abs().max())      # fp32 per-lane partials: the two code shapes contract their multiply-adds differently
+                assert float(sst.abs().sum()) > 0
+                ran.add(kind)
+    finally:
+        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
+        lib.prx_gemm_tile_override(ctx, -8, 0, 1)
+        lib.prx_gemm_tile_override(ctx, -12, 0, 0)
+    return ran
+
+
+@pytest.mark.parametrize("tile", SPEC_TILES)
+def test_gemm_fit_specialised_epilogues_match_the_generic_kernel(tile):
+    ran = fit_spec_vs_generic(tile)
+    assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or {"gn", "res16_gn", "gnb"} <= ran)
+
+
 def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
     """the planner gives the ViT-B/32 products of 64 cutouts (M = 3200) one workgroup per CU: 240 tiles of 160 x 256, 160 x 192 or
     80 x 128, and the result is the 4-wave kernels' to fp32 round-off (another K summation order on the two-K-group tile)"""

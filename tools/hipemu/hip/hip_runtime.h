@@ -154,6 +154,7 @@ static inline void __threadfence_system() {}
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_logf(x) log2f(x)
 #define HIPEMU_ASM(...) ((void)0)          /* the emulated build rewrites `asm volatile(` (all of them s_waitcnt) to this */
 
