@@ -146,6 +146,8 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a_in, int bm, int bn, dim3 
     } else a.ws = nullptr;
     static const int trace_rep = getenv("PRX_FIT_TRACE_REP") ? atoi(getenv("PRX_FIT_TRACE_REP")) : 0;
     if (trace_rep) a.fit_flags |= 128;
+    static const int trace_loop = getenv("PRX_FIT_TRACE_LOOP") ? atoi(getenv("PRX_FIT_TRACE_LOOP")) : 0;       // 1: no MFMAs, 2: no DMA in the steady state
+    a.fit_flags |= (trace_loop & 3) << 8;
 #else
     const prx_gemm_dev::GemmArgs& a = a_in;
 #endif

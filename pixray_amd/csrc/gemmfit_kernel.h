@@ -652,21 +652,33 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     FIT_TRACE(1);
     if (0 < nk) issue(0, 0);
     if (1 < nk) issue(1, 1);
+#ifdef PRX_FIT_TRACE
+    // loop experiments of the diagnostic build (PRX_FIT_TRACE_LOOP): bit 8 = no MFMAs / fragment reads (DMA, waits and barriers
+    // only), bit 9 = no DMA after the first two stages (fragment reads + MFMAs on whatever the ring holds)
+    const bool x_nomma = (p.fit_flags & 256) != 0, x_nodma = (p.fit_flags & 512) != 0;
+#define FIT_ISSUE(T, ST) do { if (!x_nodma) issue(T, ST); } while (0)
+#define FIT_COMPUTE(ST) do { if (!x_nomma) compute(ST); } while (0)
+#else
+#define FIT_ISSUE(T, ST) issue(T, ST)
+#define FIT_COMPUTE(ST) compute(ST)
+#endif
 #define FIT_STEP(T, ST)                                                                                                 \
     do {                                                                                                                \
         if ((T) + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");                                    \
         else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
         __builtin_amdgcn_s_barrier();       /* stage T landed for every wave; everyone is done reading stage T - 1 */   \
         if ((T) == 0) FIT_TRACE(2);                                                                                     \
-        if (!late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                      \
-        compute(ST);                                                                                                    \
-        if (late && (T) + 2 < nk) issue((T) + 2, ((ST) + 2) % 3);                                                       \
+        if (!late && (T) + 2 < nk) FIT_ISSUE((T) + 2, ((ST) + 2) % 3);                                                  \
+        FIT_COMPUTE(ST);                                                                                                \
+        if (late && (T) + 2 < nk) FIT_ISSUE((T) + 2, ((ST) + 2) % 3);                                                   \
     } while (0)
     int t = 0;
     for (; t + 3 <= nk; t += 3) { FIT_STEP(t, 0); FIT_STEP(t + 1, 1); FIT_STEP(t + 2, 2); }
     if (t < nk) { FIT_STEP(t, 0); ++t; }
     if (t < nk) { FIT_STEP(t, 1); ++t; }
 #undef FIT_STEP
+#undef FIT_ISSUE
+#undef FIT_COMPUTE
     FIT_TRACE(3);
     __builtin_amdgcn_s_barrier();           // the ring is dead: LDS is reused below
 
