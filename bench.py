@@ -320,7 +320,10 @@ def main():
                     T_ = (c_.input_resolution // c_.patch_size) ** 2 + 1
                     tail_gflop += 2 * 2.0 * (n_loc * T_ - n_loc) * (c_.width ** 2 + 2 * 4 * c_.width ** 2) / 1e9
             gemm_gflop_alg = gemm_gflop_step + tail_gflop
-            achieved = gemm_gflop_alg * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
+            # `achieved` / `frac` = what the matrix pipes DID: launched flops over the launches' time.  The algorithmic figure (with the
+            # products the class-token tail skips) is reported beside it as an MFU-style field, not as the roofline fraction
+            achieved = gemm_gflop_step * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
+            achieved_alg = gemm_gflop_alg * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
             kern = (f"GEMM engine: gemmfit_kernel<WGM,WGN,FM,FN,KS,CONV> + gemm_glds_kernel / gemm8p_kernel ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
                     if args.precision != "f32"
                     else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
@@ -328,19 +331,22 @@ def main():
             # command, gfx950 FETCH correction applied): not measurable from inside this process, so `traffic` is null here
             # and the committed profile of the round is quoted next to it when there is one for this configuration
             pmc = None
-            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (5, 4, 3, 2))
+            pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{rr:02d}_{args.config}_hbm_traffic.json") for rr in (6, 5, 4, 3, 2))
                              if os.path.exists(q)), "")
             if args.precision != "f32" and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 pmc["source"] = os.path.relpath(pmc_path, ROOT)
+                pmc["measured_in_this_run"] = False      # a committed rocprofv3 --pmc profile of the same command, not this process
             # `traffic`: HBM-side bytes per launch of this kernel family from the committed PMC passes of this command (FETCH_SIZE
             # and WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 corrections applied: tools/profile_run.sh, tools/pmc_summary.py);
             # the counters cannot be read from inside the process, so the number is the profile's, with its source beside it
             traffic = round(float(pmc["bytes_per_launch"])) if pmc and pmc.get("bytes_per_launch") else None
             roofline = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_unit": "bytes per launch (HBM-side fetch + write)" if traffic else None, "traffic_pmc_profile": pmc,
+                        "traffic_unit": "bytes per launch (HBM-side fetch + write), from the committed PMC profile named in traffic_pmc_profile.source -- NOT measured in this run" if traffic else None,
+                        "traffic_pmc_profile": pmc,
+                        "achieved_algorithmic": round(achieved_alg, 1), "frac_algorithmic": round(achieved_alg / peak, 4),
                         "launches_per_step": n // args.profile_steps,
                         "gemm_gflop_per_step": round(gemm_gflop_alg, 1),
                         "gemm_gflop_launched_per_step": round(gemm_gflop_step, 1),
@@ -376,7 +382,7 @@ def main():
             if prec == args.precision:
                 continue
             s2 = api.build_workload(args.config, num_cuts=cutn, precision=prec, device=dev)
-            n2, w2 = (10, 2) if prec in ("f32", "ref") else (steps, warmup)
+            n2, w2 = (10, 2) if prec == "f32" else (steps, warmup)      # the like-for-like "ref" leg runs the timed leg's step count
             for i in range(w2):
                 s2.train(i)
             torch.cuda.synchronize(dev)

@@ -139,7 +139,39 @@ def load_taming(config_path: str, checkpoint_path: str, with_encoder: bool = Non
     sd = {k: v for k, v in sd.items() if not k.startswith("loss.")}
     if gumbel and "quantize.embed.weight" in sd:
         sd["quantize.embedding.weight"] = sd.pop("quantize.embed.weight")
-    return cfg, vqgan_from_taming(sd, cfg, with_encoder), gumbel
+    out = vqgan_from_taming(sd, cfg, with_encoder)
+    if gumbel:
+        # GumbelQuantize's logits projection (a 1x1 convolution z_channels -> n_embed): not on the decode path; kept so that
+        # VqganDrawer can ENCODE an image the way GumbelVQ.encode does (init_image / overlay / z labels, vqgan.py:174-185)
+        for k in ("quantize.proj.weight", "quantize.proj.bias"):
+            if k in sd:
+                out[k] = sd[k].detach().float().contiguous()
+    return cfg, out, gumbel
+
+
+def clip_state_dict_from_archive(path: str) -> Dict[str, torch.Tensor]:
+    """What `clip.load(name, download_root="models")` reads (slip.py:175): OpenAI publishes every CLIP model as a TorchScript
+    archive (`ViT-B-32.pt`, ...), and `clip.load` takes `torch.jit.load(path).state_dict()` from it; a plain pickled state dict
+    (or `{"state_dict": ...}`) is accepted as well, as `clip.load` does when the file is not an archive.  The result feeds
+    `clip_visual_from_openai` / `clip_text_from_openai` (fp16 tensors are cast to fp32 there)."""
+    try:
+        module = torch.jit.load(path, map_location="cpu")
+        sd = module.state_dict()
+    except RuntimeError:
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+        sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob.state_dict()
+    return {k: v.detach() for k, v in sd.items()}
+
+
+def clip_config_from_state_dict(sd: Dict[str, torch.Tensor], name: str = "checkpoint") -> ClipVitConfig:
+    """`clip.model.build_model` reads the ViT geometry off the tensors' shapes; so does this (visual tower of the ViT family)."""
+    if "visual.proj" not in sd:
+        raise ValueError("not a CLIP ViT state dict (no visual.proj): ModifiedResNet towers are configured by name")
+    width = sd["visual.conv1.weight"].shape[0]
+    patch = sd["visual.conv1.weight"].shape[-1]
+    layers = len({k.split(".")[3] for k in sd if k.startswith("visual.transformer.resblocks.")})
+    grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    return ClipVitConfig(name, patch * grid, patch, width, layers, width // 64, sd["visual.proj"].shape[1])
 
 
 def vgg16_from_torchvision(state_dict: Dict[str, torch.Tensor]):

@@ -62,7 +62,7 @@ __device__ __forceinline__ float prompt_loss_row(const float* __restrict__ x, co
 
 // One wave per row, four rows per workgroup.  The scalar the loop adds up -- loss = |w| * sum(rowloss) / denom, pixray.py:280 --
 // leaves the same launch (it used to take a torch reduction and a scalar multiply per Prompt and iteration): the workgroup that
-// finishes last (a ticket counter the caller hands over zeroed; it is zero again on exit) adds the row values in a fixed order.
+// finishes last (a wrapping ticket counter the caller hands over zeroed; it is zero again once every workgroup drew) adds the row values in a fixed order.
 __global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restrict__ x, const float* __restrict__ embed,
                                                           int n, int m, int D, float weight, float stop, float denom,
                                                           float* __restrict__ rowloss, float* __restrict__ grad, float* __restrict__ loss_out,
@@ -74,14 +74,16 @@ __global__ __launch_bounds__(256) void prompt_loss_kernel(const float* __restric
     __shared__ unsigned last;
     __threadfence();                       // this workgroup's row values are visible device-wide before its ticket is drawn
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    // atomicInc wraps to zero when the last ticket is drawn: the word is zero again on exit WITHOUT a second store, so a launch
+    // never depends on an earlier one having run to its last line
+    if (threadIdx.x == 0) last = atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!last || threadIdx.x >= 64) return;
     __threadfence();
     float t = 0.f;
     for (int r = lane; r < n; r += 64) t += *reinterpret_cast<const volatile float*>(rowloss + r);      // written by other workgroups: read past this CU's L1
     t = wave_sum(t);
-    if (lane == 0) { *loss_out = t * (fabsf(weight) / denom); *ticket = 0u; }
+    if (lane == 0) *loss_out = t * (fabsf(weight) / denom);
 }
 
 // e_hat = e/|e|  (slip.py:66) and its backward  de = (g - e_hat (e_hat.g))/|e|

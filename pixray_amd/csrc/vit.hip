@@ -95,6 +95,7 @@ struct PrxVit {
     // GPU arithmetic for this tower (slip.py:175: the CLIP model runs in fp16, residual adds included).  One 16-bit tensor is
     // the saved activation, the LayerNorm input and the residual operand of the next product; dx / dh have no fp32 copy.
     int lean;
+    int cls_tail;      // 1 (default): the class-token tail below; PRX_VIT_CLS_TAIL=0 runs the last block on every token row (A/B, bisection)
     float* ws; size_t ws_bytes;
     int cur_n;
     // The class-token tail: only the class token of the LAST block's output is ever read (ln_post on token 0, slip.py:66 / clip
@@ -149,6 +150,7 @@ int prx_vit_create_impl(PrxVit** out, int res, int patch, int width, int layers,
     v->prec = precision; v->f32 = prec_is_f32(precision); v->h16 = prec_is_h16(precision);
     v->gs = nullptr;
     { const char* e = getenv("PRX_LEAN"); v->lean = (v->h16 && !(e && atoi(e) == 0)) ? 1 : 0; }
+    { const char* e = getenv("PRX_VIT_CLS_TAIL"); v->cls_tail = (e && atoi(e) == 0) ? 0 : 1; }
     v->T = T; v->max_n = max_n; v->KP = (3 * patch * patch + 7) / 8 * 8; v->cur_n = 0;   // K padded to x8 (L/14: 588 -> 592)
     const int W = width, KP = v->KP;
     int r;
@@ -278,7 +280,7 @@ int prx_vit_forward_impl(PrxVit* v, const float* cutouts, int n, const float* mm
         else { if ((r = prx_mha_fwd_gen((const bf16_t*)y.qkv, (bf16_t*)y.o_save, y.lse, n, T, W, v->heads, s, v->h16))) return r; att = y.o_save; }
         // the class-token tail: rows = the n class tokens, reached through a row stride of T * W in the token-major buffers;
         // LN / MLP intermediates of those rows are stored densely ([n][...]) at the start of their buffers
-        const bool tail = l == v->layers - 1;
+        const bool tail = v->cls_tail && l == v->layers - 1;
         const int rows = tail ? n : R;
         const int ldt = tail ? T * W : W;            // row stride of the token-major fp32 / 16-bit [R, W] buffers
         {   GemmDesc d; d.A = att; d.lda = ldt; d.B = y.Wo; d.ldb = W; d.M = rows; d.N = W; d.K = W;
@@ -332,7 +334,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     // backward, which takes the incoming gradient as zero on every other row (add_every = T) and writes all of them -- so the
     // streams need no clearing (two fills of 14.7 MB per iteration at the headline)
     const int lean = v->lean;
-    if (v->layers == 0) PRX_CHECK_HIP(hipMemsetAsync(lean ? v->dx_bf : (void*)v->dx, 0, (lean ? sizeof(bf16_t) : sizeof(float)) * (size_t)R * W, s));
+    if (v->layers == 0 || !v->cls_tail) PRX_CHECK_HIP(hipMemsetAsync(lean ? v->dx_bf : (void*)v->dx, 0, (lean ? sizeof(bf16_t) : sizeof(float)) * (size_t)R * W, s));
     // lean layout: dxs / dhs are the 16-bit gradient streams themselves (no fp32 copies exist)
     const void* dxs = lean ? v->dx_bf : (const void*)v->dx;
     const void* dhs = lean ? v->dh_bf : (const void*)v->dh;
@@ -341,7 +343,7 @@ int prx_vit_backward_a_impl(PrxVit* v, const float* cutouts, const float* mm, co
     for (int l = v->layers - 1; l >= 0; --l) {
         VitLayer& y = v->L[l];
         // the class-token tail (see the forward): the gradient entering the last block is non-zero on the class-token rows only
-        const bool tail = l == v->layers - 1;
+        const bool tail = v->cls_tail && l == v->layers - 1;
         const int rows = tail ? n : R;
         const int ldt = tail ? T * W : W;
         // MLP: x_next = x_mid + c_proj(quickgelu(c_fc(ln_2(x_mid))))

@@ -361,8 +361,11 @@ class MakeCutouts(nn.Module):
             self.cutn, S, self.generator, self.iteration, self.noise_fac, fill=self.fill, aspect=self.aspect_width)
         if self.noise_fac and prm.get("noise") is None and "noise_seed" not in prm:
             # the reference's randn_like (pixray.py:510) is drawn inside the stage-B kernel: one Philox key per cutout and
-            # iteration, from a stream of its own so that the augmentation draws above stay where they were
-            prm = dict(prm, noise_seed=torch.randint(1, 2 ** 31 - 1, (self.cutn,), generator=self._noise_keys()))
+            # iteration, from a stream of its own so that the augmentation draws above stay where they were.  53-bit keys (what a
+            # float64 descriptor word holds exactly; both Philox key words are used): no birthday collisions over a run's
+            # ~1e5 (cutout, iteration) draws.  The draws do not follow torch's device RNG state the way the reference's
+            # randn_like does: same seed -> same run here, but not the reference's noise field (statistically equivalent)
+            prm = dict(prm, noise_seed=torch.randint(1, 2 ** 53 - 1, (self.cutn,), generator=self._noise_keys()))
         self.last_params = prm
         desc = build_descriptors(prm, S, self.conventions)
         self.transforms = desc          # this iteration's geometry (opaque, like the reference's composed 3x3 cache)
@@ -394,7 +397,7 @@ class MakeCutouts(nn.Module):
             desc = build_cached_descriptors(self.transforms, self.cutn, S, bool(prm["reflect"]), float(prm["fill"]), facs, asp,
                                             self.conventions)
             if self.noise_fac:
-                desc[:, 32] = torch.randint(1, 2 ** 31 - 1, (self.cutn,), generator=self._noise_keys()).double()    # noise drawn in the kernel
+                desc[:, 32] = torch.randint(1, 2 ** 53 - 1, (self.cutn,), generator=self._noise_keys()).double()    # noise drawn in the kernel
             return ops.make_cutouts(input, desc[lo:hi].contiguous().to(input.device), None, S, base_size(S, asp), spot_mask)
         if not getattr(self, "_prepared", False):
             self.prepare()

@@ -223,16 +223,22 @@ class _ClipEncodeFn(torch.autograd.Function):
     differentiates.  Nothing is ever differentiated through another call's activations."""
 
     @staticmethod
-    def forward(ctx, cutouts, handle, group, comm=None):
+    def forward(ctx, cutouts, handle, group, comm=None, fixed_range=None):
         _need_cuda(cutouts)
         cutouts = cutouts.contiguous().float()
         n = cutouts.shape[0]
         R = handle.cfg.input_resolution
         assert cutouts.shape[1:] == (3, R, R), f"perceptor expects [n,3,{R},{R}] cutouts"
         dev = cutouts.device
-        mm = torch.empty(2, device=dev)
-        call(handle.abi + "_minmax", handle.h, cutouts, n, mm, _stream())
-        if group is not None or comm is not None:
+        ctx.fixed_range = fixed_range is not None
+        if fixed_range is not None:
+            # a caller-given input range (slip.py:21-36 with input_range, or images that are already in [0, 1]): no batch min / max,
+            # nothing to exchange between ranks, and no gradient through the range in the backward
+            mm = torch.tensor([float(fixed_range[0]), float(fixed_range[1])], device=dev)
+        else:
+            mm = torch.empty(2, device=dev)
+            call(handle.abi + "_minmax", handle.h, cutouts, n, mm, _stream())
+        if fixed_range is None and (group is not None or comm is not None):
             # batch-global renorm couples every cutout (slip.py:21-36): min/max over all ranks -- on the C-ABI one-shot exchange
             # (csrc/comm.hip) when the session has one, else torch.distributed (RCCL)
             mm[0].neg_()
@@ -266,18 +272,21 @@ class _ClipEncodeFn(torch.autograd.Function):
             ctx.generation = handle.generation
         acc = torch.empty(4, device=dev, dtype=torch.float64)
         call(handle.abi + "_backward_reduce", handle.h, cutouts, mm, g, acc, _stream())
-        if ctx.comm is not None:
+        if ctx.fixed_range:
+            acc.zero_()                       # the range is a constant of the call: no d/dmin, d/dmax terms
+        elif ctx.comm is not None:
             ctx.comm.all_reduce_(acc, "sum")
         elif ctx.group is not None:
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=ctx.group)
         gc = torch.empty_like(cutouts)
         call(handle.abi + "_backward_finish", handle.h, cutouts, mm, acc, gc, _stream())
-        return gc, None, None, None
+        return gc, None, None, None, None
 
 
-def clip_encode_image(cutouts, handle: ClipVitHandle, group=None, comm=None):
-    return _ClipEncodeFn.apply(cutouts, handle, group, comm)
+def clip_encode_image(cutouts, handle: ClipVitHandle, group=None, comm=None, fixed_range=None):
+    """`fixed_range` = (lo, hi): renormalise with this range instead of the batch's min / max (slip.py:21-36 `input_range`)"""
+    return _ClipEncodeFn.apply(cutouts, handle, group, comm, fixed_range)
 
 
 class _ClipTextCfg(ctypes.Structure):
@@ -497,8 +506,8 @@ _TICKETS = {}
 
 
 def _ticket(device):
-    """the prompt kernel's "last workgroup adds up" counter: zero on entry, zero again on exit -- one resident word per
-    (device, stream)"""
+    """the prompt kernel's "last workgroup adds up" counter: a wrapping ticket (atomicInc modulo the grid), zero whenever no
+    launch is in flight -- one resident word per (device, stream); a process uses a handful of streams, so the table stays small"""
     key = (str(device), _stream())
     t = _TICKETS.get(key)
     if t is None:

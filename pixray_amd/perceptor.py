@@ -27,15 +27,44 @@ class ClipVitPerceptor:
         else:
             self.handle = ops.ClipVitHandle(cfg, params, max_batch, self.device, precision=precision)
 
+    CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # slip.py:55
+    CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
     def preprocess(self, imgs, input_range=None):
-        raise NotImplementedError("preprocessing (slip.py:21-42,58-60) is fused into encode_image on this path")
+        """slip.py:58-60: `adjust_range(imgs, [0, 1], input_range)` (slip.py:21-42: the batch's own min / max when no range is
+        given), torchvision `Resize(R)` (shorter side to R, bilinear, tensors are not antialiased) + `CenterCrop(R)` +
+        `Normalize(mean, std)`.  Plain differentiable tensor arithmetic on the caller's device: it is not on the loop's path
+        (the loop's `encode_image` fuses range + normalisation into the tower's first kernel); it exists so that a caller who
+        preprocesses once and encodes with `apply_preprocess=False`, as the reference allows, finds the same two methods."""
+        import torch.nn.functional as F
+        imgs = imgs.float()
+        lo = imgs.min() if input_range is None else torch.as_tensor(float(input_range[0]), device=imgs.device)
+        x = imgs - lo
+        hi = x.max() if input_range is None else torch.as_tensor(float(input_range[1]), device=imgs.device) - lo
+        x = torch.where(hi != 0, x / torch.where(hi != 0, hi, torch.ones_like(hi)), x)       # slip.py:32-33: divided only when the span is not 0
+        R = self.input_resolution
+        h, w = x.shape[-2:]
+        if min(h, w) != R:
+            nh, nw = (R, max(R, int(R * w / h))) if h <= w else (max(R, int(R * h / w)), R)
+            x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=False)
+            h, w = nh, nw
+        top, left = int(round((h - R) / 2.0)), int(round((w - R) / 2.0))
+        x = x[..., top:top + R, left:left + R]
+        mean = torch.tensor(self.CLIP_MEAN, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(self.CLIP_STD, device=x.device).view(1, 3, 1, 1)
+        return (x - mean) / std
 
     def encode_image(self, imgs, input_range=None, apply_preprocess=True):
-        """slip.py:62-66.  `input_range` is ignored exactly as the reference ignores it (slip.py:64)."""
-        if not apply_preprocess:
-            raise NotImplementedError("apply_preprocess=False is not supported by the fused path")
+        """slip.py:62-66.  `input_range` is ignored exactly as the reference ignores it (slip.py:64).  With
+        `apply_preprocess=False` the images are taken as already preprocessed ([n, 3, R, R], normalised): the tower's first kernel
+        fuses `(x - lo) / (hi - lo)` and the channel normalisation, so they are handed to it un-normalised with the fixed range
+        (0, 1) -- the same values enter the patch embedding, and the gradient flows back through both affine maps."""
         if imgs.shape[0] > self.handle.max_batch:
             raise ValueError(f"batch {imgs.shape[0]} exceeds the perceptor capacity {self.handle.max_batch}")
+        if not apply_preprocess:
+            mean = torch.tensor(self.CLIP_MEAN, device=imgs.device).view(1, 3, 1, 1)
+            std = torch.tensor(self.CLIP_STD, device=imgs.device).view(1, 3, 1, 1)
+            return ops.clip_encode_image(imgs.float() * std + mean, self.handle, fixed_range=(0.0, 1.0))
         return ops.clip_encode_image(imgs, self.handle, self.group, getattr(self, "comm", None))
 
     # -- text side (slip.py:68-74) ---------------------------------------------------------------------------------

@@ -33,7 +33,8 @@ class VqganDrawer(DrawingInterface):
         self.weight_seed = getattr(settings, "weight_seed", 0)
         self.precision = getattr(settings, "precision", None)             # None = "fp16" | "bf16" | "f32" (exact-f32 MFMA parity mode)
         self.z = None
-        self.gumbel = False          # set by load_taming for GumbelVQ checkpoints (vqgan.py:149-153)
+        # GumbelVQ (vqgan.py:149-153): set by load_taming from the yaml's target, or by the caller of a ready state dict
+        self.gumbel = bool(getattr(settings, "vqgan_gumbel", False))
         self._fused_clamp = False
 
     def load_model(self, settings, device):
@@ -101,11 +102,24 @@ class VqganDrawer(DrawingInterface):
         if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
             raise ValueError(f"expected an image tensor [1,3,H,W] in [-1,1], got {tuple(t.shape)}")
         if self.gumbel:
-            # taming's GumbelQuantize encodes through `quantize.proj` logits + gumbel_softmax (vqgan.py:175-185 via
-            # GumbelVQ.encode), not through nearest-codebook lookup; those weights are not on the decode path and are
-            # dropped on load, so producing a z here would silently be a different z
-            raise NotImplementedError("init_image / overlay / z-label encoding is not implemented for GumbelVQ checkpoints "
-                                      "(decode / synth is); use a VQModel checkpoint for image-initialised runs")
+            # taming's GumbelVQ.encode (vqgan.py:175-185): Encoder -> quant_conv -> GumbelQuantize, which in eval mode is
+            # one_hot(argmax(proj(h) + Gumbel noise)) @ embed -- `F.gumbel_softmax(logits, tau, dim=1, hard=True)` draws its noise
+            # in eval mode too.  The encoder and quant_conv run on the HIP runner (the latent BEFORE its nearest-code step); the
+            # 1x1 logits projection, the noise (torch's generator, as the reference's) and the code lookup are three tensor ops
+            # on a [n_embed, h*w] matrix, once per init / overlay -- not on the iteration's path
+            sd = self.state_dict or {}
+            if "quantize.proj.weight" not in sd:
+                raise KeyError("the GumbelVQ state dict has no `quantize.proj.*` entries: cannot encode an image "
+                               "(checkpoints.load_taming keeps them)")
+            _, _, pre = ops.vqgan_encode(t.to(self.device), self._encoder(), return_pre=True)
+            wp = sd["quantize.proj.weight"].to(self.device).float().reshape(self.cfg.n_embed, -1)
+            bp = sd["quantize.proj.bias"].to(self.device).float()
+            logits = torch.einsum("nc,bchw->bnhw", wp, pre) + bp.view(1, -1, 1, 1)
+            gumbels = -torch.empty_like(logits).exponential_().log()                 # F.gumbel_softmax's own draw
+            idx = (logits + gumbels).argmax(dim=1)                                     # hard=True: the forward value is the one-hot
+            cb = self._params["quantize.embedding.weight"].to(self.device)
+            self.last_encode_indices = idx.reshape(-1).int()
+            return cb[idx].permute(0, 3, 1, 2).contiguous()
         z, idx = ops.vqgan_encode(t.to(self.device), self._encoder())
         self.last_encode_indices = idx
         return z

@@ -157,41 +157,19 @@ def test_handles_refuse_weights_whose_shapes_do_not_fit_the_configuration(emu):
 
 
 def test_cutout_noise_drawn_in_the_kernel(emu):
-    """pixray.py:508-510 (`batch + fac * randn_like(batch)`) without a noise tensor: the stage-B kernel draws N(0,1) itself
-    (Philox4x32-10 keyed by descriptor word 32, counter = pixel index, Box-Muller).  Zero canvas, identity geometry, factor 1:
-    the output IS the noise -- moments, independence of channels / neighbours / cutouts, same key -> same bits, and a shard of
-    the batch sees the draws the whole batch sees"""
-    from pixray_amd import cutouts as pc, ops
-    n, S = 6, 64
-    desc = torch.zeros(n, pc.DESC_WORDS, dtype=torch.float64)
-    desc[:, 0:9] = torch.eye(3, dtype=torch.float64).reshape(9); desc[:, 9:18] = desc[:, 0:9]
-    desc[:, 18] = pc.MODE_IDENT; desc[:, 19] = pc.MODE_IDENT
-    desc[:, 25] = 1.0
-    desc[:, 28:32] = torch.tensor([0.0, 0.0, float(S), float(S)], dtype=torch.float64)
-    desc[:, 32] = torch.tensor([11, 12, 13, 2 ** 31 - 2, 15, 11], dtype=torch.float64)        # first and last cutout share a key
-    img = torch.zeros(1, 3, S, S)
-    z = ops.make_cutouts(img, desc, None, S)
-    assert z.shape == (n, 3, S, S) and torch.isfinite(z).all()
-    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
-    assert abs(float((z ** 3).mean())) < 0.06 and abs(float((z ** 4).mean()) - 3.0) < 0.15
-    assert torch.equal(z[0], z[5]) and not torch.equal(z[0], z[1])
-    flat = z[:5].reshape(5, 3, -1)
-    c = lambda a, b: abs(float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())))
-    assert c(flat[:, 0], flat[:, 1]) < 0.02 and c(flat[:, 0], flat[:, 2]) < 0.02 and c(flat[:, 1], flat[:, 2]) < 0.02   # channels
-    assert c(flat[:, :, 1:], flat[:, :, :-1]) < 0.02 and c(flat[0], flat[1]) < 0.03                                      # neighbours, cutouts
-    assert torch.equal(ops.make_cutouts(img, desc, None, S), z)
-    assert torch.equal(ops.make_cutouts(img, desc[2:4].contiguous(), None, S), z[2:4])
-    desc[:, 32] = 0.0                                                                           # no key, no tensor: no noise
-    assert float(ops.make_cutouts(img, desc, None, S).abs().max()) == 0.0
-    # the module draws one key per cutout and iteration from a stream of its own: the augmentation draws stay where they were
-    mk = pc.MakeCutouts(S, 4, noise_fac=0.1, generator=torch.Generator().manual_seed(5))
-    mk.prepare(iteration=0, fill=0.5)
-    k0 = mk.last_params["noise_seed"].clone()
-    ref = pc.sample_cutout_params(4, S, torch.Generator().manual_seed(5), 0, 0.1, fill=0.5)
-    assert all(torch.equal(mk.last_params[k], v) for k, v in ref.items() if isinstance(v, torch.Tensor))
-    mk(torch.rand(1, 3, S, S))
-    mk.prepare(iteration=1, fill=0.5)
-    assert not torch.equal(mk.last_params["noise_seed"], k0)
+    """the in-kernel Philox noise of the stage-B cutout kernel on the emulated kernels (the checks live in tests/test_path_gpu.py,
+    where the device runs them too and compares its draws with these)"""
+    emu.tp.cutout_noise_checks()
+
+
+def test_perceptor_preprocess_surface_on_the_emulated_tower(emu):
+    """CLIP_Base.preprocess / apply_preprocess=False (slip.py:58-66) against the fused default path"""
+    emu.tp.perceptor_preprocess_checks()
+
+
+def test_gumbel_vq_encode_on_the_emulated_encoder(emu):
+    """GumbelVQ.encode (vqgan.py:174-185) behind VqganDrawer.init_from_tensor"""
+    emu.tp.gumbel_vq_encode_checks()
 
 
 def test_dma_rings_under_the_eager_completion_model_too(emu):

@@ -597,6 +597,49 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
         checkpoints.vqgan_config_from_taming_yaml(dict(model=dict(target="taming.models.other.Thing", params={})))
 
 
+def test_clip_torchscript_archive_adapter(tmp_path):
+    """slip.py:175 `clip.load(name)` reads OpenAI's TorchScript archives: checkpoints.clip_state_dict_from_archive takes
+    `torch.jit.load(path).state_dict()` (or a pickled state dict), clip_config_from_state_dict reads the ViT geometry off the shapes
+    the way clip.model.build_model does, and the result passes the visual adapter"""
+    import torch.nn as nn
+    from pixray_amd import checkpoints, weights
+    cfg = weights.CLIP_CONFIGS["tiny-B/32"]
+    vis = weights.synthetic_clip_vit_params(cfg, 0)
+
+    def build(prefix_params):
+        root = nn.Module()
+        for name, t in prefix_params.items():
+            m = root
+            parts = name.split(".")
+            for p_ in parts[:-1]:
+                if not hasattr(m, p_):
+                    m.add_module(p_, nn.Module())
+                m = getattr(m, p_)
+            m.register_parameter(parts[-1], nn.Parameter(t.clone().half(), requires_grad=False))      # the archives hold fp16 weights
+        return root
+
+    class Wrap(nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.visual = inner
+
+        def forward(self, x):
+            return x
+    mod = Wrap(build(vis))
+    path = str(tmp_path / "ViT-tiny.pt")
+    torch.jit.save(torch.jit.script(mod), path)
+    sd = checkpoints.clip_state_dict_from_archive(path)
+    assert "visual.conv1.weight" in sd and sd["visual.proj"].dtype == torch.float16
+    got = checkpoints.clip_config_from_state_dict(sd, "tiny-B/32")
+    assert (got.input_resolution, got.patch_size, got.width, got.layers, got.heads, got.output_dim) == \
+           (cfg.input_resolution, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.output_dim)
+    params = checkpoints.clip_visual_from_openai(sd, got)
+    assert all(torch.allclose(params[k], vis[k].half().float()) for k in vis)
+    plain = str(tmp_path / "plain.pt")
+    torch.save({"state_dict": {"visual." + k: v for k, v in vis.items()}}, plain)
+    assert set(checkpoints.clip_state_dict_from_archive(plain)) == {"visual." + k for k in vis}
+
+
 def _kernel_scratch(src: str, obj: str = None):
     """[(kernel name, scratch bytes per lane)] of every gfx950 kernel of a .hip source.  Read from the object file the build
     left beside it (the AMDGPU metadata note of the device code object inside its fat binary: a second or two) when that object

@@ -9,9 +9,11 @@ Tolerances (stated per check):
     and cosine >= 0.999 (BASELINE.md §3 targets: 2e-2 / 0.999).
 """
 import math
+import os
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +83,74 @@ def test_make_cutouts_vs_oracle(cutn, S, HW, it, kind):
         assert (d > 1e-2 * scale).float().mean().item() < 1.5e-2
         assert rel_l2(gd, gref) < 2e-2, rel_l2(gd, gref)      # measured 5e-3 .. 1.3e-2
         assert cosine(gd, gref) > 0.9998
+
+
+def cutout_noise_checks():
+    """pixray.py:508-510 (`batch + fac * randn_like(batch)`) without a noise tensor: the stage-B kernel draws N(0,1) itself
+    (Philox4x32-10 keyed by descriptor word 32, counter = pixel index, Box-Muller).  Zero canvas, identity geometry, factor 1:
+    the output IS the noise -- moments, independence of channels / neighbours / cutouts, same key -> same bits, and a shard of
+    the batch sees the draws the whole batch sees.  Device-agnostic (DEV): the emulator suite calls it on CPU tensors.
+    Returns the draws."""
+    n, S = 6, 64
+    desc = torch.zeros(n, pc.DESC_WORDS, dtype=torch.float64)
+    desc[:, 0:9] = torch.eye(3, dtype=torch.float64).reshape(9); desc[:, 9:18] = desc[:, 0:9]
+    desc[:, 18] = pc.MODE_IDENT; desc[:, 19] = pc.MODE_IDENT
+    desc[:, 25] = 1.0
+    desc[:, 28:32] = torch.tensor([0.0, 0.0, float(S), float(S)], dtype=torch.float64)
+    desc[:, 32] = torch.tensor([11, 12, 13, 2 ** 52 + 12345, 15, 11], dtype=torch.float64)     # first and last cutout share a key; one key above 2^32
+    desc = desc.to(DEV)
+    img = torch.zeros(1, 3, S, S, device=DEV)
+    z = ops.make_cutouts(img, desc, None, S)
+    assert z.shape == (n, 3, S, S) and torch.isfinite(z).all()
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    assert abs(float((z ** 3).mean())) < 0.06 and abs(float((z ** 4).mean()) - 3.0) < 0.15
+    assert torch.equal(z[0], z[5]) and not torch.equal(z[0], z[1])
+    flat = z[:5].reshape(5, 3, -1)
+    c = lambda a, b: abs(float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std())))
+    assert c(flat[:, 0], flat[:, 1]) < 0.02 and c(flat[:, 0], flat[:, 2]) < 0.02 and c(flat[:, 1], flat[:, 2]) < 0.02   # channels
+    assert c(flat[:, :, 1:], flat[:, :, :-1]) < 0.02 and c(flat[0], flat[1]) < 0.03                                      # neighbours, cutouts
+    assert torch.equal(ops.make_cutouts(img, desc, None, S), z)
+    assert torch.equal(ops.make_cutouts(img, desc[2:4].contiguous(), None, S), z[2:4])                                   # a shard sees the whole batch's draws
+    d0 = desc.clone(); d0[:, 32] = 0.0                                                          # no key, no tensor: no noise
+    assert float(ops.make_cutouts(img, d0, None, S).abs().max()) == 0.0
+    # the module draws one key per cutout and iteration from a stream of its own: the augmentation draws stay where they were
+    mk = pc.MakeCutouts(S, 4, noise_fac=0.1, generator=torch.Generator().manual_seed(5))
+    mk.prepare(iteration=0, fill=0.5)
+    k0 = mk.last_params["noise_seed"].clone()
+    ref = pc.sample_cutout_params(4, S, torch.Generator().manual_seed(5), 0, 0.1, fill=0.5)
+    assert all(torch.equal(mk.last_params[k], v) for k, v in ref.items() if isinstance(v, torch.Tensor))
+    mk(torch.rand(1, 3, S, S, device=DEV))
+    mk.prepare(iteration=1, fill=0.5)
+    assert not torch.equal(mk.last_params["noise_seed"], k0)
+    assert int(mk.last_params["noise_seed"].max()) < 2 ** 53                                    # a key is one exact descriptor word (float64)
+    # the noise has the reference's scale: fac * N(0, 1) on top of the cutouts (statistics of a larger batch)
+    desc2 = desc.clone(); desc2[:, 25] = 0.1
+    z2 = ops.make_cutouts(img, desc2, None, S)
+    assert abs(float(z2.std()) - 0.1) < 0.003
+    return z.detach().cpu()
+
+
+def test_cutout_noise_drawn_in_the_kernel_on_the_device():
+    """the branch of the stage-B kernel that bench.py and Session.train run (no noise tensor: in-kernel Philox) ON THE DEVICE --
+    every parity harness hands an explicit noise tensor and takes the other branch.  Moments / independence / key and shard
+    invariance as on the emulation, and the device's draws against the emulated kernel's for the same keys: the Philox integers are
+    exact on both, so the normals agree to the rounding of logf / sincosf / sqrtf (a few ulps of values <= 6)."""
+    z_dev = cutout_noise_checks()
+    import _emu
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None:
+        pytest.skip("no host toolchain for tools/hipemu on this box: device-vs-emulator comparison not run")
+    global DEV
+    with _emu.enable():
+        DEV = "cpu"
+        try:
+            z_emu = cutout_noise_checks()
+        finally:
+            DEV = "cuda"
+    d = (z_dev - z_emu).abs()
+    same = float((z_dev == z_emu).float().mean())
+    print(f"device vs emulated Philox normals: max |diff| {float(d.max()):.3e}, bit-identical {100 * same:.2f} %")
+    assert float(d.max()) < 4e-6 and same > 0.5
 
 
 @pytest.mark.parametrize("flip", ["crop_align_corners", "perspective_align_corners", "affine_align_corners"])
@@ -229,6 +299,123 @@ def test_clip_vit_vs_oracle(name, n):
     assert cosine(out, ref) > 0.9995
     assert rel_l2(gd, gref) < 3e-2, rel_l2(gd, gref)
     assert cosine(gd, gref) > 0.999
+
+
+def perceptor_preprocess_checks():
+    """CLIP_Base.preprocess / encode_image(apply_preprocess=False) (slip.py:58-66): preprocessing once and encoding without it gives
+    the embeddings -- and the image gradient -- of the fused default path; a given input_range replaces the batch's min / max;
+    a non-square, larger image is resized on its shorter side and centre-cropped"""
+    from pixray_amd.perceptor import get_clip_perceptor
+    perc = get_clip_perceptor("tiny-B/32", DEV, max_batch=4, precision="f32")
+    R = perc.input_resolution
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(3, 3, R, R, generator=g) * 1.7 - 0.3).to(DEV).requires_grad_(True)
+    gout = torch.randn(3, perc.output_dim, generator=g).to(DEV)
+    e0 = perc.encode_image(x)
+    (g0,) = torch.autograd.grad(e0, x, gout)
+    p = perc.preprocess(x)
+    lo, hi = float(x.detach().min()), float(x.detach().max())
+    mean = torch.tensor(perc.CLIP_MEAN, device=DEV).view(1, 3, 1, 1); std = torch.tensor(perc.CLIP_STD, device=DEV).view(1, 3, 1, 1)
+    assert torch.allclose(p, ((x - lo) / (hi - lo) - mean) / std, atol=1e-6)          # slip.py:21-42 + Normalize, literally
+    e1 = perc.encode_image(p, apply_preprocess=False)
+    (g1,) = torch.autograd.grad(e1, x, gout)
+    assert rel_l2(e1, e0) < 1e-5, rel_l2(e1, e0)
+    # gradient: the default path also differentiates the batch min / max (two pixels); through preprocess() autograd carries them
+    assert rel_l2(g1, g0) < 1e-4, rel_l2(g1, g0)
+    p2 = perc.preprocess(x.detach(), input_range=(-0.5, 2.0))
+    assert torch.allclose(p2, ((x.detach() + 0.5) / 2.5 - mean) / std, atol=1e-6)
+    big = torch.rand(2, 3, 2 * R, 3 * R, generator=g).to(DEV)
+    pb = perc.preprocess(big)
+    assert pb.shape == (2, 3, R, R) and torch.isfinite(perc.encode_image(pb, apply_preprocess=False)).all()
+
+
+def test_perceptor_preprocess_and_apply_preprocess_false():
+    perceptor_preprocess_checks()
+
+
+def gumbel_vq_encode_checks():
+    """VqganDrawer.init_from_tensor / get_z_from_tensor on a GumbelVQ checkpoint (vqgan.py:149-153, 174-185): taming's
+    GumbelQuantize in eval mode = codebook[argmax(proj(h) + Gumbel noise)] with F.gumbel_softmax's own noise draw -- the same
+    codes as that expression evaluated in torch on the runner's pre-quantisation latent under the same generator state"""
+    import types
+    from pixray_amd.vqgan_drawer import VqganDrawer
+    cfg = weights.VQGAN_CONFIGS["tiny_f4"]
+    sd = dict(weights.synthetic_vqgan_params(cfg, 2))
+    sd.update(weights.synthetic_vqgan_encoder_params(cfg, 2, codebook=sd["quantize.embedding.weight"]))
+    g = torch.Generator().manual_seed(8)
+    sd["quantize.proj.weight"] = torch.randn(cfg.n_embed, cfg.embed_dim, 1, 1, generator=g) * 3.0
+    sd["quantize.proj.bias"] = torch.randn(cfg.n_embed, generator=g)
+    st = types.SimpleNamespace(vqgan_model="tiny_f4", size=(32, 32), vqgan_state_dict=sd, vqgan_gumbel=True, precision="f32")
+    dr = VqganDrawer(st)
+    dr.load_model(st, DEV)
+    img = (torch.rand(1, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    torch.manual_seed(77)
+    dr.init_from_tensor(img)
+    z = dr.z.detach().clone()
+    assert z.shape == (1, cfg.embed_dim, 8, 8) and dr.z.requires_grad
+    # the reference expression on the same latent, same generator state
+    _, _, pre = ops.vqgan_encode(img, dr._encoder(), return_pre=True)
+    torch.manual_seed(77)
+    logits = F.conv2d(pre, sd["quantize.proj.weight"].to(DEV), sd["quantize.proj.bias"].to(DEV))
+    one_hot = F.gumbel_softmax(logits, tau=1.0, dim=1, hard=True)
+    z_ref = torch.einsum("bnhw,nd->bdhw", one_hot, sd["quantize.embedding.weight"].to(DEV))
+    assert torch.equal(dr.last_encode_indices.long().cpu(), one_hot.argmax(1).reshape(-1).cpu())
+    assert torch.allclose(z, z_ref, atol=1e-6)
+    out = dr.synth(0)                                   # ... and the drawer decodes from it
+    assert out.shape == (1, 3, 32, 32) and torch.isfinite(out).all()
+    st2 = types.SimpleNamespace(vqgan_model="tiny_f4", size=(32, 32), vqgan_gumbel=True,
+                                vqgan_state_dict={k: v for k, v in sd.items() if not k.startswith("quantize.proj")})
+    d2 = VqganDrawer(st2); d2.load_model(st2, DEV)
+    with pytest.raises(KeyError, match="quantize.proj"):
+        d2.init_from_tensor(img)
+
+
+def test_gumbel_vq_checkpoints_encode_images():
+    gumbel_vq_encode_checks()
+
+
+def vit_switch_ab(env_name, precision, name="tiny-B/32", n=4):
+    """one ViT tower forward + gradient with a debug switch of the runner off and on (read at handle creation): (embeddings,
+    gradient) of both runs"""
+    cfg = weights.CLIP_CONFIGS[name]
+    params = weights.synthetic_clip_vit_params(cfg, 5)
+    g = torch.Generator().manual_seed(6)
+    cut = torch.rand(n, 3, cfg.input_resolution, cfg.input_resolution, generator=g)
+    gout = torch.randn(n, cfg.output_dim, generator=g)
+    res = []
+    old = os.environ.get(env_name)
+    try:
+        for val in ("0", "1"):
+            os.environ[env_name] = val
+            h = ops.ClipVitHandle(cfg, params, max_batch=n, device=DEV, precision=precision)
+            cd = cut.to(DEV).requires_grad_(True)
+            out = ops.clip_encode_image(cd, h)
+            (gd,) = torch.autograd.grad(out, cd, gout.to(DEV))
+            res.append((out.detach().float().cpu(), gd.detach().float().cpu()))
+    finally:
+        if old is None:
+            os.environ.pop(env_name, None)
+        else:
+            os.environ[env_name] = old
+    return res
+
+
+def test_vit_class_token_tail_is_the_same_tower():
+    """PRX_VIT_CLS_TAIL=0 runs the last block on every token row, the default only on the class-token rows that ln_post reads:
+    the same embeddings and the same gradient, to fp32 round-off in the exact-f32 mode (other tile shapes sum K in another
+    order) and to 16-bit operand rounding in the half mode"""
+    (e0, g0), (e1, g1) = vit_switch_ab("PRX_VIT_CLS_TAIL", "f32")
+    assert rel_l2(e1, e0) < 2e-6 and rel_l2(g1, g0) < 2e-5, (rel_l2(e1, e0), rel_l2(g1, g0))
+    (e0, g0), (e1, g1) = vit_switch_ab("PRX_VIT_CLS_TAIL", "fp16")
+    assert rel_l2(e1, e0) < 2e-3 and rel_l2(g1, g0) < 5e-3, (rel_l2(e1, e0), rel_l2(g1, g0))
+
+
+def test_vit_lean_streams_ab():
+    """PRX_LEAN=0 (fp32 residual / gradient streams with 16-bit twins) against the half mode's default (streams in IEEE half
+    only): the bisection switch of the lean layout keeps working, and the two layouts differ by stream rounding only"""
+    (e0, g0), (e1, g1) = vit_switch_ab("PRX_LEAN", "fp16")
+    assert rel_l2(e1, e0) < 3e-3 and rel_l2(g1, g0) < 1e-2, (rel_l2(e1, e0), rel_l2(g1, g0))
+    assert not torch.equal(e0, e1)
 
 
 # ------------------------------------------------------------------------------------------ VQGAN

@@ -210,6 +210,7 @@ static inline unsigned long long __activemask() { return hipemu::wave_live_mask(
 
 // ---- atomics (single OS thread: plain read-modify-write) ------------------------------------------------------------------
 template <typename T, typename U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (T)v; return o; }
+static inline unsigned atomicInc(unsigned* p, unsigned wrap) { unsigned o = *p; *p = o >= wrap ? 0u : o + 1u; return o; }
 template <typename T, typename U> static inline T atomicSub(T* p, U v) { T o = *p; *p = o - (T)v; return o; }
 template <typename T, typename U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
 template <typename T, typename U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
