@@ -9,6 +9,7 @@
 // accumulator tiles.  The next K tile's global loads are issued before the
 // MFMAs of the current one.
 #include "gemm_epi.h"
+#include "norms.h"
 #include <vector>
 #include <mutex>
 #include <stdlib.h>
@@ -1058,7 +1059,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     PRX_REQUIRE((d.act != PRX_ACT_MUL_DQUICKGELU && d.act != PRX_ACT_MUL_RELUMASK && d.act != PRX_ACT_RELUMASK_POST) || d.aux,
                 "gemm: MUL_DQUICKGELU / MUL_RELUMASK / RELUMASK_POST need aux");
     PRX_REQUIRE(d.act != PRX_ACT_RELUMASK_POST || d.resid, "gemm: RELUMASK_POST masks product + residual: it needs resid");
-    PRX_REQUIRE(!d.f32 || (!d.gn_stats && !d.gnb_x), "gemm: the fused GroupNorm statistics are a bf16-path epilogue");
+    // exact mode: the fused GroupNorm statistics live in the fp32-operand fit kernels (gemmfit_f32.hip); a problem those do not take
+    // runs without them here and gets the statistics from the norm kernels' own pass right after (gemm_launch_one below)
     PRX_REQUIRE(!d.f32 || d.row16 == 0, "gemm: 16-bit residual / GroupNorm-input streams (row16) belong to the 16-bit operand modes");
 
     // ---- tile / split-K selection (tools/gemm_tune.py sweeps; MI355X: 256 CUs) -------------------------------
@@ -1112,7 +1114,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     if (BM == 256 && BN == 256 && !prx_gemm8p_eligible(d)) { BM = 128; BN = 128; }     // row-major 16-bit operands, K % 128 == 0 only
     if (fit_tile && !prx_gemmfit_eligible(d, BM, BN)) { fit_tile = false; if (!fourwave_tile(BM, BN)) { BM = 128; BN = 128; } }
-    if (d.f32 && BM == 256) BM = 128;    // the exact mode has the three 4-wave tiles only
+    if (d.f32 && BM == 256 && !fit_tile) BM = 128;    // the exact mode's 4-wave family has three tiles only (256 x 128 is a fit tile)
     if (!fit_tile && BM == 256 && BN == 128) BM = 128;     // 256 x 128 exists as a fit tile only
     const int bk = d.f32 ? BKF : BK;
     GemmArgs a;
@@ -1157,8 +1159,19 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_REQUIRE(((uintptr_t)d.gnb_x % 16) == 0 && ((uintptr_t)d.gnb_gamma % 16) == 0 && ((uintptr_t)d.gnb_beta % 16) == 0,
                     "gemm: gnb operands must be 16-byte aligned");
     }
+    if (d.f32 && d.gn_stats && !fit_tile) {
+        // the 4-wave fp32 kernels have no statistics epilogue: the product without them, then the norm kernels' statistics pass over
+        // the result (what the runner would have launched had it not asked for the fusion)
+        PRX_REQUIRE(d.out_f32 && d.ldc_f32 == d.N && d.N == 32 * d.gn_gs, "gemm: fp32 GroupNorm statistics need a dense fp32 output with N == 32 * gn_gs");
+        GemmDesc d2 = d;
+        d2.gn_stats = nullptr; d2.gnb_x = nullptr; d2.gnb_fstats = nullptr; d2.gnb_gamma = d2.gnb_beta = nullptr;
+        int r = gemm_launch_one(d2, ws, ws_bytes, stream, ctx, use8p);
+        if (r) return r;
+        if (d.gnb_x) return prx_groupnorm_bwd_stats(d.out_f32, d.gnb_x, d.gnb_gamma, d.gnb_beta, d.gnb_fstats, d.gn_stats, 1, d.M, d.N, d.gnb_swish, d.gnb_eps, stream);
+        return prx_groupnorm_fwd(d.out_f32, nullptr, nullptr, d.gn_stats, nullptr, nullptr, 1, d.M, d.N, 0, 1e-6f, stream, /*zero_stats=*/0, /*stats_ready=*/0);
+    }
     if (d.gn_stats) {
-        PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && cx.use_glds,
+        PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && (cx.use_glds || d.f32),
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
     a.fit_flags = fit_tile ? (cx.fit_flags & (15 | 64)) : 0;   // gemmfit.hip A/B switches (PRX_FIT_FLAGS); bit 6: generic epilogues only
@@ -1184,7 +1197,10 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
 
     dim3 grid(tiles, splits);
-    if (d.f32) {
+    if (fit_tile && d.f32) {
+        int e = prx_gemmfit_launch(a, BM, BN, grid, stream);      // fp32-operand fit kernels (gemmfit_f32.hip)
+        if (e) return e;
+    } else if (d.f32) {
         if (BM == 128 && BN == 128) launch_f32<128, 128>(a, grid, stream);
         else if (BM == 128 && BN == 64) launch_f32<128, 64>(a, grid, stream);
         else launch_f32<64, 64>(a, grid, stream);

@@ -30,6 +30,27 @@ bool prx_gemmfit_eligible(const GemmDesc& d, int bm, int bn) {
     const int ks = ft->ks;
     const int wave_tn = ft->tn;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };       // null passes
+    if (d.f32) {
+        // the exact mode's fp32-operand kernels (FIT_EPI_F32: the decoder tiles): K tiles of 32 floats, a plain epilogue -- alpha,
+        // bias_n, fp32 residual, fp32 output(s); everything else stays with the 4-wave fp32 kernels
+        static const bool on = [] { const char* e = getenv("PRX_FIT_F32"); return !(e && atoi(e) == 0); }();
+        if (!on || bm % 80 == 0 || (bm == 256 && bn == 16)) return false;
+        bool stats32 = !d.gnb_x || d.gn_stats;
+        if (d.gn_stats) {
+            const int lpr = wave_tn / 8;
+            stats32 = (lpr & (lpr - 1)) == 0 && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && bn % d.gn_gs == 0 && al16(d.gnb_x) &&
+                      (!d.gnb_x || (!d.resid && d.gnb_fstats && d.gnb_gamma && d.gnb_beta && al16(d.gnb_gamma) && al16(d.gnb_beta)));
+        }
+        const bool epi = d.N % 8 == 0 && d.act == PRX_ACT_NONE && !d.bias_m && !d.aux && stats32 && !d.out_bf16_pre && d.row16 == 0 &&
+                         (d.out_f32 || d.out_bf16) && al16(d.bias_n) && al16(d.resid) && al16(d.out_f32) && al16(d.out_bf16) &&
+                         (!d.resid || d.ldr % 4 == 0) && (!d.out_f32 || d.ldc_f32 % 4 == 0) && (!d.out_bf16 || d.ldc_bf16 % 4 == 0);
+        const bool a_ok32 = d.a_mode == PRX_A_ROWMAJOR
+                                ? (unsigned long long)d.M * d.lda < (1ull << 31)
+                                : (d.a_mode == PRX_A_CONV3X3 && d.Cin % 32 == 0 && d.K == 9 * d.Cin && (d.up == 0 || d.up == 1) && d.H > 0 && d.W > 0 &&
+                                   d.M % (d.H * d.W) == 0 && (unsigned long long)d.M * d.lda < (1ull << 31));
+        return !d.a_is_f32 && epi && a_ok32 && d.K % (32 * ks) == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.M >= 1 &&
+               (unsigned long long)d.N * d.ldb < (1ull << 31);
+    }
     // the epilogue handles 8 consecutive columns per lane with 16-byte accesses
     const bool epi_ok = d.N % 8 == 0 && al16(d.bias_n) && al16(d.resid) && al16(d.aux) && al16(d.out_f32) && al16(d.out_bf16) &&
                         al16(d.out_bf16_pre) && (!d.resid || d.ldr % ((d.row16 & 1) ? 8 : 4) == 0) && (!d.aux || d.ldaux % 8 == 0) &&
@@ -153,6 +174,10 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a_in, int bm, int bn, dim3 
 #endif
     // the descriptor patterns of the two runners have kernels with a compile-time epilogue (gemmfit_spec_*.hip); bit 6 of the
     // switch word (PRX_FIT_FLAGS / override -8) keeps every launch on the generic kernels (A/B runs, tests of the generic path)
+    if (a.d.f32) {
+        PRX_REQUIRE(prx_gemmfit_launch_f32(a, bm, bn, grid, s, zp), "gemmfit: no fp32-operand kernel for a %d x %d tile", bm, bn);
+        return 0;
+    }
     if (!(a.fit_flags & 64)) {
         const int epi = prx_gemmfit_epi_kind(a.d);
         if (epi != FIT_EPI_GENERIC &&

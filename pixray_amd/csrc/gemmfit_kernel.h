@@ -46,6 +46,7 @@ bool prx_gemmfit_launch_spec_tower(const prx_gemm_dev::GemmArgs& a, int bm, int 
 bool prx_gemmfit_launch_spec_dec_a(const prx_gemm_dev::GemmArgs& a, int bm, int bn, int epi, dim3 grid, hipStream_t s, const bf16_t* zp);
 bool prx_gemmfit_launch_spec_dec_b(const prx_gemm_dev::GemmArgs& a, int bm, int bn, int epi, dim3 grid, hipStream_t s, const bf16_t* zp);
 bool prx_gemmfit_launch_spec_dec_c(const prx_gemm_dev::GemmArgs& a, int bm, int bn, int epi, dim3 grid, hipStream_t s, const bf16_t* zp);
+bool prx_gemmfit_launch_f32(const prx_gemm_dev::GemmArgs& a, int bm, int bn, dim3 grid, hipStream_t s, const bf16_t* zp);      // gemmfit_f32.hip
 
 namespace {
 using namespace prx_gemm_dev;
@@ -330,6 +331,7 @@ enum { FIT_EPI_GENERIC = 0,
        FIT_EPI_GN,         // OUT16 + the next GroupNorm's sums
        FIT_EPI_RES16_GN,   // RES16 + the next GroupNorm's sums
        FIT_EPI_GNB,        // OUT16 + a GroupNorm-backward's sums on its 16-bit input stream
+       FIT_EPI_F32,        // fp32 OPERANDS (the exact mode, v_mfma_f32_16x16x4_f32): alpha, bias_n, fp32 residual -> fp32 out(s)
        FIT_EPI_COUNT };
 
 __device__ __forceinline__ float fit_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -468,22 +470,148 @@ __device__ __forceinline__ void fit_finish_spec(const GemmArgs& p, float* const 
     if constexpr (STATS) fit_stats_tail<WGM, WGN, FN, KS>(d, fl + DUMP + 2 * NW * SLAB, gsa0, gsa1, gsb0, gsb1, tn, kg, wm, wn, lane);
 }
 
+// ---- the epilogue of the fp32-OPERAND kernels (FIT_EPI_F32: the exact mode's decoder products) ------------------------------
+// alpha, bias_n, an fp32 residual, one or two fp32 outputs (`out_f32`, and `out_bf16` -- which addresses fp32 data in this
+// mode, gemm.h -- when the caller wants the value in a second buffer).  Same staging as the specialised 16-bit epilogues; a lane's
+// 8 columns are two 16-byte accesses; the residual rows of slab i + 1 are fetched while slab i is finished.
+template <int WGM, int WGN, int FM, int FN, int KS>
+__device__ __forceinline__ void fit_finish_f32(const GemmArgs& p, float* const fl, f32x4 (&acc)[FM][FN], int tm, int tn, int wave, int kg,
+                                               int wt, int wm, int wn, int lane FIT_TRACE_ARG) {
+    constexpr int NWT = WGM * WGN, NW = NWT * KS;
+    constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN, TN = 16 * FN;
+    const GemmDesc& d = p.d;
+    const int l15 = lane & 15, kq = lane >> 4;
+    constexpr int DUMP = KS > 1 ? NW * FM * FN * 256 : 0;          // floats
+    fit_ksum<WGM, WGN, FM, FN, KS>(fl, acc, kg, wt, lane);
+    FIT_TRACE(4);
+    constexpr int LDW = TN + 4, LPR = TN / 8, RPP = 64 / LPR, NPASS = (16 + RPP - 1) / RPP;
+    constexpr int NOWN = (FM + KS - 1) / KS;
+    constexpr int NBUF = NOWN > 1 ? 2 : 1, SLAB = 16 * LDW;
+    float* const stage = fl + DUMP + wave * (2 * SLAB);
+    const int rbase = tm * BM + wm * (16 * FM), cbase = tn * BN + wn * TN;
+    const int lr0 = lane / LPR, lc = (lane - lr0 * LPR) * 8;
+    const int col = cbase + lc;
+    const bool col_ok = lane < RPP * LPR && col < d.N;
+    const int colc = col_ok ? col : 0;
+    const float alpha = d.alpha_dev ? d.alpha * *d.alpha_dev : d.alpha;
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d.bias_n) {
+        const float4 b0 = *reinterpret_cast<const float4*>(d.bias_n + colc), b1 = *reinterpret_cast<const float4*>(d.bias_n + colc + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
+    // wave-uniform switches: a residual, the next GroupNorm's sums of the output, or a GroupNorm-backward's sums (whose fp32
+    // input rows take the residual's place as the row operand; never both).  These kernels run tens of microseconds on the
+    // matrix pipes, so the fused sums are run-time branches here, not further instances
+    const bool do_stats = d.gn_stats != nullptr;
+    const bool gnb = do_stats && d.gnb_x != nullptr;
+    const bool has_resid = d.resid != nullptr && !gnb;
+    const bool has_row = has_resid || gnb;
+    const float* const rowp = gnb ? d.gnb_x : d.resid;
+    const int ldrow = gnb ? d.N : d.ldr;
+    GnbConst gc0{}, gc1{};
+    if (gnb) { gc0 = gnb_load(d, colc); gc1 = gnb_load(d, colc + 4); }
+    float gsa0 = 0.f, gsa1 = 0.f, gsb0 = 0.f, gsb1 = 0.f;
+    const int mlast = d.M - 1;
+    float* const o32 = d.out_f32;
+    float* const o2 = reinterpret_cast<float*>(d.out_bf16);
+    auto fetch = [&](int i, float4 (&r)[NPASS][2]) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            int lr = ps * RPP + lr0;
+            lr = lr < 15 ? lr : 15;
+            int row = rbase + i * 16 + lr;
+            row = row < mlast ? row : mlast;
+            const float* q = rowp + ((size_t)row * ldrow + colc);
+            r[ps][0] = *reinterpret_cast<const float4*>(q);
+            r[ps][1] = *reinterpret_cast<const float4*>(q + 4);
+        }
+    };
+    auto put = [&](int i, float* st) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(4 * kq + r) * LDW + j * 16 + l15] = acc[i][j][r];
+    };
+    float4 rnext[NPASS][2];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) rnext[ps][0] = rnext[ps][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        if (KS > 1 && i % KS != kg) continue;                      // wave-uniform
+        float* const st = stage + ((i / KS) % NBUF) * SLAB;
+        if (i < KS) { put(i, st); if (has_row) fetch(i, rnext); }
+        float4 rcur[NPASS][2];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) { rcur[ps][0] = rnext[ps][0]; rcur[ps][1] = rnext[ps][1]; }
+        if (i + KS < FM) {
+            put(i + KS, stage + (((i + KS) / KS) % NBUF) * SLAB);
+            if (has_row) fetch(i + KS, rnext);
+        }
+        /*hipemu:wave_sync*/
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int lr = ps * RPP + lr0, row = rbase + i * 16 + lr;
+            const bool ok = col_ok && lr < 16 && row < d.M;
+            const int lrc = lr < 15 ? lr : 15;
+            const float4 s0 = *reinterpret_cast<const float4*>(&st[lrc * LDW + lc]);
+            const float4 s1 = *reinterpret_cast<const float4*>(&st[lrc * LDW + lc + 4]);
+            float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float x[8] = {rcur[ps][0].x, rcur[ps][0].y, rcur[ps][0].z, rcur[ps][0].w, rcur[ps][1].x, rcur[ps][1].y, rcur[ps][1].z, rcur[ps][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] *= alpha;
+                v[e] += bias[e];
+                if (!gnb) v[e] += x[e];                              // zeros without a residual
+            }
+            if (ok) {
+                if (o32) {
+                    float* q = o32 + ((size_t)row * d.ldc_f32 + col);
+                    *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (o2) {
+                    float* q = o2 + ((size_t)row * d.ldc_bf16 + col);
+                    *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (gnb) {
+                    fit_gnb_accum(d, gc0, make_float4(x[0], x[1], x[2], x[3]), make_float4(v[0], v[1], v[2], v[3]), gsa0, gsa1);
+                    fit_gnb_accum(d, gc1, make_float4(x[4], x[5], x[6], x[7]), make_float4(v[4], v[5], v[6], v[7]), gsb0, gsb1);
+                } else if (do_stats) {
+                    gsa0 += (v[0] + v[1]) + (v[2] + v[3]);
+                    gsa1 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    gsb0 += (v[4] + v[5]) + (v[6] + v[7]);
+                    gsb1 += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
+                }
+            }
+        }
+        /*hipemu:wave_sync*/
+    }
+    FIT_TRACE(5);
+    if (do_stats) fit_stats_tail<WGM, WGN, FN, KS>(d, fl + DUMP + 2 * NW * SLAB, gsa0, gsa1, gsb0, gsb1, tn, kg, wm, wn, lane);
+}
+
 // WGM x WGN waves per K group, KS K groups; wave tile (16 FM) x (16 FN); block tile BM x BN = (16 FM WGM) x (16 FN WGN).
 // EPI: FIT_EPI_GENERIC, or the epilogue specialisation this instance was compiled for (half operands only).
 template <int WGM, int WGN, int FM, int FN, int KS, bool CONV, typename T16, int EPI = FIT_EPI_GENERIC>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const GemmArgs p, const bf16_t* __restrict__ zero_page) {
     constexpr int NWT = WGM * WGN, NW = NWT * KS;
     constexpr int BM = 16 * FM * WGM, BN = 16 * FN * WGN;
-    constexpr int SUB = (BM + BN) * FIT_BK;              // elements of one K tile (A rows, then B rows)
+    typedef T16 E;                                       // operand element: bf16_t / half_t, or float (the exact mode: FIT_EPI_F32)
+    constexpr bool F32 = std::is_same<T16, float>::value;
+    constexpr int BKE = 128 / (int)sizeof(E);            // elements of one 128-byte K-tile row: 64 (16-bit) or 32 (fp32)
+    constexpr int CH = 16 / (int)sizeof(E);              // elements of one 16-byte chunk
+    static_assert(F32 == (EPI == FIT_EPI_F32), "the fp32-operand kernels have their own epilogue");
+    constexpr int SUB = (BM + BN) * BKE;                 // elements of one K tile (A rows, then B rows)
     constexpr int STAGE = KS * SUB;                      // elements of one ring stage
     constexpr int NA = BM / 8, NB = BN / 8, NPS = NA + NB, NP = KS * NPS;   // DMA pieces (8 rows x 128 B) per stage
     constexpr int PW = (NP + NW - 1) / NW;               // pieces per wave per stage (the last ones may be duplicates)
     constexpr int TN = 16 * FN;
     static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole DMA pieces");
-    static_assert(FIT_STAGES * STAGE * 2 <= 160 * 1024, "ring exceeds the LDS");
+    static_assert(FIT_STAGES * STAGE * (int)sizeof(E) <= 160 * 1024, "ring exceeds the LDS");
     static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
 
-    __shared__ __attribute__((aligned(16))) bf16_t lds[FIT_STAGES * STAGE];     // the only __shared__ object
+    __shared__ __attribute__((aligned(16))) E lds[FIT_STAGES * STAGE];     // the only __shared__ object
 
     const GemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -510,8 +638,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // walk consecutive K tiles, so an implicit convolution changes its tap only every Cin / 64 stages
     const int nkg = p.kt_total / KS;
     // ---- DMA coordinates: slot j of wave w moves piece min(w + NW j, NP - 1) of every stage ----------------------------
-    const bf16_t* const Ap = reinterpret_cast<const bf16_t*>(d.A);
-    const bf16_t* const Bp = reinterpret_cast<const bf16_t*>(d.B);
+    const E* const Ap = reinterpret_cast<const E*>(d.A);
+    const E* const Bp = reinterpret_cast<const E*>(d.B);
     const int lrow = lane >> 3, cpos = lane & 7;
     unsigned voff[PW];                                    // per-lane ELEMENT offset from the operand base at K tile 0 (conv A: the chunk only)
     int pieceA[PW], pieceOff[PW];                         // wave-uniform: operand select, LDS element offset inside a stage
@@ -532,11 +660,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         const int r = (isA ? q : q - NA) * 8 + lrow;      // row inside the A (B) tile
         const int chunk = cpos ^ ((r >> 1) & 7);
         pieceA[j] = isA;
-        pieceOff[j] = pc * (8 * FIT_BK);
+        pieceOff[j] = pc * (8 * BKE);
         if (isA) {
             const int g = tm * BM + r;
             if constexpr (CONV) {
-                voff[j] = (unsigned)(chunk * 8);
+                voff[j] = (unsigned)(chunk * CH);
                 const int Hs = d.up == 1 ? (d.H >> 1) : d.H, Ws = d.up == 1 ? (d.W >> 1) : d.W;
                 const int hw = d.H * d.W;
                 const int b = g / hw, rem = g - b * hw, y = rem / d.W, x = rem - y * d.W;
@@ -554,26 +682,26 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                 c_ok[j] = okm;
                 c_r1[j] = ro[1]; c_rd[j] = ((ro[0] - ro[1]) & 0xffff) | ((ro[2] - ro[1]) << 16);
                 c_c1[j] = co[1];
-                s_tap[j] = (sub * nkg * FIT_BK) / d.Cin;
-                s_c0[j] = sub * nkg * FIT_BK - s_tap[j] * d.Cin;
+                s_tap[j] = (sub * nkg * BKE) / d.Cin;
+                s_c0[j] = sub * nkg * BKE - s_tap[j] * d.Cin;
                 s_cur[j] = -1; c_off[j] = -1;
             } else {
                 const int gc = g < d.M ? g : d.M - 1;
-                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
+                voff[j] = (unsigned)gc * (unsigned)d.lda + (unsigned)(sub * nkg * BKE + chunk * CH);
             }
         } else {
             int g = tn * BN + r;
             g = g < d.N ? g : d.N - 1;
-            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * nkg * FIT_BK + chunk * 8);
+            voff[j] = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * nkg * BKE + chunk * CH);
             if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; s_cur[j] = -1; c_off[j] = -1; }
         }
     }
     // stages are issued in K order, exactly once each
     auto issue = [&](int it, int stage) {
-        const size_t kel = (size_t)it * FIT_BK;
+        const size_t kel = (size_t)it * BKE;
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const bf16_t* src;
+            const E* src;
             if (CONV && pieceA[j]) {
                 const int tap = s_tap[j];
                 if (tap != s_cur[j]) {                       // wave-uniform: a new tap every Cin / 64 stages
@@ -585,8 +713,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                     c_off[j] = ok ? (ro + co) * d.lda + (int)voff[j] : -1;      // M * lda < 2^31 (eligibility)
                     s_cur[j] = tap;
                 }
-                src = c_off[j] >= 0 ? Ap + (size_t)(unsigned)(c_off[j] + s_c0[j]) : zero_page;
-                s_c0[j] += FIT_BK;
+                src = c_off[j] >= 0 ? Ap + (size_t)(unsigned)(c_off[j] + s_c0[j]) : reinterpret_cast<const E*>(zero_page);
+                s_c0[j] += BKE;
                 if (s_c0[j] >= d.Cin) { s_c0[j] -= d.Cin; ++s_tap[j]; }
             } else {
                 src = (pieceA[j] ? Ap : Bp) + kel + voff[j];
@@ -597,9 +725,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
 
     // ---- fragment coordinates (16x16x32: lane -> row lane & 15, k = 8 (lane >> 4) .. + 7 of the 32-wide step) ------------
     const int l15 = lane & 15, kq = lane >> 4, fkey = (l15 >> 1) & 7;
-    const int koff0 = ((kq ^ fkey) << 3), koff1 = (((4 + kq) ^ fkey) << 3);
-    const int a_el = kg * SUB + (wm * (16 * FM) + l15) * FIT_BK;                 // + fm * 16 * BK
-    const int b_el = kg * SUB + BM * FIT_BK + (wn * TN + l15) * FIT_BK;          // + fn * 16 * BK
+    const int koff0 = (kq ^ fkey) * CH, koff1 = ((4 + kq) ^ fkey) * CH;
+    const int a_el = kg * SUB + (wm * (16 * FM) + l15) * BKE;                 // + fm * 16 * BK
+    const int b_el = kg * SUB + BM * BKE + (wn * TN + l15) * BKE;          // + fn * 16 * BK
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -608,17 +736,45 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int stage) {
-        const bf16_t* const As = lds + stage * STAGE + a_el;
-        const bf16_t* const Bs = lds + stage * STAGE + b_el;
+        if constexpr (F32) {
+            // fp32 operands on v_mfma_f32_16x16x4_f32 (exact: an fmaf chain; 32 cycles per SIMD, the fp32 vector rate): a lane's
+            // 16-byte chunk holds four consecutive k of its row; MFMA s takes component s of every lane, i.e. the k set
+            // {s, 4 + s, 8 + s, 12 + s} of the 16 k two chunk groups cover -- A and B agree on it, so the sum over k is complete
+            const float* const As = lds + stage * STAGE + a_el;
+            const float* const Bs = lds + stage * STAGE + b_el;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ko = h ? koff1 : koff0;
+                float4 af[FM], bf[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * (16 * BKE) + ko);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * (16 * BKE) + ko);
+                // component-major: the four MFMAs of one accumulator are FM * FN issues apart (a dependent 16x16x4 waits 40 cycles,
+                // an independent one issues every 32)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            const float av = c == 0 ? af[i].x : c == 1 ? af[i].y : c == 2 ? af[i].z : af[i].w;
+                            const float bv = c == 0 ? bf[j].x : c == 1 ? bf[j].y : c == 2 ? bf[j].z : bf[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            }
+        } else {
+        const E* const As = lds + stage * STAGE + a_el;
+        const E* const Bs = lds + stage * STAGE + b_el;
         bf16x8 af0[FM], bf0[FN], af1[FM], bf1[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf0[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * FIT_BK) + koff0);
+        for (int j = 0; j < FN; ++j) bf0[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * BKE) + koff0);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * FIT_BK) + koff0);
+        for (int i = 0; i < FM; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * BKE) + koff0);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf1[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * FIT_BK) + koff1);
+        for (int j = 0; j < FN; ++j) bf1[j] = *reinterpret_cast<const bf16x8*>(Bs + j * (16 * BKE) + koff1);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af1[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * FIT_BK) + koff1);
+        for (int i = 0; i < FM; ++i) af1[i] = *reinterpret_cast<const bf16x8*>(As + i * (16 * BKE) + koff1);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -638,6 +794,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
         __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: the second k-step's fragments
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN - 1, 0);   // the rest of the first k-step's MFMAs
         __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);       // the second k-step's
+    }
     };
 
     // ---- main loop: ring of 3 stages, counted waits (PW DMA instructions per wave per stage) ---------------------------
@@ -689,7 +846,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * 2, "epilogue scratch exceeds the ring");
+    static_assert(fit_scratch_floats<WGM, WGN, FM, FN, KS>() * 4 <= FIT_STAGES * STAGE * (int)sizeof(E), "epilogue scratch exceeds the ring");
 #ifdef PRX_FIT_TRACE
     // experiment (PRX_FIT_TRACE_REP=1, KS == 1 tiles): the epilogue a second time from the SAME code addresses -- the first pass
     // runs it from a cold instruction cache, the second from a warm one; the second pass's stamps replace slots 1 (begin) and 2 (end)
@@ -697,6 +854,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     for (int rep = 0; rep < nrep; ++rep) {
         if (rep) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tr[1] = __builtin_amdgcn_s_memtime(); }
         if constexpr (EPI == FIT_EPI_GENERIC) fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane FIT_TRACE_PASS);
+        else if constexpr (EPI == FIT_EPI_F32) fit_finish_f32<WGM, WGN, FM, FN, KS>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane FIT_TRACE_PASS);
         else fit_finish_spec<WGM, WGN, FM, FN, KS, EPI>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane FIT_TRACE_PASS);
         if (rep) { tr[2] = tr[5]; }
         else if (nrep > 1) { tr[3] = tr[4]; tr[7] = tr[5]; }
@@ -713,6 +871,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     }
 #else
     if constexpr (EPI == FIT_EPI_GENERIC) fit_finish<WGM, WGN, FM, FN, KS, T16>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
+    else if constexpr (EPI == FIT_EPI_F32) fit_finish_f32<WGM, WGN, FM, FN, KS>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
     else fit_finish_spec<WGM, WGN, FM, FN, KS, EPI>(p, reinterpret_cast<float*>(lds), acc, tm, tn, wave, kg, wt, wm, wn, lane);
 #endif
 }
@@ -742,6 +901,14 @@ void launch_fit_spec(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* 
         }
     }
     hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, half_t, EPI>), grid, dim3(threads), 0, s, a, zp);
+}
+
+// the fp32-operand instance of a tile (exact mode)
+template <int WGM, int WGN, int FM, int FN, int KS>
+void launch_fit_f32(const GemmArgs& a, dim3 grid, hipStream_t s, const bf16_t* zp) {
+    constexpr int threads = 64 * WGM * WGN * KS;
+    if (a.d.a_mode == PRX_A_CONV3X3) hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, true, float, FIT_EPI_F32>), grid, dim3(threads), 0, s, a, zp);
+    else hipLaunchKernelGGL((gemmfit_kernel<WGM, WGN, FM, FN, KS, false, float, FIT_EPI_F32>), grid, dim3(threads), 0, s, a, zp);
 }
 }  // namespace
 

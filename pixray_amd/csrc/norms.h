@@ -10,6 +10,10 @@ int prx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, doub
 int prx_groupnorm_bwd(const void* g, const void* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const void* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
                       float eps, hipStream_t s, int zero_stats = 1, int stats_ready = 0, int h16 = 0, int s16 = 0);
+// the backward's statistics pass alone (sum dxhat, sum dxhat * xhat per group, accumulated into bstats, which the caller zeroed):
+// what a producing GEMM's epilogue does when it can (gemm.h gnb_*); fp32 streams
+int prx_groupnorm_bwd_stats(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
+                            double* bstats, int NB, int P, int C, int swish, float eps, hipStream_t s);
 // LayerNorm on rows of width C.
 // s16 (forward): x is a 16-bit stream.  s16 (backward), bits: 1 = x, 2 = g, 4 = add are 16-bit streams; dx (fp32) may be null
 // when only the 16-bit output is wanted.

@@ -341,6 +341,19 @@ int prx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, doub
     return 0;
 }
 
+int prx_groupnorm_bwd_stats(const float* g, const float* x, const float* gamma, const float* beta, const double* fstats,
+                            double* bstats, int NB, int P, int C, int swish, float eps, hipStream_t s) {
+    PRX_REQUIRE(256 % (C / 4) == 0 && (C / 32) % 4 == 0, "groupnorm bwd: unsupported C=%d", C);
+    GNArgs a{};
+    a.x = x; a.g = g; a.fstats = fstats; a.gamma = gamma; a.beta = beta; a.stats = bstats;
+    a.P = P; a.C = C; a.swish = swish; a.eps = eps; a.s16 = 0; a.h16 = 0;
+    const int ppb = 256 / (C / 4);
+    int blocks = std::min(ceil_div(P, ppb * 4), 256);
+    hipLaunchKernelGGL((gn_stats_kernel<1, false>), dim3(blocks, NB), dim3(256), 0, s, a);
+    PRX_LAUNCH_CHECK();
+    return 0;
+}
+
 int prx_groupnorm_bwd(const void* g, const void* x, const float* gamma, const float* beta, const double* fstats,
                       double* bstats, const void* add, float* dx, bf16_t* dx_bf16, int NB, int P, int C, int swish,
                       float eps, hipStream_t s, int zero_stats, int stats_ready, int h16, int s16) {

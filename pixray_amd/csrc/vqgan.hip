@@ -350,8 +350,13 @@ void prx_vqgan_destroy_impl(PrxVqgan* v) {
 }
 
 // the GEMM epilogue can accumulate the next GroupNorm's sums only for power-of-two group sizes >= 4 channels
-// (a bf16-path epilogue: the exact mode runs the separate statistics kernels)
-static bool fusable(const PrxVqgan* v, int C) { const int gs = C / 32; return !v->f32 && C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0; }
+// (the exact mode too: its fp32-operand fit kernels carry the sums, and the engine falls back to the norm kernels' own
+// statistics pass for a product those kernels do not take -- gemm.hip; PRX_F32_GN_FUSE=0: always the separate passes)
+static bool fusable(const PrxVqgan* v, int C) {
+    static const bool f32_fuse = [] { const char* e = getenv("PRX_F32_GN_FUSE"); return !(e && atoi(e) == 0); }();
+    const int gs = C / 32;
+    return (!v->f32 || f32_fuse) && C % 32 == 0 && gs >= 4 && (gs & (gs - 1)) == 0;
+}
 
 // Token counts of the attention maps (P = h*w of the latent) are arbitrary (pixray sizes are multiples of 16 pixels, so
 // e.g. 25x14 = 350 tokens), but GEMM K dimensions and leading dimensions must be multiples of 8: every [*, P] operand is

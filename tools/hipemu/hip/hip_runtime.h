@@ -352,3 +352,35 @@ template <typename ACC> static inline ACC mfma_32x32x2_f32(float a, float b, ACC
 }
 }  // namespace hipemu
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2_f32((a), (b), (c))
+namespace hipemu {
+//   16x16x4 f32: A lane l holds row l % 16, k = l / 16;  B column l % 16, same k;  D/C column l % 16, rows 4 (l / 16) + i
+static void mfma_16x16x4_f32_reduce(unsigned char (*dep)[DEPOSIT], unsigned long long mask, unsigned char (*res)[RESULT]) {
+    struct Dep { float a, b; float c[4]; };
+    static float A[16][4], B[4][16], D[16][16];
+    for (int l = 0; l < 64; ++l) {
+        const Dep* d = (const Dep*)dep[l];
+        const bool live = (mask >> l) & 1;
+        const int rc = l % 16, k = l / 16;
+        A[rc][k] = live ? d->a : 0.f;
+        B[k][rc] = live ? d->b : 0.f;
+        for (int i = 0; i < 4; ++i) D[4 * k + i][rc] = live ? d->c[i] : 0.f;
+    }
+    for (int m = 0; m < 16; ++m)
+        for (int k = 0; k < 4; ++k)
+            for (int n = 0; n < 16; ++n) D[m][n] = fmaf(A[m][k], B[k][n], D[m][n]);      // one fused multiply-add per k, k ascending
+    for (int l = 0; l < 64; ++l) {
+        float* out = (float*)res[l];
+        const int rc = l % 16, k = l / 16;
+        for (int i = 0; i < 4; ++i) out[i] = D[4 * k + i][rc];
+    }
+}
+template <typename ACC> static inline ACC mfma_16x16x4_f32(float a, float b, ACC c) {
+    struct Dep { float a, b; float c[4]; } mine;
+    mine.a = a; mine.b = b;
+    for (int i = 0; i < 4; ++i) mine.c[i] = c[i];
+    const float* r = (const float*)wave_collective(&mine, sizeof(Dep), &mfma_16x16x4_f32_reduce);
+    for (int i = 0; i < 4; ++i) c[i] = r[i];
+    return c;
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4_f32((a), (b), (c))
