@@ -79,6 +79,14 @@ __device__ __forceinline__ f32x4 fit_mfma(const bf16x8& a, const bf16x8& b, cons
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// One fp32 fragment (16 bytes of a ring row) through a __restrict__ parameter: inlining gives the read a scoped-noalias tag, which is
+// what tells the compiler's wait-count insertion that it does not alias the LDS-DMA writes in flight (the ring discipline
+// guarantees it: a stage is read only after the counted wait + barrier that retired its DMA).  Without the tag every fragment
+// read of the fp32 kernels was preceded by s_waitcnt vmcnt(0) -- the stage just issued awaited in full, each stage.
+__device__ __forceinline__ float4 fit_frag_f32(const bf16_t* __restrict__ p) {
+    return __builtin_bit_cast(float4, *reinterpret_cast<const bf16x8*>(p));
+}
+
 // GroupNorm-backward sums on prefetched x (gemm_epi.h gnb_accum with the load taken out)
 __device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst& c, const float4& x, const float4& o, float& s0, float& s1) {
     const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
@@ -611,7 +619,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     static_assert(FIT_STAGES * STAGE * (int)sizeof(E) <= 160 * 1024, "ring exceeds the LDS");
     static_assert(NW >= 2 && NW % 2 == 0, "the stagger splits the workgroup in two halves");
 
-    __shared__ __attribute__((aligned(16))) E lds[FIT_STAGES * STAGE];     // the only __shared__ object
+    __shared__ __attribute__((aligned(16))) bf16_t lds_raw[FIT_STAGES * STAGE * (int)(sizeof(E) / 2)];     // the only __shared__ object
+    E* const lds = reinterpret_cast<E*>(lds_raw);     // the only __shared__ object
 
     const GemmDesc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -740,16 +749,19 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             // fp32 operands on v_mfma_f32_16x16x4_f32 (exact: an fmaf chain; 32 cycles per SIMD, the fp32 vector rate): a lane's
             // 16-byte chunk holds four consecutive k of its row; MFMA s takes component s of every lane, i.e. the k set
             // {s, 4 + s, 8 + s, 12 + s} of the 16 k two chunk groups cover -- A and B agree on it, so the sum over k is complete
-            const float* const As = lds + stage * STAGE + a_el;
-            const float* const Bs = lds + stage * STAGE + b_el;
+            // (fragments are read as 16-byte vectors of the ring's 16-bit carrier type and re-typed in registers: read through
+            // a float-typed pointer, the compiler orders the reads behind the LDS-DMA just issued with s_waitcnt vmcnt(0) -- the
+            // whole stage latency exposed, every stage; tools/disasm.sh shows the difference)
+            const bf16_t* const As = reinterpret_cast<const bf16_t*>(lds) + 2 * (stage * STAGE + a_el);
+            const bf16_t* const Bs = reinterpret_cast<const bf16_t*>(lds) + 2 * (stage * STAGE + b_el);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ko = h ? koff1 : koff0;
+                const int ko = 2 * (h ? koff1 : koff0);
                 float4 af[FM], bf[FN];
 #pragma unroll
-                for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + j * (16 * BKE) + ko);
+                for (int j = 0; j < FN; ++j) bf[j] = fit_frag_f32(Bs + j * (32 * BKE) + ko);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const float4*>(As + i * (16 * BKE) + ko);
+                for (int i = 0; i < FM; ++i) af[i] = fit_frag_f32(As + i * (32 * BKE) + ko);
                 // component-major: the four MFMAs of one accumulator are FM * FN issues apart (a dependent 16x16x4 waits 40 cycles,
                 // an independent one issues every 32)
 #pragma unroll
@@ -762,6 +774,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
                             const float bv = c == 0 ? bf[j].x : c == 1 ? bf[j].y : c == 2 ? bf[j].z : bf[j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
                         }
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);       // DS reads: this half's fragments
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * FM * FN, 0);   // its MFMAs
             }
         } else {
         const E* const As = lds + stage * STAGE + a_el;
