@@ -115,8 +115,8 @@ int prx_k_gemm(const prx_gemm_args* g, void* ws, size_t ws_bytes, prx_stream_t s
 int prx_k_gemm_gn(const prx_gemm_args* g, double* gn_stats, int gn_gs, const float* gnb_x, const double* gnb_fstats,
                   const float* gnb_gamma, const float* gnb_beta, int gnb_swish, float gnb_eps, void* ws, size_t ws_bytes,
                   prx_stream_t stream);
-/* Diagnostics: how many launches of this process ran a fit kernel whose epilogue is specialised at compile time (csrc/gemmfit_kernel.h
- * FIT_EPI_*: the descriptor patterns of the two runners, IEEE-half operands) -- tests use it to know that the specialised kernel,
+/* Diagnostics: how many launches of this process ran a fit or 8-phase kernel whose epilogue is specialised at compile time
+ * (csrc/gemmfit_kernel.h FIT_EPI_*, csrc/gemm8p.hip: the descriptor patterns of the two runners, IEEE-half operands) -- tests use it to know that the specialised kernel,
  * not the generic one, produced what they compare. */
 long long prx_gemm_fit_spec_launches(void);
 

@@ -1174,7 +1174,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_REQUIRE(a.vec_epi && d.gn_gs >= 4 && d.gn_gs % 4 == 0 && d.N == 32 * d.gn_gs && !d.a_is_f32 && (cx.use_glds || d.f32),
                     "gemm: fused GroupNorm statistics need the v2 kernel's vector epilogue and N == 32 * gn_gs");
     }
-    a.fit_flags = fit_tile ? (cx.fit_flags & (15 | 64)) : 0;   // gemmfit.hip A/B switches (PRX_FIT_FLAGS); bit 6: generic epilogues only
+    a.fit_flags = fit_tile ? (cx.fit_flags & (15 | 64)) : (cx.fit_flags & 64);   // gemmfit.hip A/B switches (PRX_FIT_FLAGS); bit 6: generic epilogues only
     if (fit_tile && (cx.fit_flags & 32) == 0 && d.N > d.M) a.fit_flags |= 16;      // weight-heavy: column-major tile order (bit 5 of the switch word turns it off)
     a.kt_per_split = ceil_div(a.kt_total, splits);
     if (BM == 256 && BN == 256) a.kt_per_split = (a.kt_per_split + 1) & ~1;      // the 8-phase loop body covers two K tiles

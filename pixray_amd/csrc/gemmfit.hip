@@ -106,7 +106,10 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
         if (t.bn >= 32) consider(t.bm, t.bn, t.eff);
 }
 static std::atomic<long long> g_spec_launches{0};
-extern "C" long long prx_gemm_fit_spec_launches(void) { return g_spec_launches.load(std::memory_order_relaxed); }
+extern std::atomic<long long> g_prx_gemm8p_spec_launches;      // gemm8p.hip: the 8-phase kernel's specialised instances
+extern "C" long long prx_gemm_fit_spec_launches(void) {
+    return g_spec_launches.load(std::memory_order_relaxed) + g_prx_gemm8p_spec_launches.load(std::memory_order_relaxed);
+}
 
 // The compile-time epilogue (FIT_EPI_*) a descriptor is an instance of, FIT_EPI_GENERIC when none: IEEE-half operands, one
 // 16-bit output (plus FC1's 16-bit pre-activation), no fp32 output, no per-row bias, at most one 16-bit row operand.

@@ -660,6 +660,32 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     int s_tap[CONV ? PW : 1], s_c0[CONV ? PW : 1];        // wave-uniform: (tap, first channel) of the slot's K tile in the NEXT stage to issue
     int s_cur[CONV ? PW : 1];                             // wave-uniform: the tap c_off was computed for (-1: none yet)
     int c_off[CONV ? PW : 1];                             // per lane: element offset of the tap's source pixel + the lane's chunk, < 0: padding
+    // pixel index -> (image, y, x): shifts when the map is a power of two on both counts (every level of a square power-of-two
+    // canvas: wave-uniform test), two integer divisions per lane and A piece otherwise
+    const int hw_ = CONV ? d.H * d.W : 1, w_ = CONV ? d.W : 1;
+    const bool pow2_map = CONV && ((hw_ & (hw_ - 1)) | (w_ & (w_ - 1))) == 0;
+    const int sh_hw = __builtin_ctz((unsigned)hw_ | 0x80000000u), sh_w = __builtin_ctz((unsigned)w_ | 0x80000000u);
+    // the weight rows of stage 0 first: an implicit convolution's A slots cost a pixel decode and a dozen selects per lane before
+    // their first address exists, and the B pieces (2/3 of a small tile's bytes) are on their way before that arithmetic starts.
+    // (A slot's pieces complete in issue order per stage: the counted waits of the main loop still see stage 0 before stage 1.)
+    const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
+    if constexpr (CONV) {
+        if (0 < nk) {
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                int pc = wave + NW * j;
+                pc = pc < NP ? pc : NP - 1;
+                const int sub = pc / NPS, q = pc - sub * NPS;
+                if (q < NA) continue;                            // wave-uniform
+                const int r = (q - NA) * 8 + lrow;
+                const int chunk = cpos ^ ((r >> 1) & 7);
+                int g = tn * BN + r;
+                g = g < d.N ? g : d.N - 1;
+                const unsigned vo = (unsigned)g * (unsigned)d.ldb + (unsigned)(sub * nkg * BKE + chunk * CH);
+                __builtin_amdgcn_global_load_lds((fit_gptr)(Bp + vo), (fit_lptr)(lds + pc * (8 * BKE)), 16, 0, 0);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         int pc = wave + NW * j;
@@ -675,8 +701,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             if constexpr (CONV) {
                 voff[j] = (unsigned)(chunk * CH);
                 const int Hs = d.up == 1 ? (d.H >> 1) : d.H, Ws = d.up == 1 ? (d.W >> 1) : d.W;
-                const int hw = d.H * d.W;
-                const int b = g / hw, rem = g - b * hw, y = rem / d.W, x = rem - y * d.W;
+                const int hw = hw_;
+                int b, rem, y, x;
+                if (pow2_map) { b = g >> sh_hw; rem = g & (hw - 1); y = rem >> sh_w; x = rem & (w_ - 1); }
+                else { b = g / hw; rem = g - b * hw; y = rem / d.W; x = rem - y * d.W; }
                 int okm = 0, ro[3], co[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -705,11 +733,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
             if constexpr (CONV) { c_ok[j] = 0; c_r1[j] = c_rd[j] = c_c1[j] = 0; s_tap[j] = s_c0[j] = 0; s_cur[j] = -1; c_off[j] = -1; }
         }
     }
-    // stages are issued in K order, exactly once each
-    auto issue = [&](int it, int stage) {
+    // stages are issued in K order, exactly once each; a_only: the A slots alone (the prologue's stage 0 of a convolution, whose B
+    // pieces left before the decode)
+    auto issue = [&](int it, int stage, bool a_only) {
         const size_t kel = (size_t)it * BKE;
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
+            if (a_only && !pieceA[j]) continue;                           // wave-uniform
             const E* src;
             if (CONV && pieceA[j]) {
                 const int tap = s_tap[j];
@@ -818,19 +848,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemmfit_kernel(const Gemm
     // while all eight issue; staggered, one wave of a SIMD computes while the other issues.  The late group's pieces of
     // stage T + 2 are issued after every wave passed barrier T (stage T - 1 was read before it: WAR), and are waited for by
     // the same counted wait in front of barrier T + 2.
-    const int nk = (p.fit_flags & 8) ? 0 : nkg;                  // bit 3 (timing experiments only): no main loop
     const bool late = (p.fit_flags & 1) && wave >= NW / 2;
     FIT_TRACE(1);
-    if (0 < nk) issue(0, 0);
-    if (1 < nk) issue(1, 1);
+    if (0 < nk) issue(0, 0, CONV);
+    if (1 < nk) issue(1, 1, false);
 #ifdef PRX_FIT_TRACE
     // loop experiments of the diagnostic build (PRX_FIT_TRACE_LOOP): bit 8 = no MFMAs / fragment reads (DMA, waits and barriers
     // only), bit 9 = no DMA after the first two stages (fragment reads + MFMAs on whatever the ring holds)
     const bool x_nomma = (p.fit_flags & 256) != 0, x_nodma = (p.fit_flags & 512) != 0;
-#define FIT_ISSUE(T, ST) do { if (!x_nodma) issue(T, ST); } while (0)
+#define FIT_ISSUE(T, ST) do { if (!x_nodma) issue(T, ST, false); } while (0)
 #define FIT_COMPUTE(ST) do { if (!x_nomma) compute(ST); } while (0)
 #else
-#define FIT_ISSUE(T, ST) issue(T, ST)
+#define FIT_ISSUE(T, ST) issue(T, ST, false)
 #define FIT_COMPUTE(ST) compute(ST)
 #endif
 #define FIT_STEP(T, ST)                                                                                                 \

@@ -130,23 +130,30 @@ __device__ __forceinline__ void gn_lane_load(const GNArgs& a, const double* bsta
     L.b = b;
 }
 
+// (32-bit indices: the host checks NB * P * C / 4 < 2^31 -- the 64-bit divisions of the slice arithmetic were a third of a small
+// launch; the first elements are requested BEFORE the statistics are fetched and turned into mean / rstd, so the two memory round
+// trips of a launch-bound pass overlap instead of following each other)
 template <bool S16>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_t* out_bf16, float* out_f32, int NB, int xcd, int h16) {
-    const int C4 = a.C >> 2;
-    const size_t total = (size_t)NB * a.P * C4, per_b = (size_t)a.P * C4;
-    size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = (size_t)gridDim.x * blockDim.x;
+    const unsigned C4 = (unsigned)a.C >> 2;
+    const unsigned total = (unsigned)NB * (unsigned)a.P * C4, per_b = (unsigned)a.P * C4;
+    unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = gridDim.x * blockDim.x;
     if (xcd) {
-        const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
+        const unsigned per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
         i0 = lo + threadIdx.x; i1 = lo + per < total ? lo + per : total; step = blockDim.x;
     }
     if (i0 >= i1) return;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned idx = i0;
+    float4 v0 = stream_ld4<S16>(a.x, idx, a.h16);
+    float4 v1 = idx + step < i1 ? stream_ld4<S16>(a.x, idx + step, a.h16) : z4;
     const int cq = (int)(i0 % C4);
     GnLane L;
     L.ga = reinterpret_cast<const float4*>(a.gamma)[cq];
     L.be = reinterpret_cast<const float4*>(a.beta)[cq];
     gn_lane_load<false>(a, nullptr, NB == 1 ? 0 : (int)(i0 / per_b), cq, L);
-    auto one = [&](size_t idx, const float4& v) {
-        if (NB != 1) { const int b = (int)(idx / per_b); if (b != L.b) gn_lane_load<false>(a, nullptr, b, cq, L); }
+    auto one = [&](unsigned id, const float4& v) {
+        if (NB != 1) { const int b = (int)(id / per_b); if (b != L.b) gn_lane_load<false>(a, nullptr, b, cq, L); }
         const float xv[4] = {v.x, v.y, v.z, v.w};
         const float gav[4] = {L.ga.x, L.ga.y, L.ga.z, L.ga.w}, bev[4] = {L.be.x, L.be.y, L.be.z, L.be.w};
         float o[4];
@@ -155,37 +162,45 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const GNArgs a, bf16_
             float y = (xv[i] - L.mean) * L.rstd * gav[i] + bev[i];
             o[i] = a.swish ? y * sigmoidf_(y) : y;
         }
-        if (out_bf16) reinterpret_cast<bf16x4*>(out_bf16)[idx] = to_op16x4(o[0], o[1], o[2], o[3], h16);
-        if (out_f32) reinterpret_cast<float4*>(out_f32)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+        if (out_bf16) reinterpret_cast<bf16x4*>(out_bf16)[id] = to_op16x4(o[0], o[1], o[2], o[3], h16);
+        if (out_f32) reinterpret_cast<float4*>(out_f32)[id] = make_float4(o[0], o[1], o[2], o[3]);
     };
-    size_t idx = i0;
     for (; idx + step < i1; idx += 2 * step) {
-        const float4 v0 = stream_ld4<S16>(a.x, idx, a.h16), v1 = stream_ld4<S16>(a.x, idx + step, a.h16);
+        const unsigned nx = idx + 2 * step;                       // the next pair is in flight while this one is finished
+        const float4 n0 = nx < i1 ? stream_ld4<S16>(a.x, nx, a.h16) : z4;
+        const float4 n1 = nx + step < i1 ? stream_ld4<S16>(a.x, nx + step, a.h16) : z4;
         one(idx, v0); one(idx + step, v1);
+        v0 = n0; v1 = n1;
     }
-    if (idx < i1) one(idx, stream_ld4<S16>(a.x, idx, a.h16));
+    if (idx < i1) one(idx, v0);
 }
 
 // dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat)) (+ add)
 template <bool S16>
 __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const double* bstats, const void* add,
                                                            float* dx, bf16_t* dx_bf16, int NB, int xcd, int h16) {
-    const int C4 = a.C >> 2;
-    const size_t total = (size_t)NB * a.P * C4, per_b = (size_t)a.P * C4;
-    size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = (size_t)gridDim.x * blockDim.x;
+    const unsigned C4 = (unsigned)a.C >> 2;
+    const unsigned total = (unsigned)NB * (unsigned)a.P * C4, per_b = (unsigned)a.P * C4;
+    unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x, i1 = total, step = gridDim.x * blockDim.x;
     if (xcd) {
-        const size_t per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
+        const unsigned per = (total + gridDim.x - 1) / gridDim.x, lo = per * xcd_linear(blockIdx.x, gridDim.x);
         i0 = lo + threadIdx.x; i1 = lo + per < total ? lo + per : total; step = blockDim.x;
     }
     if (i0 >= i1) return;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned idx = i0;
+    // the first pair is requested before the statistics (see the forward kernel)
+    const bool two0 = idx + step < i1;
+    float4 v0 = stream_ld4<S16>(a.x, idx, a.h16), g0 = stream_ld4<S16>(a.g, idx, a.h16), a0 = add ? stream_ld4<S16>(add, idx, a.h16) : z4;
+    float4 v1 = two0 ? stream_ld4<S16>(a.x, idx + step, a.h16) : z4, g1 = two0 ? stream_ld4<S16>(a.g, idx + step, a.h16) : z4;
+    float4 a1 = (two0 && add) ? stream_ld4<S16>(add, idx + step, a.h16) : z4;
     const int cq = (int)(i0 % C4);
     GnLane L;
     L.ga = reinterpret_cast<const float4*>(a.gamma)[cq];
     L.be = reinterpret_cast<const float4*>(a.beta)[cq];
     gn_lane_load<true>(a, bstats, NB == 1 ? 0 : (int)(i0 / per_b), cq, L);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto one = [&](size_t idx, const float4& v, const float4& gg, const float4& ad) {
-        if (NB != 1) { const int b = (int)(idx / per_b); if (b != L.b) gn_lane_load<true>(a, bstats, b, cq, L); }
+    auto one = [&](unsigned id, const float4& v, const float4& gg, const float4& ad) {
+        if (NB != 1) { const int b = (int)(id / per_b); if (b != L.b) gn_lane_load<true>(a, bstats, b, cq, L); }
         const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
         const float gav[4] = {L.ga.x, L.ga.y, L.ga.z, L.ga.w}, bev[4] = {L.be.x, L.be.y, L.be.z, L.be.w};
         float o[4];
@@ -198,17 +213,20 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const GNArgs a, const
             o[i] = L.rstd * (dxh - L.m1 - xh * L.m2);
         }
         o[0] += ad.x; o[1] += ad.y; o[2] += ad.z; o[3] += ad.w;
-        if (dx) reinterpret_cast<float4*>(dx)[idx] = make_float4(o[0], o[1], o[2], o[3]);      // dx may be null: only the operand twin is wanted
-        if (dx_bf16) reinterpret_cast<bf16x4*>(dx_bf16)[idx] = to_op16x4(o[0], o[1], o[2], o[3], h16);
+        if (dx) reinterpret_cast<float4*>(dx)[id] = make_float4(o[0], o[1], o[2], o[3]);      // dx may be null: only the operand twin is wanted
+        if (dx_bf16) reinterpret_cast<bf16x4*>(dx_bf16)[id] = to_op16x4(o[0], o[1], o[2], o[3], h16);
     };
-    size_t idx = i0;
     for (; idx + step < i1; idx += 2 * step) {
-        const float4 v0 = stream_ld4<S16>(a.x, idx, a.h16), v1 = stream_ld4<S16>(a.x, idx + step, a.h16);
-        const float4 g0 = stream_ld4<S16>(a.g, idx, a.h16), g1 = stream_ld4<S16>(a.g, idx + step, a.h16);
-        const float4 a0 = add ? stream_ld4<S16>(add, idx, a.h16) : z4, a1 = add ? stream_ld4<S16>(add, idx + step, a.h16) : z4;
+        const unsigned nx = idx + 2 * step;
+        const bool m0 = nx < i1, m1 = nx + step < i1;
+        const float4 nv0 = m0 ? stream_ld4<S16>(a.x, nx, a.h16) : z4, ng0 = m0 ? stream_ld4<S16>(a.g, nx, a.h16) : z4;
+        const float4 na0 = (m0 && add) ? stream_ld4<S16>(add, nx, a.h16) : z4;
+        const float4 nv1 = m1 ? stream_ld4<S16>(a.x, nx + step, a.h16) : z4, ng1 = m1 ? stream_ld4<S16>(a.g, nx + step, a.h16) : z4;
+        const float4 na1 = (m1 && add) ? stream_ld4<S16>(add, nx + step, a.h16) : z4;
         one(idx, v0, g0, a0); one(idx + step, v1, g1, a1);
+        v0 = nv0; g0 = ng0; a0 = na0; v1 = nv1; g1 = ng1; a1 = na1;
     }
-    if (idx < i1) one(idx, stream_ld4<S16>(a.x, idx, a.h16), stream_ld4<S16>(a.g, idx, a.h16), add ? stream_ld4<S16>(add, idx, a.h16) : z4);
+    if (idx < i1) one(idx, v0, g0, a0);
 }
 
 // ---------------------------------------------------------------------------
@@ -332,6 +350,7 @@ int prx_groupnorm_fwd(const void* x, const float* gamma, const float* beta, doub
         PRX_LAUNCH_CHECK();
     }
     if (out_bf16 || out_f32) {
+        PRX_REQUIRE((unsigned long long)NB * P * C / 4 < (1ull << 31), "groupnorm: %d x %d x %d elements exceed the 32-bit index range", NB, P, C);
         if (s16) hipLaunchKernelGGL(gn_apply_fwd_kernel<true>, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, out_bf16,
                                     out_f32, NB, prx_xcd_local(), h16);
         else hipLaunchKernelGGL(gn_apply_fwd_kernel<false>, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, out_bf16,
@@ -369,6 +388,7 @@ int prx_groupnorm_bwd(const void* g, const void* x, const float* gamma, const fl
         else hipLaunchKernelGGL((gn_stats_kernel<1, false>), dim3(blocks, NB), dim3(256), 0, s, a);
         PRX_LAUNCH_CHECK();
     }
+    PRX_REQUIRE((unsigned long long)NB * P * C / 4 < (1ull << 31), "groupnorm bwd: %d x %d x %d elements exceed the 32-bit index range", NB, P, C);
     if (s16) hipLaunchKernelGGL(gn_apply_bwd_kernel<true>, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,
                                 dx_bf16, NB, prx_xcd_local(), h16);
     else hipLaunchKernelGGL(gn_apply_bwd_kernel<false>, dim3(gn_grid((size_t)NB * P * C / 4)), dim3(256), 0, s, a, bstats, add, dx,

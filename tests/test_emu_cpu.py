@@ -75,6 +75,8 @@ def test_fit_kernels_with_compile_time_epilogues_match_the_generic_kernel(emu):
     for tile in [(160, 192), (80, 128), (128, 128), (64, 64), (16, 32)]:
         ran = emu.tk.fit_spec_vs_generic(tile, shapes=small, conv_shapes=convs)
         assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or {"gn", "res16_gn", "gnb"} <= ran), (tile, ran)
+    ran = emu.tk.fit_spec_vs_generic((256, 256), shapes=[(300, 264, 256), (257, 136, 384)])       # the 8-phase kernel's tower epilogues
+    assert {"out16", "res16", "gelu", "dgelu"} <= ran
 
 
 def test_gemm_engine_random_shapes_every_kernel_family(emu):

@@ -376,8 +376,8 @@ def fit_spec_vs_generic(tile, shapes=None, conv_shapes=None):
     at most one half-precision ulp); GroupNorm sums agree to the rounding of their fp32 per-lane partials"""
     lib = _lib.load()
     dt = torch.float16
-    ks = FIT_KS[tile]
-    tower = tile[0] % 80 == 0
+    ks = FIT_KS.get(tile, 2)                      # (256, 256): the 8-phase kernel, K % 128 == 0
+    tower = tile[0] % 80 == 0 or tile == (256, 256)
     torch.manual_seed(21)
     ctx = _lib.tool_ctx()
     ran = set()
@@ -488,10 +488,11 @@ def fit_spec_vs_generic(tile, shapes=None, conv_shapes=None):
     return ran
 
 
-@pytest.mark.parametrize("tile", SPEC_TILES)
+@pytest.mark.parametrize("tile", SPEC_TILES + [(256, 256)])
 def test_gemm_fit_specialised_epilogues_match_the_generic_kernel(tile):
+    """... and the 8-phase 256 x 256 kernel's tower epilogues (gemm8p.hip) by the same rule"""
     ran = fit_spec_vs_generic(tile)
-    assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or {"gn", "res16_gn", "gnb"} <= ran)
+    assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or tile == (256, 256) or {"gn", "res16_gn", "gnb"} <= ran)
 
 
 def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
