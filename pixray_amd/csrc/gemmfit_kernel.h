@@ -88,6 +88,7 @@ __device__ __forceinline__ float4 fit_frag_f32(const bf16_t* __restrict__ p) {
 }
 
 // GroupNorm-backward sums on prefetched x (gemm_epi.h gnb_accum with the load taken out)
+template <bool FAST = false>
 __device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst& c, const float4& x, const float4& o, float& s0, float& s1) {
     const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {o.x, o.y, o.z, o.w};
     const float gav[4] = {c.ga.x, c.ga.y, c.ga.z, c.ga.w}, bev[4] = {c.be.x, c.be.y, c.be.z, c.be.w};
@@ -97,7 +98,7 @@ __device__ __forceinline__ void fit_gnb_accum(const GemmDesc& d, const GnbConst&
         float gy = gv[i];
         if (d.gnb_swish) {
             const float y = xh * gav[i] + bev[i];
-            const float sg = sigmoidf_(y);
+            const float sg = FAST ? __builtin_amdgcn_rcpf(1.f + __expf(-y)) : sigmoidf_(y);     // FAST: v_exp + v_rcp (the specialised epilogues)
             gy *= sg * (1.f + y * (1.f - sg));
         }
         const float dxh = gy * gav[i];
@@ -460,8 +461,8 @@ __device__ __forceinline__ void fit_finish_spec(const GemmArgs& p, float* const 
             }
             if constexpr (GNB) {
                 if (ok) {
-                    fit_gnb_accum(d, gc0, make_float4(x[0], x[1], x[2], x[3]), make_float4(v[0], v[1], v[2], v[3]), gsa0, gsa1);
-                    fit_gnb_accum(d, gc1, make_float4(x[4], x[5], x[6], x[7]), make_float4(v[4], v[5], v[6], v[7]), gsb0, gsb1);
+                    fit_gnb_accum<true>(d, gc0, make_float4(x[0], x[1], x[2], x[3]), make_float4(v[0], v[1], v[2], v[3]), gsa0, gsa1);
+                    fit_gnb_accum<true>(d, gc1, make_float4(x[4], x[5], x[6], x[7]), make_float4(v[4], v[5], v[6], v[7]), gsb0, gsb1);
                 }
             } else if constexpr (STATS) {
                 if (ok) {

@@ -478,7 +478,7 @@ def fit_spec_vs_generic(tile, shapes=None, conv_shapes=None):
             for kind in ("gn", "res16_gn", "gnb"):
                 (s16, sst), (g16, gst) = both(lambda: runc(kind))
                 assert torch.equal(bits(s16), bits(g16)), (tile, kind)
-                assert torch.allclose(sst, gst, rtol=2e-6, atol=1e-3), (tile, kind, (sst - gst).abs().max())      # fp32 per-lane partials: the two code shapes contract their multiply-adds differently
+                assert torch.allclose(sst, gst, rtol=2e-5 if kind == "gnb" else 2e-6, atol=1e-2 if kind == "gnb" else 1e-3), (tile, kind, (sst - gst).abs().max())      # fp32 per-lane partials: the two code shapes contract their multiply-adds differently
                 assert float(sst.abs().sum()) > 0
                 ran.add(kind)
     finally:
