@@ -4,6 +4,8 @@
 #include "gemmfit_kernel.h"
 #include <atomic>
 
+static std::atomic<long long> g_spec_launches{0};       // launches on kernels with a compile-time epilogue (prx_gemm_fit_spec_launches)
+
 namespace {
 // the tile shapes this kernel exists in
 struct FitTile { int bm, bn, ks, tn; double eff; };  // tn: wave-tile width; eff: relative efficiency at full occupancy (planner weight)
@@ -105,7 +107,6 @@ void prx_gemmfit_plan(const GemmDesc& d, int n_cu, int* bm, int* bn) {
     for (const FitTile& t : kFitTiles)
         if (t.bn >= 32) consider(t.bm, t.bn, t.eff);
 }
-static std::atomic<long long> g_spec_launches{0};
 extern std::atomic<long long> g_prx_gemm8p_spec_launches;      // gemm8p.hip: the 8-phase kernel's specialised instances
 extern "C" long long prx_gemm_fit_spec_launches(void) {
     return g_spec_launches.load(std::memory_order_relaxed) + g_prx_gemm8p_spec_launches.load(std::memory_order_relaxed);
@@ -179,6 +180,7 @@ int prx_gemmfit_launch(const prx_gemm_dev::GemmArgs& a_in, int bm, int bn, dim3 
     // switch word (PRX_FIT_FLAGS / override -8) keeps every launch on the generic kernels (A/B runs, tests of the generic path)
     if (a.d.f32) {
         PRX_REQUIRE(prx_gemmfit_launch_f32(a, bm, bn, grid, s, zp), "gemmfit: no fp32-operand kernel for a %d x %d tile", bm, bn);
+        g_spec_launches.fetch_add(1, std::memory_order_relaxed);       // FIT_EPI_F32 is a compile-time epilogue too
         return 0;
     }
     if (!(a.fit_flags & 64)) {

@@ -245,20 +245,12 @@ def test_vgg16_extractor_exact_mode_vs_oracle(emu):
         tf.DEV = "cuda"
 
 
-def test_vqgan_decoder_exact_mode_on_the_fp32_fit_kernels(emu):
-    """the exact-f32 decoder (the `ref` precision's drawer): its convolutions run on the fp32-operand fit kernels (gemmfit_f32.hip,
-    v_mfma_f32_16x16x4_f32) with the GroupNorm sums -- forward and backward -- in their epilogue, and fall back to the 4-wave fp32
-    kernels + the norm kernels' own statistics pass where a shape does not fit (the non-square case); image and dL/dz at fp32
-    round-off against the oracle, and the same with the fusion switched off"""
-    import test_f32_mode_gpu as tf
-    tf.DEV = "cpu"
-    try:
-        tf.test_vqgan_synth_f32_vs_oracle("tiny_f4", 16)
-        tf.test_vqgan_synth_f32_vs_oracle("tiny_f4", (12, 20))
-        tf.test_gemm_f32_conv3x3_matches_float64(16, 16, 256, 512, 0, 1)
-        tf.test_gemm_f32_conv3x3_matches_float64(32, 32, 64, 128, 1, 1)
-    finally:
-        tf.DEV = "cuda"
+def test_fp32_operand_fit_kernels_and_their_groupnorm_sums(emu):
+    """the exact mode's decoder products on the fp32-operand fit kernels (gemmfit_f32.hip, v_mfma_f32_16x16x4_f32): implicit
+    convolutions on a 1-, a 2- and an 8-K-group tile with bias + fp32 residual, the next GroupNorm's sums and a GroupNorm-backward's
+    sums in the epilogue, against float64; and a shape those kernels do not take (Cin % 32 != 0): the engine runs the 4-wave fp32
+    kernel and the norm kernels' own statistics pass instead -- same sums"""
+    emu.tk.fit_f32_conv_and_stats_checks([(128, 128), (64, 64), (16, 32)])
 
 
 def test_one_iteration_of_the_reduced_configuration_vs_oracle(emu):

@@ -547,6 +547,8 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
     prefix, gumbel = checkpoints.TAMING_TARGETS[target]
     if gumbel:
         sd["quantize.embed.weight"] = sd.pop("quantize.embedding.weight")
+        sd["quantize.proj.weight"] = torch.randn(cfg.n_embed, cfg.embed_dim, 1, 1)     # GumbelQuantize's logits projection: kept for encode()
+        sd["quantize.proj.bias"] = torch.randn(cfg.n_embed)
     sd = OrderedDict((prefix + k, v) for k, v in sd.items())
     sd[prefix + "loss.discriminator.main.0.weight"] = torch.zeros(8, 3, 4, 4)          # dropped by `del model.loss`
     if prefix:
@@ -558,7 +560,8 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
     got_cfg, params, got_gumbel = checkpoints.load_taming(str(ypath), str(cpath))
     assert got_cfg == cfg and got_gumbel == gumbel
     want = list(OrderedDict.fromkeys(list(weights.vqgan_param_shapes(cfg)) + list(weights.vqgan_encoder_param_shapes(cfg))))
-    assert list(params) == want            # decoder entries in the C ABI's order, then the encoder's (codebook shared)
+    assert [k for k in params if not k.startswith("quantize.proj")] == want            # decoder entries in the C ABI's order, then the encoder's (codebook shared)
+    assert ("quantize.proj.weight" in params) == gumbel                                 # ... and GumbelVQ's logits projection after them
     for k in weights.vqgan_param_shapes(cfg):
         assert torch.equal(params[k], dec[k]), k
     for k in weights.vqgan_encoder_param_shapes(cfg):
@@ -583,11 +586,13 @@ def test_taming_yaml_and_lightning_checkpoint_load(tmp_path, target):
             drawer.load_model(args, "cpu")
     finally:
         ops.VqganHandle = real
-    # the flag is consulted -- a GumbelVQ checkpoint decodes, but its encoder side (quantize.proj logits +
-    # gumbel_softmax, vqgan.py:175-185) is not the nearest-code lookup the HIP encoder does, so it must refuse loudly
+    # the flag is consulted: a GumbelVQ checkpoint encodes through its own quantiser (quantize.proj logits + gumbel_softmax,
+    # vqgan.py:175-185; tests/test_path_gpu.py gumbel_vq_encode_checks runs it), never through the nearest-code lookup --
+    # without the projection weights it refuses loudly
     assert drawer.gumbel == gumbel and VqganDrawer(args).gumbel is False
     if gumbel:
-        with pytest.raises(NotImplementedError, match="GumbelVQ"):
+        drawer.state_dict = {k: v for k, v in drawer.state_dict.items() if not k.startswith("quantize.proj")}
+        with pytest.raises(KeyError, match="quantize.proj"):
             drawer.init_from_tensor(torch.zeros(1, 3, 64, 64))
     bad = VqganDrawer.add_settings(argparse.ArgumentParser()).parse_args(["--vqgan_config", str(tmp_path / "nope.yaml")])
     bad.size = (64, 64)

@@ -495,6 +495,81 @@ def test_gemm_fit_specialised_epilogues_match_the_generic_kernel(tile):
     assert {"out16", "res16", "gelu", "dgelu"} <= ran and (tile[0] % 80 == 0 or tile == (256, 256) or {"gn", "res16_gn", "gnb"} <= ran)
 
 
+def fit_f32_conv_and_stats_checks(tiles):
+    """fp32-operand fit kernels (FIT_EPI_F32) forced on small implicit convolutions: output vs float64, fused GroupNorm forward sums and
+    GroupNorm-backward sums vs float64; then a convolution they are not eligible for (Cin = 48), where the engine must deliver the
+    same statistics through its fallback (4-wave fp32 kernel + the norm kernels' statistics pass)"""
+    lib = _lib.load()
+    ctx = _lib.tool_ctx()
+    torch.manual_seed(9)
+    try:
+        for tile in list(tiles) + [None]:
+            lib.prx_gemm_tile_override(ctx, -12, 0, 1)
+            if tile is not None:
+                lib.prx_gemm_tile_override(ctx, tile[0], tile[1], 1)
+                H, W, Cin, Cout = 8, 8, 64 * FIT_KS[tile] // (2 if FIT_KS[tile] > 1 else 1), 128      # K = 9 Cin a multiple of 32 KS
+            else:
+                lib.prx_gemm_tile_override(ctx, 0, 0, 0)
+                H, W, Cin, Cout = 8, 12, 48, 128
+            M, K = H * W, 9 * Cin
+            x = torch.randn(1, H, W, Cin, device=DEV)
+            w = torch.randn(Cout, K, device=DEV) / math.sqrt(K)
+            bias = torch.randn(Cout, device=DEV); resid = torch.randn(M, Cout, device=DEV)
+            gs = Cout // 32
+            xr = x.permute(0, 3, 1, 2).double().cpu()
+            wr = w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu()
+            ref = F.conv2d(xr, wr, bias.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, Cout) + resid.double().cpu()
+
+            def args():
+                g = GemmArgs()
+                g.A = x.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = w.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, Cout, K
+                g.H, g.W, g.Cin, g.up = H, W, Cin, 0
+                g.alpha = 1.0; g.f32 = 1
+                return g
+            g = args(); g.bias_n = bias.data_ptr(); g.resid = resid.data_ptr(); g.ldr = Cout
+            out = torch.full((M + 2, Cout), float("nan"), device=DEV); g.out_f32 = out.data_ptr(); g.ldc_f32 = Cout
+            st = torch.zeros(64, device=DEV, dtype=torch.float64)
+            n0 = lib.prx_gemm_fit_spec_launches()
+            call("prx_k_gemm_gn", g, st, gs, None, None, None, None, 0, 1e-6, None, 0, stream())
+            torch.cuda.synchronize()
+            assert lib.prx_gemm_fit_spec_launches() - n0 == (1 if tile is not None else 0), tile        # the fp32 fit kernel ran / the fallback did
+            assert torch.isnan(out[M:]).all()
+            o = out[:M].double().cpu()
+            assert float((o - ref).norm() / ref.norm()) < 2e-6, (tile, float((o - ref).norm() / ref.norm()))
+            o64 = o.view(M, 32, gs)
+            want = torch.stack([o64.sum(dim=(0, 2)), (o64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1)
+            assert torch.allclose(st.cpu(), want, rtol=1e-5, atol=1e-3), (tile, float((st.cpu() - want).abs().max()))
+            # GroupNorm-backward sums of a dgrad-shaped launch (no bias / residual): out2 = d(GN output), xg = that GroupNorm's input
+            xg = torch.randn(M, Cout, device=DEV)
+            x64 = xg.double().cpu().view(M, 32, gs)
+            fstats = torch.stack([x64.sum(dim=(0, 2)), (x64 ** 2).sum(dim=(0, 2))], dim=1).reshape(-1).contiguous().to(DEV)
+            gamma, beta = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+            bst = torch.zeros(64, device=DEV, dtype=torch.float64)
+            g2 = args()
+            out2 = torch.full((M, Cout), float("nan"), device=DEV); g2.out_f32 = out2.data_ptr(); g2.ldc_f32 = Cout
+            call("prx_k_gemm_gn", g2, bst, gs, xg, fstats, gamma, beta, 1, 1e-6, None, 0, stream())
+            torch.cuda.synchronize()
+            o2 = out2.double().cpu()
+            assert float((o2 - (ref - resid.double().cpu() - bias.double().cpu())).norm() / o2.norm()) < 2e-6
+            n = M * gs
+            mean = fstats.cpu().view(32, 2)[:, 0] / n
+            var = (fstats.cpu().view(32, 2)[:, 1] / n - mean ** 2).clamp(min=0)
+            rstd = 1.0 / torch.sqrt(var + 1e-6)
+            xh = (x64 - mean.view(1, 32, 1)) * rstd.view(1, 32, 1)
+            y = xh.float().double() * gamma.double().cpu().view(1, 32, gs) + beta.double().cpu().view(1, 32, gs)
+            sg = torch.sigmoid(y)
+            dxh = o2.view(M, 32, gs) * (sg * (1 + y * (1 - sg))) * gamma.double().cpu().view(1, 32, gs)
+            wantb = torch.stack([dxh.sum(dim=(0, 2)), (dxh * xh).sum(dim=(0, 2))], dim=1).reshape(-1)
+            assert torch.allclose(bst.cpu(), wantb, rtol=5e-4, atol=5e-3), (tile, float((bst.cpu() - wantb).abs().max()))
+    finally:
+        lib.prx_gemm_tile_override(ctx, 0, 0, 0)
+        lib.prx_gemm_tile_override(ctx, -12, 0, 0)
+
+
+def test_gemm_fit_fp32_operand_kernels_conv_and_groupnorm_sums():
+    fit_f32_conv_and_stats_checks([(256, 128), (128, 128), (128, 64), (64, 64), (32, 64), (16, 64), (16, 32)])
+
+
 def test_gemm_fit_tiles_are_what_the_headline_tower_runs_on():
     """the planner gives the ViT-B/32 products of 64 cutouts (M = 3200) one workgroup per CU: 240 tiles of 160 x 256, 160 x 192 or
     80 x 128, and the result is the 4-wave kernels' to fp32 round-off (another K summation order on the two-K-group tile)"""

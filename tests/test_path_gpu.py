@@ -295,10 +295,12 @@ weights.CLIP_CONFIGS.setdefault("test-L/14", weights.ClipVitConfig("test-L/14", 
 @pytest.mark.parametrize("name,n", [("tiny-B/32", 4), ("ViT-B/32", 8), ("test-B/16", 3), ("test-L/14", 2)])
 def test_clip_vit_vs_oracle(name, n):
     ref, out, gref, gd = _clip_case(name, n, 5)
-    assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
-    assert cosine(out, ref) > 0.9995
-    assert rel_l2(gd, gref) < 3e-2, rel_l2(gd, gref)
-    assert cosine(gd, gref) > 0.999
+    # gates at the stated fast-mode figures or tighter (measured in round 6, IEEE-half operands and streams: embeddings 5.7e-4 ...
+    # 1.1e-3, gradient 3.6e-4 ... 4.3e-3, cosines 1 - 1e-6)
+    assert rel_l2(out, ref) < 5e-3, rel_l2(out, ref)
+    assert cosine(out, ref) > 0.9999
+    assert rel_l2(gd, gref) < 2e-2, rel_l2(gd, gref)
+    assert cosine(gd, gref) > 0.9999
 
 
 def perceptor_preprocess_checks():
@@ -445,11 +447,12 @@ def test_vqgan_synth_vs_oracle(name, hw):
     ref, out, gref, gd, idx_ref, idx = _vqgan_case(name, hw, 9)
     assert torch.equal(idx, idx_ref), "VQ code selection differs"
     assert out.shape == ref.shape
-    # image in [0,1]: bf16 operand rounding through ~60 layers
-    assert (out.cpu() - ref.detach()).abs().mean().item() < 5e-3
-    assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
-    assert rel_l2(gd, gref) < 5e-2, rel_l2(gd, gref)
-    assert cosine(gd, gref) > 0.998
+    # image in [0,1]: IEEE-half operand rounding through ~60 layers.  Gates at SURVEY 8(d)'s stated fast-mode figures or tighter
+    # (measured in round 6: image rel-L2 4.8e-4 ... 5.6e-4, gradient 1.5e-3 ... 6.1e-3, cosine >= 0.99998)
+    assert (out.cpu() - ref.detach()).abs().mean().item() < 1e-3
+    assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
+    assert rel_l2(gd, gref) < 2e-2, rel_l2(gd, gref)
+    assert cosine(gd, gref) > 0.9999
 
 
 # ------------------------------------------------------------------------------------------ VQGAN encoder
