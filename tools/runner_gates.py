@@ -1,3 +1,6 @@
+"""Diagnostic (run on the GPU box): the measured parity figures of the two runners alone -- CLIP ViT tower (embeddings, gradient to the
+cutouts) and VQGAN decoder (image, gradient to z) against the oracle in the default precision -- the numbers the per-runner gates of
+tests/test_path_gpu.py are set from.    python tools/runner_gates.py"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import torch
