@@ -13,6 +13,7 @@
 #include "cutouts.h"
 #include "prompt_vq.h"
 #include "vit.h"  // prx_pack_* helpers
+#include <cstdlib>
 #include <vector>
 #include <memory>
 #include <algorithm>
@@ -263,6 +264,12 @@ struct PrxResNet {
     int res, width, heads, out_dim, max_n, C, G, T, cur_n;
     int prec;         // PRX_PREC_*
     int f32, h16;     // derived: operands are fp32 / the 16-bit operand format is IEEE half
+    // The lean layout (half mode, PRX_RN_LEAN, as vit.hip's PRX_LEAN): the residual stream of the Bottleneck stack and its
+    // gradient live in IEEE half only -- the reference's own activation precision (CLIP's convert_weights runs the
+    // tower in half).  The conv3 / downsample GEMMs then write 2 bytes per element instead of 6 and read a 2-byte
+    // identity, the conv1 dgrad reads a 2-byte identity gradient and writes 2 bytes instead of 6: these 1x1 GEMMs are
+    // bound by exactly those streams.  The last block keeps its fp32 output (the attention pool's token mean reads it).
+    int lean;
     float* gs;        // half mode: device {S, 1/S} = the power-of-two scale of the backward in flight (common.h) + 64 partials; else null
     GemmCtx gctx;     // this handle's engine state
     std::vector<void*> allocs;
@@ -274,6 +281,7 @@ struct PrxResNet {
     void *s1, *s2a, *s3a, *s0_bf; float* s0_f32;     // stem outputs; s0 = pooled stem output (layer1 input)
     void *tok, *qkv, *att, *o0, *dtok, *dqkv, *do0; float *lse, *e, *de, *dtokf;
     float *gA, *gB, *tf; void *tb1, *tb2, *gbf;      // backward ping-pong / temporaries
+    void *gb2, *gb3;                                 // lean layout: second gradient stream, downsample-branch gradient
     float *dY, *mm_part, *ws; size_t ws_bytes;
 };
 
@@ -349,9 +357,9 @@ int rg(PrxResNet* r, GemmDesc& d, hipStream_t s) {
 
 // 1x1 conv forward / dgrad as GEMMs
 int lin(PrxResNet* r, const void* A, int M, int K, const void* Bt, int N, const float* bias, const float* resid, int act,
-        const void* aux, float* of, void* ob, hipStream_t s) {
+        const void* aux, float* of, void* ob, hipStream_t s, int resid16 = 0) {
     GemmDesc d; d.A = A; d.lda = K; d.B = Bt; d.ldb = K; d.M = M; d.N = N; d.K = K;
-    d.bias_n = bias; d.resid = resid; d.ldr = N; d.act = act; d.aux = aux; d.ldaux = N;
+    d.bias_n = bias; d.resid = resid; d.ldr = N; d.act = act; d.aux = aux; d.ldaux = N; d.row16 = resid16 ? 1 : 0;
     d.out_f32 = of; d.ldc_f32 = N; d.out_bf16 = ob; d.ldc_bf16 = N;
     return rg(r, d, s);
 }
@@ -377,6 +385,7 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     std::unique_ptr<PrxResNet> guard(r);
     r->prec = precision; r->f32 = prec_is_f32(precision); r->h16 = prec_is_h16(precision);
     r->gs = nullptr;
+    { const char* ev = getenv("PRX_RN_LEAN"); r->lean = (r->h16 && !(ev && atoi(ev) == 0)) ? 1 : 0; }
     r->res = res; r->width = width; r->heads = heads; r->out_dim = out_dim; r->max_n = max_n; r->cur_n = 0;
     r->C = width * 32; r->G = res / 32; r->T = r->G * r->G + 1;
     RCur cur{w, n_w, 0};
@@ -403,7 +412,9 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
             RALLOC_OP(k.a1, Min * planes); RALLOC_OP(k.a2, Min * planes);
             k.p2 = k.a2; k.xp = nullptr;
             if (k.stride > 1) { RALLOC_OP(k.p2, Mout * planes); RALLOC_OP(k.xp, Mout * inplanes); }
-            RALLOC_OP(k.out_bf, Mout * planes * 4); RALLOC(k.out_f32, Mout * planes * 4);
+            RALLOC_OP(k.out_bf, Mout * planes * 4);
+            k.out_f32 = nullptr;
+            if (!r->lean || (li == 3 && b == layers[li] - 1)) RALLOC(k.out_f32, Mout * planes * 4);
             maxMC = std::max(maxMC, std::max(Min * (size_t)std::max(inplanes, planes), Mout * (size_t)planes * 4));
             r->blocks.push_back(k);
             inplanes = planes * 4; H = (int)Ho;
@@ -429,7 +440,9 @@ int prx_resnet_create_impl(PrxResNet** out, int res, int width, const int* layer
     RALLOC_OP(r->tok, N * T * C); RALLOC_OP(r->qkv, N * T * 3 * C); RALLOC_OP(r->att, N * T * C); RALLOC_OP(r->o0, N * C);
     RALLOC_OP(r->dtok, N * T * C); RALLOC_OP(r->dqkv, N * T * 3 * C); RALLOC_OP(r->do0, N * C); RALLOC(r->dtokf, N * T * C);
     RALLOC(r->lse, N * heads * T); RALLOC(r->e, N * out_dim); RALLOC(r->de, N * out_dim);
-    RALLOC(r->gA, maxMC); RALLOC(r->gB, maxMC); RALLOC(r->tf, maxMC);
+    RALLOC(r->gA, maxMC); RALLOC(r->tf, maxMC);
+    r->gB = nullptr; r->gb2 = r->gb3 = nullptr;
+    if (r->lean) { RALLOC_OP(r->gb2, maxMC); RALLOC_OP(r->gb3, maxMC); } else RALLOC(r->gB, maxMC);
     RALLOC_OP(r->tb1, maxMC); RALLOC_OP(r->tb2, maxMC); RALLOC_OP(r->gbf, maxMC);
     RALLOC(r->dY, N * 3 * (size_t)res * res); RALLOC(r->mm_part, 2 * 1024);
     if (r->h16) RALLOC(r->gs, 2 + 64);
@@ -461,6 +474,7 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     RLAUNCH(avgpool2_fwd_kernel, (size_t)n * S4 * S4 * w, r->s3a, r->s0_bf, n, S2, S2, w);
     // the identity path of layer1.0 goes through its downsample conv, so no fp32 copy of the stem output is needed
     const void* x_bf = r->s0_bf; const float* x_f32 = nullptr;
+    const int lean = r->lean;
     for (RBlock& k : r->blocks) {
         const int H = k.Hin, Ho = H / k.stride, Min = n * H * H, Mout = n * Ho * Ho, p = k.planes;
         k.xin_bf = x_bf; k.xin_f32 = x_f32;
@@ -469,18 +483,20 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
         if (k.stride > 1) {
             RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * p, k.a2, k.p2, n, H, H, p);
         }
-        const float* idn = x_f32;
+        // the identity: fp32, or (lean) the 16-bit stream itself -- tb1 holds the downsample output (free in the forward)
+        const float* idn = lean ? (const float*)x_bf : x_f32;
         if (k.has_ds) {
             const void* xi = x_bf;
             if (k.stride > 1) {
                 RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * k.Cin, x_bf, k.xp, n, H, H, k.Cin);
                 xi = k.xp;
             }
-            if ((e = lin(r, xi, Mout, k.Cin, k.ds.W, 4 * p, k.ds.b, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-            idn = r->tf;
+            if ((e = lin(r, xi, Mout, k.Cin, k.ds.W, 4 * p, k.ds.b, nullptr, PRX_ACT_NONE, nullptr, lean ? nullptr : r->tf,
+                         lean ? r->tb1 : nullptr, s))) return e;
+            idn = lean ? (const float*)r->tb1 : r->tf;
         }
         PRX_REQUIRE(idn != nullptr, "resnet: identity path without an fp32 input");
-        if ((e = lin(r, k.p2, Mout, p, k.c3.W, 4 * p, k.c3.b, idn, PRX_ACT_RELU, nullptr, k.out_f32, k.out_bf, s))) return e;
+        if ((e = lin(r, k.p2, Mout, p, k.c3.W, 4 * p, k.c3.b, idn, PRX_ACT_RELU, nullptr, k.out_f32, k.out_bf, s, lean))) return e;
         x_bf = k.out_bf; x_f32 = k.out_f32;
     }
     // attention pool
@@ -518,6 +534,8 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     else if ((e = prx_mha_bwd_gen((const bf16_t*)r->qkv, (const bf16_t*)r->att, (const bf16_t*)r->dtok, r->lse, (bf16_t*)r->dqkv, n, T, C, r->heads, s, r->h16))) return e;
     if ((e = lin(r, r->dqkv, n * T, 3 * C, r->WinT, C, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->dtokf, nullptr, s))) return e;
     float* g = r->gA; float* g2 = r->gB;
+    const int lean = r->lean;
+    void* gb = r->gbf; void* gb_alt = r->gb2;     // lean layout: the 16-bit gradient stream and the buffer its successor goes to
     RLAUNCH(tokens_bwd_kernel, (size_t)n * P * C, r->dtokf, g, n, P, C);
     for (int bi = (int)r->blocks.size() - 1; bi >= 0; --bi) {
         RBlock& k = r->blocks[bi];
@@ -527,35 +545,46 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
         // this block's mask in its epilogue and wrote both copies (PRX_ACT_RELUMASK_POST below): 25 of RN50x4's 26 passes
         // over the residual-stream gradient (12 bytes per element each) are gone.
         if (bi == (int)r->blocks.size() - 1)
-            RLAUNCH(relu_mask_kernel, (size_t)Mout * 4 * p, g, k.out_bf, r->gbf, (size_t)Mout * 4 * p);
+            RLAUNCH(relu_mask_kernel, (size_t)Mout * 4 * p, g, k.out_bf, gb, (size_t)Mout * 4 * p);
         // main branch: conv3 (1x1) dgrad [-> avgpool bwd] -> ReLU mask of a2
         if (k.stride > 1) {
-            if ((e = lin(r, r->gbf, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
+            if ((e = lin(r, gb, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
             RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * p, r->tf, k.a2, (float*)nullptr, r->tb1, n, H, H, p);
         } else {
-            if ((e = lin(r, r->gbf, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_MUL_RELUMASK, k.a2, nullptr, r->tb1, s))) return e;
+            if ((e = lin(r, gb, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_MUL_RELUMASK, k.a2, nullptr, r->tb1, s))) return e;
         }
         // conv2 (3x3) dgrad -> ReLU mask of a1
         if ((e = conv3(r, r->tb1, n, H, p, k.c2.Wd, p, nullptr, PRX_ACT_MUL_RELUMASK, k.a1, nullptr, r->tb2, s))) return e;
         // identity branch
-        const float* gid = g;
+        const float* gid = lean ? (const float*)gb : g;
         if (k.has_ds) {
             if (k.stride > 1) {
-                if ((e = lin(r, r->gbf, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-                RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * k.Cin, r->tf, (const void*)nullptr, g2,
-                                   (void*)nullptr, n, H, H, k.Cin);
-                gid = g2;
+                if ((e = lin(r, gb, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
+                RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * k.Cin, r->tf, (const void*)nullptr, lean ? (float*)nullptr : g2,
+                                   lean ? r->gb3 : (void*)nullptr, n, H, H, k.Cin);
+                gid = lean ? (const float*)r->gb3 : g2;
             } else {
-                if ((e = lin(r, r->gbf, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-                gid = r->tf;
+                if ((e = lin(r, gb, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, lean ? nullptr : r->tf,
+                             lean ? r->gb3 : nullptr, s))) return e;
+                gid = lean ? (const float*)r->gb3 : r->tf;
             }
+        }
+        if (lean) {
+            // conv1 (1x1) dgrad + the 16-bit identity gradient -> the next 16-bit stream (never the buffer being added); block 0
+            // hands the stem an fp32 gradient
+            if (bi > 0) {
+                if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_RELUMASK_POST, r->blocks[bi - 1].out_bf, nullptr,
+                             gb_alt, s, 1))) return e;
+                std::swap(gb, gb_alt);
+            } else if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_NONE, nullptr, g, nullptr, s, 1))) return e;
+            continue;
         }
         // conv1 (1x1) dgrad + identity gradient -> gradient w.r.t. the block input
         float* dst = (gid == g2) ? g : g2;        // never write over the residual being added
         if (gid == r->tf) dst = g2;
         // ... masked by the output ReLU of the block below (its out_bf is this block's input), fp32 + operand twin
         if (bi > 0) {
-            if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_RELUMASK_POST, r->blocks[bi - 1].out_bf, dst, r->gbf, s))) return e;
+            if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_RELUMASK_POST, r->blocks[bi - 1].out_bf, dst, gb, s))) return e;
         } else if ((e = lin(r, r->tb2, Min, p, k.c1.WT, k.Cin, nullptr, gid, PRX_ACT_NONE, nullptr, dst, nullptr, s))) return e;
         if (dst != g) std::swap(g, g2);
     }

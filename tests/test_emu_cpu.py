@@ -230,6 +230,7 @@ def test_the_other_runners_vs_oracle(emu):
     tp.test_vqgan_encode_vs_oracle("tiny_f4", (40, 56))
     tp.test_clip_text_tower_vs_oracle("tiny-B/32", 5)
     tp.test_clip_resnet_vs_oracle("tiny-RN", 3, "fp16")
+    tp.test_resnet_lean_streams_ab()
     tp.test_make_cutouts_shard_matches_full()
     tp.test_cutout_align_corners_convention_is_a_descriptor_field("crop_align_corners")
 

@@ -377,10 +377,11 @@ def test_gumbel_vq_checkpoints_encode_images():
 
 
 def vit_switch_ab(env_name, precision, name="tiny-B/32", n=4):
-    """one ViT tower forward + gradient with a debug switch of the runner off and on (read at handle creation): (embeddings,
-    gradient) of both runs"""
-    cfg = weights.CLIP_CONFIGS[name]
-    params = weights.synthetic_clip_vit_params(cfg, 5)
+    """one image tower (ViT, or ModifiedResNet for the "*RN*" configs) forward + gradient with a debug switch of the runner
+    off and on (read at handle creation): (embeddings, gradient) of both runs"""
+    resnet = name in weights.CLIP_RESNET_CONFIGS
+    cfg = weights.CLIP_RESNET_CONFIGS[name] if resnet else weights.CLIP_CONFIGS[name]
+    params = weights.synthetic_clip_resnet_params(cfg, 5) if resnet else weights.synthetic_clip_vit_params(cfg, 5)
     g = torch.Generator().manual_seed(6)
     cut = torch.rand(n, 3, cfg.input_resolution, cfg.input_resolution, generator=g)
     gout = torch.randn(n, cfg.output_dim, generator=g)
@@ -389,7 +390,7 @@ def vit_switch_ab(env_name, precision, name="tiny-B/32", n=4):
     try:
         for val in ("0", "1"):
             os.environ[env_name] = val
-            h = ops.ClipVitHandle(cfg, params, max_batch=n, device=DEV, precision=precision)
+            h = (ops.ClipResNetHandle if resnet else ops.ClipVitHandle)(cfg, params, max_batch=n, device=DEV, precision=precision)
             cd = cut.to(DEV).requires_grad_(True)
             out = ops.clip_encode_image(cd, h)
             (gd,) = torch.autograd.grad(out, cd, gout.to(DEV))
@@ -418,6 +419,17 @@ def test_vit_lean_streams_ab():
     (e0, g0), (e1, g1) = vit_switch_ab("PRX_LEAN", "fp16")
     assert rel_l2(e1, e0) < 3e-3 and rel_l2(g1, g0) < 1e-2, (rel_l2(e1, e0), rel_l2(g1, g0))
     assert not torch.equal(e0, e1)
+
+
+def test_resnet_lean_streams_ab():
+    """PRX_RN_LEAN=0 (fp32 Bottleneck residual stream / gradient with 16-bit twins) against the half mode's default (both in
+    IEEE half only, resnet.hip): the bisection switch keeps working and the layouts differ by stream rounding (plus the ReLU
+    masks that rounding flips) only; the bf16 mode has no lean layout, so there the switch changes nothing at all"""
+    (e0, g0), (e1, g1) = vit_switch_ab("PRX_RN_LEAN", "fp16", name="tiny-RN", n=3)
+    assert rel_l2(e1, e0) < 3e-3 and rel_l2(g1, g0) < 3e-2 and cosine(g1, g0) > 0.9995, (rel_l2(e1, e0), rel_l2(g1, g0))
+    assert not torch.equal(e0, e1)
+    (e0, g0), (e1, g1) = vit_switch_ab("PRX_RN_LEAN", "bf16", name="tiny-RN", n=3)
+    assert torch.equal(e0, e1) and torch.equal(g0, g1)
 
 
 # ------------------------------------------------------------------------------------------ VQGAN
