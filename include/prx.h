@@ -119,6 +119,9 @@ int prx_k_gemm_gn(const prx_gemm_args* g, double* gn_stats, int gn_gs, const flo
  * (csrc/gemmfit_kernel.h FIT_EPI_*, csrc/gemm8p.hip: the descriptor patterns of the two runners, IEEE-half operands) -- tests use it to know that the specialised kernel,
  * not the generic one, produced what they compare. */
 long long prx_gemm_fit_spec_launches(void);
+/* ... and how many ran the row-streaming kernel (csrc/gemmrow.hip: row-major 16-bit problems with K <= 192, N a multiple of 128 or
+ * 160, M N >= 5 Mi -- the ModifiedResNet runner's stage-1 / stage-2 1x1 convolutions; PRX_GEMM_ROWK=0 keeps them on the tiled kernels). */
+long long prx_gemm_row_launches(void);
 
 /* taming `Normalize` = GroupNorm(32, C, eps 1e-6) (+ swish `nonlinearity`) on an NHWC fp32
  * tensor x[NB][P][C]  [UPSTREAM taming/modules/diffusionmodules/model.py; call site vqgan.py:195].

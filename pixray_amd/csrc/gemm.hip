@@ -1027,6 +1027,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         for (const GemmTileRule& r : cx.rules) forced = forced || (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode);
     }
     if (!forced && d.M > 0 && d.N > 0 && d.K > 0) {
+        if (prx_gemmrow_eligible(d)) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 2);     // skinny K, very tall: the row-streaming kernel (gemmrow.hip)
         const Plan8p p = plan_8phase(d, cx);
         if (p.main_rows >= d.M) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 1);
         if (p.main_rows > 0) {
@@ -1100,7 +1101,9 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         }
         if (fbm) { BM = fbm; BN = fbn; fit_tile = true; }
     }
-    if (use8p) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)
+    const bool rowk = use8p == 2;
+    if (use8p == 1) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)
+    if (rowk) { BM = 16; BN = d.N % 160 == 0 ? 160 : 128; fit_tile = false; }
     // a forced tile selects the fit kernel when the override says so (cx.force_fit), or when only that family has the shape
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; fit_tile = prx_gemmfit_tile(BM, BN, nullptr) && (cx.force_fit || !fourwave_tile(BM, BN)); }
     int rule_splits = 0;
@@ -1124,7 +1127,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     a.kt_total = ceil_div(d.K, bk);
     int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
-    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16 && !(BM == 256 && BN == 256) && !fit_tile) {
+    if (ws && tiles <= n_cu / 2 && a.kt_total >= 16 && !(BM == 256 && BN == 256) && !fit_tile && !rowk) {
         // few tiles, long K (the 16x16 / 32x32 decoder convs): aim at ~320 blocks, >= 4 K tiles per split
         splits = std::max(1, std::min(std::min((320 + tiles / 2) / tiles, a.kt_total / 4), 32));
         while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
@@ -1192,12 +1195,14 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
         PRX_CHECK_HIP(hipEventCreate(&rec.a));
         PRX_CHECK_HIP(hipEventCreate(&rec.b));
         rec.flop = 2.0 * d.M * d.N * d.K;
-        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32 + 8 * d.f32; rec.bm = fit_tile ? BM + 1000 : BM; rec.bn = BN; rec.splits = splits;      // + 1000: the fit kernel of that tile shape
+        rec.M = d.M; rec.N = d.N; rec.K = d.K; rec.mode = d.a_mode + 2 * d.up + 4 * d.a_is_f32 + 8 * d.f32; rec.bm = fit_tile ? BM + 1000 : (rowk ? BM + 2000 : BM); rec.bn = BN; rec.splits = splits;      // + 1000: the fit kernel of that tile shape
         PRX_CHECK_HIP(hipEventRecord(rec.a, stream));
     }
 
     dim3 grid(tiles, splits);
-    if (fit_tile && d.f32) {
+    if (rowk) {
+        prx_gemmrow_launch(a, n_cu, stream);
+    } else if (fit_tile && d.f32) {
         int e = prx_gemmfit_launch(a, BM, BN, grid, stream);      // fp32-operand fit kernels (gemmfit_f32.hip)
         if (e) return e;
     } else if (d.f32) {

@@ -79,6 +79,11 @@ def test_fit_kernels_with_compile_time_epilogues_match_the_generic_kernel(emu):
     assert {"out16", "res16", "gelu", "dgelu"} <= ran
 
 
+def test_row_streaming_kernel_vs_tiled_kernels(emu):
+    """gemmrow.hip on the emulator: the slab permutation, the transposed MFMA, the K tail, ragged M, every runner epilogue, both formats"""
+    emu.tk.row_kernel_checks([("fp16", 16405, 320, 80), ("fp16", 8200, 640, 160), ("bf16", 20483, 256, 64)])
+
+
 def test_gemm_engine_random_shapes_every_kernel_family(emu):
     """300 random row-major products and 300 random implicit convolutions (tests/_emu_fuzz.py): ragged shapes against every tile,
     strided operands and outputs, fp32 A converted on load, every fused epilogue, every kernel family (planner's choice, forced

@@ -154,6 +154,76 @@ def test_gemm_8phase_kernel_ragged_edges_and_epilogues(prec):
         lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
 
 
+def row_kernel_checks(cases=None):
+    """gemmrow_kernel (gemmrow.hip: weights of a column slab resident in LDS, 16-row wave tiles streamed through registers, the MFMA
+    transposed so that a lane owns 8 consecutive output columns) on the shapes of the ModifiedResNet runner's stage-1 / stage-2
+    1x1 convolutions, scaled down in M: ragged M (clamped loads, masked stores), K = 64 .. 192 including K % 32 != 0 (zero-filled
+    K tail), N = 128-wide and 160-wide slabs, every epilogue of the runner -- conv3 forward (bias + 16-bit identity + ReLU),
+    downsample forward (bias only), conv1 dgrad (16-bit identity gradient + ReLU mask of the block below), block 0's fp32 output; in
+    bf16 the fp32 identity with both outputs.  Against the TILED kernels on the same descriptor (forced 128 x 128: the engine's
+    previous path; same epilogue arithmetic, another summation order) and an fp32 product; the launch counter proves which ran."""
+    lib = _lib.load()
+    torch.manual_seed(31)
+    cases = cases or [("fp16", 16405, 320, 80), ("fp16", 8200, 640, 160), ("fp16", 13700, 384, 96), ("fp16", 8192 + 7, 640, 192),
+                      ("bf16", 20483, 256, 64), ("bf16", 16400, 320, 80)]
+    for prec, M, N, K in cases:
+        dt = torch.float16 if prec == "fp16" else torch.bfloat16
+        tol16 = 5e-4 if prec == "fp16" else 4e-3
+        A = torch.randn(M, K, device=DEV).to(dt)
+        Bt = (torch.randn(N, K, device=DEV) * torch.linspace(0.5, 1.5, N, device=DEV)[:, None] / math.sqrt(K)).to(dt)
+        bias = torch.randn(N, device=DEV)
+        res32 = torch.randn(M, N, device=DEV)
+        res = res32.to(dt) if prec == "fp16" else res32
+        mask = torch.randn(M, N, device=DEV).to(dt)
+        prod = A.float() @ Bt.float().T
+
+        def run(act, use_bias, use_res, want32, want16, forced):
+            g = GemmArgs()
+            g.A = A.data_ptr(); g.lda = K; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, N, K
+            g.alpha = 1.0; g.f32 = 2 if prec == "fp16" else 0; g.act = act
+            if use_bias: g.bias_n = bias.data_ptr()
+            if use_res: g.resid = res.data_ptr(); g.ldr = N; g.row16 = 1 if prec == "fp16" else 0
+            if act == 5: g.aux = mask.data_ptr(); g.ldaux = N
+            o32 = torch.full((M, N), float("nan"), device=DEV) if want32 else None
+            o16 = torch.full((M + 1, N), float("nan"), device=DEV, dtype=dt) if want16 else None      # + a guard row
+            if want32: g.out_f32 = o32.data_ptr(); g.ldc_f32 = N
+            if want16: g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = N
+            try:
+                if forced: lib.prx_gemm_tile_override(_lib.tool_ctx(), 128, 128, 1)
+                n0 = lib.prx_gemm_row_launches()
+                call("prx_k_gemm", g, None, 0, stream())
+                torch.cuda.synchronize()
+                assert lib.prx_gemm_row_launches() - n0 == (0 if forced else 1), (prec, M, N, K, act, forced)
+            finally:
+                if forced: lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+            if want16:
+                assert torch.isnan(o16[M].float()).all()        # nothing written past row M - 1
+                o16 = o16[:M]
+            return o32, o16
+
+        RELU, RMP = 3, 5          # include/prx.h PRX_ACT_RELU, PRX_ACT_RELUMASK_POST
+        rr = res.float()
+        for act, use_bias, use_res, want32, want16, ref in [
+                (RELU, True, True, prec == "bf16", True, torch.relu(prod + bias + rr)),                          # conv3 forward
+                (0, True, False, False, True, prod + bias),                                                   # downsample forward
+                (RMP, False, True, prec == "bf16", True, (prod + rr) * (mask.float() > 0)),                      # conv1 dgrad
+                (0, False, True, True, False, prod + rr)]:                                                    # ... of block 0
+            o32, o16 = run(act, use_bias, use_res, want32, want16, False)
+            t32, t16 = run(act, use_bias, use_res, want32, want16, True)
+            if want32:
+                assert rel_l2(o32, ref) < 2e-5, (prec, M, N, K, act, rel_l2(o32, ref))
+                assert rel_l2(o32, t32) < 2e-6 and (o32 - t32).abs().max() <= 2e-5 * ref.abs().max()
+            if want16:
+                assert rel_l2(o16, ref) < tol16 and not torch.isnan(o16.float()).any(), (prec, M, N, K, act, rel_l2(o16, ref))
+                # same epilogue arithmetic on sums that differ in their last fp32 bits: a 16-bit rounding boundary is crossed rarely
+                assert (o16 != t16).float().mean().item() < 2e-3, (prec, M, N, K, act)
+                assert ((o16.float() > 0) == (t16.float() > 0)).float().mean().item() > 0.9999
+
+
+def test_gemm_row_streaming_kernel_vs_tiled_kernels():
+    row_kernel_checks()
+
+
 @pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("stages", [2, 3, 4])
 @pytest.mark.parametrize("splits", [1, 3])

@@ -52,5 +52,5 @@ print(f"{'M':>6} {'N':>5} {'K':>5} mode tile       sp  n/it  avg_us  ms/it   TF 
 for key, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     M, N, K, mode, bm, bn, sp = key
     avg = us / cnt
-    tile = f"fit{bm - 1000}x{bn}" if bm >= 1000 else f"{bm}x{bn}"
+    tile = f"row{bm - 2000}x{bn}" if bm >= 2000 else (f"fit{bm - 1000}x{bn}" if bm >= 1000 else f"{bm}x{bn}")
     print(f"{M:6d} {N:5d} {K:5d} {mode:4d} {tile:<10s} {sp:3d} {cnt / steps:5.1f} {avg:7.1f} {us / steps / 1e3:6.3f} {2.0 * M * N * K / avg / 1e6:5.0f}")
