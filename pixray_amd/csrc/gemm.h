@@ -85,6 +85,8 @@ struct GemmCtx {
     int dbg_only = -2, dbg_count = 0;   // bisection aid (override -13)
     int fit_conv = 1;            // ... for the implicit 3x3 convolutions as well (PRX_FIT_CONV)
     int fit = 1;                 // fit tiles (gemmfit.hip) when their grid fills the chip better (PRX_GEMM_FIT)
+    int rowk = 1;                // row-streaming kernels (gemmrow.hip) for skinny-K, very tall row-major problems (PRX_GEMM_ROWK)
+    int rowk_min = 24 << 20;     // ... from this many output elements on (PRX_GEMM_ROWK_MIN; override -14: tests run them on small problems)
     std::vector<GemmTileRule> rules;  // per-shape (M, N, K, mode) -> tile / split-K, consulted before the heuristic
     bool prof_on = false;
     std::vector<GemmProfRec> prof;

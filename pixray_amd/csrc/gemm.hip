@@ -889,6 +889,8 @@ GemmCtx::GemmCtx() {
     fit_flags = env_int("PRX_FIT_FLAGS", 1);
     fit_conv = env_int("PRX_FIT_CONV", 1);
     use_glds = env_int("PRX_GEMM_V1", 0) ? 0 : 1;
+    rowk = env_int("PRX_GEMM_ROWK", 1);
+    rowk_min = env_int("PRX_GEMM_ROWK_MIN", 24 << 20);
 }
 
 void prx_gemm_ctx_tile_rule(GemmCtx* c, int M, int N, int K, int mode, int bm, int bn, int splits) {
@@ -913,6 +915,7 @@ void prx_gemm_ctx_force_tile(GemmCtx* c, int bm, int bn, int splits) {
     if (bm == -8) { c->fit_flags = splits; return; }     // (-8, x, bits): fit kernel switches (bit 0: staggered wave groups)
     if (bm == -12) { c->force_fit = splits; return; }    // (-12, x, on/off): a forced 128 x 128 / 128 x 64 / 64 x 64 / 256 x 128 tile means the fit kernel of that shape
     if (bm == -9) { c->fit_conv = splits; return; }      // (-9, x, on/off): fit tiles for the implicit convolutions too
+    if (bm == -14) { c->rowk_min = splits > 0 ? splits : (24 << 20); return; }     // (-14, x, n): row-streaming kernels from n output elements on (0 restores the default)
     if (bm == -13) { c->dbg_only = splits; c->dbg_count = 0; return; }   // (-13, x, i): bisection aid -- only the i-th fit convolution (-1: all, counting; -2: off)
     if (bm < 0) return;
     c->force_bm = bm; c->force_bn = bn; c->force_splits = splits;
@@ -1027,7 +1030,7 @@ int prx_gemm_launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t s
         for (const GemmTileRule& r : cx.rules) forced = forced || (r.M == d.M && r.N == d.N && r.K == d.K && r.mode == mode);
     }
     if (!forced && d.M > 0 && d.N > 0 && d.K > 0) {
-        if (prx_gemmrow_eligible(d)) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 2);     // skinny K, very tall: the row-streaming kernel (gemmrow.hip)
+        if (cx.rowk && (long long)d.M * d.N >= cx.rowk_min && prx_gemmrow_eligible(d)) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 2);     // skinny K, very tall: the row-streaming kernel (gemmrow.hip)
         const Plan8p p = plan_8phase(d, cx);
         if (p.main_rows >= d.M) return gemm_launch_one(d, ws, ws_bytes, stream, ctx, 1);
         if (p.main_rows > 0) {
@@ -1103,7 +1106,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     const bool rowk = use8p == 2;
     if (use8p == 1) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)
-    if (rowk) { BM = 16; BN = d.N % 160 == 0 ? 160 : 128; fit_tile = false; }
+    if (rowk) { BM = 16; BN = d.N % 160 == 0 ? 160 : (d.N % 128 == 0 ? 128 : 80); fit_tile = false; }
     // a forced tile selects the fit kernel when the override says so (cx.force_fit), or when only that family has the shape
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; fit_tile = prx_gemmfit_tile(BM, BN, nullptr) && (cx.force_fit || !fourwave_tile(BM, BN)); }
     int rule_splits = 0;
@@ -1201,7 +1204,8 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
 
     dim3 grid(tiles, splits);
     if (rowk) {
-        prx_gemmrow_launch(a, n_cu, stream);
+        int e = prx_gemmrow_launch(a, n_cu, stream);
+        if (e) return e;
     } else if (fit_tile && d.f32) {
         int e = prx_gemmfit_launch(a, BM, BN, grid, stream);      // fp32-operand fit kernels (gemmfit_f32.hip)
         if (e) return e;

@@ -183,9 +183,9 @@ __device__ __forceinline__ void epilogue_store8(const GemmDesc& d, int row, int 
 // gemm8p.hip: the 256 x 256 8-phase kernel (row-major 16-bit operands, K % 128 == 0, no fused GroupNorm statistics)
 bool prx_gemm8p_eligible(const GemmDesc& d);
 void prx_gemm8p_launch(const prx_gemm_dev::GemmArgs& a, dim3 grid, hipStream_t s);      // grid = (tiles, splits), kt_per_split even
-// gemmrow.hip: the row-streaming kernel for skinny K (K <= 192, N % 128 == 0 or N % 160 == 0, M N >= 5 Mi): weights resident in LDS
+// gemmrow.hip: the row-streaming kernels for skinny K (K <= 320; N % 160 == 0, N % 128 == 0 or N % 80 == 0; M N >= 5 Mi): weights resident in LDS
 bool prx_gemmrow_eligible(const GemmDesc& d);
-void prx_gemmrow_launch(const prx_gemm_dev::GemmArgs& a, int n_cu, hipStream_t s);
+int prx_gemmrow_launch(const prx_gemm_dev::GemmArgs& a, int n_cu, hipStream_t s);
 long long prx_gemmrow_launches();
 // gemmfit.hip: tiles whose count matches the chip (row-major 16-bit operands or implicit 3x3 convolutions with Cin % 64 == 0,
 // K % (64 ks) == 0, 16-byte-friendly epilogue operands, no split-K across workgroups)

@@ -1,0 +1,5 @@
+// gemmrow_kernel.h instances: IEEE half operands, 16-bit residual streams, K <= 320
+#include "gemmrow_kernel.h"
+bool prx_gemmrow_launch_h10(const prx_gemm_dev::GemmArgs& a, int nt, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s) {
+    return prx_gemmrow_dev::launch_slab<half_t, 2, 10>(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s);
+}

@@ -155,17 +155,29 @@ def test_gemm_8phase_kernel_ragged_edges_and_epilogues(prec):
 
 
 def row_kernel_checks(cases=None):
-    """gemmrow_kernel (gemmrow.hip: weights of a column slab resident in LDS, 16-row wave tiles streamed through registers, the MFMA
-    transposed so that a lane owns 8 consecutive output columns) on the shapes of the ModifiedResNet runner's stage-1 / stage-2
-    1x1 convolutions, scaled down in M: ragged M (clamped loads, masked stores), K = 64 .. 192 including K % 32 != 0 (zero-filled
-    K tail), N = 128-wide and 160-wide slabs, every epilogue of the runner -- conv3 forward (bias + 16-bit identity + ReLU),
-    downsample forward (bias only), conv1 dgrad (16-bit identity gradient + ReLU mask of the block below), block 0's fp32 output; in
-    bf16 the fp32 identity with both outputs.  Against the TILED kernels on the same descriptor (forced 128 x 128: the engine's
-    previous path; same epilogue arithmetic, another summation order) and an fp32 product; the launch counter proves which ran."""
+    """gemmrow_kernel (gemmrow_kernel.h: weights of a column slab resident in LDS, 16-row wave tiles streamed through registers, the
+    MFMA transposed so that a lane owns 8 consecutive output columns) on the shapes of the ModifiedResNet runner's 1x1
+    convolutions, scaled down in M: ragged M (clamped loads, masked stores), K = 64 .. 320 including K % 32 != 0 (zero-filled K
+    tail) and both K ranges (next-tile prefetch / none), 160-, 128- and 80-column slabs (the last with a lone 16-column tile), every
+    epilogue of the runner -- conv3 forward (bias + 16-bit identity + ReLU), downsample forward (bias only), conv1 dgrad (16-bit
+    identity gradient + ReLU mask of the block below), block 0's fp32 output; on N = 80: conv1 forward (bias + ReLU), conv3 dgrad
+    (ReLU mask of the saved activation), its unmasked fp32 form; in bf16 the fp32 identity with both outputs.  Against the TILED
+    kernels on the same descriptor (forced 128 x 128: the engine's previous path; same epilogue arithmetic, another summation
+    order) and an fp32 product; the launch counter proves which ran."""
     lib = _lib.load()
     torch.manual_seed(31)
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -14, 0, 1 << 20)       # the engine's own rule starts at 24 Mi output elements
+    try:
+        _row_kernel_cases(lib, cases)
+    finally:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -14, 0, 0)
+
+
+def _row_kernel_cases(lib, cases):
     cases = cases or [("fp16", 16405, 320, 80), ("fp16", 8200, 640, 160), ("fp16", 13700, 384, 96), ("fp16", 8192 + 7, 640, 192),
-                      ("bf16", 20483, 256, 64), ("bf16", 16400, 320, 80)]
+                      ("fp16", 4200, 1280, 320), ("fp16", 30003, 80, 320), ("fp16", 26000, 80, 80), ("fp16", 12000, 240, 200),
+                      ("bf16", 20483, 256, 64), ("bf16", 16400, 320, 80), ("bf16", 8200, 640, 320), ("bf16", 26003, 80, 320)]
+    RELU, MRM, RMP = 3, 4, 5          # include/prx.h PRX_ACT_RELU, PRX_ACT_MUL_RELUMASK, PRX_ACT_RELUMASK_POST
     for prec, M, N, K in cases:
         dt = torch.float16 if prec == "fp16" else torch.bfloat16
         tol16 = 5e-4 if prec == "fp16" else 4e-3
@@ -183,7 +195,7 @@ def row_kernel_checks(cases=None):
             g.alpha = 1.0; g.f32 = 2 if prec == "fp16" else 0; g.act = act
             if use_bias: g.bias_n = bias.data_ptr()
             if use_res: g.resid = res.data_ptr(); g.ldr = N; g.row16 = 1 if prec == "fp16" else 0
-            if act == 5: g.aux = mask.data_ptr(); g.ldaux = N
+            if act in (MRM, RMP): g.aux = mask.data_ptr(); g.ldaux = N
             o32 = torch.full((M, N), float("nan"), device=DEV) if want32 else None
             o16 = torch.full((M + 1, N), float("nan"), device=DEV, dtype=dt) if want16 else None      # + a guard row
             if want32: g.out_f32 = o32.data_ptr(); g.ldc_f32 = N
@@ -201,13 +213,18 @@ def row_kernel_checks(cases=None):
                 o16 = o16[:M]
             return o32, o16
 
-        RELU, RMP = 3, 5          # include/prx.h PRX_ACT_RELU, PRX_ACT_RELUMASK_POST
         rr = res.float()
-        for act, use_bias, use_res, want32, want16, ref in [
-                (RELU, True, True, prec == "bf16", True, torch.relu(prod + bias + rr)),                          # conv3 forward
-                (0, True, False, False, True, prod + bias),                                                   # downsample forward
-                (RMP, False, True, prec == "bf16", True, (prod + rr) * (mask.float() > 0)),                      # conv1 dgrad
-                (0, False, True, True, False, prod + rr)]:                                                    # ... of block 0
+        if N % 160 != 0 and N % 128 != 0:       # 80-column slabs: conv1 forward, conv3 dgrad and its unmasked fp32 form
+            patterns = [(RELU, True, False, False, True, torch.relu(prod + bias)),
+                        (MRM, False, False, prec == "bf16", True, prod * (mask.float() > 0)),
+                        (0, False, False, True, False, prod),
+                        (0, False, True, True, False, prod + rr)]                                             # conv1 dgrad of the first block
+        else:
+            patterns = [(RELU, True, True, prec == "bf16", True, torch.relu(prod + bias + rr)),               # conv3 forward
+                        (0, True, False, False, True, prod + bias),                                           # downsample forward
+                        (RMP, False, True, prec == "bf16", True, (prod + rr) * (mask.float() > 0)),           # conv1 dgrad
+                        (0, False, True, True, False, prod + rr)]                                             # ... of block 0
+        for act, use_bias, use_res, want32, want16, ref in patterns:
             o32, o16 = run(act, use_bias, use_res, want32, want16, False)
             t32, t16 = run(act, use_bias, use_res, want32, want16, True)
             if want32:
