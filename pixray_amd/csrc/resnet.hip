@@ -147,38 +147,53 @@ __global__ __launch_bounds__(256) void stem1_bwd_kernel(const void* __restrict__
     }
 }
 
-// 2x2 average pooling of an NHWC bf16 map
+// 2x2 average pooling of an NHWC map in the operand format; a thread owns 4 consecutive channels of an output pixel (C % 4 == 0:
+// 8- / 16-byte accesses -- these passes move up to 1 GB each and were bound by their 2-byte accesses)
 template <typename TOp>
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const void* __restrict__ x_, void* __restrict__ out_, int N, int H, int W, int C) {
     const TOp* x = reinterpret_cast<const TOp*>(x_);
     TOp* out = reinterpret_cast<TOp*>(out_);
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)N * Ho * Wo * C;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const size_t pix = idx / C;
+        const int c = (int)(idx % C4) * 4;
+        const size_t pix = idx / C4;
         const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Ho * Wo));
-        const TOp* p = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
-        const float v = ((float)p[0] + (float)p[C]) + ((float)p[(size_t)W * C] + (float)p[(size_t)W * C + C]);
-        out[idx] = op_cvt<TOp>(0.25f * v);
+        const size_t p = (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + c;
+        const float4 a = op_ld4v(x, p), b = op_ld4v(x, p + C), e = op_ld4v(x, p + (size_t)W * C), f = op_ld4v(x, p + (size_t)W * C + C);
+        op_st4(out, pix * C + c, 0.25f * ((a.x + b.x) + (e.x + f.x)), 0.25f * ((a.y + b.y) + (e.y + f.y)),
+               0.25f * ((a.z + b.z) + (e.z + f.z)), 0.25f * ((a.w + b.w) + (e.w + f.w)));
     }
 }
-// backward: dx[n][y][x][c] = 0.25 * g[n][y/2][x/2][c]  (* [mask > 0] when `mask` is given); fp32 and/or bf16 outputs
+// backward: dx[n][y][x][c] = 0.25 * g[n][y/2][x/2][c]  (* [mask > 0] when `mask` is given); fp32 and/or operand-format outputs.
+// A thread owns 4 consecutive channels of one OUTPUT-gradient pixel and writes its four input pixels (g is read once).
 template <typename TOp>
 __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ g, const void* __restrict__ mask_,
                                                            float* __restrict__ dx_f32, void* __restrict__ dx_bf_, int N, int H, int W, int C) {
     const TOp* mask = reinterpret_cast<const TOp*>(mask_);
     TOp* dx_bf = reinterpret_cast<TOp*>(dx_bf_);
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)N * H * W * C;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const size_t pix = idx / C;
-        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)H * W));
-        float v = 0.25f * g[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
-        if (mask && !((float)mask[idx] > 0.f)) v = 0.f;
-        if (dx_f32) dx_f32[idx] = v;
-        if (dx_bf) dx_bf[idx] = op_cvt<TOp>(v);
+        const int c = (int)(idx % C4) * 4;
+        const size_t pix = idx / C4;
+        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), n = (int)(pix / ((size_t)Ho * Wo));
+        float4 v = *reinterpret_cast<const float4*>(g + pix * C + c);
+        v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t o = (((size_t)n * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1)) * C + c;
+            float4 u = v;
+            if (mask) {
+                const float4 m = op_ld4v(mask, o);
+                if (!(m.x > 0.f)) u.x = 0.f;
+                if (!(m.y > 0.f)) u.y = 0.f;
+                if (!(m.z > 0.f)) u.z = 0.f;
+                if (!(m.w > 0.f)) u.w = 0.f;
+            }
+            if (dx_f32) *reinterpret_cast<float4*>(dx_f32 + o) = u;
+            if (dx_bf) op_st4(dx_bf, o, u.x, u.y, u.z, u.w);
+        }
     }
 }
 // g <- g * [out > 0] in place (fp32) and as bf16
@@ -471,7 +486,7 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
     STEM_LAUNCH(stem1_fwd_kernel, (size_t)n * S2 * S2, wh, cutouts, mm, r->w1, r->b1, r->s1, n, S);
     if ((e = conv3(r, r->s1, n, S2, wh, r->s2.Wf, wh, r->s2.b, PRX_ACT_RELU, nullptr, nullptr, r->s2a, s))) return e;
     if ((e = conv3(r, r->s2a, n, S2, wh, r->s3.Wf, w, r->s3.b, PRX_ACT_RELU, nullptr, nullptr, r->s3a, s))) return e;
-    RLAUNCH(avgpool2_fwd_kernel, (size_t)n * S4 * S4 * w, r->s3a, r->s0_bf, n, S2, S2, w);
+    RLAUNCH(avgpool2_fwd_kernel, (size_t)n * S4 * S4 * w / 4, r->s3a, r->s0_bf, n, S2, S2, w);
     // the identity path of layer1.0 goes through its downsample conv, so no fp32 copy of the stem output is needed
     const void* x_bf = r->s0_bf; const float* x_f32 = nullptr;
     const int lean = r->lean;
@@ -481,14 +496,14 @@ int prx_resnet_forward_impl(PrxResNet* r, const float* cutouts, int n, const flo
         if ((e = lin(r, x_bf, Min, k.Cin, k.c1.W, p, k.c1.b, nullptr, PRX_ACT_RELU, nullptr, nullptr, k.a1, s))) return e;
         if ((e = conv3(r, k.a1, n, H, p, k.c2.Wf, p, k.c2.b, PRX_ACT_RELU, nullptr, nullptr, k.a2, s))) return e;
         if (k.stride > 1) {
-            RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * p, k.a2, k.p2, n, H, H, p);
+            RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * p / 4, k.a2, k.p2, n, H, H, p);
         }
         // the identity: fp32, or (lean) the 16-bit stream itself -- tb1 holds the downsample output (free in the forward)
         const float* idn = lean ? (const float*)x_bf : x_f32;
         if (k.has_ds) {
             const void* xi = x_bf;
             if (k.stride > 1) {
-                RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * k.Cin, x_bf, k.xp, n, H, H, k.Cin);
+                RLAUNCH(avgpool2_fwd_kernel, (size_t)Mout * k.Cin / 4, x_bf, k.xp, n, H, H, k.Cin);
                 xi = k.xp;
             }
             if ((e = lin(r, xi, Mout, k.Cin, k.ds.W, 4 * p, k.ds.b, nullptr, PRX_ACT_NONE, nullptr, lean ? nullptr : r->tf,
@@ -549,7 +564,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
         // main branch: conv3 (1x1) dgrad [-> avgpool bwd] -> ReLU mask of a2
         if (k.stride > 1) {
             if ((e = lin(r, gb, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-            RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * p, r->tf, k.a2, (float*)nullptr, r->tb1, n, H, H, p);
+            RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * p / 16, r->tf, k.a2, (float*)nullptr, r->tb1, n, H, H, p);
         } else {
             if ((e = lin(r, gb, Mout, 4 * p, k.c3.WT, p, nullptr, nullptr, PRX_ACT_MUL_RELUMASK, k.a2, nullptr, r->tb1, s))) return e;
         }
@@ -560,7 +575,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
         if (k.has_ds) {
             if (k.stride > 1) {
                 if ((e = lin(r, gb, Mout, 4 * p, k.ds.WT, k.Cin, nullptr, nullptr, PRX_ACT_NONE, nullptr, r->tf, nullptr, s))) return e;
-                RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * k.Cin, r->tf, (const void*)nullptr, lean ? (float*)nullptr : g2,
+                RLAUNCH(avgpool2_bwd_kernel, (size_t)Min * k.Cin / 16, r->tf, (const void*)nullptr, lean ? (float*)nullptr : g2,
                                    lean ? r->gb3 : (void*)nullptr, n, H, H, k.Cin);
                 gid = lean ? (const float*)r->gb3 : g2;
             } else {
@@ -590,7 +605,7 @@ int prx_resnet_backward_a_impl(PrxResNet* r, const float* cutouts, const float* 
     }
     // stem: avgpool -> relu3 mask -> conv3 dgrad -> relu2 mask -> conv2 dgrad -> relu1 mask -> conv1 input gradient
     const int S = r->res, S2 = S / 2, w = r->width, wh = w / 2;
-    RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
+    RLAUNCH(avgpool2_bwd_kernel, (size_t)n * S2 * S2 * w / 16, g, r->s3a, (float*)nullptr, r->tb1, n, S2, S2, w);
     if ((e = conv3(r, r->tb1, n, S2, w, r->s3.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s2a, nullptr, r->tb2, s))) return e;
     if ((e = conv3(r, r->tb2, n, S2, wh, r->s2.Wd, wh, nullptr, PRX_ACT_MUL_RELUMASK, r->s1, nullptr, r->tb1, s))) return e;
     STEM_LAUNCH(stem1_bwd_kernel, (size_t)n * S * S, wh, r->tb1, r->w1, r->dY, n, S, (const float*)(r->h16 ? r->gs + 1 : nullptr));

@@ -85,6 +85,11 @@ def test_row_streaming_kernel_vs_tiled_kernels(emu):
                               ("fp16", 16403, 80, 200), ("bf16", 13140, 80, 80)])
 
 
+def test_row_streaming_conv3x3_vs_conv2d_and_tiled_kernels(emu):
+    """gemmrowconv_kernel.h on the emulator: tap decode per 16-byte chunk, border zeros, the half tile of N = 40, both epilogues"""
+    emu.tk.row_conv_checks([("fp16", 2, 30, 34, 80, 80), ("fp16", 1, 40, 45, 40, 40), ("bf16", 1, 33, 40, 40, 80), ("fp16", 1, 48, 40, 80, 40)])
+
+
 def test_gemm_engine_random_shapes_every_kernel_family(emu):
     """300 random row-major products and 300 random implicit convolutions (tests/_emu_fuzz.py): ragged shapes against every tile,
     strided operands and outputs, fp32 A converted on load, every fused epilogue, every kernel family (planner's choice, forced

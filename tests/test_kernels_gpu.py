@@ -241,6 +241,60 @@ def test_gemm_row_streaming_kernel_vs_tiled_kernels():
     row_kernel_checks()
 
 
+def row_conv_checks(cases=None):
+    """gemmrowconv_kernel (gemmrowconv_kernel.h: all weights resident in LDS, 16-pixel wave tiles whose taps are loaded straight into
+    MFMA operand registers) on the ModifiedResNet runner's small-channel 3x3 convolutions, scaled down: Cin, N in {40, 80} (the
+    N = 40 slab ends in half a tile), image borders / several images / a ragged last tile, bias + ReLU (forward) and the ReLU mask of
+    a saved activation (dgrad), both formats; against F.conv2d on the same rounded operands and the tiled kernels (forced 128 x
+    128) on the same descriptor"""
+    lib = _lib.load()
+    torch.manual_seed(37)
+    cases = cases or [("fp16", 2, 70, 90, 80, 80), ("fp16", 3, 50, 62, 40, 40), ("fp16", 1, 96, 100, 40, 80), ("fp16", 2, 64, 66, 80, 40),
+                      ("bf16", 2, 50, 50, 80, 80), ("bf16", 1, 72, 130, 40, 80)]
+    lib.prx_gemm_tile_override(_lib.tool_ctx(), -14, 0, 1 << 16)
+    try:
+        for prec, NB, H, W, Cin, Cout in cases:
+            dt = torch.float16 if prec == "fp16" else torch.bfloat16
+            tol16 = 5e-4 if prec == "fp16" else 4e-3
+            M, K = NB * H * W, 9 * Cin
+            x = torch.randn(NB, H, W, Cin, device=DEV).to(dt)
+            w = (torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(K)).to(dt)
+            Bt = w.permute(0, 2, 3, 1).reshape(Cout, K).contiguous()              # [co][tap * Cin + ci]
+            bias = torch.randn(Cout, device=DEV)
+            mask = torch.randn(M, Cout, device=DEV).to(dt)
+            conv = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+            for act, ref in [(3, torch.relu(conv + bias)), (4, conv * (mask.float() > 0))]:
+                outs = []
+                for forced in (False, True):
+                    g = GemmArgs()
+                    g.A = x.data_ptr(); g.a_mode = 1; g.lda = Cin; g.B = Bt.data_ptr(); g.ldb = K; g.M, g.N, g.K = M, Cout, K
+                    g.H, g.W, g.Cin = H, W, Cin
+                    g.alpha = 1.0; g.f32 = 2 if prec == "fp16" else 0; g.act = act
+                    if act == 3: g.bias_n = bias.data_ptr()
+                    else: g.aux = mask.data_ptr(); g.ldaux = Cout
+                    o16 = torch.full((M + 1, Cout), float("nan"), device=DEV, dtype=dt)
+                    g.out_bf16 = o16.data_ptr(); g.ldc_bf16 = Cout
+                    try:
+                        if forced: lib.prx_gemm_tile_override(_lib.tool_ctx(), 128, 128, 1)
+                        n0 = lib.prx_gemm_row_launches()
+                        call("prx_k_gemm", g, None, 0, stream())
+                        torch.cuda.synchronize()
+                        assert lib.prx_gemm_row_launches() - n0 == (0 if forced else 1), (prec, NB, H, W, Cin, Cout, act, forced)
+                    finally:
+                        if forced: lib.prx_gemm_tile_override(_lib.tool_ctx(), 0, 0, 0)
+                    assert torch.isnan(o16[M].float()).all()
+                    outs.append(o16[:M])
+                o16, t16 = outs
+                assert rel_l2(o16, ref) < tol16 and not torch.isnan(o16.float()).any(), (prec, NB, H, W, Cin, Cout, act, rel_l2(o16, ref))
+                assert (o16 != t16).float().mean().item() < 2e-3
+    finally:
+        lib.prx_gemm_tile_override(_lib.tool_ctx(), -14, 0, 0)
+
+
+def test_gemm_row_streaming_conv3x3_vs_conv2d_and_tiled_kernels():
+    row_conv_checks()
+
+
 @pytest.mark.parametrize("tile", [(256, 128), (128, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
 @pytest.mark.parametrize("stages", [2, 3, 4])
 @pytest.mark.parametrize("splits", [1, 3])
