@@ -1106,7 +1106,7 @@ static int gemm_launch_one(const GemmDesc& d, float* ws, size_t ws_bytes, hipStr
     }
     const bool rowk = use8p == 2;
     if (use8p == 1) { BM = 256; BN = 256; fit_tile = false; }          // planned by plan_8phase (prx_gemm_launch)
-    if (rowk) { BM = 16; BN = d.N % 160 == 0 ? 160 : (d.N % 128 == 0 ? 128 : 80); fit_tile = false; }
+    if (rowk) { BM = 16; BN = (d.K > 320 || d.a_mode == PRX_A_CONV3X3) ? 80 : (d.N % 160 == 0 ? 160 : (d.N % 128 == 0 ? 128 : 80)); fit_tile = false; }
     // a forced tile selects the fit kernel when the override says so (cx.force_fit), or when only that family has the shape
     if (cx.force_bm) { BM = cx.force_bm; BN = cx.force_bn; fit_tile = prx_gemmfit_tile(BM, BN, nullptr) && (cx.force_fit || !fourwave_tile(BM, BN)); }
     int rule_splits = 0;

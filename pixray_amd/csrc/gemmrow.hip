@@ -27,13 +27,14 @@ bool prx_gemmrow_eligible(const GemmDesc& d) {
         return d.out_f32 || d.out_bf16;
     }
     if (d.f32 || d.a_is_f32 || d.a_mode != PRX_A_ROWMAJOR) return false;
-    const int nt = slab_tiles(d.N);
-    if (d.K > 320 || d.K % 8 != 0 || nt == 0) return false;
+    const int nt = d.K > 320 ? (d.N % 80 == 0 ? 5 : 0) : slab_tiles(d.N);      // K in (320, 640]: 80-column slabs only
+    if (d.K > 640 || d.K % 8 != 0 || nt == 0) return false;
     if (d.bias_m || d.gn_stats || d.gnb_x || d.out_bf16_pre) return false;
     const bool odd = (nt & 1) != 0;
-    if (odd) {      // N = 80 k: conv1 forward / conv3 dgrad -- no residual; conv1 dgrad of the first block -- residual, no activation
-        if (d.act != PRX_ACT_NONE && d.act != PRX_ACT_RELU && d.act != PRX_ACT_MUL_RELUMASK) return false;
-        if (d.resid && d.act != PRX_ACT_NONE) return false;
+    if (odd) {      // 80-column slabs: conv1 forward / conv3 dgrad (no residual) and every residual pattern of the wider slabs
+        if (d.act != PRX_ACT_NONE && d.act != PRX_ACT_RELU && d.act != PRX_ACT_MUL_RELUMASK && d.act != PRX_ACT_RELUMASK_POST) return false;
+        if (d.resid && d.act == PRX_ACT_MUL_RELUMASK) return false;
+        if (d.act == PRX_ACT_RELUMASK_POST && !d.resid) return false;
     } else {
         if (d.act != PRX_ACT_NONE && d.act != PRX_ACT_RELU && d.act != PRX_ACT_RELUMASK_POST) return false;
         if (d.act == PRX_ACT_RELUMASK_POST && !d.resid) return false;
@@ -60,22 +61,24 @@ int prx_gemmrow_launch(const prx_gemm_dev::GemmArgs& a, int n_cu, hipStream_t s)
         g_row_launches.fetch_add(1, std::memory_order_relaxed);
         return 0;
     }
-    const int nt = slab_tiles(d.N), nslab = d.N / (nt * 16);
     const int ksteps = (d.K + 31) / 32;
+    const int nt = ksteps > 10 ? 5 : slab_tiles(d.N), nslab = d.N / (nt * 16);
     const int row_tiles = (d.M + 15) / 16;
     // one workgroup of 8 waves per CU (the kernels hold 130 - 220 registers: two waves per SIMD); the grid is a whole number of
     // (8 XCDs x nslab) groups
     static const int per_cu = [] { const char* e = getenv("PRX_GEMM_ROWK_WGS"); return e ? std::max(1, atoi(e)) : 1; }();
     const int group = 8 * nslab;
     // (the 80-column slabs: <= 128 registers and 32 / 52 KB of LDS -- two workgroups per CU keep more of their long activation rows in flight)
-    const int wgs = nt == 5 ? 2 * per_cu : per_cu;
+    const int wgs = (nt == 5 && ksteps <= 10) ? 2 * per_cu : per_cu;
     const int grid = std::max(1, (wgs * (n_cu > 0 ? n_cu : 256)) / group) * group;
     const int nchunks = (grid / group) * 8;
     bool ok;
     if (d.h16) ok = ksteps <= 6 ? prx_gemmrow_launch_h6(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s)
-                                : prx_gemmrow_launch_h10(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s);
+                  : (ksteps <= 10 ? prx_gemmrow_launch_h10(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s)
+                                  : prx_gemmrow_launch_h20(a, ksteps, nslab, row_tiles, nchunks, grid, s));
     else ok = ksteps <= 6 ? prx_gemmrow_launch_b6(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s)
-                          : prx_gemmrow_launch_b10(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s);
+            : (ksteps <= 10 ? prx_gemmrow_launch_b10(a, nt, ksteps, nslab, row_tiles, nchunks, grid, s)
+                            : prx_gemmrow_launch_b20(a, ksteps, nslab, row_tiles, nchunks, grid, s));
     PRX_REQUIRE(ok, "gemmrow: no kernel instance for act %d, residual %d, N %d (eligibility and instances disagree)", d.act, d.resid != nullptr, d.N);
     g_row_launches.fetch_add(1, std::memory_order_relaxed);
     return 0;

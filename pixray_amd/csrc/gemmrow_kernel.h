@@ -60,8 +60,8 @@ __device__ __forceinline__ bf16x8 gr_zero8() {
 
 // NT: 16-column MFMA tiles of a slab (NW = 16 NT columns): NT / 2 column PAIRS (a lane owns 8 consecutive columns of each) and, for odd
 //     NT, one lone tile at the end (4 consecutive columns per lane) -- N = 80 is 2 pairs + 1
-// KSM: K steps of 32 the kernel has registers and LDS for (6: K <= 192, the next tile's activations prefetched; 10: K <= 320, loaded
-//     at the start of their own tile)
+// KSM: K steps of 32 the kernel has registers and LDS for (6: K <= 192, the next tile's activations prefetched; 10: K <= 320 and
+//     20: K <= 640, loaded at the start of their own tile; 20 exists for 80-column slabs only: 104 KB of weights)
 // RES: 0 none, 1 fp32 residual, 2 residual in the 16-bit operand format (GemmDesc::row16 bit 0)
 template <typename T16, int ACT, int RES, int NT, int KSM>
 __global__ __launch_bounds__(GR_WAVES * 64) void gemmrow_kernel(GemmArgs a, int ksteps, int nslab, int row_tiles, int nchunks) {
@@ -259,12 +259,18 @@ inline bool launch_instance(const GemmArgs& a, int ksteps, int nslab, int row_ti
         }
     } else {
         switch (a.d.act) {
-            GR_CASE(PRX_ACT_NONE)
+            GR_CASE(PRX_ACT_NONE) GR_CASE(PRX_ACT_RELU) GR_CASE(PRX_ACT_RELUMASK_POST)
             default: return false;
         }
     }
     return false;
 #undef GR_CASE
+}
+// K in (320, 640]: 80-column slabs only (the weights of a wider slab do not fit the LDS)
+template <typename T16, int RES_ON>
+inline bool launch_slab80_k640(const GemmArgs& a, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s) {
+    return a.d.resid != nullptr ? launch_instance<T16, RES_ON, 5, 20>(a, ksteps, nslab, row_tiles, nchunks, grid, s)
+                                : launch_instance<T16, 0, 5, 20>(a, ksteps, nslab, row_tiles, nchunks, grid, s);
 }
 template <typename T16, int RES_ON, int KSM>
 inline bool launch_slab(const GemmArgs& a, int nt, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s) {
@@ -284,3 +290,5 @@ bool prx_gemmrow_launch_h6(const prx_gemm_dev::GemmArgs& a, int nt, int ksteps, 
 bool prx_gemmrow_launch_h10(const prx_gemm_dev::GemmArgs& a, int nt, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s);
 bool prx_gemmrow_launch_b6(const prx_gemm_dev::GemmArgs& a, int nt, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s);
 bool prx_gemmrow_launch_b10(const prx_gemm_dev::GemmArgs& a, int nt, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s);
+bool prx_gemmrow_launch_h20(const prx_gemm_dev::GemmArgs& a, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s);
+bool prx_gemmrow_launch_b20(const prx_gemm_dev::GemmArgs& a, int ksteps, int nslab, int row_tiles, int nchunks, int grid, hipStream_t s);

@@ -82,7 +82,7 @@ def test_fit_kernels_with_compile_time_epilogues_match_the_generic_kernel(emu):
 def test_row_streaming_kernel_vs_tiled_kernels(emu):
     """gemmrow.hip on the emulator: the slab permutation, the transposed MFMA, the K tail, ragged M, every runner epilogue, both formats"""
     emu.tk.row_kernel_checks([("fp16", 16405, 320, 80), ("fp16", 8200, 640, 160), ("bf16", 20483, 256, 64), ("fp16", 4200, 1280, 320),
-                              ("fp16", 16403, 80, 200), ("bf16", 13140, 80, 80)])
+                              ("fp16", 16403, 80, 200), ("bf16", 13140, 80, 80), ("fp16", 6600, 160, 640)])
 
 
 def test_row_streaming_conv3x3_vs_conv2d_and_tiled_kernels(emu):

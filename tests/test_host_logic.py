@@ -690,7 +690,7 @@ def test_gemm_engine_kernels_have_no_scratch():
     tests green.  The compiler's resource figures are the guard: no kernel of gemm.hip / gemmfit.hip may use scratch."""
     for fname, at_least in (("gemm.hip", 20), ("gemmfit.hip", 6), ("gemmfit_spec_tower.hip", 8), ("gemmfit_spec_dec_a.hip", 8),
                             ("gemmfit_spec_dec_b.hip", 8), ("gemmfit_spec_dec_c.hip", 8), ("gemmfit_f32.hip", 8),
-                            ("gemmrow_h6.hip", 8), ("gemmrow_h10.hip", 8), ("gemmrow_b6.hip", 8), ("gemmrow_b10.hip", 8),
+                            ("gemmrow_h6.hip", 8), ("gemmrow_h10.hip", 8), ("gemmrow_b6.hip", 8), ("gemmrow_b10.hip", 8), ("gemmrow_h20.hip", 6), ("gemmrow_b20.hip", 6),
                             ("gemmrowconv_h.hip", 8), ("gemmrowconv_b.hip", 8)):   # (the conv kernels hold a tile's 23 operand fragments: 250 registers)
         kernels = _kernel_scratch(os.path.join(os.path.dirname(HERE), "pixray_amd", "csrc", fname))
         assert len(kernels) >= at_least

@@ -176,7 +176,8 @@ def row_kernel_checks(cases=None):
 def _row_kernel_cases(lib, cases):
     cases = cases or [("fp16", 16405, 320, 80), ("fp16", 8200, 640, 160), ("fp16", 13700, 384, 96), ("fp16", 8192 + 7, 640, 192),
                       ("fp16", 4200, 1280, 320), ("fp16", 30003, 80, 320), ("fp16", 26000, 80, 80), ("fp16", 12000, 240, 200),
-                      ("bf16", 20483, 256, 64), ("bf16", 16400, 320, 80), ("bf16", 8200, 640, 320), ("bf16", 26003, 80, 320)]
+                      ("bf16", 20483, 256, 64), ("bf16", 16400, 320, 80), ("bf16", 8200, 640, 320), ("bf16", 26003, 80, 320),
+                      ("fp16", 8200, 160, 640), ("fp16", 1100, 2560, 640), ("bf16", 4100, 320, 520)]      # K in (320, 640]: 80-column slabs
     RELU, MRM, RMP = 3, 4, 5          # include/prx.h PRX_ACT_RELU, PRX_ACT_MUL_RELUMASK, PRX_ACT_RELUMASK_POST
     for prec, M, N, K in cases:
         dt = torch.float16 if prec == "fp16" else torch.bfloat16
