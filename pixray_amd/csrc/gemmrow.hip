@@ -15,8 +15,9 @@ int slab_tiles(int N) { return N % 160 == 0 ? 10 : (N % 128 == 0 ? 8 : (N % 80 =
 bool prx_gemmrow_eligible(const GemmDesc& d) {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!d.f32 && !d.a_is_f32 && d.a_mode == PRX_A_CONV3X3) {
-        // implicit 3x3 convolutions with Cin, N in {40, 80} (gemmrowconv_kernel.h): bias + ReLU, or the ReLU mask of `aux`
-        if (d.up != 0 || (d.Cin != 40 && d.Cin != 80) || (d.N != 40 && d.N != 80) || d.K != 9 * d.Cin) return false;
+        // implicit 3x3 convolutions with Cin, N in {40, 80} or Cin = N = 160 (gemmrowconv_kernel.h): bias + ReLU, or the ReLU mask of `aux`
+        const bool small = (d.Cin == 40 || d.Cin == 80) && (d.N == 40 || d.N == 80);
+        if (d.up != 0 || !(small || (d.Cin == 160 && d.N == 160)) || d.K != 9 * d.Cin) return false;
         if (d.bias_m || d.gn_stats || d.gnb_x || d.out_bf16_pre || d.resid) return false;
         if (d.act != PRX_ACT_RELU && d.act != PRX_ACT_MUL_RELUMASK) return false;
         if (d.act == PRX_ACT_MUL_RELUMASK && (!d.aux || !al16(d.aux) || d.ldaux % 8 != 0)) return false;
@@ -55,8 +56,8 @@ int prx_gemmrow_launch(const prx_gemm_dev::GemmArgs& a, int n_cu, hipStream_t s)
     if (d.a_mode == PRX_A_CONV3X3) {
         // one persistent workgroup per CU, each on a contiguous run of 16-pixel tiles (neighbouring image rows: the 9 taps of a pixel
         // are fetched from HBM once and from the L2 of the chunk's XCD after that... as far as the round-robin of workgroups allows)
-        const int row_tiles = (d.M + 15) / 16, nchunks = n_cu > 0 ? n_cu : 256;
-        const bool ok = d.h16 ? prx_gemmrowconv_launch_h(a, row_tiles, nchunks, s) : prx_gemmrowconv_launch_b(a, row_tiles, nchunks, s);
+        const int row_tiles = (d.M + 15) / 16, cus = n_cu > 0 ? n_cu : 256;
+        const bool ok = d.h16 ? prx_gemmrowconv_launch_h(a, row_tiles, cus, s) : prx_gemmrowconv_launch_b(a, row_tiles, cus, s);
         PRX_REQUIRE(ok, "gemmrow: no convolution instance for N %d, Cin %d, act %d (eligibility and instances disagree)", d.N, d.Cin, d.act);
         g_row_launches.fetch_add(1, std::memory_order_relaxed);
         return 0;

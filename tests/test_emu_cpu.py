@@ -87,7 +87,8 @@ def test_row_streaming_kernel_vs_tiled_kernels(emu):
 
 def test_row_streaming_conv3x3_vs_conv2d_and_tiled_kernels(emu):
     """gemmrowconv_kernel.h on the emulator: tap decode per 16-byte chunk, border zeros, the half tile of N = 40, both epilogues"""
-    emu.tk.row_conv_checks([("fp16", 2, 30, 34, 80, 80), ("fp16", 1, 40, 45, 40, 40), ("bf16", 1, 33, 40, 40, 80), ("fp16", 1, 48, 40, 80, 40)])
+    emu.tk.row_conv_checks([("fp16", 2, 30, 34, 80, 80), ("fp16", 1, 40, 45, 40, 40), ("bf16", 1, 33, 40, 40, 80), ("fp16", 1, 48, 40, 80, 40),
+                            ("fp16", 1, 24, 27, 160, 160)])
 
 
 def test_gemm_engine_random_shapes_every_kernel_family(emu):

@@ -244,14 +244,15 @@ def test_gemm_row_streaming_kernel_vs_tiled_kernels():
 
 def row_conv_checks(cases=None):
     """gemmrowconv_kernel (gemmrowconv_kernel.h: all weights resident in LDS, 16-pixel wave tiles whose taps are loaded straight into
-    MFMA operand registers) on the ModifiedResNet runner's small-channel 3x3 convolutions, scaled down: Cin, N in {40, 80} (the
-    N = 40 slab ends in half a tile), image borders / several images / a ragged last tile, bias + ReLU (forward) and the ReLU mask of
+    MFMA operand registers) on the ModifiedResNet runner's small-channel 3x3 convolutions, scaled down: Cin, N in {40, 80} and Cin = N =
+    160 (40-column slabs end in half a tile), image borders / several images / a ragged last tile, bias + ReLU (forward) and the ReLU mask of
     a saved activation (dgrad), both formats; against F.conv2d on the same rounded operands and the tiled kernels (forced 128 x
     128) on the same descriptor"""
     lib = _lib.load()
     torch.manual_seed(37)
     cases = cases or [("fp16", 2, 70, 90, 80, 80), ("fp16", 3, 50, 62, 40, 40), ("fp16", 1, 96, 100, 40, 80), ("fp16", 2, 64, 66, 80, 40),
-                      ("bf16", 2, 50, 50, 80, 80), ("bf16", 1, 72, 130, 40, 80)]
+                      ("bf16", 2, 50, 50, 80, 80), ("bf16", 1, 72, 130, 40, 80),
+                      ("fp16", 2, 72, 75, 160, 160), ("bf16", 1, 60, 61, 160, 160)]       # four 40-column slabs, the ring K loop
     lib.prx_gemm_tile_override(_lib.tool_ctx(), -14, 0, 1 << 16)
     try:
         for prec, NB, H, W, Cin, Cout in cases:
