@@ -28,7 +28,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemmrowconv_kernel(GemmArgs a, int
     typedef __attribute__((ext_vector_type(8))) T16 t16x8;
     typedef __attribute__((ext_vector_type(4))) T16 t16x4;
     constexpr int NW = NT * 16, NP = NT / 2, NV = NT == 5 ? 80 : 40;      // slab rows in LDS; pairs; columns that exist
-    constexpr int KCH = 9 * CIN8, KS = (KCH + 3) / 4;      // 16-byte chunks of a K row; K steps of 32
+    constexpr int KCH = 9 * CIN8;                          // 16-byte chunks of a K row
+    constexpr int KS0 = (KCH + 3) / 4, KS = RING == 0 ? KS0 : (KS0 + RING - 1) / RING * RING;      // K steps of 32 (a whole number of rings: zero chunks)
     constexpr int LD = KS * 32 + 8;
     constexpr bool HAS_AUX = ACT == PRX_ACT_MUL_RELUMASK;
     static_assert((NT & 1) == 1 && ((LD / 2) / 4) % 2 == 1, "pairs + a lone tile; conflict-free slab stride");
@@ -208,6 +209,8 @@ inline bool launch_conv_act(const GemmArgs& a, int row_tiles, int n_cu, hipStrea
         hipLaunchKernelGGL((gemmrowconv_kernel<T16, ACT, NT_, CIN_ / 8, RING_, WAVES_>), dim3(grid), dim3(WAVES_ * 64), 0, s, a, row_tiles, nchunks, nslab); \
         return true;                                                                                                             \
     }
+    // (measured: the ring + 16 waves loses on Cin = 80 -- N = 80: 125 -> 133 us, N = 40: 371 -> 466 us -- where a tile's 23 fragments fit the
+    // registers; 16 waves of the register form win on the stem's 40 -> 40: 239 -> 176 us)
     GRC_CASE(80, 80, 5, 0, 8) GRC_CASE(80, 40, 5, 0, 8) GRC_CASE(40, 80, 3, 0, 8) GRC_CASE(40, 40, 3, 0, 16) GRC_CASE(160, 160, 3, 9, 16)
 #undef GRC_CASE
     return false;
