@@ -54,3 +54,13 @@ for n in 64 32 16 8; do
 import json,sys
 d=json.loads(sys.stdin.read()); print('cutn $n', d['value'], 'it/s', d['ms_per_step'], 'ms; collectives', d.get('collectives_ms_per_step'))"
 done
+# 8. configs[2]: the engine's per-shape table with the row-streaming kernels (gemmrow*.hip) and on the tiled kernels they replaced, and
+#    the same-box bench line of the round's starting arithmetic layout (tiled kernels, fp32 residual streams in the ModifiedResNet runner)
+( hdr "tools/gemm_shapes.py 3 cfg2"; timeout 600 python tools/gemm_shapes.py 3 cfg2 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_cfg2_gemm_shapes_row.txt
+( hdr "PRX_GEMM_ROWK=0 tools/gemm_shapes.py 3 cfg2"; PRX_GEMM_ROWK=0 timeout 600 python tools/gemm_shapes.py 3 cfg2 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_cfg2_gemm_shapes_tiled.txt
+( PRX_GEMM_ROWK=0 PRX_RN_LEAN=0 timeout 900 python bench.py --config cfg2 --no-cpu-baseline --no-other-modes > gpurun_out/r06_bench_cfg2_tiled_fp32streams.json ) 2> gpurun_out/r06_bench_cfg2_tiled_fp32streams.err
+grep '^{' gpurun_out/r06_bench_cfg2_tiled_fp32streams.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
+print('cfg2 tiled kernels + fp32 streams (same box)', d['value'], 'it/s', d['ms_per_step'], 'ms; engine', r.get('gemm_ms_per_step'))"
+head -12 gpurun_out/r06_cfg2_gemm_shapes_row.txt
