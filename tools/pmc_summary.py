@@ -16,7 +16,8 @@ from collections import OrderedDict
 fetch_csv, write_csv, iters, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 
 FAMILIES = [
-    ("GEMM engine (gemmfit_kernel / gemm_glds_kernel / gemm8p_kernel / gemm_kernel / splitk_reduce, all shapes)", r"gemmfit_kernel|gemm_glds_kernel|gemm8p_kernel|gemm_kernel|gemm_f32_kernel|splitk_reduce"),
+    ("GEMM engine (gemmfit_kernel / gemm_glds_kernel / gemm8p_kernel / gemmrow_kernel / gemmrowconv_kernel / gemm_kernel / splitk_reduce, all shapes)",
+     r"gemmfit_kernel|gemm_glds_kernel|gemm8p_kernel|gemmrow_kernel|gemmrowconv_kernel|gemm_kernel|gemm_f32_kernel|splitk_reduce"),
     ("GroupNorm kernels", r"gn_stats|gn_apply"),
     ("LayerNorm", r"ln_fwd|ln_bwd"),
     ("ViT attention", r"mha_"),
@@ -58,7 +59,7 @@ with open(dst, "w") as out:
         fmb = 2.0 * fk * 1024 / 1e6 / iters
         wmb = wk * 1024 / 1e6 / iters
         out.write(f"\"{fam}\",{n},{fk:.0f},{fmb:.1f},{wmb:.1f},{n / iters:.1f},{(fmb + wmb) / (n / iters):.2f}\n")
-# per-kernel table (top 30 by bytes): which launches re-read their operands
+# per-kernel table (top 45 by bytes): which launches re-read their operands
 per = {}
 for path, counter, slot in ((fetch_csv, "FETCH_SIZE", 0), (write_csv, "WRITE_SIZE", 1)):
     for r in csv.DictReader(open(path)):
@@ -70,7 +71,7 @@ for path, counter, slot in ((fetch_csv, "FETCH_SIZE", 0), (write_csv, "WRITE_SIZ
         e[1 + slot] += float(r["Counter_Value"])
 with open(dst, "a") as out:
     out.write("# per kernel: name,launches_per_iter,fetch_MB_corrected_per_launch,write_MB_per_launch\n")
-    for name, (n, fk, wk) in sorted(per.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2]))[:30]:
+    for name, (n, fk, wk) in sorted(per.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2]))[:45]:
         if n:
             out.write(f"\"{name[:150]}\",{n / iters:.1f},{2.0 * fk * 1024 / 1e6 / n:.2f},{wk * 1024 / 1e6 / n:.2f}\n")
 print(open(dst).read())
