@@ -243,14 +243,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     if (row >= rows) return;
     const int nv = C >> 8;  // float4 per lane
     const size_t xr4 = (size_t)row * ldx / 4;          // ldx % 4 == 0 (checked on the host)
-    float4 v[MAXV];
+    // every load of the row -- x, gamma, beta -- is requested up front with a CLAMPED vector index (i >= nv re-reads vector 0 and is
+    // ignored), not inside `if (i < nv)`: a wave-uniform branch around a load is a join point at which the compiler waits for
+    // everything in flight, so the three x vectors of a 768-wide row and then its gamma / beta vectors were six dependent round trips
+    // of a kernel that is one round trip + two wave reductions long
+    float4 v[MAXV], gav[MAXV], bev[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = stream_ld4<S16>(x, xr4 + (i < nv ? i : 0) * 64 + lane, h16);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        gav[i] = reinterpret_cast<const float4*>(gamma)[(i < nv ? i : 0) * 64 + lane];
+        bev[i] = reinterpret_cast<const float4*>(beta)[(i < nv ? i : 0) * 64 + lane];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-            v[i] = stream_ld4<S16>(x, xr4 + i * 64 + lane, h16);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
+    for (int i = 0; i < MAXV; ++i) s += i < nv ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
     const float mean = wave_sum(s) / (float)C;
     float ss = 0.f;
 #pragma unroll
@@ -269,8 +276,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     for (int i = 0; i < MAXV; ++i)
         if (i < nv) {
             const int c4 = i * 64 + lane;
-            float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
-            float4 be = reinterpret_cast<const float4*>(beta)[c4];
+            const float4 ga = gav[i], be = bev[i];
             float o0 = (v[i].x - mean) * rstd * ga.x + be.x;
             float o1 = (v[i].y - mean) * rstd * ga.y + be.y;
             float o2 = (v[i].z - mean) * rstd * ga.z + be.z;
@@ -297,19 +303,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ g,
     const int nv = C >> 8;
     const float mean = mean_in[row], rstd = rstd_in[row];
     const size_t xr4 = (size_t)row * ldx / 4, gr4 = (size_t)row * ldg / 4;        // leading dimensions are multiples of 4 (host check)
-    float4 xh[MAXV], dh[MAXV];
+    // all loads of the row up front with clamped vector indices (ln_fwd_kernel's note); `add` is wave-uniform: clamped to x when absent
+    float4 xh[MAXV], dh[MAXV], adv[MAXV];
+    {
+        float4 xv[MAXV], gv[MAXV], ga[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = (i < nv ? i : 0) * 64 + lane;
+            xv[i] = stream_ld4<(S16 & 1) != 0>(x, xr4 + c4, h16);
+            gv[i] = stream_ld4<(S16 & 2) != 0>(g, gr4 + c4, h16);
+            ga[i] = reinterpret_cast<const float4*>(gamma)[c4];
+        }
+        if (add) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) adv[i] = stream_ld4<(S16 & 4) != 0>(add, (size_t)row * ldadd / 4 + (i < nv ? i : 0) * 64 + lane, h16);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            xh[i] = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
+            dh[i] = make_float4(gv[i].x * ga[i].x, gv[i].y * ga[i].y, gv[i].z * ga[i].z, gv[i].w * ga[i].w);
+        }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv) {
-            const int c4 = i * 64 + lane;
-            float4 xv = stream_ld4<(S16 & 1) != 0>(x, xr4 + c4, h16), gv = stream_ld4<(S16 & 2) != 0>(g, gr4 + c4, h16);
-            float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
-            xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-            dh[i] = make_float4(gv.x * ga.x, gv.y * ga.y, gv.z * ga.z, gv.w * ga.w);
-            s1 += (dh[i].x + dh[i].y) + (dh[i].z + dh[i].w);
-            s2 += (dh[i].x * xh[i].x + dh[i].y * xh[i].y) + (dh[i].z * xh[i].z + dh[i].w * xh[i].w);
-        }
+    for (int i = 0; i < MAXV; ++i) {
+        s1 += i < nv ? (dh[i].x + dh[i].y) + (dh[i].z + dh[i].w) : 0.f;
+        s2 += i < nv ? (dh[i].x * xh[i].x + dh[i].y * xh[i].y) + (dh[i].z * xh[i].z + dh[i].w * xh[i].w) : 0.f;
+    }
     const float m1 = wave_sum(s1) / (float)C;
     const float m2 = wave_sum(s2) / (float)C;
 #pragma unroll
@@ -318,10 +338,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ g,
             const int c4 = i * 64 + lane;
             float4 o = make_float4(rstd * (dh[i].x - m1 - xh[i].x * m2), rstd * (dh[i].y - m1 - xh[i].y * m2),
                                    rstd * (dh[i].z - m1 - xh[i].z * m2), rstd * (dh[i].w - m1 - xh[i].w * m2));
-            if (add) {
-                float4 ad = stream_ld4<(S16 & 4) != 0>(add, (size_t)row * ldadd / 4 + c4, h16);
-                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-            }
+            if (add) { o.x += adv[i].x; o.y += adv[i].y; o.z += adv[i].z; o.w += adv[i].w; }
             if (dx) reinterpret_cast<float4*>(dx + (size_t)row * lddx)[c4] = o;
             if (dx_bf16) {
                 reinterpret_cast<bf16x4*>(dx_bf16 + (size_t)row * lddxb)[c4] = to_op16x4(o.x, o.y, o.z, o.w, h16);

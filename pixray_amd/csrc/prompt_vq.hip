@@ -15,9 +15,13 @@ __device__ __forceinline__ float prompt_loss_row(const float* __restrict__ x, co
     const int ne = D / 64;
     float xv[MAXE], gacc[MAXE];
     float ss = 0.f;
+    // loads with a clamped element index, outside `if (e < ne)`: a branch around each load made them D / 64 dependent round trips
+    // (norms.hip ln_fwd_kernel's note); the arithmetic keeps its order
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) xv[e] = x[(size_t)i * D + (e < ne ? e : 0) * 64 + lane];
 #pragma unroll
     for (int e = 0; e < MAXE; ++e)
-        if (e < ne) { xv[e] = x[(size_t)i * D + e * 64 + lane]; ss += xv[e] * xv[e]; gacc[e] = 0.f; }
+        if (e < ne) { ss += xv[e] * xv[e]; gacc[e] = 0.f; }
     const float xnorm = fmaxf(sqrtf(wave_sum(ss)), 1e-12f);      // F.normalize eps
     const float ixn = 1.f / xnorm;
     const float sgn = (weight > 0.f) ? 1.f : ((weight < 0.f) ? -1.f : 0.f);
@@ -26,8 +30,10 @@ __device__ __forceinline__ float prompt_loss_row(const float* __restrict__ x, co
         float ev[MAXE];
         float es = 0.f;
 #pragma unroll
+        for (int e = 0; e < MAXE; ++e) ev[e] = embed[(size_t)j * D + (e < ne ? e : 0) * 64 + lane];
+#pragma unroll
         for (int e = 0; e < MAXE; ++e)
-            if (e < ne) { ev[e] = embed[(size_t)j * D + e * 64 + lane]; es += ev[e] * ev[e]; }
+            if (e < ne) es += ev[e] * ev[e];
         const float ien = 1.f / fmaxf(sqrtf(wave_sum(es)), 1e-12f);
         float r2 = 0.f;
 #pragma unroll
@@ -150,25 +156,41 @@ __global__ __launch_bounds__(256) void vq_dist_kernel(const float* __restrict__ 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = vq_f32x2{0.f, 0.f};
+    // the operands of K step k0 + 16 are requested (clamped addresses + select: no branch around a load) before the products of step
+    // k0: as `load -> LDS -> barrier -> products` per step the kernel paid one exposed global round trip for each of its D / 16 steps
+    float xr[4];
+    float4 cr[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {        // 64 tokens x 16 k (strided source: NCHW or NHWC)
+            const int e = tid + 256 * r;     // 0..1023
+            const int kk = e >> 6, p = p0 + (e & 63);
+            const float v = z[(long long)(k0 + kk) * ch_stride + (long long)(p < P ? p : P - 1) * tok_stride];
+            xr[r] = (p < P) ? v : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {        // 128 codes x 16 k (rows of the codebook: k contiguous, 16-byte loads)
+            const int e = tid + 256 * r;     // 0..511
+            const int c = c0 + (e >> 2), q = e & 3;
+            const float4 v = *reinterpret_cast<const float4*>(codebook + (size_t)(c < NC ? c : NC - 1) * D + k0 + 4 * q);
+            cr[r] = (c < NC) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < D; k0 += 16) {
-        // 64 tokens x 16 k (strided source: NCHW or NHWC) and 128 codes x 16 k (rows of the codebook: k contiguous, 16-byte loads)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int e = tid + 256 * r;     // 0..1023
-            const int kk = e >> 6, t = e & 63;
-            const int p = p0 + t;
-            Xs[kk][t] = (p < P) ? z[(long long)(k0 + kk) * ch_stride + (long long)p * tok_stride] : 0.f;
+            const int e = tid + 256 * r;
+            Xs[e >> 6][e & 63] = xr[r];
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int e = tid + 256 * r;     // 0..511
+            const int e = tid + 256 * r;
             const int cc = e >> 2, q = e & 3;
-            const int c = c0 + cc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < NC) v = *reinterpret_cast<const float4*>(codebook + (size_t)c * D + k0 + 4 * q);
-            Cs[4 * q + 0][cc] = v.x; Cs[4 * q + 1][cc] = v.y; Cs[4 * q + 2][cc] = v.z; Cs[4 * q + 3][cc] = v.w;
+            Cs[4 * q + 0][cc] = cr[r].x; Cs[4 * q + 1][cc] = cr[r].y; Cs[4 * q + 2][cc] = cr[r].z; Cs[4 * q + 3][cc] = cr[r].w;
         }
         __syncthreads();
+        if (k0 + 16 < D) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float4 xa = *reinterpret_cast<const float4*>(&Xs[kk][ty * 4]);
