@@ -9,6 +9,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
 todb() { find "$1" -name "*.db" | head -1; }
+# a box that is handed out again keeps its /tmp: an output directory left by an earlier call of the same tag would be read instead of this run's
+rm -rf /tmp/prof_${tag}_k /tmp/prof_${tag}_FETCH_SIZE /tmp/prof_${tag}_WRITE_SIZE /tmp/${tag}_raw_stats.csv /tmp/${tag}_FETCH_SIZE.csv /tmp/${tag}_WRITE_SIZE.csv
 if [ "$what" = stats ] || [ "$what" = both ]; then
     rocprofv3 --kernel-trace --stats -d /tmp/prof_${tag}_k -- python $R/bench.py "$@" --no-cpu-baseline --no-other-modes --profile-steps 0 --phase-steps 0 > $R/gpurun_out/${tag}_rocprof_stats.log 2>&1
     db=$(todb /tmp/prof_${tag}_k)

@@ -26,6 +26,7 @@ done
 # 4. SQ counters of the headline (one --pmc pass)
 cd /tmp
 COUNTERS="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+rm -rf /tmp/prof_sq /tmp/r06_sq.csv
 timeout 300 rocprofv3 --pmc $COUNTERS -d /tmp/prof_sq -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-other-modes --profile-steps 0 --phase-steps 0 > $R/gpurun_out/r06_sq.log 2>&1
 db=$(find /tmp/prof_sq -name "*.db" | head -1)
 [ -n "$db" ] && python $R/tools/rocpd_to_csv.py counters "$db" /tmp/r06_sq.csv && python $R/tools/pmc_sq_summary.py /tmp/r06_sq.csv 15 $R/gpurun_out/r06_cfg1_sq_counters.csv && sed -i "1i # tree $H" $R/gpurun_out/r06_cfg1_sq_counters.csv
