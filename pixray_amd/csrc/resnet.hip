@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
     const float mn = mm[0], range = mm[1] - mm[0];
     const float inv = range != 0.f ? 1.f / range : 1.f;
     const size_t total = (size_t)N * So * So;
-    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+    constexpr bool STAGE = sizeof(TOp) == 2;             // (the fp32 mode's tile would not fit beside the weights: it keeps its direct stores)
+    __shared__ __attribute__((aligned(16))) TOp otile[STAGE ? 256 * CO : 4];
+    for (size_t pixb = (size_t)blockIdx.x * blockDim.x; pixb < total; pixb += (size_t)gridDim.x * blockDim.x) {      // workgroup-uniform trip count (barriers inside)
+        const size_t pix = pixb + threadIdx.x;
+        if (pix < total) {
         const int xo = (int)(pix % So), yo = (int)((pix / So) % So), n = (int)(pix / ((size_t)So * So));
         float v[27];                       // taps outside the image stay 0: adding 0 * w leaves the sum as the skipped tap did
 #pragma unroll
@@ -79,10 +83,16 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
                 for (int kx = 0; kx < 3; ++kx) {
                     const int y = 2 * yo + ky - 1, x = 2 * xo + kx - 1, t = (c * 3 + ky) * 3 + kx;
                     const bool ok = y >= 0 && y < S && x >= 0 && x < S;
-                    v[t] = ok ? ((cut[(((size_t)n * 3 + c) * S + y) * S + x] - mn) * inv - im) * is : 0.f;
+                    // clamped address + select: a branch around each of the 27 loads made them 27 dependent round trips
+                    const int yc = y < 0 ? 0 : (y < S ? y : S - 1), xc = x < 0 ? 0 : (x < S ? x : S - 1);
+                    const float raw = cut[(((size_t)n * 3 + c) * S + yc) * S + xc];
+                    v[t] = ok ? ((raw - mn) * inv - im) * is : 0.f;
                 }
         }
-        TOp* o = out + pix * CO;
+        // the CO results of a pixel go to an LDS tile [256 pixels][CO] and leave as 16-byte pieces of the workgroup's CONTIGUOUS output
+        // range: written per thread (8 bytes every 2 CO bytes) the stores were partial sectors -- 673 MB of HBM writes for a 212 MB map
+        // (profiles/r06_cfg2_pmc_hbm_traffic.csv)
+        TOp* orow = STAGE ? otile + threadIdx.x * CO : out + pix * CO;
 #pragma unroll 1
         for (int c0 = 0; c0 < CO; c0 += 4) {
             float a[4] = {bs[c0], bs[c0 + 1], bs[c0 + 2], bs[c0 + 3]};
@@ -91,7 +101,20 @@ __global__ __launch_bounds__(256) void stem1_fwd_kernel(const float* __restrict_
                 const float4 w4 = *reinterpret_cast<const float4*>(&ws[t * CO + c0]);
                 a[0] += v[t] * w4.x; a[1] += v[t] * w4.y; a[2] += v[t] * w4.z; a[3] += v[t] * w4.w;
             }
-            op_st4(o, (size_t)c0, fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+            op_st4(orow, (size_t)c0, fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        }
+        }
+        if constexpr (STAGE) {
+        __syncthreads();
+        {
+            const size_t pix0 = pixb;                                       // first pixel of this workgroup's tile
+            const size_t npix = total - pix0 < 256 ? total - pix0 : 256;
+            const int pieces = (int)(npix * CO * sizeof(TOp) / 16);           // CO * sizeof(TOp) % 16 == 0
+            const float4* src = reinterpret_cast<const float4*>(otile);
+            float4* dst = reinterpret_cast<float4*>(out + pix0 * CO);
+            for (int i = threadIdx.x; i < pieces; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
         }
     }
 }
