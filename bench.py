@@ -324,7 +324,7 @@ def main():
             # products the class-token tail skips) is reported beside it as an MFU-style field, not as the roofline fraction
             achieved = gemm_gflop_step * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
             achieved_alg = gemm_gflop_alg * args.profile_steps * 1e9 / (ms * 1e-3) / 1e12
-            kern = (f"GEMM engine: gemmfit_kernel<WGM,WGN,FM,FN,KS,CONV> + gemm_glds_kernel / gemm8p_kernel ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
+            kern = (f"GEMM engine: gemmfit_kernel<WGM,WGN,FM,FN,KS,CONV> + gemm_glds_kernel / gemm8p_kernel / gemmrow_kernel / gemmrowconv_kernel ({args.precision} MFMA GEMM / implicit 3x3 conv, all launches)"
                     if args.precision != "f32"
                     else "gemm_f32_kernel<BM,BN,AMODE> (v_mfma_f32_32x32x2_f32 GEMM / implicit 3x3 conv, all launches)")
             # HBM-side bytes per launch come from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
